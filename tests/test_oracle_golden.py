@@ -1,0 +1,237 @@
+"""Pins the CPU oracle (oracle/pols_oracle.c) against every known-answer vector the reference holds for
+the hot path: the README's printed outputs, the literal Woodbury case of
+src/lib.rs, the Rust unit-test scenarios of src/lib.rs:47-171 and the seeded `_make_data` cases of
+tests/test_ols.py evaluated with the reference's own third-party oracles (committed under tests/golden/).
+CPU only."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from refdata import make_data, insert_nulls, sort_by_group
+
+
+def _frame(kat):
+    f = {k: np.asarray(v, dtype=np.float64) for k, v in kat["frame"].items()}
+    f["group"] = f["group"].astype(np.int64)
+    return f
+
+
+# ----------------------------------------------------------------------------- README KATs
+
+def test_readme_coefficients_full(golden):
+    kat = golden["kat"]; f = _frame(kat)
+    x = np.column_stack([f["x1"], f["x2"], np.ones(10)])  # intercept LAST (least_squares.py:188)
+    coef = orc.get_coefficients(f["y"], x)
+    assert np.allclose(np.round(coef, 6), kat["coefficients_full"], atol=1.1e-6)
+
+
+def test_readme_coefficients_group(golden):
+    kat = golden["kat"]; f = _frame(kat)
+    order, offs, keys = sort_by_group(f["group"])
+    out = orc.batched_least_squares(f["y"][order], [f["x1"][order], f["x2"][order]], offs, add_intercept=True)
+    for g, key in enumerate(keys):
+        assert np.allclose(np.round(out["coef"][g], 6), kat["coefficients_group"][str(key)], atol=1.1e-6)
+
+
+def test_readme_lasso_predictions(golden):
+    kat = golden["kat"]; f = _frame(kat)
+    order, offs, _ = sort_by_group(f["group"])
+    out = orc.batched_least_squares(f["y"][order], [f["x1"][order], f["x2"][order]], offs, add_intercept=True,
+                                    alpha=0.0001, l1_ratio=1.0)
+    assert np.array_equal(np.round(out["pred"][:5], 2), kat["predictions_lasso_head5_round2"])
+
+
+def test_readme_wls_predictions(golden):
+    kat = golden["kat"]; f = _frame(kat)
+    out = orc.batched_least_squares(f["y"], [f["x1"], f["x2"]], [0, 10], weights=f["weights"])
+    assert np.array_equal(np.round(out["pred"][:5], 2), kat["predictions_wls_head5_round2"])
+
+
+def test_readme_rls_path(golden):
+    kat = golden["kat"]; f = _frame(kat)
+    order, offs, _ = sort_by_group(f["group"])
+    out = orc.batched_rls(f["y"][order], [f["x1"][order], f["x2"][order]], offs)  # defaults: P0=10, no forgetting
+    assert np.allclose(np.round(out["coef"][:5], 6), kat["rls_coefficients_head5"], atol=1.1e-6)
+
+
+def test_readme_statistics(golden):
+    kat = golden["kat"]; f = _frame(kat); s = kat["statistics"]
+    x = np.column_stack([f["x1"], f["x2"], np.ones(10)])
+    st = orc.statistics(f["y"], x)
+    assert np.round(st["r2"], 5) == s["r2"] and np.round(st["mae"], 6) == s["mae"] and np.round(st["mse"], 5) == s["mse"]
+    assert np.allclose(np.round(st["standard_errors"], 6), s["standard_errors"], atol=1.1e-6)
+    assert np.allclose(np.round(st["t_values"], 6), s["t_values"], atol=1.1e-5)
+    assert np.allclose(st["p_values"], s["p_values"], rtol=1e-4)
+
+
+def test_lib_rs_woodbury_literal(golden):
+    w = golden["kat"]["woodbury"]
+    a, u, c, v = (np.array(w[k]) for k in "aucv")
+    got = orc.woodbury_update(np.linalg.inv(a), u, c, v, c_is_diag=True)
+    assert np.allclose(got, np.linalg.inv(a + u @ c @ v), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- src/lib.rs unit-test scenarios
+
+def _lib_rs_data():
+    rng = np.random.default_rng(123)
+    x = rng.normal(size=(10_000, 2))
+    return x.sum(1), x
+
+
+def test_lib_rs_ols_ridge_enet():
+    y, x = _lib_rs_data()
+    assert np.allclose(orc.get_coefficients(y, x), [1, 1], rtol=1e-3)
+    assert np.allclose(orc.get_coefficients(y, x, solve_method="svd"), [1, 1], rtol=1e-3)
+    assert np.allclose(orc.get_coefficients(y, x, alpha=10.0), [0.999, 0.999], rtol=1e-3)
+    assert np.allclose(orc.get_coefficients(y, x, alpha=10.0, solve_method="svd"), orc.get_coefficients(y, x, alpha=10.0), rtol=1e-9)
+    w, _ = orc.solve_elastic_net(y, x, 0.001, l1_ratio=0.5)
+    assert np.allclose(w, [0.999, 0.999], rtol=1e-3)
+
+
+def test_lib_rs_rls_and_rolling():
+    y, x = _lib_rs_data()
+    c = orc.solve_rls(y, x, half_life=252.0, initial_state_covariance=0.01)
+    assert np.allclose(c[-1], [1, 1], rtol=1e-4)
+    c = orc.solve_rolling_ols(y, x, 1000, min_periods=100, use_woodbury=False, null_policy="drop_window")
+    assert np.allclose(c[-1], [1, 1], rtol=1e-4)
+    assert np.isnan(c[:99]).all() and not np.isnan(c[99:]).any()
+
+
+def test_lib_rs_update_xtx_inv():
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(252, 5))
+    xtx = x.T @ x
+    x_new = np.array([0.5, 2.0, -0.3, 0.1, 0.2]); x_old = x[0]
+    got = orc.update_xtx_inv(orc.inv(xtx, True), np.stack([x_old, x_new]), np.array([[-1.0, 0], [0, 1.0]]))
+    exp = np.linalg.inv(xtx - np.outer(x_old, x_old) + np.outer(x_new, x_new))
+    assert np.allclose(got, exp, rtol=1e-5, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------- tests/test_ols.py cases
+
+@pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])
+def test_ols_all_methods(golden, method):
+    z = golden["npz"]
+    coef = orc.get_coefficients(z["ols_y"], z["ols_x"], solve_method=method)
+    assert np.allclose(coef, z["ols_coef"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(z["ols_x"] @ coef, z["ols_pred"], rtol=1e-9, atol=1e-10)
+
+
+def test_ridge(golden):
+    z = golden["npz"]
+    for m in ("chol", "lu", None):
+        assert np.allclose(orc.get_coefficients(z["ridge_y"], z["ridge_x"], alpha=0.01, solve_method=m),
+                           z["ridge_coef_chol"], rtol=1e-10)
+    assert np.allclose(orc.get_coefficients(z["ridge_y"], z["ridge_x"], alpha=0.01, solve_method="svd"),
+                       z["ridge_coef_svd"], rtol=1e-9)
+    assert np.allclose(orc.get_coefficients(z["ridge_y"], z["ridge_x"], alpha=10.0), z["ridge_coef_alpha10"], rtol=1e-10)
+
+
+def test_wls_and_intercept(golden):
+    z = golden["npz"]
+    cols = [np.ascontiguousarray(z["ridge_x"][:, j]) for j in range(2)]
+    out = orc.batched_least_squares(z["ridge_y"], cols, [0, 5000], weights=z["wls_w"], add_intercept=True)
+    assert np.allclose(out["coef"][0], z["wls_coef"], rtol=1e-9)
+    assert np.allclose(out["pred"], z["wls_pred"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(out["resid"], z["ridge_y"] - z["wls_pred"], rtol=1e-8, atol=1e-10)
+    out = orc.batched_least_squares(z["ridge_y"], cols, [0, 5000], add_intercept=True)
+    assert np.allclose(out["coef"][0], z["intercept_coef"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,k,sparsity,alpha,method",
+                         [("enet2", 2, 0.0, 0.1, "cd"), ("enet100", 100, 0.5, 0.3, "cd"),
+                          ("enet100", 100, 0.5, 0.3, "cd_active_set")])
+def test_elastic_net(golden, name, k, sparsity, alpha, method):
+    z = golden["npz"]
+    d = make_data(n_features=k, sparsity=sparsity)
+    # reference tolerance for this comparison is 1e-4 at tol=1e-4 (tests/test_ols.py:599); we pin tighter
+    coef = orc.get_coefficients(d["y"], d["x"], alpha=alpha, l1_ratio=0.5, tol=1e-9, max_iter=10_000, solve_method=method)
+    if method == "cd":
+        assert np.allclose(coef, z[f"{name}_coef"], atol=1e-7)
+    assert np.allclose(d["x"] @ coef, z[f"{name}_pred"], atol=1e-4, rtol=1e-4)
+    coef = orc.get_coefficients(d["y"], d["x"], alpha=alpha, l1_ratio=0.5, tol=1e-4, solve_method=method)
+    assert np.allclose(d["x"] @ coef, z[f"{name}_pred"], atol=1e-4, rtol=1e-4)
+
+
+def test_elastic_net_non_negative(golden):
+    z = golden["npz"]
+    d = make_data()
+    xn = np.column_stack([d["x"][:, 0], -d["x"][:, 1]])
+    coef = orc.get_coefficients(d["y"], xn, alpha=0.1, l1_ratio=0.5, tol=1e-9, positive=True)
+    assert np.allclose(coef, z["nnls_coef"], atol=1e-7) and coef[1] == 0.0
+
+
+def test_grouped_non_contiguous(golden):
+    z = golden["npz"]
+    d = make_data(n_groups=10)
+    order, offs, keys = sort_by_group(d["group"])
+    out = orc.batched_least_squares(d["y"][order], [d["x1"][order], d["x2"][order]], offs, n_threads=4)
+    assert np.allclose(out["coef"], z["group_coef"], rtol=1e-9)
+    pred = np.empty(5000); pred[order] = out["pred"]  # scatter back to row order
+    assert np.allclose(pred, np.einsum("ij,ij->i", d["x"], z["group_coef"][d["group"]]), rtol=1e-9, atol=1e-10)
+
+
+def test_rls_expanding_equals_ols(golden):
+    z = golden["npz"]
+    x, y = z["nulls_x"], z["nulls_y"]
+    valid = ~np.isnan(x).any(axis=1) & ~np.isnan(y)
+    c = orc.solve_rls(np.nan_to_num(y), np.nan_to_num(x), initial_state_covariance=1e6, is_valid=valid)
+    assert np.allclose(c[-1], z["rls_expanding_last"], rtol=1e-4, atol=1e-4)
+    # strong prior sticks (tests/test_ols.py:684-715)
+    d = make_data()
+    c = orc.solve_rls(d["y"], d["x"], initial_state_covariance=1e-6, initial_state_mean=[0.25, 0.25])
+    assert np.allclose(c[0], 0.25, rtol=1e-3) and np.allclose(c[10], 0.25, rtol=1e-3)
+
+
+@pytest.mark.parametrize("win,mp,woodbury", [(2, 2, False), (10, 2, False), (10, 2, True), (63, 5, False),
+                                             (252, 5, False), (252, 5, True)])
+def test_rolling_drop_window(golden, win, mp, woodbury):
+    z = golden["npz"]
+    x, y = z["roll_x"], z["roll_y"]
+    valid = ~np.isnan(y)
+    c = orc.solve_rolling_ols(np.nan_to_num(y), x, win, min_periods=mp, use_woodbury=woodbury,
+                              is_valid=valid, null_policy="drop_window")
+    exp = z[f"roll_{win}_{mp}"]
+    assert np.allclose(c, exp, rtol=1e-3, atol=1e-3, equal_nan=True)
+
+
+@pytest.mark.parametrize("mp,expected", [(999, 2), (1000, 1), (1001, 0)])
+def test_rolling_insufficient_data(mp, expected):
+    d = make_data(n_samples=1_000)
+    c = orc.solve_rolling_ols(d["y"], d["x"], 2_000, min_periods=mp, use_woodbury=False, null_policy="drop_window")
+    assert (~np.isnan(c[:, 0])).sum() == expected
+
+
+@pytest.mark.parametrize("win", [21, 252])
+def test_rolling_drop_equals_dropna(win):
+    d = insert_nulls(make_data(n_samples=1_000), columns=("y",))
+    valid = ~np.isnan(d["y"])
+    c_full = orc.solve_rolling_ols(np.nan_to_num(d["y"]), d["x"], win, is_valid=valid, null_policy="drop")
+    c_drop = orc.solve_rolling_ols(d["y"][valid], d["x"][valid], win, null_policy="drop")
+    assert np.allclose(c_full[valid], c_drop, equal_nan=True)
+
+
+def test_statistics(golden):
+    z = golden["npz"]
+    d = make_data()
+    xi = np.column_stack([d["x"], np.ones(5000)])
+    st = orc.statistics(d["y"], xi)
+    assert np.allclose(st["coefficients"], z["stats_coef"]) and np.allclose(st["standard_errors"], z["stats_se"])
+    assert np.allclose(st["t_values"], z["stats_t"]) and np.allclose(st["p_values"], z["stats_p"], rtol=1e-6, atol=1e-300)
+    assert np.allclose([st["r2"], st["mse"]], z["stats_r2_mse"])
+
+
+def test_svd_min_norm_wide_and_collinear():
+    d = make_data(n_samples=10, n_features=100, scale=1e-4)
+    c = orc.get_coefficients(d["y"], d["x"])  # n <= k -> SVD (least_squares.rs:225-229)
+    assert np.allclose(c, np.linalg.lstsq(d["x"], d["y"], rcond=None)[0], atol=1e-8)
+    d = make_data(n_samples=100, n_features=10, scale=1e-4)
+    x = np.column_stack([d["x"], d["x"][:, -1] + 1e-12])
+    c = orc.get_coefficients(d["y"], x, solve_method="svd")
+    e = np.linalg.lstsq(x, d["y"], rcond=1e-16)[0]
+    assert np.allclose(x @ c, x @ e, rtol=1e-4, atol=1e-4)
+
+
+def test_empty_features_gives_zeros():
+    assert np.array_equal(orc.get_coefficients(np.zeros(0), np.zeros((0, 3))), np.zeros(3))
