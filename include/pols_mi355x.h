@@ -1,0 +1,182 @@
+/*
+ * pols_mi355x.h -- C-ABI of libpols_mi355x.so, the MI355X (gfx950) batched
+ * least-squares engine that replaces the solve path of azmyrajab/polars_ols.
+ *
+ * The boundary sits at the seam between the reference's plugin layer
+ * (src/expressions.rs) and its solver layer (src/least_squares.rs), i.e. at the
+ * `use crate::least_squares::{...}` import of src/expressions.rs:15-18.  Each
+ * entry point below names the reference functions it replaces; INTEGRATION.md
+ * shows the `extern "C"` block a maintainer of the reference would add to
+ * src/expressions.rs to bind them.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types, no exceptions or panics cross
+ *    the boundary.  Every entry returns POLS_OK (0) or a negative pols_error;
+ *    pols_last_error() returns a thread-local message for the last failure.
+ *    The reference's `panic!/assert!` cases (src/least_squares.rs:231,335,349,
+ *    366,404-413) map to POLS_ERR_PANIC with the reference's message.
+ *  - the caller owns every input / output buffer; the library owns only device
+ *    scratch and the HIP stream inside a pols_ctx.  A pols_ctx may be used by
+ *    one thread at a time; create one per thread (Polars calls plugins from a
+ *    rayon pool, README.md:19).
+ *  - data layout: struct-of-arrays, exactly what Polars hands a plugin -- one
+ *    contiguous buffer per column (src/expressions.rs:22-63 is the copy into a
+ *    row-major matrix that this library deletes).  Rows of one group are
+ *    contiguous: group g owns rows [group_offsets[g], group_offsets[g+1]).
+ *    A single un-grouped call (what the reference plugin receives per group) is
+ *    n_groups = 1, group_offsets = {0, n}.
+ *  - `mem` says where ALL data pointers of a batch / out live (HOST: the library
+ *    stages through its own device scratch, PCIe-inclusive; DEVICE: zero-copy,
+ *    asynchronous on the context's stream).  group_offsets and x_cols (the array
+ *    of column pointers itself) are always HOST arrays.
+ *  - NaN marks undefined rows of rolling outputs, like src/least_squares.rs:864.
+ *  - there is NO CPU fallback: if no gfx950 device is usable every compute entry
+ *    fails with POLS_ERR_NO_DEVICE.
+ */
+#ifndef POLS_MI355X_H
+#define POLS_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POLS_MAX_FEATURES 32 /* features incl. the intercept column */
+
+typedef enum {
+    POLS_OK = 0,
+    POLS_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unsorted offsets ...) */
+    POLS_ERR_UNSUPPORTED = -2, /* valid request this build has no kernel for (message says which) */
+    POLS_ERR_HIP = -3,         /* HIP runtime error (message carries hipGetErrorString) */
+    POLS_ERR_PANIC = -4,       /* the reference would panic!/assert! on these arguments */
+    POLS_ERR_NO_DEVICE = -5    /* no usable gfx950 device; there is no CPU fallback */
+} pols_error;
+
+typedef enum { POLS_F32 = 0, POLS_F64 = 1 } pols_dtype;
+typedef enum { POLS_MEM_HOST = 0, POLS_MEM_DEVICE = 1 } pols_mem;
+
+/* SolveMethod, src/least_squares.rs:41-65; POLS_SOLVE_AUTO == Option::None. */
+typedef enum {
+    POLS_SOLVE_AUTO = 0, POLS_SOLVE_QR = 1, POLS_SOLVE_SVD = 2, POLS_SOLVE_CHOL = 3,
+    POLS_SOLVE_LU = 4, POLS_SOLVE_CD = 5, POLS_SOLVE_CD_ACTIVE_SET = 6
+} pols_solve_method;
+
+/* NullPolicy, src/least_squares.rs:67-91. */
+typedef enum {
+    POLS_NULL_IGNORE = 0, POLS_NULL_ZERO = 1, POLS_NULL_DROP = 2, POLS_NULL_DROP_ZERO = 3,
+    POLS_NULL_DROP_Y_ZERO_X = 4, POLS_NULL_DROP_WINDOW = 5
+} pols_null_policy;
+
+/* Per-group status written to pols_out.status. */
+typedef enum {
+    POLS_GROUP_OK = 0,
+    POLS_GROUP_FALLBACK = 1, /* Cholesky failed, the reference's fallback solver was taken (ls.rs:299-327) */
+    POLS_GROUP_EMPTY = 2,    /* no rows: coefficients are zeros (src/expressions.rs:357-359) */
+    POLS_GROUP_NOT_CONVERGED = 3 /* coordinate descent hit max_iter (result still returned, like the reference) */
+} pols_group_status;
+
+typedef struct pols_ctx pols_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+int pols_device_count(void);
+const char *pols_version(void);
+const char *pols_last_error(void);
+/* device_id: HIP ordinal.  Creates a private non-blocking stream. */
+int pols_create(int device_id, pols_ctx **out);
+void pols_destroy(pols_ctx *ctx);
+/* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the private one. */
+int pols_set_stream(pols_ctx *ctx, void *hip_stream);
+int pols_synchronize(pols_ctx *ctx);
+/* Kernel timing with HIP events on the context's stream (used by bench.py's roofline leg).
+ * While enabled every compute entry brackets its dominant kernel with an event pair. */
+int pols_timing_enable(pols_ctx *ctx, int enable);
+/* Synchronises, copies up to `max` per-launch durations (ms) recorded since the last call, returns the count. */
+int pols_timing_collect(pols_ctx *ctx, float *ms_out, int max);
+/* Name of the kernel variant the last compute entry launched (for profiles / DESIGN.md). */
+const char *pols_last_kernel_name(pols_ctx *ctx);
+
+/* ---- problem description ------------------------------------------------- */
+
+/* OLSKwargs (src/expressions.rs:298-308) with the Python defaults of
+ * polars_ols/least_squares.py:101-107 (see pols_ols_params_default).  has_* == 0 <=> Option::None. */
+typedef struct {
+    double alpha;
+    double l1_ratio;
+    int32_t has_l1_ratio;
+    int64_t max_iter;
+    double tol;
+    int32_t positive;
+    int32_t solve_method; /* pols_solve_method */
+    double rcond;
+    int32_t has_rcond;
+    int32_t null_policy;  /* pols_null_policy; "ignore" is the OLS default */
+} pols_ols_params;
+void pols_ols_params_default(pols_ols_params *p);
+
+/* RLSKwargs (src/expressions.rs:310-316; defaults polars_ols/least_squares.py:137-140). */
+typedef struct {
+    double half_life;
+    int32_t has_half_life;
+    double initial_state_covariance;        /* default 10.0 */
+    const double *initial_state_mean;       /* HOST, n_features values, or NULL */
+    int32_t null_policy;                    /* default "drop" */
+} pols_rls_params;
+void pols_rls_params_default(pols_rls_params *p);
+
+/* RollingKwargs (src/expressions.rs:318-325; defaults polars_ols/least_squares.py:156-160). */
+typedef struct {
+    int64_t window_size;
+    int64_t min_periods;  /* < 0 <=> None -> min(k, window) (ls.rs:860) */
+    int32_t use_woodbury; /* < 0 <=> None -> k > 60 (ls.rs:863) */
+    double alpha;         /* 0 <=> None */
+    int32_t null_policy;  /* dataclass default "drop_window"; the namespace method passes "drop" */
+} pols_rolling_params;
+void pols_rolling_params_default(pols_rolling_params *p);
+
+typedef struct {
+    int32_t dtype;                /* pols_dtype of y / x / weights and of every output */
+    int32_t mem;                  /* pols_mem of the data pointers below */
+    int64_t n_rows;
+    int64_t n_groups;
+    const int64_t *group_offsets; /* HOST, n_groups + 1 ascending values, [0] == 0, [n_groups] == n_rows */
+    int32_t n_features;           /* user features, excluding the intercept */
+    const void *y;                /* target column, n_rows */
+    const void *const *x_cols;    /* HOST array of n_features column pointers, each n_rows */
+    const void *weights;          /* sample_weights column or NULL (polars_ols/least_squares.py:190-196) */
+    const uint8_t *valid;         /* optional row validity, 1 byte per row (1 = valid), or NULL = all valid */
+    int32_t add_intercept;        /* append a ones column LAST, named "const" (least_squares.py:184-188) */
+} pols_batch;
+
+typedef struct {
+    void *coef;      /* static models: n_groups x kt; dynamic (rls / rolling): n_rows x kt; kt = n_features + add_intercept */
+    void *pred;      /* n_rows, or NULL */
+    void *resid;     /* n_rows: ORIGINAL target - predictions (least_squares.py:239), or NULL */
+    int32_t *status; /* n_groups pols_group_status values, or NULL */
+} pols_out;
+
+/* ---- compute entries ------------------------------------------------------ */
+
+/* Replaces, for every group in one launch: _get_least_squares_coefficients
+ * (src/expressions.rs:351-388) -> solve_ols / solve_ridge / solve_elastic_net
+ * (src/least_squares.rs:211-240, 342-371, 386-492) and make_predictions
+ * (src/expressions.rs:175-195), including the sqrt(w) pre-scaling, the intercept
+ * column and the 1/sqrt(w) un-scaling that polars_ols/least_squares.py:163-239
+ * performs around the plugin call. */
+int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o);
+
+/* Replaces solve_recursive_least_squares (src/least_squares.rs:568-598) + the
+ * dynamic make_predictions (src/expressions.rs:184,640-645); one sequence per group. */
+int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o);
+
+/* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions. */
+int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o);
+
+/* Replaces the `predict` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t,j] * coef[t,j]
+ * (coef_rows == n_rows) or x . coef[g] per group (coef_rows == n_groups). */
+int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, void *pred_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

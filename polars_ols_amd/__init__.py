@@ -1,0 +1,12 @@
+"""polars_ols_amd -- MI355X-native batched least-squares engine behind the ``least_squares`` plugin surface
+of azmyrajab/polars_ols.
+
+Only the hot path lives here: ``csrc/`` (hand-written gfx950 HIP kernels + the C-ABI of
+``include/pols_mi355x.h``) and the host-side mirror of the reference's operator interface
+(``least_squares.py`` / ``frame.py``).  Importing the package does not need a GPU; computing does, and there
+is no CPU fallback.
+"""
+from ._lib import LIB_PATH, PolsError, PolsPanic, build  # noqa: F401
+from .engine import Engine, default_engine  # noqa: F401
+
+__version__ = "0.1.0"

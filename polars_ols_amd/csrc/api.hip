@@ -1,0 +1,374 @@
+// api.hip -- C-ABI entry points of libpols_mi355x.so (see include/pols_mi355x.h).
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+
+#include "common.hpp"
+#include "k1_gram_chol.hpp"
+
+namespace pols {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ------------------------------------------------------------------ scratch / offsets / timing
+int ensure_scratch(pols_ctx *ctx, int slot, size_t bytes, void **out) {
+    Scratch &s = ctx->scratch[slot];
+    if (bytes > s.cap) {
+        if (s.ptr) POLS_HIP(hipFree(s.ptr));
+        s.ptr = nullptr;
+        s.cap = 0;
+        const size_t want = std::max(bytes, (size_t)1 << 16);
+        POLS_HIP(hipMalloc(&s.ptr, want));
+        s.cap = want;
+    }
+    *out = s.ptr;
+    return POLS_OK;
+}
+
+int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const int64_t **d_offs, int64_t *max_rows) {
+    // cheap content hash so steady-state calls on the same frame skip the re-upload
+    uint64_t sum = 1469598103934665603ULL;
+    int64_t mx = 0;
+    for (int64_t g = 0; g <= n_groups; ++g) {
+        sum = (sum ^ (uint64_t)offs[g]) * 1099511628211ULL;
+        if (g > 0) {
+            const int64_t d = offs[g] - offs[g - 1];
+            if (d < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending (offsets[%lld] < offsets[%lld])", (long long)g, (long long)(g - 1));
+            mx = std::max(mx, d);
+        }
+    }
+    void *dptr = nullptr;
+    const size_t bytes = sizeof(int64_t) * (size_t)(n_groups + 1);
+    const bool hit = ctx->scratch[0].ptr && ctx->offs_n == n_groups && ctx->offs_sum == sum && ctx->scratch[0].cap >= bytes;
+    if (!hit) {
+        int rc = ensure_scratch(ctx, 0, bytes, &dptr);
+        if (rc) return rc;
+        POLS_HIP(hipMemcpyAsync(dptr, offs, bytes, hipMemcpyHostToDevice, ctx->stream));
+        POLS_HIP(hipStreamSynchronize(ctx->stream));  // the host array may be freed by the caller after return
+        ctx->offs_n = n_groups;
+        ctx->offs_sum = sum;
+        ctx->offs_max_rows = mx;
+    }
+    *d_offs = static_cast<const int64_t *>(ctx->scratch[0].ptr);
+    *max_rows = mx;
+    return POLS_OK;
+}
+
+void timing_begin(pols_ctx *ctx) {
+    if (!ctx->timing) return;
+    if (ctx->timed_used == ctx->timed.size()) {
+        TimedLaunch t;
+        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return;
+        ctx->timed.push_back(t);
+    }
+    hipEventRecord(ctx->timed[ctx->timed_used].start, ctx->stream);
+}
+
+void timing_end(pols_ctx *ctx) {
+    if (!ctx->timing || ctx->timed_used >= ctx->timed.size()) return;
+    hipEventRecord(ctx->timed[ctx->timed_used].stop, ctx->stream);
+    ctx->timed_used++;
+}
+
+static int check_ctx(pols_ctx *ctx) {
+    if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
+    POLS_HIP(hipSetDevice(ctx->device));
+    return POLS_OK;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Host-resident batch: stage every column into device scratch (PCIe-inclusive path).
+struct Staged {
+    const void *y = nullptr, *w = nullptr;
+    const uint8_t *valid = nullptr;
+    const void *x[POLS_MAX_FEATURES] = {};
+    void *coef = nullptr, *pred = nullptr, *resid = nullptr;
+    int32_t *status = nullptr;
+};
+
+static size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static int stage_inputs(pols_ctx *ctx, const pols_batch *b, int64_t coef_rows, int kt, const pols_out *o, Staged *st) {
+    const size_t sz = dtype_size(b->dtype);
+    const size_t colb = round256(sz * (size_t)b->n_rows);
+    if (b->mem == POLS_MEM_DEVICE) {
+        st->y = b->y; st->w = b->weights; st->valid = b->valid;
+        for (int j = 0; j < b->n_features; ++j) st->x[j] = b->x_cols[j];
+        if (o) { st->coef = o->coef; st->pred = o->pred; st->resid = o->resid; st->status = o->status; }
+        bool ok = aligned16(st->y) && aligned16(st->w) && aligned16(st->pred) && aligned16(st->resid);
+        for (int j = 0; j < b->n_features; ++j) ok = ok && aligned16(st->x[j]);
+        if (!ok) return fail(POLS_ERR_INVALID, "device columns must be 16-byte aligned");
+        return POLS_OK;
+    }
+    const int ncols = b->n_features + 1 + (b->weights ? 1 : 0);
+    void *in = nullptr, *out = nullptr;
+    int rc = ensure_scratch(ctx, 1, colb * ncols + round256((size_t)b->n_rows), &in);
+    if (rc) return rc;
+    char *p = static_cast<char *>(in);
+    auto put = [&](const void *src, size_t bytes, const void **dst) -> int {
+        POLS_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        *dst = p;
+        p += round256(bytes);
+        return POLS_OK;
+    };
+    if ((rc = put(b->y, sz * b->n_rows, &st->y))) return rc;
+    for (int j = 0; j < b->n_features; ++j)
+        if ((rc = put(b->x_cols[j], sz * b->n_rows, &st->x[j]))) return rc;
+    if (b->weights && (rc = put(b->weights, sz * b->n_rows, &st->w))) return rc;
+    if (b->valid) {
+        const void *v = nullptr;
+        if ((rc = put(b->valid, (size_t)b->n_rows, &v))) return rc;
+        st->valid = static_cast<const uint8_t *>(v);
+    }
+    if (o) {
+        const size_t coefb = round256(sz * (size_t)coef_rows * kt);
+        const size_t statb = round256(sizeof(int32_t) * (size_t)b->n_groups);
+        rc = ensure_scratch(ctx, 2, coefb + 2 * colb + statb, &out);
+        if (rc) return rc;
+        char *q = static_cast<char *>(out);
+        if (o->coef) st->coef = q;
+        q += coefb;
+        if (o->pred) st->pred = q;
+        q += colb;
+        if (o->resid) st->resid = q;
+        q += colb;
+        if (o->status) st->status = reinterpret_cast<int32_t *>(q);
+    }
+    return POLS_OK;
+}
+
+static int unstage_outputs(pols_ctx *ctx, const pols_batch *b, int64_t coef_rows, int kt, const pols_out *o, const Staged &st) {
+    if (b->mem == POLS_MEM_DEVICE) return POLS_OK;
+    const size_t sz = dtype_size(b->dtype);
+    if (o->coef) POLS_HIP(hipMemcpyAsync(o->coef, st.coef, sz * (size_t)coef_rows * kt, hipMemcpyDeviceToHost, ctx->stream));
+    if (o->pred) POLS_HIP(hipMemcpyAsync(o->pred, st.pred, sz * (size_t)b->n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (o->resid) POLS_HIP(hipMemcpyAsync(o->resid, st.resid, sz * (size_t)b->n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (o->status) POLS_HIP(hipMemcpyAsync(o->status, st.status, sizeof(int32_t) * (size_t)b->n_groups, hipMemcpyDeviceToHost, ctx->stream));
+    POLS_HIP(hipStreamSynchronize(ctx->stream));
+    return POLS_OK;
+}
+
+static int check_batch(const pols_batch *b, const pols_out *o) {
+    if (!b || !o) return fail(POLS_ERR_INVALID, "batch / out is NULL");
+    if (b->dtype != POLS_F32 && b->dtype != POLS_F64) return fail(POLS_ERR_INVALID, "dtype must be POLS_F32 or POLS_F64");
+    if (b->mem != POLS_MEM_HOST && b->mem != POLS_MEM_DEVICE) return fail(POLS_ERR_INVALID, "mem must be POLS_MEM_HOST or POLS_MEM_DEVICE");
+    if (b->n_rows < 0 || b->n_groups < 0) return fail(POLS_ERR_INVALID, "negative size");
+    if (b->n_features < 1) return fail(POLS_ERR_INVALID, "must pass at least 2 series");  // ex.rs:72
+    if (b->n_features + (b->add_intercept ? 1 : 0) > POLS_MAX_FEATURES)
+        return fail(POLS_ERR_UNSUPPORTED, "%d features > POLS_MAX_FEATURES", b->n_features);
+    if (!b->group_offsets || !b->x_cols || (!b->y && b->n_rows)) return fail(POLS_ERR_INVALID, "NULL column / offsets pointer");
+    if (b->group_offsets[0] != 0 || b->group_offsets[b->n_groups] != b->n_rows)
+        return fail(POLS_ERR_INVALID, "group_offsets must start at 0 and end at n_rows");
+    for (int j = 0; j < b->n_features; ++j)
+        if (!b->x_cols[j] && b->n_rows) return fail(POLS_ERR_INVALID, "x_cols[%d] is NULL", j);
+    return POLS_OK;
+}
+
+}  // namespace pols
+
+using namespace pols;
+
+// ------------------------------------------------------------------ context
+extern "C" {
+
+int pols_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *pols_version(void) { return "pols_mi355x 0.1.0 (gfx950)"; }
+const char *pols_last_error(void) { return g_err; }
+
+int pols_create(int device_id, pols_ctx **out) {
+    if (!out) return fail(POLS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(POLS_ERR_NO_DEVICE, "no HIP device visible; libpols_mi355x has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(POLS_ERR_INVALID, "device_id %d out of range [0, %d)", device_id, n);
+    POLS_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    POLS_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(POLS_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code objects only", device_id, prop.gcnArchName);
+    pols_ctx *ctx = new pols_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(POLS_ERR_HIP, "hipStreamCreate failed");
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return POLS_OK;
+}
+
+void pols_destroy(pols_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->scratch)
+        if (s.ptr) hipFree(s.ptr);
+    for (auto &t : ctx->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pols_set_stream(pols_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return POLS_OK;
+}
+
+int pols_synchronize(pols_ctx *ctx) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    POLS_HIP(hipStreamSynchronize(ctx->stream));
+    return POLS_OK;
+}
+
+int pols_timing_enable(pols_ctx *ctx, int enable) {
+    if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
+    ctx->timing = enable != 0;
+    ctx->timed_used = 0;
+    return POLS_OK;
+}
+
+int pols_timing_collect(pols_ctx *ctx, float *ms_out, int max) {
+    if (!ctx || !ms_out) return fail(POLS_ERR_INVALID, "NULL argument");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(POLS_ERR_HIP, "stream sync failed");
+    int n = 0;
+    for (size_t i = 0; i < ctx->timed_used && n < max; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->timed[i].start, ctx->timed[i].stop) == hipSuccess) ms_out[n++] = ms;
+    }
+    ctx->timed_used = 0;
+    return n;
+}
+
+const char *pols_last_kernel_name(pols_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
+
+// ------------------------------------------------------------------ defaults (ls.py:101-107, 137-140, 156-160)
+void pols_ols_params_default(pols_ols_params *p) {
+    std::memset(p, 0, sizeof(*p));
+    p->alpha = 0.0;
+    p->has_l1_ratio = 0;
+    p->max_iter = 1000;
+    p->tol = 1.0e-5;
+    p->positive = 0;
+    p->solve_method = POLS_SOLVE_AUTO;
+    p->has_rcond = 0;
+    p->null_policy = POLS_NULL_IGNORE;
+}
+
+void pols_rls_params_default(pols_rls_params *p) {
+    std::memset(p, 0, sizeof(*p));
+    p->has_half_life = 0;
+    p->initial_state_covariance = 10.0;
+    p->initial_state_mean = nullptr;
+    p->null_policy = POLS_NULL_DROP;
+}
+
+void pols_rolling_params_default(pols_rolling_params *p) {
+    std::memset(p, 0, sizeof(*p));
+    p->window_size = 1000000;
+    p->min_periods = -1;
+    p->use_woodbury = -1;
+    p->alpha = 0.0;
+    p->null_policy = POLS_NULL_DROP_WINDOW;
+}
+
+// ------------------------------------------------------------------ static least squares
+int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = check_batch(b, o))) return rc;
+    if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
+    if (b->valid || p->null_policy != POLS_NULL_IGNORE)
+        return fail(POLS_ERR_UNSUPPORTED, "null policies other than 'ignore' are not built yet (SURVEY 8f-1)");
+
+    // Dispatcher of src/expressions.rs:366-387.
+    const int m = p->solve_method;
+    const double alpha = p->alpha;
+    const bool positive = p->positive != 0;
+    double ridge_alpha = 0.0;
+    if (alpha == 0.0 && !positive && (m == POLS_SOLVE_AUTO || m == POLS_SOLVE_SVD || m == POLS_SOLVE_QR)) {
+        ridge_alpha = 0.0;  // solve_ols: QR / SVD least squares == normal-equation solution for full column rank
+    } else if (alpha >= 0.0 && (p->has_l1_ratio ? p->l1_ratio : 0.0) == 0.0 && !positive) {
+        if (!(m == POLS_SOLVE_AUTO || m == POLS_SOLVE_CHOL || m == POLS_SOLVE_LU || m == POLS_SOLVE_SVD))
+            return fail(POLS_ERR_PANIC, "Only 'Cholesky', 'LU', & 'SVD' are currently supported solver methods for Ridge.");  // ls.rs:366
+        ridge_alpha = alpha;
+    } else {
+        if (!(m == POLS_SOLVE_AUTO || m == POLS_SOLVE_CD || m == POLS_SOLVE_CD_ACTIVE_SET))
+            return fail(POLS_ERR_PANIC, "Only solve_method 'CD' (coordinate descent) is currently supported for Elastic Net / Lasso problems.");  // ls.rs:404
+        if (!(alpha > 0.0)) return fail(POLS_ERR_PANIC, "'alpha' must be strictly positive");  // ls.rs:409
+        const double l1 = p->has_l1_ratio ? p->l1_ratio : 0.5;
+        if (!(l1 >= 0.0 && l1 <= 1.0)) return fail(POLS_ERR_PANIC, "'l1_ratio' must be strictly between 0. and 1.");  // ls.rs:410
+        return fail(POLS_ERR_UNSUPPORTED, "elastic-net kernel (K5) is not built yet");
+    }
+
+    const int kt = b->n_features + (b->add_intercept ? 1 : 0);
+    if (b->n_groups == 0) return POLS_OK;
+    const int64_t *d_offs = nullptr;
+    int64_t max_rows = 0;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
+    Staged st;
+    if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
+
+    if (kt > K1_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "%d features (incl. intercept) needs the MFMA Gram engine (not built yet)", kt);
+    K1Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.y = st.y; a.w = st.w; a.valid = st.valid;
+    for (int j = 0; j < b->n_features; ++j) a.x[j] = st.x[j];
+    a.offs = d_offs;
+    a.n_groups = b->n_groups;
+    a.n_rows = b->n_rows;
+    a.coef = st.coef; a.pred = st.pred; a.resid = st.resid; a.status = st.status;
+    a.alpha = ridge_alpha;
+    a.k_user = b->n_features;
+    if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
+    return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
+}
+
+int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o) {
+    (void)ctx; (void)b; (void)p; (void)o;
+    return fail(POLS_ERR_UNSUPPORTED, "RLS kernel (K3) is not built yet");
+}
+
+int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o) {
+    (void)ctx; (void)b; (void)p; (void)o;
+    return fail(POLS_ERR_UNSUPPORTED, "rolling kernel (K4) is not built yet");
+}
+
+int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, void *pred_out) {
+    (void)ctx; (void)b; (void)coef; (void)coef_rows; (void)pred_out;
+    return fail(POLS_ERR_UNSUPPORTED, "predict kernel is not built yet");
+}
+
+}  // extern "C"
+
+namespace pols {
+template <typename T> int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
+
+int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_group_rows, bool) {
+    return dtype == POLS_F32 ? k1_launch_t<float>(ctx, kt, a, max_group_rows) : k1_launch_t<double>(ctx, kt, a, max_group_rows);
+}
+}  // namespace pols

@@ -1,0 +1,49 @@
+// k1_gram_chol.hpp -- K1 "gram_chol_predict": the static least-squares hot path.
+//
+// Replaces, for ALL groups in one launch, what the reference does once per plugin call:
+//   construct_features_array   src/expressions.rs:22-63   (column -> row-major copy: deleted, we read the columns)
+//   solve_ols / solve_ridge    src/least_squares.rs:211-240, 342-364  (QR / Gram+Cholesky on one small problem)
+//   make_predictions           src/expressions.rs:175-195 (X . beta)
+//   sqrt(w) scaling, intercept, 1/sqrt(w) un-scaling, residuals   polars_ols/least_squares.py:184-196, 234-239
+//
+// Mapping to gfx950: one TEAM (a 64-lane wave, or a 256-thread workgroup) per group.  Lanes walk the
+// row axis of every column with 16-byte loads (lane i owns rows base+VEC*i ..), so each wave instruction
+// reads 1 KiB of one column, fully coalesced.  The rows a lane loaded stay in its VGPRs (RC chunks per
+// lane), so X is read from HBM exactly once: the Gram matrix Z^T Z of Z = [sqrt(w) X | sqrt(w) y] is
+// accumulated per lane (packed upper triangle), reduced across the wave with DPP and across the waves of
+// the workgroup through LDS in a fixed order (deterministic, no atomics); every lane then runs the same
+// K x K Cholesky + two triangular solves on wave-uniform values, and the prediction X . beta is formed
+// from the register-resident rows and stored with 16-byte stores.
+//
+// Algorithmic HBM traffic per group (n rows, k features, dtype size b): read b*n*(k+1) (+ b*n weights),
+// write b*n predictions  ->  cfg2 (f32, n=1000, k=8): 40 000 B.  Flops ~ n*(k+1)(k+2) + 2nk: AI ~ 2.6
+// flop/B, so the kernel is HBM-bound; there is no GEMM worth an MFMA tile at k <= 10 (a 16x16 tile would
+// be 32 % used and cost 5x the VALU form), the MFMA Gram engine lives in k5/k2 for k > 10.
+#pragma once
+
+#include "common.hpp"
+
+namespace pols {
+
+struct K1Args {
+    const void *y;
+    const void *w;                       // sample weights or nullptr
+    const uint8_t *valid;                // row validity bytes or nullptr
+    const void *x[POLS_MAX_FEATURES];    // user feature columns
+    const int64_t *offs;                 // device, n_groups + 1
+    int64_t n_groups;
+    int64_t n_rows;
+    void *coef;                          // n_groups x KT or nullptr
+    void *pred;                          // n_rows or nullptr
+    void *resid;                         // n_rows or nullptr
+    int32_t *status;                     // n_groups or nullptr
+    double alpha;                        // ridge penalty added to diag(X^T X) (ls.rs:355-356)
+    int32_t k_user;                      // KT - add_intercept
+};
+
+// Launches the (dtype, KT, team, resident-chunks) variant that fits max_group_rows.
+int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_group_rows, bool aligned16);
+
+constexpr int K1_MAX_KT = 10;
+
+}  // namespace pols

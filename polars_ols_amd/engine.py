@@ -1,0 +1,182 @@
+"""Engine: a ``pols_ctx`` plus buffer marshalling for numpy (host) and torch (device) columns.
+
+PyTorch appears here only as a device-memory owner and stream provider (``tensor.data_ptr()``,
+``torch.cuda.current_stream().cuda_stream``); every FLOP of the hot path runs in the hand-written gfx950
+kernels behind the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+try:  # torch is optional for the host-buffer path
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(a) -> bool:
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+class Engine:
+    """One context (device, stream, scratch).  Not thread-safe: create one per thread."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = L.lib()
+        h = C.c_void_p()
+        L.check(self._lib.pols_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pols_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ stream / timing
+    def set_stream(self, stream_ptr: Optional[int]):
+        L.check(self._lib.pols_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def use_torch_stream(self):
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        L.check(self._lib.pols_synchronize(self._h))
+
+    def timing(self, enable: bool):
+        L.check(self._lib.pols_timing_enable(self._h, int(enable)))
+
+    def timing_collect(self, max_n: int = 4096) -> np.ndarray:
+        buf = (C.c_float * max_n)()
+        n = self._lib.pols_timing_collect(self._h, buf, max_n)
+        L.check(n)
+        return np.frombuffer(buf, dtype=np.float32, count=n).copy()
+
+    @property
+    def last_kernel(self) -> str:
+        return self._lib.pols_last_kernel_name(self._h).decode()
+
+    # ------------------------------------------------------------------ marshalling
+    def _batch(self, y, x_cols: Sequence, offsets, weights, valid, add_intercept: bool):
+        dev = _is_torch(y)
+        cols = list(x_cols)
+        if len(cols) == 0:
+            raise ValueError("must pass at least 2 series")  # src/expressions.rs:72
+        if dev:
+            if not y.is_cuda:
+                raise ValueError("torch inputs must live on the GPU; pass numpy arrays for host data")
+            dt = y.dtype
+            if dt not in (torch.float32, torch.float64):
+                raise TypeError("dtype must be float32 or float64")
+            keep = [y.contiguous()] + [c.to(dt).contiguous() for c in cols]
+            w = weights.to(dt).contiguous() if weights is not None else None
+            v = valid.to(torch.uint8).contiguous() if valid is not None else None
+            ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+            dtype = L.POLS_F32 if dt == torch.float32 else L.POLS_F64
+            n = y.numel()
+        else:
+            y = np.asarray(y)
+            dt = np.float32 if y.dtype == np.float32 else np.float64
+            keep = [np.ascontiguousarray(y, dtype=dt)] + [np.ascontiguousarray(c, dtype=dt) for c in cols]
+            w = np.ascontiguousarray(weights, dtype=dt) if weights is not None else None
+            v = np.ascontiguousarray(valid, dtype=np.uint8) if valid is not None else None
+            ptr = lambda a: a.ctypes.data if a is not None else None  # noqa: E731
+            dtype = L.POLS_F32 if dt == np.float32 else L.POLS_F64
+            n = keep[0].shape[0]
+        for c in keep[1:]:
+            if (c.numel() if dev else c.shape[0]) != n:
+                raise ValueError("all input series passed must be of equal length")  # src/expressions.rs:96-100
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        colp = (C.c_void_p * len(cols))(*[ptr(c) for c in keep[1:]])
+        b = L.Batch(dtype=dtype, mem=L.POLS_MEM_DEVICE if dev else L.POLS_MEM_HOST, n_rows=n,
+                    n_groups=len(offs) - 1, group_offsets=offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                    n_features=len(cols), y=ptr(keep[0]), x_cols=colp, weights=ptr(w), valid=ptr(v),
+                    add_intercept=int(bool(add_intercept)))
+        return b, (keep, w, v, offs, colp), dev, dt
+
+    def _alloc(self, dev: bool, dt, shape, like=None):
+        if dev:
+            return torch.empty(shape, dtype=dt, device=like.device)
+        return np.empty(shape, dtype=dt)
+
+    @staticmethod
+    def _ptr(a):
+        if a is None:
+            return None
+        return a.data_ptr() if _is_torch(a) else a.ctypes.data
+
+    # ------------------------------------------------------------------ compute
+    def plan_least_squares(self, y, x_cols: Sequence, offsets, *, weights=None, valid=None,
+                           add_intercept: bool = False, want: Sequence[str] = ("pred",), out: Optional[Dict] = None,
+                           alpha: float = 0.0, l1_ratio: Optional[float] = None, max_iter: int = 1000,
+                           tol: float = 1e-5, positive: bool = False, solve_method: Optional[str] = None,
+                           rcond: Optional[float] = None, null_policy: str = "ignore") -> "Plan":
+        """Marshal once, launch many times (``plan.run()``): the buffers are borrowed, nothing is copied."""
+        b, keep, dev, dt = self._batch(y, x_cols, offsets, weights, valid, add_intercept)
+        kt = b.n_features + b.add_intercept
+        res: Dict = dict(out or {})
+        yy = keep[0][0]
+        if "coef" in want and "coef" not in res:
+            res["coef"] = self._alloc(dev, dt, (b.n_groups, kt), yy)
+        if "pred" in want and "pred" not in res:
+            res["pred"] = self._alloc(dev, dt, (b.n_rows,), yy)
+        if "resid" in want and "resid" not in res:
+            res["resid"] = self._alloc(dev, dt, (b.n_rows,), yy)
+        if "status" in want and "status" not in res:
+            res["status"] = self._alloc(dev, torch.int32 if dev else np.int32, (b.n_groups,), yy)
+        o = L.Out(coef=self._ptr(res.get("coef")), pred=self._ptr(res.get("pred")), resid=self._ptr(res.get("resid")),
+                  status=self._ptr(res.get("status")))
+        p = L.OlsParams()
+        self._lib.pols_ols_params_default(C.byref(p))
+        p.alpha = float(alpha if alpha is not None else 0.0)
+        p.has_l1_ratio = int(l1_ratio is not None)
+        p.l1_ratio = float(l1_ratio) if l1_ratio is not None else 0.0
+        p.max_iter = int(max_iter if max_iter is not None else 1000)
+        p.tol = float(tol if tol is not None else 1e-5)
+        p.positive = int(bool(positive))
+        p.solve_method = L.SOLVE_METHODS[solve_method]
+        p.has_rcond = int(rcond is not None)
+        p.rcond = float(rcond) if rcond is not None else 0.0
+        p.null_policy = L.NULL_POLICIES[null_policy]
+        return Plan(self, self._lib.pols_least_squares, b, p, o, res, keep)
+
+    def least_squares(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
+        """All groups of a (group-sorted) frame in one launch.  ``want`` subset of {"coef","pred","resid","status"};
+        ``out`` may carry pre-allocated buffers under the same keys."""
+        return self.plan_least_squares(y, x_cols, offsets, **kwargs).run()
+
+
+class Plan:
+    """A marshalled call: ctypes structs + references that keep every borrowed buffer alive."""
+
+    def __init__(self, eng: Engine, fn, batch, params, out, results: Dict, keep):
+        self._eng, self._fn, self._b, self._p, self._o, self.results, self._keep = eng, fn, batch, params, out, results, keep
+        self._args = (eng._h, C.byref(batch), C.byref(params), C.byref(out))
+
+    def run(self) -> Dict:
+        rc = self._fn(*self._args)
+        if rc < 0:
+            L.check(rc)
+        return self.results
+
+
+_default: Dict[int, Engine] = {}
+
+
+def default_engine(device: int = 0) -> Engine:
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]

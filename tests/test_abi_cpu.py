@@ -1,0 +1,86 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/*.h declares,
+its parameter defaults equal the reference's Python dataclass defaults, and it fails LOUDLY without a GPU
+(no CPU fallback).  No compute calls here."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from polars_ols_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not _lib.LIB_PATH.exists():
+        _lib.build()
+    return _lib.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    header = (ROOT / "include" / "pols_mi355x.h").read_text()
+    declared = set(re.findall(r"\b(pols_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no prototypes found"
+    missing = sorted(s for s in declared if not hasattr(L, s))
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS)
+
+
+def test_header_cites_reference_interfaces():
+    header = (ROOT / "include" / "pols_mi355x.h").read_text()
+    for cite in ("src/expressions.rs:351-388", "src/least_squares.rs:568-598", "src/least_squares.rs:848-1032",
+                 "src/expressions.rs:706-741", "src/expressions.rs:15-18"):
+        assert cite in header
+
+
+def test_ols_defaults_match_reference_dataclass(L):
+    # polars_ols/least_squares.py:101-107
+    p = _lib.OlsParams()
+    L.pols_ols_params_default(C.byref(p))
+    assert (p.alpha, p.has_l1_ratio, p.max_iter, p.tol, p.positive, p.solve_method, p.has_rcond, p.null_policy) == \
+        (0.0, 0, 1000, 1e-5, 0, 0, 0, _lib.NULL_POLICIES["ignore"])
+
+
+def test_rls_and_rolling_defaults_match_reference_dataclass(L):
+    # polars_ols/least_squares.py:137-140 and :156-160
+    p = _lib.RlsParams()
+    L.pols_rls_params_default(C.byref(p))
+    assert (p.has_half_life, p.initial_state_covariance, bool(p.initial_state_mean), p.null_policy) == \
+        (0, 10.0, False, _lib.NULL_POLICIES["drop"])
+    r = _lib.RollingParams()
+    L.pols_rolling_params_default(C.byref(r))
+    assert (r.window_size, r.min_periods, r.use_woodbury, r.alpha, r.null_policy) == \
+        (1_000_000, -1, -1, 0.0, _lib.NULL_POLICIES["drop_window"])
+
+
+def test_enum_values_match_header():
+    header = (ROOT / "include" / "pols_mi355x.h").read_text()
+    for name, val in {"POLS_SOLVE_QR": 1, "POLS_SOLVE_SVD": 2, "POLS_SOLVE_CHOL": 3, "POLS_SOLVE_LU": 4,
+                      "POLS_SOLVE_CD": 5, "POLS_SOLVE_CD_ACTIVE_SET": 6, "POLS_NULL_DROP_WINDOW": 5,
+                      "POLS_ERR_PANIC": -4, "POLS_ERR_NO_DEVICE": -5}.items():
+        assert re.search(rf"{name}\s*=\s*{val}\b", header), name
+
+
+def test_fails_loudly_without_gpu(L):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = L.pols_create(0, C.byref(h))
+    assert rc == -5 and not h.value
+    assert b"no CPU fallback" in L.pols_last_error()
+    from polars_ols_amd import Engine, PolsError
+
+    with pytest.raises(PolsError):
+        Engine(0)
+
+
+def test_product_never_imports_the_oracle():
+    for f in (ROOT / "polars_ols_amd").rglob("*"):
+        if f.suffix in {".py", ".hip", ".hpp", ".inl", ".cpp"}:
+            txt = f.read_text()
+            assert "oracle" not in txt.replace("the CPU oracle under ``oracle/`` is test infrastructure", "") \
+                .replace("and is never imported from here", "") or f.name == "_lib.py", f

@@ -1,0 +1,215 @@
+"""GPU parity tests of K1 (gram_chol_predict) through the C-ABI, against the CPU oracle, the committed golden
+fixtures and -- at BASELINE.json's full sizes -- size-independent properties.
+
+Tolerances (BASELINE.json north_star): 1e-6 relative for f64, 1e-4 for f32; predictions cross zero, so the
+comparison is |a-b| <= atol + rtol*|b| with atol = rtol, the reference's own convention (tests/test_ols.py:73).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 1e-4, np.float64: 1e-6}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from polars_ols_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _cuda(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _ragged_offsets(rng, n_groups, lo, hi):
+    sizes = rng.integers(lo, hi + 1, size=n_groups)
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def _frame(rng, offsets, k, dtype, weights=False):
+    N = int(offsets[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    beta = rng.uniform(0.5, 1.5, size=k)
+    y = (sum(b * c.astype(np.float64) for b, c in zip(beta, cols)) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    w = rng.uniform(0.1, 2.0, N).astype(dtype) if weights else None
+    return y, cols, w
+
+
+def _check(out, ref, dtype, keys=("coef", "pred", "resid")):
+    tol = TOL[dtype]
+    for k in keys:
+        got = out[k].double().cpu().numpy() if hasattr(out[k], "cpu") else np.asarray(out[k], dtype=np.float64)
+        assert got.shape == ref[k].shape, k
+        assert np.allclose(got, ref[k], rtol=tol, atol=tol), (k, float(np.abs(got - ref[k]).max()))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k", [1, 2, 4, 8, 10])
+def test_ols_equal_groups(eng, dtype, k):
+    from oracle import orc
+
+    rng = np.random.default_rng(k)
+    offs = np.arange(33, dtype=np.int64) * 1000
+    y, cols, _ = _frame(rng, offs, k, dtype)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "resid", "status"))
+    ref = orc.batched_least_squares(y, cols, offs)   # reference default: pivoted QR (least_squares.rs:195-240)
+    _check(out, ref, dtype)
+    assert int(out["status"].abs().sum()) == 0
+    assert "team256" in eng.last_kernel
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("lo,hi,variant", [(12, 120, "team64"), (200, 1000, "team256"), (900, 5000, "team256")])
+def test_ragged_groups_unaligned_offsets(eng, dtype, lo, hi, variant):
+    """Group starts are not multiples of the 16-byte vector width; sizes straddle every kernel variant, incl.
+    groups larger than the register-resident capacity (overflow rows are streamed twice)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(hi)
+    offs = _ragged_offsets(rng, 97, lo, hi)
+    y, cols, w = _frame(rng, offs, 5, dtype, weights=True)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=True,
+                            want=("coef", "pred", "resid", "status"))
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True)
+    _check(out, ref, dtype)
+    assert variant in eng.last_kernel
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ridge_weights_intercept_cfg3_shape(eng, dtype):
+    """BASELINE configs[2] shape at a size the oracle finishes in seconds: ridge alpha=1 + sample_weights."""
+    from oracle import orc
+    from refdata import synthetic_groups
+
+    d = synthetic_groups(200, 1000, 8, seed=11, dtype=dtype, with_weights=True)
+    out = eng.least_squares(_cuda(d["y"]), [_cuda(c) for c in d["cols"]], d["offsets"], weights=_cuda(d["w"]),
+                            alpha=1.0, l1_ratio=0.0, want=("coef", "pred", "resid"))
+    ref = orc.batched_least_squares(d["y"], d["cols"], d["offsets"], weights=d["w"], alpha=1.0, l1_ratio=0.0)
+    _check(out, ref, dtype)
+
+
+@pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])
+def test_all_solve_methods_agree_with_oracle(eng, golden, method):
+    """tests/test_ols.py:54-73: every solve_method gives lstsq's predictions on the seeded frame."""
+    z = golden["npz"]
+    x, y = z["ols_x"], z["ols_y"]
+    out = eng.least_squares(_cuda(y), [_cuda(x[:, 0]), _cuda(x[:, 1])], [0, 1000], solve_method=method,
+                            want=("coef", "pred"))
+    assert np.allclose(out["coef"].cpu().numpy()[0], z["ols_coef"], rtol=1e-9)
+    assert np.allclose(out["pred"].cpu().numpy(), z["ols_pred"], rtol=1e-6, atol=1e-6)
+
+
+def test_golden_readme_and_make_data(eng, golden):
+    from refdata import make_data, sort_by_group
+
+    kat, z = golden["kat"], golden["npz"]
+    f = {k: np.asarray(v, dtype=np.float64) for k, v in kat["frame"].items()}
+    # README.md:104 -- from_formula("x1 + x2", mode="coefficients"): intercept last
+    out = eng.least_squares(f["y"], [f["x1"], f["x2"]], [0, 10], add_intercept=True, want=("coef",))   # host buffers
+    assert np.allclose(np.round(out["coef"][0], 6), kat["coefficients_full"], atol=1.1e-6)
+    # README.md:112-113 -- .over("group")
+    order, offs, keys = sort_by_group(f["group"].astype(np.int64))
+    out = eng.least_squares(f["y"][order], [f["x1"][order], f["x2"][order]], offs, add_intercept=True, want=("coef",))
+    for g, key in enumerate(keys):
+        assert np.allclose(np.round(out["coef"][g], 6), kat["coefficients_group"][str(key)], atol=1.1e-6)
+    # README.md:72-76 -- WLS predictions rounded to 2 dp
+    out = eng.least_squares(f["y"], [f["x1"], f["x2"]], [0, 10], weights=f["weights"], want=("pred",))
+    assert np.array_equal(np.round(out["pred"][:5], 2), kat["predictions_wls_head5_round2"])
+    # tests/test_ols.py:475-503 ridge, :456-472 WLS + intercept, :377-401 grouped
+    x, y = z["ridge_x"], z["ridge_y"]
+    cols = [np.ascontiguousarray(x[:, 0]), np.ascontiguousarray(x[:, 1])]
+    out = eng.least_squares(y, cols, [0, 5000], alpha=0.01, solve_method="chol", want=("coef",))
+    assert np.allclose(out["coef"][0], z["ridge_coef_chol"], rtol=1e-9)
+    out = eng.least_squares(y, cols, [0, 5000], weights=z["wls_w"], add_intercept=True, want=("coef", "pred"))
+    assert np.allclose(out["coef"][0], z["wls_coef"], rtol=1e-8) and np.allclose(out["pred"], z["wls_pred"], rtol=1e-6, atol=1e-6)
+    d = make_data(n_groups=10)
+    order, offs, _ = sort_by_group(d["group"])
+    out = eng.least_squares(d["y"][order], [d["x1"][order], d["x2"][order]], offs, want=("coef",))
+    assert np.allclose(out["coef"], z["group_coef"], rtol=1e-8)
+
+
+def test_host_and_device_paths_are_bit_identical(eng):
+    rng = np.random.default_rng(5)
+    offs = _ragged_offsets(rng, 40, 300, 1200)
+    y, cols, w = _frame(rng, offs, 6, np.float32, weights=True)
+    a = eng.least_squares(y, cols, offs, weights=w, want=("coef", "pred"))
+    b = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), want=("coef", "pred"))
+    assert np.array_equal(a["coef"], b["coef"].cpu().numpy()) and np.array_equal(a["pred"], b["pred"].cpu().numpy())
+    c = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), want=("coef", "pred"))
+    assert np.array_equal(b["pred"].cpu().numpy(), c["pred"].cpu().numpy())   # deterministic reduction order
+
+
+def test_empty_and_tiny_groups(eng):
+    from oracle import orc
+
+    rng = np.random.default_rng(9)
+    offs = np.array([0, 0, 5, 5, 9, 300, 300], dtype=np.int64)   # empty groups at the front, middle and end
+    y, cols, _ = _frame(rng, offs, 3, np.float64)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "status"))
+    ref = orc.batched_least_squares(y, cols, offs)
+    st = out["status"].cpu().numpy()
+    assert list(st[[0, 2, 5]]) == [2, 2, 2]                      # POLS_GROUP_EMPTY -> zeros (expressions.rs:357-359)
+    assert np.array_equal(out["coef"].cpu().numpy()[[0, 2, 5]], np.zeros((3, 3)))
+    ok = [1, 3, 4]
+    assert np.allclose(out["coef"].cpu().numpy()[ok], ref["coef"][ok], rtol=1e-6, atol=1e-9)
+    assert np.allclose(out["pred"].cpu().numpy(), ref["pred"], rtol=1e-6, atol=1e-8)
+
+
+def test_weight_zero_gives_nan_prediction_like_reference(eng):
+    """sqrt(0) = 0 -> (0*x).beta * (1/0) = NaN in the reference's Python un-scaling (least_squares.py:234-235)."""
+    rng = np.random.default_rng(2)
+    offs = np.array([0, 64], dtype=np.int64)
+    y, cols, w = _frame(rng, offs, 2, np.float64, weights=True)
+    w[7] = 0.0
+    out = eng.least_squares(y, cols, offs, weights=w, want=("pred",))
+    assert np.isnan(out["pred"][7]) and np.isfinite(np.delete(out["pred"], 7)).all()
+
+
+def test_reference_panics_surface_as_errors(eng):
+    from polars_ols_amd import PolsError, PolsPanic
+
+    y = np.ones(8); x = [np.arange(8.0)]
+    with pytest.raises(PolsPanic, match="supported solver methods for Ridge"):
+        eng.least_squares(y, x, [0, 8], alpha=0.1, solve_method="qr")          # least_squares.rs:366
+    with pytest.raises(PolsPanic, match="strictly positive"):
+        eng.least_squares(y, x, [0, 8], alpha=-1.0)                           # least_squares.rs:409
+    with pytest.raises(PolsError):
+        eng.least_squares(y, x, [0, 5], want=("coef",))                       # offsets do not end at n_rows
+    with pytest.raises(ValueError):
+        eng.least_squares(y, [], [0, 8])                                      # expressions.rs:72
+
+
+@pytest.mark.parametrize("dtype,groups,rows,k", [(np.float32, 10_000, 1_000, 8)])
+def test_full_size_cfg2_properties(eng, dtype, groups, rows, k):
+    """BASELINE configs[1] at full size (10k x 1k x 8, f32, predictions): checked through properties that do not
+    need the oracle at 10^7 rows: normal equations X^T(y - yhat) = 0 per group, pred + resid == y, linearity in y,
+    and oracle parity on a sample of groups."""
+    import torch
+    from oracle import orc
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    N = groups * rows
+    cols = [torch.randn(N, generator=g, device="cuda", dtype=torch.float32) for _ in range(k)]
+    y = sum(cols) + 0.1 * torch.randn(N, generator=g, device="cuda", dtype=torch.float32)
+    offs = np.arange(groups + 1, dtype=np.int64) * rows
+    out = eng.least_squares(y, cols, offs, want=("coef", "pred", "resid", "status"))
+    assert int(out["status"].abs().sum()) == 0
+    assert torch.equal(out["pred"] + out["resid"], y) or torch.allclose(out["pred"] + out["resid"], y, atol=1e-6)
+    r = out["resid"].double().view(groups, rows)
+    for c in cols:   # X^T r == 0 (scaled by ||x|| ||r|| ~ sqrt(n) * 0.1 * sqrt(n))
+        dot = (c.double().view(groups, rows) * r).sum(1)
+        assert float(dot.abs().max()) < 1e-4 * rows * 0.1 * 10
+    out2 = eng.least_squares(2.0 * y, cols, offs, want=("pred",))
+    assert torch.allclose(out2["pred"], 2.0 * out["pred"], rtol=1e-5, atol=1e-5)
+    pick = np.array([0, 1, 4999, 9998, 9999])
+    yh = y.cpu().numpy().reshape(groups, rows)[pick].reshape(-1)
+    ch = [c.cpu().numpy().reshape(groups, rows)[pick].reshape(-1) for c in cols]
+    ref = orc.batched_least_squares(yh, ch, np.arange(len(pick) + 1) * rows)
+    assert np.allclose(out["coef"].cpu().numpy()[pick], ref["coef"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(out["pred"].cpu().numpy().reshape(groups, rows)[pick].reshape(-1), ref["pred"], rtol=1e-4, atol=1e-4)
