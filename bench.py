@@ -45,9 +45,9 @@ def cpu_baseline(rows: int, feats: int, target_seconds: float = 12.0) -> dict:
     from oracle import orc
     from refdata import synthetic_groups
 
-    sample_groups = 2_000
-    d = synthetic_groups(sample_groups, rows, feats, seed=1, dtype=np.float64)
     cores = orc.max_threads()
+    sample_groups = max(2_000, 64 * cores)
+    d = synthetic_groups(sample_groups, rows, feats, seed=1, dtype=np.float64)
     orc.batched_least_squares(d["y"], d["cols"], d["offsets"], n_threads=cores, want=("pred",))  # warm-up
     t0 = time.perf_counter()
     reps = 0

@@ -1,6 +1,7 @@
 // api.hip -- C-ABI entry points of libpols_mi355x.so (see include/pols_mi355x.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 
 #include "common.hpp"
@@ -333,7 +334,7 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
 
-    if (kt > K1_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "%d features (incl. intercept) needs the MFMA Gram engine (not built yet)", kt);
+    if (kt > K1M_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "%d features (incl. intercept) > %d: the two-tile MFMA Gram is not built yet", kt, K1M_MAX_KT);
     K1Args a;
     std::memset(&a, 0, sizeof(a));
     a.y = st.y; a.w = st.w; a.valid = st.valid;
@@ -367,8 +368,27 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
 
 namespace pols {
 template <typename T> int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
+template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
+template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);
 
+// Engine choice for the static least-squares path:
+//   K1m (LDS tile + MFMA Gram)   groups whose tile fits the 160 KiB LDS and are big enough to fill a workgroup;
+//   K1  (register-resident VALU)  small groups (one wave per group) and groups too large for LDS (streamed).
+// POLS_K1_ENGINE=valu|mfma overrides the choice (A/B measurements).
 int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_group_rows, bool) {
-    return dtype == POLS_F32 ? k1_launch_t<float>(ctx, kt, a, max_group_rows) : k1_launch_t<double>(ctx, kt, a, max_group_rows);
+    const bool f32 = dtype == POLS_F32;
+    const int vec = f32 ? 4 : 2;
+    const bool fits = kt <= K1M_MAX_KT && (f32 ? k1m_fits<float>(a.k_user, a.w != nullptr, max_group_rows)
+                                               : k1m_fits<double>(a.k_user, a.w != nullptr, max_group_rows));
+    bool use_mfma = fits && (max_group_rows > 64 * 2 * vec || kt > K1_MAX_KT);
+    if (const char *force = std::getenv("POLS_K1_ENGINE")) {
+        if (!std::strcmp(force, "valu") && kt <= K1_MAX_KT) use_mfma = false;
+        if (!std::strcmp(force, "mfma") && fits) use_mfma = true;
+    }
+    if (use_mfma) return f32 ? k1m_launch_t<float>(ctx, kt, a, max_group_rows) : k1m_launch_t<double>(ctx, kt, a, max_group_rows);
+    if (kt > K1_MAX_KT)
+        return fail(POLS_ERR_UNSUPPORTED, "%d features with %lld-row groups: tile exceeds LDS and the streamed engine stops at %d features",
+                    kt, (long long)max_group_rows, K1_MAX_KT);
+    return f32 ? k1_launch_t<float>(ctx, kt, a, max_group_rows) : k1_launch_t<double>(ctx, kt, a, max_group_rows);
 }
 }  // namespace pols

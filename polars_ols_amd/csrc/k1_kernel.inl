@@ -252,7 +252,9 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 }
 
 template <typename T, int KT, int TEAM, int RC>
-static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, const char *name) {
+static int k1_launch_variant(pols_ctx *ctx, const K1Args &a) {
+    char name[96];
+    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d_team%d_rc%d", sizeof(T) == 4 ? "f32" : "f64", KT, TEAM, RC);
     const int64_t teams_per_block = 256 / TEAM;
     const int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
@@ -264,10 +266,7 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, const char *name) {
     return POLS_OK;
 }
 
-#define K1_STR2(x) #x
-#define K1_STR(x) K1_STR2(x)
-#define K1_VARIANT(T, TN, KT, TEAM, RC) \
-    k1_launch_variant<T, KT, TEAM, RC>(ctx, a, "k1_gram_chol_" TN "_k" K1_STR(KT) "_team" K1_STR(TEAM) "_rc" K1_STR(RC))
+#define K1_VARIANT(T, TN, KT, TEAM, RC) k1_launch_variant<T, KT, TEAM, RC>(ctx, a)
 
 // Variant choice: smallest team whose registers hold the largest group (so X is read once); groups
 // larger than the biggest variant stream their overflow rows twice (Gram pass + prediction pass).

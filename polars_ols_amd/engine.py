@@ -32,6 +32,9 @@ class Engine:
         L.check(self._lib.pols_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        # torch inputs: launch on torch's CURRENT stream (same-stream ordering with the ops that produced the
+        # inputs / consume the outputs) unless the caller pinned a stream with set_stream().
+        self._follow_torch = stream is None
         if stream is not None:
             self.set_stream(stream)
 
@@ -48,6 +51,8 @@ class Engine:
 
     # ------------------------------------------------------------------ stream / timing
     def set_stream(self, stream_ptr: Optional[int]):
+        """Pin the HIP stream every launch goes to (None: back to following torch's current stream)."""
+        self._follow_torch = stream_ptr is None
         L.check(self._lib.pols_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
     def use_torch_stream(self):
@@ -81,6 +86,8 @@ class Engine:
             dt = y.dtype
             if dt not in (torch.float32, torch.float64):
                 raise TypeError("dtype must be float32 or float64")
+            if self._follow_torch:
+                L.check(self._lib.pols_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)))
             keep = [y.contiguous()] + [c.to(dt).contiguous() for c in cols]
             w = weights.to(dt).contiguous() if weights is not None else None
             v = valid.to(torch.uint8).contiguous() if valid is not None else None

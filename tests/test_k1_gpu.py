@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 TOL = {np.float32: 1e-4, np.float64: 1e-6}
 
 
+@pytest.fixture(params=["valu", "mfma"])
+def engine_kind(request, monkeypatch):
+    """A/B both engines of the static path: K1 (register-resident VALU Gram) and K1m (LDS tile + MFMA Gram)."""
+    monkeypatch.setenv("POLS_K1_ENGINE", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def eng():
     from polars_ols_amd import Engine
@@ -51,7 +58,7 @@ def _check(out, ref, dtype, keys=("coef", "pred", "resid")):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k", [1, 2, 4, 8, 10])
-def test_ols_equal_groups(eng, dtype, k):
+def test_ols_equal_groups(eng, engine_kind, dtype, k):
     from oracle import orc
 
     rng = np.random.default_rng(k)
@@ -61,12 +68,12 @@ def test_ols_equal_groups(eng, dtype, k):
     ref = orc.batched_least_squares(y, cols, offs)   # reference default: pivoted QR (least_squares.rs:195-240)
     _check(out, ref, dtype)
     assert int(out["status"].abs().sum()) == 0
-    assert "team256" in eng.last_kernel
+    assert eng.last_kernel.startswith("k1m_gram_mfma" if engine_kind == "mfma" else "k1_gram_chol"), eng.last_kernel
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("lo,hi,variant", [(12, 120, "team64"), (200, 1000, "team256"), (900, 5000, "team256")])
-def test_ragged_groups_unaligned_offsets(eng, dtype, lo, hi, variant):
+def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, variant):
     """Group starts are not multiples of the 16-byte vector width; sizes straddle every kernel variant, incl.
     groups larger than the register-resident capacity (overflow rows are streamed twice)."""
     from oracle import orc
@@ -78,11 +85,11 @@ def test_ragged_groups_unaligned_offsets(eng, dtype, lo, hi, variant):
                             want=("coef", "pred", "resid", "status"))
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True)
     _check(out, ref, dtype)
-    assert variant in eng.last_kernel
+    assert (variant in eng.last_kernel) if engine_kind == "valu" else eng.last_kernel.startswith("k1m_"), eng.last_kernel
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_ridge_weights_intercept_cfg3_shape(eng, dtype):
+def test_ridge_weights_intercept_cfg3_shape(eng, engine_kind, dtype):
     """BASELINE configs[2] shape at a size the oracle finishes in seconds: ridge alpha=1 + sample_weights."""
     from oracle import orc
     from refdata import synthetic_groups
@@ -92,6 +99,22 @@ def test_ridge_weights_intercept_cfg3_shape(eng, dtype):
                             alpha=1.0, l1_ratio=0.0, want=("coef", "pred", "resid"))
     ref = orc.batched_least_squares(d["y"], d["cols"], d["offsets"], weights=d["w"], alpha=1.0, l1_ratio=0.0)
     _check(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k", [12, 15])
+def test_wide_features_mfma_engine(eng, dtype, k):
+    """11..15 features: only the MFMA Gram engine (one 16x16 tile holds [X | y])."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k)
+    offs = _ragged_offsets(rng, 21, 300, 900)
+    y, cols, w = _frame(rng, offs, k - 1, dtype, weights=True)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=True,
+                            alpha=0.5, want=("coef", "pred", "resid"))
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True, alpha=0.5)
+    _check(out, ref, dtype)
+    assert eng.last_kernel.startswith("k1m_")
 
 
 @pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])
@@ -134,7 +157,7 @@ def test_golden_readme_and_make_data(eng, golden):
     assert np.allclose(out["coef"], z["group_coef"], rtol=1e-8)
 
 
-def test_host_and_device_paths_are_bit_identical(eng):
+def test_host_and_device_paths_are_bit_identical(eng, engine_kind):
     rng = np.random.default_rng(5)
     offs = _ragged_offsets(rng, 40, 300, 1200)
     y, cols, w = _frame(rng, offs, 6, np.float32, weights=True)
@@ -145,7 +168,7 @@ def test_host_and_device_paths_are_bit_identical(eng):
     assert np.array_equal(b["pred"].cpu().numpy(), c["pred"].cpu().numpy())   # deterministic reduction order
 
 
-def test_empty_and_tiny_groups(eng):
+def test_empty_and_tiny_groups(eng, engine_kind):
     from oracle import orc
 
     rng = np.random.default_rng(9)
@@ -161,7 +184,7 @@ def test_empty_and_tiny_groups(eng):
     assert np.allclose(out["pred"].cpu().numpy(), ref["pred"], rtol=1e-6, atol=1e-8)
 
 
-def test_weight_zero_gives_nan_prediction_like_reference(eng):
+def test_weight_zero_gives_nan_prediction_like_reference(eng, engine_kind):
     """sqrt(0) = 0 -> (0*x).beta * (1/0) = NaN in the reference's Python un-scaling (least_squares.py:234-235)."""
     rng = np.random.default_rng(2)
     offs = np.array([0, 64], dtype=np.int64)
@@ -186,7 +209,7 @@ def test_reference_panics_surface_as_errors(eng):
 
 
 @pytest.mark.parametrize("dtype,groups,rows,k", [(np.float32, 10_000, 1_000, 8)])
-def test_full_size_cfg2_properties(eng, dtype, groups, rows, k):
+def test_full_size_cfg2_properties(eng, engine_kind, dtype, groups, rows, k):
     """BASELINE configs[1] at full size (10k x 1k x 8, f32, predictions): checked through properties that do not
     need the oracle at 10^7 rows: normal equations X^T(y - yhat) = 0 per group, pred + resid == y, linearity in y,
     and oracle parity on a sample of groups."""
