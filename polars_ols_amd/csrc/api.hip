@@ -392,3 +392,36 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
     return f32 ? k1_launch_t<float>(ctx, kt, a, max_group_rows) : k1_launch_t<double>(ctx, kt, a, max_group_rows);
 }
 }  // namespace pols
+
+// ------------------------------------------------------------------ POLS_TIMELINE=1 debugging aid
+namespace pols {
+int report_timeline(pols_ctx *ctx, const unsigned long long *d_dbg, int64_t n_groups, int n_stamps, const char *name) {
+    std::vector<unsigned long long> h((size_t)n_groups * 8);
+    POLS_HIP(hipStreamSynchronize(ctx->stream));
+    POLS_HIP(hipMemcpy(h.data(), d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> phase(n_stamps, 0.0);
+    double life = 0.0;
+    // per-XCC span (s_memtime is per-XCD): concurrency = sum of lifetimes / span / CUs-per-XCC
+    unsigned long long lo[8], hi[8];
+    double sumlife[8] = {0};
+    for (int x = 0; x < 8; ++x) { lo[x] = ~0ULL; hi[x] = 0; }
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const unsigned long long *t = &h[(size_t)g * 8];
+        for (int i = 0; i + 1 < n_stamps; ++i) phase[i] += (double)(t[i + 1] - t[i]);
+        life += (double)(t[n_stamps - 1] - t[0]);
+        const int x = (int)((t[6] >> 32) & 7);
+        lo[x] = std::min(lo[x], t[0]);
+        hi[x] = std::max(hi[x], t[n_stamps - 1]);
+        sumlife[x] += (double)(t[n_stamps - 1] - t[0]);
+    }
+    std::fprintf(stderr, "[timeline] %s groups=%lld mean cycles/workgroup: life=%.0f |", name, (long long)n_groups, life / n_groups);
+    for (int i = 0; i + 1 < n_stamps; ++i) std::fprintf(stderr, " p%d=%.0f", i, phase[i] / n_groups);
+    double conc = 0.0, span = 0.0;
+    int nx = 0;
+    for (int x = 0; x < 8; ++x)
+        if (hi[x] > lo[x]) { conc += sumlife[x] / (double)(hi[x] - lo[x]); span += (double)(hi[x] - lo[x]); ++nx; }
+    std::fprintf(stderr, " | xccs=%d mean span=%.0f ticks, resident workgroups/CU=%.2f\n", nx, nx ? span / nx : 0.0,
+                 ctx->num_cus ? conc / ctx->num_cus : 0.0);
+    return POLS_OK;
+}
+}  // namespace pols

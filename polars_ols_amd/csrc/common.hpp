@@ -65,6 +65,8 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
 // timing helpers: no-ops unless ctx->timing
 void timing_begin(pols_ctx *ctx);
 void timing_end(pols_ctx *ctx);
+// POLS_TIMELINE=1 debugging: synchronise, read n_stamps s_memtime stamps per group, print phase statistics to stderr
+int report_timeline(pols_ctx *ctx, const unsigned long long *d_dbg, int64_t n_groups, int n_stamps, const char *name);
 
 inline size_t dtype_size(int dtype) { return dtype == POLS_F32 ? 4 : 8; }
 
@@ -102,6 +104,63 @@ __device__ __forceinline__ T wave_sum_row3(T v) {
     v += dpp_get<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
     v += dpp_get<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
     return v;
+}
+
+// ---- reduce-scatter over a wave (gfx950 v_permlane32_swap / v_permlane16_swap) -------------------------
+// pair_lo_hi(a, b): afterwards `a` holds, in lanes 0-31, a[l] + a[l+32] and, in lanes 32-63, b[l-32] + b[l].
+__device__ __forceinline__ void pair_halves(float &a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void pair_halves(double &a, double b) {
+    const unsigned long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) +
+        __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+// pair_rows(a, b): afterwards `a` holds per 16-lane row [a.r0 + a.r1, b.r0 + b.r1, a.r2 + a.r3, b.r2 + b.r3].
+__device__ __forceinline__ void pair_rows(float &a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void pair_rows(double &a, double b) {
+    const unsigned long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) +
+        __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+// all-reduce inside each 16-lane row: 4 DPP steps that fuse into v_add_*_dpp (no temporaries)
+template <typename T>
+__device__ __forceinline__ T row_allreduce(T v) {
+    v += dpp_get<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(v);  // row_half_mirror
+    v += dpp_get<0x140>(v);  // row_mirror
+    return v;
+}
+
+// Sum N per-lane values over the wave.  On return u[i] (i < (N+3)/4) holds, in every lane of 16-lane row r,
+// the wave total of v[4*i + rs_perm(r)]; v[] is clobbered.  ~2.5 N VALU ops instead of 6 N, and the live
+// register count halves at each of the first two steps.
+__device__ __forceinline__ constexpr int rs_perm(int row) { return row == 1 ? 2 : (row == 2 ? 1 : row); }
+
+template <typename T, int N>
+__device__ __forceinline__ void wave_reduce_scatter(T (&v)[N], T (&u)[(N + 3) / 4]) {
+    constexpr int N2 = (N + 1) / 2, N4 = (N + 3) / 4;
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const T b = (2 * i + 1 < N) ? v[2 * i + 1] : T(0);
+        pair_halves(v[2 * i], b);      // v[2i]: lanes 0-31 <- total(v[2i]) over halves, lanes 32-63 <- total(v[2i+1])
+    }
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        T a = v[4 * i];
+        const T b = (2 * i + 1 < N2) ? v[4 * i + 2] : T(0);
+        pair_rows(a, b);               // rows: [v4i, v4i+2, v4i+1, v4i+3]
+        u[i] = row_allreduce(a);
+    }
 }
 
 __device__ __forceinline__ float readlane63(float v) {

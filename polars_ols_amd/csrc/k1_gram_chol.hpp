@@ -39,6 +39,7 @@ struct K1Args {
     int32_t *status;                     // n_groups or nullptr
     double alpha;                        // ridge penalty added to diag(X^T X) (ls.rs:355-356)
     int32_t k_user;                      // KT - add_intercept
+    unsigned long long *dbg;             // POLS_TIMELINE=1: 8 s_memtime stamps per group (debug only)
 };
 
 // Launches the (dtype, KT, team, resident-chunks) variant that fits max_group_rows.

@@ -8,72 +8,94 @@ __host__ __device__ constexpr int tri_index(int i, int j) {  // packed upper tri
     return i * NZ - (i * (i - 1)) / 2 + (j - i);
 }
 
-// One chunk = VEC consecutive rows of every column, held by one lane.
-template <typename T, int KT>
+// One chunk = VEC consecutive rows of every column, held by one lane as the 16-byte vectors it loaded
+// (scaled in place by sqrt(w) when there are weights -- no second copy: register pressure decides how many
+// groups are in flight per CU, and that is what this latency-bound kernel's throughput is made of).
+template <typename T, int KT, bool HAS_W>
 struct Chunk {
-    static constexpr int VEC = Vec16<T>::N;
-    T x[VEC][KT];  // sqrt(w)-scaled features, intercept (if any) in column KT-1
-    T y[VEC];      // ORIGINAL target (needed for residuals)
-    T sw[VEC];     // sqrt(w); 1 when there are no weights
+    using V = typename Vec16<T>::type;
+    V x[KT];   // features (sqrt(w)-scaled if HAS_W); slot KT-1 holds the intercept column when there is one
+    V y;       // ORIGINAL target (needed for residuals)
+    V sw;      // sqrt(w); only meaningful when HAS_W
 };
 
-template <typename T, int KT>
-__device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_t s, int64_t e, Chunk<T, KT> &c) {
+template <typename T> __device__ __forceinline__ typename Vec16<T>::type vsplat(T v);
+template <> __device__ __forceinline__ float4 vsplat<float>(float v) { return float4{v, v, v, v}; }
+template <> __device__ __forceinline__ double2 vsplat<double>(double v) { return double2{v, v}; }
+
+template <typename T> __device__ __forceinline__ void vset(typename Vec16<T>::type &v, int i, T x);
+template <> __device__ __forceinline__ void vset<float>(float4 &v, int i, float x) {
+    if (i == 0) v.x = x; else if (i == 1) v.y = x; else if (i == 2) v.z = x; else v.w = x;
+}
+template <> __device__ __forceinline__ void vset<double>(double2 &v, int i, double x) { if (i == 0) v.x = x; else v.y = x; }
+
+template <typename T, int KT, bool HAS_W>
+__device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_t s, int64_t e, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
     const int ku = a.k_user;
     if (row0 >= s && row0 + VEC <= e) {
         // whole chunk inside the group: 16-byte loads, all issued before first use
-        V vx[KT];
 #pragma unroll
-        for (int j = 0; j < KT; ++j)
-            if (j < ku) vx[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
-        const V vy = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
-        V vw;
-        if (a.w) vw = *reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const T sw = a.w ? sqrt(vget<T>(vw, v)) : T(1);
-            c.sw[v] = sw;
-            c.y[v] = vget<T>(vy, v);
-#pragma unroll
-            for (int j = 0; j < KT; ++j) c.x[v][j] = (j < ku ? vget<T>(vx[j], v) : T(1)) * sw;
+        for (int j = 0; j < KT; ++j) {
+            if (j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
+            else c.x[j] = vsplat<T>(T(1));
         }
+        c.y = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
+        if constexpr (HAS_W) c.sw = *reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0);
     } else {
         // ragged head / tail of a group: guarded scalar loads, rows outside [s, e) contribute zeros
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int64_t r = row0 + v;
             const bool in = (r >= s) && (r < e);
-            const T sw = (in && a.w) ? sqrt(static_cast<const T *>(a.w)[r]) : T(1);
-            c.sw[v] = sw;
-            c.y[v] = in ? static_cast<const T *>(a.y)[r] : T(0);
+            vset<T>(c.y, v, in ? static_cast<const T *>(a.y)[r] : T(0));
+            if constexpr (HAS_W) vset<T>(c.sw, v, in ? static_cast<const T *>(a.w)[r] : T(1));
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 T xv = T(0);
                 if (in) xv = (j < ku) ? static_cast<const T *>(a.x[j])[r] : T(1);
-                c.x[v][j] = xv * sw;
+                vset<T>(c.x[j], v, xv);
             }
+        }
+    }
+    if constexpr (HAS_W) {   // sqrt_w scaling of every feature, intercept included (least_squares.py:190-196)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const T sw = sqrt(vget<T>(c.sw, v));
+            vset<T>(c.sw, v, sw);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) vset<T>(c.x[j], v, vget<T>(c.x[j], v) * sw);
         }
     }
 }
 
-template <typename T, int KT>
-__device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2], const Chunk<T, KT> &c) {
+template <typename T, int KT, bool HAS_W>
+__device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2], const Chunk<T, KT, HAS_W> &c) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        const T ys = c.y[v] * c.sw[v];
+        T ys = vget<T>(c.y, v);
+        if constexpr (HAS_W) ys *= vget<T>(c.sw, v);
 #pragma unroll
         for (int i = 0; i < KT; ++i) {
+            const T xi = vget<T>(c.x[i], v);
 #pragma unroll
-            for (int j = i; j < KT; ++j) acc[tri_index<NZ>(i, j)] = fma(c.x[v][i], c.x[v][j], acc[tri_index<NZ>(i, j)]);
-            acc[tri_index<NZ>(i, KT)] = fma(c.x[v][i], ys, acc[tri_index<NZ>(i, KT)]);
+            for (int j = i; j < KT; ++j) acc[tri_index<NZ>(i, j)] = fma(xi, vget<T>(c.x[j], v), acc[tri_index<NZ>(i, j)]);
+            acc[tri_index<NZ>(i, KT)] = fma(xi, ys, acc[tri_index<NZ>(i, KT)]);
         }
         acc[tri_index<NZ>(KT, KT)] = fma(ys, ys, acc[tri_index<NZ>(KT, KT)]);
     }
 }
+
+// 1/sqrt(d).  f32: v_rsq_f32 (1 ulp) + one Newton step instead of the ~25-instruction IEEE sqrt + divide
+// chain (the Cholesky is a serial dependency chain, so instruction latency is what it costs); f64: IEEE.
+__device__ __forceinline__ float inv_sqrt(float d) {
+    const float r = __builtin_amdgcn_rsqf(d);
+    return r * fmaf(-0.5f * d * r, r, 1.5f);
+}
+__device__ __forceinline__ double inv_sqrt(double d) { return 1.0 / sqrt(d); }
 
 // Cholesky (LL^T) of G + alpha I and the two triangular solves, fully unrolled on wave-uniform values.
 // Returns false on a non-positive pivot (faer's `cholesky(Side::Lower)` Err, ls.rs:289-299).
@@ -89,9 +111,7 @@ __device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 
 #pragma unroll
         for (int p = 0; p < j; ++p) d = fma(-L[j][p], L[j][p], d);
         ok = ok && (d > T(0));
-        const T dj = sqrt(d);
-        rinv[j] = T(1) / dj;
-        L[j][j] = dj;
+        rinv[j] = inv_sqrt(d);   // 1 / L[j][j]; the solves below only ever divide by the diagonal
 #pragma unroll
         for (int i = j + 1; i < KT; ++i) {
             T sacc = acc[tri_index<NZ>(j, i)];
@@ -118,41 +138,33 @@ __device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 
     return ok;
 }
 
-template <typename T, int KT>
-__device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT> &c, const T (&beta)[KT], int64_t row0,
-                                              int64_t s, int64_t e) {
+template <typename T, int KT, bool HAS_W>
+__device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT, HAS_W> &c, const T (&beta)[KT],
+                                              int64_t row0, int64_t s, int64_t e) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
-    T p[VEC];
+    V p, r;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < KT; ++j) acc = fma(c.x[v][j], beta[j], acc);   // make_predictions on the FIT features (ex.rs:398-405)
-        if (a.w) acc *= T(1) / c.sw[v];                                     // predictions *= 1/sqrt_w (ls.py:234-235)
-        p[v] = acc;
+        for (int j = 0; j < KT; ++j) acc = fma(vget<T>(c.x[j], v), beta[j], acc);   // make_predictions on the FIT features (ex.rs:398-405)
+        if constexpr (HAS_W) acc *= T(1) / vget<T>(c.sw, v);                         // predictions *= 1/sqrt_w (ls.py:234-235)
+        vset<T>(p, v, acc);
+        vset<T>(r, v, vget<T>(c.y, v) - acc);                                        // ORIGINAL target - predictions (ls.py:239)
     }
     T *pred = static_cast<T *>(a.pred);
     T *resid = static_cast<T *>(a.resid);
     if (row0 >= s && row0 + VEC <= e) {
-        if (pred) {
-            V o;
-            if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
-            *reinterpret_cast<V *>(pred + row0) = o;
-        }
-        if (resid) {
-            V o;
-            if constexpr (VEC == 4) o = V{c.y[0] - p[0], c.y[1] - p[1], c.y[2] - p[2], c.y[3] - p[3]};
-            else o = V{c.y[0] - p[0], c.y[1] - p[1]};
-            *reinterpret_cast<V *>(resid + row0) = o;
-        }
+        if (pred) *reinterpret_cast<V *>(pred + row0) = p;
+        if (resid) *reinterpret_cast<V *>(resid + row0) = r;
     } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            const int64_t r = row0 + v;
-            if (r >= s && r < e) {
-                if (pred) pred[r] = p[v];
-                if (resid) resid[r] = c.y[v] - p[v];   // ORIGINAL target - predictions (ls.py:239)
+            const int64_t rr = row0 + v;
+            if (rr >= s && rr < e) {
+                if (pred) pred[rr] = vget<T>(p, v);
+                if (resid) resid[rr] = vget<T>(r, v);
             }
         }
     }
@@ -160,7 +172,7 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 
 // TEAM = 64: four independent waves per 256-thread block, one group each, no LDS, no barriers.
 // TEAM = 256: one group per block; cross-wave reduction through LDS with ONE barrier.
-template <typename T, int KT, int TEAM, int RC>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
@@ -176,114 +188,130 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     const int64_t base = s - (s % VEC);                      // chunk grid is aligned to 16 bytes in every column
     const int64_t nch = (e - base + VEC - 1) / VEC;
 
-    Chunk<T, KT> res[RC];                                    // register-resident rows of this lane
     T acc[NACC];
 #pragma unroll
     for (int q = 0; q < NACC; ++q) acc[q] = T(0);
 
+    // rows beyond register capacity are streamed (Gram pass now, prediction pass at the end); done BEFORE the
+    // resident chunks are loaded so the two never share registers
+    for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
+        Chunk<T, KT, HAS_W> tmp;
+        load_chunk<T, KT, HAS_W>(a, base + c * VEC, s, e, tmp);
+        gram_accumulate<T, KT, HAS_W>(acc, tmp);
+    }
+    Chunk<T, KT, HAS_W> res[RC];                             // register-resident rows of this lane
 #pragma unroll
     for (int rc = 0; rc < RC; ++rc) {
         const int64_t c = (int64_t)rc * TEAM + tid;
         if (c < nch) {
-            load_chunk<T, KT>(a, base + c * VEC, s, e, res[rc]);
-            gram_accumulate<T, KT>(acc, res[rc]);
+            load_chunk<T, KT, HAS_W>(a, base + c * VEC, s, e, res[rc]);
+            gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
         }
-    }
-    for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {   // rows beyond register capacity: streamed
-        Chunk<T, KT> tmp;
-        load_chunk<T, KT>(a, base + c * VEC, s, e, tmp);
-        gram_accumulate<T, KT>(acc, tmp);
     }
 
-    // ---- team reduction, fixed order (deterministic)
+    // ---- team reduction, fixed order (deterministic): reduce-scatter inside each wave, partials through LDS
+    constexpr int NACC4 = (NACC + 3) / 4;
+    constexpr int SLOTS = NACC4 * 4;                         // accumulator slots, padded to a multiple of 4
+    __shared__ __attribute__((aligned(16))) T part[(256 / TEAM) * (SLOTS * WAVES + 16)];
+    T *mypart = part + (threadIdx.x / TEAM) * (SLOTS * WAVES + 16);   // one region per team
+    T *bcast = mypart + SLOTS * WAVES;                       // beta broadcast, 16 slots
+    {
+        T u[NACC4];
+        wave_reduce_scatter<T, NACC>(acc, u);
+        const int row = lane >> 4;
+        const int pr = (row == 1) ? 2 : ((row == 2) ? 1 : row);
+        if ((lane & 15) == 0) {
 #pragma unroll
-    for (int q = 0; q < NACC; ++q) acc[q] = wave_sum_row3(acc[q]);
-    if constexpr (WAVES == 1) {
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) acc[q] = readlane63(acc[q]);
-    } else {
-        __shared__ T part[NACC * WAVES];
-        if (lane == 63) {
-#pragma unroll
-            for (int q = 0; q < NACC; ++q) part[q * WAVES + wave] = acc[q];
+            for (int i = 0; i < NACC4; ++i) mypart[(4 * i + pr) * WAVES + wave] = u[i];
         }
-        __syncthreads();
+    }
+    if constexpr (WAVES > 1) __syncthreads();
+
+    // ---- K x K solve on wave-uniform values: ONE wave per team solves (the others would only burn the
+    // SIMDs' VALU issue slots that co-resident workgroups need), beta goes back through LDS
+    T beta[KT];
+    if (wave == 0) {
 #pragma unroll
         for (int q = 0; q < NACC; ++q) {
-            T t = part[q * WAVES];
+            T t = mypart[q * WAVES];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) t += part[q * WAVES + w];
+            for (int w = 1; w < WAVES; ++w) t += mypart[q * WAVES + w];
             acc[q] = t;
+        }
+        int st = POLS_GROUP_OK;
+        if (e == s) {                       // features.is_empty() -> zeros (ex.rs:357-359)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) beta[j] = T(0);
+            st = POLS_GROUP_EMPTY;
+        } else {
+            const bool ok = chol_solve<T, KT>(acc, (T)a.alpha, beta);
+            if (!ok) st = POLS_GROUP_FALLBACK;   // host re-dispatches this group to the fallback solver
+        }
+        if (tid == 0 && a.status) a.status[g] = st;
+        if (tid < KT) {
+            T bv = T(0);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) bv = (tid == j) ? beta[j] : bv;
+            if (a.coef) static_cast<T *>(a.coef)[g * KT + tid] = bv;
+            if constexpr (WAVES > 1) bcast[tid] = bv;
+        }
+    }
+    if constexpr (WAVES > 1) {
+        __syncthreads();
+        if (wave != 0) {
+#pragma unroll
+            for (int j = 0; j < KT; ++j) beta[j] = bcast[j];
         }
     }
 
-    // ---- K x K solve on wave-uniform values
-    T beta[KT];
-    int st = POLS_GROUP_OK;
-    if (e == s) {                       // features.is_empty() -> zeros (ex.rs:357-359)
-#pragma unroll
-        for (int j = 0; j < KT; ++j) beta[j] = T(0);
-        st = POLS_GROUP_EMPTY;
-    } else {
-        const bool ok = chol_solve<T, KT>(acc, (T)a.alpha, beta);
-        if (!ok) st = POLS_GROUP_FALLBACK;   // host re-dispatches this group to the fallback solver
-    }
-    if (tid == 0 && a.status) a.status[g] = st;
-    if (a.coef && tid < KT) {
-        T bv = T(0);
-#pragma unroll
-        for (int j = 0; j < KT; ++j) bv = (tid == j) ? beta[j] : bv;
-        static_cast<T *>(a.coef)[g * KT + tid] = bv;
-    }
-
-    // ---- fused predictions / residuals from the resident rows
+    // ---- fused predictions / residuals from the resident rows, then the streamed overflow rows
     if (a.pred || a.resid) {
 #pragma unroll
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
-            if (c < nch) predict_store<T, KT>(a, res[rc], beta, base + c * VEC, s, e);
+            if (c < nch) predict_store<T, KT, HAS_W>(a, res[rc], beta, base + c * VEC, s, e);
         }
         for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
-            Chunk<T, KT> tmp;
-            load_chunk<T, KT>(a, base + c * VEC, s, e, tmp);
-            predict_store<T, KT>(a, tmp, beta, base + c * VEC, s, e);
+            Chunk<T, KT, HAS_W> tmp;
+            load_chunk<T, KT, HAS_W>(a, base + c * VEC, s, e, tmp);
+            predict_store<T, KT, HAS_W>(a, tmp, beta, base + c * VEC, s, e);
         }
     }
 }
 
-template <typename T, int KT, int TEAM, int RC>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC>
 static int k1_launch_variant(pols_ctx *ctx, const K1Args &a) {
     char name[96];
-    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d_team%d_rc%d", sizeof(T) == 4 ? "f32" : "f64", KT, TEAM, RC);
+    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d", sizeof(T) == 4 ? "f32" : "f64", KT,
+                  HAS_W ? "_w" : "", TEAM, RC);
     const int64_t teams_per_block = 256 / TEAM;
     const int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     ctx->last_kernel = name;
     timing_begin(ctx);
-    hipLaunchKernelGGL((k1_kernel<T, KT, TEAM, RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
 
-#define K1_VARIANT(T, TN, KT, TEAM, RC) k1_launch_variant<T, KT, TEAM, RC>(ctx, a)
-
 // Variant choice: smallest team whose registers hold the largest group (so X is read once); groups
 // larger than the biggest variant stream their overflow rows twice (Gram pass + prediction pass).
+template <typename T, int KT, bool HAS_W>
+static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
+    constexpr int VEC = Vec16<T>::N;
+    if (max_rows <= 64 * 2 * VEC) return k1_launch_variant<T, KT, HAS_W, 64, 2>(ctx, a);
+    if constexpr (sizeof(T) == 4) {
+        if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a);
+        return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a);
+    } else {
+        return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a);
+    }
+}
+
 template <typename T, int KT>
 static int k1_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
-    constexpr int VEC = Vec16<T>::N;
-    constexpr const char *TN = (sizeof(T) == 4) ? "f32" : "f64";
-    (void)TN;
-    if (max_rows <= 64 * 2 * VEC) {
-        if constexpr (sizeof(T) == 4) return K1_VARIANT(T, "f32", KT, 64, 2); else return K1_VARIANT(T, "f64", KT, 64, 2);
-    }
-    if constexpr (sizeof(T) == 4) {
-        if (max_rows <= 256 * 1 * VEC) return K1_VARIANT(T, "f32", KT, 256, 1);
-        return K1_VARIANT(T, "f32", KT, 256, 2);
-    } else {
-        return K1_VARIANT(T, "f64", KT, 256, 2);
-    }
+    return a.w ? k1_launch_kw<T, KT, true>(ctx, a, max_rows) : k1_launch_kw<T, KT, false>(ctx, a, max_rows);
 }
 
 template <typename T>

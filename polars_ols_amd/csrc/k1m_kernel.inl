@@ -6,11 +6,15 @@
 //             round trip), laid out column-major with a column stride of 16 B x odd so that both the MFMA
 //             operand reads (lane = (column, row-quad)) and the row-parallel prediction reads are
 //             bank-conflict free.
-//   gram    : Z^T Z for Z = [sqrt(w) X | 1 | sqrt(w) y] as a 16 x 16 tile on the matrix cores:
+//   prep    : rows of the tile outside the group (alignment head, 8-row tail pad) are zeroed; with sample
+//             weights every column is scaled by sqrt(w) in place (least_squares.py:190-196), so the Gram
+//             loop needs no masks, selects or multiplies.
+//   gram    : Z^T Z for Z = [sqrt(w) X | sqrt(w) 1 | sqrt(w) y] as a 16 x 16 tile on the matrix cores:
 //             v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 with A = B = one LDS value per lane (lane l feeds
-//             Z[row 4t + (l >> 4)][column l & 15]); each wave takes every 4th 8-row step, two accumulators
-//             hide the dependent-issue latency; partial tiles are summed across the 4 waves through LDS in a
-//             fixed order.  Accumulator cost: 8 VGPRs instead of the (k+1)(k+2)/2 of the VALU form.
+//             Z[row 4t + (l >> 4)][column l & 15]).  Each wave owns a contiguous quarter of the 8-row steps;
+//             the loop body is ONE ds_read_b64 + TWO MFMAs per step (lanes of the unused tile columns read a
+//             block of zeros, the intercept lanes a block of ones), two accumulators hide the dependent-issue
+//             latency.  Partial tiles are summed across the 4 waves through LDS in a fixed order.
 //   solve   : every lane runs the unrolled K x K Cholesky + triangular solves on wave-uniform values.
 //   predict : X . beta from the LDS-resident tile, 16-byte coalesced stores.  X is read from HBM once.
 #include "k1_kernel.inl"
@@ -47,7 +51,9 @@ static inline int k1m_row_stride(int64_t max_rows) {
     return (int)(units * VEC);
 }
 
-template <typename T, int KT>
+constexpr int K1M_CONST_ELEMS = 32;  // zeros block + ones block: 32 elements each (>= one 4-step batch of reads)
+
+template <typename T, int KT, bool HAS_W>
 __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, const int ncols) {
     using V = typename Vec16<T>::type;
     using M = Mfma16<T>;
@@ -61,6 +67,8 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *tile = reinterpret_cast<T *>(smem);                 // [ncols][rs]: x_0..x_{ku-1}, y, (w)
     T *part = tile + (size_t)ncols * rs;                   // [4 waves][4 regs][64 lanes]; wave 0's slab later holds the sum
+    T *zeros = part + 4 * 4 * 64;                          // K1M_CONST_ELEMS zeros, then K1M_CONST_ELEMS ones
+    T *ones = zeros + K1M_CONST_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,9 +77,12 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
     const int64_t base = s - (s % VEC);
     const int head = (int)(s - base);
     const int span = (int)(e - base);                      // tile rows [head, span) belong to the group
+    const int span8 = (span + 7) & ~7;
     const int ku = a.k_user;
-    const bool has_w = a.w != nullptr;
     const bool icpt = ku != KT;
+    unsigned long long *dbg = a.dbg ? a.dbg + g * 8 : nullptr;
+#define K1M_STAMP(i) do { if (dbg && tid == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    K1M_STAMP(0);
 
     // ---- stage: HBM -> LDS, one 1 KiB piece per wave-instruction
     const int ppc = (span + RPP - 1) / RPP;
@@ -92,42 +103,91 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
             }
         }
     }
+    if (tid < 2 * K1M_CONST_ELEMS) zeros[tid] = (tid < K1M_CONST_ELEMS) ? T(0) : T(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    K1M_STAMP(1);
 
-    if (has_w) {  // w <- sqrt(w) once (sqrt_w of least_squares.py:193); NaN for w < 0 propagates like the reference
+    // ---- prep: zero the rows outside [head, span); with weights scale every column by sqrt(w) in place
+    if constexpr (HAS_W) {
         T *wc = tile + (size_t)(ku + 1) * rs;
-        for (int r = tid; r < span; r += 256) wc[r] = sqrt(wc[r]);
-        __syncthreads();
-    }
-
-    // ---- Gram on the matrix cores
-    const int zc = lane & 15, kq = lane >> 4;
-    const bool z_real = (zc < ku) || (zc == KT);
-    const bool z_one = icpt && (zc == KT - 1);
-    const T *zcol = tile + (size_t)(zc < ku ? zc : ku) * rs;
-    const T *wcol = tile + (size_t)(ku + 1) * rs;
-    acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int t = wave * 8; t < span; t += 32) {
-        int r0, r1;
-        T v0, v1, w0 = T(1), w1 = T(1);
-        if constexpr (sizeof(T) == 4) {   // one ds_read_b64: rows t + 2kq, t + 2kq + 1
-            r0 = t + 2 * kq; r1 = r0 + 1;
-            const float2 vv = *reinterpret_cast<const float2 *>(zcol + r0);
-            v0 = vv.x; v1 = vv.y;
-            if (has_w) { const float2 ww = *reinterpret_cast<const float2 *>(wcol + r0); w0 = ww.x; w1 = ww.y; }
-        } else {                          // two ds_read_b64: rows t + kq, t + 4 + kq
-            r0 = t + kq; r1 = r0 + 4;
-            v0 = zcol[r0]; v1 = zcol[r1];
-            if (has_w) { w0 = wcol[r0]; w1 = wcol[r1]; }
+        for (int row0 = tid * VEC; row0 < span8; row0 += 256 * VEC) {
+            V wv = *reinterpret_cast<V *>(wc + row0);
+            T sw[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int r = row0 + v;
+                sw[v] = (r >= head && r < span) ? sqrt(vget<T>(wv, v)) : T(0);   // NaN for w < 0, like the reference
+            }
+            if constexpr (VEC == 4) wv = V{sw[0], sw[1], sw[2], sw[3]}; else wv = V{sw[0], sw[1]};
+            *reinterpret_cast<V *>(wc + row0) = wv;
+            for (int c = 0; c <= ku; ++c) {
+                V xv = *reinterpret_cast<V *>(tile + (size_t)c * rs + row0);
+                T t[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const int r = row0 + v;
+                    t[v] = (r >= head && r < span) ? vget<T>(xv, v) * sw[v] : T(0);
+                }
+                if constexpr (VEC == 4) xv = V{t[0], t[1], t[2], t[3]}; else xv = V{t[0], t[1]};
+                *reinterpret_cast<V *>(tile + (size_t)c * rs + row0) = xv;
+            }
         }
-        const bool in0 = (r0 >= head) && (r0 < span), in1 = (r1 >= head) && (r1 < span);
-        const T a0 = in0 ? (z_one ? w0 : (z_real ? v0 * w0 : T(0))) : T(0);
-        const T a1 = in1 ? (z_one ? w1 : (z_real ? v1 * w1 : T(0))) : T(0);
-        acc0 = M::mma(a0, a0, acc0);
-        acc1 = M::mma(a1, a1, acc1);
+    } else {
+        const int npad = head + (span8 - span);            // < 4 + 8 rows
+        for (int i = tid; i < npad * ncols; i += 256) {
+            const int c = i / npad, k = i - c * npad;
+            const int r = (k < head) ? k : span + (k - head);
+            tile[(size_t)c * rs + r] = T(0);
+        }
+    }
+    __syncthreads();
+
+    // ---- Gram on the matrix cores: per step one ds_read_b64 (two rows of this lane's column) + two MFMAs
+    const int zc = lane & 15, kq = lane >> 4;
+    const int rlane = (sizeof(T) == 4) ? 2 * kq : kq;
+    const int nsteps = span8 >> 3;
+    const int per_wave = (nsteps + 3) >> 2;
+    const int t_begin = min(nsteps, wave * per_wave), t_end = min(nsteps, t_begin + per_wave);
+    const T *zp;      // this lane's operand stream
+    int zinc;         // elements per 8-row step: 8 for tile columns, 0 for the constant blocks
+    if (zc < ku) { zp = tile + (size_t)zc * rs + t_begin * 8 + rlane; zinc = 8; }
+    else if (zc == KT) { zp = tile + (size_t)ku * rs + t_begin * 8 + rlane; zinc = 8; }                       // y
+    else if (icpt && zc == KT - 1) {
+        if constexpr (HAS_W) { zp = tile + (size_t)(ku + 1) * rs + t_begin * 8 + rlane; zinc = 8; }          // sqrt(w) * 1
+        else { zp = ones; zinc = 0; }
+    } else { zp = zeros; zinc = 0; }
+    acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    int n = t_end - t_begin;
+    for (; n >= 4; n -= 4) {
+        T v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (sizeof(T) == 4) {
+                const float2 vv = *reinterpret_cast<const float2 *>(zp + u * 8);   // rows r, r + 1
+                v0[u] = vv.x; v1[u] = vv.y;
+            } else {
+                v0[u] = zp[u * 8]; v1[u] = zp[u * 8 + 4];                          // rows r, r + 4
+            }
+        }
+        // constant-block lanes keep re-reading the same 4 steps' worth of zeros / ones (zinc == 0)
+        zp += 4 * zinc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc0 = M::mma(v0[u], v0[u], acc0);
+            acc1 = M::mma(v1[u], v1[u], acc1);
+        }
+    }
+    for (; n > 0; --n) {
+        T v0, v1;
+        if constexpr (sizeof(T) == 4) { const float2 vv = *reinterpret_cast<const float2 *>(zp); v0 = vv.x; v1 = vv.y; }
+        else { v0 = zp[0]; v1 = zp[4]; }
+        zp += zinc;
+        acc0 = M::mma(v0, v0, acc0);
+        acc1 = M::mma(v1, v1, acc1);
     }
     acc0 += acc1;
+    K1M_STAMP(2);
 
     // ---- cross-wave sum, fixed order: waves 1..3 publish, wave 0 adds them to its own tile
     if (wave != 0) {
@@ -145,6 +205,7 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
         }
     }
     __syncthreads();
+    K1M_STAMP(3);
 
     // ---- K x K solve (every lane, wave-uniform values)
     T gacc[NACC];
@@ -152,6 +213,10 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
     for (int i = 0; i < NZ; ++i)
 #pragma unroll
         for (int j = i; j < NZ; ++j) gacc[tri_index<NZ>(i, j)] = part[M::slot(i, j)];
+    if constexpr (!HAS_W) {
+        // the ones block also fed the pad rows (where every other column is zero): only sum(1*1) is off
+        if (icpt) gacc[tri_index<NZ>(KT - 1, KT - 1)] = (T)(span - head);
+    }
     T beta[KT];
     int st = POLS_GROUP_OK;
     if (e == s) {
@@ -169,15 +234,17 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
         for (int j = 0; j < KT; ++j) bv = (tid == j) ? beta[j] : bv;
         static_cast<T *>(a.coef)[g * KT + tid] = bv;
     }
+    K1M_STAMP(4);
 
-    // ---- predictions / residuals from the LDS tile
+    // ---- predictions / residuals from the LDS tile (already sqrt(w)-scaled when HAS_W)
     if (a.pred || a.resid) {
         T *pred = static_cast<T *>(a.pred);
         T *resid = static_cast<T *>(a.resid);
         const T *ycol = tile + (size_t)ku * rs;
+        const T *wcol = tile + (size_t)(ku + 1) * rs;
         for (int row0 = tid * VEC; row0 < span; row0 += 256 * VEC) {
-            T p[VEC], sw[VEC];
-            if (has_w) {
+            T p[VEC], sw[VEC], yo[VEC];
+            if constexpr (HAS_W) {
                 const V wv = *reinterpret_cast<const V *>(wcol + row0);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) sw[v] = vget<T>(wv, v);
@@ -192,18 +259,31 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
                 if (j < ku) {
                     const V xv = *reinterpret_cast<const V *>(tile + (size_t)j * rs + row0);
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) p[v] = fma(vget<T>(xv, v) * sw[v], beta[j], p[v]);
+                    for (int v = 0; v < VEC; ++v) p[v] = fma(vget<T>(xv, v), beta[j], p[v]);
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) p[v] = fma(sw[v], beta[j], p[v]);   // intercept column (ones * sqrt_w)
                 }
             }
-            if (has_w) {
+            if constexpr (HAS_W) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) p[v] *= T(1) / sw[v];                  // least_squares.py:234-235
             }
-            const V yv = *reinterpret_cast<const V *>(ycol + row0);
-            if (row0 >= head && row0 + VEC <= span) {
+            const bool full = (row0 >= head) && (row0 + VEC <= span);
+            if (resid) {   // residuals use the ORIGINAL target (least_squares.py:239); the tile's y is scaled when HAS_W
+                if constexpr (HAS_W) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const int r = row0 + v;
+                        yo[v] = (r >= head && r < span) ? static_cast<const T *>(a.y)[base + r] : T(0);
+                    }
+                } else {
+                    const V yv = *reinterpret_cast<const V *>(ycol + row0);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) yo[v] = vget<T>(yv, v);
+                }
+            }
+            if (full) {
                 if (pred) {
                     V o;
                     if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
@@ -211,8 +291,8 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
                 }
                 if (resid) {
                     V o;
-                    if constexpr (VEC == 4) o = V{yv.x - p[0], yv.y - p[1], yv.z - p[2], yv.w - p[3]};
-                    else o = V{yv.x - p[0], yv.y - p[1]};
+                    if constexpr (VEC == 4) o = V{yo[0] - p[0], yo[1] - p[1], yo[2] - p[2], yo[3] - p[3]};
+                    else o = V{yo[0] - p[0], yo[1] - p[1]};
                     *reinterpret_cast<V *>(resid + base + row0) = o;
                 }
             } else {
@@ -221,38 +301,59 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
                     const int r = row0 + v;
                     if (r >= head && r < span) {
                         if (pred) pred[base + r] = p[v];
-                        if (resid) resid[base + r] = vget<T>(yv, v) - p[v];
+                        if (resid) resid[base + r] = yo[v] - p[v];
                     }
                 }
             }
         }
     }
+    K1M_STAMP(5);
+    if (dbg && tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dbg[6] = xcc;
+    }
+#undef K1M_STAMP
 }
 
 template <typename T>
 static inline size_t k1m_lds_bytes(int rs, int ncols) {
-    return sizeof(T) * ((size_t)ncols * rs + 4 * 4 * 64);
+    return sizeof(T) * ((size_t)ncols * rs + 4 * 4 * 64 + 2 * K1M_CONST_ELEMS);
 }
 
-template <typename T, int KT>
-static int k1m_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
-    const int ncols = a.k_user + 1 + (a.w ? 1 : 0);
+template <typename T, int KT, bool HAS_W>
+static int k1m_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
+    const int ncols = a.k_user + 1 + (HAS_W ? 1 : 0);
     const int rs = k1m_row_stride<T>(max_rows);
     const size_t lds = k1m_lds_bytes<T>(rs, ncols);
     static bool attr_set = false;
     if (!attr_set) {
-        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1m_kernel<T, KT>),
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1m_kernel<T, KT, HAS_W>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     char name[96];
-    std::snprintf(name, sizeof(name), "k1m_gram_mfma_%s_k%d_lds%zu", sizeof(T) == 4 ? "f32" : "f64", KT, lds);
+    std::snprintf(name, sizeof(name), "k1m_gram_mfma_%s_k%d%s_lds%zu", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", lds);
     ctx->last_kernel = name;
+    K1Args aa = a;
+    const bool timeline = std::getenv("POLS_TIMELINE") != nullptr;
+    if (timeline) {
+        void *d = nullptr;
+        int rc = ensure_scratch(ctx, 3, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);
+        if (rc) return rc;
+        aa.dbg = static_cast<unsigned long long *>(d);
+    }
     timing_begin(ctx);
-    hipLaunchKernelGGL((k1m_kernel<T, KT>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols);
+    hipLaunchKernelGGL((k1m_kernel<T, KT, HAS_W>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, aa, rs, ncols);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
+    if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
     return POLS_OK;
+}
+
+template <typename T, int KT>
+static int k1m_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
+    return a.w ? k1m_launch_kw<T, KT, true>(ctx, a, max_rows) : k1m_launch_kw<T, KT, false>(ctx, a, max_rows);
 }
 
 // true when the largest group's tile fits the 160 KiB LDS of a CU
