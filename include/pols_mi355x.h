@@ -85,8 +85,11 @@ const char *pols_last_error(void);
 /* device_id: HIP ordinal.  Creates a private non-blocking stream. */
 int pols_create(int device_id, pols_ctx **out);
 void pols_destroy(pols_ctx *ctx);
-/* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the private one. */
+/* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream).  The handle is used as
+ * given: NULL is HIP's null (legacy default) stream -- which is what torch's default stream is.
+ * pols_use_private_stream() goes back to the context's own stream. */
 int pols_set_stream(pols_ctx *ctx, void *hip_stream);
+int pols_use_private_stream(pols_ctx *ctx);
 int pols_synchronize(pols_ctx *ctx);
 /* Kernel timing with HIP events on the context's stream (used by bench.py's roofline leg).
  * While enabled every compute entry brackets its dominant kernel with an event pair. */

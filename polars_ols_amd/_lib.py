@@ -67,6 +67,7 @@ class Out(C.Structure):
 
 EXPORTS = [
     "pols_device_count", "pols_version", "pols_last_error", "pols_create", "pols_destroy", "pols_set_stream",
+    "pols_use_private_stream",
     "pols_synchronize", "pols_timing_enable", "pols_timing_collect", "pols_last_kernel_name",
     "pols_ols_params_default", "pols_rls_params_default", "pols_rolling_params_default",
     "pols_least_squares", "pols_recursive_least_squares", "pols_rolling_least_squares", "pols_predict",
@@ -102,6 +103,7 @@ def lib() -> C.CDLL:
         L.pols_destroy.argtypes = [C.c_void_p]
         L.pols_destroy.restype = None
         L.pols_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.pols_use_private_stream.argtypes = [C.c_void_p]
         L.pols_synchronize.argtypes = [C.c_void_p]
         L.pols_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.pols_timing_collect.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]

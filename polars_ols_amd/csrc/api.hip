@@ -45,9 +45,10 @@ int ensure_scratch(pols_ctx *ctx, int slot, size_t bytes, void **out) {
 int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const int64_t **d_offs, int64_t *max_rows) {
     // cheap content hash so steady-state calls on the same frame skip the re-upload
     uint64_t sum = 1469598103934665603ULL;
-    int64_t mx = 0;
+    int64_t mx = 0, ored = 0;
     for (int64_t g = 0; g <= n_groups; ++g) {
         sum = (sum ^ (uint64_t)offs[g]) * 1099511628211ULL;
+        ored |= offs[g];
         if (g > 0) {
             const int64_t d = offs[g] - offs[g - 1];
             if (d < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending (offsets[%lld] < offsets[%lld])", (long long)g, (long long)(g - 1));
@@ -66,6 +67,8 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
         ctx->offs_sum = sum;
         ctx->offs_max_rows = mx;
     }
+    ctx->offs_aligned[0] = (ored & 1) == 0;
+    ctx->offs_aligned[1] = (ored & 3) == 0;
     *d_offs = static_cast<const int64_t *>(ctx->scratch[0].ptr);
     *max_rows = mx;
     return POLS_OK;
@@ -235,7 +238,13 @@ void pols_destroy(pols_ctx *ctx) {
 
 int pols_set_stream(pols_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL == HIP's null stream (torch's default stream)
+    return POLS_OK;
+}
+
+int pols_use_private_stream(pols_ctx *ctx) {
+    if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
+    ctx->stream = ctx->own_stream;
     return POLS_OK;
 }
 

@@ -29,12 +29,12 @@ template <> __device__ __forceinline__ void vset<float>(float4 &v, int i, float 
 }
 template <> __device__ __forceinline__ void vset<double>(double2 &v, int i, double x) { if (i == 0) v.x = x; else v.y = x; }
 
-template <typename T, int KT, bool HAS_W>
+template <typename T, int KT, bool HAS_W, bool FAST>
 __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_t s, int64_t e, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
     const int ku = a.k_user;
-    if (row0 >= s && row0 + VEC <= e) {
+    if (FAST || (row0 >= s && row0 + VEC <= e)) {
         // whole chunk inside the group: 16-byte loads, all issued before first use
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 
     return ok;
 }
 
-template <typename T, int KT, bool HAS_W>
+template <typename T, int KT, bool HAS_W, bool FAST>
 __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT, HAS_W> &c, const T (&beta)[KT],
                                               int64_t row0, int64_t s, int64_t e) {
     using V = typename Vec16<T>::type;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
     }
     T *pred = static_cast<T *>(a.pred);
     T *resid = static_cast<T *>(a.resid);
-    if (row0 >= s && row0 + VEC <= e) {
+    if (FAST || (row0 >= s && row0 + VEC <= e)) {
         if (pred) *reinterpret_cast<V *>(pred + row0) = p;
         if (resid) *reinterpret_cast<V *>(resid + row0) = r;
     } else {
@@ -172,7 +172,9 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 
 // TEAM = 64: four independent waves per 256-thread block, one group each, no LDS, no barriers.
 // TEAM = 256: one group per block; cross-wave reduction through LDS with ONE barrier.
-template <typename T, int KT, bool HAS_W, int TEAM, int RC>
+// FAST: the host verified that every group starts on a 16-byte boundary, has a multiple of VEC rows and fits
+// the RC * TEAM resident chunks -> no ragged-edge and no overflow code (fewer VGPRs, more groups in flight).
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
@@ -194,20 +196,27 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 
     // rows beyond register capacity are streamed (Gram pass now, prediction pass at the end); done BEFORE the
     // resident chunks are loaded so the two never share registers
-    for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
-        Chunk<T, KT, HAS_W> tmp;
-        load_chunk<T, KT, HAS_W>(a, base + c * VEC, s, e, tmp);
-        gram_accumulate<T, KT, HAS_W>(acc, tmp);
+    unsigned long long *dbg = a.dbg ? a.dbg + g * 8 : nullptr;
+#define K1_STAMP(i) do { if (dbg && tid == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    K1_STAMP(0);
+    if constexpr (!FAST) {
+        for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
+            Chunk<T, KT, HAS_W> tmp;
+            load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, tmp);
+            gram_accumulate<T, KT, HAS_W>(acc, tmp);
+        }
     }
     Chunk<T, KT, HAS_W> res[RC];                             // register-resident rows of this lane
 #pragma unroll
     for (int rc = 0; rc < RC; ++rc) {
         const int64_t c = (int64_t)rc * TEAM + tid;
         if (c < nch) {
-            load_chunk<T, KT, HAS_W>(a, base + c * VEC, s, e, res[rc]);
+            load_chunk<T, KT, HAS_W, FAST>(a, base + c * VEC, s, e, res[rc]);
+            if (rc == RC - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
             gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
         }
     }
+    K1_STAMP(2);
 
     // ---- team reduction, fixed order (deterministic): reduce-scatter inside each wave, partials through LDS
     constexpr int NACC4 = (NACC + 3) / 4;
@@ -226,6 +235,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
         }
     }
     if constexpr (WAVES > 1) __syncthreads();
+    K1_STAMP(3);
 
     // ---- K x K solve on wave-uniform values: ONE wave per team solves (the others would only burn the
     // SIMDs' VALU issue slots that co-resident workgroups need), beta goes back through LDS
@@ -264,35 +274,59 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
         }
     }
 
+    K1_STAMP(4);
     // ---- fused predictions / residuals from the resident rows, then the streamed overflow rows
     if (a.pred || a.resid) {
 #pragma unroll
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
-            if (c < nch) predict_store<T, KT, HAS_W>(a, res[rc], beta, base + c * VEC, s, e);
+            if (c < nch) predict_store<T, KT, HAS_W, FAST>(a, res[rc], beta, base + c * VEC, s, e);
         }
-        for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
-            Chunk<T, KT, HAS_W> tmp;
-            load_chunk<T, KT, HAS_W>(a, base + c * VEC, s, e, tmp);
-            predict_store<T, KT, HAS_W>(a, tmp, beta, base + c * VEC, s, e);
+        if constexpr (!FAST) {
+            for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
+                Chunk<T, KT, HAS_W> tmp;
+                load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, tmp);
+                predict_store<T, KT, HAS_W, false>(a, tmp, beta, base + c * VEC, s, e);
+            }
         }
     }
+    K1_STAMP(5);
+    if (dbg && tid == 0) dbg[6] = 0;
+#undef K1_STAMP
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC>
-static int k1_launch_variant(pols_ctx *ctx, const K1Args &a) {
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST>
+static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
-    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d", sizeof(T) == 4 ? "f32" : "f64", KT,
-                  HAS_W ? "_w" : "", TEAM, RC);
+    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s", sizeof(T) == 4 ? "f32" : "f64", KT,
+                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "");
     const int64_t teams_per_block = 256 / TEAM;
     const int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     ctx->last_kernel = name;
+    K1Args aa = a;
+    const bool timeline = std::getenv("POLS_TIMELINE") != nullptr && TEAM == 256;
+    if (timeline) {
+        void *d = nullptr;
+        int rc = ensure_scratch(ctx, 3, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);
+        if (rc) return rc;
+        aa.dbg = static_cast<unsigned long long *>(d);
+    }
     timing_begin(ctx);
-    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
+    if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
     return POLS_OK;
+}
+
+template <typename T, int KT, bool HAS_W, int TEAM, int RC>
+static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
+    constexpr int VEC = Vec16<T>::N;
+    // FAST needs every group aligned to the vector width and resident; the offsets scan in upload_offsets() knows
+    const bool fast = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC &&
+                      std::getenv("POLS_K1_NOFAST") == nullptr;
+    return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false>(ctx, a);
 }
 
 // Variant choice: smallest team whose registers hold the largest group (so X is read once); groups
@@ -300,12 +334,12 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a) {
 template <typename T, int KT, bool HAS_W>
 static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
-    if (max_rows <= 64 * 2 * VEC) return k1_launch_variant<T, KT, HAS_W, 64, 2>(ctx, a);
+    if (max_rows <= 64 * 2 * VEC) return k1_launch_variant<T, KT, HAS_W, 64, 2>(ctx, a, max_rows);
     if constexpr (sizeof(T) == 4) {
-        if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a);
-        return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a);
+        if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
+        return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);
     } else {
-        return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a);
+        return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);
     }
 }
 

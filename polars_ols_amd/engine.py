@@ -51,9 +51,13 @@ class Engine:
 
     # ------------------------------------------------------------------ stream / timing
     def set_stream(self, stream_ptr: Optional[int]):
-        """Pin the HIP stream every launch goes to (None: back to following torch's current stream)."""
+        """Pin the HIP stream every launch goes to (0 = HIP's null stream); None: back to following torch's
+        current stream for torch inputs (host-buffer calls use the context's private stream)."""
         self._follow_torch = stream_ptr is None
-        L.check(self._lib.pols_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        if stream_ptr is None:
+            L.check(self._lib.pols_use_private_stream(self._h))
+        else:
+            L.check(self._lib.pols_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def use_torch_stream(self):
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)

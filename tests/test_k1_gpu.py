@@ -85,7 +85,7 @@ def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, varian
                             want=("coef", "pred", "resid", "status"))
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True)
     _check(out, ref, dtype)
-    assert (variant in eng.last_kernel) if engine_kind == "valu" else eng.last_kernel.startswith("k1m_"), eng.last_kernel
+    assert (variant in eng.last_kernel) if (engine_kind == "valu" or (hi > 4000 and dtype == np.float64)) else eng.last_kernel.startswith("k1m_"), eng.last_kernel
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
