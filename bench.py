@@ -151,6 +151,14 @@ def main() -> None:
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         bytes_per_launch = algorithmic_bytes_per_group(ROWS, FEATS, itemsize) * GROUPS
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their own runs,
+        # gfx950 correction applied) for this exact kernel + workload; committed under profiles/.  null if absent.
+        traffic = None
+        try:
+            pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+            traffic = pmc.get(eng.last_kernel, {}).get("traffic_bytes")
+        except Exception:
+            traffic = None
         line = {
             "metric": "group_regressions_per_sec", "value": value, "unit": "regressions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -161,7 +169,7 @@ def main() -> None:
                        "sharding": "groups" if world > 1 else "none",
                        "collective": "all_gather(coefficients) overlapped" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": eng.last_kernel,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": eng.last_kernel,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -305,7 +305,7 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     if (blocks > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     ctx->last_kernel = name;
     K1Args aa = a;
-    const bool timeline = std::getenv("POLS_TIMELINE") != nullptr && TEAM == 256;
+    const bool timeline = std::getenv("POLS_TIMELINE") != nullptr;
     if (timeline) {
         void *d = nullptr;
         int rc = ensure_scratch(ctx, 3, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);
@@ -336,6 +336,12 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
     if (max_rows <= 64 * 2 * VEC) return k1_launch_variant<T, KT, HAS_W, 64, 2>(ctx, a, max_rows);
     if constexpr (sizeof(T) == 4) {
+        // wave-per-group with 16 rows per lane: no LDS, no barriers, one reduction + one solve per group and
+        // twice the groups in flight per CU (2 waves/SIMD x 4 SIMDs = 8) -- POLS_K1_SHAPE=team forces 256 threads
+        const char *shape = std::getenv("POLS_K1_SHAPE");
+        const bool want_wave = !(shape && !std::strcmp(shape, "team"));
+        if (want_wave && max_rows <= 64 * 4 * VEC && ctx->offs_aligned[1])
+            return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);
     } else {
