@@ -6,6 +6,7 @@
 
 #include "common.hpp"
 #include "k1_gram_chol.hpp"
+#include "k3_rls.hpp"
 
 namespace pols {
 
@@ -358,9 +359,47 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
 }
 
+// Dynamic models share the staging of a batch whose coefficient output has one row per input row.
+static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, const int64_t **d_offs, int64_t *max_rows,
+                            Staged *st) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = check_batch(b, o))) return rc;
+    if (b->add_intercept || b->weights)
+        return fail(POLS_ERR_INVALID, "dynamic models take pre-processed columns: apply sqrt(w) / append the ones column "
+                                      "before the call, exactly like polars_ols/least_squares.py:184-196 does for the plugin");
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, d_offs, max_rows))) return rc;
+    return stage_inputs(ctx, b, b->n_rows, b->n_features, o, st);
+}
+
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o) {
-    (void)ctx; (void)b; (void)p; (void)o;
-    return fail(POLS_ERR_UNSUPPORTED, "RLS kernel (K3) is not built yet");
+    if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
+    const int64_t *d_offs = nullptr;
+    int64_t max_rows = 0;
+    Staged st;
+    int rc = dynamic_prologue(ctx, b, o, &d_offs, &max_rows, &st);
+    if (rc) return rc;
+    if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
+    if (o->resid) return fail(POLS_ERR_INVALID, "rls: residuals are target - predictions in the caller (least_squares.py:239)");
+    K3Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.y = st.y; a.valid = st.valid;
+    for (int j = 0; j < b->n_features; ++j) a.x[j] = st.x[j];
+    a.offs = d_offs;
+    a.n_groups = b->n_groups;
+    a.coef = st.coef; a.pred = st.pred;
+    a.k = b->n_features;
+    a.forgetting_factor = p->has_half_life ? std::exp(std::log(0.5) / p->half_life) : 1.0;   // ls.rs:513-517
+    a.initial_state_covariance = p->initial_state_covariance;
+    if (p->initial_state_mean) {
+        void *d = nullptr;
+        if ((rc = ensure_scratch(ctx, 4, sizeof(double) * POLS_MAX_FEATURES, &d))) return rc;
+        POLS_HIP(hipMemcpyAsync(d, p->initial_state_mean, sizeof(double) * b->n_features, hipMemcpyHostToDevice, ctx->stream));
+        POLS_HIP(hipStreamSynchronize(ctx->stream));   // the host array belongs to the caller
+        a.mean0 = static_cast<const double *>(d);
+    }
+    if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
+    return unstage_outputs(ctx, b, b->n_rows, b->n_features, o, st);
 }
 
 int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o) {

@@ -169,6 +169,38 @@ class Engine:
         ``out`` may carry pre-allocated buffers under the same keys."""
         return self.plan_least_squares(y, x_cols, offsets, **kwargs).run()
 
+    def _dynamic_outputs(self, b, keep, dev, dt, want, out):
+        res: Dict = dict(out or {})
+        yy = keep[0][0]
+        if "coef" in want and "coef" not in res:
+            res["coef"] = self._alloc(dev, dt, (b.n_rows, b.n_features), yy)
+        if "pred" in want and "pred" not in res:
+            res["pred"] = self._alloc(dev, dt, (b.n_rows,), yy)
+        o = L.Out(coef=self._ptr(res.get("coef")), pred=self._ptr(res.get("pred")), resid=None, status=None)
+        return res, o
+
+    def plan_recursive_least_squares(self, y, x_cols: Sequence, offsets, *, valid=None, want: Sequence[str] = ("coef", "pred"),
+                                     out: Optional[Dict] = None, half_life: Optional[float] = None,
+                                     initial_state_covariance: Optional[float] = 10.0, initial_state_mean=None,
+                                     null_policy: str = "drop") -> "Plan":
+        """solve_recursive_least_squares (src/least_squares.rs:568-598) for every group; ``coef`` is n_rows x k."""
+        b, keep, dev, dt = self._batch(y, x_cols, offsets, None, valid, False)
+        res, o = self._dynamic_outputs(b, keep, dev, dt, want, out)
+        p = L.RlsParams()
+        self._lib.pols_rls_params_default(C.byref(p))
+        p.has_half_life = int(half_life is not None)
+        p.half_life = float(half_life) if half_life is not None else 0.0
+        p.initial_state_covariance = float(10.0 if initial_state_covariance is None else initial_state_covariance)
+        mean = None
+        if initial_state_mean is not None:
+            mean = np.ascontiguousarray(np.broadcast_to(np.asarray(initial_state_mean, dtype=np.float64), (b.n_features,)))
+            p.initial_state_mean = mean.ctypes.data_as(C.POINTER(C.c_double))
+        p.null_policy = L.NULL_POLICIES[null_policy]
+        return Plan(self, self._lib.pols_recursive_least_squares, b, p, o, res, (keep, mean))
+
+    def recursive_least_squares(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
+        return self.plan_recursive_least_squares(y, x_cols, offsets, **kwargs).run()
+
 
 class Plan:
     """A marshalled call: ctypes structs + references that keep every borrowed buffer alive."""

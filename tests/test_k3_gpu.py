@@ -1,0 +1,85 @@
+"""GPU parity of K3 (recursive least squares) through the C-ABI against the CPU oracle
+(oracle restates src/least_squares.rs:494-598) and the README's RLS known answers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from polars_ols_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _cuda(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _np(t):
+    return t.double().cpu().numpy() if hasattr(t, "cpu") else np.asarray(t, dtype=np.float64)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k", [1, 2, 6, 8])
+@pytest.mark.parametrize("half_life,p0,mean", [(None, 10.0, None), (21.0, 10.0, None), (252.0, 0.01, 0.25), (None, 1e6, None)])
+def test_rls_many_groups(eng, dtype, tol, k, half_life, p0, mean):
+    from oracle import orc
+
+    rng = np.random.default_rng(k)
+    sizes = rng.integers(1, 400, size=37)
+    sizes[3] = 0                                     # an empty group
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(cols).astype(np.float64) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    valid = (rng.random(N) > 0.1).astype(np.uint8)
+    mean0 = None if mean is None else [mean] * k
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), half_life=half_life,
+                                      initial_state_covariance=p0, initial_state_mean=mean0)
+    ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0,
+                          is_valid=valid)
+    scale = 1.0 if p0 < 1e5 else 50.0               # a diffuse prior makes the first rows ill-conditioned in ANY arithmetic
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol * scale, atol=tol * scale)
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol * scale, atol=tol * scale)
+
+
+def test_rls_readme_known_answer(eng, golden):
+    """README.md:133-137: rls(x1, x2, mode="coefficients").over("group") with the default prior."""
+    from refdata import sort_by_group
+
+    kat = golden["kat"]
+    f = {k: np.asarray(v, dtype=np.float64) for k, v in kat["frame"].items()}
+    order, offs, _ = sort_by_group(f["group"].astype(np.int64))
+    out = eng.recursive_least_squares(f["y"][order], [f["x1"][order], f["x2"][order]], offs, want=("coef",))   # host buffers
+    assert np.allclose(np.round(out["coef"][:5], 6), kat["rls_coefficients_head5"], atol=1.1e-6)
+
+
+def test_rls_expanding_equals_ols_on_golden(eng, golden):
+    """tests/test_ols.py:633-681: expanding RLS with a diffuse prior and nulls ends at the full-sample OLS."""
+    z = golden["npz"]
+    x, y = z["nulls_x"], z["nulls_y"]
+    valid = (~np.isnan(x).any(axis=1) & ~np.isnan(y)).astype(np.uint8)
+    out = eng.recursive_least_squares(np.nan_to_num(y), [np.nan_to_num(x[:, 0]), np.nan_to_num(x[:, 1])], [0, len(y)],
+                                      valid=valid, initial_state_covariance=1e6, want=("coef",))
+    assert np.allclose(out["coef"][-1], z["rls_expanding_last"], rtol=1e-4, atol=1e-4)
+
+
+def test_rls_cfg4_full_size_single_sequence(eng):
+    """BASELINE configs[3]: one sequence of 1 000 000 rows, 6 features, half_life = 21, f64 -- the oracle is a
+    sequential C loop, fast enough to check every row at full size."""
+    from oracle import orc
+
+    rng = np.random.default_rng(4)
+    n, k = 1_000_000, 6
+    cols = [rng.standard_normal(n) for _ in range(k)]
+    y = sum(cols) + 0.1 * rng.standard_normal(n)
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], [0, n], half_life=21.0)
+    ref = orc.batched_rls(y, cols, [0, n], half_life=21.0)
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
