@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "k1_gram_chol.hpp"
 #include "k3_rls.hpp"
+#include "k5_enet.hpp"
 
 namespace pols {
 
@@ -320,7 +321,8 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     const int m = p->solve_method;
     const double alpha = p->alpha;
     const bool positive = p->positive != 0;
-    double ridge_alpha = 0.0;
+    double ridge_alpha = 0.0, enet_l1 = 0.5;
+    bool enet = false;
     if (alpha == 0.0 && !positive && (m == POLS_SOLVE_AUTO || m == POLS_SOLVE_SVD || m == POLS_SOLVE_QR)) {
         ridge_alpha = 0.0;  // solve_ols: QR / SVD least squares == normal-equation solution for full column rank
     } else if (alpha >= 0.0 && (p->has_l1_ratio ? p->l1_ratio : 0.0) == 0.0 && !positive) {
@@ -333,7 +335,8 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         if (!(alpha > 0.0)) return fail(POLS_ERR_PANIC, "'alpha' must be strictly positive");  // ls.rs:409
         const double l1 = p->has_l1_ratio ? p->l1_ratio : 0.5;
         if (!(l1 >= 0.0 && l1 <= 1.0)) return fail(POLS_ERR_PANIC, "'l1_ratio' must be strictly between 0. and 1.");  // ls.rs:410
-        return fail(POLS_ERR_UNSUPPORTED, "elastic-net kernel (K5) is not built yet");
+        enet = true;
+        enet_l1 = l1;
     }
 
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
@@ -343,6 +346,42 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
+
+    if (enet) {
+        // K5: one streaming Gram pass, Gram-form coordinate descent, then (only if asked for) a prediction pass
+        void *scr = nullptr;
+        const size_t nz = (size_t)kt + 1;
+        const size_t gram_bytes = round256(sizeof(double) * nz * nz * (size_t)b->n_groups);
+        const size_t c64_bytes = round256(sizeof(double) * (size_t)kt * (size_t)b->n_groups);
+        if ((rc = ensure_scratch(ctx, 5, gram_bytes + c64_bytes, &scr))) return rc;
+        GramArgs ga;
+        std::memset(&ga, 0, sizeof(ga));
+        ga.y = st.y; ga.w = st.w;
+        for (int j = 0; j < b->n_features; ++j) ga.x[j] = st.x[j];
+        ga.offs = d_offs; ga.n_groups = b->n_groups; ga.n_rows = b->n_rows;
+        ga.gram = static_cast<double *>(scr);
+        ga.k_user = b->n_features; ga.kt = kt;
+        if ((rc = gram_stream_launch(ctx, b->dtype, ga))) return rc;
+        CdArgs ca;
+        std::memset(&ca, 0, sizeof(ca));
+        ca.gram = ga.gram; ca.offs = d_offs; ca.n_groups = b->n_groups;
+        ca.coef = st.coef; ca.coef64 = reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes);
+        ca.status = st.status;
+        ca.alpha = alpha; ca.l1_ratio = enet_l1; ca.tol = p->tol; ca.max_iter = p->max_iter;
+        ca.positive = positive ? 1 : 0; ca.active_set = (m == POLS_SOLVE_CD_ACTIVE_SET) ? 1 : 0; ca.kt = kt;
+        if ((rc = gram_cd_launch(ctx, b->dtype, ca))) return rc;
+        if (st.pred || st.resid) {
+            PredictArgs pa;
+            std::memset(&pa, 0, sizeof(pa));
+            pa.y = st.y; pa.w = st.w;
+            for (int j = 0; j < b->n_features; ++j) pa.x[j] = st.x[j];
+            pa.offs = d_offs; pa.n_groups = b->n_groups; pa.n_rows = b->n_rows;
+            pa.coef64 = ca.coef64; pa.pred = st.pred; pa.resid = st.resid;
+            pa.k_user = b->n_features; pa.kt = kt;
+            if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
+        }
+        return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
+    }
 
     if (kt > K1M_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "%d features (incl. intercept) > %d: the two-tile MFMA Gram is not built yet", kt, K1M_MAX_KT);
     K1Args a;
@@ -408,8 +447,41 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
 }
 
 int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, void *pred_out) {
-    (void)ctx; (void)b; (void)coef; (void)coef_rows; (void)pred_out;
-    return fail(POLS_ERR_UNSUPPORTED, "predict kernel is not built yet");
+    // `predict` plugin body (src/expressions.rs:706-741): sum_j x[t, j] * coef[t, j]; coef in the batch dtype,
+    // coef_rows == n_rows (one coefficient row per input row, what Polars broadcasts the struct to).
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    pols_out o;
+    std::memset(&o, 0, sizeof(o));
+    o.pred = pred_out;
+    if ((rc = check_batch(b, &o))) return rc;
+    if (!coef || !pred_out) return fail(POLS_ERR_INVALID, "coef / pred_out is NULL");
+    if (coef_rows != b->n_rows) return fail(POLS_ERR_INVALID, "number of coefficient rows must match the number of rows");
+    if (b->weights) return fail(POLS_ERR_INVALID, "predict takes no weights");
+    const int kt = b->n_features + (b->add_intercept ? 1 : 0);   // predict adds pl.lit(1.0) for the intercept (ls.py:479-483)
+    if (b->n_rows == 0) return POLS_OK;
+    const int64_t *d_offs = nullptr;
+    int64_t max_rows = 0;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
+    Staged st;
+    if ((rc = stage_inputs(ctx, b, b->n_rows, kt, &o, &st))) return rc;
+    const void *d_coef = coef;
+    if (b->mem == POLS_MEM_HOST) {
+        void *d = nullptr;
+        const size_t bytes = dtype_size(b->dtype) * (size_t)coef_rows * kt;
+        if ((rc = ensure_scratch(ctx, 5, bytes, &d))) return rc;
+        POLS_HIP(hipMemcpyAsync(d, coef, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_coef = d;
+    }
+    PredictArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    for (int j = 0; j < b->n_features; ++j) pa.x[j] = st.x[j];
+    pa.offs = d_offs; pa.n_groups = b->n_groups; pa.n_rows = b->n_rows;
+    pa.coef_rows = d_coef; pa.pred = st.pred;
+    pa.k_user = b->n_features; pa.kt = kt;
+    ctx->last_kernel = "predict";
+    if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
+    return unstage_outputs(ctx, b, b->n_rows, kt, &o, st);
 }
 
 }  // extern "C"

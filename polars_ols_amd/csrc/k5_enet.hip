@@ -1,0 +1,365 @@
+// k5_enet.hip -- K5: streamed MFMA Gram, Gram-form coordinate descent, prediction pass (see k5_enet.hpp).
+#include "k5_enet.hpp"
+#include "k1m_kernel.inl"   // Mfma16, k1m_row_stride, K1M_CONST_ELEMS
+
+namespace pols {
+
+constexpr int KG_CR = 256;   // rows per LDS chunk
+
+// ------------------------------------------------------------------------------------------------ A: gram_stream
+template <typename T, int NT, bool HAS_W>
+__global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, const int rs, const int ncols, const int tile_elems) {
+    using V = typename Vec16<T>::type;
+    using M = Mfma16<T>;
+    using acc_t = typename M::acc_t;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int RPP = 64 * VEC;
+    constexpr int NPAIR = NT * (NT + 1) / 2;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *tile = reinterpret_cast<T *>(smem);          // [ncols][rs]; re-used for the cross-wave partial tiles at the end
+    T *zeros = tile + tile_elems;
+    T *ones = zeros + K1M_CONST_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t base = s - (s % VEC);
+    const int head = (int)(s - base);
+    const int64_t span = e - base;                  // rows [head, span) relative to base belong to the group
+    const int ku = a.k_user, kt = a.kt, NZ = kt + 1;
+    const bool icpt = ku != kt;
+
+    const int zc = lane & 15, kq = lane >> 4;
+    const int rlane = (sizeof(T) == 4) ? 2 * kq : kq;
+    // operand stream of this lane for each 16-column tile of Z
+    int zsrc[NT];      // tile column index, -1 = zeros block, -2 = ones block
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int z = 16 * t + zc;
+        if (z < ku) zsrc[t] = z;
+        else if (icpt && z == kt - 1) zsrc[t] = HAS_W ? ku + 1 : -2;
+        else if (z == kt) zsrc[t] = ku;
+        else zsrc[t] = -1;
+    }
+    const bool need11 = (NT == 2) && (NZ > 17);     // tile (1,1) only carries y'y when k = 16
+
+    acc_t acc[NPAIR][2];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) { acc[p][0] = acc_t{0, 0, 0, 0}; acc[p][1] = acc_t{0, 0, 0, 0}; }
+
+    if (tid < 2 * K1M_CONST_ELEMS) zeros[tid] = (tid < K1M_CONST_ELEMS) ? T(0) : T(1);
+
+    for (int64_t c0 = 0; c0 < span; c0 += KG_CR) {
+        const int rows_here = (int)min((int64_t)KG_CR, span - c0);
+        const int rows8 = (rows_here + 7) & ~7;
+        // ---- stage the chunk: HBM -> LDS
+        const int ppc = (rows_here + RPP - 1) / RPP;
+        for (int p = wave; p < ncols * ppc; p += 4) {
+            const int col = p / ppc, q = p - col * ppc;
+            const T *src = static_cast<const T *>(col < ku ? a.x[col] : (col == ku ? a.y : a.w));
+            const int row0 = q * RPP + lane * VEC;
+            const int64_t grow = base + c0 + row0;
+            T *ldst = tile + (size_t)col * rs + q * RPP;
+            if (row0 < rows_here) {
+                if (grow + VEC <= a.n_rows) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + grow),
+                                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) ldst[lane * VEC + v] = (grow + v < a.n_rows) ? src[grow + v] : T(0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- prep: zero rows outside the group, apply sqrt(w)
+        const int64_t lo = head - c0, hi = span - c0;       // valid chunk rows: lo <= r < hi
+        if constexpr (HAS_W) {
+            T *wc = tile + (size_t)(ku + 1) * rs;
+            for (int row0 = tid * VEC; row0 < rows8; row0 += 256 * VEC) {
+                V wv = *reinterpret_cast<V *>(wc + row0);
+                T sw[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { const int r = row0 + v; sw[v] = (r >= lo && r < hi) ? sqrt(vget<T>(wv, v)) : T(0); }
+                if constexpr (VEC == 4) wv = V{sw[0], sw[1], sw[2], sw[3]}; else wv = V{sw[0], sw[1]};
+                *reinterpret_cast<V *>(wc + row0) = wv;
+                for (int c = 0; c <= ku; ++c) {
+                    V xv = *reinterpret_cast<V *>(tile + (size_t)c * rs + row0);
+                    T t[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { const int r = row0 + v; t[v] = (r >= lo && r < hi) ? vget<T>(xv, v) * sw[v] : T(0); }
+                    if constexpr (VEC == 4) xv = V{t[0], t[1], t[2], t[3]}; else xv = V{t[0], t[1]};
+                    *reinterpret_cast<V *>(tile + (size_t)c * rs + row0) = xv;
+                }
+            }
+        } else {
+            const int nhead = (c0 == 0) ? head : 0;
+            const int ntail = rows8 - rows_here;
+            const int npad = nhead + ntail;
+            for (int i = tid; i < npad * ncols; i += 256) {
+                const int c = i / npad, k = i - c * npad;
+                const int r = (k < nhead) ? k : rows_here + (k - nhead);
+                tile[(size_t)c * rs + r] = T(0);
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: each wave takes a contiguous quarter of this chunk's 8-row steps
+        const int nsteps = rows8 >> 3;
+        const int per_wave = (nsteps + 3) >> 2;
+        const int t_begin = min(nsteps, wave * per_wave), t_end = min(nsteps, t_begin + per_wave);
+        const T *zp[NT];
+        int zinc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (zsrc[t] >= 0) { zp[t] = tile + (size_t)zsrc[t] * rs + t_begin * 8 + rlane; zinc[t] = 8; }
+            else { zp[t] = (zsrc[t] == -2) ? ones : zeros; zinc[t] = 0; }
+        }
+        for (int n = t_end - t_begin; n > 0; --n) {
+            T v0[NT], v1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (sizeof(T) == 4) { const float2 vv = *reinterpret_cast<const float2 *>(zp[t]); v0[t] = vv.x; v1[t] = vv.y; }
+                else { v0[t] = zp[t][0]; v1[t] = zp[t][4]; }
+                zp[t] += zinc[t];
+            }
+            int p = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj, ++p) {
+                    if (ti == 1 && !need11) continue;
+                    acc[p][0] = M::mma(v0[ti], v0[tj], acc[p][0]);
+                    acc[p][1] = M::mma(v1[ti], v1[tj], acc[p][1]);
+                }
+        }
+        __syncthreads();   // the next chunk's DMA overwrites the tile
+    }
+
+    // ---- cross-wave sum (fixed order) and write-out of the (symmetric) Gram matrix in f64
+    T *part = tile;    // [pair][wave][reg * 64 + lane]
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+        const acc_t t = acc[p][0] + acc[p][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(p * 4 + wave) * 256 + r * 64 + lane] = t[r];
+    }
+    __syncthreads();
+    double *G = a.gram + (size_t)g * NZ * NZ;
+    const int r = tid >> 6, l = tid & 63;
+    const int drow = (sizeof(T) == 4) ? (l >> 4) * 4 + r : (l >> 4) + 4 * r;   // C/D layouts of the f32 / f64 16x16x4 MFMA
+    const int dcol = l & 15;
+    int p = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < NT; ++tj, ++p) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)part[(p * 4 + w) * 256 + tid];
+            const int i = 16 * ti + drow, j = 16 * tj + dcol;
+            if (i < NZ && j < NZ) {
+                if (!HAS_W && icpt && i == kt - 1 && j == kt - 1) v = (double)(e - s);   // the ones block also fed pad rows
+                G[i * NZ + j] = v;
+                if (ti != tj) G[j * NZ + i] = v;
+            }
+        }
+}
+
+template <typename T, int NT, bool HAS_W>
+static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
+    const int ncols = a.k_user + 1 + (HAS_W ? 1 : 0);
+    const int rs = k1m_row_stride<T>(KG_CR);
+    const int npair = NT * (NT + 1) / 2;
+    const int tile_elems = std::max(ncols * rs, npair * 4 * 256);
+    const size_t lds = sizeof(T) * ((size_t)tile_elems + 2 * K1M_CONST_ELEMS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<T, NT, HAS_W>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    char name[96];
+    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_nt%d%s_k%d", sizeof(T) == 4 ? "f32" : "f64", NT, HAS_W ? "_w" : "", a.kt);
+    ctx->last_kernel = name;
+    timing_begin(ctx);
+    hipLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols, tile_elems);
+    timing_end(ctx);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
+    if (a.kt + 1 > 32) return fail(POLS_ERR_UNSUPPORTED, "gram_stream: %d features (incl. intercept) > 31", a.kt);
+    const bool two = a.kt + 1 > 16, w = a.w != nullptr;
+    if (dtype == POLS_F32) {
+        if (two) return w ? gram_stream_launch_t<float, 2, true>(ctx, a) : gram_stream_launch_t<float, 2, false>(ctx, a);
+        return w ? gram_stream_launch_t<float, 1, true>(ctx, a) : gram_stream_launch_t<float, 1, false>(ctx, a);
+    }
+    if (two) return w ? gram_stream_launch_t<double, 2, true>(ctx, a) : gram_stream_launch_t<double, 2, false>(ctx, a);
+    return w ? gram_stream_launch_t<double, 1, true>(ctx, a) : gram_stream_launch_t<double, 1, false>(ctx, a);
+}
+
+// ------------------------------------------------------------------------------------------------ B: gram_cd
+constexpr int CD_KMAX = 16;
+
+__device__ __forceinline__ double soft_threshold(double x, double thr, bool positive) {   // ls.rs:373-379
+    const double mag = fmax(fabs(x) - thr, 0.0);
+    double r = copysign(mag, x);
+    if (positive) r = fmax(r, 0.0);
+    return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) gram_cd_kernel(const CdArgs a) {
+    const int lane = threadIdx.x, sub = lane & 15;
+    const int64_t grp = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    const bool live = grp < a.n_groups;
+    const int kt = a.kt, NZ = kt + 1;
+    const int64_t gi = live ? grp : 0;
+    const double *G = a.gram + (size_t)gi * NZ * NZ;
+    const double n = (double)(a.offs[gi + 1] - a.offs[gi]);
+
+    double col[CD_KMAX], w[CD_KMAX], b[CD_KMAX], diag[CD_KMAX];
+#pragma unroll
+    for (int i = 0; i < CD_KMAX; ++i) {
+        const bool in = i < kt;
+        col[i] = (in && sub < kt) ? G[i * NZ + sub] : 0.0;     // column `sub` of X'X
+        b[i] = in ? G[i * NZ + kt] : 0.0;                     // X'y
+        diag[i] = in ? G[i * NZ + i] : 1.0;                   // xtx[[j, j]] (:431)
+        w[i] = 0.0;                                           // w = zeros (:416)
+    }
+    const double alpha_n = a.alpha * n;                       // alpha * n_samples (:419)
+    const double thr = alpha_n * a.l1_ratio, l2 = alpha_n * (1.0 - a.l1_ratio);
+    const bool positive = a.positive != 0, active_set = a.active_set != 0;
+    double wme = 0.0;                                         // w[sub], this lane's own coordinate
+    unsigned mask = (kt >= 32) ? 0xffffffffu : ((1u << kt) - 1u);
+    bool done = !live || n == 0.0;
+    int status = (n == 0.0) ? POLS_GROUP_EMPTY : POLS_GROUP_NOT_CONVERGED;
+
+    for (int64_t it = 0; it < a.max_iter; ++it) {
+        if (__all(done)) break;
+        double d2 = 0.0;
+        const unsigned sweep = mask;                          // `for j in active_indices.clone()` (:459)
+#pragma unroll
+        for (int j = 0; j < CD_KMAX; ++j) {
+            if (j >= kt) break;
+            if (!((sweep >> j) & 1u)) continue;
+            const double sdot = row_allreduce(col[j] * wme);  // sum_i G[j][i] w[i] over the group's 16 lanes
+            const double dot = b[j] - sdot + diag[j] * w[j];  // x_j . (residuals + x_j w_j)  (:428-430)
+            const double wn = soft_threshold(dot, thr, positive) / (diag[j] + l2);   // (:430-431)
+            if (!done) {
+                const double dw = wn - w[j];
+                d2 += dw * dw;
+                w[j] = wn;
+                if (sub == j) wme = wn;
+                if (active_set && fabs(wn) < a.tol) mask &= ~(1u << j);   // (:472-476)
+            }
+        }
+        if (!done && sqrt(d2) < a.tol) { done = true; status = POLS_GROUP_OK; }    // (:436-444)
+    }
+    if (live) {
+        if (sub < kt) {
+            const double out = (n == 0.0) ? 0.0 : wme;
+            if (a.coef) static_cast<T *>(a.coef)[grp * kt + sub] = (T)out;
+            if (a.coef64) a.coef64[grp * kt + sub] = out;
+        }
+        if (sub == 0 && a.status) a.status[grp] = status;
+    }
+}
+
+int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a) {
+    if (a.kt > CD_KMAX) return fail(POLS_ERR_UNSUPPORTED, "elastic net: %d features (incl. intercept) > %d", a.kt, CD_KMAX);
+    const unsigned blocks = (unsigned)((a.n_groups + 3) / 4);
+    if (dtype == POLS_F32) hipLaunchKernelGGL(gram_cd_kernel<float>, dim3(blocks), dim3(64), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(gram_cd_kernel<double>, dim3(blocks), dim3(64), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C: predict
+// pred[r] = sum_j x_j[r] * c_j with c = per-group coefficients (f64) or per-row coefficients (dynamic models,
+// src/expressions.rs:184); residuals = y - pred.  With sample weights the reference's arithmetic is kept:
+// (sqrt_w x) . c * (1 / sqrt_w)  (least_squares.py:190-196, 234-235), so w == 0 gives NaN here too.
+template <typename T>
+__global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N;
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t base = s - (s % VEC);
+    const int ku = a.k_user, kt = a.kt;
+    const bool icpt = ku != kt;
+    const double *cg = a.coef64 ? a.coef64 + (size_t)g * kt : nullptr;
+    const T *crow = static_cast<const T *>(a.coef_rows);
+    T *pred = static_cast<T *>(a.pred);
+    T *resid = static_cast<T *>(a.resid);
+    for (int64_t row0 = base + (int64_t)threadIdx.x * VEC; row0 < e; row0 += 256 * VEC) {
+        const bool full = (row0 >= s) && (row0 + VEC <= e);
+        T p[VEC], sw[VEC], yv[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { p[v] = T(0); sw[v] = T(1); yv[v] = T(0); }
+        if (a.w) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { const int64_t r = row0 + v; if (r >= s && r < e) sw[v] = sqrt(static_cast<const T *>(a.w)[r]); }
+        }
+        for (int j = 0; j < kt; ++j) {
+            T xv[VEC];
+            if (j < ku) {
+                if (full) {
+                    const V t = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) xv[v] = vget<T>(t, v);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { const int64_t r = row0 + v; xv[v] = (r >= s && r < e) ? static_cast<const T *>(a.x[j])[r] : T(0); }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) xv[v] = T(1);
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int64_t r = row0 + v;
+                T c;
+                if (cg) c = (T)cg[j];
+                else c = (r >= s && r < e) ? crow[r * kt + j] : T(0);
+                p[v] = fma(xv[v] * sw[v], c, p[v]);
+            }
+        }
+        (void)icpt;
+        if (a.w) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) p[v] *= T(1) / sw[v];
+        }
+        if (resid) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { const int64_t r = row0 + v; if (r >= s && r < e) yv[v] = static_cast<const T *>(a.y)[r]; }
+        }
+        if (full) {
+            if (pred) { V o; if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]}; *reinterpret_cast<V *>(pred + row0) = o; }
+            if (resid) {
+                V o;
+                if constexpr (VEC == 4) o = V{yv[0] - p[0], yv[1] - p[1], yv[2] - p[2], yv[3] - p[3]}; else o = V{yv[0] - p[0], yv[1] - p[1]};
+                *reinterpret_cast<V *>(resid + row0) = o;
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int64_t r = row0 + v;
+                if (r >= s && r < e) { if (pred) pred[r] = p[v]; if (resid) resid[r] = yv[v] - p[v]; }
+            }
+        }
+    }
+}
+
+int predict_launch(pols_ctx *ctx, int dtype, const PredictArgs &a) {
+    if (a.n_groups == 0) return POLS_OK;
+    if (dtype == POLS_F32) hipLaunchKernelGGL(predict_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(predict_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+}  // namespace pols

@@ -1,0 +1,62 @@
+// k5_enet.hpp -- K5 "enet_gram_cd": elastic net / lasso / non-negative least squares for every group.
+//
+// Replaces solve_elastic_net (src/least_squares.rs:386-492) + make_predictions (src/expressions.rs:175-195).
+// Three launches:
+//   A  gram_stream : one workgroup per group streams the group's columns through LDS in 256-row chunks
+//                    (global_load_lds DMA) and accumulates Z^T Z, Z = [sqrt(w) X | sqrt(w) 1 | sqrt(w) y], on the
+//                    matrix cores as up to two 16-column tiles (k + 1 <= 32): the ONE pass over X that the
+//                    reference repeats ~3k times per sweep (x_j += / dot / -= over n rows, :426-433).  HBM-bound:
+//                    b n (k + 1) bytes per group.
+//   B  gram_cd     : cyclic coordinate descent on (X^T X, X^T y) -- algebraically the reference's residual-form
+//                    update (dot_j = x_j . (y - X w + x_j w_j) = b_j - sum_i G_ji w_i + G_jj w_j), same coordinate
+//                    order, alpha * n scaling (:419), soft threshold (:373-379), active-set variant (:446-489) and
+//                    the ||w - w_old||_2 < tol stop (:436-444), in f64.  16 lanes per group.
+//   C  predict     : pred = X . w (and residuals) with per-group coefficients; also the body of pols_predict.
+#pragma once
+#include "common.hpp"
+
+namespace pols {
+
+struct GramArgs {
+    const void *y;
+    const void *w;
+    const void *x[POLS_MAX_FEATURES];
+    const int64_t *offs;
+    int64_t n_groups;
+    int64_t n_rows;
+    double *gram;        // n_groups x NZ x NZ (row-major, f64), NZ = kt + 1
+    int32_t k_user;
+    int32_t kt;          // k_user + intercept
+};
+
+struct CdArgs {
+    const double *gram;  // from gram_stream
+    const int64_t *offs;
+    int64_t n_groups;
+    void *coef;          // n_groups x kt, dtype of the batch (may alias nothing else)
+    double *coef64;      // n_groups x kt f64 scratch handed to the prediction pass
+    int32_t *status;
+    double alpha, l1_ratio, tol;
+    int64_t max_iter;
+    int32_t positive, active_set, kt;
+};
+
+struct PredictArgs {
+    const void *y;       // for residuals, or nullptr
+    const void *w;       // sample weights (reference NaN semantics at w == 0), or nullptr
+    const void *x[POLS_MAX_FEATURES];
+    const int64_t *offs;
+    int64_t n_groups;
+    int64_t n_rows;
+    const double *coef64;   // n_groups x kt (per-group coefficients) ...
+    const void *coef_rows;  // ... or n_rows x kt in the batch dtype (dynamic models / pols_predict)
+    void *pred;
+    void *resid;
+    int32_t k_user, kt;
+};
+
+int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a);
+int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a);
+int predict_launch(pols_ctx *ctx, int dtype, const PredictArgs &a);
+
+}  // namespace pols

@@ -223,3 +223,25 @@ def default_engine(device: int = 0) -> Engine:
     if device not in _default:
         _default[device] = Engine(device)
     return _default[device]
+
+
+def _engine_predict(self, x_cols: Sequence, coef, offsets=None, *, add_intercept: bool = False):
+    """``predict`` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t, j] * coef[t, j];
+    ``coef`` is n_rows x (k + add_intercept) in the columns' dtype (numpy -> host path, torch CUDA -> device path)."""
+    cols = list(x_cols)
+    n = cols[0].numel() if _is_torch(cols[0]) else len(cols[0])
+    offs = np.asarray([0, n] if offsets is None else offsets, dtype=np.int64)
+    b, keep, dev, dt = self._batch(cols[0], cols, offs, None, None, add_intercept)
+    if dev:
+        coef_k = coef.to(dt).contiguous()
+        out = torch.empty(n, dtype=dt, device=coef_k.device)
+    else:
+        coef_k = np.ascontiguousarray(coef, dtype=dt)
+        out = np.empty(n, dtype=dt)
+    rc = self._lib.pols_predict(self._h, C.byref(b), C.c_void_p(self._ptr(coef_k)), C.c_int64(coef_k.shape[0]),
+                                C.c_void_p(self._ptr(out)))
+    L.check(rc)
+    return out
+
+
+Engine.predict = _engine_predict

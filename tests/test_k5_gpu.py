@@ -1,0 +1,154 @@
+"""GPU parity of K5 (elastic net: streamed MFMA Gram + Gram-form coordinate descent + prediction pass) and of
+pols_predict, through the C-ABI, against the CPU oracle (residual-form CD of src/least_squares.rs:386-492), the
+README lasso known answer and the sklearn golden fixtures."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from polars_ols_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _cuda(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _np(t):
+    return t.double().cpu().numpy() if hasattr(t, "cpu") else np.asarray(t, dtype=np.float64)
+
+
+def _frame(rng, offs, k, dtype, sparsity=0.5, weights=False):
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    kk = max(1, int(k * (1 - sparsity)))
+    y = (sum(c.astype(np.float64) for c in cols[:kk]) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    w = rng.uniform(0.2, 2.0, N).astype(dtype) if weights else None
+    return y, cols, w
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 2e-4)])
+@pytest.mark.parametrize("k,alpha,l1,positive,method,weights,icpt", [
+    (2, 0.1, 0.5, False, "cd", False, False),
+    (8, 0.05, 1.0, False, None, False, True),          # lasso + intercept
+    (8, 0.3, 0.5, True, "cd", True, False),            # non-negative + weights
+    (15, 0.01, 0.5, False, "cd_active_set", False, True),
+    (16, 0.001, 0.5, False, "cd", False, False),       # cfg5's feature count: two MFMA tiles for [X | y]
+    (16, 0.2, 0.9, False, "cd_active_set", True, False),
+])
+def test_elastic_net_tight_tolerance(eng, dtype, tol, k, alpha, l1, positive, method, weights, icpt):
+    """Converged to tol = 1e-10 both paths must land on the same (unique) fixed point."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k + int(100 * alpha))
+    sizes = rng.integers(40, 900, size=29)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k - int(icpt), dtype, weights=weights)
+    kw = dict(alpha=alpha, l1_ratio=l1, positive=positive, solve_method=method, tol=1e-10, max_iter=20_000)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
+                            add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream")
+    assert int(_np(out["status"]).sum()) == 0
+    for key in ("coef", "pred", "resid"):
+        assert np.allclose(_np(out[key]), ref[key], rtol=tol, atol=tol), (key, float(np.abs(_np(out[key]) - ref[key]).max()))
+
+
+def test_elastic_net_default_tol_matches_oracle(eng):
+    """Default tol = 1e-5 / max_iter = 1000: same sweep count, same answer (the stop rule is ||dw||_2 < tol)."""
+    from oracle import orc
+    from refdata import synthetic_groups
+
+    d = synthetic_groups(300, 2000, 16, seed=5, dtype=np.float64)
+    out = eng.least_squares(_cuda(d["y"]), [_cuda(c) for c in d["cols"]], d["offsets"], alpha=0.001, l1_ratio=0.5,
+                            want=("coef", "pred"))
+    ref = orc.batched_least_squares(d["y"], d["cols"], d["offsets"], alpha=0.001, l1_ratio=0.5)
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
+
+
+def test_readme_lasso_and_golden_sklearn(eng, golden):
+    from refdata import make_data, sort_by_group
+
+    kat, z = golden["kat"], golden["npz"]
+    f = {k: np.asarray(v, dtype=np.float64) for k, v in kat["frame"].items()}
+    order, offs, _ = sort_by_group(f["group"].astype(np.int64))
+    out = eng.least_squares(f["y"][order], [f["x1"][order], f["x2"][order]], offs, add_intercept=True, alpha=0.0001,
+                            l1_ratio=1.0, want=("pred",))                       # README.md:58,72-76
+    assert np.array_equal(np.round(out["pred"][:5], 2), kat["predictions_lasso_head5_round2"])
+    d = make_data(n_features=2)                                                 # tests/test_ols.py:561-599, k = 2
+    out = eng.least_squares(d["y"], [d["x1"], d["x2"]], [0, 5000], alpha=0.1, l1_ratio=0.5, tol=1e-9, want=("coef", "pred"))
+    assert np.allclose(out["coef"][0], z["enet2_coef"], atol=1e-7) and np.allclose(out["pred"], z["enet2_pred"], atol=1e-6)
+    out = eng.least_squares(d["y"], [d["x1"], -d["x2"]], [0, 5000], alpha=0.1, l1_ratio=0.5, tol=1e-9, positive=True,
+                            want=("coef",))                                     # tests/test_ols.py:602-630
+    assert np.allclose(out["coef"][0], z["nnls_coef"], atol=1e-7) and out["coef"][0][1] == 0.0
+
+
+def test_max_iter_reached_is_reported(eng):
+    rng = np.random.default_rng(0)
+    offs = np.array([0, 500], dtype=np.int64)
+    y, cols, _ = _frame(rng, offs, 6, np.float64)
+    cols[1] = cols[0] + 1e-3 * cols[1]                                          # strongly correlated pair: slow CD
+    out = eng.least_squares(y, cols, offs, alpha=1e-6, l1_ratio=0.5, tol=1e-14, max_iter=3, want=("coef", "status"))
+    assert out["status"][0] == 3                                                # POLS_GROUP_NOT_CONVERGED
+
+
+def test_reference_panics(eng):
+    from polars_ols_amd import PolsPanic
+
+    y = np.ones(8); x = [np.arange(8.0)]
+    with pytest.raises(PolsPanic, match="coordinate descent"):
+        eng.least_squares(y, x, [0, 8], alpha=0.1, l1_ratio=0.5, solve_method="qr")     # least_squares.rs:404
+    with pytest.raises(PolsPanic, match="l1_ratio"):
+        eng.least_squares(y, x, [0, 8], alpha=0.1, l1_ratio=1.5)                        # least_squares.rs:410
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_predict_rowwise_coefficients(eng, dtype):
+    """pols_predict == (features * coefficients).sum(axis=1) (src/expressions.rs:728), with and without intercept."""
+    rng = np.random.default_rng(1)
+    n, k = 10_007, 5
+    cols = [rng.standard_normal(n).astype(dtype) for _ in range(k)]
+    coef = rng.standard_normal((n, k + 1)).astype(dtype)
+    exp = sum(c.astype(np.float64) * coef[:, j] for j, c in enumerate(cols)) + coef[:, k]
+    tol = 1e-4 if dtype == np.float32 else 1e-9
+    got = eng.predict([_cuda(c) for c in cols], _cuda(coef), add_intercept=True)
+    assert np.allclose(_np(got), exp, rtol=tol, atol=tol)
+    got = eng.predict(cols, coef[:, :k].copy())                                 # host buffers
+    assert np.allclose(got, exp - coef[:, k], rtol=tol, atol=tol)
+
+
+def test_cfg5_shape_medium(eng):
+    """BASELINE configs[4] shape (2 000 rows x 16 feats, alpha = 0.001, l1_ratio = 0.5, f64) on 4 000 groups generated
+    on the device; oracle parity on a sample of groups, normal-equation-style optimality on all."""
+    import torch
+    from oracle import orc
+
+    G, n, k = 4_000, 2_000, 16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cols = [torch.randn(G * n, generator=g, device="cuda", dtype=torch.float64) for _ in range(k)]
+    y = sum(cols) + 0.1 * torch.randn(G * n, generator=g, device="cuda", dtype=torch.float64)
+    offs = np.arange(G + 1, dtype=np.int64) * n
+    out = eng.least_squares(y, cols, offs, alpha=0.001, l1_ratio=0.5, want=("coef", "pred", "status"))
+    assert int(out["status"].sum()) == 0
+    pick = np.array([0, 7, 1999, 3999])
+    yh = y.cpu().numpy().reshape(G, n)[pick].reshape(-1)
+    ch = [c.cpu().numpy().reshape(G, n)[pick].reshape(-1) for c in cols]
+    ref = orc.batched_least_squares(yh, ch, np.arange(len(pick) + 1) * n, alpha=0.001, l1_ratio=0.5)
+    assert np.allclose(_np(out["coef"])[pick], ref["coef"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(_np(out["pred"]).reshape(G, n)[pick].reshape(-1), ref["pred"], rtol=1e-6, atol=1e-6)
+    # KKT of the elastic net at an interior (all non-zero) solution: x_j.(y - Xw) = n*alpha*(l1*sign(w_j) + (1-l1)*w_j)
+    w = out["coef"]
+    r = (y - out["pred"]).view(G, n)
+    for j in range(k):
+        lhs = (cols[j].view(G, n) * r).sum(1)
+        rhs = n * 0.001 * (0.5 * torch.sign(w[:, j]) + 0.5 * w[:, j])
+        assert float((lhs - rhs).abs().max()) < 5e-2    # tol = 1e-5 on w times ||x_j||^2 ~ 2000
