@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[1] --
-10 000 groups x 1 000 rows x 8 features, f32, OLS, mode="predictions" -- with the input columns already
-resident in HBM when the timed region starts.  One process per GPU; groups are independent, so every rank owns
-its own 10 000-group shard (weak scaling, no data-path collective); for N > 1 each step also all-gathers the
-per-group coefficient table over RCCL/xGMI (the "reassemble the coefficients column" step of north_star),
-issued asynchronously so it overlaps the next step's kernel.  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic input, with the input columns already resident
+in HBM when the timed region starts.  Default workload = BASELINE.json configs[1] (the configuration the metric is
+quoted on): 10 000 groups x 1 000 rows x 8 features, f32, OLS, mode="predictions".  One process per GPU; groups are
+independent, so every rank owns its own shard of groups (weak scaling, no data-path collective); for N > 1 each step
+also all-gathers the per-group coefficient table over RCCL/xGMI (the "reassemble the coefficients column" step of
+north_star), issued on a side stream so it overlaps the next step's kernel.  Prints ONE JSON line on rank 0.
+
+--config selects the other BASELINE configs for the numbers quoted in DESIGN.md (same JSON shape):
+  cfg3  10 000 x 1 000 x 8, f64, ridge alpha = 1 + sample_weights, predictions
+  cfg4  1 000 000-row RLS, 6 features, half_life = 21, f64 (ONE sequence: a dependency chain, replicas only)
+  cfg5  100 000 groups x 2 000 rows x 16 feats elastic net alpha = 0.001 l1_ratio = 0.5, f64; the groups are SPLIT
+        across the ranks (strong scaling: 100 000 / N per GPU)
 """
 from __future__ import annotations
 
@@ -29,13 +35,7 @@ for p in (str(ROOT), str(ROOT / "tests")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-GROUPS, ROWS, FEATS = 10_000, 1_000, 8
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-
-
-def algorithmic_bytes_per_group(rows: int, feats: int, itemsize: int, weights: bool = False) -> int:
-    """read X (n*k) + y (n) [+ w (n)], write predictions (n)."""
-    return itemsize * rows * (feats + 1 + (1 if weights else 0)) + itemsize * rows
 
 
 def cpu_baseline(rows: int, feats: int, target_seconds: float = 12.0) -> dict:
@@ -66,6 +66,64 @@ def cpu_baseline(rows: int, feats: int, target_seconds: float = 12.0) -> dict:
                       f"1-thread rate {sample_groups / dt1:.0f}/s"}
 
 
+def make_columns(n: int, feats: int, tdt, seed: int, weights: bool = False):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    cols = [torch.randn(n, generator=gen, device="cuda", dtype=tdt) for _ in range(feats)]
+    y = torch.zeros(n, device="cuda", dtype=tdt)
+    for c in cols:
+        y += c
+    y += 0.1 * torch.randn(n, generator=gen, device="cuda", dtype=tdt)
+    w = None
+    if weights:
+        w = torch.rand(n, generator=gen, device="cuda", dtype=tdt)
+        w /= w.mean()
+    return y, cols, w
+
+
+def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str):
+    """Returns (plan, units_per_step_per_rank, unit_name, algorithmic_bytes_per_launch, workload_text, dtype, coef, scaling)."""
+    if cfg == "cfg2":
+        G, n, k = 10_000, 1_000, 8
+        tdt = torch.float32 if dtype_flag == "f32" else torch.float64
+        b = 4 if dtype_flag == "f32" else 8
+        y, cols, _ = make_columns(G * n, k, tdt, 1234 + rank)
+        out = {"pred": torch.empty(G * n, device="cuda", dtype=tdt), "coef": torch.empty(G, k, device="cuda", dtype=tdt)}
+        plan = eng.plan_least_squares(y, cols, np.arange(G + 1, dtype=np.int64) * n, want=("pred", "coef"), out=out)
+        text = (f"BASELINE configs[1]: {G} groups x {n} rows x {k} feats {dtype_flag} OLS mode=predictions "
+                f"(+coefficients), inputs resident in HBM, per GPU")
+        return plan, G, "regressions/s", b * n * (k + 1) * G + b * n * G, text, dtype_flag, out["coef"], "weak"
+    if cfg == "cfg3":
+        G, n, k = 10_000, 1_000, 8
+        y, cols, w = make_columns(G * n, k, torch.float64, 1234 + rank, weights=True)
+        out = {"pred": torch.empty(G * n, device="cuda", dtype=torch.float64),
+               "coef": torch.empty(G, k, device="cuda", dtype=torch.float64)}
+        plan = eng.plan_least_squares(y, cols, np.arange(G + 1, dtype=np.int64) * n, weights=w, alpha=1.0, l1_ratio=0.0,
+                                      want=("pred", "coef"), out=out)
+        text = f"BASELINE configs[2]: {G} groups x {n} rows x {k} feats f64 ridge alpha=1.0 + sample_weights, predictions, per GPU"
+        return plan, G, "regressions/s", 8 * n * (k + 2) * G + 8 * n * G, text, "f64", out["coef"], "weak"
+    if cfg == "cfg4":
+        n, k = 1_000_000, 6
+        y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
+        out = {"pred": torch.empty(n, device="cuda", dtype=torch.float64),
+               "coef": torch.empty(n, k, device="cuda", dtype=torch.float64)}
+        plan = eng.plan_recursive_least_squares(y, cols, np.array([0, n], dtype=np.int64), half_life=21.0, out=out)
+        text = f"BASELINE configs[3]: ONE {n}-row sequence, {k} feats f64 RLS half_life=21 (coefficients + predictions); replicas only"
+        return plan, n, "rows/s", 8 * n * (k + 1) + 8 * n * (k + 1), text, "f64", None, "weak"
+    if cfg == "cfg5":
+        Gtot, n, k = 100_000, 2_000, 16
+        G = Gtot // world
+        y, cols, _ = make_columns(G * n, k, torch.float64, 1234 + rank)
+        out = {"coef": torch.empty(G, k, device="cuda", dtype=torch.float64),
+               "pred": torch.empty(G * n, device="cuda", dtype=torch.float64)}
+        plan = eng.plan_least_squares(y, cols, np.arange(G + 1, dtype=np.int64) * n, alpha=0.001, l1_ratio=0.5,
+                                      want=("coef", "pred"), out=out)
+        text = (f"BASELINE configs[4]: {Gtot} groups x {n} rows x {k} feats f64 elastic net alpha=0.001 l1_ratio=0.5, "
+                f"predictions (+coefficients), groups split over {world} GPU(s): {G} per GPU")
+        # the Gram pass reads X, y once; the prediction pass reads X again and writes predictions
+        return plan, G, "regressions/s", 8 * n * (k + 1) * G, text, "f64", out["coef"], "strong"
+    raise SystemExit(f"unknown --config {cfg}")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,14 +131,14 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -93,34 +151,25 @@ def main() -> None:
 
     from polars_ols_amd import Engine
 
-    tdt = torch.float32 if args.dtype == "f32" else torch.float64
-    itemsize = 4 if args.dtype == "f32" else 8
-    N = GROUPS * ROWS
-    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    cols = [torch.randn(N, generator=gen, device="cuda", dtype=tdt) for _ in range(FEATS)]
-    y = sum(cols) + 0.1 * torch.randn(N, generator=gen, device="cuda", dtype=tdt)
-    offsets = np.arange(GROUPS + 1, dtype=np.int64) * ROWS
-
     eng = Engine(local_rank)
-    out = {"pred": torch.empty(N, device="cuda", dtype=tdt), "coef": torch.empty(GROUPS, FEATS, device="cuda", dtype=tdt)}
-    gathered = torch.empty(world * GROUPS, FEATS, device="cuda", dtype=tdt) if world > 1 else None
-    side = torch.cuda.Stream() if world > 1 else None
-    plan = eng.plan_least_squares(y, cols, offsets, want=("pred", "coef"), out=out)   # marshal once
-    torch.cuda.synchronize()                                                           # inputs are resident
-
-    def step():
-        plan.run()
-        if world > 1:
-            # hand the coefficient table to the collective stream; the next step's kernel overlaps the gather
-            eng_stream_event.record(eng_stream)
-            side.wait_event(eng_stream_event)
-            with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered, out["coef"])
-
     # run the engine on a torch-visible stream so torch events / RCCL can order against it
     eng_stream = torch.cuda.Stream()
     eng.set_stream(eng_stream.cuda_stream)
-    eng_stream_event = torch.cuda.Event()
+    plan, units, unit_name, alg_bytes, text, dtype_name, coef, scaling = build_workload(args.config, eng, rank, world, args.dtype)
+    torch.cuda.synchronize()                                                           # inputs are resident
+    gather = dist is not None and coef is not None
+    gathered = torch.empty((world * coef.shape[0], coef.shape[1]), device="cuda", dtype=coef.dtype) if gather else None
+    side = torch.cuda.Stream() if gather else None
+    handoff = torch.cuda.Event()
+
+    def step():
+        plan.run()
+        if gather:
+            # hand the coefficient table to the collective stream; the next step's kernel overlaps the gather
+            handoff.record(eng_stream)
+            side.wait_event(handoff)
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(gathered, coef)
 
     for _ in range(args.warmup):
         step()
@@ -147,33 +196,34 @@ def main() -> None:
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * GROUPS * args.steps / elapsed
+        value = world * units * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-        bytes_per_launch = algorithmic_bytes_per_group(ROWS, FEATS, itemsize) * GROUPS
-        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their own runs,
         # gfx950 correction applied) for this exact kernel + workload; committed under profiles/.  null if absent.
         traffic = None
         try:
             pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-            traffic = pmc.get(eng.last_kernel, {}).get("traffic_bytes")
+            traffic = pmc.get(eng.last_kernel, {}).get("traffic_bytes") if args.config == "cfg2" else None
         except Exception:
             traffic = None
         line = {
-            "metric": "group_regressions_per_sec", "value": value, "unit": "regressions/s", "n_gpus": world,
+            "metric": "group_regressions_per_sec" if unit_name == "regressions/s" else "rls_rows_per_sec",
+            "value": value, "unit": unit_name, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {GROUPS} groups x {ROWS} rows x {FEATS} feats {args.dtype} OLS "
-                                   f"mode=predictions (+coefficients), inputs resident in HBM, per GPU",
-                       "groups_per_gpu": GROUPS, "rows_per_group": ROWS, "features": FEATS,
+            "scaling": scaling, "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": text, "units_per_gpu_per_step": units,
                        "sharding": "groups" if world > 1 else "none",
-                       "collective": "all_gather(coefficients) overlapped" if world > 1 else "none"},
+                       "collective": "all_gather(coefficients) overlapped" if gather else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": eng.last_kernel,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(ROWS, FEATS)
+        if args.config == "cfg4":
+            line["roofline"]["note"] = ("single sequence: bound by the serial rank-1 update chain, not by HBM; "
+                                        "achieved/peak only shows how far from memory-bound it is")
+        if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
+            line["cpu_baseline"] = cpu_baseline(1_000, 8)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

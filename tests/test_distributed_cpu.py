@@ -1,0 +1,98 @@
+"""N > 1 host path on CPU: world_size-2 (and 3) `gloo` process groups exercising the group sharding and the
+ragged gathers of polars_ols_amd/distributed.py.  The per-shard compute is stood in for by the CPU oracle (tests may
+use it; the product never does) so the check is end-to-end: sharded result == single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from polars_ols_amd.distributed import partition_groups, shard_for_rank
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _frame(seed=0, n_groups=41, k=3):
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(0, 60, size=n_groups)
+    sizes[5] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N) for _ in range(k)]
+    y = sum(cols) + 0.1 * rng.standard_normal(N)
+    return y, cols, offs
+
+
+def _worker(rank, world, port, q):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    from oracle import orc
+    from polars_ols_amd.distributed import gather_coefficients, gather_rows, shard_for_rank, slice_columns
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    y, cols, offs = _frame()
+    sh = shard_for_rank(offs, world, rank)
+    ly, *lcols = slice_columns([y] + cols, sh)
+    out = orc.batched_least_squares(ly, lcols, sh.offsets, alpha=0.5)        # stand-in for Engine.least_squares on this rank's GPU
+    coef = gather_coefficients(torch.from_numpy(out["coef"]), sh)
+    pred = gather_rows(torch.from_numpy(out["pred"]), sh, dst=0)
+    if rank == 0:
+        q.put((coef.numpy(), pred.numpy()))
+    else:
+        assert pred is None
+        q.put((coef.numpy(), None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single_process(world):
+    from oracle import orc
+
+    y, cols, offs = _frame()
+    ref = orc.batched_least_squares(y, cols, offs, alpha=0.5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for coef, pred in results:
+        assert np.array_equal(coef, ref["coef"])                 # every rank holds the full table, in group order
+        if pred is not None:
+            assert np.array_equal(pred, ref["pred"])             # root holds the full prediction column, in row order
+
+
+def test_partition_is_contiguous_balanced_and_deterministic():
+    offs = np.arange(10_001, dtype=np.int64) * 1_000            # BASELINE configs[1] frame
+    for world in (1, 2, 4, 8):
+        b = partition_groups(offs, world)
+        assert b[0] == 0 and b[-1] == 10_000 and all(b[i] <= b[i + 1] for i in range(world))
+        rows = [offs[b[r + 1]] - offs[b[r]] for r in range(world)]
+        assert max(rows) - min(rows) <= 1_000
+    rng = np.random.default_rng(1)
+    offs = np.concatenate([[0], np.cumsum(rng.integers(0, 5000, 777))])
+    shards = [shard_for_rank(offs, 8, r) for r in range(8)]
+    assert shards[0].group_lo == 0 and shards[-1].group_hi == 777
+    assert all(shards[r].group_hi == shards[r + 1].group_lo for r in range(7))
+    assert sum(s.row_hi - s.row_lo for s in shards) == offs[-1]
+    assert all(s.offsets[0] == 0 and s.offsets[-1] == s.row_hi - s.row_lo for s in shards)
+    assert max(shards[0].row_counts) <= offs[-1] / 8 + 5000      # balanced to within one group
+
+
+def test_more_ranks_than_groups():
+    offs = np.array([0, 10, 20], dtype=np.int64)
+    shards = [shard_for_rank(offs, 4, r) for r in range(4)]
+    assert sum(s.group_hi - s.group_lo for s in shards) == 2
