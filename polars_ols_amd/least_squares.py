@@ -1,0 +1,552 @@
+"""Host-side mirror of the reference's Python operator interface for the hot path.
+
+Same names, argument meaning, defaults and error behaviour as ``polars_ols/least_squares.py`` and the
+``least_squares`` namespace of ``polars_ols/__init__.py`` (reference file:line cited per item), re-stated over a
+dict-of-columns frame because Polars is not available in the build image: columns are 1-D numpy arrays (host path)
+or CUDA torch tensors (device path), a *null* is a NaN, and ``.over(key)`` is done here by a stable sort-by-key
+(what Polars' ``.over`` gather does on the host) followed by ONE batched call into libpols_mi355x for all groups.
+
+    from polars_ols_amd import Frame, col
+    df = Frame({"y": y, "x1": x1, "x2": x2, "group": g})
+    pred = df.select(col("y").least_squares.ols("x1", "x2", mode="predictions").over("group"))["y"]
+    coef = df.select(col("y").least_squares.from_formula("x1 + x2", mode="coefficients").over("group"))["coefficients"]
+
+What runs where: null-policy row filtering, sqrt(w) handling for null policies, group sort / scatter are data
+marshalling (the reference does them with Polars ops in src/expressions.rs:201-296 and least_squares.py:163-239);
+every solve and prediction runs in the HIP kernels behind the C-ABI.  There is no CPU compute path.
+"""
+from __future__ import annotations
+
+import logging
+import re
+from dataclasses import asdict, dataclass
+from typing import Any, Dict, List, Literal, Optional, Sequence, Set, Tuple, Union, get_args
+
+import numpy as np
+
+from .engine import Engine, _is_torch, default_engine
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+logger = logging.getLogger(__name__)
+
+__all__ = [
+    "compute_least_squares", "compute_recursive_least_squares", "compute_rolling_least_squares",
+    "compute_least_squares_from_formula", "compute_multi_target_least_squares", "predict",
+    "OLSKwargs", "RLSKwargs", "RollingKwargs", "NullPolicy", "OutputMode", "SolveMethod",
+    "Frame", "Expr", "col", "Coefficients", "LeastSquares",
+]
+
+# ---- polars_ols/least_squares.py:47-63 --------------------------------------------------------------------------
+NullPolicy = Literal["zero", "drop", "ignore", "drop_zero", "drop_y_zero_x", "drop_window"]
+OutputMode = Literal["predictions", "residuals", "coefficients", "statistics"]
+SolveMethod = Literal["qr", "svd", "chol", "lu", "cd", "cd_active_set"]
+
+_VALID_NULL_POLICIES: Set[str] = set(get_args(NullPolicy))
+_VALID_OUTPUT_MODES: Set[str] = set(get_args(OutputMode))
+_VALID_SOLVE_METHODS: Set[Any] = set(get_args(SolveMethod)).union({None})
+_EPSILON: float = 1.0e-12
+
+
+@dataclass
+class Kwargs:  # least_squares.py:66-77
+    null_policy: str = "ignore"
+
+    def to_dict(self) -> Dict[str, Any]:
+        return asdict(self)
+
+    def __post_init__(self):
+        assert self.null_policy in _VALID_NULL_POLICIES, \
+            f"'null_policy' must be one of {_VALID_NULL_POLICIES}. You passed: {self.null_policy}"
+
+
+@dataclass
+class OLSKwargs(Kwargs):  # least_squares.py:80-118
+    alpha: Optional[float] = 0.0
+    l1_ratio: Optional[float] = None
+    max_iter: Optional[int] = 1_000
+    tol: Optional[float] = 1.0e-5
+    positive: Optional[bool] = False
+    solve_method: Optional[str] = None
+    rcond: Optional[float] = None
+
+    def __post_init__(self):
+        valid_ols_policies = _VALID_NULL_POLICIES - {"drop_window"}
+        assert self.null_policy in valid_ols_policies, \
+            f"'null_policy' must be one of {valid_ols_policies}. You passed: {self.null_policy}"
+        assert self.solve_method in _VALID_SOLVE_METHODS, \
+            f"'solve_method' must be one of {_VALID_SOLVE_METHODS}. You passed: {self.solve_method}"
+
+
+@dataclass
+class RLSKwargs(Kwargs):  # least_squares.py:121-140
+    half_life: Optional[float] = None
+    initial_state_covariance: Optional[float] = 10.0
+    initial_state_mean: Union[Optional[List[float]], float] = None
+    null_policy: str = "drop"
+
+
+@dataclass
+class RollingKwargs(Kwargs):  # least_squares.py:143-160
+    window_size: int = 1_000_000
+    min_periods: Optional[int] = None
+    use_woodbury: Optional[bool] = None
+    alpha: Optional[float] = None
+    null_policy: str = "drop_window"
+
+
+# ---- frame / expression plumbing ---------------------------------------------------------------------------------
+
+class Coefficients:
+    """The coefficients struct of the reference (src/expressions.rs:114-143): one field per feature, NaN = null.
+
+    ``values`` is [n_groups x k] for static models (``keys`` = the group keys in sorted order; Polars broadcasts the
+    struct to every row of the group -- ``to_rows()``), [n_rows x k] for rls / rolling."""
+
+    def __init__(self, names: Sequence[str], values, keys=None, row_group=None):
+        self.names, self.values, self.keys, self._row_group = list(names), values, keys, row_group
+
+    def unnest(self) -> Dict[str, Any]:
+        return {n: self.values[:, j] for j, n in enumerate(self.names)}
+
+    def to_rows(self):
+        return self.values if self._row_group is None else self.values[self._row_group]
+
+    def __repr__(self):
+        return f"Coefficients(names={self.names}, shape={tuple(self.values.shape)})"
+
+
+class Expr:
+    """A column reference (optionally scaled) or a deferred least-squares expression."""
+
+    def __init__(self, name: Optional[str] = None, scale: float = 1.0, fn=None, over=None, alias: Optional[str] = None):
+        self._name, self._scale, self._fn, self._over, self._alias = name, scale, fn, over, alias
+
+    # column arithmetic that the reference's own tests use on features (e.g. ``-pl.col("x2")``, test_ols.py:615)
+    def __neg__(self):
+        return Expr(self._name, -self._scale)
+
+    def __mul__(self, c: float):
+        return Expr(self._name, self._scale * float(c))
+
+    __rmul__ = __mul__
+
+    def alias(self, name: str) -> "Expr":
+        return Expr(self._name, self._scale, self._fn, self._over, name)
+
+    def over(self, key) -> "Expr":
+        return Expr(self._name, self._scale, self._fn, key, self._alias)
+
+    @property
+    def least_squares(self) -> "LeastSquares":
+        return LeastSquares(self)
+
+    @property
+    def output_name(self) -> str:
+        return self._alias or self._name
+
+    def _column(self, frame: "Frame"):
+        c = frame[self._name]
+        return c if self._scale == 1.0 else c * self._scale
+
+
+def col(name: str) -> Expr:
+    return Expr(name)
+
+
+def parse_into_expr(e) -> Expr:  # polars_ols/utils.py:21-58 (strings are column names)
+    if isinstance(e, Expr):
+        return e
+    if isinstance(e, str):
+        return Expr(e)
+    raise TypeError(f"cannot parse {type(e)} into a column expression")
+
+
+class Frame(dict):
+    """dict of equally long 1-D columns (numpy or CUDA torch)."""
+
+    def select(self, *exprs: Expr, engine: Optional[Engine] = None) -> Dict[str, Any]:
+        out: Dict[str, Any] = {}
+        for e in exprs:
+            if e._fn is None:
+                out[e.output_name] = e._column(self)
+            else:
+                name, val = e._fn(self, e._over, engine)
+                out[e._alias or name] = val
+        return out
+
+    def with_columns(self, *exprs: Expr, engine: Optional[Engine] = None) -> "Frame":
+        f = Frame(self)
+        f.update(self.select(*exprs, engine=engine))
+        return f
+
+
+# ---- helpers over numpy / torch columns ---------------------------------------------------------------------------
+
+def _xp(a):
+    return torch if _is_torch(a) else np
+
+
+def _isnan(a):
+    return torch.isnan(a) if _is_torch(a) else np.isnan(a)
+
+
+def _nan_to_zero(a):
+    return torch.nan_to_num(a, nan=0.0) if _is_torch(a) else np.where(np.isnan(a), 0.0, a)
+
+
+def _take(a, idx):
+    return a[idx]
+
+
+def _to_index(idx, like):
+    if _is_torch(like):
+        return torch.as_tensor(idx, device=like.device)
+    return idx
+
+
+def _group_layout(key) -> Tuple[Optional[np.ndarray], np.ndarray, np.ndarray, np.ndarray]:
+    """(order or None if already contiguous-sorted, offsets, keys, group id per sorted row) for an ``over`` key."""
+    k = key.cpu().numpy() if _is_torch(key) else np.asarray(key)
+    order = None
+    if not bool(np.all(k[1:] >= k[:-1])):
+        order = np.argsort(k, kind="stable")
+        k = k[order]
+    keys, counts = np.unique(k, return_counts=True)
+    offsets = np.zeros(len(keys) + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    gid = np.repeat(np.arange(len(keys)), counts)
+    return order, offsets, keys, gid
+
+
+def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], sample_weights, add_intercept: bool):
+    """least_squares.py:163-196 up to (not including) the sqrt_w multiplications, which the kernels fuse:
+    returns (y, x columns, feature names, add_intercept flag for the engine, weights or None)."""
+    names = [f.output_name for f in features]
+    icpt = False
+    if add_intercept:
+        if any(n == "const" for n in names):
+            logger.info("feature named 'const' already detected, assuming it is an intercept")  # :185-186
+        else:
+            names = names + ["const"]                                                          # appended LAST (:188)
+            icpt = True
+    w = None
+    if sample_weights is not None:
+        w = parse_into_expr(sample_weights)._column(frame)
+        # sqrt_w = w.sqrt().fill_null(1e-12)  (:193): a null weight acts as weight 1e-24
+        w = torch.nan_to_num(w, nan=_EPSILON ** 2) if _is_torch(w) else np.where(np.isnan(w), _EPSILON ** 2, w)
+    return target._column(frame), [f._column(frame) for f in features], names, icpt, w
+
+
+def _ones_like(a):
+    return torch.ones_like(a) if _is_torch(a) else np.ones_like(a)
+
+
+def _static_fit(eng: Engine, y, xs, offs, w, icpt: bool, want, kw: OLSKwargs):
+    d = kw.to_dict()
+    d.pop("null_policy")
+    return eng.least_squares(y, xs, offs, weights=w, add_intercept=icpt, want=want, **d)
+
+
+def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, features: Sequence[Expr], sample_weights,
+                  add_intercept: bool, mode: str, kw: OLSKwargs):
+    """compute_least_squares body: least_squares.py:199-239 + src/expressions.rs:390-446 (null policies :201-296)."""
+    y, xs, names, icpt, w = _pre_process_data(frame, target, features, sample_weights, add_intercept)
+    n = y.shape[0]
+    eng = eng or default_engine(y.device.index or 0 if _is_torch(y) else 0)
+    if mode == "statistics":
+        raise NotImplementedError("mode='statistics' (src/statistics.rs) is not built yet")
+    # ---- group layout (.over)
+    if over is not None:
+        key = frame[over] if isinstance(over, str) else over
+        order, offs, keys, gid = _group_layout(key)
+    else:
+        order, offs, keys, gid = None, np.array([0, n], dtype=np.int64), None, np.zeros(n, dtype=np.int64)
+    if order is not None:
+        oi = _to_index(order, y)
+        y_s, xs_s, w_s = _take(y, oi), [_take(c, oi) for c in xs], (None if w is None else _take(w, oi))
+    else:
+        y_s, xs_s, w_s = y, xs, w
+
+    policy = kw.null_policy
+    if policy in ("ignore", "zero"):
+        if policy == "zero":                                   # handle_nulls Zero (ex.rs:264-271)
+            y_s, xs_s = _nan_to_zero(y_s), [_nan_to_zero(c) for c in xs_s]
+        want = ("coef",) if mode == "coefficients" else (("pred",) if mode == "predictions" else ("resid",))
+        out = _static_fit(eng, y_s, xs_s, offs, w_s, icpt, want, kw)
+        coef, pred = out.get("coef"), out.get("pred") if mode == "predictions" else out.get("resid")
+    else:
+        # drop / drop_zero / drop_y_zero_x (ex.rs:209-225, 272-291): fit on the valid rows only, predict on the
+        # zero-filled features of EVERY row, mask with the validity for "drop" (ex.rs:398-427).
+        # The reference hands the plugin sqrt_w-scaled columns (ls.py:190-196), so do the scaling here and fit unweighted.
+        if w_s is not None:
+            sw = torch.sqrt(w_s) if _is_torch(w_s) else np.sqrt(w_s)
+            y_f, xs_f = y_s * sw, [c * sw for c in xs_s] + ([sw] if icpt else [])
+        else:
+            sw = None
+            y_f, xs_f = y_s, list(xs_s) + ([_ones_like(y_s)] if icpt else [])
+        if policy == "drop_y_zero_x":
+            valid = ~_isnan(y_f)
+        else:
+            valid = ~_isnan(y_f)
+            for c in xs_f:
+                valid = valid & ~_isnan(c)
+        vnp = valid.cpu().numpy() if _is_torch(valid) else valid
+        vidx = np.nonzero(vnp)[0]
+        full_counts = np.bincount(gid[vnp], minlength=len(offs) - 1)          # valid rows per group
+        offs_v = np.concatenate([[0], np.cumsum(full_counts)]).astype(np.int64)
+        vi = _to_index(vidx, y_f)
+        y_v = _take(y_f, vi)
+        xs_v = [_take(c, vi) for c in xs_f]
+        if policy == "drop_y_zero_x":
+            xs_v = [_nan_to_zero(c) for c in xs_v]
+        out = _static_fit(eng, y_v, xs_v, offs_v, None, False, ("coef",), kw)
+        coef = out["coef"]
+        if mode == "coefficients":
+            pred = None
+        else:
+            gi = _to_index(gid, y_f)
+            rows_coef = coef[gi]                               # broadcast each group's coefficients to its rows
+            pred = eng.predict([_nan_to_zero(c) for c in xs_f], rows_coef)     # construct_features_array(fill_zero) (ex.rs:408)
+            if sw is not None:
+                pred = pred * (1.0 / sw)                       # ls.py:234-235
+            if policy == "drop":
+                nan = float("nan")
+                pred = torch.where(valid, pred, torch.full_like(pred, nan)) if _is_torch(pred) else np.where(valid, pred, nan)
+            if mode == "residuals":
+                pred = y_s - pred                              # ls.py:239 (original target)
+    if mode == "coefficients":
+        return "coefficients", Coefficients(names, coef, keys, None if order is None and over is None else _unsort(gid, order))
+    if order is not None:                                      # scatter back to the frame's row order
+        inv = np.empty(n, dtype=np.int64)
+        inv[order] = np.arange(n)
+        pred = _take(pred, _to_index(inv, pred))
+    return target.output_name, pred
+
+
+def _unsort(gid: np.ndarray, order: Optional[np.ndarray]) -> np.ndarray:
+    if order is None:
+        return gid
+    out = np.empty_like(gid)
+    out[order] = gid
+    return out
+
+
+def _apply_dynamic(frame: Frame, over, eng: Optional[Engine], target: Expr, features: Sequence[Expr], sample_weights,
+                   add_intercept: bool, mode: str, kind: str, kw):
+    """compute_recursive_least_squares / compute_rolling_least_squares bodies (ls.py:332-409 around
+    src/expressions.rs:593-701): the plugin gets sqrt_w-scaled, intercept-extended columns, a validity mask from the
+    null policy, and zero-filled data (NullPolicy::Zero conversion, ex.rs:603,629,656,683)."""
+    y, xs, names, icpt, w = _pre_process_data(frame, target, features, sample_weights, add_intercept)
+    n = y.shape[0]
+    eng = eng or default_engine(y.device.index or 0 if _is_torch(y) else 0)
+    xs = list(xs) + ([_ones_like(y)] if icpt else [])
+    sw = None
+    y_fit = y
+    if w is not None:
+        sw = torch.sqrt(w) if _is_torch(w) else np.sqrt(w)
+        y_fit, xs = y * sw, [c * sw for c in xs]
+    policy = kw.null_policy
+    # compute_is_valid_mask (ex.rs:201-228)
+    if policy in ("drop", "drop_zero", "drop_window"):
+        valid = ~_isnan(y_fit)
+        for c in xs:
+            valid = valid & ~_isnan(c)
+    elif policy == "drop_y_zero_x":
+        valid = ~_isnan(y_fit)
+    else:
+        valid = None
+    y0, xs0 = _nan_to_zero(y_fit), [_nan_to_zero(c) for c in xs]
+    if over is not None:
+        key = frame[over] if isinstance(over, str) else over
+        order, offs, keys, gid = _group_layout(key)
+    else:
+        order, offs = None, np.array([0, n], dtype=np.int64)
+    if order is not None:
+        oi = _to_index(order, y0)
+        y0, xs0 = _take(y0, oi), [_take(c, oi) for c in xs0]
+        valid_s = None if valid is None else _take(valid, oi)
+    else:
+        valid_s = valid
+    want = ("coef",) if mode == "coefficients" else ("pred",)
+    vbytes = None if valid_s is None else (valid_s.to(torch.uint8) if _is_torch(valid_s) else valid_s.astype(np.uint8))
+    if kind == "rls":
+        mean = kw.initial_state_mean if mode == "coefficients" else None      # quirk: ex.rs:636 passes None for predictions
+        out = eng.recursive_least_squares(y0, xs0, offs, valid=vbytes, want=want, half_life=kw.half_life,
+                                          initial_state_covariance=kw.initial_state_covariance,
+                                          initial_state_mean=mean, null_policy=policy)
+    else:
+        out = eng.rolling_least_squares(y0, xs0, offs, valid=vbytes, want=want, window_size=kw.window_size,
+                                        min_periods=kw.min_periods, use_woodbury=kw.use_woodbury, alpha=kw.alpha,
+                                        null_policy=policy)
+    res = out["coef"] if mode == "coefficients" else out["pred"]
+    if order is not None:
+        inv = np.empty(n, dtype=np.int64)
+        inv[order] = np.arange(n)
+        res = _take(res, _to_index(inv, res))
+    if mode == "coefficients":
+        return "coefficients", Coefficients(names, res)
+    pred = res
+    if valid is not None:                                      # make_predictions masks with is_valid (ex.rs:640-645)
+        nan = float("nan")
+        pred = torch.where(valid, pred, torch.full_like(pred, nan)) if _is_torch(pred) else np.where(valid, pred, nan)
+    if sw is not None:
+        pred = pred * (1.0 / sw)
+    if mode == "residuals":
+        pred = y - pred
+    return target.output_name, pred
+
+
+# ---- the reference's module-level functions (least_squares.py:242-491) -------------------------------------------
+
+def compute_least_squares(target, *features, sample_weights=None, add_intercept: bool = False,
+                          mode: str = "predictions", ols_kwargs: Optional[OLSKwargs] = None) -> Expr:
+    assert mode in _VALID_OUTPUT_MODES, f"'mode' must be one of {_VALID_OUTPUT_MODES}"
+    kw = ols_kwargs or OLSKwargs()
+    t, fs = parse_into_expr(target), [parse_into_expr(f) for f in features]
+    return Expr(t._name, fn=lambda frame, over, eng: _apply_static(frame, over, eng, t, fs, sample_weights, add_intercept, mode, kw))
+
+
+def compute_multi_target_least_squares(targets, *features, **kwargs) -> Expr:
+    raise NotImplementedError("multi-target regression (src/expressions.rs:521-591) is not built yet")
+
+
+def compute_recursive_least_squares(target, *features, sample_weights=None, add_intercept: bool = False,
+                                    mode: str = "predictions", rls_kwargs: Optional[RLSKwargs] = None) -> Expr:
+    valid_output_modes = _VALID_OUTPUT_MODES - {"statistics"}
+    assert mode in valid_output_modes, f"'mode' must be one of {valid_output_modes}"
+    kw = rls_kwargs or RLSKwargs()
+    t, fs = parse_into_expr(target), [parse_into_expr(f) for f in features]
+    return Expr(t._name, fn=lambda frame, over, eng: _apply_dynamic(frame, over, eng, t, fs, sample_weights, add_intercept, mode, "rls", kw))
+
+
+def compute_rolling_least_squares(target, *features, sample_weights=None, add_intercept: bool = False,
+                                  mode: str = "predictions", rolling_kwargs: Optional[RollingKwargs] = None) -> Expr:
+    valid_output_modes = _VALID_OUTPUT_MODES - {"statistics"}
+    assert mode in valid_output_modes, f"'mode' must be one of {valid_output_modes}"
+    kw = rolling_kwargs or RollingKwargs()
+    t, fs = parse_into_expr(target), [parse_into_expr(f) for f in features]
+    return Expr(t._name, fn=lambda frame, over, eng: _apply_dynamic(frame, over, eng, t, fs, sample_weights, add_intercept, mode, "rolling", kw))
+
+
+def _parse_formula(formula: str, include_dependent_variable: bool) -> Tuple[List[Expr], bool]:
+    """Additive patsy formulas only ("y ~ x1 + x2 - 1"): what the reference's README / tests use
+    (utils.py:61-108 delegates to patsy, which is absent here)."""
+    lhs, rhs = (formula.split("~", 1) + [None])[:2] if "~" in formula else (None, formula)
+    if rhs is None:
+        lhs, rhs = None, lhs
+    add_intercept = True
+    terms: List[str] = []
+    for sign, term in re.findall(r"([+-]?)\s*([A-Za-z_][A-Za-z_0-9]*|[01])", rhs):
+        if term in ("0", "1"):
+            if term == "0" or sign == "-":
+                add_intercept = False
+            continue
+        if sign == "-":
+            raise ValueError(f"cannot remove term '{term}'")
+        terms.append(term)
+    exprs = [col(t) for t in terms]
+    if include_dependent_variable:
+        assert lhs is not None and lhs.strip(), "formula needs a dependent variable"
+        exprs = [col(lhs.strip())] + exprs
+    return exprs, add_intercept
+
+
+def compute_least_squares_from_formula(formula: str, sample_weights=None, mode: str = "predictions", **kwargs) -> Expr:
+    exprs, add_intercept = _parse_formula(formula, include_dependent_variable=True)   # ls.py:432-452
+    if kwargs.get("half_life"):
+        return compute_recursive_least_squares(exprs[0], *exprs[1:], add_intercept=add_intercept, sample_weights=sample_weights,
+                                               mode=mode, rls_kwargs=RLSKwargs(**kwargs))
+    if kwargs.get("window_size"):
+        return compute_rolling_least_squares(exprs[0], *exprs[1:], add_intercept=add_intercept, sample_weights=sample_weights,
+                                             mode=mode, rolling_kwargs=RollingKwargs(**kwargs))
+    return compute_least_squares(exprs[0], *exprs[1:], add_intercept=add_intercept, sample_weights=sample_weights, mode=mode,
+                                 ols_kwargs=OLSKwargs(**kwargs))
+
+
+def predict(coefficients: Coefficients, *features, frame: Frame, null_policy: str = "zero", add_intercept: bool = False,
+            name: Optional[str] = None, engine: Optional[Engine] = None):
+    """least_squares.py:455-491 + src/expressions.rs:706-741: row-wise features . coefficients."""
+    assert null_policy in _VALID_NULL_POLICIES, "'null_policy' must be one of {drop, ignore, zero}"
+    fs = [parse_into_expr(f) for f in features]
+    xs = [f._column(frame) for f in fs]
+    if add_intercept and any(f.output_name == "const" for f in fs):
+        logger.warning("feature named 'const' already detected, assuming it is the intercept")
+        add_intercept = False
+    rows = coefficients.to_rows()
+    assert rows.shape[1] == len(xs) + int(add_intercept), "number of coefficients must match number of features!"  # ex.rs:717-721
+    eng = engine or default_engine(0)
+    valid = None
+    if null_policy == "drop":
+        valid = ~_isnan(xs[0])
+        for c in xs[1:]:
+            valid = valid & ~_isnan(c)
+    if null_policy != "ignore":
+        xs = [_nan_to_zero(c) for c in xs]
+    out = eng.predict(xs, rows, add_intercept=add_intercept)
+    if valid is not None:
+        nan = float("nan")
+        out = torch.where(valid, out, torch.full_like(out, nan)) if _is_torch(out) else np.where(valid, out, nan)
+    return out
+
+
+# ---- the `least_squares` namespace (polars_ols/__init__.py:35-295) -----------------------------------------------
+
+class LeastSquares:
+    def __init__(self, expr: Expr):
+        self._expr = expr
+
+    def least_squares(self, *features, sample_weights=None, add_intercept: bool = False, mode: str = "predictions",
+                      null_policy: str = "ignore", solve_method: Optional[str] = None, multi_target: bool = False,
+                      **ols_kwargs) -> Expr:
+        fn = compute_least_squares if not multi_target else compute_multi_target_least_squares
+        return fn(self._expr, *features, sample_weights=sample_weights, add_intercept=add_intercept, mode=mode,
+                  ols_kwargs=OLSKwargs(null_policy=null_policy, solve_method=solve_method, **ols_kwargs))
+
+    def ols(self, *features, **kwargs) -> Expr:
+        return self.least_squares(*features, **kwargs)
+
+    def multi_target_ols(self, *features, **kwargs) -> Expr:
+        return self.least_squares(*features, multi_target=True, **kwargs)
+
+    def wls(self, *features, sample_weights, **kwargs) -> Expr:
+        return self.least_squares(*features, sample_weights=sample_weights, **kwargs)
+
+    def ridge(self, *features, alpha: float, **kwargs) -> Expr:
+        return self.least_squares(*features, alpha=alpha, l1_ratio=0.0, **kwargs)
+
+    def lasso(self, *features, alpha: float, **kwargs) -> Expr:
+        return self.least_squares(*features, alpha=alpha, l1_ratio=1.0, **kwargs)
+
+    def elastic_net(self, *features, alpha: float, l1_ratio: float = 0.5, positive: bool = False, **kwargs) -> Expr:
+        return self.least_squares(*features, alpha=alpha, l1_ratio=l1_ratio, positive=positive, **kwargs)
+
+    def rls(self, *features, sample_weights=None, add_intercept: bool = False, mode: str = "predictions",
+            null_policy: str = "drop", half_life: Optional[float] = None, initial_state_covariance: Optional[float] = 10.0,
+            initial_state_mean=None) -> Expr:
+        return compute_recursive_least_squares(
+            self._expr, *features, sample_weights=sample_weights, add_intercept=add_intercept, mode=mode,
+            rls_kwargs=RLSKwargs(null_policy=null_policy, half_life=half_life, initial_state_mean=initial_state_mean,
+                                 initial_state_covariance=initial_state_covariance))
+
+    def rolling_ols(self, *features, window_size: int, sample_weights=None, add_intercept: bool = False,
+                    mode: str = "predictions", null_policy: str = "drop", min_periods: Optional[int] = None,
+                    use_woodbury: Optional[bool] = None, alpha: Optional[float] = None) -> Expr:
+        return compute_rolling_least_squares(
+            self._expr, *features, sample_weights=sample_weights, add_intercept=add_intercept, mode=mode,
+            rolling_kwargs=RollingKwargs(window_size=window_size, min_periods=min_periods, use_woodbury=use_woodbury,
+                                         alpha=alpha, null_policy=null_policy))
+
+    def expanding_ols(self, *features, **kwargs) -> Expr:
+        return self.rls(*features, half_life=None, **kwargs)
+
+    def from_formula(self, formula: str, **kwargs) -> Expr:
+        features, add_intercept = _parse_formula(formula, include_dependent_variable=False)
+        if kwargs.get("half_life"):
+            return self.rls(*features, add_intercept=add_intercept, **kwargs)
+        if kwargs.get("window_size"):
+            return self.rolling_ols(*features, add_intercept=add_intercept, **kwargs)
+        return self.least_squares(*features, add_intercept=add_intercept, **kwargs)

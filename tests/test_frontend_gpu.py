@@ -1,0 +1,184 @@
+"""The reference's own pytest cases (tests/test_ols.py) re-expressed against this repo's mirror of the `least_squares`
+namespace (polars_ols_amd.least_squares): same method names, kwargs and defaults; frames are dict-of-columns, null = NaN.
+Expected values come from numpy / the committed golden fixtures exactly as in the reference tests."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from refdata import insert_nulls, make_data  # noqa: E402
+
+
+def _df(d, extra=None):
+    from polars_ols_amd import Frame
+
+    f = Frame({k: v for k, v in d.items() if k != "x"})
+    if extra:
+        f.update(extra)
+    return f
+
+
+@pytest.mark.parametrize("solve_method", ("qr", "svd", "chol", "lu", None))
+def test_ols(solve_method):                                    # tests/test_ols.py:54-73
+    from polars_ols_amd import OLSKwargs, col, compute_least_squares
+
+    d = make_data(n_samples=1_000, n_features=2)
+    df = _df(d)
+    expr = compute_least_squares(col("y"), col("x1"), col("x2"), ols_kwargs=OLSKwargs(solve_method=solve_method)).alias("predictions")
+    pred = df.select(expr)["predictions"]
+    coef = np.linalg.lstsq(d["x"], d["y"], rcond=None)[0]
+    assert np.allclose(pred, d["x"] @ coef, atol=1.0e-4, rtol=1.0e-4)
+
+
+def test_coefficients_ols_groups_and_shape_broadcast():        # :377-433
+    from polars_ols_amd import col
+
+    d = make_data(n_groups=10)
+    df = _df(d)
+    c = df.select(col("y").least_squares.ols(col("x1"), col("x2"), mode="coefficients").over("group").alias("coefficients"))["coefficients"]
+    assert c.values.shape == (10, 2) and c.to_rows().shape == (5_000, 2) and c.names == ["x1", "x2"]
+    m = d["group"] == 1
+    c1 = _df({k: (v[m] if k != "x" else v) for k, v in d.items()}).select(
+        col("y").least_squares.ols(col("x1"), col("x2"), mode="coefficients"))["coefficients"]
+    assert c1.values.shape == (1, 2) and np.allclose(c.values[list(c.keys).index(1)], c1.values[0])
+    assert np.allclose(c.to_rows()[m], c1.values[0])
+
+
+def test_ols_intercept_residuals_formula_wls(golden):          # :436-472, :506-541
+    from polars_ols_amd import col, compute_least_squares, compute_least_squares_from_formula
+
+    z = golden["npz"]
+    d = make_data()
+    df = _df(d, {"sample_weights": z["wls_w"]})
+    y_hat = df.select(compute_least_squares(col("y"), col("x1"), col("x2"), add_intercept=True).alias("p"))["p"]
+    assert np.allclose(y_hat, z["intercept_pred"], atol=1e-4, rtol=1e-4)
+    res = df.select(col("y").least_squares.from_formula("x1 + x2 -1", mode="residuals"))["y"]
+    coef = np.linalg.lstsq(d["x"], d["y"], rcond=None)[0]
+    assert np.allclose(res, d["y"] - d["x"] @ coef, rtol=1e-4, atol=1e-4)
+    wls = df.select(compute_least_squares_from_formula("y ~ x1 + x2", sample_weights=col("sample_weights")).alias("p"))["p"]
+    assert np.allclose(wls, z["wls_pred"], rtol=1e-4, atol=1e-4)
+    c = df.select(col("y").least_squares.from_formula("x1 + x2", mode="coefficients"))["coefficients"]
+    assert c.names == ["x1", "x2", "const"]                    # intercept LAST and named "const" (least_squares.py:188)
+
+
+def test_least_squares_namespace_equivalences():               # :544-558
+    from polars_ols_amd import col
+
+    d = make_data()
+    df = _df(d, {"sample_weight": np.ones(5_000)})
+    out = df.select(
+        col("y").least_squares.ols(col("x1"), col("x2")).alias("ols"),
+        col("y").least_squares.ridge(col("x1"), col("x2"), alpha=0.0).alias("ridge"),
+        col("y").least_squares.wls(col("x1"), col("x2"), sample_weights=col("sample_weight")).alias("wls"),
+        col("y").least_squares.from_formula("x1 + x2 - 1").alias("formula"),
+    )
+    for k in ("ridge", "wls", "formula"):
+        assert np.allclose(out[k], out["ols"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("solve_method", ("svd", "chol"))
+def test_ridge(solve_method, golden):                          # :475-503
+    from polars_ols_amd import OLSKwargs, col, compute_least_squares
+
+    z = golden["npz"]
+    d = make_data()
+    pred = _df(d).select(compute_least_squares(col("y"), col("x1"), col("x2"),
+                                               ols_kwargs=OLSKwargs(alpha=0.01, solve_method=solve_method)).alias("p"))["p"]
+    assert np.allclose(pred, d["x"] @ z["ridge_coef_chol"], rtol=1e-4, atol=1e-4)
+
+
+def test_elastic_net_and_non_negative(golden):                 # :561-630
+    from polars_ols_amd import col
+
+    z = golden["npz"]
+    d = make_data(n_features=2)
+    df = _df(d)
+    p = df.select(col("y").least_squares.elastic_net("x1", "x2", mode="predictions", l1_ratio=0.5, alpha=0.1, max_iter=1_000,
+                                                     tol=0.0001, solve_method="cd"))["y"]
+    assert np.allclose(p, z["enet2_pred"], rtol=1e-4, atol=1e-4)
+    c = df.select(col("y").least_squares.elastic_net(col("x1"), -col("x2"), mode="coefficients", l1_ratio=0.5, alpha=0.1,
+                                                     max_iter=1_000, tol=0.0001, positive=True))["coefficients"]
+    assert np.allclose(c.values[0], z["nnls_coef"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("null_policy", ["drop", "drop_zero", "drop_y_zero_x"])
+def test_fit_missing_data_predictions_and_residuals(null_policy, golden):      # :179-249
+    from polars_ols_amd import col
+
+    z = golden["npz"]
+    x, y = z["nulls_x"], z["nulls_y"]
+    df = _df({"y": y, "x1": np.ascontiguousarray(x[:, 0]), "x2": np.ascontiguousarray(x[:, 1])})
+    pred = df.select(col("y").least_squares.ols(col("x1"), col("x2"), null_policy=null_policy, mode="predictions").alias("p"))["p"]
+    assert np.allclose(pred, z[f"nulls_{null_policy}_pred"], rtol=1e-4, atol=1e-4, equal_nan=True)
+    res = df.select(col("y").least_squares.ols(col("x1"), col("x2"), null_policy=null_policy, mode="residuals").alias("r"))["r"]
+    assert np.allclose(res, y - z[f"nulls_{null_policy}_pred"], rtol=1e-4, atol=1e-4, equal_nan=True)
+    c = df.select(col("y").least_squares.ols(col("x1"), col("x2"), null_policy=null_policy, mode="coefficients"))["coefficients"]
+    assert np.allclose(c.values[0], z[f"nulls_{null_policy}_coef"], rtol=1e-6)
+    # "zero" == fill_null(0) then "ignore" (:133-145)
+    a = df.select(col("y").least_squares.ols(col("x1"), col("x2"), null_policy="zero", mode="coefficients"))["coefficients"].values
+    f0 = _df({k: np.nan_to_num(v) for k, v in df.items()})
+    b = f0.select(col("y").least_squares.ols(col("x1"), col("x2"), null_policy="ignore", mode="coefficients"))["coefficients"].values
+    assert np.allclose(a, b)
+
+
+def test_recursive_least_squares_and_prior(golden):            # :633-715, :844-900
+    from polars_ols_amd import col
+
+    z = golden["npz"]
+    x, y = z["nulls_x"], z["nulls_y"]
+    df = _df({"y": y, "x1": np.ascontiguousarray(x[:, 0]), "x2": np.ascontiguousarray(x[:, 1])})
+    c = df.select(col("y").least_squares.rls(col("x1"), col("x2"), mode="coefficients", half_life=None,
+                                             initial_state_covariance=1_000_000.0, null_policy="drop"))["coefficients"]
+    assert np.allclose(c.values[-1], z["rls_expanding_last"], rtol=1e-4, atol=1e-4)
+    d = make_data()
+    c = _df(d).select(col("y").least_squares.rls(col("x1"), col("x2"), mode="coefficients", half_life=None,
+                                                 initial_state_covariance=1.0e-6, initial_state_mean=[0.25, 0.25]))["coefficients"]
+    assert np.allclose(c.values[0], [0.25, 0.25], rtol=1e-3, atol=1e-3) and np.allclose(c.values[10], [0.25, 0.25], rtol=1e-3, atol=1e-3)
+    assert not np.allclose(c.values[-1], [0.5, 0.5], rtol=1e-4, atol=1e-4)
+    # over("group"): expanding RLS with a diffuse prior ends at the per-group OLS
+    d = make_data(n_groups=10)
+    df = _df(d)
+    rls = df.select(col("y").least_squares.rls(col("x1"), col("x2"), half_life=None, initial_state_covariance=1.0e6,
+                                               mode="coefficients").over("group"))["coefficients"].values
+    for g in range(10):
+        last = np.nonzero(d["group"] == g)[0][-1]
+        assert np.allclose(rls[last], z["group_coef"][g], rtol=1e-4, atol=1e-4)
+
+
+def test_predict_complex_and_predict():                        # :903-944, :1075-1092
+    from polars_ols_amd import col, predict
+
+    d = make_data(n_groups=10)
+    df = _df(d)
+    out = df.select(col("y").least_squares.rls(col("x1"), col("x2"), mode="predictions").over("group").alias("p1"),
+                    col("y").least_squares.rls(col("x1"), col("x2"), mode="coefficients").over("group").alias("c"))
+    p2 = predict(out["c"], col("x1"), col("x2"), frame=df)
+    assert np.allclose(out["p1"], p2)
+    c = df.select(col("y").least_squares.ols(col("x1"), col("x2"), mode="coefficients", add_intercept=True).over("group"))["coefficients"]
+    p = predict(c, col("x1"), col("x2"), frame=df, add_intercept=True)
+    exp = df.select(col("y").least_squares.ols(col("x1"), col("x2"), add_intercept=True).over("group").alias("p"))["p"]
+    assert np.allclose(p, exp, rtol=1e-9, atol=1e-9)
+
+
+def test_python_side_validation():                             # least_squares.py:73-77, 109-118, 266
+    from polars_ols_amd import OLSKwargs, col, compute_least_squares
+
+    with pytest.raises(AssertionError):
+        OLSKwargs(null_policy="drop_window")
+    with pytest.raises(AssertionError):
+        OLSKwargs(solve_method="cholesky")
+    with pytest.raises(AssertionError):
+        compute_least_squares(col("y"), col("x1"), mode="preds")
+
+
+def test_device_frames_match_host_frames():
+    import torch
+    from polars_ols_amd import Frame, col
+
+    d = insert_nulls(make_data(n_groups=7), columns=("x1", "y"))
+    host = _df(d)
+    dev = Frame({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in host.items()})
+    for kw in (dict(null_policy="drop"), dict(null_policy="drop_zero", alpha=0.1), dict(null_policy="zero", add_intercept=True)):
+        a = host.select(col("y").least_squares.ols("x1", "x2", **kw).over("group").alias("p"))["p"]
+        b = dev.select(col("y").least_squares.ols("x1", "x2", **kw).over("group").alias("p"))["p"].cpu().numpy()
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-9, equal_nan=True)
