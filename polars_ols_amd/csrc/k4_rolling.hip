@@ -1,0 +1,277 @@
+// k4_rolling.hip -- K4 "rolling_gram_solve": rolling-window OLS, chunk-parallel.
+//
+// Replaces solve_rolling_ols (src/least_squares.rs:848-1032: warm-up :907-943, "drop" family :947-986, fixed
+// window "drop_window" :987-1029) + the dynamic make_predictions (src/expressions.rs:184, 695-700).
+//
+// The reference walks a sequence row by row keeping (X'X, X'y) of the current window -- add the new row, subtract
+// the row that leaves (NonWoodburyState::update :707-725) -- and solves a K x K system per row (Cholesky -> LU,
+// :732-734).  That state is a pure function of the data: S_i = P(i) - P(old(i)) with P the prefix sum of the valid
+// rows' outer products and old(i) = i - window (fixed window) or the row of the valid observation `window` ranks
+// back ("drop").  So the sequence is cut into chunks, ONE LANE PER CHUNK:
+//   pass 1  chunk_totals : per-chunk sums of the outer products                          (1 read of the rows)
+//   pass 2  chunk_scan   : exclusive prefix over each group's chunks                      (tiny)
+//   pass 3  chunk_walk   : the lane rebuilds S at its chunk start from the prefixes (<= 2 chunk lengths of row
+//                          work), then slides add/subtract exactly like the reference and runs the unrolled
+//                          Cholesky (LU on failure) per row in registers; coefficients of the rows that the
+//                          reference forward-fills (invalid rows, windows with too few observations) are carried.
+// A single 1M-row sequence thereby becomes ~4000 independent lanes instead of one dependency chain.  The Woodbury
+// variant (:737-787) propagates (X'X)^-1 instead of X'X: same mathematics, different rounding; it is not
+// reproduced -- `use_woodbury` is accepted and ignored.  All arithmetic is f64.
+#include "k4_rolling.hpp"
+#include "k1_kernel.inl"   // tri_index, chol_solve
+
+namespace pols {
+
+template <int K> struct K4N { static constexpr int NX = K * (K + 1) / 2; static constexpr int N = NX + K; };
+
+template <typename T, int K>
+struct K4Ctx {
+    const K4Args &a;
+    int64_t s;       // group start (absolute row)
+    int first_chunk;
+    __device__ __forceinline__ bool valid(int64_t i) const { return a.valid ? a.valid[s + i] != 0 : true; }
+    __device__ __forceinline__ int64_t cnt(int64_t i) const { return a.cnt ? (int64_t)a.cnt[s + i] : i + 1; }   // valid rows in [0, i]
+    __device__ __forceinline__ int64_t vidx(int64_t r) const { return a.vidx ? (int64_t)a.vidx[s + r] : r; }
+    __device__ __forceinline__ void load_row(int64_t i, double (&x)[K], double &y) const {
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[j] = (double)static_cast<const T *>(a.x[j])[s + i];
+        y = (double)static_cast<const T *>(a.y)[s + i];
+    }
+    // S += sign * [x x' (packed upper), x y]   (outer_product :600-607, update :714-723)
+    __device__ __forceinline__ void add_row(double (&S)[K4N<K>::N], int64_t i, double sign) const {
+        double x[K], y;
+        load_row(i, x, y);
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+#pragma unroll
+            for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] += sign * (x[p] * x[q]);
+            S[K4N<K>::NX + p] += sign * (x[p] * y);
+        }
+    }
+    // P(i): sum over the valid rows 0..i of the group (i < 0 -> 0), from the chunk prefix + a partial chunk
+    __device__ __forceinline__ void prefix(int64_t i, double (&P)[K4N<K>::N], double sign) const {
+        if (i < 0) return;
+        const int64_t c = i / a.chunk_len;
+        const double *pb = a.totals + (size_t)(first_chunk + c) * K4N<K>::N;
+#pragma unroll
+        for (int q = 0; q < K4N<K>::N; ++q) P[q] += sign * pb[q];
+        for (int64_t j = c * a.chunk_len; j <= i; ++j)
+            if (valid(j)) add_row(P, j, sign);
+    }
+};
+
+// Cholesky -> LU with partial pivoting (solve_normal_equations(.., None, Some(LU)), :732-734 / :277-337)
+template <int K>
+__device__ __noinline__ void lu_solve_small(const double *A, const double *b, double *x) {
+    double m[K][K], r[K];
+    for (int i = 0; i < K; ++i) { r[i] = b[i]; for (int j = 0; j < K; ++j) m[i][j] = A[i * K + j]; }
+    for (int j = 0; j < K; ++j) {
+        int p = j; double best = fabs(m[j][j]);
+        for (int i = j + 1; i < K; ++i) if (fabs(m[i][j]) > best) { best = fabs(m[i][j]); p = i; }
+        if (p != j) { for (int c = 0; c < K; ++c) { const double t = m[j][c]; m[j][c] = m[p][c]; m[p][c] = t; } const double t = r[j]; r[j] = r[p]; r[p] = t; }
+        const double d = m[j][j];
+        for (int i = j + 1; i < K; ++i) {
+            const double f = m[i][j] / d;
+            for (int c = j + 1; c < K; ++c) m[i][c] -= f * m[j][c];
+            r[i] -= f * r[j];
+        }
+    }
+    for (int i = K - 1; i >= 0; --i) {
+        double s = r[i];
+        for (int c = i + 1; c < K; ++c) s -= m[i][c] * x[c];
+        x[i] = s / m[i][i];
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void solve_state(const double (&S)[K4N<K>::N], double alpha, double (&beta)[K]) {
+    constexpr int NZ = K + 1;
+    double acc[(K + 1) * (K + 2) / 2];
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+#pragma unroll
+        for (int q = p; q < K; ++q) acc[tri_index<NZ>(p, q)] = S[tri_index<K>(p, q)];
+        acc[tri_index<NZ>(p, K)] = S[K4N<K>::NX + p];
+    }
+    acc[tri_index<NZ>(K, K)] = 0.0;
+    if (!chol_solve<double, K>(acc, alpha, beta)) {
+        double A[K * K], b[K], x[K];
+        for (int p = 0; p < K; ++p) {
+            for (int q = 0; q < K; ++q) A[p * K + q] = S[p <= q ? tri_index<K>(p, q) : tri_index<K>(q, p)] + (p == q ? alpha : 0.0);
+            b[p] = S[K4N<K>::NX + p];
+        }
+        lu_solve_small<K>(A, b, x);
+        for (int p = 0; p < K; ++p) beta[p] = x[p];
+    }
+}
+
+// ------------------------------------------------------------------ pass 1: per-chunk totals
+template <typename T, int K>
+__global__ void __launch_bounds__(64) k4_totals_kernel(const K4Args a) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_chunks) return;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    K4Ctx<T, K> cx{a, G.start, G.first_chunk};
+    double S[K4N<K>::N];
+#pragma unroll
+    for (int q = 0; q < K4N<K>::N; ++q) S[q] = 0.0;
+    for (int64_t i = ch.t0 - G.start; i < ch.t1 - G.start; ++i)
+        if (cx.valid(i)) cx.add_row(S, i, 1.0);
+#pragma unroll
+    for (int q = 0; q < K4N<K>::N; ++q) a.totals[(size_t)c * K4N<K>::N + q] = S[q];
+}
+
+// ------------------------------------------------------------------ pass 2: exclusive prefix over a group's chunks
+__global__ void __launch_bounds__(64) k4_scan_kernel(const K4Args a, const int nacc) {
+    const int64_t id = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t g = id / nacc;
+    const int q = (int)(id - g * nacc);
+    if (g >= a.n_groups) return;
+    const K4Group G = a.groups[g];
+    const int64_t n = G.end - G.start;
+    const int64_t nch = (n + a.chunk_len - 1) / a.chunk_len;
+    double run = 0.0;
+    for (int64_t c = 0; c < nch; ++c) {
+        double *p = a.totals + (size_t)(G.first_chunk + c) * nacc + q;
+        const double t = *p;
+        *p = run;
+        run += t;
+    }
+}
+
+// ------------------------------------------------------------------ pass 3: the walk
+template <typename T, int K>
+__global__ void __launch_bounds__(64) k4_walk_kernel(const K4Args a) {
+    constexpr int N = K4N<K>::N;
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_chunks) return;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    K4Ctx<T, K> cx{a, G.start, G.first_chunk};
+    const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
+    const int64_t w = a.window, mpv = G.mpv;
+    const bool drop = a.drop_mode != 0;
+    T *coef = static_cast<T *>(a.coef);
+    T *pred = static_cast<T *>(a.pred);
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+
+    if (G.all_nan) {                                       // :893-900
+        for (int64_t i = rel0; i < rel1; ++i) {
+            if (coef) for (int j = 0; j < K; ++j) coef[(G.start + i) * K + j] = (T)qnan;
+            if (pred) pred[G.start + i] = (T)qnan;
+        }
+        return;
+    }
+    // rows older than j_min are never subtracted: the warm-up adds every valid row of [0, mpv) (:909-921) and the
+    // sliding loop only starts subtracting at i = mpv (:989-990)
+    const int64_t j_min = drop ? 0 : max(mpv - w, (int64_t)0);
+    auto old_of = [&](int64_t i) -> int64_t {              // the row that has left the window once row i is in
+        if (!drop) return i - w;
+        const int64_t r = cx.cnt(i) - 1 - w;               // rank of the valid row `window` observations back
+        return r < 0 ? -1 : cx.vidx(r);
+    };
+    auto gate = [&](int64_t i) -> bool {                   // n_valid_window >= n_valid (:994-997, 1013, 1022)
+        const int64_t i_start = i >= w ? i - w : 0;        // saturating_sub (:990)
+        return cx.cnt(i) - cx.cnt(i_start) >= G.gate_n;
+    };
+    auto state_at = [&](int64_t i, double (&S)[N]) {       // (X'X, X'y) after row i has been processed
+#pragma unroll
+        for (int q = 0; q < N; ++q) S[q] = 0.0;
+        cx.prefix(i, S, 1.0);
+        const int64_t o = (i >= 0) ? old_of(i) : -1;
+        if (o >= j_min && i >= mpv) {                      // nothing is subtracted before the sliding loop starts
+            cx.prefix(o, S, -1.0);
+            cx.prefix(j_min - 1, S, 1.0);
+        }
+    };
+
+    double S[N], last[K];
+    state_at(rel0 - 1, S);
+    int64_t prev_old = (rel0 > 0 && rel0 - 1 >= mpv) ? old_of(rel0 - 1) : -1;
+    bool have_last = false;
+#pragma unroll
+    for (int j = 0; j < K; ++j) last[j] = qnan;
+    if (rel0 >= mpv && rel0 > 0) {                         // some earlier row already produced coefficients: carry them in
+        if (drop || rel0 - 1 == mpv - 1 || gate(rel0 - 1)) {
+            solve_state<K>(S, a.alpha, last);              // the state has not changed since the last solved row
+        } else {                                           // rare: the rows before this chunk were forward-filled
+            for (int64_t ip = rel0 - 2; ip >= mpv - 1; --ip) {
+                if (ip == mpv - 1 || gate(ip)) {
+                    double Sp[N];
+                    state_at(ip, Sp);
+                    solve_state<K>(Sp, a.alpha, last);
+                    break;
+                }
+            }
+        }
+        have_last = true;
+    }
+    (void)have_last;
+
+    for (int64_t i = rel0; i < rel1; ++i) {
+        const bool v = cx.valid(i);
+        if (v) cx.add_row(S, i, 1.0);                      // update XTX w/ latest data point
+        if (i >= mpv && (v || !drop)) {                    // subtract what left the window
+            const int64_t no = old_of(i);
+            if (drop) {
+                if (no != prev_old && no >= 0) cx.add_row(S, no, -1.0);
+            } else if (no >= j_min && no >= 0 && cx.valid(no)) {
+                cx.add_row(S, no, -1.0);
+            }
+            prev_old = no;
+        }
+        if (i >= mpv - 1) {
+            const bool do_solve = (i == mpv - 1) || (drop ? v : gate(i));
+            if (do_solve) solve_state<K>(S, a.alpha, last);
+        }
+        const int64_t row = G.start + i;
+        if (coef) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) coef[row * K + j] = (T)last[j];
+        }
+        if (pred) {                                        // (features * coefficients).sum_axis(1)  (ex.rs:184)
+            double x[K], y, p = 0.0;
+            cx.load_row(i, x, y);
+#pragma unroll
+            for (int j = 0; j < K; ++j) p += x[j] * last[j];
+            pred[row] = (T)p;
+        }
+    }
+}
+
+template <typename T, int K>
+static int k4_launch_k(pols_ctx *ctx, const K4Args &a) {
+    const unsigned blocks = (unsigned)((a.n_chunks + 63) / 64);
+    hipLaunchKernelGGL((k4_totals_kernel<T, K>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+    const int nacc = K4N<K>::N;
+    const unsigned sblocks = (unsigned)(((int64_t)a.n_groups * nacc + 63) / 64);
+    hipLaunchKernelGGL(k4_scan_kernel, dim3(sblocks), dim3(64), 0, ctx->stream, a, nacc);
+    timing_begin(ctx);
+    hipLaunchKernelGGL((k4_walk_kernel<T, K>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+    timing_end(ctx);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+template <typename T>
+static int k4_launch_t(pols_ctx *ctx, const K4Args &a) {
+    switch (a.k) {
+        case 1: return k4_launch_k<T, 1>(ctx, a);
+        case 2: return k4_launch_k<T, 2>(ctx, a);
+        case 3: return k4_launch_k<T, 3>(ctx, a);
+        case 4: return k4_launch_k<T, 4>(ctx, a);
+        case 5: return k4_launch_k<T, 5>(ctx, a);
+        case 6: return k4_launch_k<T, 6>(ctx, a);
+        case 7: return k4_launch_k<T, 7>(ctx, a);
+        case 8: return k4_launch_k<T, 8>(ctx, a);
+        default: return fail(POLS_ERR_UNSUPPORTED, "rolling: %d features > %d", a.k, K4_KMAX);
+    }
+}
+
+int k4_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
+    ctx->last_kernel = dtype == POLS_F32 ? "k4_rolling_walk_f32" : "k4_rolling_walk_f64";
+    return dtype == POLS_F32 ? k4_launch_t<float>(ctx, a) : k4_launch_t<double>(ctx, a);
+}
+
+}  // namespace pols

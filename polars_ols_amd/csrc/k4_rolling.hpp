@@ -1,0 +1,47 @@
+// k4_rolling.hpp -- K4 "rolling_gram_solve": rolling-window OLS for every group (see k4_rolling.hip).
+#pragma once
+#include "common.hpp"
+
+namespace pols {
+
+constexpr int K4_KMAX = 8;
+
+// One chunk of consecutive rows of one group, walked by one lane.
+struct K4Chunk {
+    int64_t t0, t1;      // absolute rows [t0, t1)
+    int32_t group;
+    int32_t index_in_group;
+};
+
+// Per-group constants of solve_rolling_ols (src/least_squares.rs:858-900).
+struct K4Group {
+    int64_t start, end;      // absolute rows
+    int64_t mpv;             // min_periods_valid (:881-891), relative to the group start
+    int64_t gate_n;          // n_valid as the loop of :883-891 leaves it (the n_valid_window gate of :1013,:1022)
+    int32_t first_chunk;
+    int32_t all_nan;         // early return of :893-900
+};
+
+struct K4Args {
+    const void *y;
+    const void *x[POLS_MAX_FEATURES];
+    const uint8_t *valid;        // or nullptr = all valid
+    const int32_t *cnt;          // inclusive count of valid rows inside the group, per row; nullptr when valid == nullptr
+    const int32_t *vidx;         // row (relative to the group) of the r-th valid row, per row slot; nullptr when valid == nullptr
+    const K4Chunk *chunks;
+    const K4Group *groups;
+    int64_t n_chunks;
+    int32_t n_groups;
+    double *totals;              // n_chunks x NACC: per-chunk sums, then exclusive prefix at the chunk start
+    void *coef;                  // n_rows x k or nullptr
+    void *pred;                  // n_rows or nullptr
+    int64_t window;
+    double alpha;
+    int32_t k;
+    int32_t drop_mode;           // 1: window over the last `window` VALID rows (:947-986); 0: fixed window (:987-1029)
+    int32_t chunk_len;
+};
+
+int k4_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+
+}  // namespace pols

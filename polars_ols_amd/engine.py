@@ -201,6 +201,25 @@ class Engine:
     def recursive_least_squares(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
         return self.plan_recursive_least_squares(y, x_cols, offsets, **kwargs).run()
 
+    def plan_rolling_least_squares(self, y, x_cols: Sequence, offsets, *, window_size: int, valid=None,
+                                   want: Sequence[str] = ("coef", "pred"), out: Optional[Dict] = None,
+                                   min_periods: Optional[int] = None, use_woodbury: Optional[bool] = None,
+                                   alpha: Optional[float] = None, null_policy: str = "drop_window") -> "Plan":
+        """solve_rolling_ols (src/least_squares.rs:848-1032) for every group; ``coef`` is n_rows x k, NaN where undefined."""
+        b, keep, dev, dt = self._batch(y, x_cols, offsets, None, valid, False)
+        res, o = self._dynamic_outputs(b, keep, dev, dt, want, out)
+        p = L.RollingParams()
+        self._lib.pols_rolling_params_default(C.byref(p))
+        p.window_size = int(window_size)
+        p.min_periods = -1 if min_periods is None else int(min_periods)
+        p.use_woodbury = -1 if use_woodbury is None else int(bool(use_woodbury))
+        p.alpha = float(alpha) if alpha is not None else 0.0
+        p.null_policy = L.NULL_POLICIES[null_policy]
+        return Plan(self, self._lib.pols_rolling_least_squares, b, p, o, res, keep)
+
+    def rolling_least_squares(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
+        return self.plan_rolling_least_squares(y, x_cols, offsets, **kwargs).run()
+
 
 class Plan:
     """A marshalled call: ctypes structs + references that keep every borrowed buffer alive."""
