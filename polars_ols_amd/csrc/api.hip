@@ -412,6 +412,8 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, con
     return stage_inputs(ctx, b, b->n_rows, b->n_features, o, st);
 }
 
+static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a);
+
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o) {
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
     const int64_t *d_offs = nullptr;
@@ -433,35 +435,40 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     a.initial_state_covariance = p->initial_state_covariance;
     if (p->initial_state_mean) {
         void *d = nullptr;
-        if ((rc = ensure_scratch(ctx, 4, sizeof(double) * POLS_MAX_FEATURES, &d))) return rc;
+        if ((rc = ensure_scratch(ctx, 6, sizeof(double) * POLS_MAX_FEATURES, &d))) return rc;
         POLS_HIP(hipMemcpyAsync(d, p->initial_state_mean, sizeof(double) * b->n_features, hipMemcpyHostToDevice, ctx->stream));
         POLS_HIP(hipStreamSynchronize(ctx->stream));   // the host array belongs to the caller
         a.mean0 = static_cast<const double *>(d);
     }
-    if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
+    // Long sequences: the chunk-parallel information-form scan (K3s); short ones: the wave-per-sequence P-form
+    // recursion (K3).  POLS_RLS_ENGINE=seq|scan forces one.
+    bool scan = max_rows > 4096 && b->n_features <= K4_KMAX;
+    if (const char *force = std::getenv("POLS_RLS_ENGINE")) {
+        if (!std::strcmp(force, "seq")) scan = false;
+        if (!std::strcmp(force, "scan") && b->n_features <= K4_KMAX) scan = true;
+    }
+    if (scan) {
+        const int k = b->n_features;
+        K4Args s4;
+        std::memset(&s4, 0, sizeof(s4));
+        if ((rc = build_chunk_tables(ctx, b, 1, k * (k + 1) / 2 + k + 1, &s4))) return rc;
+        s4.y = st.y; s4.valid = st.valid;
+        for (int j = 0; j < k; ++j) s4.x[j] = st.x[j];
+        s4.coef = st.coef; s4.pred = st.pred;
+        s4.k = k;
+        s4.ff = a.forgetting_factor; s4.p0 = a.initial_state_covariance; s4.mean0 = a.mean0;
+        if ((rc = k3s_launch(ctx, b->dtype, s4))) return rc;
+    } else {
+        if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
+    }
     return unstage_outputs(ctx, b, b->n_rows, b->n_features, o, st);
 }
 
-int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o) {
-    if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
-    const int64_t *d_offs = nullptr;
-    int64_t max_rows = 0;
-    Staged st;
-    int rc = dynamic_prologue(ctx, b, o, &d_offs, &max_rows, &st);
-    if (rc) return rc;
-    if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
-    if (o->resid) return fail(POLS_ERR_INVALID, "rolling: residuals are target - predictions in the caller (least_squares.py:239)");
-    const int k = b->n_features;
-    if (k > K4_KMAX) return fail(POLS_ERR_UNSUPPORTED, "rolling: %d features > %d", k, K4_KMAX);
-    if (p->window_size < 1) return fail(POLS_ERR_INVALID, "window_size must be >= 1");
-    const int64_t w = p->window_size;
-    const int64_t mp = p->min_periods >= 0 ? p->min_periods : std::min<int64_t>(k, w);          // ls.rs:860
-    if (mp < 1) return fail(POLS_ERR_INVALID, "min_periods must be >= 1 (the reference indexes row min_periods - 1, ls.rs:941-943)");
-    if (mp > w) return fail(POLS_ERR_UNSUPPORTED, "min_periods > window_size: the reference's warm-up then keeps rows the window never drops (ls.rs:869-876 warns); not reproduced");
-    const bool drop = p->null_policy == POLS_NULL_DROP || p->null_policy == POLS_NULL_DROP_ZERO ||
-                      p->null_policy == POLS_NULL_DROP_Y_ZERO_X;                                // ls.rs:947-950
-
-    // ---- host-side tables: validity prefix (cnt / vidx), per-group warm-up constants, chunk list
+// Host-side tables shared by the chunk-parallel dynamic kernels (K4 rolling, K3s RLS scan): validity prefix
+// (cnt / vidx), per-group warm-up constants of solve_rolling_ols (ls.rs:881-900) and the chunk list; uploaded to
+// scratch slot 4, the per-chunk totals live in slot 5 (`slots` doubles per chunk).
+static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a) {
+    int rc;
     const int64_t N = b->n_rows;
     std::vector<uint8_t> hvalid;
     const uint8_t *hv = nullptr;
@@ -475,14 +482,14 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
             hv = b->valid;
         }
     }
-    int64_t chunk_len = std::min<int64_t>(512, std::max<int64_t>(64, N / 16384));
+    const int64_t chunk_len = std::min<int64_t>(512, std::max<int64_t>(64, N / 16384));
     std::vector<K4Group> groups((size_t)b->n_groups);
     std::vector<K4Chunk> chunks;
     std::vector<int32_t> cnt, vidx;
     if (hv) { cnt.resize((size_t)N); vidx.assign((size_t)N, -1); }
     for (int64_t g = 0; g < b->n_groups; ++g) {
         const int64_t s = b->group_offsets[g], e = b->group_offsets[g + 1], n = e - s;
-        if (n > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "rolling: group longer than 2^31 rows");
+        if (n > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "group longer than 2^31 rows");
         K4Group G;
         G.start = s; G.end = e; G.first_chunk = (int32_t)chunks.size();
         int64_t mpv = mp, n_valid = 0;                                                           // ls.rs:881-891
@@ -508,13 +515,12 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         for (int64_t t = s, ci = 0; t < e; t += chunk_len, ++ci)
             chunks.push_back(K4Chunk{t, std::min(e, t + chunk_len), (int32_t)g, (int32_t)ci});
     }
-    const int nacc = k * (k + 1) / 2 + k;
     const size_t b_groups = round256(sizeof(K4Group) * groups.size());
     const size_t b_chunks = round256(sizeof(K4Chunk) * chunks.size());
     const size_t b_cnt = hv ? round256(sizeof(int32_t) * (size_t)N) : 0;
     void *tab = nullptr, *tot = nullptr;
-    if ((rc = ensure_scratch(ctx, 4, b_groups + b_chunks + 2 * b_cnt, &tab))) return rc;
-    if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)nacc * std::max<size_t>(1, chunks.size()), &tot))) return rc;
+    if ((rc = ensure_scratch(ctx, 4, b_groups + b_chunks + 2 * b_cnt + 256, &tab))) return rc;
+    if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)slots * std::max<size_t>(1, chunks.size()), &tot))) return rc;
     char *tp = static_cast<char *>(tab);
     POLS_HIP(hipMemcpyAsync(tp, groups.data(), sizeof(K4Group) * groups.size(), hipMemcpyHostToDevice, ctx->stream));
     POLS_HIP(hipMemcpyAsync(tp + b_groups, chunks.data(), sizeof(K4Chunk) * chunks.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -522,22 +528,46 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         POLS_HIP(hipMemcpyAsync(tp + b_groups + b_chunks, cnt.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
         POLS_HIP(hipMemcpyAsync(tp + b_groups + b_chunks + b_cnt, vidx.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
     }
+    POLS_HIP(hipStreamSynchronize(ctx->stream));   // the vectors above are locals
+    a->groups = reinterpret_cast<const K4Group *>(tp);
+    a->chunks = reinterpret_cast<const K4Chunk *>(tp + b_groups);
+    a->cnt = hv ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks) : nullptr;
+    a->vidx = hv ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks + b_cnt) : nullptr;
+    a->n_chunks = (int64_t)chunks.size();
+    a->n_groups = (int32_t)b->n_groups;
+    a->totals = static_cast<double *>(tot);
+    a->chunk_len = (int32_t)chunk_len;
+    return POLS_OK;
+}
+
+int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o) {
+    if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
+    const int64_t *d_offs = nullptr;
+    int64_t max_rows = 0;
+    Staged st;
+    int rc = dynamic_prologue(ctx, b, o, &d_offs, &max_rows, &st);
+    if (rc) return rc;
+    if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
+    if (o->resid) return fail(POLS_ERR_INVALID, "rolling: residuals are target - predictions in the caller (least_squares.py:239)");
+    const int k = b->n_features;
+    if (k > K4_KMAX) return fail(POLS_ERR_UNSUPPORTED, "rolling: %d features > %d", k, K4_KMAX);
+    if (p->window_size < 1) return fail(POLS_ERR_INVALID, "window_size must be >= 1");
+    const int64_t w = p->window_size;
+    const int64_t mp = p->min_periods >= 0 ? p->min_periods : std::min<int64_t>(k, w);          // ls.rs:860
+    if (mp < 1) return fail(POLS_ERR_INVALID, "min_periods must be >= 1 (the reference indexes row min_periods - 1, ls.rs:941-943)");
+    if (mp > w) return fail(POLS_ERR_UNSUPPORTED, "min_periods > window_size: the reference's warm-up then keeps rows the window never drops (ls.rs:869-876 warns); not reproduced");
+    const bool drop = p->null_policy == POLS_NULL_DROP || p->null_policy == POLS_NULL_DROP_ZERO ||
+                      p->null_policy == POLS_NULL_DROP_Y_ZERO_X;                                // ls.rs:947-950
+
     K4Args a;
     std::memset(&a, 0, sizeof(a));
+    if ((rc = build_chunk_tables(ctx, b, mp, k * (k + 1) / 2 + k, &a))) return rc;
     a.y = st.y; a.valid = st.valid;
     for (int j = 0; j < k; ++j) a.x[j] = st.x[j];
-    a.groups = reinterpret_cast<const K4Group *>(tp);
-    a.chunks = reinterpret_cast<const K4Chunk *>(tp + b_groups);
-    a.cnt = hv ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks) : nullptr;
-    a.vidx = hv ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks + b_cnt) : nullptr;
-    a.n_chunks = (int64_t)chunks.size();
-    a.n_groups = (int32_t)b->n_groups;
-    a.totals = static_cast<double *>(tot);
     a.coef = st.coef; a.pred = st.pred;
     a.window = w; a.alpha = p->alpha > 0.0 ? p->alpha : 0.0;                                    // ls.rs:865, 924-926
-    a.k = k; a.drop_mode = drop ? 1 : 0; a.chunk_len = (int32_t)chunk_len;
+    a.k = k; a.drop_mode = drop ? 1 : 0;
     if ((rc = k4_launch(ctx, b->dtype, a))) return rc;
-    POLS_HIP(hipStreamSynchronize(ctx->stream));   // the host tables above are locals
     return unstage_outputs(ctx, b, b->n_rows, k, o, st);
 }
 

@@ -43,8 +43,9 @@ struct pols_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int num_cus = 0;
-    // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] misc
-    pols::Scratch scratch[6];
+    // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] timeline stamps,
+    // [4] chunk / group tables, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean
+    pols::Scratch scratch[8];
     bool timing = false;
     std::vector<pols::TimedLaunch> timed;   // pool of event pairs
     size_t timed_used = 0;

@@ -269,6 +269,140 @@ static int k4_launch_t(pols_ctx *ctx, const K4Args &a) {
     }
 }
 
+// ====================================================================================================================
+// K3s: recursive least squares as a decayed scan (information form), same chunk machinery.
+//   RecursiveLeastSquares::update (ls.rs:531-540):  P' = P/ff - k k' r,  k = P x / (r ff),  r = 1 + x'P x / ff
+//   Sherman-Morrison:  P' = (ff P^-1 + x x')^-1,  and  coef' = P' (ff P^-1 coef + x y)
+//   => with A = P^-1, b = A coef:  A' = ff A + x x',  b' = ff b + x y,  coef' = A'^-1 b'   (invalid rows: no change).
+template <typename T, int K>
+__global__ void __launch_bounds__(64) k3s_totals_kernel(const K4Args a) {
+    constexpr int N = K4N<K>::N;
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_chunks) return;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    K4Ctx<T, K> cx{a, G.start, G.first_chunk};
+    double S[N], decay = 1.0;
+#pragma unroll
+    for (int q = 0; q < N; ++q) S[q] = 0.0;
+    for (int64_t i = ch.t0 - G.start; i < ch.t1 - G.start; ++i)
+        if (cx.valid(i)) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) S[q] *= a.ff;
+            cx.add_row(S, i, 1.0);
+            decay *= a.ff;
+        }
+#pragma unroll
+    for (int q = 0; q < N; ++q) a.totals[(size_t)c * (N + 1) + q] = S[q];
+    a.totals[(size_t)c * (N + 1) + N] = decay;
+}
+
+template <int K>
+__global__ void __launch_bounds__(64) k3s_scan_kernel(const K4Args a) {
+    constexpr int N = K4N<K>::N, NX = K4N<K>::NX;
+    const int64_t g = blockIdx.x;                 // one 64-thread block per group, thread q = component q
+    const int q = threadIdx.x;
+    const bool work = q < N;
+    const K4Group G = a.groups[g];
+    const int64_t n = G.end - G.start;
+    const int64_t nch = (n + a.chunk_len - 1) / a.chunk_len;
+    // carry-in of the first chunk = the prior: A_0 = I / p0, b_0 = A_0 mean0
+    double run = 0.0;
+    if (work && q < NX) {
+        int i = 0, rem = q;                       // packed upper index -> (i, j)
+        while (rem >= K - i) { rem -= K - i; ++i; }
+        if (rem == 0) run = 1.0 / a.p0;
+    } else if (work) {
+        run = a.mean0 ? a.mean0[q - NX] / a.p0 : 0.0;
+    }
+    for (int64_t c = 0; c < nch; ++c) {
+        double *row = a.totals + (size_t)(G.first_chunk + c) * (N + 1);
+        const double t = work ? row[q] : 0.0, d = row[N];
+        if (work) { row[q] = run; run = d * run + t; }   // slot N (the decay) is never overwritten
+    }
+}
+
+template <typename T, int K>
+__global__ void __launch_bounds__(64) k3s_walk_kernel(const K4Args a) {
+    constexpr int N = K4N<K>::N;
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_chunks) return;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    K4Ctx<T, K> cx{a, G.start, G.first_chunk};
+    const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
+    T *coef = static_cast<T *>(a.coef);
+    T *pred = static_cast<T *>(a.pred);
+    double S[N], last[K];
+#pragma unroll
+    for (int q = 0; q < N; ++q) S[q] = a.totals[(size_t)c * (N + 1) + q];
+    const bool seen = rel0 > 0 && cx.cnt(rel0 - 1) > 0;           // has any valid row updated the state yet?
+    if (seen) solve_state<K>(S, 0.0, last);
+    else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) last[j] = a.mean0 ? a.mean0[j] : 0.0;   // coef = initial_state_mean or zeros (:519-522)
+    }
+    for (int64_t i = rel0; i < rel1; ++i) {
+        double x[K], y;
+        cx.load_row(i, x, y);
+        if (cx.valid(i)) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) S[q] *= a.ff;
+#pragma unroll
+            for (int p = 0; p < K; ++p) {
+#pragma unroll
+                for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] += x[p] * x[q];
+                S[K4N<K>::NX + p] += x[p] * y;
+            }
+            solve_state<K>(S, 0.0, last);
+        }
+        const int64_t row = G.start + i;
+        if (coef) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) coef[row * K + j] = (T)last[j];
+        }
+        if (pred) {
+            double p = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) p += x[j] * last[j];
+            pred[row] = (T)p;
+        }
+    }
+}
+
+template <typename T, int K>
+static int k3s_launch_k(pols_ctx *ctx, const K4Args &a) {
+    const unsigned blocks = (unsigned)((a.n_chunks + 63) / 64);
+    hipLaunchKernelGGL((k3s_totals_kernel<T, K>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+    // one 64-thread block per group so that __syncthreads() covers all components of a group (N <= 44 < 64)
+    hipLaunchKernelGGL((k3s_scan_kernel<K>), dim3((unsigned)a.n_groups), dim3(64), 0, ctx->stream, a);
+    timing_begin(ctx);
+    hipLaunchKernelGGL((k3s_walk_kernel<T, K>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+    timing_end(ctx);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+template <typename T>
+static int k3s_launch_t(pols_ctx *ctx, const K4Args &a) {
+    switch (a.k) {
+        case 1: return k3s_launch_k<T, 1>(ctx, a);
+        case 2: return k3s_launch_k<T, 2>(ctx, a);
+        case 3: return k3s_launch_k<T, 3>(ctx, a);
+        case 4: return k3s_launch_k<T, 4>(ctx, a);
+        case 5: return k3s_launch_k<T, 5>(ctx, a);
+        case 6: return k3s_launch_k<T, 6>(ctx, a);
+        case 7: return k3s_launch_k<T, 7>(ctx, a);
+        case 8: return k3s_launch_k<T, 8>(ctx, a);
+        default: return fail(POLS_ERR_UNSUPPORTED, "rls: %d features > %d", a.k, K4_KMAX);
+    }
+}
+
+int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
+    ctx->last_kernel = dtype == POLS_F32 ? "k3s_rls_scan_walk_f32" : "k3s_rls_scan_walk_f64";
+    return dtype == POLS_F32 ? k3s_launch_t<float>(ctx, a) : k3s_launch_t<double>(ctx, a);
+}
+
 int k4_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
     ctx->last_kernel = dtype == POLS_F32 ? "k4_rolling_walk_f32" : "k4_rolling_walk_f64";
     return dtype == POLS_F32 ? k4_launch_t<float>(ctx, a) : k4_launch_t<double>(ctx, a);

@@ -40,8 +40,15 @@ struct K4Args {
     int32_t k;
     int32_t drop_mode;           // 1: window over the last `window` VALID rows (:947-986); 0: fixed window (:987-1029)
     int32_t chunk_len;
+    // RLS in information form (k3s_launch): totals rows carry one extra slot (the chunk's decay factor)
+    double ff;                   // forgetting factor (ls.rs:513-517)
+    double p0;                   // initial_state_covariance: A_0 = I / p0
+    const double *mean0;         // device, k values or nullptr
 };
 
 int k4_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+// Chunk-parallel RLS for long sequences: A_t = ff A_{t-1} + x x', b_t = ff b_{t-1} + x y (valid rows), beta_t = A_t^-1 b_t,
+// which is the reference's P-form recursion (ls.rs:531-540) by the Sherman-Morrison identity.
+int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 
 }  // namespace pols

@@ -15,6 +15,13 @@ def eng():
     e.close()
 
 
+@pytest.fixture(params=["seq", "scan"])
+def rls_engine(request, monkeypatch):
+    """K3 (wave-per-sequence P-form recursion) and K3s (chunk-parallel information-form scan) must both match."""
+    monkeypatch.setenv("POLS_RLS_ENGINE", request.param)
+    return request.param
+
+
 def _cuda(a):
     import torch
 
@@ -28,7 +35,7 @@ def _np(t):
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("k", [1, 2, 6, 8])
 @pytest.mark.parametrize("half_life,p0,mean", [(None, 10.0, None), (21.0, 10.0, None), (252.0, 0.01, 0.25), (None, 1e6, None)])
-def test_rls_many_groups(eng, dtype, tol, k, half_life, p0, mean):
+def test_rls_many_groups(eng, rls_engine, dtype, tol, k, half_life, p0, mean):
     from oracle import orc
 
     rng = np.random.default_rng(k)
@@ -44,6 +51,7 @@ def test_rls_many_groups(eng, dtype, tol, k, half_life, p0, mean):
                                       initial_state_covariance=p0, initial_state_mean=mean0)
     ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0,
                           is_valid=valid)
+    assert eng.last_kernel.startswith("k3s_" if rls_engine == "scan" else "k3_rls")
     scale = 1.0 if p0 < 1e5 else 50.0               # a diffuse prior makes the first rows ill-conditioned in ANY arithmetic
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol * scale, atol=tol * scale)
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol * scale, atol=tol * scale)
@@ -70,7 +78,7 @@ def test_rls_expanding_equals_ols_on_golden(eng, golden):
     assert np.allclose(out["coef"][-1], z["rls_expanding_last"], rtol=1e-4, atol=1e-4)
 
 
-def test_rls_cfg4_full_size_single_sequence(eng):
+def test_rls_cfg4_full_size_single_sequence(eng, rls_engine):
     """BASELINE configs[3]: one sequence of 1 000 000 rows, 6 features, half_life = 21, f64 -- the oracle is a
     sequential C loop, fast enough to check every row at full size."""
     from oracle import orc
