@@ -30,6 +30,21 @@
 
 static double *dalloc(size_t n) { return (double *)malloc(sizeof(double) * (n ? n : 1)); }
 
+/* Grow-only per-thread workspaces for the per-group hot loop of the batched driver: the reference allocates per
+ * call too, but through jemalloc (src/lib.rs:174-176); 100+ OpenMP threads hammering glibc malloc would make the
+ * CPU baseline look worse than the reference really is. */
+#define ORC_TLS_SLOTS 8
+static __thread double *tls_buf[ORC_TLS_SLOTS];
+static __thread size_t tls_cap[ORC_TLS_SLOTS];
+static double *tls_alloc(int slot, size_t n) {
+    if (n > tls_cap[slot]) {
+        free(tls_buf[slot]);
+        tls_cap[slot] = n + n / 4 + 64;
+        tls_buf[slot] = (double *)malloc(sizeof(double) * tls_cap[slot]);
+    }
+    return tls_buf[slot];
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -207,9 +222,10 @@ void orc_update_xtx_inv(const double *xtx_inv, const double *x_update, const dou
  * with column pivoting (largest remaining column norm), NO rank truncation,
  * then R z = (Q^T y)[:k], beta = P z.  Requires n >= k. */
 void orc_solve_ols_qr(const double *y, const double *x, int64_t n, int k, double *beta) {
-    double *a = dalloc((size_t)n * k); /* column-major */
-    double *b = dalloc((size_t)n);
-    int *jpvt = (int *)malloc(sizeof(int) * (k ? k : 1));
+    double *a = tls_alloc(0, (size_t)n * k); /* column-major */
+    double *b = tls_alloc(1, (size_t)n);
+    int jpvt_small[64];
+    int *jpvt = (k <= 64) ? jpvt_small : (int *)malloc(sizeof(int) * k);
     for (int64_t i = 0; i < n; ++i) {
         b[i] = y[i];
         for (int j = 0; j < k; ++j) a[(size_t)j * n + i] = x[i * k + j];
@@ -250,14 +266,14 @@ void orc_solve_ols_qr(const double *y, const double *x, int64_t n, int k, double
             for (int64_t i = j + 1; i < n; ++i) col[i] -= w * cj[i];
         }
     }
-    double *z = dalloc(k);
+    double *z = tls_alloc(2, (size_t)k);
     for (int i = k - 1; i >= 0; --i) {
         double s = (i < n) ? b[i] : 0.0;
         for (int p = i + 1; p < k; ++p) s -= a[(size_t)p * n + i] * z[p];
         z[i] = s / a[(size_t)i * n + i];
     }
     for (int i = 0; i < k; ++i) beta[jpvt[i]] = z[i];
-    free(a); free(b); free(jpvt); free(z);
+    if (jpvt != jpvt_small) free(jpvt);
 }
 
 /* ------------------------------------------------------------ SVD solvers */
@@ -751,13 +767,13 @@ int orc_batched_least_squares(const double *y, const double *const *x_cols,
 #endif
     for (int64_t g = 0; g < n_groups; ++g) {
         const int64_t s = offs[g], n = offs[g + 1] - offs[g];
-        double *xf = dalloc((size_t)n * kt), *yf = dalloc((size_t)n), *sw = NULL;
+        double *xf = tls_alloc(3, (size_t)n * kt), *yf = tls_alloc(4, (size_t)n), *sw = NULL;
         double beta[256];
         double *bp = (kt <= 256) ? beta : dalloc(kt);
         /* Python pre-processing, ls.py:184-196: sqrt_w = w.sqrt(); target *= sqrt_w;
          * every feature (intercept LAST, :188) *= sqrt_w. */
         if (weights) {
-            sw = dalloc((size_t)n);
+            sw = tls_alloc(5, (size_t)n);
             for (int64_t i = 0; i < n; ++i) sw[i] = sqrt(weights[s + i]);
         }
         /* plugin marshalling, ex.rs:22-63 + :79-91 */
@@ -786,7 +802,6 @@ int orc_batched_least_squares(const double *y, const double *const *x_cols,
             }
         }
         if (bp != beta) free(bp);
-        free(xf); free(yf); free(sw);
     }
     return err;
 }
