@@ -11,6 +11,7 @@
 #include "k5_enet.hpp"
 
 namespace pols {
+template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);   // k1m_f32.hip / k1m_f64.hip
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -348,8 +349,20 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
 
-    if (enet) {
-        // K5: one streaming Gram pass, Gram-form coordinate descent, then (only if asked for) a prediction pass
+    // Streamed three-launch path: elastic net always; OLS / ridge when the group does not fit the fused kernels
+    // (16..31 features, or rows beyond both K1's registers and K1m's LDS tile).  POLS_STATIC_ENGINE=stream forces it.
+    bool stream = enet;
+    if (!enet) {
+        const bool f32 = b->dtype == POLS_F32;
+        const int vec = f32 ? 4 : 2;
+        const bool fits_lds = f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
+                                  : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows);
+        const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
+        stream = kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
+        if (const char *force = std::getenv("POLS_STATIC_ENGINE")) stream = stream || !std::strcmp(force, "stream");
+    }
+    if (stream) {
+        // one streaming Gram pass, the small solve (Gram-form CD or Cholesky), then (only if asked for) a prediction pass
         void *scr = nullptr;
         const size_t nz = (size_t)kt + 1;
         const size_t gram_bytes = round256(sizeof(double) * nz * nz * (size_t)b->n_groups);
@@ -370,7 +383,12 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         ca.status = st.status;
         ca.alpha = alpha; ca.l1_ratio = enet_l1; ca.tol = p->tol; ca.max_iter = p->max_iter;
         ca.positive = positive ? 1 : 0; ca.active_set = (m == POLS_SOLVE_CD_ACTIVE_SET) ? 1 : 0; ca.kt = kt;
-        if ((rc = gram_cd_launch(ctx, b->dtype, ca))) return rc;
+        if (enet) {
+            if ((rc = gram_cd_launch(ctx, b->dtype, ca))) return rc;
+        } else {
+            ca.alpha = ridge_alpha;
+            if ((rc = gram_solve_launch(ctx, b->dtype, ca))) return rc;
+        }
         if (st.pred || st.resid) {
             PredictArgs pa;
             std::memset(&pa, 0, sizeof(pa));
@@ -384,7 +402,6 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
     }
 
-    if (kt > K1M_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "%d features (incl. intercept) > %d: the two-tile MFMA Gram is not built yet", kt, K1M_MAX_KT);
     K1Args a;
     std::memset(&a, 0, sizeof(a));
     a.y = st.y; a.w = st.w; a.valid = st.valid;
@@ -614,7 +631,6 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
 namespace pols {
 template <typename T> int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
 template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
-template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);
 
 // Engine choice for the static least-squares path:
 //   K1m (LDS tile + MFMA Gram)   groups whose tile fits the 160 KiB LDS and are big enough to fill a workgroup;

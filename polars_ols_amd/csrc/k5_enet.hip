@@ -278,6 +278,75 @@ int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a) {
     return POLS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ B': gram_solve
+// OLS / ridge from a streamed Gram matrix for any kt <= 31 (groups too big for K1 / K1m, or 16..31 features):
+// one wave per group, G + alpha I in LDS, lane i owns row i of the Cholesky factor (left-looking), then the two
+// triangular solves column by column with a lane broadcast per step.  Same pivot test as chol_solve (ls.rs:289-299).
+constexpr int GS_KMAX = 31;
+
+template <typename T>
+__global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
+    __shared__ double Ls[4][GS_KMAX * GS_KMAX];
+    __shared__ double rs[4][GS_KMAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t grp = (int64_t)blockIdx.x * 4 + wv;
+    if (grp >= a.n_groups) return;                     // wave-uniform; no block barriers below
+    const int kt = a.kt, NZ = kt + 1;
+    const double *G = a.gram + (size_t)grp * NZ * NZ;
+    double *L = Ls[wv];
+    double *rinv = rs[wv];
+    const int64_t n = a.offs[grp + 1] - a.offs[grp];
+    for (int q = lane; q < kt * kt; q += 64) {
+        const int i = q / kt, j = q - i * kt;
+        L[q] = G[i * NZ + j] + (i == j ? a.alpha : 0.0);
+    }
+    double bi = (lane < kt) ? G[lane * NZ + kt] : 0.0;          // X'y, one entry per lane
+    __builtin_amdgcn_wave_barrier();
+    bool ok = true;
+    for (int j = 0; j < kt; ++j) {
+        double d = L[j * kt + j];
+        for (int p = 0; p < j; ++p) d -= L[j * kt + p] * L[j * kt + p];
+        ok = ok && (d > 0.0);
+        const double ri = 1.0 / sqrt(d);
+        if (lane == 0) rinv[j] = ri;
+        if (lane > j && lane < kt) {
+            double sacc = L[lane * kt + j];
+            for (int p = 0; p < j; ++p) sacc -= L[lane * kt + p] * L[j * kt + p];
+            L[lane * kt + j] = sacc * ri;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // forward: t = L^-1 b   (lane i holds b_i / t_i)
+    for (int p = 0; p < kt; ++p) {
+        if (lane == p) bi *= rinv[p];
+        const double tp = __shfl(bi, p);
+        if (lane > p && lane < kt) bi -= L[lane * kt + p] * tp;
+    }
+    // backward: beta = L^-T t
+    for (int p = kt - 1; p >= 0; --p) {
+        if (lane == p) bi *= rinv[p];
+        const double bp = __shfl(bi, p);
+        if (lane < p) bi -= L[p * kt + lane] * bp;
+    }
+    int st = POLS_GROUP_OK;
+    if (n == 0) { bi = 0.0; st = POLS_GROUP_EMPTY; }
+    else if (!ok) st = POLS_GROUP_FALLBACK;
+    if (lane < kt) {
+        if (a.coef) static_cast<T *>(a.coef)[grp * kt + lane] = (T)bi;
+        if (a.coef64) a.coef64[grp * kt + lane] = bi;
+    }
+    if (lane == 0 && a.status) a.status[grp] = st;
+}
+
+int gram_solve_launch(pols_ctx *ctx, int dtype, const CdArgs &a) {
+    if (a.kt > GS_KMAX) return fail(POLS_ERR_UNSUPPORTED, "%d features (incl. intercept) > %d", a.kt, GS_KMAX);
+    const unsigned blocks = (unsigned)((a.n_groups + 3) / 4);
+    if (dtype == POLS_F32) hipLaunchKernelGGL(gram_solve_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(gram_solve_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ C: predict
 // pred[r] = sum_j x_j[r] * c_j with c = per-group coefficients (f64) or per-row coefficients (dynamic models,
 // src/expressions.rs:184); residuals = y - pred.  With sample weights the reference's arithmetic is kept:

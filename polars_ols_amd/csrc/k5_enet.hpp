@@ -57,6 +57,8 @@ struct PredictArgs {
 
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a);
 int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a);
+// OLS / ridge (alpha = ridge penalty) from the streamed Gram: generic kt <= 31, any group size
+int gram_solve_launch(pols_ctx *ctx, int dtype, const CdArgs &a);
 int predict_launch(pols_ctx *ctx, int dtype, const PredictArgs &a);
 
 }  // namespace pols

@@ -85,7 +85,9 @@ def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, varian
                             want=("coef", "pred", "resid", "status"))
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True)
     _check(out, ref, dtype)
-    assert (variant in eng.last_kernel) if (engine_kind == "valu" or (hi > 4000 and dtype == np.float64)) else eng.last_kernel.startswith("k1m_"), eng.last_kernel
+    big_f64 = hi > 4000 and dtype == np.float64        # neither registers nor the LDS tile hold 5000 f64 rows: streamed path
+    ok = eng.last_kernel.startswith("k5_gram_stream") if big_f64 else ((variant in eng.last_kernel) if engine_kind == "valu" else eng.last_kernel.startswith("k1m_"))
+    assert ok, eng.last_kernel
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

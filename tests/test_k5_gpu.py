@@ -152,3 +152,38 @@ def test_cfg5_shape_medium(eng):
         lhs = (cols[j].view(G, n) * r).sum(1)
         rhs = n * 0.001 * (0.5 * torch.sign(w[:, j]) + 0.5 * w[:, j])
         assert float((lhs - rhs).abs().max()) < 5e-2    # tol = 1e-5 on w times ||x_j||^2 ~ 2000
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 2e-4)])
+@pytest.mark.parametrize("k,alpha,weights,icpt", [(16, 0.0, False, False), (20, 1.0, True, True), (31, 0.0, False, False),
+                                                  (24, 0.3, False, True)])
+def test_static_ols_ridge_wide_features_streamed(eng, dtype, tol, k, alpha, weights, icpt):
+    """16..31 features (incl. intercept): streamed two-tile MFMA Gram + wave-cooperative Cholesky + prediction pass."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k)
+    sizes = rng.integers(200, 1500, size=13)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k - int(icpt), dtype, sparsity=0.0, weights=weights)
+    kw = dict(alpha=alpha, l1_ratio=0.0) if alpha else {}
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
+                            add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream") and int(_np(out["status"]).sum()) == 0
+    for key in ("coef", "pred", "resid"):
+        assert np.allclose(_np(out[key]), ref[key], rtol=tol, atol=tol), (key, float(np.abs(_np(out[key]) - ref[key]).max()))
+
+
+def test_static_huge_groups_streamed(eng):
+    """Groups far beyond K1's registers and K1m's LDS tile (60 000 rows x 8 features f64) take the streamed path."""
+    from oracle import orc
+
+    rng = np.random.default_rng(3)
+    offs = np.array([0, 60_000, 60_003, 135_000], dtype=np.int64)
+    y, cols, w = _frame(rng, offs, 8, np.float64, sparsity=0.0, weights=True)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), alpha=2.0, l1_ratio=0.0,
+                            want=("coef", "pred"))
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, alpha=2.0, l1_ratio=0.0)
+    assert eng.last_kernel.startswith("k5_gram_stream")
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
