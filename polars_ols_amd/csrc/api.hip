@@ -9,6 +9,7 @@
 #include "k3_rls.hpp"
 #include "k4_rolling.hpp"
 #include "k5_enet.hpp"
+#include "k6_svd.hpp"
 
 namespace pols {
 template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);   // k1m_f32.hip / k1m_f64.hip
@@ -235,6 +236,7 @@ void pols_destroy(pols_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->scratch)
         if (s.ptr) hipFree(s.ptr);
+    if (ctx->fb_flag) hipFree(ctx->fb_flag);
     for (auto &t : ctx->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -348,6 +350,49 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
+    // Every static solve is followed by the SVD fix-up pass over the groups it flags, so a status buffer always exists.
+    if (!enet && !st.status) {
+        void *sp = nullptr;
+        if ((rc = ensure_scratch(ctx, 7, sizeof(int32_t) * (size_t)b->n_groups, &sp))) return rc;
+        st.status = static_cast<int32_t *>(sp);
+    }
+    // OLS branch (the reference solves it with a backward-stable pivoted QR / dgelsd): flag groups whose Cholesky
+    // pivots say cond(X)^2 would exceed the tolerance (1e-6 f64, 1e-4 f32).  Ridge branch: the reference itself
+    // solves the normal equations, so only a failed factorisation is flagged.
+    if (!enet) {
+        if (!ctx->fb_flag) {
+            POLS_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->fb_flag), 256));
+            POLS_HIP(hipMemsetAsync(ctx->fb_flag, 0, 256, ctx->stream));
+        }
+        ctx->epoch = (ctx->epoch % 0x3fffffff) + 1;
+    }
+    const bool ols_branch = !enet && ridge_alpha == 0.0 && (m == POLS_SOLVE_AUTO || m == POLS_SOLVE_SVD || m == POLS_SOLVE_QR) && alpha == 0.0;
+    const double pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : 0.0;
+    auto svd_fixup = [&]() -> int {
+        if (enet) return POLS_OK;
+        const int workers = (int)std::min<int64_t>(b->n_groups, 64);
+        const int64_t stride = std::max<int64_t>(1, max_rows) * (kt + 1);
+        void *wk = nullptr;
+        int w_use = workers;
+        while (w_use > 1 && (double)w_use * (double)stride * 8.0 > 4e9) w_use /= 2;
+        int r2;   // slot 5 holds the Gram matrices / coef64 of the streamed path: the work area gets its own slot
+        if ((r2 = ensure_scratch(ctx, 3, sizeof(double) * (size_t)w_use * (size_t)stride, &wk))) return r2;
+        K6Args ka;
+        std::memset(&ka, 0, sizeof(ka));
+        ka.y = st.y; ka.w = st.w;
+        for (int j = 0; j < b->n_features; ++j) ka.x[j] = st.x[j];
+        ka.offs = d_offs; ka.n_groups = b->n_groups; ka.status = st.status;
+        ka.fb_flag = ctx->fb_flag; ka.epoch = ctx->epoch;
+        ka.coef = st.coef; ka.pred = st.pred; ka.resid = st.resid;
+        ka.work = static_cast<double *>(wk); ka.work_stride = stride;
+        ka.alpha = ridge_alpha;
+        // dgelsd drops s < eps * s_max (ls.rs:181-191, rcond ignored); solve_ridge_svd: rcond or eps * max(n, k) (ls.rs:143-145);
+        // the Cholesky -> LU fallback of solve_ridge (ls.rs:358-363) has no cut-off at all.
+        ka.rc_factor = ols_branch ? 2.220446049250313e-16
+                                  : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt)) : 0.0);
+        ka.k_user = b->n_features; ka.kt = kt;
+        return k6_launch(ctx, b->dtype, ka, w_use);
+    };
 
     // Streamed three-launch path: elastic net always; OLS / ridge when the group does not fit the fused kernels
     // (16..31 features, or rows beyond both K1's registers and K1m's LDS tile).  POLS_STATIC_ENGINE=stream forces it.
@@ -387,6 +432,8 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
             if ((rc = gram_cd_launch(ctx, b->dtype, ca))) return rc;
         } else {
             ca.alpha = ridge_alpha;
+            ca.pivot_tol = pivot_tol;
+            ca.fb_flag = ctx->fb_flag; ca.epoch = ctx->epoch;
             if ((rc = gram_solve_launch(ctx, b->dtype, ca))) return rc;
         }
         if (st.pred || st.resid) {
@@ -399,6 +446,7 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
             pa.k_user = b->n_features; pa.kt = kt;
             if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
         }
+        if ((rc = svd_fixup())) return rc;
         return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
     }
 
@@ -411,8 +459,11 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     a.n_rows = b->n_rows;
     a.coef = st.coef; a.pred = st.pred; a.resid = st.resid; a.status = st.status;
     a.alpha = ridge_alpha;
+    a.pivot_tol = pivot_tol;
+    a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.k_user = b->n_features;
     if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
+    if ((rc = svd_fixup())) return rc;
     return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
 }
 

@@ -38,6 +38,9 @@ struct K1Args {
     void *resid;                         // n_rows or nullptr
     int32_t *status;                     // n_groups or nullptr
     double alpha;                        // ridge penalty added to diag(X^T X) (ls.rs:355-356)
+    int32_t *fb_flag;                    // device word stamped with `epoch` when any group is flagged (lets K6 exit at once otherwise)
+    int32_t epoch;
+    double pivot_tol;                    // flag the group for the SVD fallback when a Cholesky pivot d_j <= pivot_tol * G_jj
     int32_t k_user;                      // KT - add_intercept
     unsigned long long *dbg;             // POLS_TIMELINE=1: 8 s_memtime stamps per group (debug only)
 };

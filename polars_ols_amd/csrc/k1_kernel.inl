@@ -100,7 +100,7 @@ __device__ __forceinline__ double inv_sqrt(double d) { return 1.0 / sqrt(d); }
 // Cholesky (LL^T) of G + alpha I and the two triangular solves, fully unrolled on wave-uniform values.
 // Returns false on a non-positive pivot (faer's `cholesky(Side::Lower)` Err, ls.rs:289-299).
 template <typename T, int KT>
-__device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 2], T alpha, T (&beta)[KT]) {
+__device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 2], T alpha, T (&beta)[KT], T pivot_tol = T(0)) {
     constexpr int NZ = KT + 1;
     T L[KT][KT];
     T rinv[KT];
@@ -110,7 +110,9 @@ __device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 
         T d = acc[tri_index<NZ>(j, j)] + alpha;
 #pragma unroll
         for (int p = 0; p < j; ++p) d = fma(-L[j][p], L[j][p], d);
-        ok = ok && (d > T(0));
+        // d / G_jj = sin^2 of the angle between column j and the span of the columns before it: a tiny ratio means
+        // cond(X)^2 exceeds what the normal equations can deliver -> the group goes to the SVD fallback (K6)
+        ok = ok && (d > pivot_tol * (acc[tri_index<NZ>(j, j)] + alpha));
         rinv[j] = inv_sqrt(d);   // 1 / L[j][j]; the solves below only ever divide by the diagonal
 #pragma unroll
         for (int i = j + 1; i < KT; ++i) {
@@ -254,8 +256,8 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
             for (int j = 0; j < KT; ++j) beta[j] = T(0);
             st = POLS_GROUP_EMPTY;
         } else {
-            const bool ok = chol_solve<T, KT>(acc, (T)a.alpha, beta);
-            if (!ok) st = POLS_GROUP_FALLBACK;   // host re-dispatches this group to the fallback solver
+            const bool ok = chol_solve<T, KT>(acc, (T)a.alpha, beta, (T)a.pivot_tol);
+            if (!ok) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }   // K6 re-solves this group
         }
         if (tid == 0 && a.status) a.status[g] = st;
         if (tid < KT) {

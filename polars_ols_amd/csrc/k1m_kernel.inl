@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
         for (int j = 0; j < KT; ++j) beta[j] = T(0);
         st = POLS_GROUP_EMPTY;
     } else {
-        const bool ok = chol_solve<T, KT>(gacc, (T)a.alpha, beta);
-        if (!ok) st = POLS_GROUP_FALLBACK;
+        const bool ok = chol_solve<T, KT>(gacc, (T)a.alpha, beta, (T)a.pivot_tol);
+        if (!ok) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
     }
     if (tid == 0 && a.status) a.status[g] = st;
     if (a.coef && tid < KT) {

@@ -305,8 +305,9 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
     bool ok = true;
     for (int j = 0; j < kt; ++j) {
         double d = L[j * kt + j];
+        const double gjj = d;
         for (int p = 0; p < j; ++p) d -= L[j * kt + p] * L[j * kt + p];
-        ok = ok && (d > 0.0);
+        ok = ok && (d > a.pivot_tol * gjj);
         const double ri = 1.0 / sqrt(d);
         if (lane == 0) rinv[j] = ri;
         if (lane > j && lane < kt) {
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
     }
     int st = POLS_GROUP_OK;
     if (n == 0) { bi = 0.0; st = POLS_GROUP_EMPTY; }
-    else if (!ok) st = POLS_GROUP_FALLBACK;
+    else if (!ok) { st = POLS_GROUP_FALLBACK; if (lane == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
     if (lane < kt) {
         if (a.coef) static_cast<T *>(a.coef)[grp * kt + lane] = (T)bi;
         if (a.coef64) a.coef64[grp * kt + lane] = bi;

@@ -37,6 +37,9 @@ struct CdArgs {
     double *coef64;      // n_groups x kt f64 scratch handed to the prediction pass
     int32_t *status;
     double alpha, l1_ratio, tol;
+    double pivot_tol;    // gram_solve only: see K1Args::pivot_tol
+    int32_t *fb_flag;    // gram_solve only: see K1Args::fb_flag
+    int32_t epoch;
     int64_t max_iter;
     int32_t positive, active_set, kt;
 };

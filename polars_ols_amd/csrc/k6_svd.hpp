@@ -1,0 +1,28 @@
+// k6_svd.hpp -- launch interface of K6 (see k6_svd.hip).
+#pragma once
+#include "common.hpp"
+
+namespace pols {
+
+struct K6Args {
+    const void *y;
+    const void *w;
+    const void *x[POLS_MAX_FEATURES];
+    const int64_t *offs;
+    int64_t n_groups;
+    const int32_t *fb_flag;  // the pass is a no-op unless *fb_flag == epoch (some group was flagged in THIS call)
+    int32_t epoch;
+    const int32_t *status;   // groups with POLS_GROUP_FALLBACK are (re)solved, the rest skipped
+    void *coef;
+    void *pred;
+    void *resid;
+    double *work;            // workers x work_stride doubles
+    int64_t work_stride;     // >= (kt + 1) * max_group_rows
+    double alpha;            // 0: minimum-norm least squares; > 0: ridge via d = s / (s^2 + alpha)
+    double rc_factor;        // singular values below rc_factor * s_max are dropped
+    int32_t k_user, kt;
+};
+
+int k6_launch(pols_ctx *ctx, int dtype, const K6Args &a, int workers);
+
+}  // namespace pols

@@ -1,0 +1,135 @@
+"""GPU tests of K6, the SVD fallback for groups the fused kernels flag: rank-deficient / wide (n <= k) / ill-conditioned /
+NaN groups.  Expected values: numpy's lstsq (LAPACK dgelsd -- what the reference's solve_ols_svd calls on linux,
+src/least_squares.rs:183-191) and the CPU oracle; cases from reference tests/test_ols.py:272-360."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from polars_ols_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _cuda(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _np(t):
+    return t.double().cpu().numpy() if hasattr(t, "cpu") else np.asarray(t, dtype=np.float64)
+
+
+@pytest.mark.parametrize("k", [2, 10, 16, 31])
+def test_fit_wide_min_norm(eng, k):                                  # tests/test_ols.py:272-312: n = 10 rows, k features
+    from refdata import make_data
+
+    d = make_data(n_samples=10, n_features=k, scale=1e-4)
+    cols = [np.ascontiguousarray(d["x"][:, j]) for j in range(k)]
+    out = eng.least_squares(d["y"], cols, [0, 10], want=("coef", "pred", "status"))
+    exp = np.linalg.lstsq(d["x"], d["y"], rcond=None)[0]
+    assert np.allclose(out["coef"][0], exp, rtol=1e-6, atol=1e-8)
+    assert np.corrcoef(out["pred"], d["y"])[0, 1] == pytest.approx(1.0, rel=1e-5, abs=1e-5)
+    assert out["status"][0] == (1 if k > 10 else 0)                 # n < k -> X'X is singular -> fallback taken (n == k: still PD)
+
+
+@pytest.mark.parametrize("n_features,solve_method", [(10, "svd"), (30, "svd"), (10, "qr"), (10, None)])
+def test_fit_multi_collinear(eng, n_features, solve_method):         # tests/test_ols.py:315-360
+    from refdata import make_data
+
+    d = make_data(n_samples=100, n_features=n_features, scale=1e-4)
+    x = np.column_stack([d["x"], d["x"][:, -1] + 1e-12])
+    cols = [np.ascontiguousarray(x[:, j]) for j in range(x.shape[1])]
+    out = eng.least_squares(d["y"], cols, [0, 100], solve_method=solve_method, rcond=1e-16, want=("coef", "status"))
+    coef = out["coef"][0]
+    exp = np.linalg.lstsq(x, d["y"], rcond=1e-16)[0]
+    assert out["status"][0] == 1 and np.isfinite(coef).all()
+    assert np.allclose(x @ coef, x @ exp, rtol=1e-4, atol=1e-4)
+    if solve_method == "svd":
+        assert np.allclose(coef, exp, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_degenerate_groups_do_not_disturb_healthy_ones(eng, dtype):
+    from oracle import orc
+
+    rng = np.random.default_rng(0)
+    sizes = np.array([400, 5, 300, 250, 3, 500])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N, k = int(offs[-1]), 6
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(c.astype(np.float64) for c in cols) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    cols[2][offs[2]:offs[3]] = 0.0                                   # group 2: an all-zero feature (rank deficient)
+    cols[4][offs[3]:offs[4]] = cols[3][offs[3]:offs[4]]              # group 3: two identical features
+    yd = _cuda(y); cd = [_cuda(c) for c in cols]
+    out = eng.least_squares(yd, cd, offs, want=("coef", "pred", "status"))
+    st = _np(out["status"]).astype(int)
+    assert list(st) == [0, 1, 1, 1, 1, 0]                            # groups 1 and 4 have n < k
+    tol = 1e-6 if dtype == np.float64 else 2e-4
+    coef, pred = _np(out["coef"]), _np(out["pred"])
+    for g in (0, 5):                                                 # healthy groups: the reference's QR answer
+        sl = slice(offs[g], offs[g + 1])
+        ref = orc.batched_least_squares(y[sl], [c[sl] for c in cols], [0, sizes[g]])
+        assert np.allclose(coef[g], ref["coef"][0], rtol=tol, atol=tol)
+        assert np.allclose(pred[sl], ref["pred"], rtol=tol, atol=tol)
+    for g in (1, 2, 3, 4):                                           # degenerate groups: dgelsd's minimum-norm answer
+        sl = slice(offs[g], offs[g + 1])
+        x = np.column_stack([c[sl].astype(np.float64) for c in cols])
+        exp = np.linalg.lstsq(x, y[sl].astype(np.float64), rcond=None)[0]
+        t = 1e-6 if dtype == np.float64 else 5e-3
+        assert np.allclose(x @ coef[g], x @ exp, rtol=t, atol=t)
+        assert np.allclose(pred[sl], x @ coef[g], rtol=t, atol=t)
+        if dtype == np.float64:
+            assert np.allclose(coef[g], exp, rtol=1e-6, atol=1e-8)
+
+
+def test_nan_group_gives_nan_like_reference(eng):
+    """null_policy='ignore' turns a null into NaN (src/expressions.rs:53); the reference's QR then returns NaN
+    coefficients for that group only."""
+    rng = np.random.default_rng(1)
+    offs = np.array([0, 200, 400], dtype=np.int64)
+    cols = [rng.standard_normal(400) for _ in range(3)]
+    y = sum(cols) + 0.1 * rng.standard_normal(400)
+    cols[1][250] = np.nan
+    out = eng.least_squares(y, cols, offs, want=("coef", "pred"))
+    assert np.isfinite(out["coef"][0]).all() and np.isnan(out["coef"][1]).all()
+    assert np.isfinite(out["pred"][:200]).all() and np.isnan(out["pred"][200:]).all()
+
+
+def test_ill_conditioned_f32_group_is_rescued_in_f64(eng):
+    """corr(x1, x2) = 0.99995: cond(X)^2 ~ 4e4 is beyond an f32 normal-equation solve; the pivot test sends the group
+    to the f64 Jacobi fallback, which keeps the 1e-4 parity with the reference's (f64, QR) answer."""
+    from oracle import orc
+
+    rng = np.random.default_rng(2)
+    n = 1000
+    x1 = rng.standard_normal(n)
+    x2 = x1 + 0.01 * rng.standard_normal(n)
+    x3 = rng.standard_normal(n)
+    y = x1 + x2 + x3 + 0.1 * rng.standard_normal(n)
+    cols = [c.astype(np.float32) for c in (x1, x2, x3)]
+    y32 = y.astype(np.float32)
+    out = eng.least_squares(_cuda(y32), [_cuda(c) for c in cols], [0, n], want=("coef", "pred", "status"))
+    ref = orc.batched_least_squares(y32, cols, [0, n])
+    assert int(out["status"][0]) == 1
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-4, atol=1e-4)
+
+
+def test_ridge_on_collinear_data_needs_no_fallback(eng):
+    from oracle import orc
+
+    rng = np.random.default_rng(3)
+    n = 300
+    x1 = rng.standard_normal(n)
+    cols = [x1, x1.copy(), rng.standard_normal(n)]
+    y = x1 + cols[2] + 0.1 * rng.standard_normal(n)
+    out = eng.least_squares(y, cols, [0, n], alpha=0.5, l1_ratio=0.0, want=("coef", "status"))
+    ref = orc.batched_least_squares(y, cols, [0, n], alpha=0.5, l1_ratio=0.0)
+    assert out["status"][0] == 0 and np.allclose(out["coef"], ref["coef"], rtol=1e-6, atol=1e-8)
