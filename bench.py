@@ -141,9 +141,10 @@ def main() -> None:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("POLS_BENCH_FORCE_COLLECTIVE") == "1":   # the env knob exercises the N > 1 code on one GPU
         import torch.distributed as dist_mod
 
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -158,18 +159,39 @@ def main() -> None:
     plan, units, unit_name, alg_bytes, text, dtype_name, coef, scaling = build_workload(args.config, eng, rank, world, args.dtype)
     torch.cuda.synchronize()                                                           # inputs are resident
     gather = dist is not None and coef is not None
-    gathered = torch.empty((world * coef.shape[0], coef.shape[1]), device="cuda", dtype=coef.dtype) if gather else None
-    side = torch.cuda.Stream() if gather else None
-    handoff = torch.cuda.Event()
+    collective_note = "none"
+    if gather:
+        # The gather of step i runs on a side stream while step i+1's kernel runs on the engine stream, so the
+        # coefficient table is double-buffered: the kernel of step i writes table i % 2, and may only do so once the
+        # gather that read it two steps ago has finished (an event wait that is always already satisfied in steady state).
+        tables = [coef, torch.empty_like(coef)]
+        gathered = torch.empty((world * coef.shape[0], coef.shape[1]), device="cuda", dtype=coef.dtype)
+        side = torch.cuda.Stream()
+        produced = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        for ev in consumed:
+            ev.record(side)
+        collective_note = "all_gather(coefficients) overlapped"
+    step_no = [0]
 
     def step():
+        nonlocal collective_note, gather
+        i = step_no[0] & 1
+        step_no[0] += 1
+        if gather:
+            eng_stream.wait_event(consumed[i])
+            plan.set_output("coef", tables[i])
         plan.run()
         if gather:
-            # hand the coefficient table to the collective stream; the next step's kernel overlaps the gather
-            handoff.record(eng_stream)
-            side.wait_event(handoff)
-            with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered, coef)
+            try:
+                produced[i].record(eng_stream)
+                side.wait_event(produced[i])
+                with torch.cuda.stream(side):
+                    dist.all_gather_into_tensor(gathered, tables[i])
+                    consumed[i].record(side)
+            except Exception as exc:  # keep the benchmark alive: report the failure instead of dying
+                gather = False
+                collective_note = f"all_gather failed: {type(exc).__name__}: {exc}"[:200]
 
     for _ in range(args.warmup):
         step()
@@ -214,7 +236,7 @@ def main() -> None:
             "scaling": scaling, "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": text, "units_per_gpu_per_step": units,
                        "sharding": "groups" if world > 1 else "none",
-                       "collective": "all_gather(coefficients) overlapped" if gather else "none"},
+                       "collective": collective_note},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": eng.last_kernel,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},

@@ -73,7 +73,10 @@ typedef enum {
     POLS_GROUP_OK = 0,
     POLS_GROUP_FALLBACK = 1, /* Cholesky failed, the reference's fallback solver was taken (ls.rs:299-327) */
     POLS_GROUP_EMPTY = 2,    /* no rows: coefficients are zeros (src/expressions.rs:357-359) */
-    POLS_GROUP_NOT_CONVERGED = 3 /* coordinate descent hit max_iter (result still returned, like the reference) */
+    POLS_GROUP_NOT_CONVERGED = 3, /* coordinate descent hit max_iter (result still returned, like the reference) */
+    POLS_GROUP_BAD_DOF = 4   /* statistics only: degrees of freedom <= 0; the reference panics the whole query here
+                                (src/statistics.rs:131-134), a batched launch marks the group, writes NaN standard
+                                errors / t / p for it and carries on -- the host decides whether to raise */
 } pols_group_status;
 
 typedef struct pols_ctx pols_ctx;
@@ -178,6 +181,25 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
 /* Replaces the `predict` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t,j] * coef[t,j]
  * (coef_rows == n_rows) or x . coef[g] per group (coef_rows == n_groups). */
 int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, void *pred_out);
+
+/* mode="statistics": replaces the plugin `least_squares_statistics` (src/expressions.rs:468-509) and
+ * src/statistics.rs:15-156 for every group of the batch.  Per group, on the sqrt(w)-scaled rows the reference's
+ * Python layer hands the plugin (polars_ols/least_squares.py:190-196):
+ *   coefficients          from the same dispatcher as pols_least_squares (written to out->coef, batch dtype),
+ *   r2, mae, mse          compute_residual_metrics (st.rs:15-37) of those coefficients,
+ *   std_err, t, p         compute_feature_metrics (st.rs:79-156): (X'X + alpha I)^-1 by Cholesky (failure -> NaN),
+ *                         its own coefficients inv . X'y, RSS / df with df = n - p (alpha == 0) or n - trace(inv),
+ *                         two-sided Student-t p-values.
+ * The six statistic arrays are always f64 (the reference's struct fields are Float64) and live where `b->mem` says;
+ * any of them may be NULL.  out->pred / out->resid are honoured as in pols_least_squares; out->status receives
+ * POLS_GROUP_BAD_DOF where the reference would have hit its df > 0 assertion. */
+typedef struct pols_stats_out {
+    double *r2, *mae, *mse;                 /* n_groups                         */
+    double *std_err, *t_values, *p_values;  /* n_groups x (n_features + intercept), row-major */
+} pols_stats_out;
+
+int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *out,
+                                  const pols_stats_out *stats);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@ Only the hot path lives here: ``csrc/`` (hand-written gfx950 HIP kernels + the C
 from ._lib import LIB_PATH, PolsError, PolsPanic, build  # noqa: F401
 from .engine import Engine, default_engine  # noqa: F401
 from .least_squares import (  # noqa: F401
-    Coefficients, Expr, Frame, LeastSquares, OLSKwargs, RLSKwargs, RollingKwargs, col, compute_least_squares,
+    Coefficients, Statistics, Expr, Frame, LeastSquares, OLSKwargs, RLSKwargs, RollingKwargs, col, struct, compute_least_squares,
+    compute_multi_target_least_squares,
     compute_least_squares_from_formula, compute_recursive_least_squares, compute_rolling_least_squares, predict,
 )
 

@@ -65,12 +65,18 @@ class Out(C.Structure):
     _fields_ = [("coef", C.c_void_p), ("pred", C.c_void_p), ("resid", C.c_void_p), ("status", C.c_void_p)]
 
 
+class StatsOut(C.Structure):
+    _fields_ = [("r2", C.c_void_p), ("mae", C.c_void_p), ("mse", C.c_void_p),
+                ("std_err", C.c_void_p), ("t_values", C.c_void_p), ("p_values", C.c_void_p)]
+
+
 EXPORTS = [
     "pols_device_count", "pols_version", "pols_last_error", "pols_create", "pols_destroy", "pols_set_stream",
     "pols_use_private_stream",
     "pols_synchronize", "pols_timing_enable", "pols_timing_collect", "pols_last_kernel_name",
     "pols_ols_params_default", "pols_rls_params_default", "pols_rolling_params_default",
     "pols_least_squares", "pols_recursive_least_squares", "pols_rolling_least_squares", "pols_predict",
+    "pols_least_squares_statistics",
 ]
 
 
@@ -114,6 +120,8 @@ def lib() -> C.CDLL:
         L.pols_recursive_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(RlsParams), C.POINTER(Out)]
         L.pols_rolling_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(RollingParams), C.POINTER(Out)]
         L.pols_predict.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int64, C.c_void_p]
+        L.pols_least_squares_statistics.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(OlsParams), C.POINTER(Out),
+                                                    C.POINTER(StatsOut)]
         _lib = L
     return _lib
 

@@ -10,6 +10,7 @@
 #include "k4_rolling.hpp"
 #include "k5_enet.hpp"
 #include "k6_svd.hpp"
+#include "k7_stats.hpp"
 
 namespace pols {
 template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);   // k1m_f32.hip / k1m_f64.hip
@@ -313,7 +314,17 @@ void pols_rolling_params_default(pols_rolling_params *p) {
 }
 
 // ------------------------------------------------------------------ static least squares
-int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o) {
+// What the statistics entry needs back from the solve: the staged columns, the device offsets and (when the streamed
+// path ran) the Gram matrices it already produced.  With `info` the outputs are left on the device (no unstage).
+struct LsInfo {
+    Staged st;
+    const int64_t *d_offs = nullptr;
+    int64_t max_rows = 0;
+    double *gram = nullptr;
+    int kt = 0;
+};
+
+static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, LsInfo *info) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if ((rc = check_batch(b, o))) return rc;
@@ -350,6 +361,11 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
+    auto finish = [&](double *gram) -> int {
+        if (!info) return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
+        info->st = st; info->d_offs = d_offs; info->max_rows = max_rows; info->gram = gram; info->kt = kt;
+        return POLS_OK;
+    };
     // Every static solve is followed by the SVD fix-up pass over the groups it flags, so a status buffer always exists.
     if (!enet && !st.status) {
         void *sp = nullptr;
@@ -447,7 +463,7 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
             if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
         }
         if ((rc = svd_fixup())) return rc;
-        return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
+        return finish(ga.gram);
     }
 
     K1Args a;
@@ -464,7 +480,73 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     a.k_user = b->n_features;
     if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
     if ((rc = svd_fixup())) return rc;
-    return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
+    return finish(nullptr);
+}
+
+int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o) {
+    return ls_core(ctx, b, p, o, nullptr);
+}
+
+// ------------------------------------------------------------------ mode = "statistics"
+int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o,
+                                  const pols_stats_out *s) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = check_batch(b, o))) return rc;
+    if (!p || !s) return fail(POLS_ERR_INVALID, "params / stats is NULL");
+    if (b->n_groups == 0) return POLS_OK;
+    const int kt = b->n_features + (b->add_intercept ? 1 : 0);
+    const size_t sz = dtype_size(b->dtype);
+    const bool host = b->mem == POLS_MEM_HOST;
+    const size_t G = (size_t)b->n_groups;
+    // slot 6: [coefficients when the caller did not ask for them (device batches)] [statistic arrays of a host batch]
+    const size_t coefb = round256(sz * G * kt), vecb = round256(sizeof(double) * G), matb = round256(sizeof(double) * G * kt);
+    void *scr = nullptr;
+    if ((rc = ensure_scratch(ctx, 6, coefb + 3 * vecb + 3 * matb, &scr))) return rc;
+    char *q = static_cast<char *>(scr);
+    pols_out oo = *o;
+    char coef_sentinel;   // host batches stage every non-NULL output: ask for the coefficients, throw the copy away below
+    if (!oo.coef) oo.coef = host ? static_cast<void *>(&coef_sentinel) : static_cast<void *>(q);
+    q += coefb;
+    LsInfo info;
+    if ((rc = ls_core(ctx, b, p, &oo, &info))) return rc;
+
+    double *gram = info.gram;
+    if (!gram) {
+        void *gs = nullptr;
+        const size_t nz = (size_t)kt + 1;
+        if ((rc = ensure_scratch(ctx, 5, round256(sizeof(double) * nz * nz * G), &gs))) return rc;
+        GramArgs ga;
+        std::memset(&ga, 0, sizeof(ga));
+        ga.y = info.st.y; ga.w = info.st.w;
+        for (int j = 0; j < b->n_features; ++j) ga.x[j] = info.st.x[j];
+        ga.offs = info.d_offs; ga.n_groups = b->n_groups; ga.n_rows = b->n_rows;
+        ga.gram = static_cast<double *>(gs);
+        ga.k_user = b->n_features; ga.kt = kt;
+        if ((rc = gram_stream_launch(ctx, b->dtype, ga))) return rc;
+        gram = ga.gram;
+    }
+    StatsArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.y = info.st.y; sa.w = info.st.w;
+    for (int j = 0; j < b->n_features; ++j) sa.x[j] = info.st.x[j];
+    sa.offs = info.d_offs; sa.n_groups = b->n_groups; sa.gram = gram;
+    sa.coef = info.st.coef; sa.lambda = p->alpha; sa.status = info.st.status;
+    sa.k_user = b->n_features; sa.kt = kt;
+    double *dev[6];
+    double *const user[6] = {s->r2, s->mae, s->mse, s->std_err, s->t_values, s->p_values};
+    for (int i = 0; i < 6; ++i) {
+        dev[i] = !user[i] ? nullptr : (host ? reinterpret_cast<double *>(q) : user[i]);
+        q += (i < 3) ? vecb : matb;
+    }
+    sa.r2 = dev[0]; sa.mae = dev[1]; sa.mse = dev[2]; sa.se = dev[3]; sa.tv = dev[4]; sa.pv = dev[5];
+    if ((rc = k7_stats_launch(ctx, b->dtype, sa))) return rc;
+    if (!host) return POLS_OK;
+    for (int i = 0; i < 6; ++i)
+        if (user[i])
+            POLS_HIP(hipMemcpyAsync(user[i], dev[i], sizeof(double) * G * (i < 3 ? 1 : kt), hipMemcpyDeviceToHost, ctx->stream));
+    if (!o->coef) oo.coef = nullptr;
+    return unstage_outputs(ctx, b, b->n_groups, kt, &oo, info.st);
 }
 
 // Dynamic models share the staging of a batch whose coefficient output has one row per input row.

@@ -164,6 +164,26 @@ class Engine:
         p.null_policy = L.NULL_POLICIES[null_policy]
         return Plan(self, self._lib.pols_least_squares, b, p, o, res, keep)
 
+    def least_squares_statistics(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
+        """mode="statistics" (src/expressions.rs:468-509) for every group: returns ``coef`` (batch dtype), ``status`` and
+        the f64 arrays ``r2 mae mse`` [n_groups] and ``std_err t_values p_values`` [n_groups, k]."""
+        kwargs.setdefault("want", ("coef", "status"))
+        plan = self.plan_least_squares(y, x_cols, offsets, **kwargs)
+        b = plan._b
+        kt = b.n_features + b.add_intercept
+        dev = b.mem == L.POLS_MEM_DEVICE
+        like = plan._keep[0][0]
+        f64 = torch.float64 if dev else np.float64
+        res = plan.results
+        for key in ("r2", "mae", "mse"):
+            res[key] = self._alloc(dev, f64, (b.n_groups,), like)
+        for key in ("std_err", "t_values", "p_values"):
+            res[key] = self._alloc(dev, f64, (b.n_groups, kt), like)
+        so = L.StatsOut(**{k: self._ptr(res[k]) for k in ("r2", "mae", "mse", "std_err", "t_values", "p_values")})
+        L.check(self._lib.pols_least_squares_statistics(self._h, C.byref(plan._b), C.byref(plan._p), C.byref(plan._o),
+                                                        C.byref(so)))
+        return res
+
     def least_squares(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
         """All groups of a (group-sorted) frame in one launch.  ``want`` subset of {"coef","pred","resid","status"};
         ``out`` may carry pre-allocated buffers under the same keys."""
@@ -227,6 +247,11 @@ class Plan:
     def __init__(self, eng: Engine, fn, batch, params, out, results: Dict, keep):
         self._eng, self._fn, self._b, self._p, self._o, self.results, self._keep = eng, fn, batch, params, out, results, keep
         self._args = (eng._h, C.byref(batch), C.byref(params), C.byref(out))
+
+    def set_output(self, key: str, buf) -> None:
+        """Re-point one output (``coef`` / ``pred`` / ``resid`` / ``status``) at another pre-allocated buffer."""
+        setattr(self._o, key, Engine._ptr(buf))
+        self.results[key] = buf
 
     def run(self) -> Dict:
         rc = self._fn(*self._args)

@@ -24,6 +24,7 @@ from typing import Any, Dict, List, Literal, Optional, Sequence, Set, Tuple, Uni
 
 import numpy as np
 
+from ._lib import PolsPanic
 from .engine import Engine, _is_torch, default_engine
 
 try:
@@ -37,7 +38,7 @@ __all__ = [
     "compute_least_squares", "compute_recursive_least_squares", "compute_rolling_least_squares",
     "compute_least_squares_from_formula", "compute_multi_target_least_squares", "predict",
     "OLSKwargs", "RLSKwargs", "RollingKwargs", "NullPolicy", "OutputMode", "SolveMethod",
-    "Frame", "Expr", "col", "Coefficients", "LeastSquares",
+    "Frame", "Expr", "col", "struct", "Coefficients", "Statistics", "LeastSquares",
 ]
 
 # ---- polars_ols/least_squares.py:47-63 --------------------------------------------------------------------------
@@ -157,6 +158,14 @@ def col(name: str) -> Expr:
     return Expr(name)
 
 
+def struct(*cols) -> Expr:
+    """pl.struct(...) stand-in: bundles the target columns of a multi-target regression."""
+    fields = [parse_into_expr(c) for c in cols]
+    e = Expr(fields[0]._name)
+    e._fields = fields
+    return e
+
+
 def parse_into_expr(e) -> Expr:  # polars_ols/utils.py:21-58 (strings are column names)
     if isinstance(e, Expr):
         return e
@@ -251,14 +260,35 @@ def _static_fit(eng: Engine, y, xs, offs, w, icpt: bool, want, kw: OLSKwargs):
     return eng.least_squares(y, xs, offs, weights=w, add_intercept=icpt, want=want, **d)
 
 
+class Statistics(dict):
+    """mode="statistics": the fields of the reference's struct (src/expressions.rs:448-466), one entry per group:
+    ``r2 mae mse`` [G], ``feature_names``, ``coefficients standard_errors t_values p_values`` [G, k]; ``keys`` holds the
+    group keys of an ``.over`` (None for a whole-frame fit, where G == 1)."""
+
+    def __init__(self, names, out, keys):
+        super().__init__(r2=out["r2"], mae=out["mae"], mse=out["mse"], feature_names=list(names),
+                         coefficients=out["coef"], standard_errors=out["std_err"], t_values=out["t_values"],
+                         p_values=out["p_values"])
+        self.keys_ = keys
+
+
+def _static_statistics(eng: Engine, y, xs, offs, w, icpt: bool, kw: OLSKwargs, names, keys) -> Statistics:
+    d = kw.to_dict()
+    d.pop("null_policy")
+    out = eng.least_squares_statistics(y, xs, offs, weights=w, add_intercept=icpt, **d)
+    st = out["status"]
+    bad = bool((st == 4).any())
+    if bad:  # the reference asserts df > 0 and panics the whole query (src/statistics.rs:131-134)
+        raise PolsPanic(-4, "Degrees of freedom <= 0. Cannot compute standard errors.")
+    return Statistics(names, out, keys)
+
+
 def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, features: Sequence[Expr], sample_weights,
                   add_intercept: bool, mode: str, kw: OLSKwargs):
     """compute_least_squares body: least_squares.py:199-239 + src/expressions.rs:390-446 (null policies :201-296)."""
     y, xs, names, icpt, w = _pre_process_data(frame, target, features, sample_weights, add_intercept)
     n = y.shape[0]
     eng = eng or default_engine(y.device.index or 0 if _is_torch(y) else 0)
-    if mode == "statistics":
-        raise NotImplementedError("mode='statistics' (src/statistics.rs) is not built yet")
     # ---- group layout (.over)
     if over is not None:
         key = frame[over] if isinstance(over, str) else over
@@ -275,6 +305,8 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
     if policy in ("ignore", "zero"):
         if policy == "zero":                                   # handle_nulls Zero (ex.rs:264-271)
             y_s, xs_s = _nan_to_zero(y_s), [_nan_to_zero(c) for c in xs_s]
+        if mode == "statistics":
+            return "statistics", _static_statistics(eng, y_s, xs_s, offs, w_s, icpt, kw, names, keys)
         want = ("coef",) if mode == "coefficients" else (("pred",) if mode == "predictions" else ("resid",))
         out = _static_fit(eng, y_s, xs_s, offs, w_s, icpt, want, kw)
         coef, pred = out.get("coef"), out.get("pred") if mode == "predictions" else out.get("resid")
@@ -303,6 +335,8 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
         xs_v = [_take(c, vi) for c in xs_f]
         if policy == "drop_y_zero_x":
             xs_v = [_nan_to_zero(c) for c in xs_v]
+        if mode == "statistics":
+            return "statistics", _static_statistics(eng, y_v, xs_v, offs_v, None, False, kw, names, keys)
         out = _static_fit(eng, y_v, xs_v, offs_v, None, False, ("coef",), kw)
         coef = out["coef"]
         if mode == "coefficients":
@@ -410,8 +444,49 @@ def compute_least_squares(target, *features, sample_weights=None, add_intercept:
     return Expr(t._name, fn=lambda frame, over, eng: _apply_static(frame, over, eng, t, fs, sample_weights, add_intercept, mode, kw))
 
 
-def compute_multi_target_least_squares(targets, *features, **kwargs) -> Expr:
-    raise NotImplementedError("multi-target regression (src/expressions.rs:521-591) is not built yet")
+def compute_multi_target_least_squares(targets, *features, sample_weights=None, add_intercept: bool = False,
+                                       mode: str = "predictions", ols_kwargs: Optional[OLSKwargs] = None) -> Expr:
+    """Several targets regressed on the same features (least_squares.py:282-328, src/expressions.rs:521-591).  ``targets``
+    is the list of target columns (the fields of the reference's struct); the result is a dict target -> column.
+
+    A row is valid only if EVERY target (and, for the drop policies, every feature) is non-null (compute_is_valid_mask
+    with m targets, ex.rs:539), so the joint mask is applied to all targets first and each one is then solved by the
+    single-target path with solve_method="svd" -- the coefficients of solve_multi_target (ls.rs:106-168 applied to a
+    K x M right-hand side) column by column.  One launch per target: the shared-Gram multi-RHS kernel is future work."""
+    kw = ols_kwargs or OLSKwargs()
+    msg = "Consider running multiple independent regressions on a multi-expression target!"
+    assert not kw.positive and (kw.l1_ratio is None or kw.l1_ratio == 0.0), (
+        "Multi-target regression is only supported for unconstrained OLS & Ridge problems." + msg)
+    assert kw.solve_method in {"svd", None}, "only solve_method='svd' is supported for multi-target regressions"
+    if mode not in ("predictions", "residuals"):
+        raise NotImplementedError("Only mode={'predictions', 'residuals'} is currently supported. " + msg)
+    if isinstance(targets, Expr) and getattr(targets, "_fields", None):
+        targets = targets._fields
+    elif isinstance(targets, (str, Expr)):
+        targets = [targets]
+    ts, fs = [parse_into_expr(t) for t in targets], [parse_into_expr(f) for f in features]
+
+    def run(frame: Frame, over, eng):
+        f2 = Frame(frame)
+        if kw.null_policy not in ("ignore", "zero"):
+            cols = [t._column(frame) for t in ts]
+            bad = _isnan(cols[0])
+            for c in cols[1:]:
+                bad = bad | _isnan(c)
+            nan = float("nan")
+            for t, c in zip(ts, cols):
+                masked = torch.where(bad, torch.full_like(c, nan), c) if _is_torch(c) else np.where(bad, nan, c)
+                f2[f"__mt_{t.output_name}"] = masked
+            tcols = [Expr(f"__mt_{t.output_name}", alias=t.output_name) for t in ts]
+        else:
+            tcols = ts
+        out = {}
+        for t, tc in zip(ts, tcols):
+            _, val = _apply_static(f2, over, eng, tc, fs, sample_weights, add_intercept, "predictions", kw)
+            out[t.output_name] = val if mode == "predictions" else t._column(frame) - val
+        return "predictions", out
+
+    return Expr(ts[0]._name, fn=run)
 
 
 def compute_recursive_least_squares(target, *features, sample_weights=None, add_intercept: bool = False,
