@@ -163,7 +163,8 @@ def main() -> None:
     if gather:
         # The gather of step i runs on a side stream while step i+1's kernel runs on the engine stream, so the
         # coefficient table is double-buffered: the kernel of step i writes table i % 2, and may only do so once the
-        # gather that read it two steps ago has finished (an event wait that is always already satisfied in steady state).
+        # gather that read it two steps ago has finished.  That wait is done on the HOST (the event is long complete in steady
+        # state, so it costs a poll) rather than as a barrier packet on the engine stream, which would open a bubble per step.
         tables = [coef, torch.empty_like(coef)]
         gathered = torch.empty((world * coef.shape[0], coef.shape[1]), device="cuda", dtype=coef.dtype)
         side = torch.cuda.Stream()
@@ -179,7 +180,7 @@ def main() -> None:
         i = step_no[0] & 1
         step_no[0] += 1
         if gather:
-            eng_stream.wait_event(consumed[i])
+            consumed[i].synchronize()
             plan.set_output("coef", tables[i])
         plan.run()
         if gather:

@@ -592,22 +592,24 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     }
     // Long sequences: the chunk-parallel information-form scan (K3s); short ones: the wave-per-sequence P-form
     // recursion (K3).  POLS_RLS_ENGINE=seq|scan forces one.
-    bool scan = max_rows > 4096 && b->n_features <= K4_KMAX;
+    // More than 8 features: the wave-per-chunk scan (k4w_wide.hip), whatever the length.
+    const bool wide = b->n_features > K4_KMAX;
+    bool scan = max_rows > 4096 || wide;
     if (const char *force = std::getenv("POLS_RLS_ENGINE")) {
-        if (!std::strcmp(force, "seq")) scan = false;
-        if (!std::strcmp(force, "scan") && b->n_features <= K4_KMAX) scan = true;
+        if (!std::strcmp(force, "seq") && !wide) scan = false;
+        if (!std::strcmp(force, "scan")) scan = true;
     }
     if (scan) {
         const int k = b->n_features;
         K4Args s4;
         std::memset(&s4, 0, sizeof(s4));
-        if ((rc = build_chunk_tables(ctx, b, 1, k * (k + 1) / 2 + k + 1, &s4))) return rc;
+        if ((rc = build_chunk_tables(ctx, b, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4))) return rc;
         s4.y = st.y; s4.valid = st.valid;
         for (int j = 0; j < k; ++j) s4.x[j] = st.x[j];
         s4.coef = st.coef; s4.pred = st.pred;
         s4.k = k;
         s4.ff = a.forgetting_factor; s4.p0 = a.initial_state_covariance; s4.mean0 = a.mean0;
-        if ((rc = k3s_launch(ctx, b->dtype, s4))) return rc;
+        if ((rc = wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4))) return rc;
     } else {
         if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
     }
@@ -700,7 +702,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
     if (o->resid) return fail(POLS_ERR_INVALID, "rolling: residuals are target - predictions in the caller (least_squares.py:239)");
     const int k = b->n_features;
-    if (k > K4_KMAX) return fail(POLS_ERR_UNSUPPORTED, "rolling: %d features > %d", k, K4_KMAX);
+    const bool wide = k > K4_KMAX;                                                              // k4w_wide.hip
     if (p->window_size < 1) return fail(POLS_ERR_INVALID, "window_size must be >= 1");
     const int64_t w = p->window_size;
     const int64_t mp = p->min_periods >= 0 ? p->min_periods : std::min<int64_t>(k, w);          // ls.rs:860
@@ -711,13 +713,13 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
 
     K4Args a;
     std::memset(&a, 0, sizeof(a));
-    if ((rc = build_chunk_tables(ctx, b, mp, k * (k + 1) / 2 + k, &a))) return rc;
+    if ((rc = build_chunk_tables(ctx, b, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a))) return rc;
     a.y = st.y; a.valid = st.valid;
     for (int j = 0; j < k; ++j) a.x[j] = st.x[j];
     a.coef = st.coef; a.pred = st.pred;
     a.window = w; a.alpha = p->alpha > 0.0 ? p->alpha : 0.0;                                    // ls.rs:865, 924-926
     a.k = k; a.drop_mode = drop ? 1 : 0;
-    if ((rc = k4_launch(ctx, b->dtype, a))) return rc;
+    if ((rc = wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, k, o, st);
 }
 

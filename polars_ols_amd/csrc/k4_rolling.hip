@@ -140,6 +140,10 @@ __global__ void __launch_bounds__(64) k4_scan_kernel(const K4Args a, const int n
     }
 }
 
+void k4_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, unsigned blocks) {
+    hipLaunchKernelGGL(k4_scan_kernel, dim3(blocks), dim3(64), 0, ctx->stream, a, nacc);
+}
+
 // ------------------------------------------------------------------ pass 3: the walk
 template <typename T, int K>
 __global__ void __launch_bounds__(64) k4_walk_kernel(const K4Args a) {

@@ -50,5 +50,10 @@ int k4_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 // Chunk-parallel RLS for long sequences: A_t = ff A_{t-1} + x x', b_t = ff b_{t-1} + x y (valid rows), beta_t = A_t^-1 b_t,
 // which is the reference's P-form recursion (ls.rs:531-540) by the Sherman-Morrison identity.
 int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+// 9..32 features: one wave per chunk, state in LDS (k4w_wide.hip).  Totals rows are k*k + k (+ 1 for the RLS decay) doubles.
+int k4w_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+int k3sw_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+// plain exclusive prefix over each group's chunk totals (pass 2 of the rolling kernels)
+void k4_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, unsigned blocks);
 
 }  // namespace pols

@@ -78,6 +78,53 @@ def test_rolling_many_groups(eng, policy, k, window, min_periods, alpha, null_fr
     assert window < k + 2 or strict.sum() > 0.5 * sane.sum()
 
 
+@pytest.mark.parametrize("policy", ["drop", "drop_window"])
+@pytest.mark.parametrize("k,window,min_periods,alpha,null_frac", [
+    (9, 40, None, None, 0.0), (10, 100, 1, None, 0.1), (16, 64, 16, 0.5, 0.1), (32, 300, None, None, 0.05), (12, 1_000_000, 12, None, 0.1),
+])
+def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_frac):
+    """9..32 features: the wave-per-chunk kernels (k4w_wide.hip)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 1000 + window % 997)
+    sizes = rng.integers(1, 500, size=9)
+    sizes[1] = 0
+    sizes[4] = 1_700                                 # several chunks
+    y, cols, offs, valid = _frame(rng, sizes, k, null_frac=null_frac)
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid),
+                                    window_size=window, min_periods=min_periods, alpha=alpha, null_policy=policy)
+    assert eng.last_kernel.startswith("k4w_")
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy, is_valid=valid)
+    got_c, got_p = _np(out["coef"]), _np(out["pred"])
+    nobs = _window_obs(offs, valid, window, policy)
+    # fewer observations than features (min_periods < k): X'X is exactly singular and what the LU fallback returns (NaN,
+    # inf or garbage) is rounding noise in the reference too -- the NaN pattern is only pinned outside that band
+    mp_eff = min_periods if min_periods is not None else min(k, window)
+    pinned = (nobs >= k) | (nobs < mp_eff)
+    assert np.array_equal(np.isnan(got_c)[pinned], np.isnan(ref["coef"])[pinned])
+    sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+    strict = sane & (nobs >= k + 4)
+    assert strict.sum() > 0.3 * sane.sum()
+    assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
+    assert np.allclose(got_p[strict], ref["pred"][strict], rtol=1e-5, atol=1e-6)
+
+
+def test_rolling_non_contiguous_reference_case():               # tests/test_ols.py:969-995 (10 features, weights, drop)
+    from polars_ols_amd import Frame, col
+    from refdata import insert_nulls, make_data
+
+    d = insert_nulls(make_data(n_samples=20_000, n_groups=5, n_features=10), ["y"] + [f"x{i + 1}" for i in range(10)], 0.02)
+    rng = np.random.default_rng(0)
+    df = Frame({k: v for k, v in d.items() if k != "x"})
+    df["weights"] = rng.uniform(0.0, 10.0, size=20_000)
+    feats = [col(f"x{i + 1}") for i in range(10)]
+    c = df.select(col("y").least_squares.rolling_ols(*feats, window_size=100, min_periods=1, null_policy="drop",
+                                                     sample_weights="weights", mode="coefficients").over("group"))["coefficients"]
+    rows = c.to_rows()
+    assert rows.shape == (20_000, 10)
+    assert abs(np.nanmean(rows[-1]) - 1.0) < 0.02
+
+
 @pytest.mark.parametrize("win,mp", [(2, 2), (10, 2), (63, 5), (252, 5)])
 def test_rolling_golden_bruteforce(eng, golden, win, mp):
     """tests/test_ols.py:718-772 (statsmodels RollingOLS replaced by brute-force per-window lstsq, tests/golden)."""
