@@ -202,7 +202,7 @@ int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
 }
 
 // ------------------------------------------------------------------------------------------------ B: gram_cd
-constexpr int CD_KMAX = 16;
+constexpr int CD_KMAX = 31;   // 16 lanes per group up to 16 columns, 32 lanes beyond
 
 __device__ __forceinline__ double soft_threshold(double x, double thr, bool positive) {   // ls.rs:373-379
     const double mag = fmax(fabs(x) - thr, 0.0);
@@ -211,10 +211,11 @@ __device__ __forceinline__ double soft_threshold(double x, double thr, bool posi
     return r;
 }
 
-template <typename T>
+template <typename T, int LPG>   // LPG lanes per group = the most columns it handles
 __global__ void __launch_bounds__(64) gram_cd_kernel(const CdArgs a) {
-    const int lane = threadIdx.x, sub = lane & 15;
-    const int64_t grp = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    constexpr int CD_KMAX = LPG;
+    const int lane = threadIdx.x, sub = lane & (LPG - 1);
+    const int64_t grp = (int64_t)blockIdx.x * (64 / LPG) + (lane / LPG);
     const bool live = grp < a.n_groups;
     const int kt = a.kt, NZ = kt + 1;
     const int64_t gi = live ? grp : 0;
@@ -246,7 +247,8 @@ __global__ void __launch_bounds__(64) gram_cd_kernel(const CdArgs a) {
         for (int j = 0; j < CD_KMAX; ++j) {
             if (j >= kt) break;
             if (!((sweep >> j) & 1u)) continue;
-            const double sdot = row_allreduce(col[j] * wme);  // sum_i G[j][i] w[i] over the group's 16 lanes
+            double sdot = row_allreduce(col[j] * wme);        // sum_i G[j][i] w[i] over the group's lanes
+            if (LPG == 32) sdot += __shfl_xor(sdot, 16);
             const double dot = b[j] - sdot + diag[j] * w[j];  // x_j . (residuals + x_j w_j)  (:428-430)
             const double wn = soft_threshold(dot, thr, positive) / (diag[j] + l2);   // (:430-431)
             if (!done) {
@@ -271,9 +273,15 @@ __global__ void __launch_bounds__(64) gram_cd_kernel(const CdArgs a) {
 
 int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a) {
     if (a.kt > CD_KMAX) return fail(POLS_ERR_UNSUPPORTED, "elastic net: %d features (incl. intercept) > %d", a.kt, CD_KMAX);
-    const unsigned blocks = (unsigned)((a.n_groups + 3) / 4);
-    if (dtype == POLS_F32) hipLaunchKernelGGL(gram_cd_kernel<float>, dim3(blocks), dim3(64), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(gram_cd_kernel<double>, dim3(blocks), dim3(64), 0, ctx->stream, a);
+    if (a.kt <= 16) {
+        const unsigned blocks = (unsigned)((a.n_groups + 3) / 4);
+        if (dtype == POLS_F32) hipLaunchKernelGGL((gram_cd_kernel<float, 16>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gram_cd_kernel<double, 16>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+    } else {
+        const unsigned blocks = (unsigned)((a.n_groups + 1) / 2);
+        if (dtype == POLS_F32) hipLaunchKernelGGL((gram_cd_kernel<float, 32>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gram_cd_kernel<double, 32>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+    }
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

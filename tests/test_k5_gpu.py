@@ -43,6 +43,9 @@ def _frame(rng, offs, k, dtype, sparsity=0.5, weights=False):
     (15, 0.01, 0.5, False, "cd_active_set", False, True),
     (16, 0.001, 0.5, False, "cd", False, False),       # cfg5's feature count: two MFMA tiles for [X | y]
     (16, 0.2, 0.9, False, "cd_active_set", True, False),
+    (17, 0.05, 0.5, False, "cd", False, False),        # > 16 columns: 32 lanes per group
+    (24, 0.1, 1.0, True, "cd", True, True),
+    (31, 0.02, 0.5, False, "cd_active_set", False, False),
 ])
 def test_elastic_net_tight_tolerance(eng, dtype, tol, k, alpha, l1, positive, method, weights, icpt):
     """Converged to tol = 1e-10 both paths must land on the same (unique) fixed point."""
