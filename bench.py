@@ -8,9 +8,9 @@
 A "step" is one pass of the hot path over one batch of synthetic input, with the input columns already resident
 in HBM when the timed region starts.  Default workload = BASELINE.json configs[1] (the configuration the metric is
 quoted on): 10 000 groups x 1 000 rows x 8 features, f32, OLS, mode="predictions".  One process per GPU; groups are
-independent, so every rank owns its own shard of groups (weak scaling, no data-path collective); for N > 1 each step
-also all-gathers the per-group coefficient table over RCCL/xGMI (the "reassemble the coefficients column" step of
-north_star), issued on a side stream so it overlaps the next step's kernel.  Prints ONE JSON line on rank 0.
+independent, so every rank owns its own shard of groups (weak scaling, no data-path collective); for N > 1 the per-group
+coefficient tables are all-gathered over RCCL/xGMI (the "reassemble the coefficients column" step of north_star), eight
+steps' tables per collective, on a side stream so it overlaps the following kernels.  Prints ONE JSON line on rank 0.
 
 --config selects the other BASELINE configs for the numbers quoted in DESIGN.md (same JSON shape):
   cfg3  10 000 x 1 000 x 8, f64, ridge alpha = 1 + sample_weights, predictions
@@ -160,42 +160,59 @@ def main() -> None:
     torch.cuda.synchronize()                                                           # inputs are resident
     gather = dist is not None and coef is not None
     collective_note = "none"
+    RING = 8
     if gather:
-        # The gather of step i runs on a side stream while step i+1's kernel runs on the engine stream, so the
-        # coefficient table is double-buffered: the kernel of step i writes table i % 2, and may only do so once the
-        # gather that read it two steps ago has finished.  That wait is done on the HOST (the event is long complete in steady
-        # state, so it costs a poll) rather than as a barrier packet on the engine stream, which would open a bubble per step.
-        tables = [coef, torch.empty_like(coef)]
-        gathered = torch.empty((world * coef.shape[0], coef.shape[1]), device="cuda", dtype=coef.dtype)
+        # Reassembling the coefficient column is the one exchange step of the path (north_star).  Fewer, larger collectives:
+        # the coefficient tables of RING consecutive steps go into one ring buffer and ONE all-gather moves the whole ring
+        # (RING x 320 KB per rank at cfg2) on a side stream while the next steps' kernels run.  Two rings alternate; a ring
+        # is rewritten only after the gather that read it has finished -- checked on the HOST (the event is long complete in
+        # steady state), not with a barrier packet on the engine stream, which would open a bubble per step.
+        rings = [torch.empty((RING,) + tuple(coef.shape), device="cuda", dtype=coef.dtype) for _ in range(2)]
+        gathered = torch.empty((world * RING,) + tuple(coef.shape), device="cuda", dtype=coef.dtype)
         side = torch.cuda.Stream()
         produced = [torch.cuda.Event(), torch.cuda.Event()]
         consumed = [torch.cuda.Event(), torch.cuda.Event()]
         for ev in consumed:
             ev.record(side)
-        collective_note = "all_gather(coefficients) overlapped"
+        collective_note = f"all_gather(coefficient tables of {RING} steps) on a side stream, overlapped"
     step_no = [0]
 
-    def step():
+    def exchange(r):
         nonlocal collective_note, gather
-        i = step_no[0] & 1
+        try:
+            produced[r].record(eng_stream)
+            side.wait_event(produced[r])
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(gathered, rings[r])
+                consumed[r].record(side)
+        except Exception as exc:  # keep the benchmark alive: report the failure instead of dying
+            gather = False
+            collective_note = f"all_gather failed: {type(exc).__name__}: {exc}"[:200]
+
+    def step():
+        i = step_no[0]
         step_no[0] += 1
-        if gather:
-            consumed[i].synchronize()
-            plan.set_output("coef", tables[i])
+        if not gather:
+            plan.run()
+            return
+        slot, r = i % RING, (i // RING) & 1
+        if slot == 0:
+            consumed[r].synchronize()
+        plan.set_output("coef", rings[r][slot])
         plan.run()
-        if gather:
-            try:
-                produced[i].record(eng_stream)
-                side.wait_event(produced[i])
-                with torch.cuda.stream(side):
-                    dist.all_gather_into_tensor(gathered, tables[i])
-                    consumed[i].record(side)
-            except Exception as exc:  # keep the benchmark alive: report the failure instead of dying
-                gather = False
-                collective_note = f"all_gather failed: {type(exc).__name__}: {exc}"[:200]
+        if slot == RING - 1:
+            exchange(r)
+
+    def flush():
+        """gather the partly filled ring so that every timed step's coefficients have been reassembled"""
+        i = step_no[0]
+        if gather and i % RING != 0:
+            exchange((i // RING) & 1)
+        step_no[0] = ((i + RING - 1) // RING) * RING
 
     for _ in range(args.warmup):
         step()
+    flush()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -204,6 +221,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    flush()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
