@@ -329,8 +329,13 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     if (rc) return rc;
     if ((rc = check_batch(b, o))) return rc;
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
-    if (b->valid || p->null_policy != POLS_NULL_IGNORE)
-        return fail(POLS_ERR_UNSUPPORTED, "null policies other than 'ignore' are not built yet (SURVEY 8f-1)");
+    // Null policies (src/expressions.rs:201-296): a null is a NaN; `valid` (optional) additionally drops rows under the
+    // drop family.  They are fused into the streamed path's staging / prediction passes -- no compaction, no copies.
+    const int pol = p->null_policy;
+    if (pol < POLS_NULL_IGNORE || pol > POLS_NULL_DROP_WINDOW) return fail(POLS_ERR_INVALID, "unknown null_policy %d", pol);
+    const bool nulls = pol != POLS_NULL_IGNORE;
+    if (b->valid && (pol == POLS_NULL_IGNORE || pol == POLS_NULL_ZERO))
+        return fail(POLS_ERR_INVALID, "a validity mask needs a drop-family null_policy");
 
     // Dispatcher of src/expressions.rs:366-387.
     const int m = p->solve_method;
@@ -407,6 +412,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         ka.rc_factor = ols_branch ? 2.220446049250313e-16
                                   : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt)) : 0.0);
         ka.k_user = b->n_features; ka.kt = kt;
+        ka.valid = st.valid; ka.null_policy = pol;
         return k6_launch(ctx, b->dtype, ka, w_use);
     };
 
@@ -419,7 +425,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool fits_lds = f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
                                   : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows);
         const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
-        stream = kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
+        stream = nulls || kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
         if (const char *force = std::getenv("POLS_STATIC_ENGINE")) stream = stream || !std::strcmp(force, "stream");
     }
     if (stream) {
@@ -428,7 +434,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const size_t nz = (size_t)kt + 1;
         const size_t gram_bytes = round256(sizeof(double) * nz * nz * (size_t)b->n_groups);
         const size_t c64_bytes = round256(sizeof(double) * (size_t)kt * (size_t)b->n_groups);
-        if ((rc = ensure_scratch(ctx, 5, gram_bytes + c64_bytes, &scr))) return rc;
+        const size_t nv_bytes = nulls ? round256(sizeof(double) * (size_t)b->n_groups) : 0;
+        if ((rc = ensure_scratch(ctx, 5, gram_bytes + c64_bytes + nv_bytes, &scr))) return rc;
+        double *nvalid = nulls ? reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes + c64_bytes) : nullptr;
         GramArgs ga;
         std::memset(&ga, 0, sizeof(ga));
         ga.y = st.y; ga.w = st.w;
@@ -436,6 +444,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         ga.offs = d_offs; ga.n_groups = b->n_groups; ga.n_rows = b->n_rows;
         ga.gram = static_cast<double *>(scr);
         ga.k_user = b->n_features; ga.kt = kt;
+        ga.valid = st.valid; ga.null_policy = pol; ga.nvalid = nvalid;
         if ((rc = gram_stream_launch(ctx, b->dtype, ga))) return rc;
         CdArgs ca;
         std::memset(&ca, 0, sizeof(ca));
@@ -444,6 +453,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         ca.status = st.status;
         ca.alpha = alpha; ca.l1_ratio = enet_l1; ca.tol = p->tol; ca.max_iter = p->max_iter;
         ca.positive = positive ? 1 : 0; ca.active_set = (m == POLS_SOLVE_CD_ACTIVE_SET) ? 1 : 0; ca.kt = kt;
+        ca.nvalid = nvalid;
         if (enet) {
             if ((rc = gram_cd_launch(ctx, b->dtype, ca))) return rc;
         } else {
@@ -460,6 +470,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             pa.offs = d_offs; pa.n_groups = b->n_groups; pa.n_rows = b->n_rows;
             pa.coef64 = ca.coef64; pa.pred = st.pred; pa.resid = st.resid;
             pa.k_user = b->n_features; pa.kt = kt;
+            pa.valid = st.valid; pa.null_policy = pol;
             if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
         }
         if ((rc = svd_fixup())) return rc;
@@ -494,6 +505,9 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
     if (rc) return rc;
     if ((rc = check_batch(b, o))) return rc;
     if (!p || !s) return fail(POLS_ERR_INVALID, "params / stats is NULL");
+    if (p->null_policy != POLS_NULL_IGNORE || b->valid)
+        return fail(POLS_ERR_UNSUPPORTED, "statistics: filter / zero-fill nulls before the call (what handle_nulls does above the "
+                                          "reference's statistics code, src/expressions.rs:469-471)");
     if (b->n_groups == 0) return POLS_OK;
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
     const size_t sz = dtype_size(b->dtype);

@@ -177,6 +177,36 @@ __device__ __forceinline__ double readlane63(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// ---- null policies of the static entry (src/expressions.rs:201-296).  A null is a NaN; for the drop family a 0 in the
+// optional validity bytes drops the row as well.
+__device__ __forceinline__ bool null_checks_x(int policy) {   // rows with a null FEATURE leave the fit
+    return policy == POLS_NULL_DROP || policy == POLS_NULL_DROP_ZERO || policy == POLS_NULL_DROP_WINDOW;
+}
+__device__ __forceinline__ bool null_checks_y(int policy) {   // rows with a null TARGET leave the fit
+    return null_checks_x(policy) || policy == POLS_NULL_DROP_Y_ZERO_X;
+}
+// is row r (absolute) part of the fit?  x[] are the feature columns, y the target
+template <typename T>
+__device__ __forceinline__ bool null_row_in_fit(int policy, const uint8_t *valid, const void *y, const void *const *x, int ku, int64_t r) {
+    if (policy == POLS_NULL_IGNORE || policy == POLS_NULL_ZERO) return true;
+    if (valid && !valid[r]) return false;
+    const T yv = static_cast<const T *>(y)[r];
+    if (yv != yv) return false;
+    if (null_checks_x(policy))
+        for (int j = 0; j < ku; ++j) { const T v = static_cast<const T *>(x[j])[r]; if (v != v) return false; }
+    return true;
+}
+// bit-level select, so that no floating-point reasoning of the optimiser is involved
+template <typename T> __device__ __forceinline__ T nan_if(unsigned cond, T v);
+template <> __device__ __forceinline__ float nan_if<float>(unsigned cond, float v) {
+    return __uint_as_float(cond ? 0x7fc00000u : __float_as_uint(v));
+}
+template <> __device__ __forceinline__ double nan_if<double>(unsigned cond, double v) {
+    return __longlong_as_double(cond ? 0x7ff8000000000000LL : __double_as_longlong(v));
+}
+template <typename T>
+__device__ __forceinline__ T null_fill(int policy, T v) { return (policy != POLS_NULL_IGNORE && v != v) ? T(0) : v; }
+
 template <typename T> struct Vec16;  // 16-byte vector of T
 template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };

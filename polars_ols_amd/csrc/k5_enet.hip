@@ -50,13 +50,18 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
     for (int p = 0; p < NPAIR; ++p) { acc[p][0] = acc_t{0, 0, 0, 0}; acc[p][1] = acc_t{0, 0, 0, 0}; }
 
     if (tid < 2 * K1M_CONST_ELEMS) zeros[tid] = (tid < K1M_CONST_ELEMS) ? T(0) : T(1);
+    __shared__ int nfit_s;
+    if (tid == 0) nfit_s = 0;
+    int nfit = 0;                                   // rows of the group that take part in the fit (null policies)
+    const int pol = a.null_policy;
+    const int nld = (HAS_W && !a.w) ? ncols - 1 : ncols;   // no weights column to stage: the prep pass writes ones
 
     for (int64_t c0 = 0; c0 < span; c0 += KG_CR) {
         const int rows_here = (int)min((int64_t)KG_CR, span - c0);
         const int rows8 = (rows_here + 7) & ~7;
         // ---- stage the chunk: HBM -> LDS
         const int ppc = (rows_here + RPP - 1) / RPP;
-        for (int p = wave; p < ncols * ppc; p += 4) {
+        for (int p = wave; p < nld * ppc; p += 4) {
             const int col = p / ppc, q = p - col * ppc;
             const T *src = static_cast<const T *>(col < ku ? a.x[col] : (col == ku ? a.y : a.w));
             const int row0 = q * RPP + lane * VEC;
@@ -79,17 +84,33 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
         if constexpr (HAS_W) {
             T *wc = tile + (size_t)(ku + 1) * rs;
             for (int row0 = tid * VEC; row0 < rows8; row0 += 256 * VEC) {
-                V wv = *reinterpret_cast<V *>(wc + row0);
+                V wv;
+                if (a.w) wv = *reinterpret_cast<V *>(wc + row0);
                 T sw[VEC];
+                bool ok[VEC];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) { const int r = row0 + v; sw[v] = (r >= lo && r < hi) ? sqrt(vget<T>(wv, v)) : T(0); }
+                for (int v = 0; v < VEC; ++v) { const int r = row0 + v; ok[v] = (r >= lo && r < hi); sw[v] = a.w ? sqrt(vget<T>(wv, v)) : T(1); }
+                if (pol != POLS_NULL_IGNORE) {      // which rows leave the fit (compute_is_valid_mask, ex.rs:201-228)
+                    if (a.valid && null_checks_y(pol)) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) if (ok[v]) ok[v] = a.valid[base + c0 + row0 + v] != 0;
+                    }
+                    const int c_lo = null_checks_x(pol) ? 0 : ku, c_hi = null_checks_y(pol) ? ku : -1;
+                    for (int c = c_lo; c <= c_hi; ++c) {
+                        const V xv = *reinterpret_cast<V *>(tile + (size_t)c * rs + row0);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { const T x = vget<T>(xv, v); ok[v] = ok[v] && (x == x); }
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { if (!ok[v]) sw[v] = T(0); else ++nfit; }
                 if constexpr (VEC == 4) wv = V{sw[0], sw[1], sw[2], sw[3]}; else wv = V{sw[0], sw[1]};
                 *reinterpret_cast<V *>(wc + row0) = wv;
                 for (int c = 0; c <= ku; ++c) {
                     V xv = *reinterpret_cast<V *>(tile + (size_t)c * rs + row0);
                     T t[VEC];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) { const int r = row0 + v; t[v] = (r >= lo && r < hi) ? vget<T>(xv, v) * sw[v] : T(0); }
+                    for (int v = 0; v < VEC; ++v) t[v] = ok[v] ? null_fill<T>(pol, vget<T>(xv, v)) * sw[v] : T(0);   // handle_nulls (ex.rs:257-296)
                     if constexpr (VEC == 4) xv = V{t[0], t[1], t[2], t[3]}; else xv = V{t[0], t[1]};
                     *reinterpret_cast<V *>(tile + (size_t)c * rs + row0) = xv;
                 }
@@ -137,6 +158,11 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
         __syncthreads();   // the next chunk's DMA overwrites the tile
     }
 
+    if (HAS_W && a.nvalid) {
+        if (nfit) atomicAdd(&nfit_s, nfit);
+        __syncthreads();
+        if (tid == 0) a.nvalid[g] = (double)nfit_s;
+    }
     // ---- cross-wave sum (fixed order) and write-out of the (symmetric) Gram matrix in f64
     T *part = tile;    // [pair][wave][reg * 64 + lane]
 #pragma unroll
@@ -177,7 +203,7 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     static bool attr_set = false;
     if (!attr_set) {
         POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<T, NT, HAS_W>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
     char name[96];
@@ -192,7 +218,7 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
 
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
     if (a.kt + 1 > 32) return fail(POLS_ERR_UNSUPPORTED, "gram_stream: %d features (incl. intercept) > 31", a.kt);
-    const bool two = a.kt + 1 > 16, w = a.w != nullptr;
+    const bool two = a.kt + 1 > 16, w = a.w != nullptr || a.null_policy != POLS_NULL_IGNORE;   // null policies ride on the sqrt(w) prep pass
     if (dtype == POLS_F32) {
         if (two) return w ? gram_stream_launch_t<float, 2, true>(ctx, a) : gram_stream_launch_t<float, 2, false>(ctx, a);
         return w ? gram_stream_launch_t<float, 1, true>(ctx, a) : gram_stream_launch_t<float, 1, false>(ctx, a);
@@ -220,7 +246,7 @@ __global__ void __launch_bounds__(64) gram_cd_kernel(const CdArgs a) {
     const int kt = a.kt, NZ = kt + 1;
     const int64_t gi = live ? grp : 0;
     const double *G = a.gram + (size_t)gi * NZ * NZ;
-    const double n = (double)(a.offs[gi + 1] - a.offs[gi]);
+    const double n = a.nvalid ? a.nvalid[gi] : (double)(a.offs[gi + 1] - a.offs[gi]);
 
     double col[CD_KMAX], w[CD_KMAX], b[CD_KMAX], diag[CD_KMAX];
 #pragma unroll
@@ -303,7 +329,7 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
     const double *G = a.gram + (size_t)grp * NZ * NZ;
     double *L = Ls[wv];
     double *rinv = rs[wv];
-    const int64_t n = a.offs[grp + 1] - a.offs[grp];
+    const int64_t n = a.nvalid ? (int64_t)a.nvalid[grp] : a.offs[grp + 1] - a.offs[grp];
     for (int q = lane; q < kt * kt; q += 64) {
         const int i = q / kt, j = q - i * kt;
         L[q] = G[i * NZ + j] + (i == j ? a.alpha : 0.0);
@@ -373,6 +399,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
     const T *crow = static_cast<const T *>(a.coef_rows);
     T *pred = static_cast<T *>(a.pred);
     T *resid = static_cast<T *>(a.resid);
+    const int pol = a.null_policy;
     for (int64_t row0 = base + (int64_t)threadIdx.x * VEC; row0 < e; row0 += 256 * VEC) {
         const bool full = (row0 >= s) && (row0 + VEC <= e);
         T p[VEC], sw[VEC], yv[VEC];
@@ -403,7 +430,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
                 T c;
                 if (cg) c = (T)cg[j];
                 else c = (r >= s && r < e) ? crow[r * kt + j] : T(0);
-                p[v] = fma(xv[v] * sw[v], c, p[v]);
+                p[v] = fma(null_fill<T>(pol, xv[v]) * sw[v], c, p[v]);
             }
         }
         (void)icpt;
@@ -411,9 +438,19 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) p[v] *= T(1) / sw[v];
         }
-        if (resid) {
+        if (resid || pol == POLS_NULL_DROP) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { const int64_t r = row0 + v; if (r >= s && r < e) yv[v] = static_cast<const T *>(a.y)[r]; }
+        }
+        if (pol == POLS_NULL_DROP) {                // mask the rows that were not part of the fit (ex.rs:409-417)
+            unsigned dropped = 0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int64_t r = row0 + v;
+                if (r >= s && r < e && !null_row_in_fit<T>(pol, a.valid, a.y, a.x, ku, r)) dropped |= 1u << v;
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) p[v] = nan_if<T>((dropped >> v) & 1u, p[v]);
         }
         if (full) {
             if (pred) { V o; if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]}; *reinterpret_cast<V *>(pred + row0) = o; }

@@ -27,6 +27,10 @@ struct GramArgs {
     double *gram;        // n_groups x NZ x NZ (row-major, f64), NZ = kt + 1
     int32_t k_user;
     int32_t kt;          // k_user + intercept
+    // null policy fused into the staging pass: dropped rows get sqrt(w) = 0, nulls that stay in the fit become 0
+    const uint8_t *valid;   // optional, drop family only
+    int32_t null_policy;    // pols_null_policy
+    double *nvalid;         // n_groups: rows that took part in the fit (the n of alpha * n, ls.rs:419), or nullptr
 };
 
 struct CdArgs {
@@ -42,6 +46,7 @@ struct CdArgs {
     int32_t epoch;
     int64_t max_iter;
     int32_t positive, active_set, kt;
+    const double *nvalid;   // per-group number of fit rows under a null policy, or nullptr = offs[g + 1] - offs[g]
 };
 
 struct PredictArgs {
@@ -56,6 +61,10 @@ struct PredictArgs {
     void *pred;
     void *resid;
     int32_t k_user, kt;
+    // null policy (static models): features are zero-filled for every policy but "ignore" (construct_features_array(.., true),
+    // ex.rs:408); "drop" masks the rows that were not part of the fit with NaN (ex.rs:409-417).  `y` must then be set.
+    const uint8_t *valid;
+    int32_t null_policy;
 };
 
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a);

@@ -43,14 +43,19 @@ __global__ void __launch_bounds__(256) k6_svd_kernel(const K6Args a) {
         const int64_t s = a.offs[g], e = a.offs[g + 1];
         const int64_t n = e - s;
         // ---- copy the group as f64, sqrt(w)-scaled, intercept appended last (least_squares.py:184-196)
+        const int pol = a.null_policy;
+        int nfit_l = 0;
         for (int64_t r = tid; r < n; r += 256) {
-            const double sw = a.w ? sqrt((double)static_cast<const T *>(a.w)[s + r]) : 1.0;
+            const bool in_fit = null_row_in_fit<T>(pol, a.valid, a.y, a.x, ku, s + r);   // dropped rows become zero rows
+            nfit_l += in_fit ? 1 : 0;
+            const double sw = !in_fit ? 0.0 : (a.w ? sqrt((double)static_cast<const T *>(a.w)[s + r]) : 1.0);
             for (int j = 0; j < kt; ++j) {
-                const double x = (j < ku) ? (double)static_cast<const T *>(a.x[j])[s + r] : 1.0;
-                W[(size_t)j * n + r] = x * sw;
+                const double x = (j < ku) ? (double)null_fill<T>(pol, static_cast<const T *>(a.x[j])[s + r]) : 1.0;
+                W[(size_t)j * n + r] = in_fit ? x * sw : 0.0;
             }
-            W[(size_t)kt * n + r] = (double)static_cast<const T *>(a.y)[s + r] * sw;
+            W[(size_t)kt * n + r] = in_fit ? (double)null_fill<T>(pol, static_cast<const T *>(a.y)[s + r]) * sw : 0.0;
         }
+        const double nfit = k6_block_sum((double)nfit_l, red);
         for (int q = tid; q < kt * kt; q += 256) V[q] = ((q / kt) == (q % kt)) ? 1.0 : 0.0;
         __syncthreads();
         // ---- one-sided Jacobi sweeps
@@ -107,7 +112,7 @@ __global__ void __launch_bounds__(256) k6_svd_kernel(const K6Args a) {
                 const double coef = (sj > 0.0) ? d * cj[j] / sj : 0.0;
                 acc += V[tid * kt + j] * ((smax != smax) ? smax : coef);
             }
-            if (n == 0) acc = 0.0;
+            if (nfit == 0.0) acc = 0.0;
             beta[tid] = acc;
             if (a.coef) static_cast<T *>(a.coef)[g * kt + tid] = (T)acc;
         }
@@ -118,10 +123,11 @@ __global__ void __launch_bounds__(256) k6_svd_kernel(const K6Args a) {
                 const double sw = a.w ? sqrt((double)static_cast<const T *>(a.w)[s + r]) : 1.0;
                 double p = 0.0;
                 for (int j = 0; j < kt; ++j) {
-                    const double x = (j < ku) ? (double)static_cast<const T *>(a.x[j])[s + r] : 1.0;
+                    const double x = (j < ku) ? (double)null_fill<T>(pol, static_cast<const T *>(a.x[j])[s + r]) : 1.0;
                     p += (x * sw) * beta[j];
                 }
                 if (a.w) p *= 1.0 / sw;
+                if (pol == POLS_NULL_DROP) p = nan_if<double>(null_row_in_fit<T>(pol, a.valid, a.y, a.x, ku, s + r) ? 0u : 1u, p);
                 if (a.pred) static_cast<T *>(a.pred)[s + r] = (T)p;
                 if (a.resid) static_cast<T *>(a.resid)[s + r] = (T)((double)static_cast<const T *>(a.y)[s + r] - p);
             }

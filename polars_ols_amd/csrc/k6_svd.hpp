@@ -21,6 +21,8 @@ struct K6Args {
     double alpha;            // 0: minimum-norm least squares; > 0: ridge via d = s / (s^2 + alpha)
     double rc_factor;        // singular values below rc_factor * s_max are dropped
     int32_t k_user, kt;
+    const uint8_t *valid;    // null policy of the static entry (see common.hpp::null_row_in_fit)
+    int32_t null_policy;
 };
 
 int k6_launch(pols_ctx *ctx, int dtype, const K6Args &a, int workers);

@@ -302,28 +302,27 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
         y_s, xs_s, w_s = y, xs, w
 
     policy = kw.null_policy
-    if policy in ("ignore", "zero"):
+    if mode != "statistics":
+        # Null policies are fused into the kernels (staging pass: dropped rows get weight 0, surviving nulls become 0;
+        # prediction pass: zero-filled features, "drop" masks the rows that were not fitted) -- ex.rs:201-296, 398-427.
+        want = ("coef",) if mode == "coefficients" else (("pred",) if mode == "predictions" else ("resid",))
+        d = kw.to_dict()
+        out = eng.least_squares(y_s, xs_s, offs, weights=w_s, add_intercept=icpt, want=want, **d)
+        coef, pred = out.get("coef"), out.get("pred") if mode == "predictions" else out.get("resid")
+    elif policy in ("ignore", "zero"):
         if policy == "zero":                                   # handle_nulls Zero (ex.rs:264-271)
             y_s, xs_s = _nan_to_zero(y_s), [_nan_to_zero(c) for c in xs_s]
-        if mode == "statistics":
-            return "statistics", _static_statistics(eng, y_s, xs_s, offs, w_s, icpt, kw, names, keys)
-        want = ("coef",) if mode == "coefficients" else (("pred",) if mode == "predictions" else ("resid",))
-        out = _static_fit(eng, y_s, xs_s, offs, w_s, icpt, want, kw)
-        coef, pred = out.get("coef"), out.get("pred") if mode == "predictions" else out.get("resid")
+        return "statistics", _static_statistics(eng, y_s, xs_s, offs, w_s, icpt, kw, names, keys)
     else:
-        # drop / drop_zero / drop_y_zero_x (ex.rs:209-225, 272-291): fit on the valid rows only, predict on the
-        # zero-filled features of EVERY row, mask with the validity for "drop" (ex.rs:398-427).
-        # The reference hands the plugin sqrt_w-scaled columns (ls.py:190-196), so do the scaling here and fit unweighted.
+        # statistics under the drop family (ex.rs:469-471): the statistics kernel sees the valid rows only.  The reference
+        # hands the plugin sqrt_w-scaled columns (ls.py:190-196), so do the scaling here and fit unweighted.
         if w_s is not None:
             sw = torch.sqrt(w_s) if _is_torch(w_s) else np.sqrt(w_s)
             y_f, xs_f = y_s * sw, [c * sw for c in xs_s] + ([sw] if icpt else [])
         else:
-            sw = None
             y_f, xs_f = y_s, list(xs_s) + ([_ones_like(y_s)] if icpt else [])
-        if policy == "drop_y_zero_x":
-            valid = ~_isnan(y_f)
-        else:
-            valid = ~_isnan(y_f)
+        valid = ~_isnan(y_f)
+        if policy != "drop_y_zero_x":
             for c in xs_f:
                 valid = valid & ~_isnan(c)
         vnp = valid.cpu().numpy() if _is_torch(valid) else valid
@@ -335,23 +334,7 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
         xs_v = [_take(c, vi) for c in xs_f]
         if policy == "drop_y_zero_x":
             xs_v = [_nan_to_zero(c) for c in xs_v]
-        if mode == "statistics":
-            return "statistics", _static_statistics(eng, y_v, xs_v, offs_v, None, False, kw, names, keys)
-        out = _static_fit(eng, y_v, xs_v, offs_v, None, False, ("coef",), kw)
-        coef = out["coef"]
-        if mode == "coefficients":
-            pred = None
-        else:
-            gi = _to_index(gid, y_f)
-            rows_coef = coef[gi]                               # broadcast each group's coefficients to its rows
-            pred = eng.predict([_nan_to_zero(c) for c in xs_f], rows_coef)     # construct_features_array(fill_zero) (ex.rs:408)
-            if sw is not None:
-                pred = pred * (1.0 / sw)                       # ls.py:234-235
-            if policy == "drop":
-                nan = float("nan")
-                pred = torch.where(valid, pred, torch.full_like(pred, nan)) if _is_torch(pred) else np.where(valid, pred, nan)
-            if mode == "residuals":
-                pred = y_s - pred                              # ls.py:239 (original target)
+        return "statistics", _static_statistics(eng, y_v, xs_v, offs_v, None, False, kw, names, keys)
     if mode == "coefficients":
         return "coefficients", Coefficients(names, coef, keys, None if order is None and over is None else _unsort(gid, order))
     if order is not None:                                      # scatter back to the frame's row order

@@ -1,0 +1,133 @@
+"""Null policies fused into the static kernels (src/expressions.rs:201-296 compute_is_valid_mask / handle_nulls and the
+prediction rules of :398-427), through the C-ABI: a null is a NaN.  Expected values: the oracle's solver on the rows the
+reference would have kept, predictions composed exactly as the reference composes them."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orc  # noqa: E402
+
+POLICIES = ("zero", "drop", "drop_zero", "drop_y_zero_x", "drop_window")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from polars_ols_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _frame(seed, dtype, k, G=19, lo=30, hi=900, null_frac=0.08):
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(lo, hi, size=G)
+    sizes[3] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    cols = [rng.normal(size=n).astype(dtype) for _ in range(k)]
+    y = (sum(cols) + 0.2 * rng.normal(size=n) + 0.3).astype(dtype)
+    for c in [y] + cols[: max(1, k // 2)]:
+        c[rng.random(n) < null_frac] = np.nan
+    s, e = offs[5], offs[6]
+    y[s:e] = np.nan                                     # a group with no valid target at all
+    w = rng.uniform(0.2, 2.0, size=n).astype(dtype)
+    return y, cols, offs, w
+
+
+def _expected(y, cols, offs, w, icpt, policy, **kw):
+    n = len(y)
+    k = len(cols) + int(icpt)
+    coef = np.zeros((len(offs) - 1, k))
+    pred = np.full(n, np.nan)
+    for g in range(len(offs) - 1):
+        s, e = offs[g], offs[g + 1]
+        if e == s:
+            continue
+        X = np.column_stack([c[s:e] for c in cols]).astype(np.float64)
+        if icpt:
+            X = np.column_stack([X, np.ones(e - s)])
+        yy = y[s:e].astype(np.float64)
+        sw = np.sqrt(w[s:e].astype(np.float64)) if w is not None else np.ones(e - s)
+        Xs, ys = X * sw[:, None], yy * sw
+        if policy == "zero":
+            ok = np.ones(e - s, dtype=bool)
+            Xf, yf = np.nan_to_num(Xs), np.nan_to_num(ys)
+        elif policy == "drop_y_zero_x":
+            ok = ~np.isnan(ys)
+            Xf, yf = np.nan_to_num(Xs), ys
+        else:
+            ok = ~np.isnan(ys) & ~np.isnan(Xs).any(axis=1)
+            Xf, yf = Xs, ys
+        beta = orc.get_coefficients(yf[ok], Xf[ok], **kw) if ok.any() else np.zeros(k)
+        coef[g] = beta
+        p = (np.nan_to_num(Xs) @ beta) / sw
+        if policy == "drop":
+            p[~ok] = np.nan
+        pred[s:e] = p
+    return coef, pred, y.astype(np.float64) - pred
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 3e-4)])
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("k,weights,icpt,kw", [
+    (3, False, False, {}),
+    (8, True, True, {"alpha": 0.5}),
+    (5, False, True, {"alpha": 0.01, "l1_ratio": 0.5, "tol": 1e-10, "max_iter": 20_000}),
+    (20, True, False, {}),
+])
+def test_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt, kw):
+    y, cols, offs, w = _frame(7 + k, dtype, k)
+    w = w if weights else None
+    out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "resid", "status"),
+                            null_policy=policy, **kw)
+    coef, pred, resid = _expected(y, cols, offs, w, icpt, "drop_zero" if policy == "drop_window" else policy, **kw)
+    assert np.allclose(out["coef"], coef, rtol=tol, atol=tol), float(np.nanmax(np.abs(out["coef"] - coef)))
+    assert np.array_equal(np.isnan(out["pred"]), np.isnan(pred))
+    assert np.allclose(out["pred"], pred, rtol=tol, atol=tol, equal_nan=True)
+    assert np.array_equal(np.isnan(out["resid"]), np.isnan(resid))
+    assert np.allclose(out["resid"], resid, rtol=tol, atol=10 * tol, equal_nan=True)
+
+
+def test_validity_bytes_drop_rows(eng):
+    y, cols, offs, _ = _frame(3, np.float64, 4, null_frac=0.0)
+    s, e = offs[5], offs[6]
+    y[s:e] = 1.0
+    rng = np.random.default_rng(1)
+    valid = (rng.random(len(y)) > 0.2).astype(np.uint8)
+    out = eng.least_squares(y, cols, offs, valid=valid, want=("coef", "pred"), null_policy="drop")
+    y2 = y.copy()
+    y2[valid == 0] = np.nan
+    ref = eng.least_squares(y2, cols, offs, want=("coef", "pred"), null_policy="drop")
+    assert np.array_equal(out["coef"], ref["coef"]) and np.array_equal(out["pred"], ref["pred"], equal_nan=True)
+    with pytest.raises(Exception):
+        eng.least_squares(y, cols, offs, valid=valid, want=("coef",), null_policy="ignore")
+
+
+def test_device_matches_host_with_nulls(eng):
+    import torch
+
+    y, cols, offs, w = _frame(5, np.float32, 6)
+    host = eng.least_squares(y, cols, offs, weights=w, add_intercept=True, want=("coef", "pred"), null_policy="drop")
+    dev = eng.least_squares(torch.from_numpy(y).cuda(), [torch.from_numpy(c).cuda() for c in cols], offs,
+                            weights=torch.from_numpy(w).cuda(), add_intercept=True, want=("coef", "pred"), null_policy="drop")
+    torch.cuda.synchronize()
+    assert np.array_equal(host["coef"], dev["coef"].cpu().numpy())
+    assert np.array_equal(host["pred"], dev["pred"].cpu().numpy(), equal_nan=True)
+
+
+def test_rank_deficient_group_under_drop_takes_svd(eng):
+    """After dropping, a group keeps fewer rows than features: flagged, solved by K6 on the surviving rows only."""
+    rng = np.random.default_rng(2)
+    n, k = 40, 6
+    cols = [rng.normal(size=n) for _ in range(k)]
+    y = sum(cols) + 0.1 * rng.normal(size=n)
+    y[4:] = np.nan                                      # 4 valid rows, 6 features
+    offs = np.array([0, n], dtype=np.int64)
+    out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"), null_policy="drop_zero")
+    X = np.column_stack(cols)
+    beta = np.linalg.lstsq(X[:4], y[:4], rcond=None)[0]
+    assert int(out["status"][0]) == 1
+    assert np.allclose(out["coef"][0], beta, rtol=1e-6, atol=1e-8)
+    assert np.allclose(out["pred"], X @ beta, rtol=1e-6, atol=1e-8)
