@@ -15,6 +15,7 @@ steps' tables per collective, on a side stream so it overlaps the following kern
 --config selects the other BASELINE configs for the numbers quoted in DESIGN.md (same JSON shape):
   cfg3  10 000 x 1 000 x 8, f64, ridge alpha = 1 + sample_weights, predictions
   cfg4  1 000 000-row RLS, 6 features, half_life = 21, f64 (ONE sequence: a dependency chain, replicas only)
+  cfg4r the other reading of configs[3]: 1 000 000-row rolling OLS, window = 252, 6 features, f64
   cfg5  100 000 groups x 2 000 rows x 16 feats elastic net alpha = 0.001 l1_ratio = 0.5, f64; the groups are SPLIT
         across the ranks (strong scaling: 100 000 / N per GPU)
 """
@@ -109,6 +110,15 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str):
         plan = eng.plan_recursive_least_squares(y, cols, np.array([0, n], dtype=np.int64), half_life=21.0, out=out)
         text = f"BASELINE configs[3]: ONE {n}-row sequence, {k} feats f64 RLS half_life=21 (coefficients + predictions); replicas only"
         return plan, n, "rows/s", 8 * n * (k + 1) + 8 * n * (k + 1), text, "f64", None, "weak"
+    if cfg == "cfg4r":
+        n, k = 1_000_000, 6
+        y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
+        out = {"pred": torch.empty(n, device="cuda", dtype=torch.float64),
+               "coef": torch.empty(n, k, device="cuda", dtype=torch.float64)}
+        plan = eng.plan_rolling_least_squares(y, cols, np.array([0, n], dtype=np.int64), window_size=252, min_periods=6,
+                                              null_policy="drop", out=out)
+        text = f"BASELINE configs[3], second reading: ONE {n}-row sequence, {k} feats f64 rolling OLS window=252 (coefficients + predictions); replicas only"
+        return plan, n, "rows/s", 8 * n * (k + 1) + 8 * n * (k + 1), text, "f64", None, "weak"
     if cfg == "cfg5":
         Gtot, n, k = 100_000, 2_000, 16
         G = Gtot // world
@@ -131,7 +141,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg4r", "cfg5"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,6 +178,7 @@ def main() -> None:
         # is rewritten only after the gather that read it has finished -- checked on the HOST (the event is long complete in
         # steady state), not with a barrier packet on the engine stream, which would open a bubble per step.
         rings = [torch.empty((RING,) + tuple(coef.shape), device="cuda", dtype=coef.dtype) for _ in range(2)]
+        slots = [[ring[i] for i in range(RING)] for ring in rings]      # views made once, not per step
         gathered = torch.empty((world * RING,) + tuple(coef.shape), device="cuda", dtype=coef.dtype)
         side = torch.cuda.Stream()
         produced = [torch.cuda.Event(), torch.cuda.Event()]
@@ -198,7 +209,7 @@ def main() -> None:
         slot, r = i % RING, (i // RING) & 1
         if slot == 0:
             consumed[r].synchronize()
-        plan.set_output("coef", rings[r][slot])
+        plan.set_output("coef", slots[r][slot])
         plan.run()
         if slot == RING - 1:
             exchange(r)
@@ -249,7 +260,7 @@ def main() -> None:
         except Exception:
             traffic = None
         line = {
-            "metric": "group_regressions_per_sec" if unit_name == "regressions/s" else "rls_rows_per_sec",
+            "metric": "group_regressions_per_sec" if unit_name == "regressions/s" else ("rolling_rows_per_sec" if args.config == "cfg4r" else "rls_rows_per_sec"),
             "value": value, "unit": unit_name, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
@@ -260,7 +271,7 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": eng.last_kernel,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if args.config == "cfg4":
+        if args.config in ("cfg4", "cfg4r"):
             line["roofline"]["note"] = ("single sequence: bound by the serial rank-1 update chain, not by HBM; "
                                         "achieved/peak only shows how far from memory-bound it is")
         if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":

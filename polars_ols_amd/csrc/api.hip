@@ -649,6 +649,20 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
         }
     }
     const int64_t chunk_len = std::min<int64_t>(512, std::max<int64_t>(64, N / 16384));
+    auto &cc = ctx->chunk_cache;
+    if (!hv && cc.tab && cc.tab == ctx->scratch[4].ptr && cc.offs_sum == ctx->offs_sum && cc.n_groups == b->n_groups &&
+        cc.n_rows == N && cc.mp == mp && cc.chunk_len == (int32_t)chunk_len) {      // same frame as the last call
+        void *tot = nullptr;
+        if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)slots * std::max<size_t>(1, (size_t)cc.n_chunks), &tot))) return rc;
+        const char *tp = static_cast<const char *>(cc.tab);
+        a->groups = reinterpret_cast<const K4Group *>(tp);
+        a->chunks = reinterpret_cast<const K4Chunk *>(tp + cc.b_groups);
+        a->cnt = nullptr; a->vidx = nullptr;
+        a->n_chunks = cc.n_chunks; a->n_groups = (int32_t)b->n_groups;
+        a->totals = static_cast<double *>(tot);
+        a->chunk_len = (int32_t)chunk_len;
+        return POLS_OK;
+    }
     std::vector<K4Group> groups((size_t)b->n_groups);
     std::vector<K4Chunk> chunks;
     std::vector<int32_t> cnt, vidx;
@@ -703,6 +717,11 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     a->n_groups = (int32_t)b->n_groups;
     a->totals = static_cast<double *>(tot);
     a->chunk_len = (int32_t)chunk_len;
+    cc.tab = nullptr;
+    if (!hv) {
+        cc.offs_sum = ctx->offs_sum; cc.n_groups = b->n_groups; cc.n_rows = N; cc.mp = mp; cc.n_chunks = a->n_chunks;
+        cc.chunk_len = (int32_t)chunk_len; cc.tab = tab; cc.b_groups = b_groups;
+    }
     return POLS_OK;
 }
 

@@ -59,6 +59,10 @@ struct pols_ctx {
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag
     int32_t epoch = 0;
     bool offs_aligned[2] = {false, false};   // every group start AND size a multiple of 2 / of 4 rows
+    // cache of the chunk tables of the dynamic kernels (scratch slot 4) for mask-free batches: rebuilt only when the
+    // offsets, min_periods or the chunk length change
+    struct { uint64_t offs_sum = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;
+             const void *tab = nullptr; size_t b_groups = 0; } chunk_cache;
 };
 
 namespace pols {

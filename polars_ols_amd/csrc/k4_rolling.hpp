@@ -53,7 +53,8 @@ int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 // 9..32 features: one wave per chunk, state in LDS (k4w_wide.hip).  Totals rows are k*k + k (+ 1 for the RLS decay) doubles.
 int k4w_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3sw_launch(pols_ctx *ctx, int dtype, const K4Args &a);
-// plain exclusive prefix over each group's chunk totals (pass 2 of the rolling kernels)
-void k4_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, unsigned blocks);
+// pass 2 of every chunk-parallel kernel: exclusive prefix of the chunk totals, one wave per (group, component);
+// mode 0 plain (rolling), 1 / 2 decayed with the RLS prior as carry-in (packed / full K x K state), see k4_rolling.hip
+void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);
 
 }  // namespace pols

@@ -178,27 +178,6 @@ __global__ void __launch_bounds__(64) kw_totals_kernel(const K4Args a) {
     if (RLS && cx.lane == 0) a.totals[(size_t)c * nacc + cx.NS] = decay;
 }
 
-// ------------------------------------------------------------------ pass 2 (RLS): decayed exclusive scan with the prior as carry-in
-__global__ void __launch_bounds__(64) kw_rls_scan_kernel(const K4Args a) {
-    const int K = a.k, KK = K * K, NS = KK + K;
-    const int64_t id = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const int64_t g = id / NS;
-    const int q = (int)(id - g * NS);
-    if (g >= a.n_groups) return;
-    const K4Group G = a.groups[g];
-    const int64_t n = G.end - G.start;
-    const int64_t nch = (n + a.chunk_len - 1) / a.chunk_len;
-    double run;                                               // A_0 = I / p0, b_0 = A_0 mean0
-    if (q < KK) run = (q / K == q % K) ? 1.0 / a.p0 : 0.0;
-    else run = a.mean0 ? a.mean0[q - KK] / a.p0 : 0.0;
-    for (int64_t c = 0; c < nch; ++c) {
-        double *row = a.totals + (size_t)(G.first_chunk + c) * (NS + 1);
-        const double t = row[q], d = row[NS];
-        row[q] = run;
-        run = d * run + t;
-    }
-}
-
 // ------------------------------------------------------------------ pass 3: rolling walk (k4_walk_kernel, wave form)
 template <typename T>
 __global__ void __launch_bounds__(64) kw_rolling_walk_kernel(const K4Args a) {
@@ -312,10 +291,9 @@ template <typename T>
 static int kw_rolling_launch_t(pols_ctx *ctx, const K4Args &a) {
     const size_t lds = sizeof(double) * WCtx<T>::lds_doubles(a.k);
     const int nacc = a.k * a.k + a.k;
+    timing_begin(ctx);   // the whole three-launch pass
     hipLaunchKernelGGL((kw_totals_kernel<T, false>), dim3((unsigned)a.n_chunks), dim3(64), lds, ctx->stream, a);
-    const unsigned sblocks = (unsigned)(((int64_t)a.n_groups * nacc + 63) / 64);
-    k4_scan_launch(ctx, a, nacc, sblocks);
-    timing_begin(ctx);
+    chunk_scan_launch(ctx, a, nacc, 0);
     hipLaunchKernelGGL((kw_rolling_walk_kernel<T>), dim3((unsigned)a.n_chunks), dim3(64), lds, ctx->stream, a);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
@@ -326,10 +304,9 @@ template <typename T>
 static int kw_rls_launch_t(pols_ctx *ctx, const K4Args &a) {
     const size_t lds = sizeof(double) * WCtx<T>::lds_doubles(a.k);
     const int ns = a.k * a.k + a.k;
+    timing_begin(ctx);   // the whole three-launch pass
     hipLaunchKernelGGL((kw_totals_kernel<T, true>), dim3((unsigned)a.n_chunks), dim3(64), lds, ctx->stream, a);
-    const unsigned sblocks = (unsigned)(((int64_t)a.n_groups * ns + 63) / 64);
-    hipLaunchKernelGGL(kw_rls_scan_kernel, dim3(sblocks), dim3(64), 0, ctx->stream, a);
-    timing_begin(ctx);
+    chunk_scan_launch(ctx, a, ns, 2);
     hipLaunchKernelGGL((kw_rls_walk_kernel<T>), dim3((unsigned)a.n_chunks), dim3(64), lds, ctx->stream, a);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());

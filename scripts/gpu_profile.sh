@@ -25,3 +25,27 @@ PY
   else tail -3 $O/pmc_$ctr.err; fi
 done
 ls $O | head -30
+cd $R
+echo "== other BASELINE configs"
+for cfg in cfg3 cfg4 cfg5; do
+  timeout 900 python bench.py --config $cfg --steps 20 --warmup 5 2>/dev/null > $O/${TAG}_bench_$cfg.json; cut -c1-700 $O/${TAG}_bench_$cfg.json; echo
+done
+cd /tmp
+echo "== rocprofv3 --kernel-trace --stats, cfg5 (streamed Gram on the matrix cores + coordinate descent + predict)"
+rm -rf $O/kt5; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -o k5 -- python $R/bench.py --config cfg5 --steps 10 --warmup 3 > /dev/null 2> $O/kt5.err
+f=$(find $O/kt5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_cfg5.csv && head -6 $O/${TAG}_kernel_stats_cfg5.csv | cut -c1-220
+echo "== MFMA counters available"
+rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u | tr '\n' ' ' | tee $O/${TAG}_mfma_counters_available.txt; echo
+echo "== rocprofv3 --pmc MFMA busy, cfg5 Gram kernel"
+rm -rf $O/pmc_mfma; timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python $R/bench.py --config cfg5 --steps 3 --warmup 1 > /dev/null 2> $O/pmc_mfma.err
+f=$(find $O/pmc_mfma -name "*counter_collection.csv" | head -1)
+if [ -n "$f" ]; then python3 - "$f" <<'PY' | tee $O/${TAG}_pmc_mfma_cfg5.txt
+import csv,sys,collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    acc[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k,v in acc.items():
+    print(k, {c: sum(x)/len(x) for c,x in v.items()})
+PY
+else tail -5 $O/pmc_mfma.err; fi
+ls $O | head -40
