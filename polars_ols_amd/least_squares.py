@@ -212,13 +212,29 @@ def _take(a, idx):
 
 
 def _to_index(idx, like):
+    if _is_torch(idx):
+        return idx if _is_torch(like) else idx.cpu().numpy()
     if _is_torch(like):
         return torch.as_tensor(idx, device=like.device)
     return idx
 
 
 def _group_layout(key) -> Tuple[Optional[np.ndarray], np.ndarray, np.ndarray, np.ndarray]:
-    """(order or None if already contiguous-sorted, offsets, keys, group id per sorted row) for an ``over`` key."""
+    """(order or None if already contiguous-sorted, offsets, keys, group id per sorted row) for an ``over`` key.
+
+    A CUDA key column never leaves the GPU: stable sort, run-length segmentation and the inverse scatter are device
+    operations; only the per-group row counts (one int per group) come back, because ``group_offsets`` is a host array of
+    the C-ABI -- what Polars' ``.over`` does on the host, done where the columns live."""
+    if _is_torch(key) and key.is_cuda:
+        order = None
+        k = key
+        if k.numel() > 1 and not bool((k[1:] >= k[:-1]).all()):
+            k, order = torch.sort(key, stable=True)
+        keys, counts = torch.unique_consecutive(k, return_counts=True)
+        offsets = np.zeros(keys.numel() + 1, dtype=np.int64)
+        np.cumsum(counts.cpu().numpy(), out=offsets[1:])
+        gid = torch.repeat_interleave(torch.arange(keys.numel(), device=key.device), counts)
+        return order, offsets, keys.cpu().numpy(), gid
     k = key.cpu().numpy() if _is_torch(key) else np.asarray(key)
     order = None
     if not bool(np.all(k[1:] >= k[:-1])):
@@ -327,7 +343,8 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
                 valid = valid & ~_isnan(c)
         vnp = valid.cpu().numpy() if _is_torch(valid) else valid
         vidx = np.nonzero(vnp)[0]
-        full_counts = np.bincount(gid[vnp], minlength=len(offs) - 1)          # valid rows per group
+        gid_h = gid.cpu().numpy() if _is_torch(gid) else gid
+        full_counts = np.bincount(gid_h[vnp], minlength=len(offs) - 1)        # valid rows per group
         offs_v = np.concatenate([[0], np.cumsum(full_counts)]).astype(np.int64)
         vi = _to_index(vidx, y_f)
         y_v = _take(y_f, vi)
@@ -338,17 +355,17 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
     if mode == "coefficients":
         return "coefficients", Coefficients(names, coef, keys, None if order is None and over is None else _unsort(gid, order))
     if order is not None:                                      # scatter back to the frame's row order
-        inv = np.empty(n, dtype=np.int64)
-        inv[order] = np.arange(n)
-        pred = _take(pred, _to_index(inv, pred))
+        pred = _unsort(pred, order)
     return target.output_name, pred
 
 
-def _unsort(gid: np.ndarray, order: Optional[np.ndarray]) -> np.ndarray:
+def _unsort(a, order):
+    """sorted position i holds the frame's row order[i]: out[order[i]] = a[i] (numpy or torch, index on a's side)."""
     if order is None:
-        return gid
-    out = np.empty_like(gid)
-    out[order] = gid
+        return a
+    idx = _to_index(order, a)
+    out = torch.empty_like(a) if _is_torch(a) else np.empty_like(a)
+    out[idx] = a
     return out
 
 
@@ -401,9 +418,7 @@ def _apply_dynamic(frame: Frame, over, eng: Optional[Engine], target: Expr, feat
                                         null_policy=policy)
     res = out["coef"] if mode == "coefficients" else out["pred"]
     if order is not None:
-        inv = np.empty(n, dtype=np.int64)
-        inv[order] = np.arange(n)
-        res = _take(res, _to_index(inv, res))
+        res = _unsort(res, order)
     if mode == "coefficients":
         return "coefficients", Coefficients(names, res)
     pred = res
