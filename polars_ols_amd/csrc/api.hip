@@ -11,6 +11,7 @@
 #include "k5_enet.hpp"
 #include "k6_svd.hpp"
 #include "k7_stats.hpp"
+#include "k8_wide.hpp"
 
 namespace pols {
 template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);   // k1m_f32.hip / k1m_f64.hip
@@ -108,7 +109,7 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct Staged {
     const void *y = nullptr, *w = nullptr;
     const uint8_t *valid = nullptr;
-    const void *x[POLS_MAX_FEATURES] = {};
+    std::vector<const void *> x;     // n_features column pointers (device)
     void *coef = nullptr, *pred = nullptr, *resid = nullptr;
     int32_t *status = nullptr;
 };
@@ -118,6 +119,7 @@ static size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
 static int stage_inputs(pols_ctx *ctx, const pols_batch *b, int64_t coef_rows, int kt, const pols_out *o, Staged *st) {
     const size_t sz = dtype_size(b->dtype);
     const size_t colb = round256(sz * (size_t)b->n_rows);
+    st->x.assign((size_t)b->n_features, nullptr);
     if (b->mem == POLS_MEM_DEVICE) {
         st->y = b->y; st->w = b->weights; st->valid = b->valid;
         for (int j = 0; j < b->n_features; ++j) st->x[j] = b->x_cols[j];
@@ -175,14 +177,14 @@ static int unstage_outputs(pols_ctx *ctx, const pols_batch *b, int64_t coef_rows
     return POLS_OK;
 }
 
-static int check_batch(const pols_batch *b, const pols_out *o) {
+static int check_batch(const pols_batch *b, const pols_out *o, int max_features = POLS_MAX_FEATURES) {
     if (!b || !o) return fail(POLS_ERR_INVALID, "batch / out is NULL");
     if (b->dtype != POLS_F32 && b->dtype != POLS_F64) return fail(POLS_ERR_INVALID, "dtype must be POLS_F32 or POLS_F64");
     if (b->mem != POLS_MEM_HOST && b->mem != POLS_MEM_DEVICE) return fail(POLS_ERR_INVALID, "mem must be POLS_MEM_HOST or POLS_MEM_DEVICE");
     if (b->n_rows < 0 || b->n_groups < 0) return fail(POLS_ERR_INVALID, "negative size");
     if (b->n_features < 1) return fail(POLS_ERR_INVALID, "must pass at least 2 series");  // ex.rs:72
-    if (b->n_features + (b->add_intercept ? 1 : 0) > POLS_MAX_FEATURES)
-        return fail(POLS_ERR_UNSUPPORTED, "%d features > POLS_MAX_FEATURES", b->n_features);
+    if (b->n_features + (b->add_intercept ? 1 : 0) > max_features)
+        return fail(POLS_ERR_UNSUPPORTED, "%d features (+ intercept) > %d", b->n_features, max_features);
     if (!b->group_offsets || !b->x_cols || (!b->y && b->n_rows)) return fail(POLS_ERR_INVALID, "NULL column / offsets pointer");
     if (b->group_offsets[0] != 0 || b->group_offsets[b->n_groups] != b->n_rows)
         return fail(POLS_ERR_INVALID, "group_offsets must start at 0 and end at n_rows");
@@ -324,10 +326,81 @@ struct LsInfo {
     int kt = 0;
 };
 
+// 32 .. 1024 columns (k8_wide.hip): Gram in 64 x 64 MFMA tiles with row splits, workgroup Cholesky / coordinate descent on
+// the Gram matrix in HBM, minimum-norm fallback for flagged groups of at most 32 rows, prediction pass.
+static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, int kt, bool enet,
+                       double ridge_alpha, double enet_l1, bool ols_branch) {
+    int rc;
+    const int64_t *d_offs = nullptr;
+    int64_t max_rows = 0;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
+    Staged st;
+    if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
+    const size_t G = (size_t)b->n_groups;
+    const int NZ = kt + 1, nt = (NZ + 63) / 64, npairs = nt * (nt + 1) / 2;
+    const size_t mat = sizeof(double) * (size_t)NZ * NZ;
+    // row splits: enough workgroups to fill the chip when there are few groups, bounded by the partial-Gram memory
+    int64_t splits = std::max<int64_t>(1, (2048 + (int64_t)G * npairs - 1) / ((int64_t)G * npairs));
+    splits = std::min<int64_t>(splits, std::max<int64_t>(1, (max_rows + 255) / 256));
+    while (splits > 1 && (double)splits * (double)G * (double)mat > 2e9) splits /= 2;
+    int64_t rps = (std::max<int64_t>(1, max_rows) + splits - 1) / splits;
+    rps = (rps + 63) / 64 * 64;
+    splits = (std::max<int64_t>(1, max_rows) + rps - 1) / rps;
+
+    void *tab = nullptr, *scr = nullptr;
+    if ((rc = ensure_scratch(ctx, 6, sizeof(void *) * (size_t)b->n_features, &tab))) return rc;
+    POLS_HIP(hipMemcpyAsync(tab, st.x.data(), sizeof(void *) * (size_t)b->n_features, hipMemcpyHostToDevice, ctx->stream));
+    POLS_HIP(hipStreamSynchronize(ctx->stream));                       // st.x is a local
+    const size_t gram_b = round256(mat * G), part_b = round256(mat * G * (size_t)splits), c64_b = round256(sizeof(double) * G * kt);
+    if ((rc = ensure_scratch(ctx, 5, gram_b + part_b + c64_b, &scr))) return rc;
+    if (!st.status) {
+        void *sp = nullptr;
+        if ((rc = ensure_scratch(ctx, 7, sizeof(int32_t) * G, &sp))) return rc;
+        st.status = static_cast<int32_t *>(sp);
+    }
+    if (!ctx->fb_flag) {
+        POLS_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->fb_flag), 256));
+        POLS_HIP(hipMemsetAsync(ctx->fb_flag, 0, 256, ctx->stream));
+    }
+    ctx->epoch = (ctx->epoch % 0x3fffffff) + 1;
+
+    WideArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cols = static_cast<const void *const *>(tab);
+    a.y = st.y; a.w = st.w; a.offs = d_offs; a.n_groups = b->n_groups; a.n_rows = b->n_rows;
+    a.k_user = b->n_features; a.kt = kt;
+    a.gram = static_cast<double *>(scr);
+    a.partial = reinterpret_cast<double *>(static_cast<char *>(scr) + gram_b);
+    a.coef64 = reinterpret_cast<double *>(static_cast<char *>(scr) + gram_b + part_b);
+    a.splits = (int32_t)splits; a.rows_per_split = rps;
+    a.alpha = enet ? p->alpha : ridge_alpha; a.l1_ratio = enet_l1; a.tol = p->tol; a.max_iter = p->max_iter;
+    a.positive = p->positive ? 1 : 0; a.active_set = (p->solve_method == POLS_SOLVE_CD_ACTIVE_SET) ? 1 : 0;
+    a.pivot_tol = 0.0;   // only a failed factorisation is flagged: there is no QR-grade refinement for wide groups
+    a.rc_factor = ols_branch ? 2.220446049250313e-16
+                             : (p->solve_method == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt)) : 0.0);
+    a.status = st.status; a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
+    a.coef = st.coef; a.pred = st.pred; a.resid = st.resid;
+    if ((rc = wide_gram_launch(ctx, b->dtype, a))) return rc;
+    if (enet) {
+        if ((rc = wide_cd_launch(ctx, b->dtype, a))) return rc;
+    } else {
+        if ((rc = wide_chol_launch(ctx, b->dtype, a))) return rc;
+        const int workers = (int)std::min<size_t>(G, 64);
+        void *wk = nullptr;
+        a.work_stride = (int64_t)K8_MINNORM_ROWS * kt;
+        if ((rc = ensure_scratch(ctx, 3, sizeof(double) * (size_t)workers * (size_t)a.work_stride, &wk))) return rc;
+        a.work = static_cast<double *>(wk);
+        if ((rc = wide_minnorm_launch(ctx, b->dtype, a, workers))) return rc;
+    }
+    if (st.pred || st.resid)
+        if ((rc = wide_predict_launch(ctx, b->dtype, a))) return rc;
+    return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
+}
+
 static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, LsInfo *info) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if ((rc = check_batch(b, o))) return rc;
+    if ((rc = check_batch(b, o, info ? POLS_MAX_FEATURES - 1 : K8_KMAX))) return rc;
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
     // Null policies (src/expressions.rs:201-296): a null is a NaN; `valid` (optional) additionally drops rows under the
     // drop family.  They are fused into the streamed path's staging / prediction passes -- no compaction, no copies.
@@ -361,6 +434,11 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
 
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
     if (b->n_groups == 0) return POLS_OK;
+    if (kt > 31) {
+        if (nulls) return fail(POLS_ERR_UNSUPPORTED, "null policies are not built for more than 31 columns: filter upstream");
+        const bool ols_b = !enet && ridge_alpha == 0.0 && alpha == 0.0;
+        return wide_static(ctx, b, p, o, kt, enet, ridge_alpha, enet_l1, ols_b);
+    }
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
@@ -764,7 +842,7 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
     pols_out o;
     std::memset(&o, 0, sizeof(o));
     o.pred = pred_out;
-    if ((rc = check_batch(b, &o))) return rc;
+    if ((rc = check_batch(b, &o, K8_KMAX))) return rc;
     if (!coef || !pred_out) return fail(POLS_ERR_INVALID, "coef / pred_out is NULL");
     if (coef_rows != b->n_rows) return fail(POLS_ERR_INVALID, "number of coefficient rows must match the number of rows");
     if (b->weights) return fail(POLS_ERR_INVALID, "predict takes no weights");
@@ -782,6 +860,19 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
         if ((rc = ensure_scratch(ctx, 5, bytes, &d))) return rc;
         POLS_HIP(hipMemcpyAsync(d, coef, bytes, hipMemcpyHostToDevice, ctx->stream));
         d_coef = d;
+    }
+    if (kt > POLS_MAX_FEATURES) {                                  // wide frames: column pointers through a device table
+        void *tab = nullptr;
+        if ((rc = ensure_scratch(ctx, 6, sizeof(void *) * (size_t)b->n_features, &tab))) return rc;
+        POLS_HIP(hipMemcpyAsync(tab, st.x.data(), sizeof(void *) * (size_t)b->n_features, hipMemcpyHostToDevice, ctx->stream));
+        POLS_HIP(hipStreamSynchronize(ctx->stream));
+        WideArgs wa;
+        std::memset(&wa, 0, sizeof(wa));
+        wa.cols = static_cast<const void *const *>(tab);
+        wa.n_rows = b->n_rows; wa.k_user = b->n_features; wa.kt = kt; wa.pred = st.pred;
+        ctx->last_kernel = "k8_wide_predict_rows";
+        if ((rc = wide_predict_rows_launch(ctx, b->dtype, wa, d_coef))) return rc;
+        return unstage_outputs(ctx, b, b->n_rows, kt, &o, st);
     }
     PredictArgs pa;
     std::memset(&pa, 0, sizeof(pa));

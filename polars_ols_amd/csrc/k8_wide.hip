@@ -1,0 +1,428 @@
+// k8_wide.hip -- K8: OLS / ridge / elastic net for 32 .. 1024 columns per group.
+//
+// The reference's own wide cases -- tests/benchmark.py (10 000 x 100), test_elastic_net (up to 1 000 features),
+// test_fit_wide (10 rows x up to 1 000 features) -- go through the same dispatcher (src/expressions.rs:351-388) as the
+// narrow ones; here the Gram matrix no longer fits a wave, so every step is a workgroup-sized kernel over matrices in
+// HBM / L2, and the feature columns arrive through a device table of pointers instead of a fixed kernel-argument array:
+//   gram      Z'Z, Z = [sqrt(w) X | sqrt(w) 1 | sqrt(w) y], in 64 x 64 tiles on the f64 matrix cores (16x16x4 MFMA):
+//             one workgroup per (tile pair, group, row split); 64-row chunks staged through LDS as f64 with the sqrt(w)
+//             scaling applied on the way in; partial Grams per row split are summed in a fixed order (no atomics, so the
+//             result is run-to-run identical) by `reduce`, which also mirrors the lower triangle.
+//   chol      solve_ols / solve_ridge on the normal equations: right-looking Cholesky in place, the scaled column kept
+//             in LDS for the rank-1 trailing update, then the two triangular solves.  Same pivot test as the narrow
+//             kernels; what it cannot factor is flagged (POLS_GROUP_FALLBACK).
+//   minnorm   flagged groups with at most 32 rows (n < k, test_fit_wide): minimum-norm solution through one-sided Jacobi
+//             on X' (its 32 or fewer columns of length k): X = V S U'  =>  beta = U S^+ V'y  (dgelsd semantics,
+//             ls.rs:183-191; ridge d = s / (s^2 + alpha), :143-148).
+//   cd        solve_elastic_net (ls.rs:386-492) in Gram form: per coordinate one workgroup-wide dot of a Gram row with
+//             the coefficient vector in LDS; same order, alpha * n scaling, soft threshold, active set and stop rule.
+//   predict   X . beta (+ residuals) with the reference's weighted arithmetic.
+#include "k8_wide.hpp"
+#include "k1m_kernel.inl"   // Mfma16
+
+namespace pols {
+
+constexpr int WG_TS = 64;        // tile side (columns of Z)
+constexpr int WG_RS = 65;        // LDS row stride of a staged column (doubles)
+
+template <typename T>
+__device__ __forceinline__ double wide_z(const WideArgs &a, const void *colp, int z, int64_t r) {   // unscaled Z[r][z]
+    const int ku = a.k_user, kt = a.kt;
+    if (z < ku) return (double)static_cast<const T *>(colp)[r];
+    if (z == kt) return (double)static_cast<const T *>(a.y)[r];
+    if (z == kt - 1 && ku != kt) return 1.0;
+    return 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------ gram
+template <typename T>
+__global__ void __launch_bounds__(256) wide_gram_kernel(const WideArgs a) {
+    using M = Mfma16<double>;
+    __shared__ double Zi[WG_TS * WG_RS], Zj[WG_TS * WG_RS];
+    __shared__ double sw_s[WG_TS];
+    __shared__ const void *cp_i[WG_TS], *cp_j[WG_TS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NZ = a.kt + 1, nt = (NZ + WG_TS - 1) / WG_TS;
+    int ti = 0, rem = blockIdx.x;                                  // pair index -> (ti <= tj)
+    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+    const int tj = ti + rem;
+    const int64_t g = blockIdx.y;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t r_begin = s + (int64_t)blockIdx.z * a.rows_per_split;
+    const int64_t r_end = min(e, r_begin + a.rows_per_split);
+    if (r_begin >= r_end) return;                                  // `reduce` only sums the splits that hold rows
+    if (tid < WG_TS) {
+        const int zi = WG_TS * ti + tid, zj = WG_TS * tj + tid;
+        cp_i[tid] = zi < a.k_user ? a.cols[zi] : nullptr;
+        cp_j[tid] = zj < a.k_user ? a.cols[zj] : nullptr;
+    }
+    M::acc_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = M::acc_t{0, 0, 0, 0};
+    const double *ZJ = (ti == tj) ? Zi : Zj;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += WG_TS) {
+        const int rows_here = (int)min((int64_t)WG_TS, r_end - r0);
+        __syncthreads();                                           // previous chunk consumed; pointer table visible
+        if (tid < WG_TS) sw_s[tid] = tid < rows_here ? (a.w ? sqrt((double)static_cast<const T *>(a.w)[r0 + tid]) : 1.0) : 0.0;
+        __syncthreads();
+        for (int idx = tid; idx < WG_TS * WG_TS; idx += 256) {
+            const int c = idx >> 6, r = idx & 63;
+            const bool in = r < rows_here;
+            const int zi = WG_TS * ti + c;
+            Zi[c * WG_RS + r] = (in && zi < NZ) ? wide_z<T>(a, cp_i[c], zi, r0 + r) * sw_s[r] : 0.0;
+            if (ti != tj) {
+                const int zj = WG_TS * tj + c;
+                Zj[c * WG_RS + r] = (in && zj < NZ) ? wide_z<T>(a, cp_j[c], zj, r0 + r) * sw_s[r] : 0.0;
+            }
+        }
+        __syncthreads();
+        const int zc = lane & 15, kq = lane >> 4;
+        const double *ap = Zi + (16 * wv + zc) * WG_RS + kq;
+        const double *bp = ZJ + zc * WG_RS + kq;
+#pragma unroll 4
+        for (int rr = 0; rr < WG_TS; rr += 4) {
+            const double av = ap[rr];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = M::mma(av, bp[16 * t * WG_RS + rr], acc[t]);
+        }
+    }
+    double *P = a.partial + ((size_t)blockIdx.z * a.n_groups + g) * NZ * NZ;
+    const int dcol = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = WG_TS * ti + 16 * wv + (lane >> 4) + 4 * reg, j = WG_TS * tj + 16 * t + dcol;
+            if (i < NZ && j < NZ) P[(size_t)i * NZ + j] = acc[t][reg];
+        }
+}
+
+__global__ void __launch_bounds__(256) wide_reduce_kernel(const WideArgs a) {
+    const int NZ = a.kt + 1;
+    const int64_t g = blockIdx.y;
+    const int64_t n = a.offs[g + 1] - a.offs[g];
+    const int nsp = (int)((n + a.rows_per_split - 1) / a.rows_per_split);
+    const size_t mat = (size_t)NZ * NZ;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < mat; q += (size_t)gridDim.x * 256) {
+        int i = (int)(q / NZ), j = (int)(q - (size_t)i * NZ);
+        if (i / WG_TS > j / WG_TS) { const int t = i; i = j; j = t; }        // only tile pairs ti <= tj were computed
+        double v = 0.0;
+        for (int sp = 0; sp < nsp; ++sp) v += a.partial[((size_t)sp * a.n_groups + g) * mat + (size_t)i * NZ + j];
+        a.gram[(size_t)g * mat + q] = v;
+    }
+}
+
+int wide_gram_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
+    const int NZ = a.kt + 1, nt = (NZ + WG_TS - 1) / WG_TS, npairs = nt * (nt + 1) / 2;
+    char name[64];
+    std::snprintf(name, sizeof(name), "k8_wide_gram_%s_k%d", dtype == POLS_F32 ? "f32" : "f64", a.kt);
+    ctx->last_kernel = name;
+    timing_begin(ctx);
+    const dim3 grid((unsigned)npairs, (unsigned)a.n_groups, (unsigned)a.splits);
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_gram_kernel<float>, grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(wide_gram_kernel<double>, grid, dim3(256), 0, ctx->stream, a);
+    const unsigned rb = (unsigned)std::min<size_t>(1024, ((size_t)NZ * NZ + 255) / 256);
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3(rb, (unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    timing_end(ctx);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ block reductions
+template <int NV>
+__device__ __forceinline__ void wide_block_sum(double (&v)[NV], double *red, int nwaves) {   // red: NV * nwaves doubles
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double sacc = wave_sum_row3(v[i]);
+        if (lane == 63) red[i * nwaves + wv] = sacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double t = 0.0;
+        for (int w = 0; w < nwaves; ++w) t += red[i * nwaves + w];
+        v[i] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chol
+template <typename T>
+__global__ void __launch_bounds__(1024) wide_chol_kernel(const WideArgs a) {
+    __shared__ double colj[K8_KMAX], bv[K8_KMAX], rinv[K8_KMAX], diag0[K8_KMAX];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kt = a.kt, NZ = kt + 1;
+    const int64_t g = blockIdx.x;
+    const int64_t n = a.offs[g + 1] - a.offs[g];
+    double *A = a.gram + (size_t)g * NZ * NZ;
+    for (int i = tid; i < kt; i += 1024) {
+        const double d = A[(size_t)i * NZ + i] + a.alpha;
+        A[(size_t)i * NZ + i] = d;
+        diag0[i] = d;
+        bv[i] = A[(size_t)i * NZ + kt];
+    }
+    if (tid == 0) ok_s = 1;
+    __syncthreads();
+    for (int j = 0; j < kt; ++j) {
+        const double d = A[(size_t)j * NZ + j];
+        if (tid == 0 && !(d > a.pivot_tol * diag0[j])) ok_s = 0;
+        const double rj = 1.0 / sqrt(d);
+        for (int i = j + 1 + tid; i < kt; i += 1024) {
+            const double v = A[(size_t)i * NZ + j] * rj;
+            colj[i] = v;
+            A[(size_t)i * NZ + j] = v;
+        }
+        if (tid == 0) rinv[j] = rj;
+        __syncthreads();
+        for (int i = j + 1 + wv; i < kt; i += 16) {                // trailing update, lower triangle only
+            const double li = colj[i];
+            double *row = A + (size_t)i * NZ;
+            for (int c = j + 1 + lane; c <= i; c += 64) row[c] -= li * colj[c];
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < kt; ++j) {                                 // forward: t = L^-1 b
+        if (tid == 0) bv[j] *= rinv[j];
+        __syncthreads();
+        const double tj = bv[j];
+        for (int i = j + 1 + tid; i < kt; i += 1024) bv[i] -= A[(size_t)i * NZ + j] * tj;
+        __syncthreads();
+    }
+    for (int j = kt - 1; j >= 0; --j) {                            // backward: beta = L^-T t
+        if (tid == 0) bv[j] *= rinv[j];
+        __syncthreads();
+        const double xj = bv[j];
+        const double *row = A + (size_t)j * NZ;
+        for (int i = tid; i < j; i += 1024) bv[i] -= row[i] * xj;
+        __syncthreads();
+    }
+    int st = POLS_GROUP_OK;
+    if (n == 0) st = POLS_GROUP_EMPTY;
+    else if (!ok_s) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
+    for (int i = tid; i < kt; i += 1024) {
+        const double out = (n == 0) ? 0.0 : bv[i];
+        if (a.coef) static_cast<T *>(a.coef)[g * kt + i] = (T)out;
+        a.coef64[g * kt + i] = out;
+    }
+    if (tid == 0 && a.status) a.status[g] = st;
+}
+
+int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_chol_kernel<float>, dim3((unsigned)a.n_groups), dim3(1024), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(wide_chol_kernel<double>, dim3((unsigned)a.n_groups), dim3(1024), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ minnorm
+template <typename T>
+__global__ void __launch_bounds__(256) wide_minnorm_kernel(const WideArgs a) {
+    constexpr int MR = K8_MINNORM_ROWS;
+    __shared__ double V[MR * MR], s2[MR], gsc[MR], ys[MR], red[3 * 4];
+    __shared__ int rotated;
+    const int tid = threadIdx.x;
+    const int kt = a.kt;
+    if (a.fb_flag && *a.fb_flag != a.epoch) return;
+    double *W = a.work + (size_t)blockIdx.x * a.work_stride;       // [m][kt]: column c = scaled row c of the group
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+        if (a.status[g] != POLS_GROUP_FALLBACK) continue;
+        const int64_t s = a.offs[g], e = a.offs[g + 1];
+        const int64_t n = e - s;
+        if (n > MR) {                                              // rank-deficient AND more than 32 rows: not built
+            for (int j = tid; j < kt; j += 256) {
+                if (a.coef) static_cast<T *>(a.coef)[g * kt + j] = (T)qnan;
+                a.coef64[g * kt + j] = qnan;
+            }
+            continue;
+        }
+        const int m = (int)n;
+        for (int c = 0; c < m; ++c) {
+            const double sw = a.w ? sqrt((double)static_cast<const T *>(a.w)[s + c]) : 1.0;
+            for (int j = tid; j < kt; j += 256) W[(size_t)c * kt + j] = wide_z<T>(a, j < a.k_user ? a.cols[j] : nullptr, j, s + c) * sw;
+            if (tid == 0) ys[c] = (double)static_cast<const T *>(a.y)[s + c] * sw;
+        }
+        for (int q = tid; q < m * m; q += 256) V[q] = ((q / m) == (q % m)) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            if (tid == 0) rotated = 0;
+            for (int p = 0; p < m - 1; ++p)
+                for (int q = p + 1; q < m; ++q) {
+                    double *wp = W + (size_t)p * kt, *wq = W + (size_t)q * kt;
+                    double acc[3] = {0.0, 0.0, 0.0};
+                    for (int j = tid; j < kt; j += 256) { const double u = wp[j], v = wq[j]; acc[0] += u * u; acc[1] += v * v; acc[2] += u * v; }
+                    wide_block_sum<3>(acc, red, 4);
+                    const double al = acc[0], be = acc[1], ga = acc[2];
+                    if (!(ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be))) {
+                        const double zeta = (be - al) / (2.0 * ga);
+                        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                        for (int j = tid; j < kt; j += 256) { const double u = wp[j], v = wq[j]; wp[j] = c * u - sn * v; wq[j] = sn * u + c * v; }
+                        if (tid < m) {
+                            const double u = V[tid * m + p], v = V[tid * m + q];
+                            V[tid * m + p] = c * u - sn * v;
+                            V[tid * m + q] = sn * u + c * v;
+                        }
+                        if (tid == 0) rotated = (ga == ga) ? 1 : 0;
+                    }
+                    __syncthreads();
+                }
+            __syncthreads();
+            if (!rotated) break;
+        }
+        double smax2 = 0.0;
+        for (int c = 0; c < m; ++c) {
+            double acc[1] = {0.0};
+            const double *wc = W + (size_t)c * kt;
+            for (int j = tid; j < kt; j += 256) acc[0] += wc[j] * wc[j];
+            wide_block_sum<1>(acc, red, 4);
+            if (tid == 0) s2[c] = acc[0];
+            smax2 = (acc[0] != acc[0]) ? acc[0] : fmax(smax2, acc[0]);
+        }
+        __syncthreads();
+        if (tid < m) {                                             // g_c = (v_c . y) / (s_c^2 + alpha), dropped below the cut-off
+            const double sc = sqrt(s2[tid]), cutoff = a.rc_factor * sqrt(smax2);
+            double vy = 0.0;
+            for (int r = 0; r < m; ++r) vy += V[r * m + tid] * ys[r];
+            double gv = 0.0;
+            if (sc > cutoff && sc > 0.0) gv = vy / (s2[tid] + a.alpha);
+            if (smax2 != smax2) gv = smax2;
+            gsc[tid] = gv;
+        }
+        __syncthreads();
+        for (int j = tid; j < kt; j += 256) {
+            double b = 0.0;
+            for (int c = 0; c < m; ++c) b += W[(size_t)c * kt + j] * gsc[c];
+            if (m == 0) b = 0.0;
+            if (a.coef) static_cast<T *>(a.coef)[g * kt + j] = (T)b;
+            a.coef64[g * kt + j] = b;
+        }
+        __syncthreads();
+    }
+}
+
+int wide_minnorm_launch(pols_ctx *ctx, int dtype, const WideArgs &a, int workers) {
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_minnorm_kernel<float>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(wide_minnorm_kernel<double>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ cd
+__device__ __forceinline__ double wide_soft_threshold(double x, double thr, bool positive) {   // ls.rs:373-379
+    double r = copysign(fmax(fabs(x) - thr, 0.0), x);
+    if (positive) r = fmax(r, 0.0);
+    return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) wide_cd_kernel(const WideArgs a) {
+    __shared__ double w[K8_KMAX], bv[K8_KMAX], dg[K8_KMAX], red[16];
+    __shared__ unsigned char act[K8_KMAX], act_s[K8_KMAX];
+    const int tid = threadIdx.x;
+    const int kt = a.kt, NZ = kt + 1;
+    const int64_t g = blockIdx.x;
+    const double n = (double)(a.offs[g + 1] - a.offs[g]);
+    const double *G = a.gram + (size_t)g * NZ * NZ;
+    for (int i = tid; i < kt; i += 1024) {
+        w[i] = 0.0;                                                // w = zeros (:416)
+        bv[i] = G[(size_t)i * NZ + kt];
+        dg[i] = G[(size_t)i * NZ + i];                             // xtx[[j, j]] (:431)
+        act[i] = 1;
+    }
+    const double alpha_n = a.alpha * n;                            // alpha * n_samples (:419)
+    const double thr = alpha_n * a.l1_ratio, l2 = alpha_n * (1.0 - a.l1_ratio);
+    const bool positive = a.positive != 0, active_set = a.active_set != 0;
+    int status = (n == 0.0) ? POLS_GROUP_EMPTY : POLS_GROUP_NOT_CONVERGED;
+    __syncthreads();
+    for (int64_t it = 0; it < a.max_iter && n > 0.0; ++it) {
+        for (int i = tid; i < kt; i += 1024) act_s[i] = act[i];    // `for j in active_indices.clone()` (:459)
+        __syncthreads();
+        double d2 = 0.0;
+        for (int j = 0; j < kt; ++j) {
+            if (!act_s[j]) continue;                               // block-uniform
+            const double *row = G + (size_t)j * NZ;
+            const double wj = w[j];
+            double part[1] = {0.0};
+            for (int i = tid; i < kt; i += 1024) part[0] += row[i] * w[i];
+            wide_block_sum<1>(part, red, 16);
+            const double dot = bv[j] - part[0] + dg[j] * wj;       // x_j . (residuals + x_j w_j)  (:428-430)
+            const double wn = wide_soft_threshold(dot, thr, positive) / (dg[j] + l2);
+            const double dw = wn - wj;
+            d2 += dw * dw;
+            if (tid == 0) { w[j] = wn; if (active_set && fabs(wn) < a.tol) act[j] = 0; }   // (:472-476)
+            __syncthreads();                                       // the next coordinate reads the new w[j]
+        }
+        if (sqrt(d2) < a.tol) { status = POLS_GROUP_OK; break; }   // (:436-444), block-uniform
+    }
+    for (int i = tid; i < kt; i += 1024) {
+        const double out = (n == 0.0) ? 0.0 : w[i];
+        if (a.coef) static_cast<T *>(a.coef)[g * kt + i] = (T)out;
+        a.coef64[g * kt + i] = out;
+    }
+    if (tid == 0 && a.status) a.status[g] = status;
+}
+
+int wide_cd_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_cd_kernel<float>, dim3((unsigned)a.n_groups), dim3(1024), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(wide_cd_kernel<double>, dim3((unsigned)a.n_groups), dim3(1024), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ predict
+template <typename T>
+__global__ void __launch_bounds__(256) wide_predict_kernel(const WideArgs a) {
+    __shared__ double cs[K8_KMAX];
+    const int64_t g = blockIdx.y;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int ku = a.k_user, kt = a.kt;
+    for (int j = threadIdx.x; j < kt; j += 256) cs[j] = a.coef64[g * kt + j];
+    __syncthreads();
+    T *pred = static_cast<T *>(a.pred), *resid = static_cast<T *>(a.resid);
+    for (int64_t r = s + (int64_t)blockIdx.x * 256 + threadIdx.x; r < e; r += (int64_t)gridDim.x * 256) {
+        const T sw = a.w ? sqrt(static_cast<const T *>(a.w)[r]) : T(1);
+        T p = T(0);
+        for (int j = 0; j < ku; ++j) p = fma(static_cast<const T *>(a.cols[j])[r] * sw, (T)cs[j], p);
+        if (ku != kt) p = fma(sw, (T)cs[kt - 1], p);
+        if (a.w) p *= T(1) / sw;                                   // (sqrt_w x) . c * (1 / sqrt_w)  (ls.py:190-196, 234-235)
+        if (pred) pred[r] = p;
+        if (resid) resid[r] = static_cast<const T *>(a.y)[r] - p;
+    }
+}
+
+int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
+    if (a.n_groups == 0) return POLS_OK;
+    const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (a.n_rows / std::max<int64_t>(1, a.n_groups) + 255) / 256));
+    const dim3 grid(bx, (unsigned)a.n_groups);
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_predict_kernel<float>, grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(wide_predict_kernel<double>, grid, dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) wide_predict_rows_kernel(const WideArgs a, const T *coef) {
+    const int ku = a.k_user, kt = a.kt;
+    T *pred = static_cast<T *>(a.pred);
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < a.n_rows; r += (int64_t)gridDim.x * 256) {
+        const T *c = coef + r * kt;
+        T p = T(0);
+        for (int j = 0; j < ku; ++j) p = fma(static_cast<const T *>(a.cols[j])[r], c[j], p);   // (features * coefficients).sum_axis(1)
+        if (ku != kt) p += c[kt - 1];
+        pred[r] = p;
+    }
+}
+
+int wide_predict_rows_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const void *coef_rows) {
+    if (a.n_rows == 0) return POLS_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>(4096, (a.n_rows + 255) / 256);
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_predict_rows_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, a, static_cast<const float *>(coef_rows));
+    else hipLaunchKernelGGL(wide_predict_rows_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, a, static_cast<const double *>(coef_rows));
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+}  // namespace pols

@@ -1,0 +1,43 @@
+// k8_wide.hpp -- K8: the static models for 32 .. 1024 columns (see k8_wide.hip).
+#pragma once
+#include "common.hpp"
+
+namespace pols {
+
+constexpr int K8_KMAX = 1024;      // features incl. intercept
+constexpr int K8_MINNORM_ROWS = 32;
+
+struct WideArgs {
+    const void *const *cols;   // DEVICE table of k_user feature column pointers
+    const void *y;
+    const void *w;             // sample weights or nullptr
+    const int64_t *offs;
+    int64_t n_groups, n_rows;
+    int32_t k_user, kt;        // kt = k_user + intercept; NZ = kt + 1 (the target is the last column of Z)
+    double *gram;              // n_groups x NZ x NZ, row-major
+    double *partial;           // splits x n_groups x NZ x NZ
+    int32_t splits;
+    int64_t rows_per_split;    // multiple of 64
+    // solve
+    double alpha, l1_ratio, tol, pivot_tol, rc_factor;
+    int64_t max_iter;
+    int32_t positive, active_set;
+    int32_t *status;
+    int32_t *fb_flag;
+    int32_t epoch;
+    void *coef;                // n_groups x kt, batch dtype, or nullptr
+    double *coef64;            // n_groups x kt
+    double *work;              // min-norm work area: workers x work_stride doubles
+    int64_t work_stride;       // >= K8_MINNORM_ROWS * kt
+    void *pred, *resid;
+};
+
+int wide_gram_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
+int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a);      // OLS / ridge; flags what it cannot factor
+int wide_cd_launch(pols_ctx *ctx, int dtype, const WideArgs &a);        // elastic net / lasso / non-negative
+int wide_minnorm_launch(pols_ctx *ctx, int dtype, const WideArgs &a, int workers);   // flagged groups with <= 32 rows
+int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
+// `predict` plugin body for wide frames: one coefficient row per input row (coef_rows: n_rows x kt, batch dtype)
+int wide_predict_rows_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const void *coef_rows);
+
+}  // namespace pols

@@ -1,0 +1,115 @@
+"""K8: static models for 32 .. 1024 columns (k8_wide.hip) through the C-ABI -- the reference's own wide cases:
+tests/benchmark.py (10 000 x 100), test_elastic_net (100 .. 1 000 features), test_fit_wide (10 rows x up to 1 000)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orc  # noqa: E402
+from refdata import make_data  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from polars_ols_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _frame(seed, dtype, k, sizes, sparsity=0.0):
+    rng = np.random.default_rng(seed)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    cols = [rng.normal(size=n).astype(dtype) for _ in range(k)]
+    kk = max(1, int(k * (1 - sparsity)))
+    y = (sum(c.astype(np.float64) for c in cols[:kk]) + 0.2 * rng.normal(size=n) + 0.3).astype(dtype)
+    w = rng.uniform(0.2, 2.0, size=n).astype(dtype)
+    return y, cols, offs, w
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 5e-4)])
+@pytest.mark.parametrize("k,weights,icpt,alpha", [(32, False, False, 0.0), (40, True, True, 0.0), (100, False, True, 2.0), (130, True, False, 0.0)])
+def test_wide_ols_ridge_vs_oracle(eng, dtype, tol, k, weights, icpt, alpha):
+    y, cols, offs, w = _frame(k, dtype, k, [700, 0, 2_500, 333, 1_111])
+    w = w if weights else None
+    out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, alpha=alpha, want=("coef", "pred", "resid", "status"))
+    assert eng.last_kernel.startswith("k8_wide_gram")
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, alpha=alpha)
+    assert list(out["status"]) == [0, 2, 0, 0, 0]
+    for key in ("coef", "pred", "resid"):
+        assert np.allclose(out[key], ref[key], rtol=tol, atol=tol), (key, float(np.abs(out[key] - ref[key]).max()))
+
+
+def test_reference_benchmark_shape(eng):                             # tests/benchmark.py:219 -- 10 000 rows x 100 features
+    import torch
+
+    d = make_data(n_samples=10_000, n_features=100)
+    y = torch.from_numpy(d["y"]).cuda()
+    cols = [torch.from_numpy(d[f"x{i + 1}"]).cuda() for i in range(100)]
+    out = eng.least_squares(y, cols, np.array([0, 10_000], dtype=np.int64), want=("coef", "pred"))
+    torch.cuda.synchronize()
+    coef = np.linalg.lstsq(d["x"], d["y"], rcond=None)[0]
+    assert np.allclose(out["coef"].cpu().numpy()[0], coef, rtol=1e-6, atol=1e-6)
+    assert np.allclose(out["pred"].cpu().numpy(), d["x"] @ coef, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,sparsity,alpha,method", [(100, 0.5, 0.3, "cd"), (300, 0.5, 1.0, "cd"), (500, 0.9, 0.1, "cd"),
+                                                     (1_000, 0.9, 0.3, "cd_active_set")])
+def test_elastic_net_reference_cases(eng, k, sparsity, alpha, method):   # tests/test_ols.py:562-600
+    d = make_data(n_features=k, sparsity=sparsity)
+    cols = [d[f"x{i + 1}"] for i in range(k)]
+    offs = np.array([0, len(d["y"])], dtype=np.int64)
+    kw = dict(alpha=alpha, l1_ratio=0.5, max_iter=1_000, tol=1e-4, solve_method=method)
+    out = eng.least_squares(d["y"], cols, offs, want=("coef", "pred", "status"), **kw)
+    ref = orc.batched_least_squares(d["y"], cols, offs, **kw)
+    assert int(out["status"][0]) == 0
+    assert np.allclose(out["pred"], ref["pred"], rtol=1e-4, atol=1e-4)     # the reference's own tolerance vs sklearn
+    assert np.allclose(out["coef"], ref["coef"], rtol=1e-4, atol=1e-4)
+
+
+def test_elastic_net_wide_groups_tight(eng):
+    y, cols, offs, w = _frame(3, np.float64, 48, [400, 900, 0, 650], sparsity=0.5)
+    kw = dict(alpha=0.05, l1_ratio=0.7, positive=True, tol=1e-10, max_iter=20_000)
+    out = eng.least_squares(y, cols, offs, weights=w, add_intercept=True, want=("coef", "pred"), **kw)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True, **kw)
+    assert np.allclose(out["coef"], ref["coef"], rtol=1e-6, atol=1e-6) and np.allclose(out["pred"], ref["pred"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("k", [100, 1_000])
+def test_fit_wide_reference_case(eng, k):                            # tests/test_ols.py:272-311 (10 rows, p >> n)
+    d = make_data(n_samples=10, n_features=k, scale=1.0e-4)
+    cols = [d[f"x{i + 1}"] for i in range(k)]
+    offs = np.array([0, 10], dtype=np.int64)
+    ols = eng.least_squares(d["y"], cols, offs, want=("coef", "status"))
+    ridge = eng.least_squares(d["y"], cols, offs, want=("coef",), alpha=1e-5)
+    lasso = eng.least_squares(d["y"], cols, offs, want=("coef",), alpha=1e-6, l1_ratio=1.0, tol=1e-8, max_iter=3_000)
+    assert int(ols["status"][0]) == 1                               # flagged, solved by the minimum-norm path
+    mn = np.linalg.lstsq(d["x"], d["y"], rcond=None)[0]
+    assert np.allclose(ols["coef"][0], mn, rtol=1e-6, atol=1e-8)
+    rr = np.linalg.solve(d["x"].T @ d["x"] + 1e-5 * np.eye(k), d["x"].T @ d["y"])
+    assert np.allclose(ridge["coef"][0], rr, rtol=1e-5, atol=1e-7)
+    for c in (ols["coef"][0], ridge["coef"][0], lasso["coef"][0]):   # the reference's assertion: predictions track y
+        pred = eng.predict(cols, np.tile(c, (10, 1)))
+        assert np.corrcoef(pred, d["y"])[0, 1] > 0.99
+
+
+def test_wide_device_matches_host_and_is_repeatable(eng):
+    import torch
+
+    y, cols, offs, w = _frame(9, np.float32, 70, [1_500, 800])
+    host = eng.least_squares(y, cols, offs, weights=w, add_intercept=True, want=("coef", "pred"))
+    for _ in range(2):
+        dev = eng.least_squares(torch.from_numpy(y).cuda(), [torch.from_numpy(c).cuda() for c in cols], offs,
+                                weights=torch.from_numpy(w).cuda(), add_intercept=True, want=("coef", "pred"))
+        torch.cuda.synchronize()
+        assert np.array_equal(host["coef"], dev["coef"].cpu().numpy()) and np.array_equal(host["pred"], dev["pred"].cpu().numpy())
+
+
+def test_wide_limits(eng):
+    y, cols, offs, _ = _frame(1, np.float64, 40, [100])
+    with pytest.raises(Exception):
+        eng.least_squares(y, cols, offs, want=("coef",), null_policy="drop")
+    with pytest.raises(Exception):
+        eng.recursive_least_squares(y, cols, offs)
