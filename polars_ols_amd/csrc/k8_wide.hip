@@ -148,72 +148,87 @@ __device__ __forceinline__ void wide_block_sum(double (&v)[NV], double *red, int
 }
 
 // ------------------------------------------------------------------------------------------------ chol
-template <typename T>
-__global__ void __launch_bounds__(1024) wide_chol_kernel(const WideArgs a) {
-    __shared__ double colj[K8_KMAX], bv[K8_KMAX], rinv[K8_KMAX], diag0[K8_KMAX];
+// Normal equations by a square-root-free Cholesky (L D L') of the AUGMENTED matrix [A b; b' .]: carrying the target row
+// through the trailing updates makes the forward substitution free, and leaving the columns unscaled means one workgroup
+// barrier per column instead of two -- the factorisation of a k-column group is 2 k barriers in all, which is what
+// bounds a single small problem (the reference's own benchmark shape: ONE 10 000 x 100 group).  d_j are the squared
+// Cholesky pivots, so the pivot test is the narrow kernels' test.  Up to 127 columns the matrix lives in LDS.
+template <typename T, int NTHREADS, bool IN_LDS>
+__global__ void __launch_bounds__(NTHREADS) wide_chol_kernel(const WideArgs a) {
+    extern __shared__ double a_lds[];
+    __shared__ double xs[K8_KMAX], dinv[K8_KMAX];
     __shared__ int ok_s;
+    constexpr int NW = NTHREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kt = a.kt, NZ = kt + 1;
     const int64_t g = blockIdx.x;
     const int64_t n = a.offs[g + 1] - a.offs[g];
-    double *A = a.gram + (size_t)g * NZ * NZ;
-    for (int i = tid; i < kt; i += 1024) {
-        const double d = A[(size_t)i * NZ + i] + a.alpha;
-        A[(size_t)i * NZ + i] = d;
-        diag0[i] = d;
-        bv[i] = A[(size_t)i * NZ + kt];
+    double *Gm = a.gram + (size_t)g * NZ * NZ;
+    const int LD = IN_LDS ? (NZ | 1) : NZ;
+    double *A = IN_LDS ? a_lds : Gm;
+    if (IN_LDS) {
+        for (int q = tid; q < NZ * NZ; q += NTHREADS) { const int i = q / NZ, c = q - i * NZ; if (c <= i) A[i * LD + c] = Gm[q]; }
+        __syncthreads();
     }
+    for (int i = tid; i < kt; i += NTHREADS) A[(size_t)i * LD + i] += a.alpha;
     if (tid == 0) ok_s = 1;
     __syncthreads();
     for (int j = 0; j < kt; ++j) {
-        const double d = A[(size_t)j * NZ + j];
-        if (tid == 0 && !(d > a.pivot_tol * diag0[j])) ok_s = 0;
-        const double rj = 1.0 / sqrt(d);
-        for (int i = j + 1 + tid; i < kt; i += 1024) {
-            const double v = A[(size_t)i * NZ + j] * rj;
-            colj[i] = v;
-            A[(size_t)i * NZ + j] = v;
-        }
-        if (tid == 0) rinv[j] = rj;
-        __syncthreads();
-        for (int i = j + 1 + wv; i < kt; i += 16) {                // trailing update, lower triangle only
-            const double li = colj[i];
-            double *row = A + (size_t)i * NZ;
-            for (int c = j + 1 + lane; c <= i; c += 64) row[c] -= li * colj[c];
+        const double d = A[(size_t)j * LD + j];                   // final: column j - 1's update was the last to touch it
+        const double di = 1.0 / d;
+        if (tid == 0) { dinv[j] = di; if (!(d > a.pivot_tol * (Gm[(size_t)j * NZ + j] + (IN_LDS ? a.alpha : 0.0)))) ok_s = 0; }
+        const double *cj = A + j;                                  // column j: cj[i * LD]
+        for (int i = j + 1 + wv; i <= kt; i += NW) {               // rows j+1 .. kt (row kt is the target row)
+            const double li = cj[(size_t)i * LD] * di;
+            double *row = A + (size_t)i * LD;
+            const int cmax = (i == kt) ? kt - 1 : i;
+            for (int c = j + 1 + lane; c <= cmax; c += 64) row[c] -= li * cj[(size_t)c * LD];
         }
         __syncthreads();
     }
-    for (int j = 0; j < kt; ++j) {                                 // forward: t = L^-1 b
-        if (tid == 0) bv[j] *= rinv[j];
+    // A[kt][j] = d_j z_j with z the forward solution; back substitution  x_j = (A[kt][j] - sum_{i > j} A[i][j] x_i) / d_j
+    for (int i = tid; i < kt; i += NTHREADS) xs[i] = A[(size_t)kt * LD + i];
+    __syncthreads();
+    for (int j = kt - 1; j >= 0; --j) {
+        const double xj = xs[j] * dinv[j];                         // every thread: xs[j] is final after the last barrier
+        const double *row = A + (size_t)j * LD;
+        for (int i = tid; i < j; i += NTHREADS) xs[i] -= row[i] * xj;
         __syncthreads();
-        const double tj = bv[j];
-        for (int i = j + 1 + tid; i < kt; i += 1024) bv[i] -= A[(size_t)i * NZ + j] * tj;
-        __syncthreads();
+        if (tid == 0) xs[j] = xj;
     }
-    for (int j = kt - 1; j >= 0; --j) {                            // backward: beta = L^-T t
-        if (tid == 0) bv[j] *= rinv[j];
-        __syncthreads();
-        const double xj = bv[j];
-        const double *row = A + (size_t)j * NZ;
-        for (int i = tid; i < j; i += 1024) bv[i] -= row[i] * xj;
-        __syncthreads();
-    }
+    __syncthreads();
     int st = POLS_GROUP_OK;
     if (n == 0) st = POLS_GROUP_EMPTY;
     else if (!ok_s) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
-    for (int i = tid; i < kt; i += 1024) {
-        const double out = (n == 0) ? 0.0 : bv[i];
+    for (int i = tid; i < kt; i += NTHREADS) {
+        const double out = (n == 0) ? 0.0 : xs[i];
         if (a.coef) static_cast<T *>(a.coef)[g * kt + i] = (T)out;
         a.coef64[g * kt + i] = out;
     }
     if (tid == 0 && a.status) a.status[g] = st;
 }
 
-int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
-    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_chol_kernel<float>, dim3((unsigned)a.n_groups), dim3(1024), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(wide_chol_kernel<double>, dim3((unsigned)a.n_groups), dim3(1024), 0, ctx->stream, a);
+template <typename T>
+static int wide_chol_launch_t(pols_ctx *ctx, const WideArgs &a) {
+    const int NZ = a.kt + 1;
+    if (NZ <= 128) {
+        const size_t lds = sizeof(double) * (size_t)NZ * (NZ | 1);
+        static bool attr_set = false;
+        if (!attr_set) {
+            POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_chol_kernel<T, 1024, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((wide_chol_kernel<T, 1024, true>), dim3((unsigned)a.n_groups), dim3(1024), lds, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL((wide_chol_kernel<T, 1024, false>), dim3((unsigned)a.n_groups), dim3(1024), 0, ctx->stream, a);
+    }
     POLS_HIP(hipGetLastError());
     return POLS_OK;
+}
+
+int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
+    return dtype == POLS_F32 ? wide_chol_launch_t<float>(ctx, a) : wide_chol_launch_t<double>(ctx, a);
 }
 
 // ------------------------------------------------------------------------------------------------ minnorm
