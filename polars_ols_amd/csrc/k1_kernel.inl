@@ -158,8 +158,8 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
     T *pred = static_cast<T *>(a.pred);
     T *resid = static_cast<T *>(a.resid);
     if (FAST || (row0 >= s && row0 + VEC <= e)) {
-        if (pred) *reinterpret_cast<V *>(pred + row0) = p;
-        if (resid) *reinterpret_cast<V *>(resid + row0) = r;
+        if (pred) store_stream(reinterpret_cast<V *>(pred + row0), p);
+        if (resid) store_stream(reinterpret_cast<V *>(resid + row0), r);
     } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {

@@ -287,13 +287,13 @@ __global__ void __launch_bounds__(256) k1m_kernel(const K1Args a, const int rs, 
                 if (pred) {
                     V o;
                     if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
-                    *reinterpret_cast<V *>(pred + base + row0) = o;
+                    store_stream(reinterpret_cast<V *>(pred + base + row0), o);
                 }
                 if (resid) {
                     V o;
                     if constexpr (VEC == 4) o = V{yo[0] - p[0], yo[1] - p[1], yo[2] - p[2], yo[3] - p[3]};
                     else o = V{yo[0] - p[0], yo[1] - p[1]};
-                    *reinterpret_cast<V *>(resid + base + row0) = o;
+                    store_stream(reinterpret_cast<V *>(resid + base + row0), o);
                 }
             } else {
 #pragma unroll

@@ -453,11 +453,11 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
             for (int v = 0; v < VEC; ++v) p[v] = nan_if<T>((dropped >> v) & 1u, p[v]);
         }
         if (full) {
-            if (pred) { V o; if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]}; *reinterpret_cast<V *>(pred + row0) = o; }
+            if (pred) { V o; if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]}; store_stream(reinterpret_cast<V *>(pred + row0), o); }
             if (resid) {
                 V o;
                 if constexpr (VEC == 4) o = V{yv[0] - p[0], yv[1] - p[1], yv[2] - p[2], yv[3] - p[3]}; else o = V{yv[0] - p[0], yv[1] - p[1]};
-                *reinterpret_cast<V *>(resid + row0) = o;
+                store_stream(reinterpret_cast<V *>(resid + row0), o);
             }
         } else {
 #pragma unroll

@@ -15,9 +15,30 @@ __global__ void copy4(const float4 *__restrict__ in, float4 *__restrict__ out, s
     for (; i < n; i += stride) out[i] = in[i];
 }
 
+// read-only sweep: every block sums a contiguous slice; the result is written only if it is "impossible" (keeps the loads alive)
+__global__ void read4(const float4 *__restrict__ in, float *sink, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float4 acc = {0, 0, 0, 0};
+    for (; i < n; i += stride) { const float4 v = in[i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
+}
+
+// per-workgroup re-read: a block streams its own SEG bytes (pass 1), idles `spin` iterations, streams the same bytes again
+// (pass 2): is the second pass served on-die (L2 / Infinity Cache) when the whole chip is doing the same thing?
+__global__ void __launch_bounds__(256) reread(const float4 *__restrict__ in, float *sink, int seg_vec, int spin, int passes) {
+    const float4 *p = in + (size_t)blockIdx.x * seg_vec;
+    float4 acc = {0, 0, 0, 0};
+    for (int ps = 0; ps < passes; ++ps) {
+        for (int i = threadIdx.x; i < seg_vec; i += 256) { const float4 v = p[i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        for (int k = 0; k < spin; ++k) __builtin_amdgcn_s_sleep(8);
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
+}
+
 struct Cols { const float *x[9]; float *out; };
 
-template <int TEAM, int RC>
+template <int TEAM, int RC, int NT = 0>   // NT: 1 = nontemporal stores, 2 = nontemporal loads too
 __global__ void __launch_bounds__(256) stream9(Cols c, int rows, int groups) {
     const int tid = threadIdx.x % TEAM;
     const long g = (long)blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM;
@@ -29,7 +50,12 @@ __global__ void __launch_bounds__(256) stream9(Cols c, int rows, int groups) {
         const long r = (long)(rc * TEAM + tid) * 4;
         if (r < rows) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) v[rc][j] = *reinterpret_cast<const float4 *>(c.x[j] + base + r);
+            for (int j = 0; j < 9; ++j) {
+                const float4 *src = reinterpret_cast<const float4 *>(c.x[j] + base + r);
+                if (NT == 2) { v[rc][j].x = __builtin_nontemporal_load(&src->x); v[rc][j].y = __builtin_nontemporal_load(&src->y);
+                               v[rc][j].z = __builtin_nontemporal_load(&src->z); v[rc][j].w = __builtin_nontemporal_load(&src->w); }
+                else v[rc][j] = *src;
+            }
         }
     }
 #pragma unroll
@@ -39,7 +65,10 @@ __global__ void __launch_bounds__(256) stream9(Cols c, int rows, int groups) {
             float4 s = v[rc][0];
 #pragma unroll
             for (int j = 1; j < 9; ++j) { s.x += v[rc][j].x; s.y += v[rc][j].y; s.z += v[rc][j].z; s.w += v[rc][j].w; }
-            *reinterpret_cast<float4 *>(c.out + base + r) = s;
+            float4 *dst = reinterpret_cast<float4 *>(c.out + base + r);
+            if (NT >= 1) { __builtin_nontemporal_store(s.x, &dst->x); __builtin_nontemporal_store(s.y, &dst->y);
+                           __builtin_nontemporal_store(s.z, &dst->z); __builtin_nontemporal_store(s.w, &dst->w); }
+            else *dst = s;
         }
     }
 }
@@ -69,5 +98,26 @@ int main() {
     timeit([&] { stream9<64, 4><<<groups / 4, 256>>>(c, rows, groups); }, "B 9r+1w wave-per-group rc4", bytes9);
     timeit([&] { stream9<256, 1><<<groups, 256>>>(c, rows, groups); }, "C 9r+1w team256 rc1", bytes9);
     timeit([&] { stream9<128, 2><<<groups / 2, 256>>>(c, rows, groups); }, "D 9r+1w team128 rc2", bytes9);
+    timeit([&] { stream9<64, 4, 1><<<groups / 4, 256>>>(c, rows, groups); }, "B1 wave-per-group, nt stores", bytes9);
+    timeit([&] { stream9<64, 4, 2><<<groups / 4, 256>>>(c, rows, groups); }, "B2 wave-per-group, nt loads+stores", bytes9);
+    timeit([&] { stream9<256, 1, 1><<<groups, 256>>>(c, rows, groups); }, "C1 team256, nt stores", bytes9);
+    // ---- does a re-read come from the Infinity Cache?
+    float *sink; CK(hipMalloc(&sink, 64));
+    float4 *huge; const size_t NH = (size_t)2000 * 1000 * 1000 / 16;   // 2 GB
+    CK(hipMalloc(&huge, NH * 16)); CK(hipMemset(huge, 1, NH * 16));
+    for (size_t mb : {32, 64, 128, 192, 256, 400, 1000, 2000}) {
+        const size_t nv = mb * 1000 * 1000 / 16;
+        char name[64]; snprintf(name, sizeof(name), "E read-only sweep of %4zu MB", mb);
+        timeit([&] { read4<<<4096, 256>>>(huge, sink, nv); }, name, (double)nv * 16);
+    }
+    // 88 KB and 272 KB segments (cfg3 / cfg5 groups), 2 GB total so that pass 1 is an HBM stream
+    for (int seg_kb : {88, 272}) {
+        const int seg_vec = seg_kb * 1024 / 16;
+        const int blocks = (int)(NH / seg_vec);
+        for (int passes : {1, 2}) {
+            char name[64]; snprintf(name, sizeof(name), "F %3d KB per block, %d pass(es)", seg_kb, passes);
+            timeit([&] { reread<<<blocks, 256>>>(huge, sink, seg_vec, 0, passes); }, name, (double)blocks * seg_vec * 16);
+        }
+    }
     return 0;
 }
