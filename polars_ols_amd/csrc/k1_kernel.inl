@@ -89,6 +89,54 @@ __device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2
     }
 }
 
+// The packed entries [Q0, Q1) only: the multi-pass Gram of the f64 team kernel keeps a third of the accumulators live at a
+// time (the guards are compile-time constants under the full unroll).
+template <typename T, int KT, bool HAS_W, int Q0, int Q1>
+__device__ __forceinline__ void gram_accumulate_range(T (&acc)[Q1 - Q0], const Chunk<T, KT, HAS_W> &c) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NZ = KT + 1;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        T ys = vget<T>(c.y, v);
+        if constexpr (HAS_W) ys *= vget<T>(c.sw, v);
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            const T xi = vget<T>(c.x[i], v);
+#pragma unroll
+            for (int j = i; j < KT; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int q = tri_index<NZ>(i, j);
+                if (q >= Q0 && q < Q1) acc[q - Q0] = fma(xi, vget<T>(c.x[j], v), acc[q - Q0]);
+            }
+            const int qy = tri_index<NZ>(i, KT);
+            if (qy >= Q0 && qy < Q1) acc[qy - Q0] = fma(xi, ys, acc[qy - Q0]);
+        }
+        const int qq = tri_index<NZ>(KT, KT);
+        if (qq >= Q0 && qq < Q1) acc[qq - Q0] = fma(ys, ys, acc[qq - Q0]);
+    }
+}
+
+// one pass of the multi-pass Gram: accumulate the entries [Q0, Q1) over the resident chunks, reduce-scatter inside the wave,
+// park the wave partials in LDS at their packed slots (Q0 is a multiple of 4, so slot numbering is unchanged)
+template <typename T, int KT, bool HAS_W, int RC, int TEAM, int Q0, int Q1>
+__device__ __forceinline__ void gram_pass(const Chunk<T, KT, HAS_W> (&res)[RC], int64_t nch, int tid, int lane, int wave, T *mypart) {
+    constexpr int N = Q1 - Q0, N4 = (N + 3) / 4, WAVES = TEAM / 64;
+    T acc[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] = T(0);
+#pragma unroll
+    for (int rc = 0; rc < RC; ++rc)
+        if ((int64_t)rc * TEAM + tid < nch) gram_accumulate_range<T, KT, HAS_W, Q0, Q1>(acc, res[rc]);
+    T u[N4];
+    wave_reduce_scatter<T, N>(acc, u);
+    const int row = lane >> 4;
+    const int pr = (row == 1) ? 2 : ((row == 2) ? 1 : row);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < N4; ++i) mypart[(Q0 + 4 * i + pr) * WAVES + wave] = u[i];
+    }
+}
+
 // 1/sqrt(d).  f32: v_rsq_f32 (1 ulp) + one Newton step instead of the ~25-instruction IEEE sqrt + divide
 // chain (the Cholesky is a serial dependency chain, so instruction latency is what it costs); f64: IEEE.
 __device__ __forceinline__ float inv_sqrt(float d) {
@@ -140,6 +188,51 @@ __device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 
     return ok;
 }
 
+// Wave-cooperative variant for the multi-pass kernel: G (packed upper triangle, wave totals already summed) and the factor
+// live in LDS, lane i owns row i of L -- a handful of VGPRs instead of the ~130 the unrolled version keeps live, which is
+// what decides how many f64 workgroups fit a CU.  Returns this lane's coefficient (lanes >= KT: 0).
+template <typename T, int KT>
+__device__ __forceinline__ T chol_solve_lds(const T *G, T alpha, T pivot_tol, T *L, T *rinv, int lane, bool &ok) {
+    constexpr int NZ = KT + 1;
+    if (lane < KT) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) L[lane * KT + j] = G[lane <= j ? tri_index<NZ>(lane, j) : tri_index<NZ>(j, lane)] + (lane == j ? alpha : T(0));
+    }
+    T bi = (lane < KT) ? G[tri_index<NZ>(lane, KT)] : T(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ok = true;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        T d = L[j * KT + j];
+        const T gjj = d;
+#pragma unroll
+        for (int p = 0; p < j; ++p) d = fma(-L[j * KT + p], L[j * KT + p], d);
+        ok = ok && (d > pivot_tol * gjj);
+        const T ri = inv_sqrt(d);
+        if (lane == 0) rinv[j] = ri;
+        if (lane > j && lane < KT) {
+            T sacc = L[lane * KT + j];
+#pragma unroll
+            for (int p = 0; p < j; ++p) sacc = fma(-L[lane * KT + p], L[j * KT + p], sacc);
+            L[lane * KT + j] = sacc * ri;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {                      // forward: t = L^-1 b
+        if (lane == p) bi *= rinv[p];
+        const T tp = __shfl(bi, p);
+        if (lane > p && lane < KT) bi = fma(-L[lane * KT + p], tp, bi);
+    }
+#pragma unroll
+    for (int p = KT - 1; p >= 0; --p) {                 // backward: beta = L^-T t
+        if (lane == p) bi *= rinv[p];
+        const T bp = __shfl(bi, p);
+        if (lane < p) bi = fma(-L[p * KT + lane], bp, bi);
+    }
+    return bi;
+}
+
 template <typename T, int KT, bool HAS_W, bool FAST>
 __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT, HAS_W> &c, const T (&beta)[KT],
                                               int64_t row0, int64_t s, int64_t e) {
@@ -176,7 +269,9 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 // TEAM = 256: one group per block; cross-wave reduction through LDS with ONE barrier.
 // FAST: the host verified that every group starts on a 16-byte boundary, has a multiple of VEC rows and fits
 // the RC * TEAM resident chunks -> no ragged-edge and no overflow code (fewer VGPRs, more groups in flight).
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST>
+// NPASS > 1 (FAST only): the Gram is accumulated in NPASS passes over the resident registers, each keeping 1 / NPASS of the
+// accumulators live -- fewer VGPRs, one more workgroup per CU for the f64 team kernel.
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
@@ -192,9 +287,12 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     const int64_t base = s - (s % VEC);                      // chunk grid is aligned to 16 bytes in every column
     const int64_t nch = (e - base + VEC - 1) / VEC;
 
+    static_assert(NPASS == 1 || FAST, "the multi-pass Gram has no streamed-overflow path");
     T acc[NACC];
+    if constexpr (NPASS == 1) {
 #pragma unroll
-    for (int q = 0; q < NACC; ++q) acc[q] = T(0);
+        for (int q = 0; q < NACC; ++q) acc[q] = T(0);
+    }
 
     // rows beyond register capacity are streamed (Gram pass now, prediction pass at the end); done BEFORE the
     // resident chunks are loaded so the two never share registers
@@ -215,7 +313,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
         if (c < nch) {
             load_chunk<T, KT, HAS_W, FAST>(a, base + c * VEC, s, e, res[rc]);
             if (rc == RC - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
-            gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
+            if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
         }
     }
     K1_STAMP(2);
@@ -226,7 +324,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     __shared__ __attribute__((aligned(16))) T part[(256 / TEAM) * (SLOTS * WAVES + 16)];
     T *mypart = part + (threadIdx.x / TEAM) * (SLOTS * WAVES + 16);   // one region per team
     T *bcast = mypart + SLOTS * WAVES;                       // beta broadcast, 16 slots
-    {
+    if constexpr (NPASS == 1) {
         T u[NACC4];
         wave_reduce_scatter<T, NACC>(acc, u);
         const int row = lane >> 4;
@@ -235,6 +333,12 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 #pragma unroll
             for (int i = 0; i < NACC4; ++i) mypart[(4 * i + pr) * WAVES + wave] = u[i];
         }
+    } else {
+        constexpr int QS = (((NACC + NPASS - 1) / NPASS) + 3) & ~3;    // entries per pass, a multiple of 4
+        gram_pass<T, KT, HAS_W, RC, TEAM, 0, (QS < NACC ? QS : NACC)>(res, nch, tid, lane, wave, mypart);
+        if constexpr (QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, QS, (2 * QS < NACC ? 2 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
+        if constexpr (2 * QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, 2 * QS, (3 * QS < NACC ? 3 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
+        static_assert(3 * QS >= NACC, "at most three passes");
     }
     if constexpr (WAVES > 1) __syncthreads();
     K1_STAMP(3);
@@ -242,6 +346,34 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     // ---- K x K solve on wave-uniform values: ONE wave per team solves (the others would only burn the
     // SIMDs' VALU issue slots that co-resident workgroups need), beta goes back through LDS
     T beta[KT];
+    if constexpr (NPASS > 1) {
+        __shared__ T gsum[NACC + 3], lfac[KT * KT], lrinv[KT];   // TEAM == 256 here: one group per block
+        if (wave == 0) {
+            for (int q = lane; q < NACC; q += 64) {     // NACC = 66 at 10 columns
+                T t = mypart[q * WAVES];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) t += mypart[q * WAVES + w];
+                gsum[q] = t;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int st = POLS_GROUP_OK;
+            T bv = T(0);
+            if (e == s) st = POLS_GROUP_EMPTY;
+            else {
+                bool ok;
+                bv = chol_solve_lds<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lrinv, lane, ok);
+                if (!ok) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
+            }
+            if (tid == 0 && a.status) a.status[g] = st;
+            if (tid < KT) {
+                if (a.coef) static_cast<T *>(a.coef)[g * KT + tid] = bv;
+                bcast[tid] = bv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KT; ++j) beta[j] = bcast[j];
+    } else
     if (wave == 0) {
 #pragma unroll
         for (int q = 0; q < NACC; ++q) {
@@ -268,7 +400,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
             if constexpr (WAVES > 1) bcast[tid] = bv;
         }
     }
-    if constexpr (WAVES > 1) {
+    if constexpr (WAVES > 1 && NPASS == 1) {
         __syncthreads();
         if (wave != 0) {
 #pragma unroll
@@ -297,11 +429,11 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 #undef K1_STAMP
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1>
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
-    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s", sizeof(T) == 4 ? "f32" : "f64", KT,
-                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "");
+    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s%s", sizeof(T) == 4 ? "f32" : "f64", KT,
+                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : "_p3"));
     const int64_t teams_per_block = 256 / TEAM;
     const int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
@@ -315,7 +447,7 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         aa.dbg = static_cast<unsigned long long *>(d);
     }
     timing_begin(ctx);
-    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
     if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
@@ -328,6 +460,13 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     // FAST needs every group aligned to the vector width and resident; the offsets scan in upload_offsets() knows
     const bool fast = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC &&
                       std::getenv("POLS_K1_NOFAST") == nullptr;
+    if constexpr (sizeof(T) == 8 && TEAM == 256 && RC == 2 && KT >= 6) {
+        // f64, 6+ columns: the full accumulator set costs a workgroup per CU; POLS_K1_PASSES=1|2|3 overrides
+        int npass = 2;
+        if (const char *env = std::getenv("POLS_K1_PASSES")) npass = std::atoi(env);
+        if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
+        if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
+    }
     return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false>(ctx, a);
 }
 
