@@ -7,7 +7,11 @@ namespace pols {
 constexpr int KG_CR = 256;   // rows per LDS chunk
 
 // ------------------------------------------------------------------------------------------------ A: gram_stream
-template <typename T, int NT, bool HAS_W>
+// YV (exactly 16 columns of X incl. the intercept, i.e. cfg5's shape): the target would sit alone in a second 16-column tile
+// and double the MFMA count for one useful column -- and the f64 16x16x4 MFMA is a 64-cycle instruction on this part.
+// X'y is then accumulated on the VALU from the operands the lanes already hold (one extra LDS read + FMA per step) and only
+// tile (0, 0) goes through the matrix cores; y'y is not produced (nothing on this path reads it).
+template <typename T, int NT, bool HAS_W, bool YV = false>
 __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, const int rs, const int ncols, const int tile_elems) {
     using V = typename Vec16<T>::type;
     using M = Mfma16<T>;
@@ -48,6 +52,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
     acc_t acc[NPAIR][2];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) { acc[p][0] = acc_t{0, 0, 0, 0}; acc[p][1] = acc_t{0, 0, 0, 0}; }
+    T xy0 = T(0), xy1 = T(0);                       // YV: this lane's share of (X'y)[zc]
 
     if (tid < 2 * K1M_CONST_ELEMS) zeros[tid] = (tid < K1M_CONST_ELEMS) ? T(0) : T(1);
     __shared__ int nfit_s;
@@ -137,6 +142,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
             if (zsrc[t] >= 0) { zp[t] = tile + (size_t)zsrc[t] * rs + t_begin * 8 + rlane; zinc[t] = 8; }
             else { zp[t] = (zsrc[t] == -2) ? ones : zeros; zinc[t] = 0; }
         }
+        const T *yp = tile + (size_t)ku * rs + t_begin * 8 + rlane;      // YV: the target rows matching this lane's operands
         for (int n = t_end - t_begin; n > 0; --n) {
             T v0[NT], v1[NT];
 #pragma unroll
@@ -144,6 +150,14 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
                 if constexpr (sizeof(T) == 4) { const float2 vv = *reinterpret_cast<const float2 *>(zp[t]); v0[t] = vv.x; v1[t] = vv.y; }
                 else { v0[t] = zp[t][0]; v1[t] = zp[t][4]; }
                 zp[t] += zinc[t];
+            }
+            if constexpr (YV) {
+                T y0, y1;
+                if constexpr (sizeof(T) == 4) { const float2 yy = *reinterpret_cast<const float2 *>(yp); y0 = yy.x; y1 = yy.y; }
+                else { y0 = yp[0]; y1 = yp[4]; }
+                yp += 8;
+                xy0 = fma(v0[0], y0, xy0);
+                xy1 = fma(v1[0], y1, xy1);
             }
             int p = 0;
 #pragma unroll
@@ -165,6 +179,12 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
     }
     // ---- cross-wave sum (fixed order) and write-out of the (symmetric) Gram matrix in f64
     T *part = tile;    // [pair][wave][reg * 64 + lane]
+    if constexpr (YV) {                                     // X'y: fold the four row-quarters of the wave, then the waves
+        T xy = xy0 + xy1;
+        xy += __shfl_xor(xy, 16);
+        xy += __shfl_xor(xy, 32);
+        if (lane < 16) part[NPAIR * 4 * 256 + wave * 16 + lane] = xy;
+    }
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
         const acc_t t = acc[p][0] + acc[p][1];
@@ -191,26 +211,36 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
                 if (ti != tj) G[j * NZ + i] = v;
             }
         }
+    if constexpr (YV) {
+        if (tid < 16) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)part[NPAIR * 4 * 256 + w * 16 + tid];
+            G[tid * NZ + kt] = v;
+            G[kt * NZ + tid] = v;
+        }
+        if (tid == 16) G[kt * NZ + kt] = 0.0;               // y'y is not computed on this path
+    }
 }
 
-template <typename T, int NT, bool HAS_W>
+template <typename T, int NT, bool HAS_W, bool YV = false>
 static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     const int ncols = a.k_user + 1 + (HAS_W ? 1 : 0);
     const int rs = k1m_row_stride<T>(KG_CR);
     const int npair = NT * (NT + 1) / 2;
-    const int tile_elems = std::max(ncols * rs, npair * 4 * 256);
+    const int tile_elems = std::max(ncols * rs, npair * 4 * 256 + (YV ? 64 : 0));
     const size_t lds = sizeof(T) * ((size_t)tile_elems + 2 * K1M_CONST_ELEMS);
     static bool attr_set = false;
     if (!attr_set) {
-        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<T, NT, HAS_W>),
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<T, NT, HAS_W, YV>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
     char name[96];
-    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_nt%d%s_k%d", sizeof(T) == 4 ? "f32" : "f64", NT, HAS_W ? "_w" : "", a.kt);
+    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_nt%d%s%s_k%d", sizeof(T) == 4 ? "f32" : "f64", NT, HAS_W ? "_w" : "", YV ? "_yv" : "", a.kt);
     ctx->last_kernel = name;
     timing_begin(ctx);
-    hipLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols, tile_elems);
+    hipLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols, tile_elems);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
@@ -219,6 +249,10 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
     if (a.kt + 1 > 32) return fail(POLS_ERR_UNSUPPORTED, "gram_stream: %d features (incl. intercept) > 31", a.kt);
     const bool two = a.kt + 1 > 16, w = a.w != nullptr || a.null_policy != POLS_NULL_IGNORE;   // null policies ride on the sqrt(w) prep pass
+    if (a.kt == 16 && std::getenv("POLS_KG_NOYV") == nullptr) {   // the target would be alone in the second tile: X'y on the VALU
+        if (dtype == POLS_F32) return w ? gram_stream_launch_t<float, 1, true, true>(ctx, a) : gram_stream_launch_t<float, 1, false, true>(ctx, a);
+        return w ? gram_stream_launch_t<double, 1, true, true>(ctx, a) : gram_stream_launch_t<double, 1, false, true>(ctx, a);
+    }
     if (dtype == POLS_F32) {
         if (two) return w ? gram_stream_launch_t<float, 2, true>(ctx, a) : gram_stream_launch_t<float, 2, false>(ctx, a);
         return w ? gram_stream_launch_t<float, 1, true>(ctx, a) : gram_stream_launch_t<float, 1, false>(ctx, a);
@@ -409,28 +443,42 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { const int64_t r = row0 + v; if (r >= s && r < e) sw[v] = sqrt(static_cast<const T *>(a.w)[r]); }
         }
-        for (int j = 0; j < kt; ++j) {
-            T xv[VEC];
-            if (j < ku) {
-                if (full) {
-                    const V t = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
+        // columns in batches of JB: every load of a batch is issued before the first FMA, so a thread has JB 16-byte
+        // requests in flight instead of one (the per-column loop was a chain of full memory latencies)
+        constexpr int JB = 8;
+        for (int j0 = 0; j0 < kt; j0 += JB) {
+            T xb[JB][VEC];
+            if (full) {
+                V tv[JB];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) xv[v] = vget<T>(t, v);
-                } else {
+                for (int u = 0; u < JB; ++u)
+                    if (j0 + u < ku) tv[u] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j0 + u]) + row0);
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) { const int64_t r = row0 + v; xv[v] = (r >= s && r < e) ? static_cast<const T *>(a.x[j])[r] : T(0); }
-                }
+                for (int u = 0; u < JB; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) xb[u][v] = (j0 + u < ku) ? vget<T>(tv[u], v) : T(1);
             } else {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) xv[v] = T(1);
+                for (int u = 0; u < JB; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const int64_t r = row0 + v;
+                        xb[u][v] = (j0 + u < ku) ? ((r >= s && r < e) ? static_cast<const T *>(a.x[j0 + u])[r] : T(0)) : T(1);
+                    }
             }
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const int64_t r = row0 + v;
-                T c;
-                if (cg) c = (T)cg[j];
-                else c = (r >= s && r < e) ? crow[r * kt + j] : T(0);
-                p[v] = fma(null_fill<T>(pol, xv[v]) * sw[v], c, p[v]);
+            for (int u = 0; u < JB; ++u) {
+                const int j = j0 + u;
+                if (j < kt) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const int64_t r = row0 + v;
+                        T c;
+                        if (cg) c = (T)cg[j];
+                        else c = (r >= s && r < e) ? crow[r * kt + j] : T(0);
+                        p[v] = fma(null_fill<T>(pol, xb[u][v]) * sw[v], c, p[v]);
+                    }
+                }
             }
         }
         (void)icpt;
