@@ -375,9 +375,11 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     a.splits = (int32_t)splits; a.rows_per_split = rps;
     a.alpha = enet ? p->alpha : ridge_alpha; a.l1_ratio = enet_l1; a.tol = p->tol; a.max_iter = p->max_iter;
     a.positive = p->positive ? 1 : 0; a.active_set = (p->solve_method == POLS_SOLVE_CD_ACTIVE_SET) ? 1 : 0;
-    a.pivot_tol = 0.0;   // only a failed factorisation is flagged: there is no QR-grade refinement for wide groups
-    a.rc_factor = ols_branch ? 2.220446049250313e-16
-                             : (p->solve_method == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt)) : 0.0);
+    // OLS branch (the reference solves it with a pivoted QR / dgelsd): groups whose pivots say cond(X)^2 would eat the
+    // tolerance go to the Jacobi-SVD pass, exactly like the narrow path; ridge: only a failed factorisation is flagged
+    a.pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : 0.0;
+    const double eps_nk = 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt);   // see svd_fixup in ls_core
+    a.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (p->solve_method == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
     a.status = st.status; a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.coef = st.coef; a.pred = st.pred; a.resid = st.resid;
     if ((rc = wide_gram_launch(ctx, b->dtype, a))) return rc;
@@ -385,9 +387,12 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         if ((rc = wide_cd_launch(ctx, b->dtype, a))) return rc;
     } else {
         if ((rc = wide_chol_launch(ctx, b->dtype, a))) return rc;
-        const int workers = (int)std::min<size_t>(G, 64);
+        int workers = (int)std::min<size_t>(G, 64);
         void *wk = nullptr;
-        a.work_stride = (int64_t)K8_MINNORM_ROWS * kt;
+        const int64_t ncmax = std::min<int64_t>(std::max<int64_t>(1, max_rows), kt);
+        a.work_w_elems = (int64_t)(kt + 1) * std::max<int64_t>(1, max_rows);
+        a.work_stride = a.work_w_elems + ncmax * ncmax + 2 * ncmax;
+        while (workers > 1 && (double)workers * (double)a.work_stride * 8.0 > 1e9) workers /= 2;
         if ((rc = ensure_scratch(ctx, 3, sizeof(double) * (size_t)workers * (size_t)a.work_stride, &wk))) return rc;
         a.work = static_cast<double *>(wk);
         if ((rc = wide_minnorm_launch(ctx, b->dtype, a, workers))) return rc;
@@ -487,8 +492,11 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         ka.alpha = ridge_alpha;
         // dgelsd drops s < eps * s_max (ls.rs:181-191, rcond ignored); solve_ridge_svd: rcond or eps * max(n, k) (ls.rs:143-145);
         // the Cholesky -> LU fallback of solve_ridge (ls.rs:358-363) has no cut-off at all.
-        ka.rc_factor = ols_branch ? 2.220446049250313e-16
-                                  : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt)) : 0.0);
+        // OLS branch: dgelsd drops s < eps * s_max (rcond ignored, ls.rs:181-191).  The rotations themselves leave an exactly
+        // dependent column with a norm of a few ulps of s_max rather than 0, so the cut-off sits 8 ulps up: enough to drop that
+        // noise, far below the 1e-14-relative singular values the reference's test_fit_multi_collinear expects to be resolved.
+        const double eps_nk = 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt);
+        ka.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
         ka.k_user = b->n_features; ka.kt = kt;
         ka.valid = st.valid; ka.null_policy = pol;
         return k6_launch(ctx, b->dtype, ka, w_use);

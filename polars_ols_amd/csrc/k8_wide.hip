@@ -11,9 +11,9 @@
 //   chol      solve_ols / solve_ridge on the normal equations: right-looking Cholesky in place, the scaled column kept
 //             in LDS for the rank-1 trailing update, then the two triangular solves.  Same pivot test as the narrow
 //             kernels; what it cannot factor is flagged (POLS_GROUP_FALLBACK).
-//   minnorm   flagged groups with at most 32 rows (n < k, test_fit_wide): minimum-norm solution through one-sided Jacobi
-//             on X' (its 32 or fewer columns of length k): X = V S U'  =>  beta = U S^+ V'y  (dgelsd semantics,
-//             ls.rs:183-191; ridge d = s / (s^2 + alpha), :143-148).
+//   minnorm   flagged groups (n < k as in test_fit_wide, collinear columns as in test_fit_multi_collinear): minimum-norm
+//             solution through one-sided Jacobi on whichever of X / X' has fewer columns (dgelsd semantics, ls.rs:183-191;
+//             ridge d = s / (s^2 + alpha), :143-148).
 //   cd        solve_elastic_net (ls.rs:386-492) in Gram form: per coordinate one workgroup-wide dot of a Gram row with
 //             the coefficient vector in LDS; same order, alpha * n scaling, soft threshold, active set and stop rule.
 //   predict   X . beta (+ residuals) with the reference's weighted arithmetic.
@@ -156,7 +156,8 @@ __device__ __forceinline__ void wide_block_sum(double (&v)[NV], double *red, int
 template <typename T, int NTHREADS, bool IN_LDS>
 __global__ void __launch_bounds__(NTHREADS) wide_chol_kernel(const WideArgs a) {
     extern __shared__ double a_lds[];
-    __shared__ double xs[K8_KMAX], dinv[K8_KMAX];
+    constexpr int KCAP = IN_LDS ? 128 : K8_KMAX;                   // the LDS-resident variant is only launched below 128 columns
+    __shared__ double xs[KCAP], dinv[KCAP], diag0[KCAP];
     __shared__ int ok_s;
     constexpr int NW = NTHREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -170,13 +171,13 @@ __global__ void __launch_bounds__(NTHREADS) wide_chol_kernel(const WideArgs a) {
         for (int q = tid; q < NZ * NZ; q += NTHREADS) { const int i = q / NZ, c = q - i * NZ; if (c <= i) A[i * LD + c] = Gm[q]; }
         __syncthreads();
     }
-    for (int i = tid; i < kt; i += NTHREADS) A[(size_t)i * LD + i] += a.alpha;
+    for (int i = tid; i < kt; i += NTHREADS) { const double d0 = A[(size_t)i * LD + i] + a.alpha; A[(size_t)i * LD + i] = d0; diag0[i] = d0; }
     if (tid == 0) ok_s = 1;
     __syncthreads();
     for (int j = 0; j < kt; ++j) {
         const double d = A[(size_t)j * LD + j];                   // final: column j - 1's update was the last to touch it
         const double di = 1.0 / d;
-        if (tid == 0) { dinv[j] = di; if (!(d > a.pivot_tol * (Gm[(size_t)j * NZ + j] + (IN_LDS ? a.alpha : 0.0)))) ok_s = 0; }
+        if (tid == 0) { dinv[j] = di; if (!(d > a.pivot_tol * diag0[j])) ok_s = 0; }   // d_j / G_jj: see chol_solve (k1_kernel.inl)
         const double *cj = A + j;                                  // column j: cj[i * LD]
         for (int i = j + 1 + wv; i <= kt; i += NW) {               // rows j+1 .. kt (row kt is the target row)
             const double li = cj[(size_t)i * LD] * di;
@@ -232,53 +233,57 @@ int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
 }
 
 // ------------------------------------------------------------------------------------------------ minnorm
+// Flagged groups: minimum-norm least squares (LAPACK dgelsd semantics of solve_ols_svd, ls.rs:183-191; ridge
+// d = s / (s^2 + alpha), :143-148) by one-sided Jacobi on whichever side is smaller:
+//   primal (n >= k): the k columns of X (length n) are orthogonalised, X V = U S  =>  beta = V g,  g_c = (w_c . y) / (s_c^2 + alpha)
+//   dual   (n <  k): the n columns of X' (length k),            X' V = U S  =>  beta = W g,  g_c = (v_c . y) / (s_c^2 + alpha)
+// with w_c the rotated columns, and g_c = 0 below the cut-off.  W, V and the small vectors live in a per-worker area in HBM.
 template <typename T>
-__global__ void __launch_bounds__(256) wide_minnorm_kernel(const WideArgs a) {
-    constexpr int MR = K8_MINNORM_ROWS;
-    __shared__ double V[MR * MR], s2[MR], gsc[MR], ys[MR], red[3 * 4];
+__global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
+    __shared__ double red[3 * 4];
     __shared__ int rotated;
     const int tid = threadIdx.x;
     const int kt = a.kt;
     if (a.fb_flag && *a.fb_flag != a.epoch) return;
-    double *W = a.work + (size_t)blockIdx.x * a.work_stride;       // [m][kt]: column c = scaled row c of the group
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    double *W = a.work + (size_t)blockIdx.x * a.work_stride;
+    double *Vm = W + a.work_w_elems;
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         if (a.status[g] != POLS_GROUP_FALLBACK) continue;
-        const int64_t s = a.offs[g], e = a.offs[g + 1];
-        const int64_t n = e - s;
-        if (n > MR) {                                              // rank-deficient AND more than 32 rows: not built
+        const int64_t s = a.offs[g];
+        const int n = (int)(a.offs[g + 1] - s);
+        const bool dual = n < kt;
+        const int nc = dual ? n : kt, len = dual ? kt : n;
+        double *yv = W + (size_t)nc * len;                         // the scaled target, n values
+        double *s2 = Vm + (size_t)nc * nc, *gsc = s2 + nc;
+        for (int r = 0; r < n; r += 1) {
+            // one row at a time keeps the sqrt(w) and target reads trivial; the feature reads are strided either way
+            const double sw = a.w ? sqrt((double)static_cast<const T *>(a.w)[s + r]) : 1.0;
             for (int j = tid; j < kt; j += 256) {
-                if (a.coef) static_cast<T *>(a.coef)[g * kt + j] = (T)qnan;
-                a.coef64[g * kt + j] = qnan;
+                const double z = wide_z<T>(a, j < a.k_user ? a.cols[j] : nullptr, j, s + r) * sw;
+                if (dual) W[(size_t)r * len + j] = z; else W[(size_t)j * len + r] = z;
             }
-            continue;
+            if (tid == 0) yv[r] = (double)static_cast<const T *>(a.y)[s + r] * sw;
         }
-        const int m = (int)n;
-        for (int c = 0; c < m; ++c) {
-            const double sw = a.w ? sqrt((double)static_cast<const T *>(a.w)[s + c]) : 1.0;
-            for (int j = tid; j < kt; j += 256) W[(size_t)c * kt + j] = wide_z<T>(a, j < a.k_user ? a.cols[j] : nullptr, j, s + c) * sw;
-            if (tid == 0) ys[c] = (double)static_cast<const T *>(a.y)[s + c] * sw;
-        }
-        for (int q = tid; q < m * m; q += 256) V[q] = ((q / m) == (q % m)) ? 1.0 : 0.0;
+        for (int q = tid; q < nc * nc; q += 256) Vm[q] = ((q / nc) == (q % nc)) ? 1.0 : 0.0;
         __syncthreads();
         for (int sweep = 0; sweep < 60; ++sweep) {
             if (tid == 0) rotated = 0;
-            for (int p = 0; p < m - 1; ++p)
-                for (int q = p + 1; q < m; ++q) {
-                    double *wp = W + (size_t)p * kt, *wq = W + (size_t)q * kt;
+            for (int p = 0; p < nc - 1; ++p)
+                for (int q = p + 1; q < nc; ++q) {
+                    double *wp = W + (size_t)p * len, *wq = W + (size_t)q * len;
                     double acc[3] = {0.0, 0.0, 0.0};
-                    for (int j = tid; j < kt; j += 256) { const double u = wp[j], v = wq[j]; acc[0] += u * u; acc[1] += v * v; acc[2] += u * v; }
+                    for (int j = tid; j < len; j += 256) { const double u = wp[j], v = wq[j]; acc[0] += u * u; acc[1] += v * v; acc[2] += u * v; }
                     wide_block_sum<3>(acc, red, 4);
                     const double al = acc[0], be = acc[1], ga = acc[2];
                     if (!(ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be))) {
                         const double zeta = (be - al) / (2.0 * ga);
                         const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                         const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                        for (int j = tid; j < kt; j += 256) { const double u = wp[j], v = wq[j]; wp[j] = c * u - sn * v; wq[j] = sn * u + c * v; }
-                        if (tid < m) {
-                            const double u = V[tid * m + p], v = V[tid * m + q];
-                            V[tid * m + p] = c * u - sn * v;
-                            V[tid * m + q] = sn * u + c * v;
+                        for (int j = tid; j < len; j += 256) { const double u = wp[j], v = wq[j]; wp[j] = c * u - sn * v; wq[j] = sn * u + c * v; }
+                        for (int r = tid; r < nc; r += 256) {
+                            const double u = Vm[(size_t)r * nc + p], v = Vm[(size_t)r * nc + q];
+                            Vm[(size_t)r * nc + p] = c * u - sn * v;
+                            Vm[(size_t)r * nc + q] = sn * u + c * v;
                         }
                         if (tid == 0) rotated = (ga == ga) ? 1 : 0;
                     }
@@ -288,29 +293,30 @@ __global__ void __launch_bounds__(256) wide_minnorm_kernel(const WideArgs a) {
             if (!rotated) break;
         }
         double smax2 = 0.0;
-        for (int c = 0; c < m; ++c) {
-            double acc[1] = {0.0};
-            const double *wc = W + (size_t)c * kt;
-            for (int j = tid; j < kt; j += 256) acc[0] += wc[j] * wc[j];
-            wide_block_sum<1>(acc, red, 4);
-            if (tid == 0) s2[c] = acc[0];
+        for (int c = 0; c < nc; ++c) {                             // s_c^2 and, primal, w_c . y
+            double acc[2] = {0.0, 0.0};
+            const double *wc = W + (size_t)c * len;
+            for (int j = tid; j < len; j += 256) { acc[0] += wc[j] * wc[j]; if (!dual) acc[1] += wc[j] * yv[j]; }
+            wide_block_sum<2>(acc, red, 4);
+            if (tid == 0) { s2[c] = acc[0]; gsc[c] = acc[1]; }
             smax2 = (acc[0] != acc[0]) ? acc[0] : fmax(smax2, acc[0]);
         }
         __syncthreads();
-        if (tid < m) {                                             // g_c = (v_c . y) / (s_c^2 + alpha), dropped below the cut-off
-            const double sc = sqrt(s2[tid]), cutoff = a.rc_factor * sqrt(smax2);
-            double vy = 0.0;
-            for (int r = 0; r < m; ++r) vy += V[r * m + tid] * ys[r];
-            double gv = 0.0;
-            if (sc > cutoff && sc > 0.0) gv = vy / (s2[tid] + a.alpha);
+        const double cutoff = a.rc_factor * sqrt(smax2);
+        for (int c = tid; c < nc; c += 256) {
+            double num = gsc[c];
+            if (dual) { num = 0.0; for (int r = 0; r < nc; ++r) num += Vm[(size_t)r * nc + c] * yv[r]; }
+            const double sc = sqrt(s2[c]);
+            double gv = (sc > cutoff && sc > 0.0) ? num / (s2[c] + a.alpha) : 0.0;
             if (smax2 != smax2) gv = smax2;
-            gsc[tid] = gv;
+            gsc[c] = gv;
         }
         __syncthreads();
         for (int j = tid; j < kt; j += 256) {
             double b = 0.0;
-            for (int c = 0; c < m; ++c) b += W[(size_t)c * kt + j] * gsc[c];
-            if (m == 0) b = 0.0;
+            if (dual) { for (int c = 0; c < nc; ++c) b += W[(size_t)c * len + j] * gsc[c]; }
+            else { for (int c = 0; c < nc; ++c) b += Vm[(size_t)j * nc + c] * gsc[c]; }
+            if (n == 0) b = 0.0;
             if (a.coef) static_cast<T *>(a.coef)[g * kt + j] = (T)b;
             a.coef64[g * kt + j] = b;
         }
@@ -319,8 +325,8 @@ __global__ void __launch_bounds__(256) wide_minnorm_kernel(const WideArgs a) {
 }
 
 int wide_minnorm_launch(pols_ctx *ctx, int dtype, const WideArgs &a, int workers) {
-    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_minnorm_kernel<float>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(wide_minnorm_kernel<double>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_svd_kernel<float>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(wide_svd_kernel<double>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

@@ -5,7 +5,6 @@
 namespace pols {
 
 constexpr int K8_KMAX = 1024;      // features incl. intercept
-constexpr int K8_MINNORM_ROWS = 32;
 
 struct WideArgs {
     const void *const *cols;   // DEVICE table of k_user feature column pointers
@@ -27,15 +26,16 @@ struct WideArgs {
     int32_t epoch;
     void *coef;                // n_groups x kt, batch dtype, or nullptr
     double *coef64;            // n_groups x kt
-    double *work;              // min-norm work area: workers x work_stride doubles
-    int64_t work_stride;       // >= K8_MINNORM_ROWS * kt
+    double *work;              // min-norm work area: workers x work_stride doubles, each [W: work_w_elems][V, s^2, g]
+    int64_t work_stride;
+    int64_t work_w_elems;      // (kt + 1) * max_group_rows
     void *pred, *resid;
 };
 
 int wide_gram_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
 int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a);      // OLS / ridge; flags what it cannot factor
 int wide_cd_launch(pols_ctx *ctx, int dtype, const WideArgs &a);        // elastic net / lasso / non-negative
-int wide_minnorm_launch(pols_ctx *ctx, int dtype, const WideArgs &a, int workers);   // flagged groups with <= 32 rows
+int wide_minnorm_launch(pols_ctx *ctx, int dtype, const WideArgs &a, int workers);   // flagged groups: Jacobi SVD, minimum norm
 int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
 // `predict` plugin body for wide frames: one coefficient row per input row (coef_rows: n_rows x kt, batch dtype)
 int wide_predict_rows_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const void *coef_rows);

@@ -39,7 +39,8 @@ def test_fit_wide_min_norm(eng, k):                                  # tests/tes
     assert out["status"][0] == (1 if k > 10 else 0)                 # n < k -> X'X is singular -> fallback taken (n == k: still PD)
 
 
-@pytest.mark.parametrize("n_features,solve_method", [(10, "svd"), (30, "svd"), (10, "qr"), (10, None)])
+@pytest.mark.parametrize("n_features,solve_method", [(10, "svd"), (30, "svd"), (10, "qr"), (10, None),
+                                                     (99, "svd"), (1_000, "svd"), (90, "qr")])   # the reference's own four + small ones
 def test_fit_multi_collinear(eng, n_features, solve_method):         # tests/test_ols.py:315-360
     from refdata import make_data
 

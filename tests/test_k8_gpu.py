@@ -95,6 +95,24 @@ def test_fit_wide_reference_case(eng, k):                            # tests/tes
         assert np.corrcoef(pred, d["y"])[0, 1] > 0.99
 
 
+def test_wide_rank_deficient_tall_groups(eng):
+    """Collinear columns in tall wide groups: flagged by the pivot test, solved by the primal Jacobi pass; healthy groups untouched."""
+    y, cols, offs, _ = _frame(21, np.float64, 50, [400, 900, 650])
+    s, e = offs[1], offs[2]
+    cols[7][s:e] = cols[3][s:e]                                      # group 1: two identical columns
+    out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
+    assert list(out["status"]) == [0, 1, 0]
+    for g in range(3):
+        a, b = offs[g], offs[g + 1]
+        X = np.column_stack([c[a:b] for c in cols])
+        exp = np.linalg.lstsq(X, y[a:b], rcond=None)[0]
+        assert np.allclose(out["pred"][a:b], X @ exp, rtol=1e-6, atol=1e-6)
+        if g != 1:
+            assert np.allclose(out["coef"][g], exp, rtol=1e-6, atol=1e-6)
+        else:
+            assert np.allclose(out["coef"][g], exp, rtol=1e-5, atol=1e-6)   # minimum norm: the twin columns share the weight
+
+
 def test_wide_device_matches_host_and_is_repeatable(eng):
     import torch
 
