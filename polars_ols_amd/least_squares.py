@@ -353,7 +353,8 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
             xs_v = [_nan_to_zero(c) for c in xs_v]
         return "statistics", _static_statistics(eng, y_v, xs_v, offs_v, None, False, kw, names, keys)
     if mode == "coefficients":
-        return "coefficients", Coefficients(names, coef, keys, None if order is None and over is None else _unsort(gid, order))
+        # without .over the single struct broadcasts to every row of the frame, like a Polars scalar (gid is all zeros)
+        return "coefficients", Coefficients(names, coef, keys, _to_index(_unsort(gid, order), coef))
     if order is not None:                                      # scatter back to the frame's row order
         pred = _unsort(pred, order)
     return target.output_name, pred

@@ -205,3 +205,56 @@ def test_over_on_device_frame_matches_host_frame(mode):
         hv = h[key].to_rows() if mode == "coefficients" else h[key]
         gv = g[key].to_rows() if mode == "coefficients" else g[key]
         assert np.allclose(np.asarray(hv), gv.cpu().numpy(), rtol=1e-9, atol=1e-12, equal_nan=True), key
+
+
+@pytest.mark.parametrize("n_features", (2, 10, 100, 1_000))
+def test_fit_wide(n_features):                                  # tests/test_ols.py:272-312, same assertions
+    from polars_ols_amd import Frame, col, predict
+
+    d = make_data(n_samples=10, n_features=n_features, scale=1.0e-4)
+    df = _df(d)
+    features = [col(f"x{i + 1}") for i in range(n_features)]
+    res = df.select(
+        col("y").least_squares.ols(*features, mode="coefficients").alias("coef_ols"),
+        col("y").least_squares.ridge(*features, mode="coefficients", alpha=1.0e-5).alias("coef_ridge"),
+        col("y").least_squares.lasso(*features, mode="coefficients", alpha=1.0e-6, tol=1.0e-8, max_iter=3_000).alias("coef_lasso"),
+    )
+    for key in ("coef_ols", "coef_ridge", "coef_lasso"):
+        pred = predict(res[key], *features, frame=df)
+        assert np.corrcoef(pred, d["y"])[0, 1] == pytest.approx(1.0, rel=1.0e-5, abs=1.0e-5), key
+
+
+@pytest.mark.parametrize("n_features,solve_method", [(10, "svd"), (99, "svd"), (1_000, "svd"), (90, "qr")])
+def test_fit_multi_collinear(n_features, solve_method):         # tests/test_ols.py:315-360, same assertions
+    from polars_ols_amd import Frame, col
+
+    d = make_data(n_samples=100, n_features=n_features, scale=1.0e-4)
+    df = _df(d, {f"x{n_features + 1}": d[f"x{n_features}"] + 1.0e-12})
+    features = [col(f"x{i + 1}") for i in range(n_features + 1)]
+    coef = df.select(col("y").least_squares.ols(*features, mode="coefficients", solve_method=solve_method, rcond=1.0e-16)
+                     .alias("c"))["c"].values[0]
+    x = np.column_stack([df[f"x{i + 1}"] for i in range(n_features + 1)])
+    exp = np.linalg.lstsq(x, d["y"], rcond=1.0e-16)[0]
+    if solve_method == "svd":
+        assert np.allclose(coef, exp, rtol=1.0e-2, atol=1.0e-2)
+        assert np.allclose(x @ coef, x @ exp, rtol=1.0e-4, atol=1.0e-4)
+    else:
+        assert not np.isnan(coef).any()
+        assert np.linalg.norm(coef) != np.linalg.norm(exp)
+        assert np.allclose(x @ coef, x @ exp, rtol=1.0e-4, atol=1.0e-4)
+
+
+@pytest.mark.parametrize("n_features,sparsity,alpha,solve_method", [(2, 0.5, 0.1, "cd"), (100, 0.5, 0.3, "cd"), (500, 0.9, 0.1, "cd"),
+                                                                    (1_000, 0.9, 0.3, "cd_active_set")])
+def test_elastic_net_wide(n_features, sparsity, alpha, solve_method):    # tests/test_ols.py:562-600 vs the committed sklearn fixture logic
+    from oracle import orc
+    from polars_ols_amd import col
+
+    d = make_data(n_features=n_features, sparsity=sparsity)
+    df = _df(d)
+    features = [col(f"x{i + 1}") for i in range(n_features)]
+    pred = df.select(col("y").least_squares.elastic_net(*features, mode="predictions", l1_ratio=0.5, alpha=alpha, max_iter=1_000,
+                                                        tol=0.0001, solve_method=solve_method).alias("p"))["p"]
+    ref = orc.batched_least_squares(d["y"], [d[f"x{i + 1}"] for i in range(n_features)], [0, len(d["y"])], alpha=alpha, l1_ratio=0.5,
+                                    max_iter=1_000, tol=0.0001, solve_method=solve_method)
+    assert np.allclose(pred, ref["pred"], rtol=1.0e-4, atol=1.0e-4)
