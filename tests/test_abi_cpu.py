@@ -84,3 +84,30 @@ def test_product_never_imports_the_oracle():
             txt = f.read_text()
             assert "oracle" not in txt.replace("the CPU oracle under ``oracle/`` is test infrastructure", "") \
                 .replace("and is never imported from here", "") or f.name == "_lib.py", f
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """The boundary is a C ABI: the header compiles as strict C99 and a C translation unit links against the library with
+    nothing but the header (what a cgo / Rust-bindgen / ctypes consumer relies on)."""
+    import shutil
+    import subprocess
+
+    if not _lib.LIB_PATH.exists():
+        _lib.build()
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    src = tmp_path / "consumer.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "pols_mi355x.h"\n'
+        "int main(void) {\n"
+        "    pols_ols_params p; pols_rls_params r; pols_rolling_params w; pols_stats_out s = {0};\n"
+        "    pols_ols_params_default(&p); pols_rls_params_default(&r); pols_rolling_params_default(&w);\n"
+        "    (void)s;\n"
+        '    printf("%s %d %g %lld %d\\n", pols_version(), p.null_policy == POLS_NULL_IGNORE, r.initial_state_covariance,\n'
+        "           (long long)w.window_size, POLS_MAX_FEATURES_STATIC);\n"
+        "    return 0;\n}\n")
+    exe = tmp_path / "consumer"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+                    f"-L{_lib.LIB_PATH.parent}", "-lpols_mi355x", f"-Wl,-rpath,{_lib.LIB_PATH.parent}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[-4:] == ["1", "10", "1000000", "1024"], out
