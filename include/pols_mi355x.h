@@ -195,6 +195,16 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
  * The six statistic arrays are always f64 (the reference's struct fields are Float64) and live where `b->mem` says;
  * any of them may be NULL.  out->pred / out->resid are honoured as in pols_least_squares; out->status receives
  * POLS_GROUP_BAD_DOF where the reference would have hit its df > 0 assertion. */
+/* Several targets regressed on the same features: replaces the plugin `multi_target_least_squares`
+ * (src/expressions.rs:521-591) and solve_multi_target (src/least_squares.rs:243-260).  `b->y` is ignored; `y_cols` holds
+ * n_targets column pointers (the fields of the reference's target struct), `pred_cols` n_targets output columns (or NULL),
+ * `coef` n_groups x n_targets x (n_features + intercept) in the batch dtype (or NULL), `status` n_groups (or NULL); all
+ * live where `b->mem` says.  Unconstrained OLS / ridge with solve_method None or "svd" only, like the reference's Python
+ * checks (polars_ols/least_squares.py:303-318, reported as POLS_ERR_PANIC).  The joint validity mask over targets and
+ * features (ex.rs:539-548) is applied by the caller: null_policy must be "ignore". */
+int pols_multi_target_least_squares(pols_ctx *ctx, const pols_batch *b, const void *const *y_cols, int32_t n_targets,
+                                    const pols_ols_params *p, void *const *pred_cols, void *coef, int32_t *status);
+
 typedef struct pols_stats_out {
     double *r2, *mae, *mse;                 /* n_groups                         */
     double *std_err, *t_values, *p_values;  /* n_groups x (n_features + intercept), row-major */

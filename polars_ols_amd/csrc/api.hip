@@ -328,16 +328,37 @@ struct LsInfo {
 
 // 32 .. 1024 columns (k8_wide.hip): Gram in 64 x 64 MFMA tiles with row splits, workgroup Cholesky / coordinate descent on
 // the Gram matrix in HBM, minimum-norm fallback for flagged groups of at most 32 rows, prediction pass.
+// Multi-target calls (m > 1) pass the target / prediction column tables; the targets share the Gram matrix and one factorisation.
 static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, int kt, bool enet,
-                       double ridge_alpha, double enet_l1, bool ols_branch) {
+                       double ridge_alpha, double enet_l1, bool ols_branch, const void *const *y_cols = nullptr, int m = 1,
+                       void *const *pred_cols = nullptr) {
     int rc;
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
     Staged st;
-    if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
+    if ((rc = stage_inputs(ctx, b, b->n_groups * m, kt, o, &st))) return rc;
     const size_t G = (size_t)b->n_groups;
-    const int NZ = kt + 1, nt = (NZ + 63) / 64, npairs = nt * (nt + 1) / 2;
+    const int NZ = kt + m, nt = (NZ + 63) / 64, npairs = nt * (nt + 1) / 2;
+    // multi-target: device pointers of the m target and m prediction columns (host batches are staged in slot 4)
+    std::vector<const void *> yptr;
+    std::vector<void *> pptr;
+    const bool host = b->mem == POLS_MEM_HOST;
+    const size_t colb_mt = round256(dtype_size(b->dtype) * (size_t)b->n_rows);
+    if (m > 1) {
+        yptr.assign(y_cols, y_cols + m);
+        if (pred_cols) pptr.assign(pred_cols, pred_cols + m);
+        if (host) {
+            void *mt = nullptr;
+            if ((rc = ensure_scratch(ctx, 4, colb_mt * (size_t)m * (pred_cols ? 2 : 1), &mt))) return rc;
+            char *q = static_cast<char *>(mt);
+            for (int t = 0; t < m; ++t) {
+                POLS_HIP(hipMemcpyAsync(q, y_cols[t], dtype_size(b->dtype) * (size_t)b->n_rows, hipMemcpyHostToDevice, ctx->stream));
+                yptr[t] = q; q += colb_mt;
+            }
+            for (int t = 0; pred_cols && t < m; ++t) { pptr[t] = q; q += colb_mt; }
+        }
+    }
     const size_t mat = sizeof(double) * (size_t)NZ * NZ;
     // row splits: enough workgroups to fill the chip when there are few groups, bounded by the partial-Gram memory
     int64_t splits = std::max<int64_t>(1, (2048 + (int64_t)G * npairs - 1) / ((int64_t)G * npairs));
@@ -348,10 +369,13 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     splits = (std::max<int64_t>(1, max_rows) + rps - 1) / rps;
 
     void *tab = nullptr, *scr = nullptr;
-    if ((rc = ensure_scratch(ctx, 6, sizeof(void *) * (size_t)b->n_features, &tab))) return rc;
-    POLS_HIP(hipMemcpyAsync(tab, st.x.data(), sizeof(void *) * (size_t)b->n_features, hipMemcpyHostToDevice, ctx->stream));
-    POLS_HIP(hipStreamSynchronize(ctx->stream));                       // st.x is a local
-    const size_t gram_b = round256(mat * G), part_b = round256(mat * G * (size_t)splits), c64_b = round256(sizeof(double) * G * kt);
+    std::vector<const void *> table(st.x.begin(), st.x.end());         // [features][targets][predictions]
+    table.insert(table.end(), yptr.begin(), yptr.end());
+    table.insert(table.end(), pptr.begin(), pptr.end());
+    if ((rc = ensure_scratch(ctx, 6, sizeof(void *) * table.size(), &tab))) return rc;
+    POLS_HIP(hipMemcpyAsync(tab, table.data(), sizeof(void *) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+    POLS_HIP(hipStreamSynchronize(ctx->stream));                       // `table` is a local
+    const size_t gram_b = round256(mat * G), part_b = round256(mat * G * (size_t)splits), c64_b = round256(sizeof(double) * G * kt * m);
     if ((rc = ensure_scratch(ctx, 5, gram_b + part_b + c64_b, &scr))) return rc;
     if (!st.status) {
         void *sp = nullptr;
@@ -367,6 +391,11 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     WideArgs a;
     std::memset(&a, 0, sizeof(a));
     a.cols = static_cast<const void *const *>(tab);
+    if (m > 1) {
+        a.n_targets = m;
+        a.ycols = a.cols + b->n_features;
+        if (!pptr.empty()) a.pred_cols = static_cast<void *const *>(tab) + b->n_features + m;
+    }
     a.y = st.y; a.w = st.w; a.offs = d_offs; a.n_groups = b->n_groups; a.n_rows = b->n_rows;
     a.k_user = b->n_features; a.kt = kt;
     a.gram = static_cast<double *>(scr);
@@ -390,16 +419,19 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         int workers = (int)std::min<size_t>(G, 64);
         void *wk = nullptr;
         const int64_t ncmax = std::min<int64_t>(std::max<int64_t>(1, max_rows), kt);
-        a.work_w_elems = (int64_t)(kt + 1) * std::max<int64_t>(1, max_rows);
+        a.work_w_elems = (int64_t)(kt + m) * std::max<int64_t>(1, max_rows);
         a.work_stride = a.work_w_elems + ncmax * ncmax + 2 * ncmax;
         while (workers > 1 && (double)workers * (double)a.work_stride * 8.0 > 1e9) workers /= 2;
         if ((rc = ensure_scratch(ctx, 3, sizeof(double) * (size_t)workers * (size_t)a.work_stride, &wk))) return rc;
         a.work = static_cast<double *>(wk);
         if ((rc = wide_minnorm_launch(ctx, b->dtype, a, workers))) return rc;
     }
-    if (st.pred || st.resid)
+    if (st.pred || st.resid || a.pred_cols)
         if ((rc = wide_predict_launch(ctx, b->dtype, a))) return rc;
-    return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
+    if (m > 1 && host && pred_cols)
+        for (int t = 0; t < m; ++t)
+            POLS_HIP(hipMemcpyAsync(pred_cols[t], pptr[t], dtype_size(b->dtype) * (size_t)b->n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    return unstage_outputs(ctx, b, b->n_groups * m, kt, o, st);
 }
 
 static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, LsInfo *info) {
@@ -582,6 +614,38 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
 
 int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o) {
     return ls_core(ctx, b, p, o, nullptr);
+}
+
+// ------------------------------------------------------------------ multi-target
+int pols_multi_target_least_squares(pols_ctx *ctx, const pols_batch *b, const void *const *y_cols, int32_t n_targets,
+                                    const pols_ols_params *p, void *const *pred_cols, void *coef, int32_t *status) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!b || !p || !y_cols) return fail(POLS_ERR_INVALID, "batch / params / y_cols is NULL");
+    if (n_targets < 1 || n_targets > 256) return fail(POLS_ERR_INVALID, "n_targets must be in 1..256");
+    for (int t = 0; t < n_targets; ++t)
+        if (!y_cols[t] || (pred_cols && !pred_cols[t])) return fail(POLS_ERR_INVALID, "target / prediction column %d is NULL", t);
+    pols_batch bb = *b;
+    bb.y = y_cols[0];
+    pols_out o;
+    std::memset(&o, 0, sizeof(o));
+    o.coef = coef; o.status = status;
+    if ((rc = check_batch(&bb, &o, K8_KMAX))) return rc;
+    // least_squares.py:303-318: unconstrained OLS / ridge only, solve_method in {None, "svd"}
+    const double l1 = p->has_l1_ratio ? p->l1_ratio : 0.0;
+    if (p->positive || l1 != 0.0)
+        return fail(POLS_ERR_PANIC, "Multi-target regression is only supported for unconstrained OLS & Ridge problems.");
+    if (!(p->solve_method == POLS_SOLVE_AUTO || p->solve_method == POLS_SOLVE_SVD))
+        return fail(POLS_ERR_PANIC, "only solve_method='svd' is supported for multi-target regressions");
+    if (!(p->alpha >= 0.0)) return fail(POLS_ERR_PANIC, "alpha must be non-negative");
+    if (p->null_policy != POLS_NULL_IGNORE || b->valid)
+        return fail(POLS_ERR_UNSUPPORTED, "multi-target: apply the joint validity mask before the call (src/expressions.rs:539-548)");
+    const int kt = b->n_features + (b->add_intercept ? 1 : 0);
+    if (kt + n_targets > K8_KMAX) return fail(POLS_ERR_UNSUPPORTED, "%d columns + %d targets > %d", kt, n_targets, K8_KMAX);
+    if (b->n_groups == 0) return POLS_OK;
+    // solve_multi_target (ls.rs:243-260): alpha > 0 -> ridge (SVD form), else minimum-norm least squares: ONE Gram pass over
+    // [X | targets] and ONE factorisation serve every target; flagged groups go through the Jacobi pass once as well.
+    return wide_static(ctx, &bb, p, &o, kt, false, p->alpha, 0.0, p->alpha == 0.0, y_cols, n_targets, pred_cols);
 }
 
 // ------------------------------------------------------------------ mode = "statistics"

@@ -29,7 +29,7 @@ template <typename T>
 __device__ __forceinline__ double wide_z(const WideArgs &a, const void *colp, int z, int64_t r) {   // unscaled Z[r][z]
     const int ku = a.k_user, kt = a.kt;
     if (z < ku) return (double)static_cast<const T *>(colp)[r];
-    if (z == kt) return (double)static_cast<const T *>(a.y)[r];
+    if (z >= kt) return (double)static_cast<const T *>(a.ycols ? a.ycols[z - kt] : a.y)[r];   // target z - kt (callers keep z < NZ)
     if (z == kt - 1 && ku != kt) return 1.0;
     return 0.0;
 }
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) wide_gram_kernel(const WideArgs a) {
     __shared__ double sw_s[WG_TS];
     __shared__ const void *cp_i[WG_TS], *cp_j[WG_TS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int NZ = a.kt + 1, nt = (NZ + WG_TS - 1) / WG_TS;
+    const int NZ = a.kt + wide_m(a), nt = (NZ + WG_TS - 1) / WG_TS;
     int ti = 0, rem = blockIdx.x;                                  // pair index -> (ti <= tj)
     while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
     const int tj = ti + rem;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) wide_gram_kernel(const WideArgs a) {
 }
 
 __global__ void __launch_bounds__(256) wide_reduce_kernel(const WideArgs a) {
-    const int NZ = a.kt + 1;
+    const int NZ = a.kt + wide_m(a);
     const int64_t g = blockIdx.y;
     const int64_t n = a.offs[g + 1] - a.offs[g];
     const int nsp = (int)((n + a.rows_per_split - 1) / a.rows_per_split);
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) wide_reduce_kernel(const WideArgs a) {
 }
 
 int wide_gram_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
-    const int NZ = a.kt + 1, nt = (NZ + WG_TS - 1) / WG_TS, npairs = nt * (nt + 1) / 2;
+    const int NZ = a.kt + wide_m(a), nt = (NZ + WG_TS - 1) / WG_TS, npairs = nt * (nt + 1) / 2;
     char name[64];
     std::snprintf(name, sizeof(name), "k8_wide_gram_%s_k%d", dtype == POLS_F32 ? "f32" : "f64", a.kt);
     ctx->last_kernel = name;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(NTHREADS) wide_chol_kernel(const WideArgs a) {
     __shared__ int ok_s;
     constexpr int NW = NTHREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int kt = a.kt, NZ = kt + 1;
+    const int kt = a.kt, m = wide_m(a), NZ = kt + m;
     const int64_t g = blockIdx.x;
     const int64_t n = a.offs[g + 1] - a.offs[g];
     double *Gm = a.gram + (size_t)g * NZ * NZ;
@@ -179,39 +179,43 @@ __global__ void __launch_bounds__(NTHREADS) wide_chol_kernel(const WideArgs a) {
         const double di = 1.0 / d;
         if (tid == 0) { dinv[j] = di; if (!(d > a.pivot_tol * diag0[j])) ok_s = 0; }   // d_j / G_jj: see chol_solve (k1_kernel.inl)
         const double *cj = A + j;                                  // column j: cj[i * LD]
-        for (int i = j + 1 + wv; i <= kt; i += NW) {               // rows j+1 .. kt (row kt is the target row)
+        for (int i = j + 1 + wv; i < NZ; i += NW) {                // rows j+1 .. NZ-1 (rows kt .. are the target rows)
             const double li = cj[(size_t)i * LD] * di;
             double *row = A + (size_t)i * LD;
-            const int cmax = (i == kt) ? kt - 1 : i;
+            const int cmax = (i >= kt) ? kt - 1 : i;
             for (int c = j + 1 + lane; c <= cmax; c += 64) row[c] -= li * cj[(size_t)c * LD];
         }
         __syncthreads();
     }
-    // A[kt][j] = d_j z_j with z the forward solution; back substitution  x_j = (A[kt][j] - sum_{i > j} A[i][j] x_i) / d_j
-    for (int i = tid; i < kt; i += NTHREADS) xs[i] = A[(size_t)kt * LD + i];
-    __syncthreads();
-    for (int j = kt - 1; j >= 0; --j) {
-        const double xj = xs[j] * dinv[j];                         // every thread: xs[j] is final after the last barrier
-        const double *row = A + (size_t)j * LD;
-        for (int i = tid; i < j; i += NTHREADS) xs[i] -= row[i] * xj;
-        __syncthreads();
-        if (tid == 0) xs[j] = xj;
-    }
-    __syncthreads();
+    // A[kt + t][j] = d_j z_j with z the forward solution of target t; back substitution
+    //   x_j = (A[kt + t][j] - sum_{i > j} A[i][j] x_i) / d_j
     int st = POLS_GROUP_OK;
     if (n == 0) st = POLS_GROUP_EMPTY;
     else if (!ok_s) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
-    for (int i = tid; i < kt; i += NTHREADS) {
-        const double out = (n == 0) ? 0.0 : xs[i];
-        if (a.coef) static_cast<T *>(a.coef)[g * kt + i] = (T)out;
-        a.coef64[g * kt + i] = out;
+    for (int t = 0; t < m; ++t) {
+        __syncthreads();
+        for (int i = tid; i < kt; i += NTHREADS) xs[i] = A[(size_t)(kt + t) * LD + i];
+        __syncthreads();
+        for (int j = kt - 1; j >= 0; --j) {
+            const double xj = xs[j] * dinv[j];                     // every thread: xs[j] is final after the last barrier
+            const double *row = A + (size_t)j * LD;
+            for (int i = tid; i < j; i += NTHREADS) xs[i] -= row[i] * xj;
+            __syncthreads();
+            if (tid == 0) xs[j] = xj;
+        }
+        __syncthreads();
+        for (int i = tid; i < kt; i += NTHREADS) {
+            const double out = (n == 0) ? 0.0 : xs[i];
+            if (a.coef) static_cast<T *>(a.coef)[((size_t)g * m + t) * kt + i] = (T)out;
+            a.coef64[((size_t)g * m + t) * kt + i] = out;
+        }
     }
     if (tid == 0 && a.status) a.status[g] = st;
 }
 
 template <typename T>
 static int wide_chol_launch_t(pols_ctx *ctx, const WideArgs &a) {
-    const int NZ = a.kt + 1;
+    const int NZ = a.kt + wide_m(a);
     if (NZ <= 128) {
         const size_t lds = sizeof(double) * (size_t)NZ * (NZ | 1);
         static bool attr_set = false;
@@ -253,7 +257,8 @@ __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
         const int n = (int)(a.offs[g + 1] - s);
         const bool dual = n < kt;
         const int nc = dual ? n : kt, len = dual ? kt : n;
-        double *yv = W + (size_t)nc * len;                         // the scaled target, n values
+        const int m = wide_m(a);
+        double *yv = W + (size_t)nc * len;                         // the scaled targets, m x n values
         double *s2 = Vm + (size_t)nc * nc, *gsc = s2 + nc;
         for (int r = 0; r < n; r += 1) {
             // one row at a time keeps the sqrt(w) and target reads trivial; the feature reads are strided either way
@@ -262,7 +267,7 @@ __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
                 const double z = wide_z<T>(a, j < a.k_user ? a.cols[j] : nullptr, j, s + r) * sw;
                 if (dual) W[(size_t)r * len + j] = z; else W[(size_t)j * len + r] = z;
             }
-            if (tid == 0) yv[r] = (double)static_cast<const T *>(a.y)[s + r] * sw;
+            if (tid < m) yv[(size_t)tid * n + r] = wide_z<T>(a, nullptr, kt + tid, s + r) * sw;
         }
         for (int q = tid; q < nc * nc; q += 256) Vm[q] = ((q / nc) == (q % nc)) ? 1.0 : 0.0;
         __syncthreads();
@@ -293,34 +298,38 @@ __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
             if (!rotated) break;
         }
         double smax2 = 0.0;
-        for (int c = 0; c < nc; ++c) {                             // s_c^2 and, primal, w_c . y
-            double acc[2] = {0.0, 0.0};
+        for (int c = 0; c < nc; ++c) {                             // s_c^2
+            double acc[1] = {0.0};
             const double *wc = W + (size_t)c * len;
-            for (int j = tid; j < len; j += 256) { acc[0] += wc[j] * wc[j]; if (!dual) acc[1] += wc[j] * yv[j]; }
-            wide_block_sum<2>(acc, red, 4);
-            if (tid == 0) { s2[c] = acc[0]; gsc[c] = acc[1]; }
+            for (int j = tid; j < len; j += 256) acc[0] += wc[j] * wc[j];
+            wide_block_sum<1>(acc, red, 4);
+            if (tid == 0) s2[c] = acc[0];
             smax2 = (acc[0] != acc[0]) ? acc[0] : fmax(smax2, acc[0]);
         }
         __syncthreads();
         const double cutoff = a.rc_factor * sqrt(smax2);
-        for (int c = tid; c < nc; c += 256) {
-            double num = gsc[c];
-            if (dual) { num = 0.0; for (int r = 0; r < nc; ++r) num += Vm[(size_t)r * nc + c] * yv[r]; }
-            const double sc = sqrt(s2[c]);
-            double gv = (sc > cutoff && sc > 0.0) ? num / (s2[c] + a.alpha) : 0.0;
-            if (smax2 != smax2) gv = smax2;
-            gsc[c] = gv;
+        for (int t = 0; t < m; ++t) {
+            const double *yt = yv + (size_t)t * n;
+            for (int c = tid; c < nc; c += 256) {                  // g_c = (w_c . y  |  v_c . y) / (s_c^2 + alpha), 0 below the cut-off
+                double num = 0.0;
+                if (dual) { for (int r = 0; r < nc; ++r) num += Vm[(size_t)r * nc + c] * yt[r]; }
+                else { const double *wc = W + (size_t)c * len; for (int r = 0; r < len; ++r) num += wc[r] * yt[r]; }
+                const double sc = sqrt(s2[c]);
+                double gv = (sc > cutoff && sc > 0.0) ? num / (s2[c] + a.alpha) : 0.0;
+                if (smax2 != smax2) gv = smax2;
+                gsc[c] = gv;
+            }
+            __syncthreads();
+            for (int j = tid; j < kt; j += 256) {
+                double b = 0.0;
+                if (dual) { for (int c = 0; c < nc; ++c) b += W[(size_t)c * len + j] * gsc[c]; }
+                else { for (int c = 0; c < nc; ++c) b += Vm[(size_t)j * nc + c] * gsc[c]; }
+                if (n == 0) b = 0.0;
+                if (a.coef) static_cast<T *>(a.coef)[((size_t)g * m + t) * kt + j] = (T)b;
+                a.coef64[((size_t)g * m + t) * kt + j] = b;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int j = tid; j < kt; j += 256) {
-            double b = 0.0;
-            if (dual) { for (int c = 0; c < nc; ++c) b += W[(size_t)c * len + j] * gsc[c]; }
-            else { for (int c = 0; c < nc; ++c) b += Vm[(size_t)j * nc + c] * gsc[c]; }
-            if (n == 0) b = 0.0;
-            if (a.coef) static_cast<T *>(a.coef)[g * kt + j] = (T)b;
-            a.coef64[g * kt + j] = b;
-        }
-        __syncthreads();
     }
 }
 
@@ -400,9 +409,10 @@ __global__ void __launch_bounds__(256) wide_predict_kernel(const WideArgs a) {
     const int64_t g = blockIdx.y;
     const int64_t s = a.offs[g], e = a.offs[g + 1];
     const int ku = a.k_user, kt = a.kt;
-    for (int j = threadIdx.x; j < kt; j += 256) cs[j] = a.coef64[g * kt + j];
+    const int m = wide_m(a), t = blockIdx.z;                       // one target per grid.z slice
+    for (int j = threadIdx.x; j < kt; j += 256) cs[j] = a.coef64[((size_t)g * m + t) * kt + j];
     __syncthreads();
-    T *pred = static_cast<T *>(a.pred), *resid = static_cast<T *>(a.resid);
+    T *pred = static_cast<T *>(a.pred_cols ? a.pred_cols[t] : a.pred), *resid = static_cast<T *>(a.resid);
     for (int64_t r = s + (int64_t)blockIdx.x * 256 + threadIdx.x; r < e; r += (int64_t)gridDim.x * 256) {
         const T sw = a.w ? sqrt(static_cast<const T *>(a.w)[r]) : T(1);
         T p = T(0);
@@ -417,7 +427,7 @@ __global__ void __launch_bounds__(256) wide_predict_kernel(const WideArgs a) {
 int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
     if (a.n_groups == 0) return POLS_OK;
     const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (a.n_rows / std::max<int64_t>(1, a.n_groups) + 255) / 256));
-    const dim3 grid(bx, (unsigned)a.n_groups);
+    const dim3 grid(bx, (unsigned)a.n_groups, (unsigned)wide_m(a));
     if (dtype == POLS_F32) hipLaunchKernelGGL(wide_predict_kernel<float>, grid, dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(wide_predict_kernel<double>, grid, dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());

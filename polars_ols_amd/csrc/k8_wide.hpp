@@ -30,7 +30,14 @@ struct WideArgs {
     int64_t work_stride;
     int64_t work_w_elems;      // (kt + 1) * max_group_rows
     void *pred, *resid;
+    // multi-target (solve_multi_target, ls.rs:243-260): m targets share the Gram matrix and ONE factorisation.  Z gets m
+    // target columns (NZ = kt + m); coef / coef64 are n_groups x m x kt.  Single-target calls leave these zero.
+    const void *const *ycols;  // DEVICE table of m target column pointers (nullptr: the single target `y`)
+    void *const *pred_cols;    // DEVICE table of m prediction column pointers (multi-target predict)
+    int32_t n_targets;         // 0 or 1: single target
 };
+
+__host__ __device__ inline int wide_m(const WideArgs &a) { return a.n_targets > 1 ? a.n_targets : 1; }
 
 int wide_gram_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
 int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a);      // OLS / ridge; flags what it cannot factor

@@ -164,6 +164,32 @@ class Engine:
         p.null_policy = L.NULL_POLICIES[null_policy]
         return Plan(self, self._lib.pols_least_squares, b, p, o, res, keep)
 
+    def multi_target_least_squares(self, y_cols: Sequence, x_cols: Sequence, offsets, *, weights=None, add_intercept: bool = False,
+                                   alpha: float = 0.0, solve_method: Optional[str] = None, rcond: Optional[float] = None,
+                                   want: Sequence[str] = ("pred", "coef")) -> Dict:
+        """solve_multi_target (src/least_squares.rs:243-260) for every group: ONE Gram pass and ONE factorisation shared by all
+        targets.  Returns ``pred`` (list of n_targets columns), ``coef`` [n_groups, n_targets, k], ``status`` [n_groups]."""
+        ys = list(y_cols)
+        plan = self.plan_least_squares(ys[0], x_cols, offsets, weights=weights, add_intercept=add_intercept, alpha=alpha,
+                                       solve_method=solve_method, rcond=rcond, want=())
+        b = plan._b
+        dev = b.mem == L.POLS_MEM_DEVICE
+        like = plan._keep[0][0]
+        dt = like.dtype
+        m, kt = len(ys), b.n_features + b.add_intercept
+        ys_k = [(y.to(dt).contiguous() if dev else np.ascontiguousarray(y, dtype=dt)) for y in ys]
+        res: Dict = {"status": self._alloc(dev, torch.int32 if dev else np.int32, (b.n_groups,), like)}
+        if "coef" in want:
+            res["coef"] = self._alloc(dev, dt, (b.n_groups, m, kt), like)
+        preds = [self._alloc(dev, dt, (b.n_rows,), like) for _ in range(m)] if "pred" in want else None
+        yp = (C.c_void_p * m)(*[self._ptr(y) for y in ys_k])
+        pp = (C.c_void_p * m)(*[self._ptr(q) for q in preds]) if preds is not None else None
+        L.check(self._lib.pols_multi_target_least_squares(self._h, C.byref(b), yp, C.c_int32(m), C.byref(plan._p), pp,
+                                                          C.c_void_p(self._ptr(res.get("coef"))), C.c_void_p(self._ptr(res["status"]))))
+        if preds is not None:
+            res["pred"] = preds
+        return res
+
     def least_squares_statistics(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
         """mode="statistics" (src/expressions.rs:468-509) for every group: returns ``coef`` (batch dtype), ``status`` and
         the f64 arrays ``r2 mae mse`` [n_groups] and ``std_err t_values p_values`` [n_groups, k]."""

@@ -450,8 +450,8 @@ def compute_multi_target_least_squares(targets, *features, sample_weights=None, 
 
     A row is valid only if EVERY target (and, for the drop policies, every feature) is non-null (compute_is_valid_mask
     with m targets, ex.rs:539), so the joint mask is applied to all targets first and each one is then solved by the
-    single-target path with solve_method="svd" -- the coefficients of solve_multi_target (ls.rs:106-168 applied to a
-    K x M right-hand side) column by column.  One launch per target: the shared-Gram multi-RHS kernel is future work."""
+    engine's multi-target entry: one Gram pass over [X | targets] and one factorisation shared by all targets -- what
+    solve_multi_target (ls.rs:243-260) does with one SVD."""
     kw = ols_kwargs or OLSKwargs()
     msg = "Consider running multiple independent regressions on a multi-expression target!"
     assert not kw.positive and (kw.l1_ratio is None or kw.l1_ratio == 0.0), (
@@ -466,23 +466,65 @@ def compute_multi_target_least_squares(targets, *features, sample_weights=None, 
     ts, fs = [parse_into_expr(t) for t in targets], [parse_into_expr(f) for f in features]
 
     def run(frame: Frame, over, eng):
-        f2 = Frame(frame)
-        if kw.null_policy not in ("ignore", "zero"):
-            cols = [t._column(frame) for t in ts]
-            bad = _isnan(cols[0])
-            for c in cols[1:]:
-                bad = bad | _isnan(c)
-            nan = float("nan")
-            for t, c in zip(ts, cols):
-                masked = torch.where(bad, torch.full_like(c, nan), c) if _is_torch(c) else np.where(bad, nan, c)
-                f2[f"__mt_{t.output_name}"] = masked
-            tcols = [Expr(f"__mt_{t.output_name}", alias=t.output_name) for t in ts]
+        y0, xs, names, icpt, w = _pre_process_data(frame, ts[0], fs, sample_weights, add_intercept)
+        ys = [y0] + [t._column(frame) for t in ts[1:]]
+        n = y0.shape[0]
+        eng = eng or default_engine(y0.device.index or 0 if _is_torch(y0) else 0)
+        if over is not None:
+            key = frame[over] if isinstance(over, str) else over
+            order, offs, keys, gid = _group_layout(key)
         else:
-            tcols = ts
+            order, offs, gid = None, np.array([0, n], dtype=np.int64), np.zeros(n, dtype=np.int64)
+        if order is not None:
+            oi = _to_index(order, y0)
+            ys_s, xs_s, w_s = [_take(y, oi) for y in ys], [_take(c, oi) for c in xs], (None if w is None else _take(w, oi))
+        else:
+            ys_s, xs_s, w_s = ys, xs, w
+        policy = kw.null_policy
+        solver = dict(alpha=kw.alpha, solve_method=kw.solve_method, rcond=kw.rcond)
+        if policy in ("ignore", "zero"):
+            if policy == "zero":
+                ys_s, xs_s = [_nan_to_zero(y) for y in ys_s], [_nan_to_zero(c) for c in xs_s]
+            preds = eng.multi_target_least_squares(ys_s, xs_s, offs, weights=w_s, add_intercept=icpt, want=("pred",), **solver)["pred"]
+        else:
+            # drop family (ex.rs:539-585): fit on the rows where EVERY target (and, unless drop_y_zero_x, every feature) is
+            # non-null, predict every row from the zero-filled features, mask for "drop"
+            if w_s is not None:
+                sw = torch.sqrt(w_s) if _is_torch(w_s) else np.sqrt(w_s)
+                ys_f, xs_f = [y * sw for y in ys_s], [c * sw for c in xs_s] + ([sw] if icpt else [])
+            else:
+                sw = None
+                ys_f, xs_f = ys_s, list(xs_s) + ([_ones_like(ys_s[0])] if icpt else [])
+            valid = ~_isnan(ys_f[0])
+            for y in ys_f[1:]:
+                valid = valid & ~_isnan(y)
+            if policy != "drop_y_zero_x":
+                for c in xs_f:
+                    valid = valid & ~_isnan(c)
+            vnp = valid.cpu().numpy() if _is_torch(valid) else valid
+            gid_h = gid.cpu().numpy() if _is_torch(gid) else gid
+            counts = np.bincount(gid_h[vnp], minlength=len(offs) - 1)
+            offs_v = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            vi = _to_index(np.nonzero(vnp)[0], ys_f[0])
+            xs_v = [_take(c, vi) for c in xs_f]
+            if policy == "drop_y_zero_x":
+                xs_v = [_nan_to_zero(c) for c in xs_v]
+            coef = eng.multi_target_least_squares([_take(y, vi) for y in ys_f], xs_v, offs_v, want=("coef",), **solver)["coef"]
+            gi = _to_index(gid, ys_f[0])
+            xs_z = [_nan_to_zero(c) for c in xs_f]
+            preds = []
+            for t in range(len(ts)):
+                pr = eng.predict(xs_z, coef[:, t, :][gi])
+                if sw is not None:
+                    pr = pr * (1.0 / sw)
+                if policy == "drop":
+                    nan = float("nan")
+                    pr = torch.where(valid, pr, torch.full_like(pr, nan)) if _is_torch(pr) else np.where(valid, pr, nan)
+                preds.append(pr)
         out = {}
-        for t, tc in zip(ts, tcols):
-            _, val = _apply_static(f2, over, eng, tc, fs, sample_weights, add_intercept, "predictions", kw)
-            out[t.output_name] = val if mode == "predictions" else t._column(frame) - val
+        for t, y_s, pr in zip(ts, ys_s, preds):
+            val = pr if mode == "predictions" else y_s - pr
+            out[t.output_name] = _unsort(val, order)
         return "predictions", out
 
     return Expr(ts[0]._name, fn=run)

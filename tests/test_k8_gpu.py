@@ -131,3 +131,71 @@ def test_wide_limits(eng):
         eng.least_squares(y, cols, offs, want=("coef",), null_policy="drop")
     with pytest.raises(Exception):
         eng.recursive_least_squares(y, cols, offs)
+
+
+# ------------------------------------------------------------------------------------------------ multi-target
+def _mt_expected(ys, cols, offs, w, icpt, alpha):
+    m, k = len(ys), len(cols) + int(icpt)
+    G = len(offs) - 1
+    coef = np.zeros((G, m, k))
+    preds = [np.full(len(ys[0]), np.nan) for _ in range(m)]
+    for g in range(G):
+        s, e = offs[g], offs[g + 1]
+        if e == s:
+            continue
+        X = np.column_stack([c[s:e] for c in cols]).astype(np.float64)
+        if icpt:
+            X = np.column_stack([X, np.ones(e - s)])
+        sw = np.sqrt(w[s:e].astype(np.float64)) if w is not None else np.ones(e - s)
+        Xs = X * sw[:, None]
+        for t in range(m):
+            yt = ys[t][s:e].astype(np.float64) * sw
+            beta = np.linalg.solve(Xs.T @ Xs + alpha * np.eye(k), Xs.T @ yt) if alpha > 0 else np.linalg.lstsq(Xs, yt, rcond=None)[0]
+            coef[g, t] = beta
+            preds[t][s:e] = (Xs @ beta) / sw
+    return coef, preds
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 5e-4)])
+@pytest.mark.parametrize("k,m,weights,icpt,alpha", [(3, 2, False, False, 0.0), (8, 5, True, True, 0.1), (40, 3, False, True, 0.0)])
+def test_multi_target_vs_numpy(eng, dtype, tol, k, m, weights, icpt, alpha):
+    y0, cols, offs, w = _frame(50 + k, dtype, k, [500, 0, 1_300, 77])
+    rng = np.random.default_rng(m)
+    ys = [y0] + [(sum(rng.normal() * c.astype(np.float64) for c in cols) + 0.2 * rng.normal(size=len(y0))).astype(dtype) for _ in range(m - 1)]
+    w = w if weights else None
+    out = eng.multi_target_least_squares(ys, cols, offs, weights=w, add_intercept=icpt, alpha=alpha)
+    coef, preds = _mt_expected(ys, cols, offs, w, icpt, alpha)
+    assert list(out["status"]) == [0, 2, 0, 0]
+    assert np.allclose(out["coef"], coef, rtol=tol, atol=tol), float(np.abs(out["coef"] - coef).max())
+    for t in range(m):
+        assert np.allclose(out["pred"][t], preds[t], rtol=tol, atol=tol, equal_nan=True), t
+
+
+def test_multi_target_reference_benchmark_shape(eng):               # tests/benchmark.py:220 -- 10 000 x 100 features, 20 targets
+    import torch
+
+    d = make_data(n_samples=10_000, n_features=100)
+    rng = np.random.default_rng(1)
+    B = rng.normal(size=(100, 20))
+    Y = d["x"] @ B + 0.1 * rng.normal(size=(10_000, 20))
+    ys = [torch.from_numpy(np.ascontiguousarray(Y[:, t])).cuda() for t in range(20)]
+    cols = [torch.from_numpy(d[f"x{i + 1}"]).cuda() for i in range(100)]
+    out = eng.multi_target_least_squares(ys, cols, np.array([0, 10_000], dtype=np.int64))
+    torch.cuda.synchronize()
+    exp = np.linalg.lstsq(d["x"], Y, rcond=None)[0]                  # [k, m]
+    assert np.allclose(out["coef"].cpu().numpy()[0], exp.T, rtol=1e-6, atol=1e-6)
+    for t in range(20):
+        assert np.allclose(out["pred"][t].cpu().numpy(), d["x"] @ exp[:, t], rtol=1e-6, atol=1e-6)
+
+
+def test_multi_target_rank_deficient_group_and_panics(eng):
+    y0, cols, offs, _ = _frame(5, np.float64, 6, [300, 4, 200])       # group 1: 4 rows, 6 features -> minimum norm
+    ys = [y0, (y0 * 0.5 - cols[0]).astype(np.float64)]
+    out = eng.multi_target_least_squares(ys, cols, offs)
+    assert list(out["status"]) == [0, 1, 0]
+    coef, preds = _mt_expected(ys, cols, offs, None, False, 0.0)
+    assert np.allclose(out["coef"], coef, rtol=1e-6, atol=1e-7)
+    for t in range(2):
+        assert np.allclose(out["pred"][t], preds[t], rtol=1e-6, atol=1e-7)
+    with pytest.raises(Exception):
+        eng.multi_target_least_squares(ys, cols, offs, solve_method="chol")
