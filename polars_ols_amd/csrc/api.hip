@@ -543,7 +543,8 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool fits_lds = f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
                                   : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows);
         const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
-        stream = nulls || kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
+        // null policies: the register-resident K1 has a NULLS family; everything else goes through the streamed kernels
+        stream = (nulls && !k1_resident) || kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
         if (const char *force = std::getenv("POLS_STATIC_ENGINE")) stream = stream || !std::strcmp(force, "stream");
     }
     if (stream) {
@@ -607,6 +608,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     a.pivot_tol = pivot_tol;
     a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.k_user = b->n_features;
+    a.null_policy = pol;
     if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
     if ((rc = svd_fixup())) return rc;
     return finish(nullptr);
@@ -961,6 +963,7 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
 
 namespace pols {
 template <typename T> int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
+template <typename T> int k1n_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);   // null-policy family (k1n_*.hip)
 template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
 
 // Engine choice for the static least-squares path:
@@ -970,6 +973,10 @@ template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, i
 int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_group_rows, bool) {
     const bool f32 = dtype == POLS_F32;
     const int vec = f32 ? 4 : 2;
+    if (a.null_policy != POLS_NULL_IGNORE) {
+        if (kt > K1_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "k1 null-policy kernels stop at %d columns", K1_MAX_KT);
+        return f32 ? k1n_launch_t<float>(ctx, kt, a, max_group_rows) : k1n_launch_t<double>(ctx, kt, a, max_group_rows);
+    }
     const bool fits = kt <= K1M_MAX_KT && (f32 ? k1m_fits<float>(a.k_user, a.w != nullptr, max_group_rows)
                                                : k1m_fits<double>(a.k_user, a.w != nullptr, max_group_rows));
     // Measured on MI355X (10k groups x 1k rows, profiles/r01_*): K1 is at 93-97 % of the bandwidth a math-free

@@ -28,7 +28,8 @@ namespace pols {
 struct K1Args {
     const void *y;
     const void *w;                       // sample weights or nullptr
-    const uint8_t *valid;                // row validity bytes or nullptr
+    const uint8_t *valid;                // row validity bytes or nullptr (drop-family null policies)
+    int32_t null_policy;                 // pols_null_policy; anything but "ignore" selects the NULLS kernels
     const void *x[POLS_MAX_FEATURES];    // user feature columns
     const int64_t *offs;                 // device, n_groups + 1
     int64_t n_groups;

@@ -17,6 +17,7 @@ struct Chunk {
     V x[KT];   // features (sqrt(w)-scaled if HAS_W); slot KT-1 holds the intercept column when there is one
     V y;       // ORIGINAL target (needed for residuals)
     V sw;      // sqrt(w); only meaningful when HAS_W
+    unsigned m;  // NULLS kernels: bit v set = row v of the chunk takes part in the fit
 };
 
 template <typename T> __device__ __forceinline__ typename Vec16<T>::type vsplat(T v);
@@ -29,7 +30,7 @@ template <> __device__ __forceinline__ void vset<float>(float4 &v, int i, float 
 }
 template <> __device__ __forceinline__ void vset<double>(double2 &v, int i, double x) { if (i == 0) v.x = x; else v.y = x; }
 
-template <typename T, int KT, bool HAS_W, bool FAST>
+template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false>
 __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_t s, int64_t e, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
@@ -59,6 +60,29 @@ __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_
             }
         }
     }
+    if constexpr (NULLS) {
+        // Null policy (src/expressions.rs:201-296) on the registers: which rows take part in the fit (compute_is_valid_mask),
+        // and nulls -> 0 in the features (handle_nulls for the fit; construct_features_array(.., true) for the predictions).
+        // The target keeps its nulls: residuals are ORIGINAL target - predictions (ls.py:239).
+        const int pol = a.null_policy;
+        c.m = 0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int64_t r = row0 + v;
+            bool fit = (r >= s) && (r < e);
+            if (fit && pol != POLS_NULL_ZERO) {
+                const T yv = vget<T>(c.y, v);
+                fit = (yv == yv) && !(a.valid && !a.valid[r]);
+                if (null_checks_x(pol)) {
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) { const T xv = vget<T>(c.x[j], v); fit = fit && (xv == xv); }
+                }
+            }
+            c.m |= fit ? (1u << v) : 0u;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) vset<T>(c.x[j], v, null_fill<T>(pol, vget<T>(c.x[j], v)));
+        }
+    }
     if constexpr (HAS_W) {   // sqrt_w scaling of every feature, intercept included (least_squares.py:190-196)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -70,7 +94,7 @@ __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_
     }
 }
 
-template <typename T, int KT, bool HAS_W>
+template <typename T, int KT, bool HAS_W, bool NULLS = false>
 __device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2], const Chunk<T, KT, HAS_W> &c) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
@@ -78,14 +102,20 @@ __device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2
     for (int v = 0; v < VEC; ++v) {
         T ys = vget<T>(c.y, v);
         if constexpr (HAS_W) ys *= vget<T>(c.sw, v);
+        T mv = T(1);
+        if constexpr (NULLS) {                       // rows outside the fit contribute nothing; a null target that stays (ZERO) is 0
+            mv = ((c.m >> v) & 1u) ? T(1) : T(0);
+            ys = (ys == ys) ? ys * mv : T(0);
+        }
 #pragma unroll
         for (int i = 0; i < KT; ++i) {
-            const T xi = vget<T>(c.x[i], v);
+            const T xi = NULLS ? vget<T>(c.x[i], v) * mv : vget<T>(c.x[i], v);
 #pragma unroll
             for (int j = i; j < KT; ++j) acc[tri_index<NZ>(i, j)] = fma(xi, vget<T>(c.x[j], v), acc[tri_index<NZ>(i, j)]);
             acc[tri_index<NZ>(i, KT)] = fma(xi, ys, acc[tri_index<NZ>(i, KT)]);
         }
-        acc[tri_index<NZ>(KT, KT)] = fma(ys, ys, acc[tri_index<NZ>(KT, KT)]);
+        if constexpr (NULLS) acc[tri_index<NZ>(KT, KT)] += mv;      // the (unused) y'y slot counts the rows left in the fit
+        else acc[tri_index<NZ>(KT, KT)] = fma(ys, ys, acc[tri_index<NZ>(KT, KT)]);
     }
 }
 
@@ -233,7 +263,7 @@ __device__ __forceinline__ T chol_solve_lds(const T *G, T alpha, T pivot_tol, T 
     return bi;
 }
 
-template <typename T, int KT, bool HAS_W, bool FAST>
+template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false>
 __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT, HAS_W> &c, const T (&beta)[KT],
                                               int64_t row0, int64_t s, int64_t e) {
     using V = typename Vec16<T>::type;
@@ -245,6 +275,9 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 #pragma unroll
         for (int j = 0; j < KT; ++j) acc = fma(vget<T>(c.x[j], v), beta[j], acc);   // make_predictions on the FIT features (ex.rs:398-405)
         if constexpr (HAS_W) acc *= T(1) / vget<T>(c.sw, v);                         // predictions *= 1/sqrt_w (ls.py:234-235)
+        if constexpr (NULLS) {                                                       // "drop" masks the rows that were not fitted (ex.rs:409-417)
+            if (a.null_policy == POLS_NULL_DROP) acc = nan_if<T>(((c.m >> v) & 1u) ? 0u : 1u, acc);
+        }
         vset<T>(p, v, acc);
         vset<T>(r, v, vget<T>(c.y, v) - acc);                                        // ORIGINAL target - predictions (ls.py:239)
     }
@@ -271,7 +304,7 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 // the RC * TEAM resident chunks -> no ragged-edge and no overflow code (fewer VGPRs, more groups in flight).
 // NPASS > 1 (FAST only): the Gram is accumulated in NPASS passes over the resident registers, each keeping 1 / NPASS of the
 // accumulators live -- fewer VGPRs, one more workgroup per CU for the f64 team kernel.
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
@@ -302,8 +335,8 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     if constexpr (!FAST) {
         for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
             Chunk<T, KT, HAS_W> tmp;
-            load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, tmp);
-            gram_accumulate<T, KT, HAS_W>(acc, tmp);
+            load_chunk<T, KT, HAS_W, false, NULLS>(a, base + c * VEC, s, e, tmp);
+            gram_accumulate<T, KT, HAS_W, NULLS>(acc, tmp);
         }
     }
     Chunk<T, KT, HAS_W> res[RC];                             // register-resident rows of this lane
@@ -311,9 +344,9 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     for (int rc = 0; rc < RC; ++rc) {
         const int64_t c = (int64_t)rc * TEAM + tid;
         if (c < nch) {
-            load_chunk<T, KT, HAS_W, FAST>(a, base + c * VEC, s, e, res[rc]);
+            load_chunk<T, KT, HAS_W, FAST, NULLS>(a, base + c * VEC, s, e, res[rc]);
             if (rc == RC - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
-            if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
+            if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W, NULLS>(acc, res[rc]);
         }
     }
     K1_STAMP(2);
@@ -383,7 +416,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
             acc[q] = t;
         }
         int st = POLS_GROUP_OK;
-        if (e == s) {                       // features.is_empty() -> zeros (ex.rs:357-359)
+        if (e == s || (NULLS && acc[tri_index<NZ>(KT, KT)] == T(0))) {   // features.is_empty() -> zeros (ex.rs:357-359)
 #pragma unroll
             for (int j = 0; j < KT; ++j) beta[j] = T(0);
             st = POLS_GROUP_EMPTY;
@@ -414,13 +447,13 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 #pragma unroll
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
-            if (c < nch) predict_store<T, KT, HAS_W, FAST>(a, res[rc], beta, base + c * VEC, s, e);
+            if (c < nch) predict_store<T, KT, HAS_W, FAST, NULLS>(a, res[rc], beta, base + c * VEC, s, e);
         }
         if constexpr (!FAST) {
             for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
                 Chunk<T, KT, HAS_W> tmp;
-                load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, tmp);
-                predict_store<T, KT, HAS_W, false>(a, tmp, beta, base + c * VEC, s, e);
+                load_chunk<T, KT, HAS_W, false, NULLS>(a, base + c * VEC, s, e, tmp);
+                predict_store<T, KT, HAS_W, false, NULLS>(a, tmp, beta, base + c * VEC, s, e);
             }
         }
     }
@@ -429,11 +462,11 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 #undef K1_STAMP
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
-    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s%s", sizeof(T) == 4 ? "f32" : "f64", KT,
-                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : "_p3"));
+    std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s%s%s", sizeof(T) == 4 ? "f32" : "f64", KT,
+                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : "_p3"), NULLS ? "_nulls" : "");
     const int64_t teams_per_block = 256 / TEAM;
     const int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
@@ -447,7 +480,7 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         aa.dbg = static_cast<unsigned long long *>(d);
     }
     timing_begin(ctx);
-    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
     if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
@@ -457,6 +490,10 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
 template <typename T, int KT, bool HAS_W, int TEAM, int RC>
 static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
+#ifdef K1_NULLS_TU
+    (void)max_rows;   // the null-policy family: general (non-FAST) code only, the row masks live next to the resident rows
+    return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 1, true>(ctx, a);
+#else
     // FAST needs every group aligned to the vector width and resident; the offsets scan in upload_offsets() knows
     const bool fast = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC &&
                       std::getenv("POLS_K1_NOFAST") == nullptr;
@@ -468,6 +505,7 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
     }
     return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false>(ctx, a);
+#endif
 }
 
 // Variant choice: smallest team whose registers hold the largest group (so X is read once); groups
@@ -495,8 +533,13 @@ static int k1_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     return a.w ? k1_launch_kw<T, KT, true>(ctx, a, max_rows) : k1_launch_kw<T, KT, false>(ctx, a, max_rows);
 }
 
+#ifdef K1_NULLS_TU
+#define K1_LAUNCH_NAME k1n_launch_t
+#else
+#define K1_LAUNCH_NAME k1_launch_t
+#endif
 template <typename T>
-int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
+int K1_LAUNCH_NAME(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
     switch (kt) {
         case 1: return k1_launch_kt<T, 1>(ctx, a, max_rows);
         case 2: return k1_launch_kt<T, 2>(ctx, a, max_rows);

@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(256) k6_svd_kernel(const K6Args a) {
             W[(size_t)kt * n + r] = in_fit ? (double)null_fill<T>(pol, static_cast<const T *>(a.y)[s + r]) * sw : 0.0;
         }
         const double nfit = k6_block_sum((double)nfit_l, red);
+        if (nfit == 0.0 && tid == 0) a.status[g] = POLS_GROUP_EMPTY;   // every row dropped by the null policy: zeros, like an empty group
         for (int q = tid; q < kt * kt; q += 256) V[q] = ((q / kt) == (q % kt)) ? 1.0 : 0.0;
         __syncthreads();
         // ---- one-sided Jacobi sweeps

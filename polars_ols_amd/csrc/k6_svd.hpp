@@ -12,7 +12,7 @@ struct K6Args {
     int64_t n_groups;
     const int32_t *fb_flag;  // the pass is a no-op unless *fb_flag == epoch (some group was flagged in THIS call)
     int32_t epoch;
-    const int32_t *status;   // groups with POLS_GROUP_FALLBACK are (re)solved, the rest skipped
+    int32_t *status;         // groups with POLS_GROUP_FALLBACK are (re)solved, the rest skipped; no fit rows left -> POLS_GROUP_EMPTY
     void *coef;
     void *pred;
     void *resid;
