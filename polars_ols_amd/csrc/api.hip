@@ -979,7 +979,7 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
     }
     const bool fits = kt <= K1M_MAX_KT && (f32 ? k1m_fits<float>(a.k_user, a.w != nullptr, max_group_rows)
                                                : k1m_fits<double>(a.k_user, a.w != nullptr, max_group_rows));
-    // Measured on MI355X (10k groups x 1k rows, profiles/r01_*): K1 is at 93-97 % of the bandwidth a math-free
+    // Measured on MI355X (10k groups x 1k rows, profiles/r01_*): K1 is at ~90 % of the bandwidth a math-free
     // kernel with the same access pattern reaches whenever a group's rows stay register-resident (k <= 8:
     // <= 2048 rows f32, <= 1024 rows f64); K1m reads HBM once for any group whose tile fits LDS and carries up
     // to 15 features, at ~65 % of that bandwidth (LDS caps it at 4 groups in flight per CU).
