@@ -91,6 +91,19 @@ void timing_begin(pols_ctx *ctx) {
     hipEventRecord(ctx->timed[ctx->timed_used].start, ctx->stream);
 }
 
+bool timing_pair(pols_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
+    if (!ctx->timing) return false;
+    if (ctx->timed_used == ctx->timed.size()) {
+        TimedLaunch t;
+        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return false;
+        ctx->timed.push_back(t);
+    }
+    *start = ctx->timed[ctx->timed_used].start;
+    *stop = ctx->timed[ctx->timed_used].stop;
+    ctx->timed_used++;
+    return true;
+}
+
 void timing_end(pols_ctx *ctx) {
     if (!ctx->timing || ctx->timed_used >= ctx->timed.size()) return;
     hipEventRecord(ctx->timed[ctx->timed_used].stop, ctx->stream);

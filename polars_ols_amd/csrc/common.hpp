@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -73,6 +74,9 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
 // timing helpers: no-ops unless ctx->timing
 void timing_begin(pols_ctx *ctx);
 void timing_end(pols_ctx *ctx);
+// single-kernel form: hands out the next event pair for hipExtLaunchKernelGGL, which stamps them with the kernel's own
+// begin / end -- the duration rocprofv3 reports, without the event packets' latency inside the bracket.  False = timing off.
+bool timing_pair(pols_ctx *ctx, hipEvent_t *start, hipEvent_t *stop);
 // POLS_TIMELINE=1 debugging: synchronise, read n_stamps s_memtime stamps per group, print phase statistics to stderr
 int report_timeline(pols_ctx *ctx, const unsigned long long *d_dbg, int64_t n_groups, int n_stamps, const char *name);
 

@@ -479,9 +479,11 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         if (rc) return rc;
         aa.dbg = static_cast<unsigned long long *>(d);
     }
-    timing_begin(ctx);
-    hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
-    timing_end(ctx);
+    hipEvent_t ev0, ev1;
+    if (timing_pair(ctx, &ev0, &ev1))
+        hipExtLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
+    else
+        hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
     POLS_HIP(hipGetLastError());
     if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
     return POLS_OK;

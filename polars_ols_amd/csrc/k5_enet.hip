@@ -239,9 +239,11 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     char name[96];
     std::snprintf(name, sizeof(name), "k5_gram_stream_%s_nt%d%s%s_k%d", sizeof(T) == 4 ? "f32" : "f64", NT, HAS_W ? "_w" : "", YV ? "_yv" : "", a.kt);
     ctx->last_kernel = name;
-    timing_begin(ctx);
-    hipLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols, tile_elems);
-    timing_end(ctx);
+    hipEvent_t ev0, ev1;
+    if (timing_pair(ctx, &ev0, &ev1))
+        hipExtLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), (unsigned)lds, ctx->stream, ev0, ev1, 0, a, rs, ncols, tile_elems);
+    else
+        hipLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols, tile_elems);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
