@@ -42,7 +42,9 @@
 extern "C" {
 #endif
 
-#define POLS_MAX_FEATURES 32        /* RLS / rolling / statistics: features incl. the intercept column */
+#define POLS_MAX_FEATURES 32        /* statistics: features incl. the intercept column (RLS / rolling: POLS_MAX_FEATURES_DYNAMIC) */
+#define POLS_MAX_FEATURES_DYNAMIC 128 /* pols_recursive_least_squares / pols_rolling_least_squares (the reference's README
+                                         benchmark runs them at 100 features) */
 #define POLS_MAX_FEATURES_STATIC 1024 /* pols_least_squares / pols_predict: the reference's own wide cases (tests/benchmark.py
                                          at 100 features, test_elastic_net and test_fit_wide up to 1 000) */
 

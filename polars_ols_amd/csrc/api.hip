@@ -733,7 +733,7 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, con
                             Staged *st) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if ((rc = check_batch(b, o))) return rc;
+    if ((rc = check_batch(b, o, K4X_KMAX))) return rc;
     if (b->add_intercept || b->weights)
         return fail(POLS_ERR_INVALID, "dynamic models take pre-processed columns: apply sqrt(w) / append the ones column "
                                       "before the call, exactly like polars_ols/least_squares.py:184-196 does for the plugin");
@@ -742,6 +742,23 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, con
 }
 
 static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a);
+
+// Scratch slot 6 of the dynamic entries: [128 doubles: RLS prior mean][column pointer table for more than 32 features]
+static int dynamic_slot6(pols_ctx *ctx, void **base) {
+    return ensure_scratch(ctx, 6, sizeof(double) * K4X_KMAX + sizeof(void *) * K4X_KMAX, base);
+}
+static int upload_column_table(pols_ctx *ctx, const Staged &st, int k, K4Args *a) {
+    for (int j = 0; j < std::min(k, (int)POLS_MAX_FEATURES); ++j) a->x[j] = st.x[j];
+    if (k <= POLS_MAX_FEATURES) return POLS_OK;
+    void *d = nullptr;
+    int rc = dynamic_slot6(ctx, &d);
+    if (rc) return rc;
+    char *tab = static_cast<char *>(d) + sizeof(double) * K4X_KMAX;
+    POLS_HIP(hipMemcpyAsync(tab, st.x.data(), sizeof(void *) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+    POLS_HIP(hipStreamSynchronize(ctx->stream));
+    a->xtab = reinterpret_cast<const void *const *>(tab);
+    return POLS_OK;
+}
 
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o) {
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
@@ -755,7 +772,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     K3Args a;
     std::memset(&a, 0, sizeof(a));
     a.y = st.y; a.valid = st.valid;
-    for (int j = 0; j < b->n_features; ++j) a.x[j] = st.x[j];
+    for (int j = 0; j < std::min<int>(b->n_features, POLS_MAX_FEATURES); ++j) a.x[j] = st.x[j];
     a.offs = d_offs;
     a.n_groups = b->n_groups;
     a.coef = st.coef; a.pred = st.pred;
@@ -764,15 +781,16 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     a.initial_state_covariance = p->initial_state_covariance;
     if (p->initial_state_mean) {
         void *d = nullptr;
-        if ((rc = ensure_scratch(ctx, 6, sizeof(double) * POLS_MAX_FEATURES, &d))) return rc;
+        if ((rc = dynamic_slot6(ctx, &d))) return rc;
         POLS_HIP(hipMemcpyAsync(d, p->initial_state_mean, sizeof(double) * b->n_features, hipMemcpyHostToDevice, ctx->stream));
         POLS_HIP(hipStreamSynchronize(ctx->stream));   // the host array belongs to the caller
         a.mean0 = static_cast<const double *>(d);
     }
     // Long sequences: the chunk-parallel information-form scan (K3s); short ones: the wave-per-sequence P-form
     // recursion (K3).  POLS_RLS_ENGINE=seq|scan forces one.
-    // More than 8 features: the wave-per-chunk scan (k4w_wide.hip), whatever the length.
-    const bool wide = b->n_features > K4_KMAX;
+    // More than 8 features: the wave-per-chunk scan (k4w_wide.hip), whatever the length; more than 32: the workgroup-per-chunk
+    // kernels that propagate the inverse (k4x_inverse.hip).
+    const bool wide = b->n_features > K4_KMAX, xwide = b->n_features > POLS_MAX_FEATURES;
     bool scan = max_rows > 4096 || wide;
     if (const char *force = std::getenv("POLS_RLS_ENGINE")) {
         if (!std::strcmp(force, "seq") && !wide) scan = false;
@@ -784,11 +802,11 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         std::memset(&s4, 0, sizeof(s4));
         if ((rc = build_chunk_tables(ctx, b, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4))) return rc;
         s4.y = st.y; s4.valid = st.valid;
-        for (int j = 0; j < k; ++j) s4.x[j] = st.x[j];
+        if ((rc = upload_column_table(ctx, st, k, &s4))) return rc;
         s4.coef = st.coef; s4.pred = st.pred;
         s4.k = k;
         s4.ff = a.forgetting_factor; s4.p0 = a.initial_state_covariance; s4.mean0 = a.mean0;
-        if ((rc = wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4))) return rc;
+        if ((rc = xwide ? k3x_launch(ctx, b->dtype, s4) : (wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4)))) return rc;
     } else {
         if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
     }
@@ -900,7 +918,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
     if (o->resid) return fail(POLS_ERR_INVALID, "rolling: residuals are target - predictions in the caller (least_squares.py:239)");
     const int k = b->n_features;
-    const bool wide = k > K4_KMAX;                                                              // k4w_wide.hip
+    const bool wide = k > K4_KMAX, xwide = k > POLS_MAX_FEATURES;                               // k4w_wide.hip / k4x_inverse.hip
     if (p->window_size < 1) return fail(POLS_ERR_INVALID, "window_size must be >= 1");
     const int64_t w = p->window_size;
     const int64_t mp = p->min_periods >= 0 ? p->min_periods : std::min<int64_t>(k, w);          // ls.rs:860
@@ -913,11 +931,11 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     std::memset(&a, 0, sizeof(a));
     if ((rc = build_chunk_tables(ctx, b, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a))) return rc;
     a.y = st.y; a.valid = st.valid;
-    for (int j = 0; j < k; ++j) a.x[j] = st.x[j];
+    if ((rc = upload_column_table(ctx, st, k, &a))) return rc;
     a.coef = st.coef; a.pred = st.pred;
     a.window = w; a.alpha = p->alpha > 0.0 ? p->alpha : 0.0;                                    // ls.rs:865, 924-926
     a.k = k; a.drop_mode = drop ? 1 : 0;
-    if ((rc = wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a))) return rc;
+    if ((rc = xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a)))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, k, o, st);
 }
 

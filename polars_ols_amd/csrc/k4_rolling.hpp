@@ -25,6 +25,7 @@ struct K4Group {
 struct K4Args {
     const void *y;
     const void *x[POLS_MAX_FEATURES];
+    const void *const *xtab;     // DEVICE table of k column pointers: used instead of x[] beyond 32 features (k4x_inverse.hip)
     const uint8_t *valid;        // or nullptr = all valid
     const int32_t *cnt;          // inclusive count of valid rows inside the group, per row; nullptr when valid == nullptr
     const int32_t *vidx;         // row (relative to the group) of the r-th valid row, per row slot; nullptr when valid == nullptr
@@ -53,6 +54,10 @@ int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 // 9..32 features: one wave per chunk, state in LDS (k4w_wide.hip).  Totals rows are k*k + k (+ 1 for the RLS decay) doubles.
 int k4w_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3sw_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+// 33..128 features: one workgroup per chunk, the inverse propagated in LDS (k4x_inverse.hip).  Totals rows as for k4w.
+int k4x_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+int k3x_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+constexpr int K4X_KMAX = 128;
 // pass 2 of every chunk-parallel kernel: exclusive prefix of the chunk totals, one wave per (group, component);
 // mode 0 plain (rolling), 1 / 2 decayed with the RLS prior as carry-in (packed / full K x K state), see k4_rolling.hip
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);

@@ -1,0 +1,327 @@
+// k4x_inverse.hip -- rolling OLS and RLS for 33 .. 128 features: ONE WORKGROUP PER CHUNK, the INVERSE propagated in LDS.
+//
+// For more than 60 features the reference itself stops re-factoring X'X per row and propagates (X'X)^-1 with Woodbury
+// updates (WoodburyState, src/least_squares.rs:737-787; `use_woodbury` defaults to k > 60, :863); RLS always propagates
+// P = A^-1 (RecursiveLeastSquares::update, :531-540).  Same three passes as k4_rolling.hip -- per-chunk totals of the outer
+// products, the wave-parallel (decayed) scan, the walk -- but the walk keeps the K x K inverse in LDS (131 KB at K = 128):
+//   chunk start   the state (X'X + alpha I, or the decayed information matrix with the prior) is rebuilt from the scanned
+//                 totals (+ partial chunks, exactly like state_at() in k4_rolling.hip) and inverted in place by K sweeps of
+//                 the symmetric sweep operator (pivots = the squared Cholesky pivots; K^3 multiply-adds once per chunk, so
+//                 rounding does not accumulate beyond a chunk);
+//   per row       rolling: P -= v v' / (1 + x'v) for the row that enters, P += v v' / (1 - x'v) for the row that leaves
+//                 (v = P x), beta = P b;   RLS: the reference's update literally (r, gain, beta += gain * error,
+//                 P = P / ff - gain gain' r);   each is O(K^2) over 256 threads and a handful of barriers.
+// Control flow (warm-up, gate, forward fill, "drop" family) is k4_walk_kernel's, statement for statement.
+#include "k4_rolling.hpp"
+
+namespace pols {
+
+constexpr int KX_MAX = 128;
+
+template <typename T>
+struct XCtx {
+    const K4Args &a;
+    int64_t s;
+    int first_chunk;
+    int K, LD, NS, tid;
+    double *P, *xs, *v, *bv, *beta, *red;
+    const T *mycol;
+    __device__ XCtx(const K4Args &a_, int64_t s_, int fc, double *lds) : a(a_), s(s_), first_chunk(fc) {
+        K = a.k; LD = K | 1; NS = K * K + K; tid = threadIdx.x;
+        P = lds; xs = P + (size_t)K * LD; v = xs + KX_MAX + 2; bv = v + KX_MAX; beta = bv + KX_MAX; red = beta + KX_MAX;
+        mycol = tid < K ? static_cast<const T *>(a.xtab ? a.xtab[tid] : a.x[tid]) : static_cast<const T *>(a.y);
+    }
+    static __host__ __device__ size_t lds_doubles(int K) { return (size_t)K * (K | 1) + 4 * KX_MAX + 2 + 16; }
+
+    __device__ __forceinline__ bool valid(int64_t i) const { return a.valid ? a.valid[s + i] != 0 : true; }
+    __device__ __forceinline__ int64_t cnt(int64_t i) const { return a.cnt ? (int64_t)a.cnt[s + i] : i + 1; }
+    __device__ __forceinline__ int64_t vidx(int64_t r) const { return a.vidx ? (int64_t)a.vidx[s + r] : r; }
+
+    __device__ __forceinline__ void load_row(int64_t i) const {      // xs[0..K) = x, xs[K] = y
+        __syncthreads();
+        if (tid <= K) xs[tid] = (double)mycol[s + i];
+        __syncthreads();
+    }
+    __device__ double block_sum(double x) const {                     // all 256 threads
+        const double w = wave_sum_row3(x);
+        __syncthreads();
+        if ((tid & 63) == 63) red[tid >> 6] = w;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    }
+    // ---- raw Gram form (before the inversion): P holds X'X, bv holds X'y
+    __device__ void zero() const {
+        for (int q = tid; q < K * LD; q += 256) P[q] = 0.0;
+        if (tid < K) bv[tid] = 0.0;
+        __syncthreads();
+    }
+    __device__ void gram_axpy(const double *src, double sign) const { // src: K*K (row-major, stride K) then K
+        for (int q = tid; q < K * K; q += 256) { const int i = q / K, c = q - i * K; P[i * LD + c] += sign * src[q]; }
+        if (tid < K) bv[tid] += sign * src[K * K + tid];
+        __syncthreads();
+    }
+    __device__ void gram_add_row(int64_t i, double sign) const {
+        load_row(i);
+        for (int q = tid; q < K * K; q += 256) { const int r = q / K, c = q - r * K; P[r * LD + c] += sign * (xs[r] * xs[c]); }
+        if (tid < K) bv[tid] += sign * (xs[tid] * xs[K]);
+        __syncthreads();
+    }
+    __device__ void gram_prefix(int64_t i, double sign, int nacc) const {
+        if (i < 0) return;
+        const int64_t c = i / a.chunk_len;
+        gram_axpy(a.totals + (size_t)(first_chunk + c) * nacc, sign);
+        for (int64_t j = c * a.chunk_len; j <= i; ++j)
+            if (valid(j)) gram_add_row(j, sign);
+    }
+    // ---- in-place inverse of P + alpha I by the symmetric sweep operator (result: the inverse, sign fixed at the end)
+    __device__ void invert(double alpha) const {
+        if (tid < K) P[tid * LD + tid] += alpha;
+        __syncthreads();
+        for (int j = 0; j < K; ++j) {
+            const double p = 1.0 / P[j * LD + j];
+            if (tid < K) v[tid] = P[tid * LD + j];                    // column j (= row j)
+            __syncthreads();
+            for (int q = tid; q < K * K; q += 256) {
+                const int i = q / K, c = q - i * K;
+                double val;
+                if (i == j && c == j) val = -p;
+                else if (i == j) val = v[c] * p;
+                else if (c == j) val = v[i] * p;
+                else val = P[i * LD + c] - v[i] * v[c] * p;
+                P[i * LD + c] = val;
+            }
+            __syncthreads();
+        }
+        for (int q = tid; q < K * K; q += 256) { const int i = q / K, c = q - i * K; P[i * LD + c] = -P[i * LD + c]; }
+        __syncthreads();
+    }
+    // out = P x   (thread t < K owns row t)
+    __device__ void matvec(const double *x, double *out) const {
+        if (tid < K) {
+            double acc = 0.0;
+            const double *row = P + tid * LD;
+            for (int c = 0; c < K; ++c) acc += row[c] * x[c];
+            out[tid] = acc;
+        }
+        __syncthreads();
+    }
+    __device__ void rank1(double coef) const {                        // P += coef * v v'
+        for (int q = tid; q < K * K; q += 256) { const int i = q / K, c = q - i * K; P[i * LD + c] += coef * (v[i] * v[c]); }
+        __syncthreads();
+    }
+    // Sherman-Morrison: the row in xs enters (sign = +1) or leaves (sign = -1) the window
+    __device__ void sm_update(double sign) const {
+        matvec(xs, v);
+        const double xv = block_sum(tid < K ? xs[tid] * v[tid] : 0.0);
+        rank1(-sign / (1.0 + sign * xv));
+        if (tid < K) bv[tid] += sign * (xs[tid] * xs[K]);
+        __syncthreads();
+    }
+    __device__ void solve_beta() const { matvec(bv, beta); }           // beta = P b
+    __device__ void store(int64_t i, bool have, T *coef, T *pred) const {
+        const int64_t row = s + i;
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        if (coef && tid < K) coef[row * K + tid] = (T)(have ? beta[tid] : qnan);
+        if (pred) {
+            load_row(i);
+            const double p = block_sum(tid < K ? xs[tid] * (have ? beta[tid] : qnan) : 0.0);
+            if (tid == 0) pred[row] = (T)p;
+        }
+    }
+};
+
+// ------------------------------------------------------------------ pass 1: per-chunk totals (decayed for RLS)
+template <typename T, bool RLS>
+__global__ void __launch_bounds__(256) kx_totals_kernel(const K4Args a) {
+    extern __shared__ double lds[];
+    const int64_t c = blockIdx.x;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    XCtx<T> cx(a, G.start, G.first_chunk, lds);
+    const int K = cx.K, nacc = cx.NS + (RLS ? 1 : 0);
+    cx.zero();
+    double decay = 1.0;
+    for (int64_t i = ch.t0 - G.start; i < ch.t1 - G.start; ++i)
+        if (cx.valid(i)) {
+            if (RLS) {
+                for (int q = cx.tid; q < K * cx.LD; q += 256) cx.P[q] *= a.ff;
+                if (cx.tid < K) cx.bv[cx.tid] *= a.ff;
+                decay *= a.ff;
+                __syncthreads();
+            }
+            cx.gram_add_row(i, 1.0);
+        }
+    double *out = a.totals + (size_t)c * nacc;
+    for (int q = cx.tid; q < K * K; q += 256) { const int i = q / K, cc = q - i * K; out[q] = cx.P[i * cx.LD + cc]; }
+    if (cx.tid < K) out[K * K + cx.tid] = cx.bv[cx.tid];
+    if (RLS && cx.tid == 0) out[cx.NS] = decay;
+}
+
+// ------------------------------------------------------------------ pass 3: rolling walk
+template <typename T>
+__global__ void __launch_bounds__(256) kx_rolling_walk_kernel(const K4Args a) {
+    extern __shared__ double lds[];
+    const int64_t c = blockIdx.x;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    XCtx<T> cx(a, G.start, G.first_chunk, lds);
+    const int K = cx.K, nacc = cx.NS;
+    const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
+    const int64_t w = a.window, mpv = G.mpv;
+    const bool drop = a.drop_mode != 0;
+    T *coef = static_cast<T *>(a.coef);
+    T *pred = static_cast<T *>(a.pred);
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+
+    if (G.all_nan) {                                           // :893-900
+        for (int64_t i = rel0; i < rel1; ++i) {
+            if (coef && cx.tid < K) coef[(G.start + i) * K + cx.tid] = (T)qnan;
+            if (pred && cx.tid == 0) pred[G.start + i] = (T)qnan;
+        }
+        return;
+    }
+    const int64_t j_min = drop ? 0 : max(mpv - w, (int64_t)0);
+    auto old_of = [&](int64_t i) -> int64_t {
+        if (!drop) return i - w;
+        const int64_t r = cx.cnt(i) - 1 - w;
+        return r < 0 ? -1 : cx.vidx(r);
+    };
+    auto gate = [&](int64_t i) -> bool {                       // n_valid_window >= n_valid (:994-997, 1013, 1022)
+        const int64_t i_start = i >= w ? i - w : 0;
+        return cx.cnt(i) - cx.cnt(i_start) >= G.gate_n;
+    };
+    auto gram_state_at = [&](int64_t i) {                      // raw (X'X, X'y) after row i has been processed
+        cx.zero();
+        cx.gram_prefix(i, 1.0, nacc);
+        const int64_t o = (i >= 0) ? old_of(i) : -1;
+        if (o >= j_min && i >= mpv) {
+            cx.gram_prefix(o, -1.0, nacc);
+            cx.gram_prefix(j_min - 1, 1.0, nacc);
+        }
+    };
+
+    bool inverted = false, have = false;                       // `have`: some row at or before the current one produced coefficients
+    int64_t prev_old = (rel0 > 0 && rel0 - 1 >= mpv) ? old_of(rel0 - 1) : -1;
+    if (rel0 >= mpv && rel0 > 0) {
+        // an earlier row already produced coefficients: carry them in.  If the rows just before this chunk were
+        // forward-filled (gate closed), the carried coefficients belong to the last row that did solve.
+        int64_t ip = rel0 - 1;
+        if (!(drop || ip == mpv - 1 || gate(ip))) {
+            for (ip = rel0 - 2; ip >= mpv - 1; --ip)
+                if (ip == mpv - 1 || gate(ip)) break;
+        }
+        gram_state_at(ip);
+        cx.invert(a.alpha);
+        cx.solve_beta();
+        have = true;
+        if (ip != rel0 - 1) {                                  // rebuild the state of row rel0 - 1 for the walk
+            gram_state_at(rel0 - 1);
+            cx.invert(a.alpha);
+        }
+        inverted = true;
+    } else {
+        gram_state_at(rel0 - 1);
+    }
+    for (int64_t i = rel0; i < rel1; ++i) {
+        const bool vld = cx.valid(i);
+        if (vld) {
+            if (inverted) { cx.load_row(i); cx.sm_update(1.0); }
+            else cx.gram_add_row(i, 1.0);
+        }
+        if (i >= mpv && (vld || !drop)) {                      // subtract what left the window (always after the first solve)
+            const int64_t no = old_of(i);
+            bool sub = false;
+            if (drop) sub = (no != prev_old && no >= 0);
+            else sub = (no >= j_min && no >= 0 && cx.valid(no));
+            if (sub) { cx.load_row(no); cx.sm_update(-1.0); }
+            prev_old = no;
+        }
+        if (i >= mpv - 1) {
+            const bool do_solve = (i == mpv - 1) || (drop ? vld : gate(i));
+            if (do_solve) {
+                if (!inverted) { cx.invert(a.alpha); inverted = true; }   // alpha enters once, at the warm-up (:924-926)
+                cx.solve_beta();
+                have = true;
+            }
+        }
+        cx.store(i, have, coef, pred);
+    }
+}
+
+// ------------------------------------------------------------------ pass 3: RLS walk (RecursiveLeastSquares::update, literally)
+template <typename T>
+__global__ void __launch_bounds__(256) kx_rls_walk_kernel(const K4Args a) {
+    extern __shared__ double lds[];
+    const int64_t c = blockIdx.x;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    XCtx<T> cx(a, G.start, G.first_chunk, lds);
+    const int K = cx.K, nacc = cx.NS + 1;
+    const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
+    T *coef = static_cast<T *>(a.coef);
+    T *pred = static_cast<T *>(a.pred);
+    cx.zero();
+    cx.gram_axpy(a.totals + (size_t)c * nacc, 1.0);            // A = P^-1 and b = A beta at the chunk start (prior included)
+    cx.invert(0.0);
+    cx.solve_beta();                                           // beta = P b (= initial_state_mean before any valid row)
+    const double ff = a.ff;
+    for (int64_t i = rel0; i < rel1; ++i) {
+        if (cx.valid(i)) {
+            cx.load_row(i);
+            cx.matvec(cx.xs, cx.v);                            // v = P x
+            const double xv = cx.block_sum(cx.tid < K ? cx.xs[cx.tid] * cx.v[cx.tid] : 0.0);
+            const double xb = cx.block_sum(cx.tid < K ? cx.xs[cx.tid] * cx.beta[cx.tid] : 0.0);
+            const double r = 1.0 + xv / ff;                    // :533
+            const double err = cx.xs[K] - xb;
+            // gain = P x / (r ff);  beta += gain * err;  P = P / ff - gain gain' r = (P - v v' / (r ff)) / ff
+            if (cx.tid < K) cx.beta[cx.tid] += cx.v[cx.tid] / (r * ff) * err;
+            const double coef_vv = -1.0 / (r * ff);
+            for (int q = cx.tid; q < K * K; q += 256) {
+                const int ii = q / K, cc = q - ii * K;
+                cx.P[ii * cx.LD + cc] = (cx.P[ii * cx.LD + cc] + coef_vv * (cx.v[ii] * cx.v[cc])) / ff;
+            }
+            __syncthreads();
+        }
+        cx.store(i, true, coef, pred);
+    }
+}
+
+template <typename T>
+static int kx_launch_t(pols_ctx *ctx, const K4Args &a, bool rls) {
+    const size_t lds = sizeof(double) * XCtx<T>::lds_doubles(a.k);
+    const int ns = a.k * a.k + a.k;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void *fns[4] = {reinterpret_cast<const void *>(&kx_totals_kernel<T, false>), reinterpret_cast<const void *>(&kx_totals_kernel<T, true>),
+                              reinterpret_cast<const void *>(&kx_rolling_walk_kernel<T>), reinterpret_cast<const void *>(&kx_rls_walk_kernel<T>)};
+        for (const void *f : fns) POLS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        attr_set = true;
+    }
+    timing_begin(ctx);
+    if (rls) {
+        hipLaunchKernelGGL((kx_totals_kernel<T, true>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+        chunk_scan_launch(ctx, a, ns, 2);
+        hipLaunchKernelGGL((kx_rls_walk_kernel<T>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL((kx_totals_kernel<T, false>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+        chunk_scan_launch(ctx, a, ns, 0);
+        hipLaunchKernelGGL((kx_rolling_walk_kernel<T>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+    }
+    timing_end(ctx);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+int k4x_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
+    if (a.k > KX_MAX) return fail(POLS_ERR_UNSUPPORTED, "rolling: %d features > %d", a.k, KX_MAX);
+    ctx->last_kernel = dtype == POLS_F32 ? "k4x_rolling_inverse_f32" : "k4x_rolling_inverse_f64";
+    return dtype == POLS_F32 ? kx_launch_t<float>(ctx, a, false) : kx_launch_t<double>(ctx, a, false);
+}
+
+int k3x_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
+    if (a.k > KX_MAX) return fail(POLS_ERR_UNSUPPORTED, "rls: %d features > %d", a.k, KX_MAX);
+    ctx->last_kernel = dtype == POLS_F32 ? "k3x_rls_inverse_f32" : "k3x_rls_inverse_f64";
+    return dtype == POLS_F32 ? kx_launch_t<float>(ctx, a, true) : kx_launch_t<double>(ctx, a, true);
+}
+
+}  // namespace pols

@@ -83,6 +83,28 @@ def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,half_life,p0,mean", [(33, None, 10.0, None), (100, 252.0, 1.0, 0.25), (128, None, 10.0, None)])
+def test_rls_inverse_propagation_33_to_128_features(eng, dtype, tol, k, half_life, p0, mean):
+    """33..128 features (k4x_inverse.hip): the reference's P-form update, chunk-parallel (README benchmark shape: 100 features)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(300 + k)
+    sizes = np.array([900, 0, 2_300, 40])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(cols).astype(np.float64) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    valid = (rng.random(N) > 0.1).astype(np.uint8)
+    mean0 = None if mean is None else [mean] * k
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), half_life=half_life,
+                                      initial_state_covariance=p0, initial_state_mean=mean0)
+    ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0, is_valid=valid)
+    assert eng.last_kernel.startswith("k3x_")
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
+
+
 def test_rls_readme_known_answer(eng, golden):
     """README.md:133-137: rls(x1, x2, mode="coefficients").over("group") with the default prior."""
     from refdata import sort_by_group

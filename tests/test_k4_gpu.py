@@ -109,6 +109,34 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
     assert np.allclose(got_p[strict], ref["pred"][strict], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("policy", ["drop", "drop_window"])
+@pytest.mark.parametrize("k,window,min_periods,alpha,null_frac,use_woodbury", [
+    (33, 120, None, None, 0.0, None), (64, 256, 80, 0.5, 0.05, True), (100, 400, None, None, 0.05, None), (128, 512, None, 1e-3, 0.0, None),
+])
+def test_rolling_inverse_propagation_33_to_128_features(eng, policy, k, window, min_periods, alpha, null_frac, use_woodbury):
+    """33..128 features (k4x_inverse.hip): the inverse is propagated like the reference's WoodburyState (default for k > 60)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 7 + window)
+    sizes = np.array([window * 2 + 37, 0, window + 200, 50])
+    y, cols, offs, valid = _frame(rng, sizes, k, null_frac=null_frac)
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid),
+                                    window_size=window, min_periods=min_periods, alpha=alpha, null_policy=policy, use_woodbury=use_woodbury)
+    assert eng.last_kernel.startswith("k4x_")
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy, is_valid=valid,
+                              use_woodbury=use_woodbury)
+    got_c, got_p = _np(out["coef"]), _np(out["pred"])
+    nobs = _window_obs(offs, valid, window, policy)
+    mp_eff = min_periods if min_periods is not None else min(k, window)
+    pinned = (nobs >= k) | (nobs < mp_eff)
+    assert np.array_equal(np.isnan(got_c)[pinned], np.isnan(ref["coef"])[pinned])
+    sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+    strict = sane & (nobs >= 2 * k)                                  # well-conditioned windows
+    assert strict.sum() > 0.2 * sane.sum()
+    assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
+    assert np.allclose(got_p[strict], ref["pred"][strict], rtol=1e-5, atol=1e-6)
+
+
 def test_rolling_non_contiguous_reference_case():               # tests/test_ols.py:969-995 (10 features, weights, drop)
     from polars_ols_amd import Frame, col
     from refdata import insert_nulls, make_data
