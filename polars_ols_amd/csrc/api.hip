@@ -389,7 +389,9 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     POLS_HIP(hipMemcpyAsync(tab, table.data(), sizeof(void *) * table.size(), hipMemcpyHostToDevice, ctx->stream));
     POLS_HIP(hipStreamSynchronize(ctx->stream));                       // `table` is a local
     const size_t gram_b = round256(mat * G), part_b = round256(mat * G * (size_t)splits), c64_b = round256(sizeof(double) * G * kt * m);
-    if ((rc = ensure_scratch(ctx, 5, gram_b + part_b + c64_b, &scr))) return rc;
+    const bool nulls = p->null_policy != POLS_NULL_IGNORE;
+    const size_t mask_b = nulls ? round256((size_t)b->n_rows) + round256(sizeof(double) * G) : 0;
+    if ((rc = ensure_scratch(ctx, 5, gram_b + part_b + c64_b + mask_b, &scr))) return rc;
     if (!st.status) {
         void *sp = nullptr;
         if ((rc = ensure_scratch(ctx, 7, sizeof(int32_t) * G, &sp))) return rc;
@@ -424,6 +426,13 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     a.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (p->solve_method == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
     a.status = st.status; a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.coef = st.coef; a.pred = st.pred; a.resid = st.resid;
+    a.null_policy = p->null_policy;
+    if (nulls) {
+        a.valid = st.valid;
+        a.rowmask = reinterpret_cast<uint8_t *>(static_cast<char *>(scr) + gram_b + part_b + c64_b);
+        a.nfit = reinterpret_cast<double *>(static_cast<char *>(scr) + gram_b + part_b + c64_b + round256((size_t)b->n_rows));
+        if ((rc = wide_rowmask_launch(ctx, b->dtype, a))) return rc;
+    }
     if ((rc = wide_gram_launch(ctx, b->dtype, a))) return rc;
     if (enet) {
         if ((rc = wide_cd_launch(ctx, b->dtype, a))) return rc;
@@ -485,7 +494,6 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
     if (b->n_groups == 0) return POLS_OK;
     if (kt > 31) {
-        if (nulls) return fail(POLS_ERR_UNSUPPORTED, "null policies are not built for more than 31 columns: filter upstream");
         const bool ols_b = !enet && ridge_alpha == 0.0 && alpha == 0.0;
         return wide_static(ctx, b, p, o, kt, enet, ridge_alpha, enet_l1, ols_b);
     }

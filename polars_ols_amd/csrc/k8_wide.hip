@@ -28,10 +28,46 @@ constexpr int WG_RS = 65;        // LDS row stride of a staged column (doubles)
 template <typename T>
 __device__ __forceinline__ double wide_z(const WideArgs &a, const void *colp, int z, int64_t r) {   // unscaled Z[r][z]
     const int ku = a.k_user, kt = a.kt;
-    if (z < ku) return (double)static_cast<const T *>(colp)[r];
-    if (z >= kt) return (double)static_cast<const T *>(a.ycols ? a.ycols[z - kt] : a.y)[r];   // target z - kt (callers keep z < NZ)
+    if (z < ku) return (double)null_fill<T>(a.null_policy, static_cast<const T *>(colp)[r]);
+    if (z >= kt) return (double)null_fill<T>(a.null_policy, static_cast<const T *>(a.ycols ? a.ycols[z - kt] : a.y)[r]);   // target z - kt
     if (z == kt - 1 && ku != kt) return 1.0;
     return 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------ row mask (null policies)
+// compute_is_valid_mask (ex.rs:201-228) over ALL columns of a row: one workgroup per group, a thread per row, the columns
+// walked one after the other (coalesced across the threads).  Also counts the fit rows of the group (the n of alpha * n).
+template <typename T>
+__global__ void __launch_bounds__(256) wide_rowmask_kernel(const WideArgs a) {
+    __shared__ int cnt_s;
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int pol = a.null_policy;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int64_t r = s + threadIdx.x; r < e; r += 256) {
+        bool fit = true;
+        if (null_checks_y(pol)) {
+            const T yv = static_cast<const T *>(a.y)[r];
+            fit = (yv == yv) && !(a.valid && !a.valid[r]);
+            if (fit && null_checks_x(pol))
+                for (int j = 0; j < a.k_user && fit; ++j) { const T xv = static_cast<const T *>(a.cols[j])[r]; fit = (xv == xv); }
+        }
+        a.rowmask[r] = fit ? 1 : 0;
+        cnt += fit ? 1 : 0;
+    }
+    if (cnt) atomicAdd(&cnt_s, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) a.nfit[g] = (double)cnt_s;
+}
+
+int wide_rowmask_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
+    if (a.n_groups == 0) return POLS_OK;
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_rowmask_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(wide_rowmask_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ gram
@@ -63,7 +99,11 @@ __global__ void __launch_bounds__(256) wide_gram_kernel(const WideArgs a) {
     for (int64_t r0 = r_begin; r0 < r_end; r0 += WG_TS) {
         const int rows_here = (int)min((int64_t)WG_TS, r_end - r0);
         __syncthreads();                                           // previous chunk consumed; pointer table visible
-        if (tid < WG_TS) sw_s[tid] = tid < rows_here ? (a.w ? sqrt((double)static_cast<const T *>(a.w)[r0 + tid]) : 1.0) : 0.0;
+        if (tid < WG_TS) {
+            double swv = tid < rows_here ? (a.w ? sqrt((double)static_cast<const T *>(a.w)[r0 + tid]) : 1.0) : 0.0;
+            if (a.rowmask && tid < rows_here && !a.rowmask[r0 + tid]) swv = 0.0;      // dropped by the null policy
+            sw_s[tid] = swv;
+        }
         __syncthreads();
         for (int idx = tid; idx < WG_TS * WG_TS; idx += 256) {
             const int c = idx >> 6, r = idx & 63;
@@ -163,7 +203,7 @@ __global__ void __launch_bounds__(NTHREADS) wide_chol_kernel(const WideArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int kt = a.kt, m = wide_m(a), NZ = kt + m;
     const int64_t g = blockIdx.x;
-    const int64_t n = a.offs[g + 1] - a.offs[g];
+    const int64_t n = a.nfit ? (int64_t)a.nfit[g] : a.offs[g + 1] - a.offs[g];
     double *Gm = a.gram + (size_t)g * NZ * NZ;
     const int LD = IN_LDS ? (NZ | 1) : NZ;
     double *A = IN_LDS ? a_lds : Gm;
@@ -262,7 +302,8 @@ __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
         double *s2 = Vm + (size_t)nc * nc, *gsc = s2 + nc;
         for (int r = 0; r < n; r += 1) {
             // one row at a time keeps the sqrt(w) and target reads trivial; the feature reads are strided either way
-            const double sw = a.w ? sqrt((double)static_cast<const T *>(a.w)[s + r]) : 1.0;
+            double sw = a.w ? sqrt((double)static_cast<const T *>(a.w)[s + r]) : 1.0;
+            if (a.rowmask && !a.rowmask[s + r]) sw = 0.0;                // dropped rows become zero rows
             for (int j = tid; j < kt; j += 256) {
                 const double z = wide_z<T>(a, j < a.k_user ? a.cols[j] : nullptr, j, s + r) * sw;
                 if (dual) W[(size_t)r * len + j] = z; else W[(size_t)j * len + r] = z;
@@ -354,7 +395,7 @@ __global__ void __launch_bounds__(1024) wide_cd_kernel(const WideArgs a) {
     const int tid = threadIdx.x;
     const int kt = a.kt, NZ = kt + 1;
     const int64_t g = blockIdx.x;
-    const double n = (double)(a.offs[g + 1] - a.offs[g]);
+    const double n = a.nfit ? a.nfit[g] : (double)(a.offs[g + 1] - a.offs[g]);
     const double *G = a.gram + (size_t)g * NZ * NZ;
     for (int i = tid; i < kt; i += 1024) {
         w[i] = 0.0;                                                // w = zeros (:416)
@@ -416,9 +457,10 @@ __global__ void __launch_bounds__(256) wide_predict_kernel(const WideArgs a) {
     for (int64_t r = s + (int64_t)blockIdx.x * 256 + threadIdx.x; r < e; r += (int64_t)gridDim.x * 256) {
         const T sw = a.w ? sqrt(static_cast<const T *>(a.w)[r]) : T(1);
         T p = T(0);
-        for (int j = 0; j < ku; ++j) p = fma(static_cast<const T *>(a.cols[j])[r] * sw, (T)cs[j], p);
+        for (int j = 0; j < ku; ++j) p = fma(null_fill<T>(a.null_policy, static_cast<const T *>(a.cols[j])[r]) * sw, (T)cs[j], p);
         if (ku != kt) p = fma(sw, (T)cs[kt - 1], p);
         if (a.w) p *= T(1) / sw;                                   // (sqrt_w x) . c * (1 / sqrt_w)  (ls.py:190-196, 234-235)
+        if (a.null_policy == POLS_NULL_DROP) p = nan_if<T>(a.rowmask[r] ? 0u : 1u, p);   // rows that were not fitted (ex.rs:409-417)
         if (pred) pred[r] = p;
         if (resid) resid[r] = static_cast<const T *>(a.y)[r] - p;
     }

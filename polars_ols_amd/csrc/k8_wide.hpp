@@ -35,10 +35,19 @@ struct WideArgs {
     const void *const *ycols;  // DEVICE table of m target column pointers (nullptr: the single target `y`)
     void *const *pred_cols;    // DEVICE table of m prediction column pointers (multi-target predict)
     int32_t n_targets;         // 0 or 1: single target
+    // null policy (src/expressions.rs:201-296): `rowmask` (one byte per row, 1 = the row takes part in the fit) and `nfit`
+    // (fit rows per group) are produced by wide_rowmask_launch from the NaNs of ALL columns (+ the validity bytes); the
+    // Gram / min-norm passes give masked rows weight 0 and zero-fill the nulls that stay, the prediction pass zero-fills
+    // and, for "drop", masks.  Both pointers are nullptr under "ignore".
+    const uint8_t *valid;
+    uint8_t *rowmask;
+    double *nfit;
+    int32_t null_policy;
 };
 
 __host__ __device__ inline int wide_m(const WideArgs &a) { return a.n_targets > 1 ? a.n_targets : 1; }
 
+int wide_rowmask_launch(pols_ctx *ctx, int dtype, const WideArgs &a);   // null policies only: fills a.rowmask / a.nfit
 int wide_gram_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
 int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a);      // OLS / ridge; flags what it cannot factor
 int wide_cd_launch(pols_ctx *ctx, int dtype, const WideArgs &a);        // elastic net / lasso / non-negative

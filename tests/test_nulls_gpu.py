@@ -77,6 +77,8 @@ def _expected(y, cols, offs, w, icpt, policy, **kw):
     (9, True, True, {"alpha": 0.5}),
     (5, False, True, {"alpha": 0.01, "l1_ratio": 0.5, "tol": 1e-10, "max_iter": 20_000}),
     (20, True, False, {}),
+    (40, True, True, {"alpha": 0.1}),                   # wide path (K8): row-mask pre-pass
+    (36, False, False, {"alpha": 0.02, "l1_ratio": 0.5, "tol": 1e-10, "max_iter": 20_000}),
 ])
 def test_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt, kw):
     y, cols, offs, w = _frame(7 + k, dtype, k)
@@ -84,8 +86,9 @@ def test_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt, kw):
     out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "resid", "status"),
                             null_policy=policy, **kw)
     coef, pred, resid = _expected(y, cols, offs, w, icpt, "drop_zero" if policy == "drop_window" else policy, **kw)
-    k1 = k + int(icpt) <= 8 and "l1_ratio" not in kw   # register-resident NULLS family vs the streamed kernels
+    k1 = k + int(icpt) <= 8 and "l1_ratio" not in kw   # register-resident NULLS family vs the streamed / wide kernels
     assert eng.last_kernel.startswith("k1_gram_chol") == k1 and (not k1 or eng.last_kernel.endswith("_nulls")), eng.last_kernel
+    assert eng.last_kernel.startswith("k8_wide") == (k + int(icpt) > 31)
     if policy != "zero":
         assert int(out["status"][3]) == 2 and int(out["status"][5]) == 2      # no rows / no row left in the fit
     assert np.allclose(out["coef"], coef, rtol=tol, atol=tol), float(np.nanmax(np.abs(out["coef"] - coef)))
