@@ -380,7 +380,9 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     // SIMDs' VALU issue slots that co-resident workgroups need), beta goes back through LDS
     T beta[KT];
     if constexpr (NPASS > 1) {
-        __shared__ T gsum[NACC + 3], lfac[KT * KT], lrinv[KT];   // TEAM == 256 here: one group per block
+        constexpr int TEAMS = 256 / TEAM;                          // one scratch set per team of the block
+        __shared__ T gsum_s[TEAMS][NACC + 3], lfac_s[TEAMS][KT * KT], lrinv_s[TEAMS][KT];
+        T *gsum = gsum_s[threadIdx.x / TEAM], *lfac = lfac_s[threadIdx.x / TEAM], *lrinv = lrinv_s[threadIdx.x / TEAM];
         if (wave == 0) {
             for (int q = lane; q < NACC; q += 64) {     // NACC = 66 at 10 columns
                 T t = mypart[q * WAVES];
@@ -403,7 +405,8 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
                 bcast[tid] = bv;
             }
         }
-        __syncthreads();
+        if constexpr (WAVES > 1) __syncthreads();
+        else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #pragma unroll
         for (int j = 0; j < KT; ++j) beta[j] = bcast[j];
     } else
@@ -499,6 +502,8 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     // FAST needs every group aligned to the vector width and resident; the offsets scan in upload_offsets() knows
     const bool fast = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC &&
                       std::getenv("POLS_K1_NOFAST") == nullptr;
+    // (f32 wave-per-group: the multi-pass form was tried -- 216 -> 187 VGPRs with three passes, still two waves per SIMD because the
+    // 16 resident rows alone are 144 registers -- and dropped.)
     if constexpr (sizeof(T) == 8 && TEAM == 256 && RC == 2 && KT >= 6) {
         // f64, 6+ columns: the full accumulator set costs a workgroup per CU; POLS_K1_PASSES=1|2|3 overrides
         int npass = 2;
