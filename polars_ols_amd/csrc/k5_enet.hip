@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
         }
         // columns in batches of JB: every load of a batch is issued before the first FMA, so a thread has JB 16-byte
         // requests in flight instead of one (the per-column loop was a chain of full memory latencies)
-        constexpr int JB = 8;
+        constexpr int JB = 16;
         for (int j0 = 0; j0 < kt; j0 += JB) {
             T xb[JB][VEC];
             if (full) {
