@@ -342,9 +342,14 @@ struct LsInfo {
 // 32 .. 1024 columns (k8_wide.hip): Gram in 64 x 64 MFMA tiles with row splits, workgroup Cholesky / coordinate descent on
 // the Gram matrix in HBM, minimum-norm fallback for flagged groups of at most 32 rows, prediction pass.
 // Multi-target calls (m > 1) pass the target / prediction column tables; the targets share the Gram matrix and one factorisation.
+// With `info` (the statistics entry) the outputs stay on the device and the kernel arguments are handed back.
+struct WideInfo {
+    Staged st;
+    WideArgs a;
+};
 static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, int kt, bool enet,
                        double ridge_alpha, double enet_l1, bool ols_branch, const void *const *y_cols = nullptr, int m = 1,
-                       void *const *pred_cols = nullptr) {
+                       void *const *pred_cols = nullptr, WideInfo *info = nullptr) {
     int rc;
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
@@ -453,13 +458,14 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     if (m > 1 && host && pred_cols)
         for (int t = 0; t < m; ++t)
             POLS_HIP(hipMemcpyAsync(pred_cols[t], pptr[t], dtype_size(b->dtype) * (size_t)b->n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (info) { info->st = st; info->a = a; return POLS_OK; }
     return unstage_outputs(ctx, b, b->n_groups * m, kt, o, st);
 }
 
 static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, LsInfo *info) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if ((rc = check_batch(b, o, info ? POLS_MAX_FEATURES - 1 : K8_KMAX))) return rc;
+    if ((rc = check_batch(b, o, K8_KMAX))) return rc;
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
     // Null policies (src/expressions.rs:201-296): a null is a NaN; `valid` (optional) additionally drops rows under the
     // drop family.  They are fused into the streamed path's staging / prediction passes -- no compaction, no copies.
@@ -495,6 +501,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     if (b->n_groups == 0) return POLS_OK;
     if (kt > 31) {
         const bool ols_b = !enet && ridge_alpha == 0.0 && alpha == 0.0;
+        if (info) return fail(POLS_ERR_INVALID, "internal: the wide statistics path calls wide_static itself");
         return wide_static(ctx, b, p, o, kt, enet, ridge_alpha, enet_l1, ols_b);
     }
     const int64_t *d_offs = nullptr;
@@ -676,7 +683,7 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
                                   const pols_stats_out *s) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if ((rc = check_batch(b, o))) return rc;
+    if ((rc = check_batch(b, o, K8_STATS_KMAX))) return rc;
     if (!p || !s) return fail(POLS_ERR_INVALID, "params / stats is NULL");
     if (p->null_policy != POLS_NULL_IGNORE || b->valid)
         return fail(POLS_ERR_UNSUPPORTED, "statistics: filter / zero-fill nulls before the call (what handle_nulls does above the "
@@ -686,6 +693,45 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
     const size_t sz = dtype_size(b->dtype);
     const bool host = b->mem == POLS_MEM_HOST;
     const size_t G = (size_t)b->n_groups;
+    if (kt > 31) {
+        // 32 .. 127 columns: the K8 kernels solve (same dispatcher), then the wide statistics kernel works from their Gram matrix
+        if (kt > K8_STATS_KMAX) return fail(POLS_ERR_UNSUPPORTED, "statistics: %d features (incl. intercept) > %d", kt, K8_STATS_KMAX);
+        // the dispatcher's decisions, as in ls_core (src/expressions.rs:366-387)
+        const int m = p->solve_method;
+        const bool positive = p->positive != 0;
+        const double l1 = p->has_l1_ratio ? p->l1_ratio : 0.0;
+        bool enet = false;
+        double ridge_alpha = 0.0, enet_l1 = 0.5;
+        if (p->alpha == 0.0 && !positive && (m == POLS_SOLVE_AUTO || m == POLS_SOLVE_SVD || m == POLS_SOLVE_QR)) ridge_alpha = 0.0;
+        else if (p->alpha >= 0.0 && l1 == 0.0 && !positive) ridge_alpha = p->alpha;
+        else { enet = true; enet_l1 = p->has_l1_ratio ? p->l1_ratio : 0.5; }
+        const size_t vecb = round256(sizeof(double) * G), matb = round256(sizeof(double) * G * kt);
+        void *scr4 = nullptr;
+        if (host && (rc = ensure_scratch(ctx, 4, 3 * vecb + 3 * matb, &scr4))) return rc;
+        WideInfo wi;
+        pols_out oo = *o;
+        char coef_sentinel;
+        if (!oo.coef && host) oo.coef = &coef_sentinel;            // host batches stage every non-NULL output
+        const bool ols_b = !enet && ridge_alpha == 0.0 && p->alpha == 0.0;
+        if ((rc = wide_static(ctx, b, p, &oo, kt, enet, ridge_alpha, enet_l1, ols_b, nullptr, 1, nullptr, &wi))) return rc;
+        WideStatsOut so;
+        double *const user[6] = {s->r2, s->mae, s->mse, s->std_err, s->t_values, s->p_values};
+        double *dev[6];
+        char *q = static_cast<char *>(scr4);
+        for (int i = 0; i < 6; ++i) {
+            dev[i] = !user[i] ? nullptr : (host ? reinterpret_cast<double *>(q) : user[i]);
+            if (host) q += (i < 3) ? vecb : matb;
+        }
+        so.r2 = dev[0]; so.mae = dev[1]; so.mse = dev[2]; so.se = dev[3]; so.tv = dev[4]; so.pv = dev[5];
+        so.lambda = p->alpha;
+        if ((rc = wide_stats_launch(ctx, b->dtype, wi.a, so))) return rc;
+        if (!host) return POLS_OK;
+        for (int i = 0; i < 6; ++i)
+            if (user[i])
+                POLS_HIP(hipMemcpyAsync(user[i], dev[i], sizeof(double) * G * (i < 3 ? 1 : kt), hipMemcpyDeviceToHost, ctx->stream));
+        if (!o->coef) oo.coef = nullptr;
+        return unstage_outputs(ctx, b, b->n_groups, kt, &oo, wi.st);
+    }
     // slot 6: [coefficients when the caller did not ask for them (device batches)] [statistic arrays of a host batch]
     const size_t coefb = round256(sz * G * kt), vecb = round256(sizeof(double) * G), matb = round256(sizeof(double) * G * kt);
     void *scr = nullptr;

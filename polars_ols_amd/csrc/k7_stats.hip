@@ -17,39 +17,6 @@ namespace pols {
 
 constexpr int K7_KMAX = 31;
 
-__device__ double k7_betacf(double a, double b, double x) {
-    const double tiny = 1e-300;
-    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
-    double c = 1.0, d = 1.0 - qab * x / qap;
-    if (fabs(d) < tiny) d = tiny;
-    d = 1.0 / d;
-    double h = d;
-    for (int m = 1; m <= 500; ++m) {
-        const int m2 = 2 * m;
-        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
-        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d; h *= d * c;
-        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
-        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d;
-        const double del = d * c;
-        h *= del;
-        if (fabs(del - 1.0) < 1e-16) break;
-    }
-    return h;
-}
-
-// regularised incomplete beta I_x(a, b)
-__device__ double k7_betai(double a, double b, double x) {
-    if (!(x > 0.0)) return (x != x) ? x : 0.0;
-    if (x >= 1.0) return 1.0;
-    const double bt = exp(lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x));
-    if (x < (a + 1.0) / (a + b + 2.0)) return bt * k7_betacf(a, b, x) / a;
-    return 1.0 - bt * k7_betacf(b, a, 1.0 - x) / b;
-}
-
 template <int NV>
 __device__ __forceinline__ void k7_block_sum(double (&v)[NV], double (*red)[4]) {   // red: NV x 4 doubles of LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -19,6 +19,7 @@
 //   predict   X . beta (+ residuals) with the reference's weighted arithmetic.
 #include "k8_wide.hpp"
 #include "k1m_kernel.inl"   // Mfma16
+#include "k7_stats.hpp"     // k7_betai
 
 namespace pols {
 
@@ -472,6 +473,110 @@ int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
     const dim3 grid(bx, (unsigned)a.n_groups, (unsigned)wide_m(a));
     if (dtype == POLS_F32) hipLaunchKernelGGL(wide_predict_kernel<float>, grid, dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(wide_predict_kernel<double>, grid, dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ statistics
+// compute_residual_metrics (st.rs:15-37) + compute_feature_metrics (:79-156) per group, like K7 but with the k x k matrix
+// in dynamic LDS: (X'X + lambda I)^-1 by the symmetric sweep operator (a non-positive pivot = the reference's failed
+// Cholesky -> NaN standard errors / t / p, :101-111), its diagonal and trace, the side-car's own coefficients inv . X'y,
+// then two passes over the group's rows for the mean of the targets and the four sums.
+template <typename T>
+__global__ void __launch_bounds__(256) wide_stats_kernel(const WideArgs a, const WideStatsOut o) {
+    extern __shared__ double sl[];
+    __shared__ double red[4 * 4];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x;
+    const int kt = a.kt, ku = a.k_user, NZ = kt + 1, LD = kt | 1;
+    double *P = sl, *v = P + (size_t)kt * LD, *bv = v + kt, *binv = bv + kt, *cdis = binv + kt;
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1], n = e - s;
+    const double *G = a.gram + (size_t)g * NZ * NZ;
+    for (int q = tid; q < kt * kt; q += 256) { const int i = q / kt, c = q - i * kt; P[i * LD + c] = G[(size_t)i * NZ + c] + (i == c ? o.lambda : 0.0); }
+    if (tid < kt) { bv[tid] = G[(size_t)tid * NZ + kt]; cdis[tid] = a.coef64[g * kt + tid]; }
+    if (tid == 0) ok_s = 1;
+    __syncthreads();
+    for (int j = 0; j < kt; ++j) {
+        const double d = P[j * LD + j];
+        if (tid == 0 && !(d > 0.0)) ok_s = 0;
+        const double p = 1.0 / d;
+        if (tid < kt) v[tid] = P[tid * LD + j];
+        __syncthreads();
+        for (int q = tid; q < kt * kt; q += 256) {
+            const int i = q / kt, c = q - i * kt;
+            double val;
+            if (i == j && c == j) val = -p;
+            else if (i == j) val = v[c] * p;
+            else if (c == j) val = v[i] * p;
+            else val = P[i * LD + c] - v[i] * v[c] * p;
+            P[i * LD + c] = val;
+        }
+        __syncthreads();
+    }
+    if (tid < kt) {                                                // P now holds -(inverse)
+        double acc = 0.0;
+        for (int c = 0; c < kt; ++c) acc -= P[tid * LD + c] * bv[c];
+        binv[tid] = acc;                                           // A^-1 X'y  (:116)
+        v[tid] = -P[tid * LD + tid];                               // diag(A^-1)
+    }
+    __syncthreads();
+    const T *yp = static_cast<const T *>(a.y), *wp = static_cast<const T *>(a.w);
+    double sums[1] = {0.0};
+    for (int64_t r = s + tid; r < e; r += 256) sums[0] += (double)yp[r] * (wp ? sqrt((double)wp[r]) : 1.0);
+    wide_block_sum<1>(sums, red, 4);
+    const double mean = n ? sums[0] / (double)n : 0.0;             // targets.mean().unwrap_or(0.0)  (:16)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};                           // sse, sae, sst, rss
+    for (int64_t r = s + tid; r < e; r += 256) {
+        const double sw = wp ? sqrt((double)wp[r]) : 1.0;
+        const double yt = (double)yp[r] * sw;
+        double p1 = 0.0, p2 = 0.0;
+        for (int j = 0; j < kt; ++j) {
+            const double x = ((j < ku) ? (double)static_cast<const T *>(a.cols[j])[r] : 1.0) * sw;
+            p1 = fma(x, cdis[j], p1);
+            p2 = fma(x, binv[j], p2);
+        }
+        const double e1 = yt - p1, e2 = yt - p2, dm = yt - mean;
+        acc[0] += e1 * e1; acc[1] += fabs(e1); acc[2] += dm * dm; acc[3] += e2 * e2;
+    }
+    wide_block_sum<4>(acc, red, 4);
+    double trace = 0.0;
+    for (int j = 0; j < kt; ++j) trace += v[j];
+    const double nn = (double)n;
+    const double df = (o.lambda > 0.0) ? nn - trace : nn - (double)kt;          // :124-128
+    const bool ok = ok_s != 0;
+    if (tid == 0) {
+        if (o.mse) o.mse[g] = acc[0] / nn;
+        if (o.mae) o.mae[g] = acc[1] / nn;
+        if (o.r2) o.r2[g] = 1.0 - acc[0] / acc[2];
+        if (a.status && ok && !(df > 0.0)) a.status[g] = POLS_GROUP_BAD_DOF;
+    }
+    if (tid < kt) {
+        const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+        double se = nanv, tv = nanv, pv = nanv;
+        if (ok && df > 0.0) {
+            se = sqrt(acc[3] / df * fabs(v[tid]));
+            tv = binv[tid] / se;
+            pv = (tv != tv) ? nanv : k7_betai(0.5 * df, 0.5, df / (df + tv * tv));
+        }
+        if (o.se) o.se[g * kt + tid] = se;
+        if (o.tv) o.tv[g * kt + tid] = tv;
+        if (o.pv) o.pv[g * kt + tid] = pv;
+    }
+}
+
+int wide_stats_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const WideStatsOut &o) {
+    if (a.kt > K8_STATS_KMAX) return fail(POLS_ERR_UNSUPPORTED, "statistics: %d features (incl. intercept) > %d", a.kt, K8_STATS_KMAX);
+    if (a.n_groups == 0) return POLS_OK;
+    const size_t lds = sizeof(double) * ((size_t)a.kt * (a.kt | 1) + 4 * (size_t)a.kt);
+    static bool attr_set = false;
+    if (!attr_set) {
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        attr_set = true;
+    }
+    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_stats_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
+    else hipLaunchKernelGGL(wide_stats_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

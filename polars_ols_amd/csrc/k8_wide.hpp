@@ -53,6 +53,11 @@ int wide_chol_launch(pols_ctx *ctx, int dtype, const WideArgs &a);      // OLS /
 int wide_cd_launch(pols_ctx *ctx, int dtype, const WideArgs &a);        // elastic net / lasso / non-negative
 int wide_minnorm_launch(pols_ctx *ctx, int dtype, const WideArgs &a, int workers);   // flagged groups: Jacobi SVD, minimum norm
 int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
+// mode="statistics" for 32 .. 127 columns (src/statistics.rs:15-156): needs a.gram (wide_gram_launch), a.coef64 (the dispatcher's
+// coefficients) and six f64 output arrays (any may be nullptr); lambda = kwargs.alpha
+struct WideStatsOut { double *r2, *mae, *mse, *se, *tv, *pv; double lambda; };
+int wide_stats_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const WideStatsOut &o);
+constexpr int K8_STATS_KMAX = 127;
 // `predict` plugin body for wide frames: one coefficient row per input row (coef_rows: n_rows x kt, batch dtype)
 int wide_predict_rows_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const void *coef_rows);
 

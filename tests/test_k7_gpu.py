@@ -101,6 +101,18 @@ def test_statistics_wide_features_and_large_groups(engine):
     _check(res, exp, 1e-6, 1e-6)
 
 
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-6), (np.float32, 2e-3)])
+@pytest.mark.parametrize("k,weights,add_intercept,alpha", [(32, False, False, 0.0), (60, True, True, 1.5), (126, False, True, 0.0)])
+def test_statistics_wide_32_to_127_columns(engine, dtype, rtol, k, weights, add_intercept, alpha):
+    """The K8 kernels solve, the wide statistics kernel works from their Gram matrix (sweep-operator inverse in LDS)."""
+    d = _ragged(40 + k, dtype, G=5, k=k, lo=3 * k, hi=6 * k)
+    w = d["w"] if weights else None
+    res = engine.least_squares_statistics(d["y"], d["cols"], d["offsets"], weights=w, add_intercept=add_intercept, alpha=alpha)
+    exp = _oracle_stats(d, weights=w, add_intercept=add_intercept, alpha=alpha)
+    _check(res, exp, rtol, rtol)
+    assert (np.asarray(res["status"]) == 0).all()
+
+
 def test_statistics_elastic_net_uses_alpha_as_lambda(engine):
     d = _ragged(11, np.float64, G=9)
     res = engine.least_squares_statistics(d["y"], d["cols"], d["offsets"], alpha=0.01, l1_ratio=0.5)
