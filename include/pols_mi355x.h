@@ -100,7 +100,8 @@ int pols_set_stream(pols_ctx *ctx, void *hip_stream);
 int pols_use_private_stream(pols_ctx *ctx);
 int pols_synchronize(pols_ctx *ctx);
 /* Kernel timing with HIP events on the context's stream (used by bench.py's roofline leg).
- * While enabled every compute entry brackets its dominant kernel with an event pair. */
+ * While enabled every compute entry brackets its dominant kernel with an event pair; enable = n > 1 times every n-th
+ * call only (an event pair costs ~5 us on the stream's timeline, which matters next to a 75 us kernel). */
 int pols_timing_enable(pols_ctx *ctx, int enable);
 /* Synchronises, copies up to `max` per-launch durations (ms) recorded since the last call, returns the count. */
 int pols_timing_collect(pols_ctx *ctx, float *ms_out, int max);

@@ -51,17 +51,20 @@ int ensure_scratch(pols_ctx *ctx, int slot, size_t bytes, void **out) {
 
 int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const int64_t **d_offs, int64_t *max_rows) {
     // cheap content hash so steady-state calls on the same frame skip the re-upload
-    uint64_t sum = 1469598103934665603ULL;
-    int64_t mx = 0, ored = 0;
+    // (four independent multiply-xor lanes: the single chain was ~40 us per call at 10 000 groups)
+    uint64_t h[4] = {1469598103934665603ULL, 0x9E3779B97F4A7C15ULL, 0xC2B2AE3D27D4EB4FULL, 0x165667B19E3779F9ULL};
+    int64_t mx = 0, ored = 0, mn = 0;
     for (int64_t g = 0; g <= n_groups; ++g) {
-        sum = (sum ^ (uint64_t)offs[g]) * 1099511628211ULL;
+        h[g & 3] = (h[g & 3] ^ (uint64_t)offs[g]) * 1099511628211ULL;
         ored |= offs[g];
         if (g > 0) {
             const int64_t d = offs[g] - offs[g - 1];
-            if (d < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending (offsets[%lld] < offsets[%lld])", (long long)g, (long long)(g - 1));
+            mn = std::min(mn, d);
             mx = std::max(mx, d);
         }
     }
+    if (mn < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending");
+    const uint64_t sum = ((h[0] * 31 + h[1]) * 31 + h[2]) * 31 + h[3];
     void *dptr = nullptr;
     const size_t bytes = sizeof(int64_t) * (size_t)(n_groups + 1);
     const bool hit = ctx->scratch[0].ptr && ctx->offs_n == n_groups && ctx->offs_sum == sum && ctx->scratch[0].cap >= bytes;
@@ -81,8 +84,15 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
     return POLS_OK;
 }
 
+static bool timing_sampled(pols_ctx *ctx) {           // every timing_stride-th eligible launch is timed
+    if (!ctx->timing) return false;
+    return (ctx->timing_tick++ % ctx->timing_stride) == 0;
+}
+
 void timing_begin(pols_ctx *ctx) {
-    if (!ctx->timing) return;
+    ctx->timing_open = false;
+    if (!timing_sampled(ctx)) return;
+    ctx->timing_open = true;
     if (ctx->timed_used == ctx->timed.size()) {
         TimedLaunch t;
         if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return;
@@ -92,7 +102,7 @@ void timing_begin(pols_ctx *ctx) {
 }
 
 bool timing_pair(pols_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
-    if (!ctx->timing) return false;
+    if (!timing_sampled(ctx)) return false;
     if (ctx->timed_used == ctx->timed.size()) {
         TimedLaunch t;
         if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return false;
@@ -105,7 +115,8 @@ bool timing_pair(pols_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
 }
 
 void timing_end(pols_ctx *ctx) {
-    if (!ctx->timing || ctx->timed_used >= ctx->timed.size()) return;
+    if (!ctx->timing_open || ctx->timed_used >= ctx->timed.size()) return;
+    ctx->timing_open = false;
     hipEventRecord(ctx->timed[ctx->timed_used].stop, ctx->stream);
     ctx->timed_used++;
 }
@@ -280,6 +291,8 @@ int pols_synchronize(pols_ctx *ctx) {
 int pols_timing_enable(pols_ctx *ctx, int enable) {
     if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
     ctx->timing = enable != 0;
+    ctx->timing_stride = enable > 1 ? enable : 1;
+    ctx->timing_tick = 0;
     ctx->timed_used = 0;
     return POLS_OK;
 }
@@ -406,7 +419,7 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         POLS_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->fb_flag), 256));
         POLS_HIP(hipMemsetAsync(ctx->fb_flag, 0, 256, ctx->stream));
     }
-    ctx->epoch = (ctx->epoch % 0x3fffffff) + 1;
+    ctx->epoch = (ctx->epoch % 0x0ffffff0) + 1;   // (epoch << 3 | status) must fit an int32 (fused fix-up tags)
 
     WideArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -528,12 +541,13 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             POLS_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->fb_flag), 256));
             POLS_HIP(hipMemsetAsync(ctx->fb_flag, 0, 256, ctx->stream));
         }
-        ctx->epoch = (ctx->epoch % 0x3fffffff) + 1;
+        ctx->epoch = (ctx->epoch % 0x0ffffff0) + 1;   // (epoch << 3 | status) must fit an int32 (fused fix-up tags)
     }
     const bool ols_branch = !enet && ridge_alpha == 0.0 && (m == POLS_SOLVE_AUTO || m == POLS_SOLVE_SVD || m == POLS_SOLVE_QR) && alpha == 0.0;
     const double pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : 0.0;
-    auto svd_fixup = [&]() -> int {
-        if (enet) return POLS_OK;
+    K6Args ka;
+    int fix_workers = 0;
+    auto prepare_fix = [&]() -> int {                           // arguments + work area of the fix-up pass
         const int workers = (int)std::min<int64_t>(b->n_groups, 64);
         const int64_t stride = std::max<int64_t>(1, max_rows) * (kt + 1);
         void *wk = nullptr;
@@ -541,7 +555,6 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         while (w_use > 1 && (double)w_use * (double)stride * 8.0 > 4e9) w_use /= 2;
         int r2;   // slot 5 holds the Gram matrices / coef64 of the streamed path: the work area gets its own slot
         if ((r2 = ensure_scratch(ctx, 3, sizeof(double) * (size_t)w_use * (size_t)stride, &wk))) return r2;
-        K6Args ka;
         std::memset(&ka, 0, sizeof(ka));
         ka.y = st.y; ka.w = st.w;
         for (int j = 0; j < b->n_features; ++j) ka.x[j] = st.x[j];
@@ -559,7 +572,14 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         ka.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
         ka.k_user = b->n_features; ka.kt = kt;
         ka.valid = st.valid; ka.null_policy = pol;
-        return k6_launch(ctx, b->dtype, ka, w_use);
+        fix_workers = w_use;
+        return POLS_OK;
+    };
+    auto svd_fixup = [&]() -> int {
+        if (enet) return POLS_OK;
+        int r2 = prepare_fix();
+        if (r2) return r2;
+        return k6_launch(ctx, b->dtype, ka, fix_workers);
     };
 
     // Streamed three-launch path: elastic net always; OLS / ridge when the group does not fit the fused kernels
@@ -637,8 +657,20 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.k_user = b->n_features;
     a.null_policy = pol;
+    // The wave-per-group kernels can carry the fix-up pass as trailing workgroups of the same launch (no second dispatch in the
+    // common no-flag case); everything is prepared for it here and k1_launch says whether the chosen variant took it.
+    if ((rc = prepare_fix())) return rc;
+    if (!std::getenv("POLS_NO_FUSED_FIXUP")) {
+        void *tg = nullptr;                                   // persistent tag words; a fresh (or re-grown) buffer is cleared once
+        const void *before = ctx->scratch[8].ptr;
+        if ((rc = ensure_scratch(ctx, 8, sizeof(int32_t) * (size_t)b->n_groups, &tg))) return rc;
+        if (tg != before) POLS_HIP(hipMemsetAsync(tg, 0, ctx->scratch[8].cap, ctx->stream));
+        a.fix = ka; a.fix.tags = static_cast<const int32_t *>(tg); a.fix.fb_flag = nullptr;
+        a.n_k1_blocks = fix_workers; a.tags = static_cast<int32_t *>(tg);
+    }
+    ctx->last_fused = false;
     if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
-    if ((rc = svd_fixup())) return rc;
+    if (!ctx->last_fused && (rc = k6_launch(ctx, b->dtype, ka, fix_workers))) return rc;
     return finish(nullptr);
 }
 

@@ -46,8 +46,11 @@ struct pols_ctx {
     int num_cus = 0;
     // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] timeline stamps,
     // [4] chunk / group tables, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean
-    pols::Scratch scratch[8];
+    pols::Scratch scratch[9];   // [8] fused fix-up tags
     bool timing = false;
+    int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
+    int timing_tick = 0;
+    bool timing_open = false;                // a timing_begin() is waiting for its timing_end()
     std::vector<pols::TimedLaunch> timed;   // pool of event pairs
     size_t timed_used = 0;
     std::string last_kernel;
@@ -60,6 +63,7 @@ struct pols_ctx {
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag
     int32_t epoch = 0;
     bool offs_aligned[2] = {false, false};   // every group start AND size a multiple of 2 / of 4 rows
+    bool last_fused = false;                 // the last K1 launch carried its own fix-up workers
     // cache of the chunk tables of the dynamic kernels (scratch slot 4) for mask-free batches: rebuilt only when the
     // offsets, min_periods or the chunk length change
     struct { uint64_t offs_sum = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;

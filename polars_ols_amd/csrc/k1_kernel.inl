@@ -1,5 +1,6 @@
 // k1_kernel.inl -- body of K1 (see k1_gram_chol.hpp for the design notes).  Included by k1_f32.hip / k1_f64.hip.
 #include "k1_gram_chol.hpp"
+#include "k6_body.inl"
 
 namespace pols {
 
@@ -304,8 +305,32 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 // the RC * TEAM resident chunks -> no ragged-edge and no overflow code (fewer VGPRs, more groups in flight).
 // NPASS > 1 (FAST only): the Gram is accumulated in NPASS passes over the resident registers, each keeping 1 / NPASS of the
 // accumulators live -- fewer VGPRs, one more workgroup per CU for the f64 team kernel.
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
+// Trailing workgroups of a fused launch (see K1Args::n_k1_blocks): worker w owns the groups w, w + n_workers, ...
+template <typename T>
+__device__ __forceinline__ void k1_fixup_worker(const K1Args &a) {
+    __shared__ int any_flagged;
+    const int worker = (int)blockIdx.x - a.n_k1_blocks, n_workers = (int)gridDim.x - a.n_k1_blocks;
+    if (threadIdx.x == 0) any_flagged = 0;
+    __syncthreads();
+    bool mine = false;
+    for (int64_t g = worker + (int64_t)n_workers * threadIdx.x; g < a.n_groups; g += (int64_t)n_workers * 256) {
+        int32_t t;
+        while (((t = __hip_atomic_load(&a.tags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 3) != a.epoch)
+            __builtin_amdgcn_s_sleep(4);                       // the group's solver wave has not finished yet
+        mine = mine || (t & 7) == POLS_GROUP_FALLBACK;
+    }
+    if (mine) any_flagged = 1;
+    __syncthreads();
+    if (!any_flagged) return;                                  // the common case: one round of loads
+    k6_process<T>(a.fix, worker, n_workers);
+}
+
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
+    static_assert(!FUSED || TEAM == 64, "the fused fix-up counts solver WAVES");
+    if constexpr (FUSED) {
+        if ((int)blockIdx.x >= a.n_k1_blocks) { k1_fixup_worker<T>(a); return; }
+    }
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
     constexpr int NACC = NZ * (NZ + 1) / 2;
@@ -379,6 +404,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     // ---- K x K solve on wave-uniform values: ONE wave per team solves (the others would only burn the
     // SIMDs' VALU issue slots that co-resident workgroups need), beta goes back through LDS
     T beta[KT];
+    bool flagged = false;                                    // FUSED: this wave's group goes to the fix-up workers
     if constexpr (NPASS > 1) {
         constexpr int TEAMS = 256 / TEAM;                          // one scratch set per team of the block
         __shared__ T gsum_s[TEAMS][NACC + 3], lfac_s[TEAMS][KT * KT], lrinv_s[TEAMS][KT];
@@ -425,14 +451,21 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
             st = POLS_GROUP_EMPTY;
         } else {
             const bool ok = chol_solve<T, KT>(acc, (T)a.alpha, beta, (T)a.pivot_tol);
-            if (!ok) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }   // K6 re-solves this group
+            if (!ok) {                                       // K6 re-solves this group
+                st = POLS_GROUP_FALLBACK;
+                flagged = true;
+                if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch;
+            }
         }
         if (tid == 0 && a.status) a.status[g] = st;
+        if constexpr (FUSED) {                               // publish this group's verdict to the fix-up workers
+            if (tid == 0) __hip_atomic_store(&a.tags[g], (a.epoch << 3) | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid < KT) {
             T bv = T(0);
 #pragma unroll
             for (int j = 0; j < KT; ++j) bv = (tid == j) ? beta[j] : bv;
-            if (a.coef) static_cast<T *>(a.coef)[g * KT + tid] = bv;
+            if (a.coef && !(FUSED && flagged)) static_cast<T *>(a.coef)[g * KT + tid] = bv;
             if constexpr (WAVES > 1) bcast[tid] = bv;
         }
     }
@@ -446,7 +479,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 
     K1_STAMP(4);
     // ---- fused predictions / residuals from the resident rows, then the streamed overflow rows
-    if (a.pred || a.resid) {
+    if ((a.pred || a.resid) && !(FUSED && flagged)) {       // a flagged group's outputs belong to the fix-up workers
 #pragma unroll
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
@@ -465,16 +498,21 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 #undef K1_STAMP
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
     std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s%s%s", sizeof(T) == 4 ? "f32" : "f64", KT,
                   HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : "_p3"), NULLS ? "_nulls" : "");
     const int64_t teams_per_block = 256 / TEAM;
-    const int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
-    if (blocks > 0x7fffffffLL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
+    int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
+    if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     ctx->last_kernel = name;
     K1Args aa = a;
+    ctx->last_fused = FUSED;
+    if constexpr (FUSED) {
+        aa.n_k1_blocks = (int32_t)blocks;
+        blocks += a.n_k1_blocks;                             // a.n_k1_blocks carries the number of fix-up workers on entry
+    }
     const bool timeline = std::getenv("POLS_TIMELINE") != nullptr;
     if (timeline) {
         void *d = nullptr;
@@ -484,9 +522,9 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     }
     hipEvent_t ev0, ev1;
     if (timing_pair(ctx, &ev0, &ev1))
-        hipExtLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
+        hipExtLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
     else
-        hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+        hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
     POLS_HIP(hipGetLastError());
     if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
     return POLS_OK;
@@ -510,6 +548,11 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (const char *env = std::getenv("POLS_K1_PASSES")) npass = std::atoi(env);
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
+    }
+    if constexpr (TEAM == 64) {
+        // wave-per-group: the launch can carry its own fix-up workers (a.n_k1_blocks = how many the host prepared for)
+        if (fast && a.n_k1_blocks > 0 && a.tags && !std::getenv("POLS_TIMELINE"))
+            return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 1, false, true>(ctx, a);
     }
     return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false>(ctx, a);
 #endif

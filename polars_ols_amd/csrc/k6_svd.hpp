@@ -23,6 +23,8 @@ struct K6Args {
     int32_t k_user, kt;
     const uint8_t *valid;    // null policy of the static entry (see common.hpp::null_row_in_fit)
     int32_t null_policy;
+    // fused launch: the solver waves publish (epoch << 3 | group status) per group here instead of being read back from `status`
+    const int32_t *tags;
 };
 
 int k6_launch(pols_ctx *ctx, int dtype, const K6Args &a, int workers);

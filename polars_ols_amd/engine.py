@@ -65,7 +65,8 @@ class Engine:
     def synchronize(self):
         L.check(self._lib.pols_synchronize(self._h))
 
-    def timing(self, enable: bool):
+    def timing(self, enable):
+        """``True`` / ``False``, or an int n > 1 to time every n-th call only."""
         L.check(self._lib.pols_timing_enable(self._h, int(enable)))
 
     def timing_collect(self, max_n: int = 4096) -> np.ndarray:
