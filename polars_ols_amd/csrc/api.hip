@@ -660,7 +660,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     // The wave-per-group kernels can carry the fix-up pass as trailing workgroups of the same launch (no second dispatch in the
     // common no-flag case); everything is prepared for it here and k1_launch says whether the chosen variant took it.
     if ((rc = prepare_fix())) return rc;
-    if (!std::getenv("POLS_NO_FUSED_FIXUP")) {
+    // Opt-in (POLS_FUSED_FIXUP=1): measured on cfg2 it saves 1 % end to end (74.3 vs 75.2 us per call -- the no-op fix-up dispatch
+    // mostly overlaps the next call's ramp-up) but the polling tail lengthens the solver kernel itself by ~2 us.
+    if (std::getenv("POLS_FUSED_FIXUP")) {
         void *tg = nullptr;                                   // persistent tag words; a fresh (or re-grown) buffer is cleared once
         const void *before = ctx->scratch[8].ptr;
         if ((rc = ensure_scratch(ctx, 8, sizeof(int32_t) * (size_t)b->n_groups, &tg))) return rc;

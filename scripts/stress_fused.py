@@ -13,13 +13,13 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     for g in flagged:                                     # two identical columns -> rank deficient -> flagged
         cols[5][g * n:(g + 1) * n] = cols[2][g * n:(g + 1) * n]
     offs = np.arange(G + 1, dtype=np.int64) * n
+    os.environ["POLS_FUSED_FIXUP"] = "1"
     out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
     kern = eng.last_kernel
     torch.cuda.synchronize()
-    os.environ["POLS_NO_FUSED_FIXUP"] = "1"
+    del os.environ["POLS_FUSED_FIXUP"]
     ref = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
     torch.cuda.synchronize()
-    del os.environ["POLS_NO_FUSED_FIXUP"]
     st = out["status"].cpu().numpy()
     ok = (np.array_equal(st, ref["status"].cpu().numpy()) and set(np.nonzero(st == 1)[0]) == set(flagged.tolist())
           and torch.equal(out["coef"], ref["coef"]) and torch.equal(out["pred"], ref["pred"]))

@@ -134,3 +134,26 @@ def test_ridge_on_collinear_data_needs_no_fallback(eng):
     out = eng.least_squares(y, cols, [0, n], alpha=0.5, l1_ratio=0.0, want=("coef", "status"))
     ref = orc.batched_least_squares(y, cols, [0, n], alpha=0.5, l1_ratio=0.0)
     assert out["status"][0] == 0 and np.allclose(out["coef"], ref["coef"], rtol=1e-6, atol=1e-8)
+
+
+def test_fused_fixup_matches_two_launch_form(eng, monkeypatch):
+    """POLS_FUSED_FIXUP=1: the wave-per-group launch carries its own fix-up workgroups (per-group epoch tags); the result must be
+    bit-identical to the default two-dispatch form, flagged groups included."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    G, n, k = 1_000, 1_000, 8
+    cols = [torch.randn(G * n, device="cuda") for _ in range(k)]
+    y = sum(cols) + 0.1 * torch.randn(G * n, device="cuda")
+    flagged = sorted(rng.choice(G, size=17, replace=False).tolist())
+    for g in flagged:
+        cols[6][g * n:(g + 1) * n] = cols[1][g * n:(g + 1) * n]
+    offs = np.arange(G + 1, dtype=np.int64) * n
+    ref = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
+    torch.cuda.synchronize()
+    monkeypatch.setenv("POLS_FUSED_FIXUP", "1")
+    for _ in range(5):
+        out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
+        torch.cuda.synchronize()
+        assert np.nonzero(out["status"].cpu().numpy() == 1)[0].tolist() == flagged
+        assert torch.equal(out["coef"], ref["coef"]) and torch.equal(out["pred"], ref["pred"])
