@@ -157,6 +157,41 @@ def test_cfg5_shape_medium(eng):
         assert float((lhs - rhs).abs().max()) < 5e-2    # tol = 1e-5 on w times ||x_j||^2 ~ 2000
 
 
+def test_cfg5_full_size(eng):
+    """BASELINE configs[4] at FULL size on one GPU: 100 000 groups x 2 000 rows x 16 feats f64 (27 GB resident), elastic net
+    alpha = 0.001, l1_ratio = 0.5.  Size-independent properties on every group (KKT stationarity of the elastic net, every group
+    converged) + oracle parity on a sample of groups."""
+    import torch
+    from oracle import orc
+
+    G, n, k = 100_000, 2_000, 16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    cols = [torch.randn(G * n, generator=g, device="cuda", dtype=torch.float64) for _ in range(k)]
+    y = torch.zeros(G * n, device="cuda", dtype=torch.float64)
+    for c in cols:
+        y += c
+    y += 0.1 * torch.randn(G * n, generator=g, device="cuda", dtype=torch.float64)
+    offs = np.arange(G + 1, dtype=np.int64) * n
+    out = eng.least_squares(y, cols, offs, alpha=0.001, l1_ratio=0.5, want=("coef", "pred", "status"))
+    torch.cuda.synchronize()
+    assert int(out["status"].sum()) == 0
+    w = out["coef"]
+    r = (y - out["pred"]).view(G, n)
+    worst = 0.0
+    for j in range(k):
+        lhs = (cols[j].view(G, n) * r).sum(1)
+        rhs = n * 0.001 * (0.5 * torch.sign(w[:, j]) + 0.5 * w[:, j])
+        worst = max(worst, float((lhs - rhs).abs().max()))
+    assert worst < 5e-2, worst                                  # tol = 1e-5 on w times ||x_j||^2 ~ 2000
+    pick = np.array([0, 12_345, 50_000, 99_999])
+    yh = np.concatenate([y[p * n:(p + 1) * n].cpu().numpy() for p in pick])
+    ch = [np.concatenate([c[p * n:(p + 1) * n].cpu().numpy() for p in pick]) for c in cols]
+    ref = orc.batched_least_squares(yh, ch, np.arange(len(pick) + 1) * n, alpha=0.001, l1_ratio=0.5)
+    assert np.allclose(_np(out["coef"])[pick], ref["coef"], rtol=1e-6, atol=1e-6)
+    got_p = np.concatenate([out["pred"][p * n:(p + 1) * n].cpu().numpy() for p in pick])
+    assert np.allclose(got_p, ref["pred"], rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 2e-4)])
 @pytest.mark.parametrize("k,alpha,weights,icpt", [(16, 0.0, False, False), (20, 1.0, True, True), (31, 0.0, False, False),
                                                   (24, 0.3, False, True)])
