@@ -238,3 +238,31 @@ def test_full_size_cfg2_properties(eng, engine_kind, dtype, groups, rows, k):
     ref = orc.batched_least_squares(yh, ch, np.arange(len(pick) + 1) * rows)
     assert np.allclose(out["coef"].cpu().numpy()[pick], ref["coef"], rtol=1e-4, atol=1e-4)
     assert np.allclose(out["pred"].cpu().numpy().reshape(groups, rows)[pick].reshape(-1), ref["pred"], rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_cfg3_properties(eng):
+    """BASELINE configs[2] at full size (10k x 1k x 8, f64, ridge alpha = 1 + sample_weights, predictions): the weighted ridge
+    normal equations X'W(y - yhat) = alpha * beta hold for every group, pred + resid == y, and sampled groups match the oracle."""
+    import torch
+    from oracle import orc
+
+    groups, rows, k = 10_000, 1_000, 8
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N = groups * rows
+    cols = [torch.randn(N, generator=g, device="cuda", dtype=torch.float64) for _ in range(k)]
+    y = sum(cols) + 0.1 * torch.randn(N, generator=g, device="cuda", dtype=torch.float64)
+    w = torch.rand(N, generator=g, device="cuda", dtype=torch.float64) + 0.05
+    offs = np.arange(groups + 1, dtype=np.int64) * rows
+    out = eng.least_squares(y, cols, offs, weights=w, alpha=1.0, l1_ratio=0.0, want=("coef", "pred", "resid", "status"))
+    assert eng.last_kernel.startswith("k1_gram_chol_f64_k8_w")
+    assert int(out["status"].abs().sum()) == 0
+    assert torch.allclose(out["pred"] + out["resid"], y, atol=1e-12)
+    wr = (w * out["resid"]).view(groups, rows)
+    for j, c in enumerate(cols):
+        lhs = (c.view(groups, rows) * wr).sum(1)                  # x_j' W (y - X beta) = alpha * beta_j
+        assert float((lhs - 1.0 * out["coef"][:, j]).abs().max()) < 1e-9 * rows
+    pick = np.array([0, 17, 5_000, 9_999])
+    sl = lambda t: np.concatenate([t[p * rows:(p + 1) * rows].cpu().numpy() for p in pick])  # noqa: E731
+    ref = orc.batched_least_squares(sl(y), [sl(c) for c in cols], np.arange(len(pick) + 1) * rows, weights=sl(w), alpha=1.0, l1_ratio=0.0)
+    assert np.allclose(out["coef"].cpu().numpy()[pick], ref["coef"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(sl(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
