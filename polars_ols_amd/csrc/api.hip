@@ -832,7 +832,7 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, con
     return stage_inputs(ctx, b, b->n_rows, b->n_features, o, st);
 }
 
-static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a);
+static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a, int64_t min_chunk = 64);
 
 // Scratch slot 6 of the dynamic entries: [128 doubles: RLS prior mean][column pointer table for more than 32 features]
 static int dynamic_slot6(pols_ctx *ctx, void **base) {
@@ -891,12 +891,14 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         const int k = b->n_features;
         K4Args s4;
         std::memset(&s4, 0, sizeof(s4));
-        if ((rc = build_chunk_tables(ctx, b, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4))) return rc;
+        if ((rc = build_chunk_tables(ctx, b, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, 64))) return rc;
         s4.y = st.y; s4.valid = st.valid;
         if ((rc = upload_column_table(ctx, st, k, &s4))) return rc;
         s4.coef = st.coef; s4.pred = st.pred;
         s4.k = k;
         s4.ff = a.forgetting_factor; s4.p0 = a.initial_state_covariance; s4.mean0 = a.mean0;
+        if (wide) { s4.tot_cs = k * k + k + 1; s4.tot_qs = 1; }            // chunk-major for the wave / workgroup-per-chunk kernels
+        else { s4.tot_cs = 1; s4.tot_qs = s4.n_chunks; }                   // component-major for the lane-per-chunk kernels
         if ((rc = xwide ? k3x_launch(ctx, b->dtype, s4) : (wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4)))) return rc;
     } else {
         if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
@@ -907,7 +909,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
 // Host-side tables shared by the chunk-parallel dynamic kernels (K4 rolling, K3s RLS scan): validity prefix
 // (cnt / vidx), per-group warm-up constants of solve_rolling_ols (ls.rs:881-900) and the chunk list; uploaded to
 // scratch slot 4, the per-chunk totals live in slot 5 (`slots` doubles per chunk).
-static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a) {
+static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a, int64_t min_chunk) {
     int rc;
     const int64_t N = b->n_rows;
     std::vector<uint8_t> hvalid;
@@ -922,7 +924,10 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
             hv = b->valid;
         }
     }
-    const int64_t chunk_len = std::min<int64_t>(512, std::max<int64_t>(64, N / 16384));
+    // one lane (or wave / workgroup) per chunk: short chunks = more parallelism in the walk, longer chunk list for the scan
+    // (measured on the 1M-row sequence: 64-row chunks = 15 625 lanes beat 32- and 16-row chunks -- the per-lane row loads are
+    // uncoalesced and more concurrent lanes cost more in the memory system than they win in parallelism)
+    const int64_t chunk_len = std::min<int64_t>(512, std::max<int64_t>(min_chunk, N / 16384));
     auto &cc = ctx->chunk_cache;
     if (!hv && cc.tab && cc.tab == ctx->scratch[4].ptr && cc.offs_sum == ctx->offs_sum && cc.n_groups == b->n_groups &&
         cc.n_rows == N && cc.mp == mp && cc.chunk_len == (int32_t)chunk_len) {      // same frame as the last call
@@ -1020,12 +1025,14 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
 
     K4Args a;
     std::memset(&a, 0, sizeof(a));
-    if ((rc = build_chunk_tables(ctx, b, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a))) return rc;
+    if ((rc = build_chunk_tables(ctx, b, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, 64))) return rc;
     a.y = st.y; a.valid = st.valid;
     if ((rc = upload_column_table(ctx, st, k, &a))) return rc;
     a.coef = st.coef; a.pred = st.pred;
     a.window = w; a.alpha = p->alpha > 0.0 ? p->alpha : 0.0;                                    // ls.rs:865, 924-926
     a.k = k; a.drop_mode = drop ? 1 : 0;
+    if (wide) { a.tot_cs = k * k + k; a.tot_qs = 1; }
+    else { a.tot_cs = 1; a.tot_qs = a.n_chunks; }
     if ((rc = xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a)))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, k, o, st);
 }

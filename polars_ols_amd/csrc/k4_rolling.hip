@@ -52,9 +52,9 @@ struct K4Ctx {
     __device__ __forceinline__ void prefix(int64_t i, double (&P)[K4N<K>::N], double sign) const {
         if (i < 0) return;
         const int64_t c = i / a.chunk_len;
-        const double *pb = a.totals + (size_t)(first_chunk + c) * K4N<K>::N;
+        const double *pb = a.totals + (size_t)(first_chunk + c) * a.tot_cs;
 #pragma unroll
-        for (int q = 0; q < K4N<K>::N; ++q) P[q] += sign * pb[q];
+        for (int q = 0; q < K4N<K>::N; ++q) P[q] += sign * pb[(size_t)q * a.tot_qs];
         for (int64_t j = c * a.chunk_len; j <= i; ++j)
             if (valid(j)) add_row(P, j, sign);
     }
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(64) k4_totals_kernel(const K4Args a) {
     for (int64_t i = ch.t0 - G.start; i < ch.t1 - G.start; ++i)
         if (cx.valid(i)) cx.add_row(S, i, 1.0);
 #pragma unroll
-    for (int q = 0; q < K4N<K>::N; ++q) a.totals[(size_t)c * K4N<K>::N + q] = S[q];
+    for (int q = 0; q < K4N<K>::N; ++q) a.totals[(size_t)c * a.tot_cs + (size_t)q * a.tot_qs] = S[q];
 }
 
 // ------------------------------------------------------------------ pass 2: exclusive (decayed) prefix over a group's chunks
@@ -129,10 +129,13 @@ __global__ void __launch_bounds__(64) k4_totals_kernel(const K4Args a) {
 //   mode 0  plain prefix (rolling): d = 1, carry-in 0
 //   mode 1  RLS, packed upper-triangular state of K features (K4N<K>): d = the chunk's decay (slot nacc), carry-in = prior
 //   mode 2  RLS, full K x K state (k4w_wide.hip)
-__global__ void __launch_bounds__(64) chunk_scan_kernel(const K4Args a, const int nacc, const int mode) {
+// SW waves per (group, component): a long sequence's chunk list is cut into SW segments; every wave first composes its own segment
+// (no writes), the segment aggregates meet in LDS, and each wave then re-walks its segment from its carry-in writing the prefixes.
+template <int SW>
+__global__ void __launch_bounds__(64 * SW) chunk_scan_kernel(const K4Args a, const int nacc, const int mode) {
+    __shared__ double segD[SW], segT[SW];
     const int64_t g = blockIdx.x;
-    const int q = blockIdx.y, lane = threadIdx.x;
-    const int stride = nacc + (mode ? 1 : 0);
+    const int q = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const K4Group G = a.groups[g];
     const int64_t n = G.end - G.start;
     const int64_t nch = (n + a.chunk_len - 1) / a.chunk_len;
@@ -149,24 +152,23 @@ __global__ void __launch_bounds__(64) chunk_scan_kernel(const K4Args a, const in
             carry = a.mean0 ? a.mean0[q - nx] / a.p0 : 0.0;
         }
     }
-    double *base = a.totals + (size_t)G.first_chunk * stride;
+    double *base = a.totals + (size_t)G.first_chunk * a.tot_cs + (size_t)q * a.tot_qs;      // this component's chunk series
+    const double *dbase = a.totals + (size_t)G.first_chunk * a.tot_cs + (size_t)nacc * a.tot_qs;   // the decay series (mode != 0)
+    const int64_t cs = a.tot_cs;
     constexpr int CPL = 4;                                   // consecutive chunks per lane -> 256 chunks per step
+    constexpr int TILE = 64 * CPL;
+    const int64_t seg = SW == 1 ? nch : ((nch + SW - 1) / SW + TILE - 1) / TILE * TILE;   // segment length, a multiple of the tile
+    const int64_t c_lo = min(nch, (int64_t)wv * seg), c_hi = min(nch, c_lo + seg);
     auto fetch = [&](int64_t c, double (&d)[CPL], double (&t)[CPL]) {
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            const bool in = c + i < nch;
-            t[i] = in ? base[(size_t)(c + i) * stride + q] : 0.0;
-            d[i] = (in && mode) ? base[(size_t)(c + i) * stride + nacc] : 1.0;
+            const bool in = c + i < c_hi;
+            t[i] = in ? base[(size_t)(c + i) * cs] : 0.0;
+            d[i] = (in && mode) ? dbase[(size_t)(c + i) * cs] : 1.0;
         }
     };
-    double dn[CPL], tn[CPL];
-    fetch((int64_t)lane * CPL, dn, tn);
-    for (int64_t c0 = 0; c0 < nch; c0 += 64 * CPL) {
-        double d[CPL], t[CPL];
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) { d[i] = dn[i]; t[i] = tn[i]; }
-        fetch(c0 + 64 * CPL + (int64_t)lane * CPL, dn, tn);  // prefetch the next tile
-        double D = d[0], T = t[0];                           // this lane's chunks composed
+    auto lane_compose = [&](const double (&d)[CPL], const double (&t)[CPL], double &D, double &T) {
+        D = d[0]; T = t[0];
 #pragma unroll
         for (int i = 1; i < CPL; ++i) { T = d[i] * T + t[i]; D = D * d[i]; }
 #pragma unroll
@@ -174,12 +176,39 @@ __global__ void __launch_bounds__(64) chunk_scan_kernel(const K4Args a, const in
             const double dp = __shfl_up(D, off), tp = __shfl_up(T, off);
             if (lane >= off) { T = D * tp + T; D = D * dp; }
         }
+    };
+    if constexpr (SW > 1) {
+        // ---- phase 1: this wave's segment as ONE element (Dseg, Tseg)
+        double Dseg = 1.0, Tseg = 0.0, dn[CPL], tn[CPL];
+        fetch(c_lo + (int64_t)lane * CPL, dn, tn);
+        for (int64_t c0 = c_lo; c0 < c_hi; c0 += TILE) {
+            double d[CPL], t[CPL], D, T;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) { d[i] = dn[i]; t[i] = tn[i]; }
+            fetch(c0 + TILE + (int64_t)lane * CPL, dn, tn);
+            lane_compose(d, t, D, T);
+            const double Dt = __shfl(D, 63), Tt = __shfl(T, 63);
+            Tseg = Dt * Tseg + Tt; Dseg = Dseg * Dt;
+        }
+        if (lane == 0) { segD[wv] = Dseg; segT[wv] = Tseg; }
+        __syncthreads();
+        for (int sgm = 0; sgm < wv; ++sgm) carry = segD[sgm] * carry + segT[sgm];
+    }
+    // ---- phase 2: exclusive prefixes of the segment from its carry-in
+    double dn[CPL], tn[CPL];
+    fetch(c_lo + (int64_t)lane * CPL, dn, tn);
+    for (int64_t c0 = c_lo; c0 < c_hi; c0 += TILE) {
+        double d[CPL], t[CPL], D, T;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { d[i] = dn[i]; t[i] = tn[i]; }
+        fetch(c0 + TILE + (int64_t)lane * CPL, dn, tn);      // prefetch the next tile
+        lane_compose(d, t, D, T);
         const double dex = __shfl_up(D, 1), tex = __shfl_up(T, 1);
         double run = (lane == 0) ? carry : dex * carry + tex;   // state entering this lane's first chunk
         const int64_t c = c0 + (int64_t)lane * CPL;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
-            if (c + i < nch) base[(size_t)(c + i) * stride + q] = run;
+            if (c + i < c_hi) base[(size_t)(c + i) * cs] = run;
             run = d[i] * run + t[i];
         }
         carry = __shfl(D, 63) * carry + __shfl(T, 63);
@@ -187,7 +216,10 @@ __global__ void __launch_bounds__(64) chunk_scan_kernel(const K4Args a, const in
 }
 
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode) {
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3((unsigned)a.n_groups, (unsigned)nacc), dim3(64), 0, ctx->stream, a, nacc, mode);
+    // few long sequences: 8 waves per (group, component); many short ones: one wave each
+    const bool lng = a.n_chunks / std::max<int64_t>(1, a.n_groups) > 2048;
+    if (lng) hipLaunchKernelGGL(chunk_scan_kernel<8>, dim3((unsigned)a.n_groups, (unsigned)nacc), dim3(512), 0, ctx->stream, a, nacc, mode);
+    else hipLaunchKernelGGL(chunk_scan_kernel<1>, dim3((unsigned)a.n_groups, (unsigned)nacc), dim3(64), 0, ctx->stream, a, nacc, mode);
 }
 
 // ------------------------------------------------------------------ pass 3: the walk
@@ -341,8 +373,8 @@ __global__ void __launch_bounds__(64) k3s_totals_kernel(const K4Args a) {
             decay *= a.ff;
         }
 #pragma unroll
-    for (int q = 0; q < N; ++q) a.totals[(size_t)c * (N + 1) + q] = S[q];
-    a.totals[(size_t)c * (N + 1) + N] = decay;
+    for (int q = 0; q < N; ++q) a.totals[(size_t)c * a.tot_cs + (size_t)q * a.tot_qs] = S[q];
+    a.totals[(size_t)c * a.tot_cs + (size_t)N * a.tot_qs] = decay;
 }
 
 template <typename T, int K>
@@ -358,17 +390,24 @@ __global__ void __launch_bounds__(64) k3s_walk_kernel(const K4Args a) {
     T *pred = static_cast<T *>(a.pred);
     double S[N], last[K];
 #pragma unroll
-    for (int q = 0; q < N; ++q) S[q] = a.totals[(size_t)c * (N + 1) + q];
+    for (int q = 0; q < N; ++q) S[q] = a.totals[(size_t)c * a.tot_cs + (size_t)q * a.tot_qs];
     const bool seen = rel0 > 0 && cx.cnt(rel0 - 1) > 0;           // has any valid row updated the state yet?
     if (seen) solve_state<K>(S, 0.0, last);
     else {
 #pragma unroll
         for (int j = 0; j < K; ++j) last[j] = a.mean0 ? a.mean0[j] : 0.0;   // coef = initial_state_mean or zeros (:519-522)
     }
+    double xn[K], yn;                                             // the next row, loaded while the current one is being solved
+    bool vn = rel0 < rel1 && cx.valid(rel0);
+    if (rel0 < rel1) cx.load_row(rel0, xn, yn);
     for (int64_t i = rel0; i < rel1; ++i) {
         double x[K], y;
-        cx.load_row(i, x, y);
-        if (cx.valid(i)) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[j] = xn[j];
+        y = yn;
+        const bool v_i = vn;
+        if (i + 1 < rel1) { cx.load_row(i + 1, xn, yn); vn = cx.valid(i + 1); }
+        if (v_i) {
 #pragma unroll
             for (int q = 0; q < N; ++q) S[q] *= a.ff;
 #pragma unroll

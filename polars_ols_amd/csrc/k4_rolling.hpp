@@ -33,7 +33,11 @@ struct K4Args {
     const K4Group *groups;
     int64_t n_chunks;
     int32_t n_groups;
-    double *totals;              // n_chunks x NACC: per-chunk sums, then exclusive prefix at the chunk start
+    double *totals;              // per-chunk sums, then exclusive prefix at the chunk start: element (chunk c, component q) lives at
+                                 // totals[c * tot_cs + q * tot_qs].  Lane-per-chunk kernels use component-major storage
+                                 // (tot_cs = 1, tot_qs = n_chunks: consecutive lanes = consecutive chunks = consecutive words, for the
+                                 // totals writes, the scan and the walk alike); wave / workgroup-per-chunk kernels chunk-major.
+    int64_t tot_cs, tot_qs;
     void *coef;                  // n_rows x k or nullptr
     void *pred;                  // n_rows or nullptr
     int64_t window;
