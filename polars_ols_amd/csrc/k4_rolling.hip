@@ -37,6 +37,24 @@ struct K4Ctx {
         for (int j = 0; j < K; ++j) x[j] = (double)static_cast<const T *>(a.x[j])[s + i];
         y = (double)static_cast<const T *>(a.y)[s + i];
     }
+    // PF consecutive rows at once: every load is issued before the first use, so the (L2) latency is paid once per window, not per row
+    template <int PF>
+    __device__ __forceinline__ void load_window(int64_t i0, int64_t i_end, double (&x)[PF][K], double (&y)[PF], bool (&v)[PF]) const {
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int64_t i = (i0 + r < i_end) ? i0 + r : i_end - 1;    // clamp: the tail re-reads the last row (unused)
+            load_row(i, x[r], y[r]);
+            v[r] = (i0 + r < i_end) && valid(i);
+        }
+    }
+    __device__ __forceinline__ void add_loaded(double (&S)[K4N<K>::N], const double (&x)[K], double y, double sign) const {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+#pragma unroll
+            for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] += sign * (x[p] * x[q]);
+            S[K4N<K>::NX + p] += sign * (x[p] * y);
+        }
+    }
     // S += sign * [x x' (packed upper), x y]   (outer_product :600-607, update :714-723)
     __device__ __forceinline__ void add_row(double (&S)[K4N<K>::N], int64_t i, double sign) const {
         double x[K], y;
@@ -116,8 +134,16 @@ __global__ void __launch_bounds__(64) k4_totals_kernel(const K4Args a) {
     double S[K4N<K>::N];
 #pragma unroll
     for (int q = 0; q < K4N<K>::N; ++q) S[q] = 0.0;
-    for (int64_t i = ch.t0 - G.start; i < ch.t1 - G.start; ++i)
-        if (cx.valid(i)) cx.add_row(S, i, 1.0);
+    constexpr int PF = 4;
+    const int64_t i_end = ch.t1 - G.start;
+    for (int64_t i0 = ch.t0 - G.start; i0 < i_end; i0 += PF) {
+        double xw[PF][K], yw[PF];
+        bool vw[PF];
+        cx.template load_window<PF>(i0, i_end, xw, yw, vw);
+#pragma unroll
+        for (int r = 0; r < PF; ++r)
+            if (vw[r]) cx.add_loaded(S, xw[r], yw[r], 1.0);
+    }
 #pragma unroll
     for (int q = 0; q < K4N<K>::N; ++q) a.totals[(size_t)c * a.tot_cs + (size_t)q * a.tot_qs] = S[q];
 }
@@ -365,13 +391,21 @@ __global__ void __launch_bounds__(64) k3s_totals_kernel(const K4Args a) {
     double S[N], decay = 1.0;
 #pragma unroll
     for (int q = 0; q < N; ++q) S[q] = 0.0;
-    for (int64_t i = ch.t0 - G.start; i < ch.t1 - G.start; ++i)
-        if (cx.valid(i)) {
+    constexpr int PF = 4;
+    const int64_t i_end = ch.t1 - G.start;
+    for (int64_t i0 = ch.t0 - G.start; i0 < i_end; i0 += PF) {
+        double xw[PF][K], yw[PF];
+        bool vw[PF];
+        cx.template load_window<PF>(i0, i_end, xw, yw, vw);
 #pragma unroll
-            for (int q = 0; q < N; ++q) S[q] *= a.ff;
-            cx.add_row(S, i, 1.0);
-            decay *= a.ff;
-        }
+        for (int r = 0; r < PF; ++r)
+            if (vw[r]) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) S[q] *= a.ff;
+                cx.add_loaded(S, xw[r], yw[r], 1.0);
+                decay *= a.ff;
+            }
+    }
 #pragma unroll
     for (int q = 0; q < N; ++q) a.totals[(size_t)c * a.tot_cs + (size_t)q * a.tot_qs] = S[q];
     a.totals[(size_t)c * a.tot_cs + (size_t)N * a.tot_qs] = decay;
@@ -397,37 +431,32 @@ __global__ void __launch_bounds__(64) k3s_walk_kernel(const K4Args a) {
 #pragma unroll
         for (int j = 0; j < K; ++j) last[j] = a.mean0 ? a.mean0[j] : 0.0;   // coef = initial_state_mean or zeros (:519-522)
     }
-    double xn[K], yn;                                             // the next row, loaded while the current one is being solved
-    bool vn = rel0 < rel1 && cx.valid(rel0);
-    if (rel0 < rel1) cx.load_row(rel0, xn, yn);
-    for (int64_t i = rel0; i < rel1; ++i) {
-        double x[K], y;
+    constexpr int PF = 2;                                         // rows loaded ahead of the solves (the per-row solve is the long part)
+    for (int64_t i0 = rel0; i0 < rel1; i0 += PF) {
+        double xw[PF][K], yw[PF];
+        bool vw[PF];
+        cx.template load_window<PF>(i0, rel1, xw, yw, vw);
 #pragma unroll
-        for (int j = 0; j < K; ++j) x[j] = xn[j];
-        y = yn;
-        const bool v_i = vn;
-        if (i + 1 < rel1) { cx.load_row(i + 1, xn, yn); vn = cx.valid(i + 1); }
-        if (v_i) {
+        for (int r = 0; r < PF; ++r) {
+            const int64_t i = i0 + r;
+            if (i >= rel1) break;
+            if (vw[r]) {
 #pragma unroll
-            for (int q = 0; q < N; ++q) S[q] *= a.ff;
-#pragma unroll
-            for (int p = 0; p < K; ++p) {
-#pragma unroll
-                for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] += x[p] * x[q];
-                S[K4N<K>::NX + p] += x[p] * y;
+                for (int q = 0; q < N; ++q) S[q] *= a.ff;
+                cx.add_loaded(S, xw[r], yw[r], 1.0);
+                solve_state<K>(S, 0.0, last);
             }
-            solve_state<K>(S, 0.0, last);
-        }
-        const int64_t row = G.start + i;
-        if (coef) {
+            const int64_t row = G.start + i;
+            if (coef) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) coef[row * K + j] = (T)last[j];
-        }
-        if (pred) {
-            double p = 0.0;
+                for (int j = 0; j < K; ++j) coef[row * K + j] = (T)last[j];
+            }
+            if (pred) {
+                double p = 0.0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) p += x[j] * last[j];
-            pred[row] = (T)p;
+                for (int j = 0; j < K; ++j) p += xw[r][j] * last[j];
+                pred[row] = (T)p;
+            }
         }
     }
 }
