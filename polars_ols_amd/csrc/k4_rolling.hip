@@ -123,6 +123,52 @@ __device__ __forceinline__ void solve_state(const double (&S)[K4N<K>::N], double
     }
 }
 
+// P = A^-1 (packed upper, like S) from the packed SPD matrix in S[0 .. NX): Cholesky A = L L', M = L^-1 by forward substitution,
+// P = M' M.  false on a non-positive pivot.  Used once per chunk by the RLS walk, which then propagates P with the reference's
+// own rank-1 update (ls.rs:531-540) instead of re-factoring the information matrix on every row.
+template <int K>
+__device__ __forceinline__ bool spd_inverse_packed(const double (&S)[K4N<K>::N], double (&P)[K * (K + 1) / 2]) {
+    double L[K][K], M[K][K];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        double d = S[tri_index<K>(j, j)];
+#pragma unroll
+        for (int p = 0; p < j; ++p) d = fma(-L[j][p], L[j][p], d);
+        ok = ok && (d > 0.0);
+        const double ri = 1.0 / sqrt(d);
+        L[j][j] = ri;                                           // 1 / L_jj
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            double acc = S[tri_index<K>(j, i)];
+#pragma unroll
+            for (int p = 0; p < j; ++p) acc = fma(-L[i][p], L[j][p], acc);
+            L[i][j] = acc * ri;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) {                               // column c of M = L^-1
+        M[c][c] = L[c][c];
+#pragma unroll
+        for (int i = c + 1; i < K; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p = c; p < i; ++p) acc = fma(L[i][p], M[p][c], acc);
+            M[i][c] = -acc * L[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = i; j < K; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p = j; p < K; ++p) acc = fma(M[p][i], M[p][j], acc);   // (M'M)_ij, M lower triangular
+            P[tri_index<K>(i, j)] = acc;
+        }
+    return ok;
+}
+
 // ------------------------------------------------------------------ pass 1: per-chunk totals
 template <typename T, int K>
 __global__ void __launch_bounds__(64) k4_totals_kernel(const K4Args a) {
@@ -431,7 +477,63 @@ __global__ void __launch_bounds__(64) k3s_walk_kernel(const K4Args a) {
 #pragma unroll
         for (int j = 0; j < K; ++j) last[j] = a.mean0 ? a.mean0[j] : 0.0;   // coef = initial_state_mean or zeros (:519-522)
     }
-    constexpr int PF = 2;                                         // rows loaded ahead of the solves (the per-row solve is the long part)
+    constexpr int PF = 2;                                         // rows loaded ahead of the updates
+    // Inside the chunk the covariance form is propagated, exactly the reference's update: P = A^-1 once per chunk, then
+    //   v = P x,  r = 1 + x'v / ff,  gain = v / (r ff),  beta += gain (y - x'beta),  P = (P - v gain') / ff     (ls.rs:531-540)
+    // -- about 110 f64 operations per row at K = 6 against ~250 for re-factoring A.  (A holds the prior, so it is SPD; should
+    // the factorisation fail anyway, the per-row solve below is the fallback.)
+    constexpr int NXP = K * (K + 1) / 2;
+    double P[NXP];
+    if (spd_inverse_packed<K>(S, P)) {
+        if (!seen) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) last[j] = a.mean0 ? a.mean0[j] : 0.0;
+        }
+        const double ff = a.ff, iff = 1.0 / a.ff;
+        for (int64_t i0 = rel0; i0 < rel1; i0 += PF) {
+            double xw[PF][K], yw[PF];
+            bool vw[PF];
+            cx.template load_window<PF>(i0, rel1, xw, yw, vw);
+#pragma unroll
+            for (int r = 0; r < PF; ++r) {
+                const int64_t i = i0 + r;
+                if (i >= rel1) break;
+                if (vw[r]) {
+                    double v[K], xv = 0.0, xb = 0.0;
+#pragma unroll
+                    for (int p = 0; p < K; ++p) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < K; ++q) acc = fma(P[p <= q ? tri_index<K>(p, q) : tri_index<K>(q, p)], xw[r][q], acc);
+                        v[p] = acc;
+                        xv = fma(xw[r][p], acc, xv);
+                        xb = fma(xw[r][p], last[p], xb);
+                    }
+                    const double rr = 1.0 + xv * iff;
+                    const double gs = 1.0 / (rr * ff);                  // gain = v * gs
+                    const double err = yw[r] - xb;
+#pragma unroll
+                    for (int p = 0; p < K; ++p) last[p] = fma(v[p] * gs, err, last[p]);
+#pragma unroll
+                    for (int p = 0; p < K; ++p)
+#pragma unroll
+                        for (int q = p; q < K; ++q) P[tri_index<K>(p, q)] = (P[tri_index<K>(p, q)] - v[p] * (v[q] * gs)) * iff;
+                }
+                const int64_t row = G.start + i;
+                if (coef) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) coef[row * K + j] = (T)last[j];
+                }
+                if (pred) {
+                    double p = 0.0;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) p += xw[r][j] * last[j];
+                    pred[row] = (T)p;
+                }
+            }
+        }
+        return;
+    }
     for (int64_t i0 = rel0; i0 < rel1; i0 += PF) {
         double xw[PF][K], yw[PF];
         bool vw[PF];
