@@ -43,3 +43,20 @@ def test_bench_collective_path_on_one_gpu():
     d = _run({"POLS_BENCH_FORCE_COLLECTIVE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"}, "--no-cpu-baseline")
     assert d["config"]["collective"].startswith("all_gather(coefficient tables of 8 steps)"), d["config"]
     assert d["value"] > 1e7
+
+
+def test_native_cabi_harness(tmp_path):
+    """examples/cabi_bench.cpp: the hot path from native code through the C-ABI alone (no Python / PyTorch in the process); the
+    harness checks group 0 against a double-precision normal-equation solve itself and exits non-zero on a mismatch."""
+    import shutil
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "cabi_bench"
+    lib = ROOT / "polars_ols_amd"
+    subprocess.run([hipcc, "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "examples" / "cabi_bench.cpp"), f"-L{lib}", "-lpols_mi355x",
+                    f"-Wl,-rpath,{lib}"], check=True, timeout=600)
+    out = subprocess.run([str(exe), "2000", "1000", "8", "20"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["kernel"].startswith("k1_gram_chol_f32_k8") and d["groups_not_ok"] == 0
+    assert d["max_abs_dcoef_group0"] < 1e-4 and d["max_abs_dpred_group0"] < 1e-4 and d["regressions_per_s"] > 1e6
