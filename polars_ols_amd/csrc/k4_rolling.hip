@@ -363,33 +363,41 @@ __global__ void __launch_bounds__(64) k4_walk_kernel(const K4Args a) {
     }
     (void)have_last;
 
-    for (int64_t i = rel0; i < rel1; ++i) {
-        const bool v = cx.valid(i);
-        if (v) cx.add_row(S, i, 1.0);                      // update XTX w/ latest data point
-        if (i >= mpv && (v || !drop)) {                    // subtract what left the window
-            const int64_t no = old_of(i);
-            if (drop) {
-                if (no != prev_old && no >= 0) cx.add_row(S, no, -1.0);
-            } else if (no >= j_min && no >= 0 && cx.valid(no)) {
-                cx.add_row(S, no, -1.0);
+    constexpr int PF = 2;                                  // entering rows are loaded a window ahead of the solves
+    for (int64_t i0 = rel0; i0 < rel1; i0 += PF) {
+        double xw[PF][K], yw[PF];
+        bool vw[PF];
+        cx.template load_window<PF>(i0, rel1, xw, yw, vw);
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int64_t i = i0 + r;
+            if (i >= rel1) break;
+            const bool v = vw[r];
+            if (v) cx.add_loaded(S, xw[r], yw[r], 1.0);        // update XTX w/ latest data point
+            if (i >= mpv && (v || !drop)) {                    // subtract what left the window
+                const int64_t no = old_of(i);
+                if (drop) {
+                    if (no != prev_old && no >= 0) cx.add_row(S, no, -1.0);
+                } else if (no >= j_min && no >= 0 && cx.valid(no)) {
+                    cx.add_row(S, no, -1.0);
+                }
+                prev_old = no;
             }
-            prev_old = no;
-        }
-        if (i >= mpv - 1) {
-            const bool do_solve = (i == mpv - 1) || (drop ? v : gate(i));
-            if (do_solve) solve_state<K>(S, a.alpha, last);
-        }
-        const int64_t row = G.start + i;
-        if (coef) {
+            if (i >= mpv - 1) {
+                const bool do_solve = (i == mpv - 1) || (drop ? v : gate(i));
+                if (do_solve) solve_state<K>(S, a.alpha, last);
+            }
+            const int64_t row = G.start + i;
+            if (coef) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) coef[row * K + j] = (T)last[j];
-        }
-        if (pred) {                                        // (features * coefficients).sum_axis(1)  (ex.rs:184)
-            double x[K], y, p = 0.0;
-            cx.load_row(i, x, y);
+                for (int j = 0; j < K; ++j) coef[row * K + j] = (T)last[j];
+            }
+            if (pred) {                                        // (features * coefficients).sum_axis(1)  (ex.rs:184)
+                double p = 0.0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) p += x[j] * last[j];
-            pred[row] = (T)p;
+                for (int j = 0; j < K; ++j) p += xw[r][j] * last[j];
+                pred[row] = (T)p;
+            }
         }
     }
 }
