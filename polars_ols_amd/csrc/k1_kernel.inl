@@ -31,20 +31,30 @@ template <> __device__ __forceinline__ void vset<float>(float4 &v, int i, float 
 }
 template <> __device__ __forceinline__ void vset<double>(double2 &v, int i, double x) { if (i == 0) v.x = x; else v.y = x; }
 
-template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false>
+// the 16-byte loads of one chunk, nothing else: the FAST kernels issue these for ALL resident chunks back to back
+template <typename T, int KT, bool HAS_W>
+__device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Chunk<T, KT, HAS_W> &c) {
+    using V = typename Vec16<T>::type;
+    const int ku = a.k_user;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        if (j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
+        else c.x[j] = vsplat<T>(T(1));
+    }
+    c.y = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
+    if constexpr (HAS_W) c.sw = *reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0);
+}
+
+template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false, bool LOADED = false>
 __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_t s, int64_t e, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
     const int ku = a.k_user;
-    if (FAST || (row0 >= s && row0 + VEC <= e)) {
+    if (LOADED) {
+        // the vectors are already in c (load_chunk_raw): only the null policy and the sqrt(w) scaling below are left
+    } else if (FAST || (row0 >= s && row0 + VEC <= e)) {
         // whole chunk inside the group: 16-byte loads, all issued before first use
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            if (j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
-            else c.x[j] = vsplat<T>(T(1));
-        }
-        c.y = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
-        if constexpr (HAS_W) c.sw = *reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0);
+        load_chunk_raw<T, KT, HAS_W>(a, row0, c);
     } else {
         // ragged head / tail of a group: guarded scalar loads, rows outside [s, e) contribute zeros
 #pragma unroll
@@ -365,13 +375,34 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
         }
     }
     Chunk<T, KT, HAS_W> res[RC];                             // register-resident rows of this lane
+    if constexpr (FAST) {
+        // every 16-byte load of every resident chunk is issued before the first use: RC x (KT + 1) requests in flight per lane
+        // instead of KT + 1 (a lane without a chunk re-reads chunk 0, which exists whenever the group has rows)
+        if (nch > 0) {
 #pragma unroll
-    for (int rc = 0; rc < RC; ++rc) {
-        const int64_t c = (int64_t)rc * TEAM + tid;
-        if (c < nch) {
-            load_chunk<T, KT, HAS_W, FAST, NULLS>(a, base + c * VEC, s, e, res[rc]);
-            if (rc == RC - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
-            if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W, NULLS>(acc, res[rc]);
+            for (int rc = 0; rc < RC; ++rc) {
+                const int64_t c = (int64_t)rc * TEAM + tid;
+                load_chunk_raw<T, KT, HAS_W>(a, base + (c < nch ? c : 0) * VEC, res[rc]);
+            }
+        }
+        if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+            const int64_t c = (int64_t)rc * TEAM + tid;
+            if (c < nch) {
+                load_chunk<T, KT, HAS_W, FAST, NULLS, true>(a, base + c * VEC, s, e, res[rc]);
+                if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W, NULLS>(acc, res[rc]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+            const int64_t c = (int64_t)rc * TEAM + tid;
+            if (c < nch) {
+                load_chunk<T, KT, HAS_W, FAST, NULLS>(a, base + c * VEC, s, e, res[rc]);
+                if (rc == RC - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
+                if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W, NULLS>(acc, res[rc]);
+            }
         }
     }
     K1_STAMP(2);
