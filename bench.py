@@ -166,7 +166,12 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend_note = None
+        try:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        except Exception as exc:  # RCCL unavailable: keep the ranks in step over gloo (barrier + max), skip the coefficient gather
+            backend_note = f"nccl init failed ({type(exc).__name__}); gloo used for barriers only"
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_mod
 
     from polars_ols_amd import Engine
@@ -177,8 +182,9 @@ def main() -> None:
     eng.set_stream(eng_stream.cuda_stream)
     plan, units, unit_name, alg_bytes, text, dtype_name, coef, scaling = build_workload(args.config, eng, rank, world, args.dtype)
     torch.cuda.synchronize()                                                           # inputs are resident
-    gather = dist is not None and coef is not None
-    collective_note = "none"
+    on_gloo = dist is not None and dist.get_backend() == "gloo"
+    gather = dist is not None and coef is not None and not on_gloo
+    collective_note = "none" if not on_gloo else backend_note
     RING = 8
     if gather:
         # Reassembling the coefficient column is the one exchange step of the path (north_star).  Fewer, larger collectives:
@@ -253,7 +259,7 @@ def main() -> None:
     eng.timing(False)
 
     if dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if on_gloo else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
