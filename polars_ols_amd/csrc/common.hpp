@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -85,6 +86,14 @@ bool timing_pair(pols_ctx *ctx, hipEvent_t *start, hipEvent_t *stop);
 int report_timeline(pols_ctx *ctx, const unsigned long long *d_dbg, int64_t n_groups, int n_stamps, const char *name);
 
 inline size_t dtype_size(int dtype) { return dtype == POLS_F32 ? 4 : 8; }
+
+// hipFuncSetAttribute is per device: a kernel's launcher keeps one of these masks and applies the attribute once per device.  Two
+// host threads racing on the same device both apply it (idempotent) before either publishes the bit.
+struct OncePerDevice {
+    std::atomic<uint64_t> mask{0};
+    bool needed(int device) const { return (mask.load(std::memory_order_acquire) & (1ull << (device & 63))) == 0; }
+    void done(int device) { mask.fetch_or(1ull << (device & 63), std::memory_order_release); }
+};
 
 // ---------------------------------------------------------------- device helpers
 #if defined(__HIPCC__)

@@ -326,11 +326,11 @@ static int k1m_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     const int ncols = a.k_user + 1 + (HAS_W ? 1 : 0);
     const int rs = k1m_row_stride<T>(max_rows);
     const size_t lds = k1m_lds_bytes<T>(rs, ncols);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_once;
+    if (attr_once.needed(ctx->device)) {
         POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k1m_kernel<T, KT, HAS_W>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.done(ctx->device);
     }
     char name[96];
     std::snprintf(name, sizeof(name), "k1m_gram_mfma_%s_k%d%s_lds%zu", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", lds);

@@ -290,12 +290,12 @@ template <typename T>
 static int kx_launch_t(pols_ctx *ctx, const K4Args &a, bool rls) {
     const size_t lds = sizeof(double) * XCtx<T>::lds_doubles(a.k);
     const int ns = a.k * a.k + a.k;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_once;
+    if (attr_once.needed(ctx->device)) {
         const void *fns[4] = {reinterpret_cast<const void *>(&kx_totals_kernel<T, false>), reinterpret_cast<const void *>(&kx_totals_kernel<T, true>),
                               reinterpret_cast<const void *>(&kx_rolling_walk_kernel<T>), reinterpret_cast<const void *>(&kx_rls_walk_kernel<T>)};
         for (const void *f : fns) POLS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr_set = true;
+        attr_once.done(ctx->device);
     }
     timing_begin(ctx);
     if (rls) {

@@ -230,11 +230,11 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     const int npair = NT * (NT + 1) / 2;
     const int tile_elems = std::max(ncols * rs, npair * 4 * 256 + (YV ? 64 : 0));
     const size_t lds = sizeof(T) * ((size_t)tile_elems + 2 * K1M_CONST_ELEMS);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_once;
+    if (attr_once.needed(ctx->device)) {
         POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<T, NT, HAS_W, YV>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
+        attr_once.done(ctx->device);
     }
     char name[96];
     std::snprintf(name, sizeof(name), "k5_gram_stream_%s_nt%d%s%s_k%d", sizeof(T) == 4 ? "f32" : "f64", NT, HAS_W ? "_w" : "", YV ? "_yv" : "", a.kt);

@@ -259,11 +259,11 @@ static int wide_chol_launch_t(pols_ctx *ctx, const WideArgs &a) {
     const int NZ = a.kt + wide_m(a);
     if (NZ <= 128) {
         const size_t lds = sizeof(double) * (size_t)NZ * (NZ | 1);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static OncePerDevice attr_once;
+        if (attr_once.needed(ctx->device)) {
             POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_chol_kernel<T, 1024, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-            attr_set = true;
+            attr_once.done(ctx->device);
         }
         hipLaunchKernelGGL((wide_chol_kernel<T, 1024, true>), dim3((unsigned)a.n_groups), dim3(1024), lds, ctx->stream, a);
     } else {
@@ -569,11 +569,11 @@ int wide_stats_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const WideSta
     if (a.kt > K8_STATS_KMAX) return fail(POLS_ERR_UNSUPPORTED, "statistics: %d features (incl. intercept) > %d", a.kt, K8_STATS_KMAX);
     if (a.n_groups == 0) return POLS_OK;
     const size_t lds = sizeof(double) * ((size_t)a.kt * (a.kt | 1) + 4 * (size_t)a.kt);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OncePerDevice attr_once;
+    if (attr_once.needed(ctx->device)) {
         POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        attr_set = true;
+        attr_once.done(ctx->device);
     }
     if (dtype == POLS_F32) hipLaunchKernelGGL(wide_stats_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
     else hipLaunchKernelGGL(wide_stats_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
