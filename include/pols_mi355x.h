@@ -217,6 +217,39 @@ typedef struct pols_stats_out {
 int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *out,
                                   const pols_stats_out *stats);
 
+/* ---- group-key ingestion: `.over(key)` / `group_by(key)` ------------------------------------------------------------
+ * The reference's plugin functions never see a key column: Polars partitions the frame on the host and calls them once per
+ * group (README.md:19, README.md:57 and :91 `.over("group")`, tests/test_ols.py:110, :384, :860).  The batched entries
+ * above take the whole frame with rows sorted by group, so the host needs that partitioning; these entries do it where the
+ * columns live.  A pols_layout holds, for one key column of one frame: the stable permutation `order` (sorted position i
+ * holds frame row order[i]; rows of a group keep their frame order, which the recursive / rolling models depend on), the
+ * groups' offsets and keys (ascending).  Keys are 64-bit integers (the host hashes / dictionary-encodes anything else, as
+ * Polars does for its own group-by).  Fewer than 2^32 rows. */
+typedef struct pols_layout pols_layout;
+/* keys: n_rows int64 where `mem` says.  Synchronises the context's stream (the group count comes back to the host). */
+int pols_layout_create(pols_ctx *ctx, const int64_t *keys, int64_t n_rows, int mem, pols_layout **out);
+void pols_layout_destroy(pols_layout *layout);
+int64_t pols_layout_n_rows(const pols_layout *layout);
+int64_t pols_layout_n_groups(const pols_layout *layout);
+/* 1 when the key column was already non-decreasing: take / untake are copies, callers may skip them and pass the frame's
+ * own columns. */
+int pols_layout_is_identity(const pols_layout *layout);
+/* host arrays owned by the layout: n_groups + 1 offsets (pass as pols_batch.group_offsets) and n_groups keys */
+const int64_t *pols_layout_group_offsets(const pols_layout *layout);
+const int64_t *pols_layout_group_keys(const pols_layout *layout);
+/* frame order -> group order: dst[c][i] = src[c][order[i]] for n_cols columns whose elements are element_bytes wide: 1
+ * (validity bytes), 4 or 8 (f32 / f64 columns), or any other multiple of 4 for row-major tables moved a row at a time
+ * (an [n_rows, k] coefficient table is one "column" of k * sizeof(T)-byte elements).  src != dst.  `mem` says where BOTH tables' columns live (host columns are staged through the device). */
+int pols_layout_take(pols_ctx *ctx, pols_layout *layout, int element_bytes, const void *const *src_cols, void *const *dst_cols,
+                     int32_t n_cols, int mem);
+/* group order -> frame order: dst[c][order[i]] = src[c][i]  (predictions / residuals / per-row coefficients back onto the
+ * frame, like the Series `.over` returns). */
+int pols_layout_untake(pols_ctx *ctx, pols_layout *layout, int element_bytes, const void *const *src_cols, void *const *dst_cols,
+                       int32_t n_cols, int mem);
+/* out[r] = index (into group_keys / a coefficient table) of the group frame row r belongs to: what broadcasts a per-group
+ * coefficient struct over the frame (mode="coefficients" under `.over`, README.md:91). */
+int pols_layout_row_groups(pols_ctx *ctx, pols_layout *layout, int64_t *out, int mem);
+
 #ifdef __cplusplus
 }
 #endif

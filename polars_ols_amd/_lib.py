@@ -77,6 +77,8 @@ EXPORTS = [
     "pols_ols_params_default", "pols_rls_params_default", "pols_rolling_params_default",
     "pols_least_squares", "pols_recursive_least_squares", "pols_rolling_least_squares", "pols_predict",
     "pols_least_squares_statistics", "pols_multi_target_least_squares",
+    "pols_layout_create", "pols_layout_destroy", "pols_layout_n_rows", "pols_layout_n_groups", "pols_layout_is_identity",
+    "pols_layout_group_offsets", "pols_layout_group_keys", "pols_layout_take", "pols_layout_untake", "pols_layout_row_groups",
 ]
 
 
@@ -124,6 +126,17 @@ def lib() -> C.CDLL:
                                                       C.POINTER(OlsParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
         L.pols_least_squares_statistics.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(OlsParams), C.POINTER(Out),
                                                     C.POINTER(StatsOut)]
+        L.pols_layout_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.pols_layout_destroy.argtypes = [C.c_void_p]
+        L.pols_layout_destroy.restype = None
+        for fn in (L.pols_layout_n_rows, L.pols_layout_n_groups):
+            fn.argtypes, fn.restype = [C.c_void_p], C.c_int64
+        L.pols_layout_is_identity.argtypes = [C.c_void_p]
+        for fn in (L.pols_layout_group_offsets, L.pols_layout_group_keys):
+            fn.argtypes, fn.restype = [C.c_void_p], C.POINTER(C.c_int64)
+        for fn in (L.pols_layout_take, L.pols_layout_untake):
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int]
+        L.pols_layout_row_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 

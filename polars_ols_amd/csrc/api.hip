@@ -141,7 +141,6 @@ struct Staged {
     int32_t *status = nullptr;
 };
 
-static size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 static int stage_inputs(pols_ctx *ctx, const pols_batch *b, int64_t coef_rows, int kt, const pols_out *o, Staged *st) {
     const size_t sz = dtype_size(b->dtype);

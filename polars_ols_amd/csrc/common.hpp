@@ -47,7 +47,7 @@ struct pols_ctx {
     int num_cus = 0;
     // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] timeline stamps,
     // [4] chunk / group tables, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean
-    pols::Scratch scratch[9];   // [8] fused fix-up tags
+    pols::Scratch scratch[10];  // [8] fused fix-up tags, [9] group-key ingestion (K9)
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
     int timing_tick = 0;
@@ -86,6 +86,7 @@ bool timing_pair(pols_ctx *ctx, hipEvent_t *start, hipEvent_t *stop);
 int report_timeline(pols_ctx *ctx, const unsigned long long *d_dbg, int64_t n_groups, int n_stamps, const char *name);
 
 inline size_t dtype_size(int dtype) { return dtype == POLS_F32 ? 4 : 8; }
+inline size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // hipFuncSetAttribute is per device: a kernel's launcher keeps one of these masks and applies the attribute once per device.  Two
 // host threads racing on the same device both apply it (idempotent) before either publishes the bit.

@@ -268,6 +268,95 @@ class Engine:
         return self.plan_rolling_least_squares(y, x_cols, offsets, **kwargs).run()
 
 
+class Layout:
+    """`.over(key)` ingestion (``pols_layout_*``): the stable permutation that sorts a frame's rows by an int64 key column,
+    the groups' offsets / keys, and the column movers either way.  Device keys stay on the device."""
+
+    def __init__(self, eng: Engine, keys):
+        self._eng, self._lib = eng, eng._lib
+        dev = _is_torch(keys)
+        if dev:
+            if not keys.is_cuda:
+                raise ValueError("torch keys must live on the GPU; pass a numpy array for host keys")
+            if eng._follow_torch:
+                L.check(self._lib.pols_set_stream(eng._h, C.c_void_p(torch.cuda.current_stream(keys.device).cuda_stream)))
+            k = keys.to(torch.int64).contiguous()
+            ptr, n = k.data_ptr(), k.numel()
+        else:
+            k = np.ascontiguousarray(keys, dtype=np.int64)
+            ptr, n = k.ctypes.data, k.shape[0]
+        self.on_device, self._like = dev, (keys if dev else None)
+        h = C.c_void_p()
+        L.check(self._lib.pols_layout_create(eng._h, C.c_void_p(ptr), n, L.POLS_MEM_DEVICE if dev else L.POLS_MEM_HOST, C.byref(h)))
+        self._h = h
+        self.n_rows, self.n_groups = n, int(self._lib.pols_layout_n_groups(h))
+        self.identity = bool(self._lib.pols_layout_is_identity(h))
+        self.offsets = np.ctypeslib.as_array(self._lib.pols_layout_group_offsets(h), shape=(self.n_groups + 1,)).copy()
+        self.keys = (np.ctypeslib.as_array(self._lib.pols_layout_group_keys(h), shape=(self.n_groups,)).copy()
+                     if self.n_groups else np.zeros(0, dtype=np.int64))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pols_layout_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _move(self, fn, cols: Sequence):
+        cols = list(cols)
+        if self.identity or not cols:
+            return cols
+        dev = _is_torch(cols[0])
+        if dev and self._eng._follow_torch:
+            L.check(self._lib.pols_set_stream(self._eng._h, C.c_void_p(torch.cuda.current_stream(cols[0].device).cuda_stream)))
+        out, by_size = [None] * len(cols), {}
+        src = [c.contiguous() if dev else np.ascontiguousarray(c) for c in cols]
+        for i, c in enumerate(src):
+            if c.shape[0] != self.n_rows:
+                raise ValueError("all input series passed must be of equal length")
+            width = c.element_size() if dev else c.itemsize
+            if c.ndim > 1:                                       # an [n, k] table moves a row (k elements) at a time
+                width *= int(np.prod(c.shape[1:]))
+            if width != 1 and width % 4:
+                raise TypeError(f"unsupported element size {width}")
+            by_size.setdefault(width, []).append(i)
+        for width, idxs in by_size.items():
+            dst = [torch.empty_like(src[i]) if dev else np.empty_like(src[i]) for i in idxs]
+            sp = (C.c_void_p * len(idxs))(*[Engine._ptr(src[i]) for i in idxs])
+            dp = (C.c_void_p * len(idxs))(*[Engine._ptr(d) for d in dst])
+            L.check(fn(self._eng._h, self._h, width, sp, dp, len(idxs), L.POLS_MEM_DEVICE if dev else L.POLS_MEM_HOST))
+            for i, d in zip(idxs, dst):
+                out[i] = d
+        return out
+
+    def take(self, cols: Sequence):
+        """frame order -> group order (``None`` entries pass through)."""
+        idx = [i for i, c in enumerate(cols) if c is not None]
+        moved = self._move(self._lib.pols_layout_take, [cols[i] for i in idx])
+        out = list(cols)
+        for i, m in zip(idx, moved):
+            out[i] = m
+        return out
+
+    def untake(self, cols: Sequence):
+        """group order -> frame order."""
+        return self._move(self._lib.pols_layout_untake, cols)
+
+    def row_groups(self):
+        """group index of every frame row (int64, where the keys live)."""
+        if self.on_device:
+            out = torch.empty(self.n_rows, dtype=torch.int64, device=self._like.device)
+        else:
+            out = np.empty(self.n_rows, dtype=np.int64)
+        L.check(self._lib.pols_layout_row_groups(self._eng._h, self._h, C.c_void_p(Engine._ptr(out) or 0),
+                                                 L.POLS_MEM_DEVICE if self.on_device else L.POLS_MEM_HOST))
+        return out
+
+
 class Plan:
     """A marshalled call: ctypes structs + references that keep every borrowed buffer alive."""
 

@@ -25,7 +25,7 @@ from typing import Any, Dict, List, Literal, Optional, Sequence, Set, Tuple, Uni
 import numpy as np
 
 from ._lib import PolsPanic
-from .engine import Engine, _is_torch, default_engine
+from .engine import Engine, Layout, _is_torch, default_engine
 
 try:
     import torch
@@ -219,32 +219,53 @@ def _to_index(idx, like):
     return idx
 
 
-def _group_layout(key) -> Tuple[Optional[np.ndarray], np.ndarray, np.ndarray, np.ndarray]:
-    """(order or None if already contiguous-sorted, offsets, keys, group id per sorted row) for an ``over`` key.
+class _Groups:
+    """What ``.over(key)`` needs (README.md:19, :57): the groups' offsets / keys and the row movers between frame order and the
+    group-sorted order the batched entries take.  Built by the engine's native ingestion (``pols_layout_*``: stable radix sort,
+    run lengths, gather kernels) wherever the key column lives; non-integer keys are dictionary-encoded first, like Polars'
+    own group-by.  ``key is None`` is the whole-frame fit: one group, nothing moves."""
 
-    A CUDA key column never leaves the GPU: stable sort, run-length segmentation and the inverse scatter are device
-    operations; only the per-group row counts (one int per group) come back, because ``group_offsets`` is a host array of
-    the C-ABI -- what Polars' ``.over`` does on the host, done where the columns live."""
-    if _is_torch(key) and key.is_cuda:
-        order = None
-        k = key
-        if k.numel() > 1 and not bool((k[1:] >= k[:-1]).all()):
-            k, order = torch.sort(key, stable=True)
-        keys, counts = torch.unique_consecutive(k, return_counts=True)
-        offsets = np.zeros(keys.numel() + 1, dtype=np.int64)
-        np.cumsum(counts.cpu().numpy(), out=offsets[1:])
-        gid = torch.repeat_interleave(torch.arange(keys.numel(), device=key.device), counts)
-        return order, offsets, keys.cpu().numpy(), gid
-    k = key.cpu().numpy() if _is_torch(key) else np.asarray(key)
-    order = None
-    if not bool(np.all(k[1:] >= k[:-1])):
-        order = np.argsort(k, kind="stable")
-        k = k[order]
-    keys, counts = np.unique(k, return_counts=True)
-    offsets = np.zeros(len(keys) + 1, dtype=np.int64)
-    np.cumsum(counts, out=offsets[1:])
-    gid = np.repeat(np.arange(len(keys)), counts)
-    return order, offsets, keys, gid
+    def __init__(self, eng: Engine, key, n: int):
+        self._lay, self.n = None, n
+        if key is None:
+            self.offsets, self.keys, self.identity = np.array([0, n], dtype=np.int64), None, True
+            return
+        codes, uniq = key, None
+        if _is_torch(key) and not key.is_cuda:
+            key = codes = key.numpy()
+        if _is_torch(key):
+            if key.dtype.is_floating_point or key.dtype.is_complex:
+                uniq, codes = torch.unique(key, return_inverse=True)
+                uniq = uniq.cpu().numpy()
+        else:
+            codes = np.asarray(key)
+            if codes.dtype.kind not in "iub":
+                uniq, codes = np.unique(codes, return_inverse=True)
+        self._lay = Layout(eng, codes)
+        self.offsets, self.identity = self._lay.offsets, self._lay.identity
+        self.keys = self._lay.keys if uniq is None else uniq[self._lay.keys]
+
+    def take(self, cols):
+        """frame order -> group order; ``None`` entries pass through."""
+        return list(cols) if self.identity else self._lay.take(cols)
+
+    def untake(self, a):
+        """group order -> frame order (a column or an [n, k] table)."""
+        return a if self.identity else self._lay.untake([a])[0]
+
+    def gid_frame(self, like):
+        """index of its group for every frame row, where ``like`` lives."""
+        if self._lay is None:
+            g = np.zeros(self.n, dtype=np.int64)
+        else:
+            g = self._lay.row_groups()
+        return _to_index(g, like)
+
+    def gid_sorted(self, like):
+        """the same for every group-sorted row."""
+        if self._lay is not None and self._lay.on_device and _is_torch(like):
+            return self._lay.take([self._lay.row_groups()])[0]
+        return _to_index(np.repeat(np.arange(len(self.offsets) - 1, dtype=np.int64), np.diff(self.offsets)), like)
 
 
 def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], sample_weights, add_intercept: bool):
@@ -306,16 +327,10 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
     n = y.shape[0]
     eng = eng or default_engine(y.device.index or 0 if _is_torch(y) else 0)
     # ---- group layout (.over)
-    if over is not None:
-        key = frame[over] if isinstance(over, str) else over
-        order, offs, keys, gid = _group_layout(key)
-    else:
-        order, offs, keys, gid = None, np.array([0, n], dtype=np.int64), None, np.zeros(n, dtype=np.int64)
-    if order is not None:
-        oi = _to_index(order, y)
-        y_s, xs_s, w_s = _take(y, oi), [_take(c, oi) for c in xs], (None if w is None else _take(w, oi))
-    else:
-        y_s, xs_s, w_s = y, xs, w
+    grp = _Groups(eng, None if over is None else (frame[over] if isinstance(over, str) else over), n)
+    offs, keys = grp.offsets, grp.keys
+    moved = grp.take([y, w] + list(xs))
+    y_s, w_s, xs_s = moved[0], moved[1], moved[2:]
 
     policy = kw.null_policy
     if mode != "statistics":
@@ -343,7 +358,7 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
                 valid = valid & ~_isnan(c)
         vnp = valid.cpu().numpy() if _is_torch(valid) else valid
         vidx = np.nonzero(vnp)[0]
-        gid_h = gid.cpu().numpy() if _is_torch(gid) else gid
+        gid_h = grp.gid_sorted(vnp)
         full_counts = np.bincount(gid_h[vnp], minlength=len(offs) - 1)        # valid rows per group
         offs_v = np.concatenate([[0], np.cumsum(full_counts)]).astype(np.int64)
         vi = _to_index(vidx, y_f)
@@ -354,20 +369,8 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
         return "statistics", _static_statistics(eng, y_v, xs_v, offs_v, None, False, kw, names, keys)
     if mode == "coefficients":
         # without .over the single struct broadcasts to every row of the frame, like a Polars scalar (gid is all zeros)
-        return "coefficients", Coefficients(names, coef, keys, _to_index(_unsort(gid, order), coef))
-    if order is not None:                                      # scatter back to the frame's row order
-        pred = _unsort(pred, order)
-    return target.output_name, pred
-
-
-def _unsort(a, order):
-    """sorted position i holds the frame's row order[i]: out[order[i]] = a[i] (numpy or torch, index on a's side)."""
-    if order is None:
-        return a
-    idx = _to_index(order, a)
-    out = torch.empty_like(a) if _is_torch(a) else np.empty_like(a)
-    out[idx] = a
-    return out
+        return "coefficients", Coefficients(names, coef, keys, grp.gid_frame(coef))
+    return target.output_name, grp.untake(pred)                # back to the frame's row order
 
 
 def _apply_dynamic(frame: Frame, over, eng: Optional[Engine], target: Expr, features: Sequence[Expr], sample_weights,
@@ -395,17 +398,10 @@ def _apply_dynamic(frame: Frame, over, eng: Optional[Engine], target: Expr, feat
     else:
         valid = None
     y0, xs0 = _nan_to_zero(y_fit), [_nan_to_zero(c) for c in xs]
-    if over is not None:
-        key = frame[over] if isinstance(over, str) else over
-        order, offs, keys, gid = _group_layout(key)
-    else:
-        order, offs = None, np.array([0, n], dtype=np.int64)
-    if order is not None:
-        oi = _to_index(order, y0)
-        y0, xs0 = _take(y0, oi), [_take(c, oi) for c in xs0]
-        valid_s = None if valid is None else _take(valid, oi)
-    else:
-        valid_s = valid
+    grp = _Groups(eng, None if over is None else (frame[over] if isinstance(over, str) else over), n)
+    offs = grp.offsets
+    moved = grp.take([y0, valid] + list(xs0))
+    y0, valid_s, xs0 = moved[0], moved[1], moved[2:]
     want = ("coef",) if mode == "coefficients" else ("pred",)
     vbytes = None if valid_s is None else (valid_s.to(torch.uint8) if _is_torch(valid_s) else valid_s.astype(np.uint8))
     if kind == "rls":
@@ -418,8 +414,7 @@ def _apply_dynamic(frame: Frame, over, eng: Optional[Engine], target: Expr, feat
                                         min_periods=kw.min_periods, use_woodbury=kw.use_woodbury, alpha=kw.alpha,
                                         null_policy=policy)
     res = out["coef"] if mode == "coefficients" else out["pred"]
-    if order is not None:
-        res = _unsort(res, order)
+    res = grp.untake(res)
     if mode == "coefficients":
         return "coefficients", Coefficients(names, res)
     pred = res
@@ -470,16 +465,10 @@ def compute_multi_target_least_squares(targets, *features, sample_weights=None, 
         ys = [y0] + [t._column(frame) for t in ts[1:]]
         n = y0.shape[0]
         eng = eng or default_engine(y0.device.index or 0 if _is_torch(y0) else 0)
-        if over is not None:
-            key = frame[over] if isinstance(over, str) else over
-            order, offs, keys, gid = _group_layout(key)
-        else:
-            order, offs, gid = None, np.array([0, n], dtype=np.int64), np.zeros(n, dtype=np.int64)
-        if order is not None:
-            oi = _to_index(order, y0)
-            ys_s, xs_s, w_s = [_take(y, oi) for y in ys], [_take(c, oi) for c in xs], (None if w is None else _take(w, oi))
-        else:
-            ys_s, xs_s, w_s = ys, xs, w
+        grp = _Groups(eng, None if over is None else (frame[over] if isinstance(over, str) else over), n)
+        offs = grp.offsets
+        moved = grp.take([w] + list(ys) + list(xs))
+        w_s, ys_s, xs_s = moved[0], moved[1:1 + len(ys)], moved[1 + len(ys):]
         policy = kw.null_policy
         solver = dict(alpha=kw.alpha, solve_method=kw.solve_method, rcond=kw.rcond)
         if policy in ("ignore", "zero"):
@@ -502,15 +491,14 @@ def compute_multi_target_least_squares(targets, *features, sample_weights=None, 
                 for c in xs_f:
                     valid = valid & ~_isnan(c)
             vnp = valid.cpu().numpy() if _is_torch(valid) else valid
-            gid_h = gid.cpu().numpy() if _is_torch(gid) else gid
-            counts = np.bincount(gid_h[vnp], minlength=len(offs) - 1)
+            counts = np.bincount(grp.gid_sorted(vnp)[vnp], minlength=len(offs) - 1)
             offs_v = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
             vi = _to_index(np.nonzero(vnp)[0], ys_f[0])
             xs_v = [_take(c, vi) for c in xs_f]
             if policy == "drop_y_zero_x":
                 xs_v = [_nan_to_zero(c) for c in xs_v]
             coef = eng.multi_target_least_squares([_take(y, vi) for y in ys_f], xs_v, offs_v, want=("coef",), **solver)["coef"]
-            gi = _to_index(gid, ys_f[0])
+            gi = grp.gid_sorted(ys_f[0])
             xs_z = [_nan_to_zero(c) for c in xs_f]
             preds = []
             for t in range(len(ts)):
@@ -524,7 +512,7 @@ def compute_multi_target_least_squares(targets, *features, sample_weights=None, 
         out = {}
         for t, y_s, pr in zip(ts, ys_s, preds):
             val = pr if mode == "predictions" else y_s - pr
-            out[t.output_name] = _unsort(val, order)
+            out[t.output_name] = grp.untake(val)
         return "predictions", out
 
     return Expr(ts[0]._name, fn=run)

@@ -103,6 +103,10 @@ def test_header_is_plain_c_and_links(tmp_path):
         "    pols_ols_params p; pols_rls_params r; pols_rolling_params w; pols_stats_out s = {0};\n"
         "    pols_ols_params_default(&p); pols_rls_params_default(&r); pols_rolling_params_default(&w);\n"
         "    (void)s;\n"
+        "    pols_layout *lay = 0;   /* NULL handles are answered, not dereferenced */\n"
+        "    if (pols_layout_n_rows(lay) != -1 || pols_layout_n_groups(lay) != -1 || pols_layout_group_offsets(lay)) return 1;\n"
+        "    if (pols_layout_create(0, 0, 0, POLS_MEM_HOST, &lay) != POLS_ERR_INVALID) return 2;\n"
+        "    pols_layout_destroy(lay);\n"
         '    printf("%s %d %g %lld %d\\n", pols_version(), p.null_policy == POLS_NULL_IGNORE, r.initial_state_covariance,\n'
         "           (long long)w.window_size, POLS_MAX_FEATURES_STATIC);\n"
         "    return 0;\n}\n")
