@@ -203,13 +203,14 @@ def main() -> None:
         collective_note = f"all_gather(coefficient tables of {RING} steps) on a side stream, overlapped"
     step_no = [0]
 
-    def exchange(r):
+    def exchange(r, used=RING):
         nonlocal collective_note, gather
         try:
             produced[r].record(eng_stream)
             side.wait_event(produced[r])
             with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered, rings[r])
+                # a partly filled ring (the flush after the last step) moves only the slots that were written
+                dist.all_gather_into_tensor(gathered[: world * used], rings[r][:used])
                 consumed[r].record(side)
         except Exception as exc:  # keep the benchmark alive: report the failure instead of dying
             gather = False
@@ -233,7 +234,7 @@ def main() -> None:
         """gather the partly filled ring so that every timed step's coefficients have been reassembled"""
         i = step_no[0]
         if gather and i % RING != 0:
-            exchange((i // RING) & 1)
+            exchange((i // RING) & 1, i % RING)
         step_no[0] = ((i + RING - 1) // RING) * RING
 
     for _ in range(args.warmup):

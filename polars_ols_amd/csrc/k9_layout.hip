@@ -9,15 +9,18 @@
 //   rocprim        stable LSD radix_sort_pairs (the device-wide sort is the library's, like a plain GEMM would be hipBLASLt's;
 //                  stability keeps each group's rows in frame order, which RLS / rolling depend on), run_length_encode for
 //                  the group keys / sizes, exclusive_scan for the offsets;
-//   take / untake  frame order -> group order for up to 32 columns per launch, a column at a time (coalesced writes), and
-//                  group order -> frame order through the inverse permutation (built once, so the way back is a gather with
-//                  coalesced writes too, not a scatter of 4-byte read-modify-writes);
+//   take / untake  frame order <-> group order for up to 32 columns per launch, a column at a time, always WALKING THE FRAME in
+//                  XCD-sized slabs (see slab_block): the group-sorted side is then touched at one slowly advancing front per
+//                  group, which an XCD's L2 turns into whole-line traffic -- a scatter on the way in, a gather through the
+//                  inverse permutation on the way back; with more groups than an L2 holds fronts for, a plain gather;
 //   row_groups     the group id of every frame row (what broadcasts a per-group coefficient struct back over the frame).
 // All of it is HBM-bound integer / byte work: no LDS tricks, just coalesced streams and as few passes as the key range allows.
 #include "common.hpp"
 
 #include <rocprim/rocprim.hpp>
 
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 struct pols_layout {
@@ -92,14 +95,25 @@ struct TakeArgs {
     int n_cols;
 };
 
-// blockIdx.y = column, one thread = VEC consecutive output rows of it.  Workgroups are dispatched x-fastest, so the launch walks
-// the frame one column at a time: a 10M-row f32 column is 40 MB and stays in the 256 MB Infinity Cache while its rows are
-// gathered at random, where a thread that gathered the same row of EVERY column kept 9 x 40 MB in play and went to HBM for a
-// 64-byte line per 4-byte element (1.65 ms -> see DESIGN.md for 10M rows x 9 columns).  The index is re-read per column (L2 /
-// Infinity Cache hits, 4 coalesced bytes per row); the VEC gathers of a thread are all issued before its one VEC-wide store.
-template <typename E, int VEC>
+// The hardware deals workgroups round-robin over the 8 XCDs, each with its own 4 MB L2.  A kernel that walks the frame in row
+// order touches, per group, one slowly advancing "front" of the group-sorted column (a group's rows keep their frame order),
+// i.e. n_groups cache lines at a time -- L2-sized for thousands of groups, but only if a line's 16-32 visits come from ONE XCD.
+// So the frame is cut into 8 contiguous slabs, one per XCD: logical block = (b % 8) * (blocks / 8) + b / 8  (gridDim.x is a
+// multiple of 8; logical blocks past the end return).
+__device__ __forceinline__ int64_t slab_block(bool slab) {
+    if (!slab) return blockIdx.x;
+    const unsigned per = gridDim.x >> 3;
+    return (int64_t)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+
+// blockIdx.y = column, one thread = VEC consecutive output rows of it: dst[i] = src[index[i]].  Workgroups are dispatched
+// x-fastest, so a launch walks the frame one column at a time (a 10M-row f32 column is 40 MB and stays in the 256 MB Infinity
+// Cache while it is gathered); the index is re-read per column (4 coalesced bytes per row); the VEC gathers of a thread are
+// all issued before its one VEC-wide non-temporal store.  SLAB: the walk is in frame order (untake through the inverse
+// permutation) -- see slab_block().
+template <typename E, int VEC, bool SLAB>
 __global__ void __launch_bounds__(256) take_kernel(const TakeArgs a) {
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int64_t i0 = (slab_block(SLAB) * 256 + threadIdx.x) * VEC;
     if (i0 >= a.n) return;
     const E *s = static_cast<const E *>(a.src[blockIdx.y]);
     E *d = static_cast<E *>(a.dst[blockIdx.y]) + i0;
@@ -121,6 +135,35 @@ __global__ void __launch_bounds__(256) take_kernel(const TakeArgs a) {
     }
 }
 
+// The same permutation as a scatter that walks the FRAME: dst[index[j]] = src[j] with index = the inverse permutation.  Reads are
+// perfectly coalesced; the writes land on the groups' fronts and are merged into whole lines by the XCD's L2 before they leave it
+// (slab_block).  Gathering in group order instead reads every row of a group from a different line of the frame column with no
+// reuse inside any L2: 128 bytes over the fabric per 4-byte element (measured 0.17 ms per 10M-row f32 column against 0.0x ms here).
+// Only worth it while the fronts fit an L2 (move_columns decides).
+template <typename E, int VEC>
+__global__ void __launch_bounds__(256) put_kernel(const TakeArgs a) {
+    const int64_t j0 = (slab_block(true) * 256 + threadIdx.x) * VEC;
+    if (j0 >= a.n) return;
+    const E *s = static_cast<const E *>(a.src[blockIdx.y]) + j0;
+    E *d = static_cast<E *>(a.dst[blockIdx.y]);
+    typedef E VecE __attribute__((ext_vector_type(VEC)));
+    typedef uint32_t VecI __attribute__((ext_vector_type(VEC)));
+    if (j0 + VEC <= a.n) {
+        const VecI idx = *reinterpret_cast<const VecI *>(a.index + j0);
+        VecE vv;
+        if ((reinterpret_cast<uintptr_t>(s) & (sizeof(VecE) - 1)) == 0) {
+            vv = __builtin_nontemporal_load(reinterpret_cast<const VecE *>(s));
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) vv[v] = s[v];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) d[idx[v]] = vv[v];
+    } else {
+        for (int v = 0; j0 + v < a.n; ++v) d[a.index[j0 + v]] = s[v];
+    }
+}
+
 // Rows of `words` 4-byte words (a per-row coefficient table [n, k]): one thread per word, coalesced along the row both ways.
 __global__ void __launch_bounds__(256) take_rows_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
                                                         const uint32_t *__restrict__ index, int64_t n, int words) {
@@ -131,7 +174,9 @@ __global__ void __launch_bounds__(256) take_rows_kernel(const uint32_t *__restri
     __builtin_nontemporal_store(src[(int64_t)index[i] * words + w], dst + t);
 }
 
-// out[order[i]] = the group holding sorted position i (binary search over the offsets: log2(G) L2-resident probes per row)
+// out[order[i]] = the group holding sorted position i.  Walking the SORTED side keeps the binary search over the offsets coherent
+// (a wave's 64 positions sit in one or two groups, so its log2(G) probes are broadcasts); the 8-byte writes scatter over the
+// frame.  Walking the frame instead (coalesced writes, divergent probes) measured 0.185 ms against 0.135 ms on 10M rows.
 __global__ void __launch_bounds__(256) row_groups_kernel(const int64_t *__restrict__ offs, int64_t n_groups, const uint32_t *__restrict__ order,
                                                          int64_t n, int64_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -241,9 +286,19 @@ static int move_columns(pols_ctx *ctx, pols_layout *L, int dtype_bytes, const vo
         if (mem == POLS_MEM_HOST) POLS_HIP(hipStreamSynchronize(ctx->stream));
         return POLS_OK;
     }
-    int rc = to_group_order ? POLS_OK : ensure_inverse(ctx, L);
+    // frame -> group order: scatter along the frame while the groups' fronts (one line per group, two while a front crosses a line)
+    // fit an XCD's 4 MB L2 next to the streams passing through it; gather in group order otherwise.  POLS_K9_TAKE=gather|scatter
+    // overrides (profiling).
+    bool scatter = to_group_order && dtype_bytes <= 8 && L->n_groups <= 12288;
+    if (const char *e = getenv("POLS_K9_TAKE")) {
+        if (!strcmp(e, "gather")) scatter = false;
+        if (!strcmp(e, "scatter")) scatter = to_group_order && dtype_bytes <= 8;
+    }
+    int rc = (to_group_order && !scatter) ? POLS_OK : ensure_inverse(ctx, L);
     if (rc) return rc;
-    const uint32_t *index = to_group_order ? L->order : L->inverse;
+    const uint32_t *index = (to_group_order && !scatter) ? L->order : L->inverse;
+    const bool slab = !to_group_order || scatter;
+    const unsigned nblk = slab ? ((blocks_for(n, 1024) + 7u) & ~7u) : blocks_for(n, 1024);
     for (int c0 = 0; c0 < n_cols; c0 += TAKE_COLS) {
         const int nc = std::min(TAKE_COLS, n_cols - c0);
         TakeArgs a;
@@ -268,10 +323,21 @@ static int move_columns(pols_ctx *ctx, pols_layout *L, int dtype_bytes, const vo
                 a.dst[c] = dst[c0 + c];
             }
         }
-        if (dtype_bytes == 4) hipLaunchKernelGGL((take_kernel<uint32_t, 4>), dim3(blocks_for(n, 1024), nc), dim3(256), 0, ctx->stream, a);
-        else if (dtype_bytes == 8) hipLaunchKernelGGL((take_kernel<uint64_t, 4>), dim3(blocks_for(n, 1024), nc), dim3(256), 0, ctx->stream, a);
-        else if (dtype_bytes == 1) hipLaunchKernelGGL((take_kernel<uint8_t, 4>), dim3(blocks_for(n, 1024), nc), dim3(256), 0, ctx->stream, a);
-        else {
+        const dim3 grid(nblk, nc);
+        if (scatter) {
+            if (dtype_bytes == 4) hipLaunchKernelGGL((put_kernel<uint32_t, 4>), grid, dim3(256), 0, ctx->stream, a);
+            else if (dtype_bytes == 8) hipLaunchKernelGGL((put_kernel<uint64_t, 4>), grid, dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((put_kernel<uint8_t, 4>), grid, dim3(256), 0, ctx->stream, a);
+        } else if (dtype_bytes == 4) {
+            if (slab) hipLaunchKernelGGL((take_kernel<uint32_t, 4, true>), grid, dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((take_kernel<uint32_t, 4, false>), grid, dim3(256), 0, ctx->stream, a);
+        } else if (dtype_bytes == 8) {
+            if (slab) hipLaunchKernelGGL((take_kernel<uint64_t, 4, true>), grid, dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((take_kernel<uint64_t, 4, false>), grid, dim3(256), 0, ctx->stream, a);
+        } else if (dtype_bytes == 1) {
+            if (slab) hipLaunchKernelGGL((take_kernel<uint8_t, 4, true>), grid, dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((take_kernel<uint8_t, 4, false>), grid, dim3(256), 0, ctx->stream, a);
+        } else {
             const int words = dtype_bytes / 4;
             if (n * words >= ((int64_t)1 << 40)) return fail(POLS_ERR_UNSUPPORTED, "group_layout: table too large");
             for (int c = 0; c < nc; ++c)

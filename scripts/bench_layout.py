@@ -1,6 +1,7 @@
 """Times K9 group-key ingestion on BASELINE configs[1]'s frame in arrival order (10 000 interleaved groups x 1 000 rows, 8 f32
 features + target): layout build, columns into group order, predictions back to frame order -- next to the solve itself."""
 import json
+import os
 import sys
 import time
 
@@ -32,6 +33,12 @@ def main():
     res["layout_create_ms"] = timed(lambda: Layout(eng, key).close())
     lay = Layout(eng, key)
     res["take_9_f32_columns_ms"] = timed(lambda: lay.take(cols))
+    for mode in ("gather", "scatter"):
+        os.environ["POLS_K9_TAKE"] = mode
+        res[f"take_9_f32_columns_{mode}_ms"] = timed(lambda: lay.take(cols))
+    os.environ.pop("POLS_K9_TAKE")
+    cols64 = [c.double() for c in cols[:3]]
+    res["take_3_f64_columns_ms"] = timed(lambda: lay.take(cols64))
     moved = lay.take(cols)
     res["untake_1_f32_column_ms"] = timed(lambda: lay.untake([moved[0]]))
     res["row_groups_ms"] = timed(lambda: lay.row_groups())
