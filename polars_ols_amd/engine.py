@@ -59,6 +59,12 @@ class Engine:
         else:
             L.check(self._lib.pols_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def use_private_stream(self):
+        """Every launch (torch inputs included) goes to the context's own non-blocking stream: what a host thread of its
+        own wants.  The caller orders it against the producers / consumers of the buffers (``synchronize()``)."""
+        self._follow_torch = False
+        L.check(self._lib.pols_use_private_stream(self._h))
+
     def use_torch_stream(self):
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -266,3 +266,57 @@ def test_full_size_cfg3_properties(eng):
     ref = orc.batched_least_squares(sl(y), [sl(c) for c in cols], np.arange(len(pick) + 1) * rows, weights=sl(w), alpha=1.0, l1_ratio=0.0)
     assert np.allclose(out["coef"].cpu().numpy()[pick], ref["coef"], rtol=1e-6, atol=1e-6)
     assert np.allclose(sl(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
+
+
+def test_contexts_are_independent_across_host_threads():
+    """The boundary's threading contract (Polars calls plugins from its rayon pool): one context per host thread,
+    concurrent calls, private streams and scratch.  Four threads run different models on different shapes at once; every
+    result must be bit-identical to the same call made alone."""
+    import threading
+
+    import torch
+
+    from polars_ols_amd import Engine
+
+    def make(seed, G, n, k, dt):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        cols = [torch.randn(G * n, device="cuda", dtype=dt, generator=g) for _ in range(k)]
+        y = sum(cols) + 0.1 * torch.randn(G * n, device="cuda", dtype=dt, generator=g)
+        return y, cols, np.arange(G + 1, dtype=np.int64) * n
+
+    jobs = [
+        (make(1, 3000, 500, 8, torch.float32), dict(want=("coef", "pred"))),
+        (make(2, 2000, 700, 6, torch.float64), dict(want=("coef", "pred"), alpha=1.0)),
+        (make(3, 500, 1500, 16, torch.float64), dict(want=("coef", "pred"), alpha=0.001, l1_ratio=0.5)),
+        (make(4, 40, 2000, 40, torch.float64), dict(want=("coef", "pred"))),                 # wide path (device column tables)
+    ]
+    torch.cuda.synchronize()
+
+    def run(job, reps, sink):
+        (y, cols, offs), kw = job
+        e = Engine(0)
+        e.use_private_stream()                  # threads must not serialise on torch's default stream
+        try:
+            for _ in range(reps):
+                out = e.least_squares(y, cols, offs, **kw)
+                e.synchronize()
+            sink.append({k: v.clone() for k, v in out.items() if k in ("coef", "pred")})
+        except Exception as exc:  # surfaced in the main thread
+            sink.append(exc)
+        finally:
+            e.close()
+
+    alone = []
+    for job in jobs:
+        run(job, 1, alone)
+    together = [[] for _ in jobs]
+    threads = [threading.Thread(target=run, args=(job, 20, sink)) for job, sink in zip(jobs, together)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, sink in zip(alone, together):
+        assert not isinstance(a, Exception), a
+        assert len(sink) == 1 and not isinstance(sink[0], Exception), sink
+        for key in ("coef", "pred"):
+            assert torch.equal(a[key], sink[0][key]) or torch.allclose(a[key], sink[0][key], rtol=0, atol=0, equal_nan=True), key
