@@ -105,8 +105,11 @@ __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_
     }
 }
 
-template <typename T, int KT, bool HAS_W, bool NULLS = false>
-__device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2], const Chunk<T, KT, HAS_W> &c) {
+// MODE 0: plain (the y'y slot holds y'y).  MODE 1: null policy, masked -- rows outside the fit contribute nothing, a null target
+// that stays (policy ZERO) counts as 0, the (unused) y'y slot counts the rows left in the fit.  MODE 2: null policy, but the caller
+// has established that every row of the chunk is in the fit with a non-null target: plain products, same row count.
+template <typename T, int KT, bool HAS_W, int MODE>
+__device__ __forceinline__ void gram_rows(T (&acc)[(KT + 1) * (KT + 2) / 2], const Chunk<T, KT, HAS_W> &c) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
 #pragma unroll
@@ -114,19 +117,35 @@ __device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2
         T ys = vget<T>(c.y, v);
         if constexpr (HAS_W) ys *= vget<T>(c.sw, v);
         T mv = T(1);
-        if constexpr (NULLS) {                       // rows outside the fit contribute nothing; a null target that stays (ZERO) is 0
+        if constexpr (MODE == 1) {
             mv = ((c.m >> v) & 1u) ? T(1) : T(0);
             ys = (ys == ys) ? ys * mv : T(0);
         }
 #pragma unroll
         for (int i = 0; i < KT; ++i) {
-            const T xi = NULLS ? vget<T>(c.x[i], v) * mv : vget<T>(c.x[i], v);
+            const T xi = MODE == 1 ? vget<T>(c.x[i], v) * mv : vget<T>(c.x[i], v);
 #pragma unroll
             for (int j = i; j < KT; ++j) acc[tri_index<NZ>(i, j)] = fma(xi, vget<T>(c.x[j], v), acc[tri_index<NZ>(i, j)]);
             acc[tri_index<NZ>(i, KT)] = fma(xi, ys, acc[tri_index<NZ>(i, KT)]);
         }
-        if constexpr (NULLS) acc[tri_index<NZ>(KT, KT)] += mv;      // the (unused) y'y slot counts the rows left in the fit
-        else acc[tri_index<NZ>(KT, KT)] = fma(ys, ys, acc[tri_index<NZ>(KT, KT)]);
+        if constexpr (MODE == 0) acc[tri_index<NZ>(KT, KT)] = fma(ys, ys, acc[tri_index<NZ>(KT, KT)]);
+        else acc[tri_index<NZ>(KT, KT)] += mv;
+    }
+}
+
+template <typename T, int KT, bool HAS_W, bool NULLS = false>
+__device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2], const Chunk<T, KT, HAS_W> &c) {
+    if constexpr (!NULLS) {
+        gram_rows<T, KT, HAS_W, 0>(acc, c);
+    } else {
+        // Frames are mostly null-free even when a drop policy is asked for: when no lane of the wave holds a dropped row or a null
+        // target in this chunk (one ballot) the masking multiplies are skipped.
+        constexpr int VEC = Vec16<T>::N;
+        bool clean = c.m == ((1u << VEC) - 1u);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { const T yv = vget<T>(c.y, v); clean = clean && (yv == yv); }
+        if (__all(clean)) gram_rows<T, KT, HAS_W, 2>(acc, c);
+        else gram_rows<T, KT, HAS_W, 1>(acc, c);
     }
 }
 
@@ -565,8 +584,10 @@ template <typename T, int KT, bool HAS_W, int TEAM, int RC>
 static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
 #ifdef K1_NULLS_TU
-    (void)max_rows;   // the null-policy family: general (non-FAST) code only, the row masks live next to the resident rows
-    return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 1, true>(ctx, a);
+    // the null-policy family: the row masks live next to the resident rows; single-pass Gram only.  FAST as below: every load of
+    // every resident chunk is in flight before the masks are built (POLS_K1_NOFAST=1: the general code)
+    const bool fastn = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC && std::getenv("POLS_K1_NOFAST") == nullptr;
+    return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 1, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 1, true>(ctx, a);
 #else
     // FAST needs every group aligned to the vector width and resident; the offsets scan in upload_offsets() knows
     const bool fast = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC &&
