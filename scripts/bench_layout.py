@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polars_ols_amd.engine import Engine, Layout  # noqa: E402
 
 

@@ -1,11 +1,12 @@
 """K1 with a fused null policy next to the plain kernel: BASELINE configs[1] with 5 % null targets, null_policy="drop"."""
 import json
+import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polars_ols_amd.engine import Engine  # noqa: E402
 
 
