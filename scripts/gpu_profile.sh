@@ -35,7 +35,7 @@ echo "== rocprofv3 --kernel-trace --stats, cfg5 (streamed Gram on the matrix cor
 rm -rf $O/kt5; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -o k5 -- python $R/bench.py --config cfg5 --steps 10 --warmup 3 > /dev/null 2> $O/kt5.err
 f=$(find $O/kt5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_cfg5.csv && head -6 $O/${TAG}_kernel_stats_cfg5.csv | cut -c1-220
 echo "== MFMA counters available"
-rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u | tr '\n' ' ' | tee $O/${TAG}_mfma_counters_available.txt; echo
+timeout 60 rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u | tr '\n' ' ' | tee $O/${TAG}_mfma_counters_available.txt; echo
 echo "== rocprofv3 --pmc MFMA busy, cfg5 Gram kernel"
 rm -rf $O/pmc_mfma; timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python $R/bench.py --config cfg5 --steps 3 --warmup 1 > /dev/null 2> $O/pmc_mfma.err
 f=$(find $O/pmc_mfma -name "*counter_collection.csv" | head -1)
