@@ -1,5 +1,7 @@
 """Randomised differential check of the C-ABI against the oracle (not part of pytest; run on a GPU box)."""
-import sys; sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from polars_ols_amd import Engine
 from oracle import orc
@@ -72,4 +74,82 @@ for it in range(N_DYN):
     except Exception as exc:
         bad += 1
         print("DYNAMIC ERROR", it, k, G, repr(exc)[:200])
-print("fuzz done: bad =", bad)
+# ---- null policies (static models; expected values composed like the reference composes them: tests/test_nulls_gpu.py::_expected)
+from test_nulls_gpu import _expected
+for it in range(80):
+    dtype = np.float64 if rng.random() < 0.6 else np.float32
+    k = int(rng.integers(1, 36)); G = int(rng.integers(1, 25))
+    icpt = bool(rng.random() < 0.4); wts = bool(rng.random() < 0.4)
+    policy = str(rng.choice(["zero", "drop", "drop_zero", "drop_y_zero_x", "drop_window"]))
+    kind = rng.choice(["ols", "ridge", "enet"])
+    kw = {} if kind == "ols" else ({"alpha": float(rng.uniform(0.05, 2.0))} if kind == "ridge" else
+                                   {"alpha": float(rng.uniform(0.005, 0.2)), "l1_ratio": float(rng.uniform(0.1, 1.0)), "tol": 1e-10, "max_iter": 50_000})
+    y, cols, offs, w = frame(G, 4 * (k + 2), 4 * (k + 2) + int(rng.integers(10, 1500)), k, dtype)
+    frac = float(rng.choice([0.0, 0.01, 0.1]))
+    for c in [y] + cols[: int(rng.integers(0, k + 1))]:
+        c[rng.random(len(y)) < frac] = np.nan
+    if G > 2 and rng.random() < 0.3:
+        y[offs[1]:offs[2]] = np.nan                                  # a group with nothing left to fit
+    w = w if wts else None
+    try:
+        out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "resid"), null_policy=policy, **kw)
+        coef, pred, resid = _expected(y, cols, offs, w, icpt, "drop_zero" if policy == "drop_window" else policy, **kw)
+        tol = 2e-6 if dtype == np.float64 else 2e-3
+        # groups left with fewer fit rows than columns are min-norm problems: compare predictions on fit rows only there
+        ok = np.array_equal(np.isnan(out["pred"]), np.isnan(pred)) and np.allclose(out["pred"], pred, rtol=tol, atol=tol, equal_nan=True)
+        ok = ok and np.allclose(out["coef"], coef, rtol=tol, atol=tol)
+        if not ok:
+            bad += 1
+            print("NULLS MISMATCH", it, dtype.__name__, "k", k, "G", G, "icpt", icpt, "w", wts, policy, kind, kw, "frac", frac, eng.last_kernel,
+                  float(np.nanmax(np.abs(out["coef"] - coef))))
+    except Exception as exc:
+        bad += 1
+        print("NULLS ERROR", it, dtype.__name__, k, G, policy, kind, repr(exc)[:200])
+# ---- statistics
+for it in range(40):
+    dtype = np.float64
+    k = int(rng.integers(1, 60)); G = int(rng.integers(1, 12))
+    icpt = bool(rng.random() < 0.5); alpha = float(rng.choice([0.0, 0.0, 0.3]))
+    y, cols, offs, w = frame(G, 3 * (k + 2), 3 * (k + 2) + int(rng.integers(10, 1200)), k, dtype)
+    try:
+        out = eng.least_squares_statistics(y, cols, offs, add_intercept=icpt, alpha=alpha)
+        for g in range(G):
+            s, e = offs[g], offs[g + 1]
+            X = np.column_stack([c[s:e] for c in cols] + ([np.ones(e - s)] if icpt else [])).astype(np.float64)
+            ref = orc.statistics(y[s:e].astype(np.float64), X, alpha=alpha)
+            tol = 1e-6 if dtype == np.float64 else 5e-3
+            for a, b in (("r2", "r2"), ("mae", "mae"), ("mse", "mse"), ("std_err", "standard_errors"), ("t_values", "t_values"), ("p_values", "p_values")):
+                got, exp = np.asarray(out[a][g], dtype=np.float64), np.asarray(ref[b], dtype=np.float64)
+                if not np.allclose(got, exp, rtol=tol, atol=tol, equal_nan=True):
+                    bad += 1
+                    print("STATS MISMATCH", it, dtype.__name__, "k", k, "icpt", icpt, "alpha", alpha, a, eng.last_kernel, float(np.nanmax(np.abs(got - exp))))
+                    break
+    except Exception as exc:
+        bad += 1
+        print("STATS ERROR", it, dtype.__name__, k, G, repr(exc)[:300])
+# ---- .over(key): a frame in arrival order through the native layout == the same frame pre-sorted, bit for bit
+import torch
+from polars_ols_amd.least_squares import Frame, col
+for it in range(30):
+    k = int(rng.integers(1, 12)); G = int(rng.integers(1, 400)); n = int(rng.integers(G * (k + 3), G * (k + 3) + 20000))
+    keys = rng.integers(-G, G, size=n) * int(rng.choice([1, 1, 1 << 33]))
+    cols = {f"x{j}": rng.normal(size=n) for j in range(k)}
+    y = sum(cols.values()) + 0.1 * rng.normal(size=n)
+    dev = bool(rng.random() < 0.5)
+    conv = (lambda a: torch.as_tensor(a, device="cuda")) if dev else (lambda a: a)
+    order = np.argsort(keys, kind="stable")
+    try:
+        res = []
+        for idx in (np.arange(n), order):
+            f = Frame({name: conv(c[idx]) for name, c in cols.items()})
+            f["y"], f["g"] = conv(y[idx]), conv(keys[idx])
+            mode = str(rng.choice(["predictions", "residuals"])) if idx is not order else mode
+            p = f.select(col("y").least_squares.ols(*[col(c) for c in cols], mode=mode).over("g").alias("p"), engine=eng)["p"]
+            res.append(p.cpu().numpy() if dev else p)
+        if not np.array_equal(res[0][order], res[1], equal_nan=True):
+            bad += 1
+            print("OVER MISMATCH", it, "k", k, "G", G, "n", n, "dev", dev, float(np.nanmax(np.abs(res[0][order] - res[1]))))
+    except Exception as exc:
+        bad += 1
+        print("OVER ERROR", it, k, G, n, dev, repr(exc)[:300])
+print(f"fuzz done: {N_STATIC} static + {N_DYN} dynamic + 80 null-policy + 40 statistics + 30 over(key) cases, bad =", bad)
