@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     const int lane = threadIdx.x & 63;
     const int wave = (threadIdx.x >> 6) % WAVES;
     const int tid = threadIdx.x % TEAM;
-    const int64_t g = (int64_t)blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM;
+    const int64_t g = (int64_t)blockIdx.x * (blockDim.x / TEAM) + threadIdx.x / TEAM;   // blockDim.x: 256, or TEAM (see k1_launch_fast)
     if (g >= a.n_groups) return;   // wave-uniform for TEAM=64; never taken for TEAM=256 (grid == n_groups)
 
     const int64_t s = a.offs[g], e = a.offs[g + 1];
@@ -553,7 +553,10 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
     std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s%s%s", sizeof(T) == 4 ? "f32" : "f64", KT,
                   HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : "_p3"), NULLS ? "_nulls" : "");
-    const int64_t teams_per_block = 256 / TEAM;
+    // (one team per workgroup -- a finished wave's slot refilled at once instead of waiting for its block-mates -- measured no
+    // different: 74.4 vs 74.0 us on configs[1])
+    const int block_threads = 256;
+    const int64_t teams_per_block = block_threads / TEAM;
     int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     ctx->last_kernel = name;
@@ -572,9 +575,9 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     }
     hipEvent_t ev0, ev1;
     if (timing_pair(ctx, &ev0, &ev1))
-        hipExtLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
+        hipExtLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, ev0, ev1, 0, aa);
     else
-        hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+        hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, aa);
     POLS_HIP(hipGetLastError());
     if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
     return POLS_OK;
@@ -626,6 +629,20 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);
     } else {
+#ifndef K1_NULLS_TU
+        // f64, 6+ columns, aligned groups of up to 1 024 rows: TWO waves per group with 8 rows per lane (218-240 VGPRs, two waves per
+        // SIMD) keep four groups in flight per CU where the 256-thread team keeps three -- 153 vs 160 us on 10 000 x 1 000 x 8, 174 vs
+        // 177 us with weights (cfg3).  POLS_K1_F64_TEAM=256 goes back; POLS_K1_PASSES=3 splits the Gram in three.
+        if constexpr (KT >= 6) {
+            const char *t = std::getenv("POLS_K1_F64_TEAM");
+            if (!(t && std::atoi(t) == 256) && ctx->offs_aligned[0] && max_rows <= 128 * 4 * VEC && !std::getenv("POLS_K1_NOFAST") &&
+                !std::getenv("POLS_TIMELINE")) {
+                const char *pp = std::getenv("POLS_K1_PASSES");
+                if (pp && std::atoi(pp) == 3) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
+                if (!pp || std::atoi(pp) == 2) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 2>(ctx, a);
+            }
+        }
+#endif
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);
     }
 }
