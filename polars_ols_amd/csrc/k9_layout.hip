@@ -364,7 +364,7 @@ static int move_columns(pols_ctx *ctx, pols_layout *L, int dtype_bytes, const vo
             else hipLaunchKernelGGL((take_kernel<uint8_t, 4, false>), grid, dim3(256), 0, ctx->stream, a);
         } else {
             const int words = dtype_bytes / 4;
-            if (n * words >= ((int64_t)1 << 40)) return fail(POLS_ERR_UNSUPPORTED, "group_layout: table too large");
+            if (n * words > (int64_t)0x7fffffff * 256) return fail(POLS_ERR_UNSUPPORTED, "group_layout: table too large for one launch");
             for (int c = 0; c < nc; ++c)
                 hipLaunchKernelGGL(take_rows_kernel, dim3(blocks_for(n * words, 256)), dim3(256), 0, ctx->stream,
                                    static_cast<const uint32_t *>(a.src[c]), static_cast<uint32_t *>(a.dst[c]), index, n, words);
