@@ -43,7 +43,7 @@ extern "C" {
 #endif
 
 #define POLS_MAX_FEATURES 32        /* size of the fixed kernel-argument column arrays; wider calls use device pointer tables */
-#define POLS_MAX_FEATURES_STATISTICS 127 /* pols_least_squares_statistics: features incl. the intercept column */
+#define POLS_MAX_FEATURES_STATISTICS 1024 /* pols_least_squares_statistics: features incl. the intercept column */
 #define POLS_MAX_FEATURES_DYNAMIC 128 /* pols_recursive_least_squares / pols_rolling_least_squares (the reference's README
                                          benchmark runs them at 100 features) */
 #define POLS_MAX_FEATURES_STATIC 1024 /* pols_least_squares / pols_predict: the reference's own wide cases (tests/benchmark.py

@@ -719,7 +719,7 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
                                   const pols_stats_out *s) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if ((rc = check_batch(b, o, K8_STATS_KMAX))) return rc;
+    if ((rc = check_batch(b, o, K8_KMAX))) return rc;
     if (!p || !s) return fail(POLS_ERR_INVALID, "params / stats is NULL");
     if (p->null_policy != POLS_NULL_IGNORE || b->valid)
         return fail(POLS_ERR_UNSUPPORTED, "statistics: filter / zero-fill nulls before the call (what handle_nulls does above the "
@@ -730,8 +730,7 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
     const bool host = b->mem == POLS_MEM_HOST;
     const size_t G = (size_t)b->n_groups;
     if (kt > 31) {
-        // 32 .. 127 columns: the K8 kernels solve (same dispatcher), then the wide statistics kernel works from their Gram matrix
-        if (kt > K8_STATS_KMAX) return fail(POLS_ERR_UNSUPPORTED, "statistics: %d features (incl. intercept) > %d", kt, K8_STATS_KMAX);
+        // 32 .. 1 024 columns: the K8 kernels solve (same dispatcher), then the wide statistics kernel works from their Gram matrix
         // the dispatcher's decisions, as in ls_core (src/expressions.rs:366-387)
         const int m = p->solve_method;
         const bool positive = p->positive != 0;
@@ -760,6 +759,7 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
         }
         so.r2 = dev[0]; so.mae = dev[1]; so.mse = dev[2]; so.se = dev[3]; so.tv = dev[4]; so.pv = dev[5];
         so.lambda = p->alpha;
+        so.factored = !enet && kt + 1 > 128;                       // wide_chol ran on the Gram matrix in place (k8_wide.hip)
         if ((rc = wide_stats_launch(ctx, b->dtype, wi.a, so))) return rc;
         if (!host) return POLS_OK;
         for (int i = 0; i < 6; ++i)

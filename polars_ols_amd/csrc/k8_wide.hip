@@ -482,52 +482,74 @@ int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a) {
 // in dynamic LDS: (X'X + lambda I)^-1 by the symmetric sweep operator (a non-positive pivot = the reference's failed
 // Cholesky -> NaN standard errors / t / p, :101-111), its diagonal and trace, the side-car's own coefficients inv . X'y,
 // then two passes over the group's rows for the mean of the targets and the four sums.
-template <typename T>
-__global__ void __launch_bounds__(256) wide_stats_kernel(const WideArgs a, const WideStatsOut o) {
+// IN_LDS (up to 127 columns, 256 threads): the matrix lives in dynamic LDS.  Otherwise (up to 1 024 columns, 1 024 threads) it
+// lives in a per-group HBM / L2 work area (o.work) -- one workgroup still owns it, so a barrier orders its global accesses.
+template <typename T, int NT, bool IN_LDS>
+__global__ void __launch_bounds__(NT) wide_stats_kernel(const WideArgs a, const WideStatsOut o) {
     extern __shared__ double sl[];
-    __shared__ double red[4 * 4];
+    constexpr int NW = NT / 64;
+    __shared__ double red[4 * NW];
     __shared__ int ok_s;
     const int tid = threadIdx.x;
     const int kt = a.kt, ku = a.k_user, NZ = kt + 1, LD = kt | 1;
-    double *P = sl, *v = P + (size_t)kt * LD, *bv = v + kt, *binv = bv + kt, *cdis = binv + kt;
     const int64_t g = blockIdx.x;
+    double *P = IN_LDS ? sl : o.work + (size_t)g * kt * LD;
+    double *v = IN_LDS ? P + (size_t)kt * LD : sl, *bv = v + kt, *binv = bv + kt, *cdis = binv + kt;
     const int64_t s = a.offs[g], e = a.offs[g + 1], n = e - s;
     const double *G = a.gram + (size_t)g * NZ * NZ;
-    for (int q = tid; q < kt * kt; q += 256) { const int i = q / kt, c = q - i * kt; P[i * LD + c] = G[(size_t)i * NZ + c] + (i == c ? o.lambda : 0.0); }
-    if (tid < kt) { bv[tid] = G[(size_t)tid * NZ + kt]; cdis[tid] = a.coef64[g * kt + tid]; }
+    if (o.factored) {
+        // Beyond 127 columns wide_chol factored the Gram matrix IN PLACE: its lower triangle now holds L_ip d_p, its diagonal the
+        // pivots d_i (of G + alpha I); the strict upper triangle is untouched.  The matrix comes back from the upper triangle and
+        // G_ii + alpha = d_i + sum_{p < i} L_ip^2 d_p.
+        for (int i = tid; i < kt; i += NT) {
+            double dsum = G[(size_t)i * NZ + i];
+            for (int p = 0; p < i; ++p) { const double l = G[(size_t)i * NZ + p]; dsum += l * l / G[(size_t)p * NZ + p]; }
+            v[i] = dsum + (o.lambda - a.alpha);
+        }
+        __syncthreads();
+        for (int q = tid; q < kt * kt; q += NT) {
+            const int i = q / kt, c = q - i * kt;
+            P[i * LD + c] = (i == c) ? v[i] : G[(size_t)(i < c ? i : c) * NZ + (i < c ? c : i)];
+        }
+    } else {
+        for (int q = tid; q < kt * kt; q += NT) { const int i = q / kt, c = q - i * kt; P[i * LD + c] = G[(size_t)i * NZ + c] + (i == c ? o.lambda : 0.0); }
+    }
+    for (int i = tid; i < kt; i += NT) { bv[i] = G[(size_t)i * NZ + kt]; cdis[i] = a.coef64[g * kt + i]; }
     if (tid == 0) ok_s = 1;
     __syncthreads();
     for (int j = 0; j < kt; ++j) {
         const double d = P[j * LD + j];
         if (tid == 0 && !(d > 0.0)) ok_s = 0;
         const double p = 1.0 / d;
-        if (tid < kt) v[tid] = P[tid * LD + j];
+        for (int i = tid; i < kt; i += NT) v[i] = P[i * LD + j];
         __syncthreads();
-        for (int q = tid; q < kt * kt; q += 256) {
-            const int i = q / kt, c = q - i * kt;
+        const int di = NT / kt, dc = NT - di * kt;                // (i, c) advance by NT elements without a divide per element
+        for (int i = tid / kt, c = tid - (tid / kt) * kt; i < kt;) {
             double val;
             if (i == j && c == j) val = -p;
             else if (i == j) val = v[c] * p;
             else if (c == j) val = v[i] * p;
             else val = P[i * LD + c] - v[i] * v[c] * p;
             P[i * LD + c] = val;
+            i += di; c += dc;
+            if (c >= kt) { c -= kt; ++i; }
         }
         __syncthreads();
     }
-    if (tid < kt) {                                                // P now holds -(inverse)
+    for (int i = tid; i < kt; i += NT) {                           // P now holds -(inverse)
         double acc = 0.0;
-        for (int c = 0; c < kt; ++c) acc -= P[tid * LD + c] * bv[c];
-        binv[tid] = acc;                                           // A^-1 X'y  (:116)
-        v[tid] = -P[tid * LD + tid];                               // diag(A^-1)
+        for (int c = 0; c < kt; ++c) acc -= P[i * LD + c] * bv[c];
+        binv[i] = acc;                                             // A^-1 X'y  (:116)
+        v[i] = -P[i * LD + i];                                     // diag(A^-1)
     }
     __syncthreads();
     const T *yp = static_cast<const T *>(a.y), *wp = static_cast<const T *>(a.w);
     double sums[1] = {0.0};
-    for (int64_t r = s + tid; r < e; r += 256) sums[0] += (double)yp[r] * (wp ? sqrt((double)wp[r]) : 1.0);
-    wide_block_sum<1>(sums, red, 4);
+    for (int64_t r = s + tid; r < e; r += NT) sums[0] += (double)yp[r] * (wp ? sqrt((double)wp[r]) : 1.0);
+    wide_block_sum<1>(sums, red, NW);
     const double mean = n ? sums[0] / (double)n : 0.0;             // targets.mean().unwrap_or(0.0)  (:16)
     double acc[4] = {0.0, 0.0, 0.0, 0.0};                           // sse, sae, sst, rss
-    for (int64_t r = s + tid; r < e; r += 256) {
+    for (int64_t r = s + tid; r < e; r += NT) {
         const double sw = wp ? sqrt((double)wp[r]) : 1.0;
         const double yt = (double)yp[r] * sw;
         double p1 = 0.0, p2 = 0.0;
@@ -539,7 +561,7 @@ __global__ void __launch_bounds__(256) wide_stats_kernel(const WideArgs a, const
         const double e1 = yt - p1, e2 = yt - p2, dm = yt - mean;
         acc[0] += e1 * e1; acc[1] += fabs(e1); acc[2] += dm * dm; acc[3] += e2 * e2;
     }
-    wide_block_sum<4>(acc, red, 4);
+    wide_block_sum<4>(acc, red, NW);
     double trace = 0.0;
     for (int j = 0; j < kt; ++j) trace += v[j];
     const double nn = (double)n;
@@ -551,32 +573,44 @@ __global__ void __launch_bounds__(256) wide_stats_kernel(const WideArgs a, const
         if (o.r2) o.r2[g] = 1.0 - acc[0] / acc[2];
         if (a.status && ok && !(df > 0.0)) a.status[g] = POLS_GROUP_BAD_DOF;
     }
-    if (tid < kt) {
+    for (int i = tid; i < kt; i += NT) {
         const double nanv = __longlong_as_double(0x7ff8000000000000LL);
         double se = nanv, tv = nanv, pv = nanv;
         if (ok && df > 0.0) {
-            se = sqrt(acc[3] / df * fabs(v[tid]));
-            tv = binv[tid] / se;
+            se = sqrt(acc[3] / df * fabs(v[i]));
+            tv = binv[i] / se;
             pv = (tv != tv) ? nanv : k7_betai(0.5 * df, 0.5, df / (df + tv * tv));
         }
-        if (o.se) o.se[g * kt + tid] = se;
-        if (o.tv) o.tv[g * kt + tid] = tv;
-        if (o.pv) o.pv[g * kt + tid] = pv;
+        if (o.se) o.se[g * kt + i] = se;
+        if (o.tv) o.tv[g * kt + i] = tv;
+        if (o.pv) o.pv[g * kt + i] = pv;
     }
 }
 
-int wide_stats_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const WideStatsOut &o) {
-    if (a.kt > K8_STATS_KMAX) return fail(POLS_ERR_UNSUPPORTED, "statistics: %d features (incl. intercept) > %d", a.kt, K8_STATS_KMAX);
+int wide_stats_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const WideStatsOut &o_in) {
+    if (a.kt > K8_KMAX) return fail(POLS_ERR_UNSUPPORTED, "statistics: %d features (incl. intercept) > %d", a.kt, K8_KMAX);
     if (a.n_groups == 0) return POLS_OK;
-    const size_t lds = sizeof(double) * ((size_t)a.kt * (a.kt | 1) + 4 * (size_t)a.kt);
-    static OncePerDevice attr_once;
-    if (attr_once.needed(ctx->device)) {
-        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        attr_once.done(ctx->device);
+    WideStatsOut o = o_in;
+    if (a.kt <= K8_STATS_LDS_KMAX) {
+        const size_t lds = sizeof(double) * ((size_t)a.kt * (a.kt | 1) + 4 * (size_t)a.kt);
+        static OncePerDevice attr_once;
+        if (attr_once.needed(ctx->device)) {
+            POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<float, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_stats_kernel<double, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            attr_once.done(ctx->device);
+        }
+        if (dtype == POLS_F32) hipLaunchKernelGGL((wide_stats_kernel<float, 256, true>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
+        else hipLaunchKernelGGL((wide_stats_kernel<double, 256, true>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
+    } else {
+        // the solve is over: its work area (slot 3) is free to hold one kt x kt matrix per group
+        void *w = nullptr;
+        int rc = ensure_scratch(ctx, 3, sizeof(double) * (size_t)a.n_groups * a.kt * (a.kt | 1), &w);
+        if (rc) return rc;
+        o.work = static_cast<double *>(w);
+        const size_t lds = sizeof(double) * 4 * (size_t)a.kt;
+        if (dtype == POLS_F32) hipLaunchKernelGGL((wide_stats_kernel<float, 1024, false>), dim3((unsigned)a.n_groups), dim3(1024), lds, ctx->stream, a, o);
+        else hipLaunchKernelGGL((wide_stats_kernel<double, 1024, false>), dim3((unsigned)a.n_groups), dim3(1024), lds, ctx->stream, a, o);
     }
-    if (dtype == POLS_F32) hipLaunchKernelGGL(wide_stats_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
-    else hipLaunchKernelGGL(wide_stats_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, o);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

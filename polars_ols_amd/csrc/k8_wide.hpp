@@ -55,9 +55,9 @@ int wide_minnorm_launch(pols_ctx *ctx, int dtype, const WideArgs &a, int workers
 int wide_predict_launch(pols_ctx *ctx, int dtype, const WideArgs &a);
 // mode="statistics" for 32 .. 127 columns (src/statistics.rs:15-156): needs a.gram (wide_gram_launch), a.coef64 (the dispatcher's
 // coefficients) and six f64 output arrays (any may be nullptr); lambda = kwargs.alpha
-struct WideStatsOut { double *r2, *mae, *mse, *se, *tv, *pv; double lambda; };
+struct WideStatsOut { double *r2, *mae, *mse, *se, *tv, *pv; double lambda; double *work = nullptr; bool factored = false; };   // work: set by the launcher; factored: see wide_stats_kernel
 int wide_stats_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const WideStatsOut &o);
-constexpr int K8_STATS_KMAX = 127;
+constexpr int K8_STATS_LDS_KMAX = 127;   // statistics: the k x k inverse fits dynamic LDS up to here, beyond it lives in HBM / L2
 // `predict` plugin body for wide frames: one coefficient row per input row (coef_rows: n_rows x kt, batch dtype)
 int wide_predict_rows_launch(pols_ctx *ctx, int dtype, const WideArgs &a, const void *coef_rows);
 

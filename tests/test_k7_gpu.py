@@ -113,6 +113,17 @@ def test_statistics_wide_32_to_127_columns(engine, dtype, rtol, k, weights, add_
     assert (np.asarray(res["status"]) == 0).all()
 
 
+@pytest.mark.parametrize("k,weights,add_intercept,alpha,G", [(127, False, True, 0.0, 3), (200, True, False, 0.5, 3), (640, False, True, 0.0, 2)])
+def test_statistics_beyond_127_columns(engine, k, weights, add_intercept, alpha, G):
+    """128 .. 1 024 columns: the same sweep-operator inverse, the matrix in an HBM / L2 work area owned by one workgroup."""
+    d = _ragged(400 + k, np.float64, G=G, k=k, lo=2 * k + 50, hi=3 * k)
+    w = d["w"] if weights else None
+    res = engine.least_squares_statistics(d["y"], d["cols"], d["offsets"], weights=w, add_intercept=add_intercept, alpha=alpha)
+    exp = _oracle_stats(d, weights=w, add_intercept=add_intercept, alpha=alpha)
+    _check(res, exp, 1e-6, 1e-6)
+    assert (np.asarray(res["status"]) == 0).all()
+
+
 def test_statistics_elastic_net_uses_alpha_as_lambda(engine):
     d = _ragged(11, np.float64, G=9)
     res = engine.least_squares_statistics(d["y"], d["cols"], d["offsets"], alpha=0.01, l1_ratio=0.5)
