@@ -44,8 +44,9 @@ extern "C" {
 
 #define POLS_MAX_FEATURES 32        /* size of the fixed kernel-argument column arrays; wider calls use device pointer tables */
 #define POLS_MAX_FEATURES_STATISTICS 1024 /* pols_least_squares_statistics: features incl. the intercept column */
-#define POLS_MAX_FEATURES_DYNAMIC 128 /* pols_recursive_least_squares / pols_rolling_least_squares (the reference's README
-                                         benchmark runs them at 100 features) */
+#define POLS_MAX_FEATURES_DYNAMIC 1024 /* pols_recursive_least_squares / pols_rolling_least_squares (the reference's README
+                                          benchmark runs them at 100 features; beyond 128 the k x k state of a chunk lives in
+                                          HBM: correct, but every row costs O(k^2) L2 traffic) */
 #define POLS_MAX_FEATURES_STATIC 1024 /* pols_least_squares / pols_predict: the reference's own wide cases (tests/benchmark.py
                                          at 100 features, test_elastic_net and test_fit_wide up to 1 000) */
 

@@ -831,7 +831,10 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, con
     return stage_inputs(ctx, b, b->n_rows, b->n_features, o, st);
 }
 
-static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a, int64_t min_chunk = 64);
+static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a, int64_t min_chunk = 64, int64_t max_chunk = 512);
+// beyond 128 features a chunk carries a k x k state and a k x k total in HBM (16 MB at k = 1 024) and its workgroup an O(k^3)
+// inversion: a few hundred long chunks instead of thousands of 64-row ones
+static int64_t hbm_state_chunk(int64_t n_rows) { return std::max<int64_t>(64, (n_rows + 383) / 384); }
 
 // Scratch slot 6 of the dynamic entries: [128 doubles: RLS prior mean][column pointer table for more than 32 features]
 static int dynamic_slot6(pols_ctx *ctx, void **base) {
@@ -890,7 +893,8 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         const int k = b->n_features;
         K4Args s4;
         std::memset(&s4, 0, sizeof(s4));
-        if ((rc = build_chunk_tables(ctx, b, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, 64))) return rc;
+        const int64_t minc = k > 128 ? hbm_state_chunk(b->n_rows) : 64;
+        if ((rc = build_chunk_tables(ctx, b, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, minc, std::max<int64_t>(512, minc)))) return rc;
         s4.y = st.y; s4.valid = st.valid;
         if ((rc = upload_column_table(ctx, st, k, &s4))) return rc;
         s4.coef = st.coef; s4.pred = st.pred;
@@ -908,7 +912,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
 // Host-side tables shared by the chunk-parallel dynamic kernels (K4 rolling, K3s RLS scan): validity prefix
 // (cnt / vidx), per-group warm-up constants of solve_rolling_ols (ls.rs:881-900) and the chunk list; uploaded to
 // scratch slot 4, the per-chunk totals live in slot 5 (`slots` doubles per chunk).
-static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a, int64_t min_chunk) {
+static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a, int64_t min_chunk, int64_t max_chunk) {
     int rc;
     const int64_t N = b->n_rows;
     std::vector<uint8_t> hvalid;
@@ -926,7 +930,7 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     // one lane (or wave / workgroup) per chunk: short chunks = more parallelism in the walk, longer chunk list for the scan
     // (measured on the 1M-row sequence: 64-row chunks = 15 625 lanes beat 32- and 16-row chunks -- the per-lane row loads are
     // uncoalesced and more concurrent lanes cost more in the memory system than they win in parallelism)
-    const int64_t chunk_len = std::min<int64_t>(512, std::max<int64_t>(min_chunk, N / 16384));
+    const int64_t chunk_len = std::min<int64_t>(std::max(max_chunk, min_chunk), std::max<int64_t>(min_chunk, N / 16384));
     auto &cc = ctx->chunk_cache;
     if (!hv && cc.tab && cc.tab == ctx->scratch[4].ptr && cc.offs_sum == ctx->offs_sum && cc.n_groups == b->n_groups &&
         cc.n_rows == N && cc.mp == mp && cc.chunk_len == (int32_t)chunk_len) {      // same frame as the last call
@@ -1024,7 +1028,8 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
 
     K4Args a;
     std::memset(&a, 0, sizeof(a));
-    if ((rc = build_chunk_tables(ctx, b, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, 64))) return rc;
+    const int64_t minc = k > 128 ? hbm_state_chunk(b->n_rows) : 64;
+    if ((rc = build_chunk_tables(ctx, b, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, minc, std::max<int64_t>(512, minc)))) return rc;
     a.y = st.y; a.valid = st.valid;
     if ((rc = upload_column_table(ctx, st, k, &a))) return rc;
     a.coef = st.coef; a.pred = st.pred;

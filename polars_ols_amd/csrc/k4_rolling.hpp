@@ -49,6 +49,7 @@ struct K4Args {
     double ff;                   // forgetting factor (ls.rs:513-517)
     double p0;                   // initial_state_covariance: A_0 = I / p0
     const double *mean0;         // device, k values or nullptr
+    double *state;               // k4x beyond 128 features: one k x (k | 1) matrix per chunk in HBM (set by the launcher)
 };
 
 int k4_launch(pols_ctx *ctx, int dtype, const K4Args &a);
@@ -58,10 +59,10 @@ int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 // 9..32 features: one wave per chunk, state in LDS (k4w_wide.hip).  Totals rows are k*k + k (+ 1 for the RLS decay) doubles.
 int k4w_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3sw_launch(pols_ctx *ctx, int dtype, const K4Args &a);
-// 33..128 features: one workgroup per chunk, the inverse propagated in LDS (k4x_inverse.hip).  Totals rows as for k4w.
+// 33..1024 features: one workgroup per chunk, the inverse propagated in LDS (HBM / L2 beyond 128) (k4x_inverse.hip).  Totals rows as for k4w.
 int k4x_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3x_launch(pols_ctx *ctx, int dtype, const K4Args &a);
-constexpr int K4X_KMAX = 128;
+constexpr int K4X_KMAX = 1024;
 // pass 2 of every chunk-parallel kernel: exclusive prefix of the chunk totals, one wave per (group, component);
 // mode 0 plain (rolling), 1 / 2 decayed with the RLS prior as carry-in (packed / full K x K state), see k4_rolling.hip
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);

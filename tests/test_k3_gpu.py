@@ -84,9 +84,11 @@ def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
-@pytest.mark.parametrize("k,half_life,p0,mean", [(33, None, 10.0, None), (100, 252.0, 1.0, 0.25), (128, None, 10.0, None)])
-def test_rls_inverse_propagation_33_to_128_features(eng, dtype, tol, k, half_life, p0, mean):
-    """33..128 features (k4x_inverse.hip): the reference's P-form update, chunk-parallel (README benchmark shape: 100 features)."""
+@pytest.mark.parametrize("k,half_life,p0,mean", [(33, None, 10.0, None), (100, 252.0, 1.0, 0.25), (128, None, 10.0, None),
+                                                 (129, 300.0, 10.0, None), (200, None, 2.0, 0.1)])
+def test_rls_inverse_propagation_33_features_and_up(eng, dtype, tol, k, half_life, p0, mean):
+    """33+ features (k4x_inverse.hip): the reference's P-form update, chunk-parallel (README benchmark shape: 100 features); beyond
+    128 the K x K state of a chunk lives in HBM / L2 instead of LDS."""
     from oracle import orc
 
     rng = np.random.default_rng(300 + k)
@@ -100,7 +102,7 @@ def test_rls_inverse_propagation_33_to_128_features(eng, dtype, tol, k, half_lif
     out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), half_life=half_life,
                                       initial_state_covariance=p0, initial_state_mean=mean0)
     ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0, is_valid=valid)
-    assert eng.last_kernel.startswith("k3x_")
+    assert eng.last_kernel.startswith("k3x_") and ("_hbm_" in eng.last_kernel) == (k > 128)
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
 

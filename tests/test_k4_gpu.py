@@ -112,8 +112,9 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
 @pytest.mark.parametrize("policy", ["drop", "drop_window"])
 @pytest.mark.parametrize("k,window,min_periods,alpha,null_frac,use_woodbury", [
     (33, 120, None, None, 0.0, None), (64, 256, 80, 0.5, 0.05, True), (100, 400, None, None, 0.05, None), (128, 512, None, 1e-3, 0.0, None),
+    (150, 600, None, None, 0.03, None), (192, 500, None, 0.1, 0.0, None),                 # state in HBM / L2
 ])
-def test_rolling_inverse_propagation_33_to_128_features(eng, policy, k, window, min_periods, alpha, null_frac, use_woodbury):
+def test_rolling_inverse_propagation_33_features_and_up(eng, policy, k, window, min_periods, alpha, null_frac, use_woodbury):
     """33..128 features (k4x_inverse.hip): the inverse is propagated like the reference's WoodburyState (default for k > 60)."""
     from oracle import orc
 
@@ -122,7 +123,7 @@ def test_rolling_inverse_propagation_33_to_128_features(eng, policy, k, window, 
     y, cols, offs, valid = _frame(rng, sizes, k, null_frac=null_frac)
     out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid),
                                     window_size=window, min_periods=min_periods, alpha=alpha, null_policy=policy, use_woodbury=use_woodbury)
-    assert eng.last_kernel.startswith("k4x_")
+    assert eng.last_kernel.startswith("k4x_") and ("_hbm_" in eng.last_kernel) == (k > 128)
     ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy, is_valid=valid,
                               use_woodbury=use_woodbury)
     got_c, got_p = _np(out["coef"]), _np(out["pred"])

@@ -126,9 +126,14 @@ def test_wide_device_matches_host_and_is_repeatable(eng):
 
 
 def test_wide_limits(eng):
-    y2, cols2, offs2, _ = _frame(1, np.float64, 130, [100])
-    with pytest.raises(Exception):
-        eng.recursive_least_squares(y2, cols2, offs2)                 # RLS / rolling stop at 128 features
+    """every entry takes up to 1 024 columns (POLS_MAX_FEATURES_STATIC / _DYNAMIC / _STATISTICS); one more is refused"""
+    y2, cols2, offs2, _ = _frame(1, np.float64, 8, [40])
+    cols2 = cols2 * 129                                               # 1 032 column pointers
+    for call in (eng.recursive_least_squares, eng.least_squares, eng.least_squares_statistics):
+        with pytest.raises(Exception, match="features|columns"):
+            call(y2, cols2[:1025], offs2)
+    with pytest.raises(Exception, match="features|columns"):
+        eng.rolling_least_squares(y2, cols2[:1025], offs2, window_size=10)
 
 
 # ------------------------------------------------------------------------------------------------ multi-target
