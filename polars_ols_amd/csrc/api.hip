@@ -823,7 +823,7 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, con
                             Staged *st) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if ((rc = check_batch(b, o, K4X_KMAX))) return rc;
+    if ((rc = check_batch(b, o, K4Y_KMAX))) return rc;
     if (b->add_intercept || b->weights)
         return fail(POLS_ERR_INVALID, "dynamic models take pre-processed columns: apply sqrt(w) / append the ones column "
                                       "before the call, exactly like polars_ols/least_squares.py:184-196 does for the plugin");
@@ -838,7 +838,7 @@ static int64_t hbm_state_chunk(int64_t n_rows) { return std::max<int64_t>(64, (n
 
 // Scratch slot 6 of the dynamic entries: [128 doubles: RLS prior mean][column pointer table for more than 32 features]
 static int dynamic_slot6(pols_ctx *ctx, void **base) {
-    return ensure_scratch(ctx, 6, sizeof(double) * K4X_KMAX + sizeof(void *) * K4X_KMAX, base);
+    return ensure_scratch(ctx, 6, sizeof(double) * K4Y_KMAX + sizeof(void *) * K4Y_KMAX, base);
 }
 static int upload_column_table(pols_ctx *ctx, const Staged &st, int k, K4Args *a) {
     for (int j = 0; j < std::min(k, (int)POLS_MAX_FEATURES); ++j) a->x[j] = st.x[j];
@@ -846,7 +846,7 @@ static int upload_column_table(pols_ctx *ctx, const Staged &st, int k, K4Args *a
     void *d = nullptr;
     int rc = dynamic_slot6(ctx, &d);
     if (rc) return rc;
-    char *tab = static_cast<char *>(d) + sizeof(double) * K4X_KMAX;
+    char *tab = static_cast<char *>(d) + sizeof(double) * K4Y_KMAX;
     POLS_HIP(hipMemcpyAsync(tab, st.x.data(), sizeof(void *) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
     POLS_HIP(hipStreamSynchronize(ctx->stream));
     a->xtab = reinterpret_cast<const void *const *>(tab);
@@ -902,7 +902,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         s4.ff = a.forgetting_factor; s4.p0 = a.initial_state_covariance; s4.mean0 = a.mean0;
         if (wide) { s4.tot_cs = k * k + k + 1; s4.tot_qs = 1; }            // chunk-major for the wave / workgroup-per-chunk kernels
         else { s4.tot_cs = 1; s4.tot_qs = s4.n_chunks; }                   // component-major for the lane-per-chunk kernels
-        if ((rc = xwide ? k3x_launch(ctx, b->dtype, s4) : (wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4)))) return rc;
+        if ((rc = k > K4X_KMAX ? k3y_launch(ctx, b->dtype, s4) : xwide ? k3x_launch(ctx, b->dtype, s4) : (wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4)))) return rc;
     } else {
         if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
     }
@@ -1037,7 +1037,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     a.k = k; a.drop_mode = drop ? 1 : 0;
     if (wide) { a.tot_cs = k * k + k; a.tot_qs = 1; }
     else { a.tot_cs = 1; a.tot_qs = a.n_chunks; }
-    if ((rc = xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a)))) return rc;
+    if ((rc = k > K4X_KMAX ? k4y_launch(ctx, b->dtype, a) : xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a)))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, k, o, st);
 }
 

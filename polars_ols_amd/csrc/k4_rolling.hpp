@@ -59,10 +59,14 @@ int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 // 9..32 features: one wave per chunk, state in LDS (k4w_wide.hip).  Totals rows are k*k + k (+ 1 for the RLS decay) doubles.
 int k4w_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3sw_launch(pols_ctx *ctx, int dtype, const K4Args &a);
-// 33..1024 features: one workgroup per chunk, the inverse propagated in LDS (HBM / L2 beyond 128) (k4x_inverse.hip).  Totals rows as for k4w.
+// 33..128 features: one workgroup per chunk, the inverse propagated in LDS (k4x_inverse.hip).  Totals rows as for k4w.
 int k4x_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3x_launch(pols_ctx *ctx, int dtype, const K4Args &a);
-constexpr int K4X_KMAX = 1024;
+constexpr int K4X_KMAX = 128;
+// 129..1024 features: the same with the per-chunk state in HBM / L2 and 1 024 threads (k4y_hbm.hip)
+int k4y_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+int k3y_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+constexpr int K4Y_KMAX = 1024;
 // pass 2 of every chunk-parallel kernel: exclusive prefix of the chunk totals, one wave per (group, component);
 // mode 0 plain (rolling), 1 / 2 decayed with the RLS prior as carry-in (packed / full K x K state), see k4_rolling.hip
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);

@@ -1,4 +1,6 @@
-// k4x_inverse.hip -- rolling OLS and RLS for 33 .. 128 features: ONE WORKGROUP PER CHUNK, the INVERSE propagated in LDS.
+// k4y_hbm.hip -- rolling OLS and RLS for 129 .. 1 024 features: k4x_inverse.hip's algorithm (ONE WORKGROUP PER CHUNK propagating the
+// INVERSE) with the K x K state of a chunk in an HBM / L2 area owned by its workgroup instead of LDS, and 1 024 threads.  The
+// 33 .. 128-feature kernels stay as they were tuned; this file trades their LDS idioms for stride-NT loops so that K may exceed NT.
 //
 // For more than 60 features the reference itself stops re-factoring X'X per row and propagates (X'X)^-1 with Woodbury
 // updates (WoodburyState, src/least_squares.rs:737-787; `use_woodbury` defaults to k > 60, :863); RLS always propagates
@@ -16,22 +18,35 @@
 
 namespace pols {
 
-constexpr int KX_MAX = 128;
+constexpr int KY_LDS_MAX = 128;      // the K x K state fits dynamic LDS up to here
+constexpr int KY_MAX = 1024;
 
-template <typename T>
-struct XCtx {
+// NT threads; GLOBAL: the K x K state lives at a.state + chunk * K * LD instead of LDS (one workgroup owns it, so the barriers that
+// order LDS accesses order these too).  Every "thread t owns element t" statement is a stride-NT loop, so K may exceed NT.
+template <typename T, int NT, bool GLOBAL>
+struct YCtx {
     const K4Args &a;
     int64_t s;
     int first_chunk;
     int K, LD, NS, tid;
     double *P, *xs, *v, *bv, *beta, *red;
-    const T *mycol;
-    __device__ XCtx(const K4Args &a_, int64_t s_, int fc, double *lds) : a(a_), s(s_), first_chunk(fc) {
+    const T *mycol;              // column tid (the target for tid == K): the pointer of the first load_row() stride, kept in a register
+    __device__ YCtx(const K4Args &a_, int64_t s_, int fc, double *lds) : a(a_), s(s_), first_chunk(fc) {
         K = a.k; LD = K | 1; NS = K * K + K; tid = threadIdx.x;
-        P = lds; xs = P + (size_t)K * LD; v = xs + KX_MAX + 2; bv = v + KX_MAX; beta = bv + KX_MAX; red = beta + KX_MAX;
-        mycol = tid < K ? static_cast<const T *>(a.xtab ? a.xtab[tid] : a.x[tid]) : static_cast<const T *>(a.y);
+        mycol = tid < K ? column(tid) : static_cast<const T *>(a.y);
+        P = GLOBAL ? a.state + (size_t)blockIdx.x * K * LD : lds;
+        xs = GLOBAL ? lds : P + (size_t)K * LD;
+        v = xs + K + 2; bv = v + K; beta = bv + K; red = beta + K;
     }
-    static __host__ __device__ size_t lds_doubles(int K) { return (size_t)K * (K | 1) + 4 * KX_MAX + 2 + 16; }
+    static __host__ __device__ size_t lds_doubles(int K) { return (GLOBAL ? 0 : (size_t)K * (K | 1)) + 4 * (size_t)K + 2 + 16; }
+    __device__ __forceinline__ const T *column(int j) const { return static_cast<const T *>(a.xtab ? a.xtab[j] : a.x[j]); }
+    // (i, c) of element q = tid, tid + NT, ... of a K x K walk, carried: no divide per element (up to a thousand per thread and pivot)
+    struct Walk {
+        int i, c, di, dc, K;
+        __device__ Walk(int tid, int K_) : K(K_) { i = tid / K; c = tid - i * K; di = NT / K; dc = NT - di * K; }
+        __device__ __forceinline__ bool more() const { return i < K; }
+        __device__ __forceinline__ void next() { i += di; c += dc; if (c >= K) { c -= K; ++i; } }
+    };
 
     __device__ __forceinline__ bool valid(int64_t i) const { return a.valid ? a.valid[s + i] != 0 : true; }
     __device__ __forceinline__ int64_t cnt(int64_t i) const { return a.cnt ? (int64_t)a.cnt[s + i] : i + 1; }
@@ -40,30 +55,41 @@ struct XCtx {
     __device__ __forceinline__ void load_row(int64_t i) const {      // xs[0..K) = x, xs[K] = y
         __syncthreads();
         if (tid <= K) xs[tid] = (double)mycol[s + i];
+        for (int j = tid + NT; j <= K; j += NT) xs[j] = (double)(j < K ? column(j) : static_cast<const T *>(a.y))[s + i];
         __syncthreads();
     }
-    __device__ double block_sum(double x) const {                     // all 256 threads
+    __device__ double block_sum(double x) const {                     // all NT threads
         const double w = wave_sum_row3(x);
         __syncthreads();
         if ((tid & 63) == 63) red[tid >> 6] = w;
         __syncthreads();
-        return red[0] + red[1] + red[2] + red[3];
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NT / 64; ++q) t += red[q];
+        return t;
+    }
+    // sum_j p[j] * q[j] over the K entries of two LDS vectors
+    __device__ double dot(const double *p, const double *q) const {
+        double acc = 0.0;
+        for (int j = tid; j < K; j += NT) acc += p[j] * q[j];
+        return block_sum(acc);
     }
     // ---- raw Gram form (before the inversion): P holds X'X, bv holds X'y
     __device__ void zero() const {
-        for (int q = tid; q < K * LD; q += 256) P[q] = 0.0;
-        if (tid < K) bv[tid] = 0.0;
+        for (int q = tid; q < K * LD; q += NT) P[q] = 0.0;
+        for (int j = tid; j < K; j += NT) bv[j] = 0.0;
         __syncthreads();
     }
     __device__ void gram_axpy(const double *src, double sign) const { // src: K*K (row-major, stride K) then K
-        for (int q = tid; q < K * K; q += 256) { const int i = q / K, c = q - i * K; P[i * LD + c] += sign * src[q]; }
-        if (tid < K) bv[tid] += sign * src[K * K + tid];
+        int q = tid;
+        for (Walk w(tid, K); w.more(); w.next(), q += NT) P[w.i * LD + w.c] += sign * src[q];
+        for (int j = tid; j < K; j += NT) bv[j] += sign * src[K * K + j];
         __syncthreads();
     }
     __device__ void gram_add_row(int64_t i, double sign) const {
         load_row(i);
-        for (int q = tid; q < K * K; q += 256) { const int r = q / K, c = q - r * K; P[r * LD + c] += sign * (xs[r] * xs[c]); }
-        if (tid < K) bv[tid] += sign * (xs[tid] * xs[K]);
+        for (Walk w(tid, K); w.more(); w.next()) P[w.i * LD + w.c] += sign * (xs[w.i] * xs[w.c]);
+        for (int j = tid; j < K; j += NT) bv[j] += sign * (xs[j] * xs[K]);
         __syncthreads();
     }
     __device__ void gram_prefix(int64_t i, double sign, int nacc) const {
@@ -75,14 +101,14 @@ struct XCtx {
     }
     // ---- in-place inverse of P + alpha I by the symmetric sweep operator (result: the inverse, sign fixed at the end)
     __device__ void invert(double alpha) const {
-        if (tid < K) P[tid * LD + tid] += alpha;
+        for (int j = tid; j < K; j += NT) P[j * LD + j] += alpha;
         __syncthreads();
         for (int j = 0; j < K; ++j) {
             const double p = 1.0 / P[j * LD + j];
-            if (tid < K) v[tid] = P[tid * LD + j];                    // column j (= row j)
+            for (int t = tid; t < K; t += NT) v[t] = P[t * LD + j];    // column j (= row j)
             __syncthreads();
-            for (int q = tid; q < K * K; q += 256) {
-                const int i = q / K, c = q - i * K;
+            for (Walk w(tid, K); w.more(); w.next()) {
+                const int i = w.i, c = w.c;
                 double val;
                 if (i == j && c == j) val = -p;
                 else if (i == j) val = v[c] * p;
@@ -92,79 +118,89 @@ struct XCtx {
             }
             __syncthreads();
         }
-        for (int q = tid; q < K * K; q += 256) { const int i = q / K, c = q - i * K; P[i * LD + c] = -P[i * LD + c]; }
+        for (Walk w(tid, K); w.more(); w.next()) P[w.i * LD + w.c] = -P[w.i * LD + w.c];
         __syncthreads();
     }
-    // out = P x   (thread t < K owns row t)
+    // out = P x, thread t owns entry t.  LDS: along ROW t (LD is odd: conflict-free, and consecutive words pair up into wide LDS
+    // reads).  HBM / L2: P is symmetric, so down COLUMN t -- consecutive threads, consecutive words.
     __device__ void matvec(const double *x, double *out) const {
-        if (tid < K) {
+        for (int t = tid; t < K; t += NT) {
             double acc = 0.0;
-            const double *row = P + tid * LD;
-            for (int c = 0; c < K; ++c) acc += row[c] * x[c];
-            out[tid] = acc;
+            if (GLOBAL) {
+                const double *col = P + t;
+                for (int c = 0; c < K; ++c) acc += col[(size_t)c * LD] * x[c];
+            } else {
+                const double *row = P + t * LD;
+                for (int c = 0; c < K; ++c) acc += row[c] * x[c];
+            }
+            out[t] = acc;
         }
         __syncthreads();
     }
     __device__ void rank1(double coef) const {                        // P += coef * v v'
-        for (int q = tid; q < K * K; q += 256) { const int i = q / K, c = q - i * K; P[i * LD + c] += coef * (v[i] * v[c]); }
+        for (Walk w(tid, K); w.more(); w.next()) P[w.i * LD + w.c] += coef * (v[w.i] * v[w.c]);
         __syncthreads();
     }
     // Sherman-Morrison: the row in xs enters (sign = +1) or leaves (sign = -1) the window
     __device__ void sm_update(double sign) const {
         matvec(xs, v);
-        const double xv = block_sum(tid < K ? xs[tid] * v[tid] : 0.0);
+        const double xv = dot(xs, v);
         rank1(-sign / (1.0 + sign * xv));
-        if (tid < K) bv[tid] += sign * (xs[tid] * xs[K]);
+        for (int j = tid; j < K; j += NT) bv[j] += sign * (xs[j] * xs[K]);
         __syncthreads();
     }
     __device__ void solve_beta() const { matvec(bv, beta); }           // beta = P b
     __device__ void store(int64_t i, bool have, T *coef, T *pred) const {
         const int64_t row = s + i;
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        if (coef && tid < K) coef[row * K + tid] = (T)(have ? beta[tid] : qnan);
+        if (coef)
+            for (int j = tid; j < K; j += NT) coef[row * K + j] = (T)(have ? beta[j] : qnan);
         if (pred) {
             load_row(i);
-            const double p = block_sum(tid < K ? xs[tid] * (have ? beta[tid] : qnan) : 0.0);
-            if (tid == 0) pred[row] = (T)p;
+            const double p = dot(xs, beta);
+            if (tid == 0) pred[row] = (T)(have ? p : qnan);
         }
     }
 };
 
 // ------------------------------------------------------------------ pass 1: per-chunk totals (decayed for RLS)
-template <typename T, bool RLS>
-__global__ void __launch_bounds__(256) kx_totals_kernel(const K4Args a) {
+template <typename T, bool RLS, int NT, bool GLOBAL>
+__global__ void __launch_bounds__(NT) ky_totals_kernel(const K4Args a) {
     extern __shared__ double lds[];
     const int64_t c = blockIdx.x;
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
-    XCtx<T> cx(a, G.start, G.first_chunk, lds);
+    YCtx<T, NT, GLOBAL> cx(a, G.start, G.first_chunk, lds);
     const int K = cx.K, nacc = cx.NS + (RLS ? 1 : 0);
     cx.zero();
     double decay = 1.0;
     for (int64_t i = ch.t0 - G.start; i < ch.t1 - G.start; ++i)
         if (cx.valid(i)) {
             if (RLS) {
-                for (int q = cx.tid; q < K * cx.LD; q += 256) cx.P[q] *= a.ff;
-                if (cx.tid < K) cx.bv[cx.tid] *= a.ff;
+                for (int q = cx.tid; q < K * cx.LD; q += NT) cx.P[q] *= a.ff;
+                for (int j = cx.tid; j < K; j += NT) cx.bv[j] *= a.ff;
                 decay *= a.ff;
                 __syncthreads();
             }
             cx.gram_add_row(i, 1.0);
         }
     double *out = a.totals + (size_t)c * nacc;
-    for (int q = cx.tid; q < K * K; q += 256) { const int i = q / K, cc = q - i * K; out[q] = cx.P[i * cx.LD + cc]; }
-    if (cx.tid < K) out[K * K + cx.tid] = cx.bv[cx.tid];
+    {
+        int q = cx.tid;
+        for (typename YCtx<T, NT, GLOBAL>::Walk w(cx.tid, K); w.more(); w.next(), q += NT) out[q] = cx.P[w.i * cx.LD + w.c];
+    }
+    for (int j = cx.tid; j < K; j += NT) out[K * K + j] = cx.bv[j];
     if (RLS && cx.tid == 0) out[cx.NS] = decay;
 }
 
 // ------------------------------------------------------------------ pass 3: rolling walk
-template <typename T>
-__global__ void __launch_bounds__(256) kx_rolling_walk_kernel(const K4Args a) {
+template <typename T, int NT, bool GLOBAL>
+__global__ void __launch_bounds__(NT) ky_rolling_walk_kernel(const K4Args a) {
     extern __shared__ double lds[];
     const int64_t c = blockIdx.x;
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
-    XCtx<T> cx(a, G.start, G.first_chunk, lds);
+    YCtx<T, NT, GLOBAL> cx(a, G.start, G.first_chunk, lds);
     const int K = cx.K, nacc = cx.NS;
     const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
     const int64_t w = a.window, mpv = G.mpv;
@@ -175,7 +211,8 @@ __global__ void __launch_bounds__(256) kx_rolling_walk_kernel(const K4Args a) {
 
     if (G.all_nan) {                                           // :893-900
         for (int64_t i = rel0; i < rel1; ++i) {
-            if (coef && cx.tid < K) coef[(G.start + i) * K + cx.tid] = (T)qnan;
+            if (coef)
+                for (int j = cx.tid; j < K; j += NT) coef[(G.start + i) * K + j] = (T)qnan;
             if (pred && cx.tid == 0) pred[G.start + i] = (T)qnan;
         }
         return;
@@ -249,13 +286,13 @@ __global__ void __launch_bounds__(256) kx_rolling_walk_kernel(const K4Args a) {
 }
 
 // ------------------------------------------------------------------ pass 3: RLS walk (RecursiveLeastSquares::update, literally)
-template <typename T>
-__global__ void __launch_bounds__(256) kx_rls_walk_kernel(const K4Args a) {
+template <typename T, int NT, bool GLOBAL>
+__global__ void __launch_bounds__(NT) ky_rls_walk_kernel(const K4Args a) {
     extern __shared__ double lds[];
     const int64_t c = blockIdx.x;
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
-    XCtx<T> cx(a, G.start, G.first_chunk, lds);
+    YCtx<T, NT, GLOBAL> cx(a, G.start, G.first_chunk, lds);
     const int K = cx.K, nacc = cx.NS + 1;
     const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
     T *coef = static_cast<T *>(a.coef);
@@ -269,59 +306,65 @@ __global__ void __launch_bounds__(256) kx_rls_walk_kernel(const K4Args a) {
         if (cx.valid(i)) {
             cx.load_row(i);
             cx.matvec(cx.xs, cx.v);                            // v = P x
-            const double xv = cx.block_sum(cx.tid < K ? cx.xs[cx.tid] * cx.v[cx.tid] : 0.0);
-            const double xb = cx.block_sum(cx.tid < K ? cx.xs[cx.tid] * cx.beta[cx.tid] : 0.0);
+            const double xv = cx.dot(cx.xs, cx.v);
+            const double xb = cx.dot(cx.xs, cx.beta);
             const double r = 1.0 + xv / ff;                    // :533
             const double err = cx.xs[K] - xb;
             // gain = P x / (r ff);  beta += gain * err;  P = P / ff - gain gain' r = (P - v v' / (r ff)) / ff
-            if (cx.tid < K) cx.beta[cx.tid] += cx.v[cx.tid] / (r * ff) * err;
+            for (int j = cx.tid; j < K; j += NT) cx.beta[j] += cx.v[j] / (r * ff) * err;
             const double coef_vv = -1.0 / (r * ff);
-            for (int q = cx.tid; q < K * K; q += 256) {
-                const int ii = q / K, cc = q - ii * K;
-                cx.P[ii * cx.LD + cc] = (cx.P[ii * cx.LD + cc] + coef_vv * (cx.v[ii] * cx.v[cc])) / ff;
-            }
+            for (typename YCtx<T, NT, GLOBAL>::Walk w(cx.tid, K); w.more(); w.next())
+                cx.P[w.i * cx.LD + w.c] = (cx.P[w.i * cx.LD + w.c] + coef_vv * (cx.v[w.i] * cx.v[w.c])) / ff;
             __syncthreads();
         }
         cx.store(i, true, coef, pred);
     }
 }
 
-template <typename T>
-static int kx_launch_t(pols_ctx *ctx, const K4Args &a, bool rls) {
-    const size_t lds = sizeof(double) * XCtx<T>::lds_doubles(a.k);
+template <typename T, int NT, bool GLOBAL>
+static int ky_launch_t(pols_ctx *ctx, const K4Args &a_in, bool rls) {
+    K4Args a = a_in;
+    const size_t lds = sizeof(double) * YCtx<T, NT, GLOBAL>::lds_doubles(a.k);
     const int ns = a.k * a.k + a.k;
-    static OncePerDevice attr_once;
-    if (attr_once.needed(ctx->device)) {
-        const void *fns[4] = {reinterpret_cast<const void *>(&kx_totals_kernel<T, false>), reinterpret_cast<const void *>(&kx_totals_kernel<T, true>),
-                              reinterpret_cast<const void *>(&kx_rolling_walk_kernel<T>), reinterpret_cast<const void *>(&kx_rls_walk_kernel<T>)};
-        for (const void *f : fns) POLS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr_once.done(ctx->device);
+    if (GLOBAL) {                                              // one K x K state per chunk (scratch slot 3)
+        void *st = nullptr;
+        int rc = ensure_scratch(ctx, 3, sizeof(double) * (size_t)a.n_chunks * a.k * (a.k | 1), &st);
+        if (rc) return rc;
+        a.state = static_cast<double *>(st);
+    } else {
+        static OncePerDevice attr_once;
+        if (attr_once.needed(ctx->device)) {
+            const void *fns[4] = {reinterpret_cast<const void *>(&ky_totals_kernel<T, false, NT, GLOBAL>), reinterpret_cast<const void *>(&ky_totals_kernel<T, true, NT, GLOBAL>),
+                                  reinterpret_cast<const void *>(&ky_rolling_walk_kernel<T, NT, GLOBAL>), reinterpret_cast<const void *>(&ky_rls_walk_kernel<T, NT, GLOBAL>)};
+            for (const void *f : fns) POLS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            attr_once.done(ctx->device);
+        }
     }
     timing_begin(ctx);
     if (rls) {
-        hipLaunchKernelGGL((kx_totals_kernel<T, true>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL((ky_totals_kernel<T, true, NT, GLOBAL>), dim3((unsigned)a.n_chunks), dim3(NT), lds, ctx->stream, a);
         chunk_scan_launch(ctx, a, ns, 2);
-        hipLaunchKernelGGL((kx_rls_walk_kernel<T>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL((ky_rls_walk_kernel<T, NT, GLOBAL>), dim3((unsigned)a.n_chunks), dim3(NT), lds, ctx->stream, a);
     } else {
-        hipLaunchKernelGGL((kx_totals_kernel<T, false>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL((ky_totals_kernel<T, false, NT, GLOBAL>), dim3((unsigned)a.n_chunks), dim3(NT), lds, ctx->stream, a);
         chunk_scan_launch(ctx, a, ns, 0);
-        hipLaunchKernelGGL((kx_rolling_walk_kernel<T>), dim3((unsigned)a.n_chunks), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL((ky_rolling_walk_kernel<T, NT, GLOBAL>), dim3((unsigned)a.n_chunks), dim3(NT), lds, ctx->stream, a);
     }
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
 
-int k4x_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
-    if (a.k > KX_MAX) return fail(POLS_ERR_UNSUPPORTED, "rolling: %d features > %d", a.k, KX_MAX);
-    ctx->last_kernel = dtype == POLS_F32 ? "k4x_rolling_inverse_f32" : "k4x_rolling_inverse_f64";
-    return dtype == POLS_F32 ? kx_launch_t<float>(ctx, a, false) : kx_launch_t<double>(ctx, a, false);
+int k4y_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
+    if (a.k > KY_MAX) return fail(POLS_ERR_UNSUPPORTED, "rolling: %d features > %d", a.k, KY_MAX);
+    ctx->last_kernel = dtype == POLS_F32 ? "k4y_rolling_inverse_hbm_f32" : "k4y_rolling_inverse_hbm_f64";
+    return dtype == POLS_F32 ? ky_launch_t<float, 1024, true>(ctx, a, false) : ky_launch_t<double, 1024, true>(ctx, a, false);
 }
 
-int k3x_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
-    if (a.k > KX_MAX) return fail(POLS_ERR_UNSUPPORTED, "rls: %d features > %d", a.k, KX_MAX);
-    ctx->last_kernel = dtype == POLS_F32 ? "k3x_rls_inverse_f32" : "k3x_rls_inverse_f64";
-    return dtype == POLS_F32 ? kx_launch_t<float>(ctx, a, true) : kx_launch_t<double>(ctx, a, true);
+int k3y_launch(pols_ctx *ctx, int dtype, const K4Args &a) {
+    if (a.k > KY_MAX) return fail(POLS_ERR_UNSUPPORTED, "rls: %d features > %d", a.k, KY_MAX);
+    ctx->last_kernel = dtype == POLS_F32 ? "k3y_rls_inverse_hbm_f32" : "k3y_rls_inverse_hbm_f64";
+    return dtype == POLS_F32 ? ky_launch_t<float, 1024, true>(ctx, a, true) : ky_launch_t<double, 1024, true>(ctx, a, true);
 }
 
 }  // namespace pols
