@@ -654,3 +654,23 @@ class LeastSquares:
         if kwargs.get("window_size"):
             return self.rolling_ols(*features, add_intercept=add_intercept, **kwargs)
         return self.least_squares(*features, add_intercept=add_intercept, **kwargs)
+
+    def predict(self, *features, name: Optional[str] = None, add_intercept: bool = False, null_policy: str = "zero") -> Expr:
+        """``pl.col("coefficients").least_squares.predict(x1, x2)`` (__init__.py:274-287): the namespace's column is a
+        coefficients struct (a ``Coefficients`` held in the frame, e.g. by ``with_columns(... mode="coefficients")``)."""
+        assert null_policy in _VALID_NULL_POLICIES, "'null_policy' must be one of {drop, ignore, zero}"
+        src = self._expr
+
+        def run(frame: Frame, over, eng):
+            coefficients = frame[src._name]
+            if not isinstance(coefficients, Coefficients):
+                raise TypeError(f"column '{src._name}' does not hold a coefficients struct")
+            return name or "predictions", predict(coefficients, *features, frame=frame, null_policy=null_policy,
+                                                  add_intercept=add_intercept, engine=eng)
+
+        return Expr(src._name, fn=run, alias=name or "predictions")
+
+    def predict_from_formula(self, formula: str, name: Optional[str] = None) -> Expr:  # __init__.py:289-295
+        features, add_intercept = _parse_formula(formula, include_dependent_variable=False)
+        has_const = any(f.output_name == "const" for f in features)
+        return self.predict(*features, name=name, add_intercept=add_intercept and not has_const)

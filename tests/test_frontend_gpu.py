@@ -160,6 +160,22 @@ def test_predict_complex_and_predict():                        # :903-944, :1075
     assert np.allclose(p, exp, rtol=1e-9, atol=1e-9)
 
 
+def test_predict_through_the_namespace():                      # tests/test_ols.py:1075-1092 spelled like the reference
+    from polars_ols_amd import col
+
+    df = _df(make_data(n_groups=10))
+    df = (df.with_columns(col("y").least_squares.rls(col("x1"), col("x2"), mode="predictions").over("group").alias("predictions_1"),
+                          col("y").least_squares.rls(col("x1"), col("x2"), mode="coefficients").over("group").alias("coefficients"))
+            .with_columns(col("coefficients").least_squares.predict(col("x1"), col("x2")).alias("predictions_2")))
+    assert np.allclose(df["predictions_1"], df["predictions_2"])
+    fit = df.with_columns(col("y").least_squares.from_formula("x1 + x2", mode="coefficients").over("group").alias("b"))
+    p = fit.select(col("b").least_squares.predict_from_formula("x1 + x2", name="p"))["p"]
+    exp = df.select(col("y").least_squares.from_formula("x1 + x2").over("group").alias("p"))["p"]
+    assert np.allclose(p, exp, rtol=1e-9, atol=1e-9)
+    with pytest.raises(TypeError):
+        df.select(col("y").least_squares.predict(col("x1")))
+
+
 def test_python_side_validation():                             # least_squares.py:73-77, 109-118, 266
     from polars_ols_amd import OLSKwargs, col, compute_least_squares
 
