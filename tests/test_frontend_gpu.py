@@ -176,6 +176,59 @@ def test_predict_through_the_namespace():                      # tests/test_ols.
         df.select(col("y").least_squares.predict(col("x1")))
 
 
+def test_fit_missing_data_coefficients():                      # tests/test_ols.py:130-176
+    from polars_ols_amd import col
+
+    d = insert_nulls(make_data(), ["y", "x1", "x2"], 0.1)
+    df = _df({k: d[k] for k in ("y", "x1", "x2")})
+    fit = lambda f, policy: f.select(col("y").least_squares.ols(col("x1"), col("x2"), null_policy=policy,  # noqa: E731
+                                                                mode="coefficients"))["coefficients"].values
+    keep_all = ~(np.isnan(d["y"]) | np.isnan(d["x1"]) | np.isnan(d["x2"]))
+    keep_y = ~np.isnan(d["y"])
+    assert np.allclose(fit(df, "zero"), fit(_df({k: np.nan_to_num(v) for k, v in df.items()}), "ignore"))
+    assert np.allclose(fit(df, "drop"), fit(_df({k: v[keep_all] for k, v in df.items()}), "ignore"))
+    assert np.allclose(fit(df, "drop_y_zero_x"), fit(_df({k: np.nan_to_num(v[keep_y]) for k, v in df.items()}), "ignore"))
+
+
+def test_all_empty_data():                                     # tests/test_ols.py:252-268
+    from polars_ols_amd import col
+
+    nan = np.nan
+    df = _df({"A": np.array([nan, 2.0, nan, 4.0]), "B": np.array([1.0, nan, 3.0, nan])})
+    r = df.select(col("A").least_squares.ols(col("B"), mode="residuals", null_policy="drop", solve_method="svd").alias("residuals"))["residuals"]
+    assert np.isnan(r).all()
+
+
+def test_moving_window_regressions_over():                     # tests/test_ols.py:844-900
+    from polars_ols_amd import col
+
+    d = make_data(n_groups=10)
+    df = _df(d)
+    out = df.select(
+        col("y").least_squares.rolling_ols(col("x1"), col("x2"), mode="coefficients", window_size=1_000_000, min_periods=2)
+        .over("group").alias("rolling"),
+        col("y").least_squares.rls(col("x1"), col("x2"), half_life=None, initial_state_covariance=1.0e6, mode="coefficients")
+        .over("group").alias("rls"),
+        col("y").least_squares.ols(col("x1"), col("x2"), mode="coefficients").over("group").alias("ols"))
+    ols_rows = out["ols"].to_rows()
+    for g in np.unique(d["group"]):
+        last = np.nonzero(d["group"] == g)[0][-1]
+        assert np.allclose(ols_rows[last], out["rolling"].values[last])
+        assert np.allclose(ols_rows[last], out["rls"].values[last], rtol=1e-4, atol=1e-4)
+
+
+def test_coefficients_shape_broadcast():                       # tests/test_ols.py:404-432
+    from polars_ols_amd import col
+
+    d = make_data(n_samples=5_000, n_groups=10)
+    df = _df(d)
+    c = df.select(col("y").least_squares.ols(col("x1"), col("x2"), mode="coefficients"))["coefficients"]
+    assert c.values.shape == (1, 2) and c.to_rows().shape == (5_000, 2)            # one struct, broadcast over the frame
+    cg = df.select(col("y").least_squares.ols(col("x1"), col("x2"), mode="coefficients").over("group"))["coefficients"]
+    rows = cg.to_rows()
+    assert rows.shape == (5_000, 2) and len(np.unique(np.column_stack([rows, d["group"]]), axis=0)) == 10
+
+
 def test_python_side_validation():                             # least_squares.py:73-77, 109-118, 266
     from polars_ols_amd import OLSKwargs, col, compute_least_squares
 
