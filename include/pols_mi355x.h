@@ -185,8 +185,10 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
 /* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions. */
 int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o);
 
-/* Replaces the `predict` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t,j] * coef[t,j]
- * (coef_rows == n_rows) or x . coef[g] per group (coef_rows == n_groups). */
+/* Replaces the `predict` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t,j] * coef[t,j].  `coef` holds one
+ * coefficient row per input row (coef_rows == n_rows, batch dtype, where `b->mem` says) -- what Polars broadcasts the
+ * coefficient struct to before the plugin sees it; b->add_intercept appends the literal 1.0 feature of
+ * polars_ols/least_squares.py:479-483; nulls are the caller's (the Python layer zero-fills or masks, :455-491). */
 int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, void *pred_out);
 
 /* mode="statistics": replaces the plugin `least_squares_statistics` (src/expressions.rs:468-509) and
