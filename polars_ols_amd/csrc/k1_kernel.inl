@@ -57,6 +57,7 @@ __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_
         load_chunk_raw<T, KT, HAS_W>(a, row0, c);
     } else {
         // ragged head / tail of a group: guarded scalar loads, rows outside [s, e) contribute zeros
+        // (full 16-byte loads with the neighbouring group's rows zeroed in registers measured 3-4 % SLOWER on ragged frames)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int64_t r = row0 + v;
@@ -624,7 +625,12 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // twice the groups in flight per CU (2 waves/SIMD x 4 SIMDs = 8) -- POLS_K1_SHAPE=team forces 256 threads
         const char *shape = std::getenv("POLS_K1_SHAPE");
         const bool want_wave = !(shape && !std::strcmp(shape, "team"));
-        if (want_wave && max_rows <= 64 * 4 * VEC && ctx->offs_aligned[1])
+        // (unaligned group starts: the chunk grid begins up to VEC - 1 rows before the group)
+        // Ragged frames (what `.over(key)` delivers): groups up to 1/8 beyond the 1 024 resident rows stay with the wave kernel, their
+        // overflow rows streamed twice -- 83.7 us against 101.2 us for the 256-thread team on 10 000 groups of 950..1 100 rows
+        // (scripts/bench_ragged.py); unaligned group starts no longer exclude it either (900..1 020 rows: 88.3 -> 76.9 us).
+        const int64_t wave_cap = 64 * 4 * VEC + 64 * 4 * VEC / 8;
+        if (want_wave && max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= wave_cap)
             return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);

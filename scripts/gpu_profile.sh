@@ -54,3 +54,4 @@ timeout 120 python $R/scripts/bench_layout.py 2>/dev/null | tail -1 > $O/${TAG}_
 rm -rf $O/kt9; timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt9 -o l -- python $R/scripts/bench_layout.py > /dev/null 2> $O/kt9.err
 f=$(find $O/kt9 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -v "at::native\|ROCPRIM_400001" "$f" > $O/${TAG}_kernel_stats_layout.csv && head -12 $O/${TAG}_kernel_stats_layout.csv | cut -c1-160
 timeout 120 python $R/scripts/bench_nulls.py 2>/dev/null | tail -1 > $O/${TAG}_bench_nulls.json; cat $O/${TAG}_bench_nulls.json
+timeout 120 python $R/scripts/bench_ragged.py 2>/dev/null | tail -1 > $O/${TAG}_bench_ragged.json; cat $O/${TAG}_bench_ragged.json
