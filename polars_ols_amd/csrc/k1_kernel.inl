@@ -333,7 +333,8 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 // TEAM = 256: one group per block; cross-wave reduction through LDS with ONE barrier.
 // FAST: the host verified that every group starts on a 16-byte boundary, has a multiple of VEC rows and fits
 // the RC * TEAM resident chunks -> no ragged-edge and no overflow code (fewer VGPRs, more groups in flight).
-// NPASS > 1 (FAST only): the Gram is accumulated in NPASS passes over the resident registers, each keeping 1 / NPASS of the
+// NPASS > 1 (every row resident -- FAST, or the host checked max_rows against the capacity): the Gram is accumulated in NPASS passes
+// over the resident registers, each keeping 1 / NPASS of the
 // accumulators live -- fewer VGPRs, one more workgroup per CU for the f64 team kernel.
 // Trailing workgroups of a fused launch (see K1Args::n_k1_blocks): worker w owns the groups w, w + n_workers, ...
 template <typename T>
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     const int64_t base = s - (s % VEC);                      // chunk grid is aligned to 16 bytes in every column
     const int64_t nch = (e - base + VEC - 1) / VEC;
 
-    static_assert(NPASS == 1 || FAST, "the multi-pass Gram has no streamed-overflow path");
+    // the multi-pass Gram has no streamed-overflow path: NPASS > 1 without FAST is launched only when every group fits the registers
     T acc[NACC];
     if constexpr (NPASS == 1) {
 #pragma unroll
@@ -387,7 +388,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     unsigned long long *dbg = a.dbg ? a.dbg + g * 8 : nullptr;
 #define K1_STAMP(i) do { if (dbg && tid == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     K1_STAMP(0);
-    if constexpr (!FAST) {
+    if constexpr (!FAST && NPASS == 1) {
         for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
             Chunk<T, KT, HAS_W> tmp;
             load_chunk<T, KT, HAS_W, false, NULLS>(a, base + c * VEC, s, e, tmp);
@@ -536,7 +537,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
             const int64_t c = (int64_t)rc * TEAM + tid;
             if (c < nch) predict_store<T, KT, HAS_W, FAST, NULLS>(a, res[rc], beta, base + c * VEC, s, e);
         }
-        if constexpr (!FAST) {
+        if constexpr (!FAST && NPASS == 1) {
             for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
                 Chunk<T, KT, HAS_W> tmp;
                 load_chunk<T, KT, HAS_W, false, NULLS>(a, base + c * VEC, s, e, tmp);
@@ -639,13 +640,21 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // f64, 6+ columns, aligned groups of up to 1 024 rows: TWO waves per group with 8 rows per lane (218-240 VGPRs, two waves per
         // SIMD) keep four groups in flight per CU where the 256-thread team keeps three -- 153 vs 160 us on 10 000 x 1 000 x 8, 174 vs
         // 177 us with weights (cfg3).  POLS_K1_F64_TEAM=256 goes back; POLS_K1_PASSES=3 splits the Gram in three.
+        // Ragged frames (group starts / sizes not multiples of 2 rows) take the same shape without the FAST specialisation as long as
+        // every group -- plus the up to VEC - 1 rows its chunk grid starts early -- stays resident; groups of up to 512 rows use half
+        // the resident chunks (10 000 groups of 900..1 020 rows: 165 -> 148 us; 50 000 groups of 400..500 rows: 126 -> 78 us).
         if constexpr (KT >= 6) {
             const char *t = std::getenv("POLS_K1_F64_TEAM");
-            if (!(t && std::atoi(t) == 256) && ctx->offs_aligned[0] && max_rows <= 128 * 4 * VEC && !std::getenv("POLS_K1_NOFAST") &&
-                !std::getenv("POLS_TIMELINE")) {
+            const bool al = ctx->offs_aligned[0] && !std::getenv("POLS_K1_NOFAST");
+            const int64_t need = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1);
+            if (!(t && std::atoi(t) == 256) && need <= 128 * 4 * VEC && !std::getenv("POLS_TIMELINE")) {
                 const char *pp = std::getenv("POLS_K1_PASSES");
-                if (pp && std::atoi(pp) == 3) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
-                if (!pp || std::atoi(pp) == 2) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 2>(ctx, a);
+                if (pp && std::atoi(pp) == 3 && al) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
+                if (!pp || std::atoi(pp) == 2) {
+                    if (need <= 128 * 2 * VEC)
+                        return al ? k1_launch_fast<T, KT, HAS_W, 128, 2, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, 128, 2, false, 2>(ctx, a);
+                    return al ? k1_launch_fast<T, KT, HAS_W, 128, 4, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, 128, 4, false, 2>(ctx, a);
+                }
             }
         }
 #endif

@@ -14,14 +14,17 @@ def main():
     eng = Engine(0)
     rng = np.random.default_rng(0)
     res = {}
-    for name, lo, hi in (("equal_1000", 1000, 1000), ("ragged_900_1020", 900, 1020), ("ragged_950_1100", 950, 1100), ("ragged_100_300", 100, 300)):
+    for name, lo, hi, dt in (("equal_1000", 1000, 1000, torch.float32), ("ragged_900_1020", 900, 1020, torch.float32),
+                             ("ragged_950_1100", 950, 1100, torch.float32), ("ragged_100_300", 100, 300, torch.float32),
+                             ("f64_equal_1000", 1000, 1000, torch.float64), ("f64_ragged_900_1020", 900, 1020, torch.float64),
+                             ("f64_ragged_400_500", 400, 500, torch.float64)):
         G = 10_000 if hi > 400 else 50_000
         sizes = rng.integers(lo, hi + 1, size=G)
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         n = int(offs[-1])
         g = torch.Generator(device="cuda").manual_seed(0)
-        cols = [torch.randn(n, device="cuda", generator=g) for _ in range(8)]
-        y = sum(cols) + 0.1 * torch.randn(n, device="cuda", generator=g)
+        cols = [torch.randn(n, device="cuda", generator=g, dtype=dt) for _ in range(8)]
+        y = sum(cols) + 0.1 * torch.randn(n, device="cuda", generator=g, dtype=dt)
         plan = eng.plan_least_squares(y, cols, offs, want=("pred",))
         for _ in range(10):
             plan.run()
@@ -31,7 +34,7 @@ def main():
         ms = eng.timing_collect()
         eng.timing(False)
         us = float(np.mean(ms) * 1e3)
-        res[name] = {"kernel": eng.last_kernel, "us": round(us, 1), "TBps": round(n * 40 / us / 1e6, 2)}
+        res[name] = {"kernel": eng.last_kernel, "us": round(us, 1), "TBps": round(n * (40 if dt == torch.float32 else 80) / us / 1e6, 2)}
         del cols, y, plan
     print(json.dumps(res))
 

@@ -85,8 +85,8 @@ def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, varian
                             want=("coef", "pred", "resid", "status"))
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True)
     _check(out, ref, dtype)
-    if hi <= 1000 and dtype == np.float32:
-        variant = "team64"                               # wave-per-group holds 1 024 f32 rows, aligned or not
+    if 120 < hi <= 1000:                                 # up to 1 024 rows, aligned or not: one wave per group (f32), two (f64, 6+ columns)
+        variant = "team64" if dtype == np.float32 else "team128"
     big_f64 = hi > 4000 and dtype == np.float64        # neither registers nor the LDS tile hold 5000 f64 rows: streamed path
     ok = eng.last_kernel.startswith("k5_gram_stream") if big_f64 else ((variant in eng.last_kernel) if engine_kind == "valu" else eng.last_kernel.startswith("k1m_"))
     assert ok, eng.last_kernel
