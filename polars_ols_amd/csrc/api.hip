@@ -64,8 +64,14 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
     for (; g < cnt; ++g) h0 = (h0 ^ u[g]) * P;
     int64_t mx = 0, ored = 0, mn = 0;
     for (int64_t i = 0; i < cnt; ++i) ored |= offs[i];
-    for (int64_t i = 1; i < cnt; ++i) { const int64_t d = offs[i] - offs[i - 1]; mn = d < mn ? d : mn; mx = d > mx ? d : mx; }
+    int64_t over = 0;                                  // rows beyond the 1 021 (+ 3 of chunk-grid slack) a wave-per-group f32 kernel keeps resident
+    for (int64_t i = 1; i < cnt; ++i) {
+        const int64_t d = offs[i] - offs[i - 1];
+        mn = d < mn ? d : mn; mx = d > mx ? d : mx;
+        over += d > 1021 ? d - 1021 : 0;
+    }
     if (mn < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending");
+    ctx->offs_wave_overflow = over;
     const uint64_t h[4] = {h0, h1, h2, h3};
     const uint64_t sum = ((h[0] * 31 + h[1]) * 31 + h[2]) * 31 + h[3];
     void *dptr = nullptr;

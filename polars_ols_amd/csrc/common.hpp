@@ -61,6 +61,7 @@ struct pols_ctx {
     int64_t offs_n = 0;
     uint64_t offs_sum = 0;
     int64_t offs_max_rows = 0;
+    int64_t offs_wave_overflow = 0;          // sum over groups of the rows beyond 1 021 (see k1_launch_kw)
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag
     int32_t epoch = 0;
     bool offs_aligned[2] = {false, false};   // every group start AND size a multiple of 2 / of 4 rows

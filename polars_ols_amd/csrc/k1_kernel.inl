@@ -630,8 +630,11 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // Ragged frames (what `.over(key)` delivers): groups up to 1/8 beyond the 1 024 resident rows stay with the wave kernel, their
         // overflow rows streamed twice -- 83.7 us against 101.2 us for the 256-thread team on 10 000 groups of 950..1 100 rows
         // (scripts/bench_ragged.py); unaligned group starts no longer exclude it either (900..1 020 rows: 88.3 -> 76.9 us).
-        const int64_t wave_cap = 64 * 4 * VEC + 64 * 4 * VEC / 8;
-        if (want_wave && max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= wave_cap)
+        // The rule: every group within twice the resident rows (one wave streams its overflow serially) and at most 1/16 of the
+        // frame's rows beyond them (each is read twice).
+        const int64_t wave_cap = 64 * 4 * VEC;
+        const int64_t need = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1);
+        if (want_wave && (need <= wave_cap || (need <= 2 * wave_cap && ctx->offs_wave_overflow * 16 <= a.n_rows)))
             return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);

@@ -47,6 +47,8 @@ def main():
     res["torch_index_9_columns_ms"] = timed(lambda: [c[order] for c in cols])
     plan = eng.plan_least_squares(moved[0], moved[1:], lay.offsets, want=("pred",))
     res["solve_ms"] = timed(lambda: plan.run())
+    res["solve_kernel"] = eng.last_kernel
+    res["group_rows_min_max"] = [int(np.diff(lay.offsets).min()), int(np.diff(lay.offsets).max())]
     # bytes: take reads the index (4 B) + 9 gathered 4-byte elements (each a 32 B sector at random) and writes 36 B per row
     res["take_useful_GBps"] = n * (4 + 2 * 4 * (k + 1)) / res["take_9_f32_columns_ms"] / 1e6
     print(json.dumps(res))
