@@ -550,6 +550,91 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 #undef K1_STAMP
 }
 
+#ifndef K1_NULLS_TU
+// K1t: groups of at most SUB * 2 * VEC rows -- SUB = 16: 128 f32 / 64 f64 rows (per-asset-per-month sized regressions), FOUR groups
+// per wave, one per 16-lane DPP row; SUB = 32: 256 / 128 rows, TWO groups per wave (one more all-reduce step: v_permlane16_swap).  A wave-per-group kernel spends its time in the per-group reduction + Cholesky with most lanes idle (650 M
+// groups/s whatever the size below 100 rows); here the reduction is a 4-step row all-reduce, after which every lane holds its own
+// group's Gram matrix and the (unrolled, register-resident) Cholesky runs once per wave for four groups.  No LDS, no barriers, no
+// early exit (the DPP steps need all 64 lanes active).
+constexpr int K1T_RC = 2;
+template <typename T, int KT, bool HAS_W, int K1T_SUB>
+__global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
+    static_assert(K1T_SUB == 16 || K1T_SUB == 32, "a team is one DPP row or two");
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NZ = KT + 1;
+    constexpr int NACC = NZ * (NZ + 1) / 2;
+    const int lane = threadIdx.x & 63, sub = lane & (K1T_SUB - 1);
+    const int64_t g = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / K1T_SUB) + (lane / K1T_SUB);
+    const bool live = g < a.n_groups;
+    const int64_t s = live ? a.offs[g] : 0, e = live ? a.offs[g + 1] : 0;
+    const int64_t base = s - (s % VEC);                      // chunk grid aligned to 16 bytes in every column
+    const int64_t nch = (e - base + VEC - 1) / VEC;          // <= K1T_SUB * K1T_RC: the host checked the largest group
+    T acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = T(0);
+    Chunk<T, KT, HAS_W> res[K1T_RC];
+#pragma unroll
+    for (int rc = 0; rc < K1T_RC; ++rc) {
+        const int64_t c = (int64_t)rc * K1T_SUB + sub;
+        if (c < nch) {
+            load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, res[rc]);
+            gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) {
+        acc[q] = row_allreduce(acc[q]);
+        if constexpr (K1T_SUB == 32) { T t = acc[q]; pair_rows(t, acc[q]); acc[q] = t; }   // rows [r0 + r1, r0 + r1, r2 + r3, r2 + r3]
+    }
+    T beta[KT];
+    int st = POLS_GROUP_OK;
+    if (e == s) {                                            // features.is_empty() -> zeros (ex.rs:357-359)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) beta[j] = T(0);
+        st = POLS_GROUP_EMPTY;
+    } else if (!chol_solve<T, KT>(acc, (T)a.alpha, beta, (T)a.pivot_tol)) {
+        st = POLS_GROUP_FALLBACK;                            // K6 re-solves this group
+    }
+    if (live && sub == 0) {
+        if (a.status) a.status[g] = st;
+        if (st == POLS_GROUP_FALLBACK && a.fb_flag) *a.fb_flag = a.epoch;
+    }
+    if (live && a.coef && sub < KT) {
+        T bv = T(0);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) bv = (sub == j) ? beta[j] : bv;
+        static_cast<T *>(a.coef)[g * KT + sub] = bv;
+    }
+    if (a.pred || a.resid) {
+#pragma unroll
+        for (int rc = 0; rc < K1T_RC; ++rc) {
+            const int64_t c = (int64_t)rc * K1T_SUB + sub;
+            if (c < nch) predict_store<T, KT, HAS_W, false>(a, res[rc], beta, base + c * VEC, s, e);
+        }
+    }
+}
+
+template <typename T, int KT, bool HAS_W, int K1T_SUB>
+static int k1t_launch(pols_ctx *ctx, const K1Args &a) {
+    char name[96];
+    std::snprintf(name, sizeof(name), "k1t_gram_chol_%s_k%d%s_sub%d_rc%d", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", K1T_SUB, K1T_RC);
+    const int64_t per_block = 4 * (64 / K1T_SUB);
+    const int64_t blocks = (a.n_groups + per_block - 1) / per_block;
+    if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
+    ctx->last_kernel = name;
+    ctx->last_fused = false;
+    K1Args aa = a;
+    aa.n_k1_blocks = 0;
+    hipEvent_t ev0, ev1;
+    if (timing_pair(ctx, &ev0, &ev1))
+        hipExtLaunchKernelGGL((k1t_kernel<T, KT, HAS_W, K1T_SUB>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
+    else
+        hipLaunchKernelGGL((k1t_kernel<T, KT, HAS_W, K1T_SUB>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+#endif
+
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
@@ -620,6 +705,15 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 template <typename T, int KT, bool HAS_W>
 static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
+#ifndef K1_NULLS_TU
+    if (!std::getenv("POLS_K1_NOTINY") && !std::getenv("POLS_TIMELINE")) {
+        const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
+        if (need <= 16 * K1T_RC * VEC) return k1t_launch<T, KT, HAS_W, 16>(ctx, a);
+        // (SUB = 32, two groups per wave up to 256 / 128 rows, measured SLOWER than one wave per group: 1 022 vs 910 us on 500 000
+        // f32 groups of 130..252 rows, 1 815 vs 1 217 us on f64 groups of 40..120 -- the kernel template keeps the variant, nothing
+        // launches it)
+    }
+#endif
     if (max_rows <= 64 * 2 * VEC) return k1_launch_variant<T, KT, HAS_W, 64, 2>(ctx, a, max_rows);
     if constexpr (sizeof(T) == 4) {
         // wave-per-group with 16 rows per lane: no LDS, no barriers, one reduction + one solve per group and

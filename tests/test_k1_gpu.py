@@ -72,7 +72,8 @@ def test_ols_equal_groups(eng, engine_kind, dtype, k):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("lo,hi,variant", [(12, 120, "team64"), (200, 1000, "team256"), (900, 1150, "team256"), (900, 5000, "team256")])
+@pytest.mark.parametrize("lo,hi,variant", [(12, 60, "k1t_"), (12, 120, "team64"), (130, 250, "team64"), (200, 1000, "team256"), (900, 1150, "team256"),
+                                           (900, 5000, "team256")])
 def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, variant):
     """Group starts are not multiples of the 16-byte vector width; sizes straddle every kernel variant, incl.
     groups larger than the register-resident capacity (overflow rows are streamed twice)."""
@@ -86,7 +87,9 @@ def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, varian
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True)
     _check(out, ref, dtype)
     if 120 < hi <= 1000:                                 # up to 1 024 rows, aligned or not: one wave per group (f32), two (f64, 6+ columns)
-        variant = "team64" if dtype == np.float32 else "team128"
+        variant = "team64" if (dtype == np.float32 or hi <= 256) else "team128"
+    if hi == 120 and dtype == np.float32:                # up to 128 f32 / 64 f64 rows: four groups per wave
+        variant = "sub16"
     if hi == 1150 and dtype == np.float32:               # a few rows beyond the wave's 1 024 resident ones: streamed by the same wave
         variant = "team64_rc4"
     big_f64 = hi > 4000 and dtype == np.float64        # neither registers nor the LDS tile hold 5000 f64 rows: streamed path
