@@ -556,8 +556,7 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 // groups/s whatever the size below 100 rows); here the reduction is a 4-step row all-reduce, after which every lane holds its own
 // group's Gram matrix and the (unrolled, register-resident) Cholesky runs once per wave for four groups.  No LDS, no barriers, no
 // early exit (the DPP steps need all 64 lanes active).
-constexpr int K1T_RC = 2;
-template <typename T, int KT, bool HAS_W, int K1T_SUB>
+template <typename T, int KT, bool HAS_W, int K1T_SUB, int K1T_RC>
 __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
     static_assert(K1T_SUB == 16 || K1T_SUB == 32, "a team is one DPP row or two");
     constexpr int VEC = Vec16<T>::N;
@@ -614,7 +613,7 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
     }
 }
 
-template <typename T, int KT, bool HAS_W, int K1T_SUB>
+template <typename T, int KT, bool HAS_W, int K1T_SUB, int K1T_RC>
 static int k1t_launch(pols_ctx *ctx, const K1Args &a) {
     char name[96];
     std::snprintf(name, sizeof(name), "k1t_gram_chol_%s_k%d%s_sub%d_rc%d", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", K1T_SUB, K1T_RC);
@@ -627,9 +626,9 @@ static int k1t_launch(pols_ctx *ctx, const K1Args &a) {
     aa.n_k1_blocks = 0;
     hipEvent_t ev0, ev1;
     if (timing_pair(ctx, &ev0, &ev1))
-        hipExtLaunchKernelGGL((k1t_kernel<T, KT, HAS_W, K1T_SUB>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
+        hipExtLaunchKernelGGL((k1t_kernel<T, KT, HAS_W, K1T_SUB, K1T_RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
     else
-        hipLaunchKernelGGL((k1t_kernel<T, KT, HAS_W, K1T_SUB>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+        hipLaunchKernelGGL((k1t_kernel<T, KT, HAS_W, K1T_SUB, K1T_RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
@@ -708,7 +707,8 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 #ifndef K1_NULLS_TU
     if (!std::getenv("POLS_K1_NOTINY") && !std::getenv("POLS_TIMELINE")) {
         const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
-        if (need <= 16 * K1T_RC * VEC) return k1t_launch<T, KT, HAS_W, 16>(ctx, a);
+        if (need <= 16 * 1 * VEC) return k1t_launch<T, KT, HAS_W, 16, 1>(ctx, a);      // one chunk per lane: a third fewer registers
+        if (need <= 16 * 2 * VEC) return k1t_launch<T, KT, HAS_W, 16, 2>(ctx, a);
         // (SUB = 32, two groups per wave up to 256 / 128 rows, measured SLOWER than one wave per group: 1 022 vs 910 us on 500 000
         // f32 groups of 130..252 rows, 1 815 vs 1 217 us on f64 groups of 40..120 -- the kernel template keeps the variant, nothing
         // launches it)
