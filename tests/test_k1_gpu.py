@@ -327,3 +327,45 @@ def test_contexts_are_independent_across_host_threads():
         assert len(sink) == 1 and not isinstance(sink[0], Exception), sink
         for key in ("coef", "pred"):
             assert torch.equal(a[key], sink[0][key]) or torch.allclose(a[key], sink[0][key], rtol=0, atol=0, equal_nan=True), key
+
+
+@pytest.mark.parametrize("dtype,lo,hi,tag", [(np.float32, 12, 40, "sub16_rc1"), (np.float32, 40, 120, "sub16_rc2"), (np.float64, 12, 30, "sub16_rc1"),
+                                             (np.float64, 20, 60, "sub16_rc2")])
+def test_many_tiny_groups_four_per_wave(eng, dtype, lo, hi, tag):
+    """K1t at scale: 300 000 ragged groups, four per wave.  Size-independent checks on every group (X'(y - yhat) = 0 through a
+    segmented sum, pred + resid == y, exact scaling in y) and oracle parity on a sample that includes both ends of the frame."""
+    import torch
+    from oracle import orc
+
+    G, k = 300_000, 5
+    rng = np.random.default_rng(hi)
+    sizes = rng.integers(lo, hi + 1, size=G)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    g = torch.Generator(device="cuda").manual_seed(hi)
+    cols = [torch.randn(N, generator=g, device="cuda", dtype=tdt) for _ in range(k)]
+    y = sum(cols) * 0.5 + 0.1 * torch.randn(N, generator=g, device="cuda", dtype=tdt) + 0.3
+    out = eng.least_squares(y, cols, offs, add_intercept=True, want=("coef", "pred", "resid", "status"))
+    assert tag in eng.last_kernel and eng.last_kernel.startswith("k1t_"), eng.last_kernel
+    assert int(out["status"].abs().sum()) == 0
+    tol = 1e-4 if dtype == np.float32 else 1e-9
+    assert torch.allclose(out["pred"] + out["resid"], y, atol=10 * tol)
+    gid = torch.repeat_interleave(torch.arange(G, device="cuda"), torch.as_tensor(sizes, device="cuda"))
+    r = out["resid"].double()
+    for c in cols + [torch.ones_like(y)]:                                          # normal equations, every group
+        dot = torch.zeros(G, device="cuda", dtype=torch.float64).index_add_(0, gid, c.double() * r)
+        assert float(dot.abs().max()) < (2e-3 if dtype == np.float32 else 1e-9) * hi
+    out2 = eng.least_squares(-3.0 * y, cols, offs, add_intercept=True, want=("coef",))
+    assert torch.allclose(out2["coef"], -3.0 * out["coef"], rtol=10 * tol, atol=10 * tol)
+    pick = np.array([0, 1, 2, 3, 4, 15, 16, 17, G // 2, G - 17, G - 3, G - 2, G - 1])
+    yh, ch, oh = [], [[] for _ in cols], [0]
+    for p in pick:
+        s, e = offs[p], offs[p + 1]
+        yh.append(y[s:e].cpu().numpy())
+        for j, c in enumerate(cols):
+            ch[j].append(c[s:e].cpu().numpy())
+        oh.append(oh[-1] + int(e - s))
+    ref = orc.batched_least_squares(np.concatenate(yh), [np.concatenate(c) for c in ch], np.array(oh, dtype=np.int64), add_intercept=True)
+    rt = TOL[dtype]
+    assert np.allclose(out["coef"].cpu().numpy()[pick], ref["coef"], rtol=rt, atol=rt)
