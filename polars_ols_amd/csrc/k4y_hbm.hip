@@ -18,7 +18,6 @@
 
 namespace pols {
 
-constexpr int KY_LDS_MAX = 128;      // the K x K state fits dynamic LDS up to here
 constexpr int KY_MAX = 1024;
 
 // NT threads; GLOBAL: the K x K state lives at a.state + chunk * K * LD instead of LDS (one workgroup owns it, so the barriers that

@@ -438,9 +438,9 @@ int pols_layout_create(pols_ctx *ctx, const int64_t *keys, int64_t n_rows, int m
 
 void pols_layout_destroy(pols_layout *L) {
     if (!L) return;
-    hipSetDevice(L->device);
-    if (L->arena) hipFree(L->arena);
-    if (L->d_offsets && L->offsets_own) hipFree(L->d_offsets);
+    (void)hipSetDevice(L->device);
+    if (L->arena) (void)hipFree(L->arena);
+    if (L->d_offsets && L->offsets_own) (void)hipFree(L->d_offsets);
     delete L;
 }
 
