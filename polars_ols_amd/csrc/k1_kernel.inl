@@ -357,7 +357,7 @@ __device__ __forceinline__ void k1_fixup_worker(const K1Args &a) {
 }
 
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
-__global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
+__device__ __forceinline__ void k1_body(const K1Args &a) {
     static_assert(!FUSED || TEAM == 64, "the fused fix-up counts solver WAVES");
     if constexpr (FUSED) {
         if ((int)blockIdx.x >= a.n_k1_blocks) { k1_fixup_worker<T>(a); return; }
@@ -550,6 +550,16 @@ __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
 #undef K1_STAMP
 }
 
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+__global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
+}
+// The same body held to 128 VGPRs (four waves per SIMD): the ragged one-chunk-per-lane wave kernel needs 130.
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k1_kernel_occ4(const K1Args a) {
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
+}
+
 #ifndef K1_NULLS_TU
 // K1t: groups of at most SUB * 2 * VEC rows -- SUB = 16: 128 f32 / 64 f64 rows (per-asset-per-month sized regressions), FOUR groups
 // per wave, one per 16-lane DPP row; SUB = 32: 256 / 128 rows, TWO groups per wave (one more all-reduce step: v_permlane16_swap).  A wave-per-group kernel spends its time in the per-group reduction + Cholesky with most lanes idle (650 M
@@ -660,10 +670,15 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         aa.dbg = static_cast<unsigned long long *>(d);
     }
     hipEvent_t ev0, ev1;
+    constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !FUSED && !NULLS;
+    void (*kern)(const K1Args) = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
+    if constexpr (OCC4) {
+        if (!std::getenv("POLS_K1_NOOCC4")) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
+    }
     if (timing_pair(ctx, &ev0, &ev1))
-        hipExtLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, ev0, ev1, 0, aa);
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, ev0, ev1, 0, aa);
     else
-        hipLaunchKernelGGL((k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>), dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, aa);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, aa);
     POLS_HIP(hipGetLastError());
     if (timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
     return POLS_OK;
@@ -714,6 +729,11 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // launches it)
     }
 #endif
+    if constexpr (sizeof(T) == 4) {
+        // up to 256 f32 rows (a year of trading days): one chunk per lane -- ~36 registers fewer, four waves per SIMD instead of three
+        if (max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= 64 * 1 * VEC && !std::getenv("POLS_K1_NORC1"))
+            return k1_launch_variant<T, KT, HAS_W, 64, 1>(ctx, a, max_rows);
+    }
     if (max_rows <= 64 * 2 * VEC) return k1_launch_variant<T, KT, HAS_W, 64, 2>(ctx, a, max_rows);
     if constexpr (sizeof(T) == 4) {
         // wave-per-group with 16 rows per lane: no LDS, no barriers, one reduction + one solve per group and
