@@ -252,7 +252,8 @@ __device__ __forceinline__ bool chol_solve(const T (&acc)[(KT + 1) * (KT + 2) / 
 // Wave-cooperative variant for the multi-pass kernel: G (packed upper triangle, wave totals already summed) and the factor
 // live in LDS, lane i owns row i of L -- a handful of VGPRs instead of the ~130 the unrolled version keeps live, which is
 // what decides how many f64 workgroups fit a CU.  Returns this lane's coefficient (lanes >= KT: 0).
-template <typename T, int KT>
+// WIDTH: the lanes that cooperate (64: a wave; 16: one DPP row of K1t, `lane` then counts inside the row).
+template <typename T, int KT, int WIDTH = 64>
 __device__ __forceinline__ T chol_solve_lds(const T *G, T alpha, T pivot_tol, T *L, T *rinv, int lane, bool &ok) {
     constexpr int NZ = KT + 1;
     if (lane < KT) {
@@ -282,13 +283,13 @@ __device__ __forceinline__ T chol_solve_lds(const T *G, T alpha, T pivot_tol, T 
 #pragma unroll
     for (int p = 0; p < KT; ++p) {                      // forward: t = L^-1 b
         if (lane == p) bi *= rinv[p];
-        const T tp = __shfl(bi, p);
+        const T tp = __shfl(bi, p, WIDTH);
         if (lane > p && lane < KT) bi = fma(-L[lane * KT + p], tp, bi);
     }
 #pragma unroll
     for (int p = KT - 1; p >= 0; --p) {                 // backward: beta = L^-T t
         if (lane == p) bi *= rinv[p];
-        const T bp = __shfl(bi, p);
+        const T bp = __shfl(bi, p, WIDTH);
         if (lane < p) bi = fma(-L[p * KT + lane], bp, bi);
     }
     return bi;
@@ -578,10 +579,59 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
     const int64_t s = live ? a.offs[g] : 0, e = live ? a.offs[g + 1] : 0;
     const int64_t base = s - (s % VEC);                      // chunk grid aligned to 16 bytes in every column
     const int64_t nch = (e - base + VEC - 1) / VEC;          // <= K1T_SUB * K1T_RC: the host checked the largest group
-    T acc[NACC];
+    constexpr bool TWO_PASS = sizeof(T) == 8 && KT >= 6 && K1T_SUB == 16;
+    T acc[TWO_PASS ? 1 : NACC];
+    Chunk<T, KT, HAS_W> res[K1T_RC];
+    T beta[KT];
+    int st = POLS_GROUP_OK;
+    if constexpr (TWO_PASS) {
+        // f64, 6+ columns: 45 f64 accumulators + the unrolled Cholesky are 230-256 VGPRs (two waves per SIMD).  Like the f64 team
+        // kernel, the Gram is taken in two passes over the resident rows (half the accumulators live at a time), the row totals go to
+        // LDS, and the row solves cooperatively there (lane i of the row owns row i of L).
+        constexpr int TEAMS = 256 / K1T_SUB;
+        constexpr int Q1 = ((NACC + 1) / 2 + 3) & ~3;        // entries of the first pass
+        __shared__ T gs[TEAMS][NACC + 3], lf[TEAMS][KT * KT], lr[TEAMS][KT], bc[TEAMS][KT];
+        const int team = threadIdx.x / K1T_SUB;
+#pragma unroll
+        for (int rc = 0; rc < K1T_RC; ++rc) {
+            const int64_t c = (int64_t)rc * K1T_SUB + sub;
+            if (c < nch) load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, res[rc]);
+        }
+        {
+            T p1[Q1];
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) p1[q] = T(0);
+#pragma unroll
+            for (int rc = 0; rc < K1T_RC; ++rc)
+                if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, 0, Q1>(p1, res[rc]);
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) { const T t = row_allreduce(p1[q]); if ((q % K1T_SUB) == sub) gs[team][q] = t; }
+        }
+        {
+            T p2[NACC - Q1];
+#pragma unroll
+            for (int q = 0; q < NACC - Q1; ++q) p2[q] = T(0);
+#pragma unroll
+            for (int rc = 0; rc < K1T_RC; ++rc)
+                if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, Q1, NACC>(p2, res[rc]);
+#pragma unroll
+            for (int q = 0; q < NACC - Q1; ++q) { const T t = row_allreduce(p2[q]); if (((q + Q1) % K1T_SUB) == sub) gs[team][q + Q1] = t; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        T bv = T(0);
+        if (e == s) st = POLS_GROUP_EMPTY;
+        else {
+            bool ok;
+            bv = chol_solve_lds<T, KT, K1T_SUB>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], lr[team], sub, ok);
+            if (!ok) st = POLS_GROUP_FALLBACK;
+        }
+        if (sub < KT) bc[team][sub] = bv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < KT; ++j) beta[j] = bc[team][j];
+    } else {
 #pragma unroll
     for (int q = 0; q < NACC; ++q) acc[q] = T(0);
-    Chunk<T, KT, HAS_W> res[K1T_RC];
 #pragma unroll
     for (int rc = 0; rc < K1T_RC; ++rc) {
         const int64_t c = (int64_t)rc * K1T_SUB + sub;
@@ -595,14 +645,13 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
         acc[q] = row_allreduce(acc[q]);
         if constexpr (K1T_SUB == 32) { T t = acc[q]; pair_rows(t, acc[q]); acc[q] = t; }   // rows [r0 + r1, r0 + r1, r2 + r3, r2 + r3]
     }
-    T beta[KT];
-    int st = POLS_GROUP_OK;
     if (e == s) {                                            // features.is_empty() -> zeros (ex.rs:357-359)
 #pragma unroll
         for (int j = 0; j < KT; ++j) beta[j] = T(0);
         st = POLS_GROUP_EMPTY;
     } else if (!chol_solve<T, KT>(acc, (T)a.alpha, beta, (T)a.pivot_tol)) {
         st = POLS_GROUP_FALLBACK;                            // K6 re-solves this group
+    }
     }
     if (live && sub == 0) {
         if (a.status) a.status[g] = st;
