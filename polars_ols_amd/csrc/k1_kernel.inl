@@ -773,6 +773,13 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
         if (need <= 16 * 1 * VEC) return k1t_launch<T, KT, HAS_W, 16, 1>(ctx, a);      // one chunk per lane: a third fewer registers
         if (need <= 16 * 2 * VEC) return k1t_launch<T, KT, HAS_W, 16, 2>(ctx, a);
+        // four chunks per lane (128 f64 / 256 f32 rows): f64 with 6+ columns has the registers for it since the two-pass form;
+        // f32 only on request (POLS_K1T_RC4=1: A/B against the one-chunk wave kernel)
+        if (need <= 16 * 4 * VEC) {
+            const char *r4 = std::getenv("POLS_K1T_RC4");
+            const bool want = r4 ? std::atoi(r4) != 0 : (sizeof(T) == 8 && KT >= 6);
+            if (want) return k1t_launch<T, KT, HAS_W, 16, 4>(ctx, a);
+        }
         // (SUB = 32, two groups per wave up to 256 / 128 rows, measured SLOWER than one wave per group: 1 022 vs 910 us on 500 000
         // f32 groups of 130..252 rows, 1 815 vs 1 217 us on f64 groups of 40..120 -- the kernel template keeps the variant, nothing
         // launches it)

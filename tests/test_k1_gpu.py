@@ -88,8 +88,8 @@ def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, varian
     _check(out, ref, dtype)
     if 120 < hi <= 1000:                                 # up to 1 024 rows, aligned or not: one wave per group (f32), two (f64, 6+ columns)
         variant = "team64" if (dtype == np.float32 or hi <= 256) else "team128"
-    if hi == 120 and dtype == np.float32:                # up to 128 f32 / 64 f64 rows: four groups per wave
-        variant = "sub16"
+    if hi == 120:                                        # up to 128 rows: four groups per wave (f64, 6+ columns: four chunks per lane)
+        variant = "sub16_rc2" if dtype == np.float32 else "sub16_rc4"
     if hi == 1150 and dtype == np.float32:               # a few rows beyond the wave's 1 024 resident ones: streamed by the same wave
         variant = "team64_rc4"
     big_f64 = hi > 4000 and dtype == np.float64        # neither registers nor the LDS tile hold 5000 f64 rows: streamed path
