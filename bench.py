@@ -138,8 +138,8 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str):
                                       want=("coef", "pred"), out=out)
         text = (f"BASELINE configs[4]: {Gtot} groups x {n} rows x {k} feats f64 elastic net alpha=0.001 l1_ratio=0.5, "
                 f"predictions (+coefficients), groups split over {world} GPU(s): {G} per GPU")
-        # the Gram pass reads X, y once; the prediction pass reads X again and writes predictions
-        return plan, G, "regressions/s", 8 * n * (k + 1) * G, text, "f64", out["coef"], "strong"
+        # whole path, one launch: X and y read once (8 n (k + 1) bytes per group), predictions written (8 n)
+        return plan, G, "regressions/s", 8 * n * (k + 1) * G + 8 * n * G, text, "f64", out["coef"], "strong"
     raise SystemExit(f"unknown --config {cfg}")
 
 

@@ -108,6 +108,10 @@ int pols_timing_enable(pols_ctx *ctx, int enable);
 int pols_timing_collect(pols_ctx *ctx, float *ms_out, int max);
 /* Name of the kernel variant the last compute entry launched (for profiles / DESIGN.md). */
 const char *pols_last_kernel_name(pols_ctx *ctx);
+/* Tuning / diagnostic knobs (engine choices for A/B measurements, debug stamps).  `key` is the name of the matching POLS_*
+ * environment variable, with or without the prefix; value NULL restores the default.  The environment is read ONCE, in
+ * pols_create(); no compute entry calls getenv. */
+int pols_set_option(pols_ctx *ctx, const char *key, const char *value);
 
 /* ---- problem description ------------------------------------------------- */
 
@@ -159,6 +163,11 @@ typedef struct {
     const void *weights;          /* sample_weights column or NULL (polars_ols/least_squares.py:190-196) */
     const uint8_t *valid;         /* optional row validity, 1 byte per row (1 = valid), or NULL = all valid */
     int32_t add_intercept;        /* append a ones column LAST, named "const" (least_squares.py:184-188) */
+    uint64_t offsets_generation;  /* 0: group_offsets is content-checked on every call (hash, then memcmp against the copy the
+                                     library keeps of what it last uploaded).  Non-zero: the caller PROMISES that the same
+                                     (group_offsets pointer, n_groups, offsets_generation) always names the same content and bumps
+                                     the value whenever it rewrites the array -- repeated calls on one frame then cost O(1) on
+                                     the host instead of a pass over the offsets */
 } pols_batch;
 
 typedef struct {

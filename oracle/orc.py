@@ -127,6 +127,17 @@ def solve_ridge_svd(y, x, alpha, rcond=None) -> np.ndarray:
     return beta[:, 0] if y.ndim == 1 else beta
 
 
+def solve_multi_target(y, x, alpha=0.0, rcond=None) -> np.ndarray:
+    """src/least_squares.rs:243-260: y is n x m, returns k x m."""
+    y, x = _f64(y), _f64(x)
+    n, k = x.shape
+    m = y.shape[1]
+    beta = np.empty((k, m))
+    lib().orc_solve_multi_target(_p(y), _p(x), C.c_int64(n), C.c_int(k), C.c_int(m), C.c_double(alpha),
+                                 C.c_int(rcond is not None), C.c_double(rcond or 0.0), _p(beta))
+    return beta
+
+
 def solve_elastic_net(y, x, alpha, l1_ratio=None, max_iter=1000, tol=1e-5, positive=False, solve_method=None):
     y, x = _f64(y), _f64(x)
     n, k = x.shape

@@ -58,7 +58,7 @@ class Batch(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("mem", C.c_int32), ("n_rows", C.c_int64), ("n_groups", C.c_int64),
                 ("group_offsets", C.POINTER(C.c_int64)), ("n_features", C.c_int32), ("y", C.c_void_p),
                 ("x_cols", C.POINTER(C.c_void_p)), ("weights", C.c_void_p), ("valid", C.c_void_p),
-                ("add_intercept", C.c_int32)]
+                ("add_intercept", C.c_int32), ("offsets_generation", C.c_uint64)]
 
 
 class Out(C.Structure):
@@ -73,7 +73,7 @@ class StatsOut(C.Structure):
 EXPORTS = [
     "pols_device_count", "pols_version", "pols_last_error", "pols_create", "pols_destroy", "pols_set_stream",
     "pols_use_private_stream",
-    "pols_synchronize", "pols_timing_enable", "pols_timing_collect", "pols_last_kernel_name",
+    "pols_synchronize", "pols_timing_enable", "pols_timing_collect", "pols_last_kernel_name", "pols_set_option",
     "pols_ols_params_default", "pols_rls_params_default", "pols_rolling_params_default",
     "pols_least_squares", "pols_recursive_least_squares", "pols_rolling_least_squares", "pols_predict",
     "pols_least_squares_statistics", "pols_multi_target_least_squares",
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         L.pols_synchronize.argtypes = [C.c_void_p]
         L.pols_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.pols_timing_collect.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.pols_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.pols_ols_params_default.argtypes = [C.POINTER(OlsParams)]
         L.pols_rls_params_default.argtypes = [C.POINTER(RlsParams)]
         L.pols_rolling_params_default.argtypes = [C.POINTER(RollingParams)]

@@ -1,11 +1,14 @@
 // api.hip -- C-ABI entry points of libpols_mi355x.so (see include/pols_mi355x.h).
 #include <algorithm>
 #include <cmath>
+#include <cctype>
 #include <cstdlib>
+#include <strings.h>
 #include <mutex>
 
 #include "common.hpp"
 #include "k1_gram_chol.hpp"
+#include "k2_resident.hpp"
 #include "k3_rls.hpp"
 #include "k4_rolling.hpp"
 #include "k5_enet.hpp"
@@ -15,6 +18,17 @@
 
 namespace pols {
 template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);   // k1m_f32.hip / k1m_f64.hip
+
+// solve_ridge_svd with a caller-supplied rcond (ls.rs:143-148) truncates singular values on EVERY group, so every non-empty group
+// is handed to the Jacobi-SVD pass: its status word becomes POLS_GROUP_FALLBACK and the call's epoch is published.
+__global__ void __launch_bounds__(256) mark_fallback_kernel(const int64_t *offs, int64_t n_groups, int32_t *status, int32_t *fb_flag,
+                                                            int32_t epoch, int only_if_not_empty) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) *fb_flag = epoch;
+    if (g >= n_groups) return;
+    if (only_if_not_empty) { if (status[g] != POLS_GROUP_EMPTY) status[g] = POLS_GROUP_FALLBACK; }
+    else status[g] = (offs[g + 1] == offs[g]) ? POLS_GROUP_EMPTY : POLS_GROUP_FALLBACK;
+}
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -49,14 +63,43 @@ int ensure_scratch(pols_ctx *ctx, int slot, size_t bytes, void **out) {
     return POLS_OK;
 }
 
-int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const int64_t **d_offs, int64_t *max_rows) {
-    // cheap content hash so steady-state calls on the same frame skip the re-upload
-    // (four independent multiply-xor chains in scalars, and the min / max / or reductions in their own vectorisable loops: the
-    // single chain was ~40 us per call at 10 000 groups)
+int upload_small(pols_ctx *ctx, void *dst_device, const void *src, size_t bytes) {
+    if (bytes == 0) return POLS_OK;
+    auto &slot = ctx->pinned[ctx->pinned_next];
+    ctx->pinned_next = (ctx->pinned_next + 1) % 4;
+    if (slot.busy) { POLS_HIP(hipEventSynchronize(slot.done)); slot.busy = false; }   // long complete in steady state
+    if (bytes > slot.cap) {
+        if (slot.ptr) POLS_HIP(hipHostFree(slot.ptr));
+        slot.ptr = nullptr; slot.cap = 0;
+        const size_t want = std::max(bytes, (size_t)1 << 16);
+        POLS_HIP(hipHostMalloc(&slot.ptr, want, hipHostMallocDefault));
+        slot.cap = want;
+    }
+    if (!slot.done) POLS_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    std::memcpy(slot.ptr, src, bytes);
+    POLS_HIP(hipMemcpyAsync(dst_device, slot.ptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    POLS_HIP(hipEventRecord(slot.done, ctx->stream));
+    slot.busy = true;
+    return POLS_OK;
+}
+
+int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const int64_t **d_offs, int64_t *max_rows,
+                   uint64_t generation) {
+    const int64_t cnt = n_groups + 1;
+    const size_t bytes = sizeof(int64_t) * (size_t)cnt;
+    // Promised hit: the caller vouches that (pointer, count, generation) names the same content as last time -- O(1), what a
+    // marshalled Plan passes.  The statistics of the offsets (largest group, alignment, overflow rows) are cached with them.
+    if (generation != 0 && ctx->scratch[0].ptr && ctx->offs_host == offs && ctx->offs_n == n_groups &&
+        ctx->offs_generation == generation) {
+        *d_offs = static_cast<const int64_t *>(ctx->scratch[0].ptr);
+        *max_rows = ctx->offs_max_rows;
+        return POLS_OK;
+    }
+    // Otherwise the content decides.  A cheap hash (four independent multiply-xor chains) picks the candidate, a memcmp
+    // against the host copy of what was uploaded CONFIRMS it: a collision can never make two frames share offsets.
     uint64_t h0 = 1469598103934665603ULL, h1 = 0x9E3779B97F4A7C15ULL, h2 = 0xC2B2AE3D27D4EB4FULL, h3 = 0x165667B19E3779F9ULL;
     const uint64_t P = 1099511628211ULL;
     const uint64_t *u = reinterpret_cast<const uint64_t *>(offs);
-    const int64_t cnt = n_groups + 1;
     int64_t g = 0;
     for (; g + 4 <= cnt; g += 4) {
         h0 = (h0 ^ u[g]) * P; h1 = (h1 ^ u[g + 1]) * P; h2 = (h2 ^ u[g + 2]) * P; h3 = (h3 ^ u[g + 3]) * P;
@@ -71,26 +114,71 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
         over += d > 1021 ? d - 1021 : 0;
     }
     if (mn < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending");
-    ctx->offs_wave_overflow = over;
-    const uint64_t h[4] = {h0, h1, h2, h3};
-    const uint64_t sum = ((h[0] * 31 + h[1]) * 31 + h[2]) * 31 + h[3];
-    void *dptr = nullptr;
-    const size_t bytes = sizeof(int64_t) * (size_t)(n_groups + 1);
-    const bool hit = ctx->scratch[0].ptr && ctx->offs_n == n_groups && ctx->offs_sum == sum && ctx->scratch[0].cap >= bytes;
+    const uint64_t sum = ((h0 * 31 + h1) * 31 + h2) * 31 + h3;
+    const bool hit = ctx->scratch[0].ptr && ctx->offs_n == n_groups && ctx->offs_sum == sum &&
+                     ctx->offs_copy.size() == (size_t)cnt && std::memcmp(ctx->offs_copy.data(), offs, bytes) == 0;
     if (!hit) {
+        void *dptr = nullptr;
         int rc = ensure_scratch(ctx, 0, bytes, &dptr);
         if (rc) return rc;
-        POLS_HIP(hipMemcpyAsync(dptr, offs, bytes, hipMemcpyHostToDevice, ctx->stream));
-        POLS_HIP(hipStreamSynchronize(ctx->stream));  // the host array may be freed by the caller after return
+        if ((rc = upload_small(ctx, dptr, offs, bytes))) return rc;   // pinned ring: no stream synchronisation
+        ctx->offs_copy.assign(offs, offs + cnt);
         ctx->offs_n = n_groups;
         ctx->offs_sum = sum;
-        ctx->offs_max_rows = mx;
+        ctx->offs_id++;
     }
+    ctx->offs_host = offs;
+    ctx->offs_generation = generation;
+    ctx->offs_max_rows = mx;
+    ctx->offs_wave_overflow = over;
     ctx->offs_aligned[0] = (ored & 1) == 0;
     ctx->offs_aligned[1] = (ored & 3) == 0;
     *d_offs = static_cast<const int64_t *>(ctx->scratch[0].ptr);
     *max_rows = mx;
     return POLS_OK;
+}
+
+// ------------------------------------------------------------------ options (POLS_* knobs)
+static bool ieq(const char *a, const char *b) {
+    for (; *a && *b; ++a, ++b)
+        if (std::tolower((unsigned char)*a) != std::tolower((unsigned char)*b)) return false;
+    return *a == *b;
+}
+
+bool options_set(Options &o, const char *key, const char *v) {
+    if (!key) return false;
+    if (!strncasecmp(key, "POLS_", 5)) key += 5;
+    const bool on = v != nullptr;
+    const Options d;
+    if (ieq(key, "TIMELINE")) o.timeline = on;
+    else if (ieq(key, "K1_NOOCC4")) o.k1_noocc4 = on;
+    else if (ieq(key, "K1_NOFAST")) o.k1_nofast = on;
+    else if (ieq(key, "K1_NOTINY")) o.k1_notiny = on;
+    else if (ieq(key, "K1_NORC1")) o.k1_norc1 = on;
+    else if (ieq(key, "K1_SHAPE")) o.k1_shape_team = on && ieq(v, "team");
+    else if (ieq(key, "K1_F64_TEAM")) o.k1_f64_team256 = on && std::atoi(v) == 256;
+    else if (ieq(key, "KG_NOYV")) o.kg_noyv = on;
+    else if (ieq(key, "FUSED_FIXUP")) o.fused_fixup = on;
+    else if (ieq(key, "K1_PASSES")) o.k1_passes = on ? std::atoi(v) : d.k1_passes;
+    else if (ieq(key, "K1T_RC4")) o.k1t_rc4 = on ? (std::atoi(v) != 0) : d.k1t_rc4;
+    else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
+    else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : 0;
+    else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : 0;
+    else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
+    else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
+    else return false;
+    return true;
+}
+
+void options_from_env(Options &o) {
+    static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
+                                       "KG_NOYV", "FUSED_FIXUP", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
+                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE"};
+    char name[64];
+    for (const char *k : keys) {
+        std::snprintf(name, sizeof(name), "POLS_%s", k);
+        if (const char *v = std::getenv(name)) options_set(o, k, v);
+    }
 }
 
 static bool timing_sampled(pols_ctx *ctx) {           // every timing_stride-th eligible launch is timed
@@ -261,7 +349,14 @@ int pols_create(int device_id, pols_ctx **out) {
         return fail(POLS_ERR_HIP, "hipStreamCreate failed");
     }
     ctx->stream = ctx->own_stream;
+    options_from_env(ctx->opt);            // the only getenv calls of the library: no launch path reads the environment
     *out = ctx;
+    return POLS_OK;
+}
+
+int pols_set_option(pols_ctx *ctx, const char *key, const char *value) {
+    if (!ctx || !key) return fail(POLS_ERR_INVALID, "ctx / key is NULL");
+    if (!options_set(ctx->opt, key, value)) return fail(POLS_ERR_INVALID, "unknown option '%s'", key);
     return POLS_OK;
 }
 
@@ -273,6 +368,10 @@ void pols_destroy(pols_ctx *ctx) {
         if (s.ptr) hipFree(s.ptr);
     if (ctx->fb_flag) hipFree(ctx->fb_flag);
     for (auto &t : ctx->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    for (auto &ps : ctx->pinned) {
+        if (ps.done) hipEventDestroy(ps.done);
+        if (ps.ptr) hipHostFree(ps.ptr);
+    }
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -374,7 +473,7 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     int rc;
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
-    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows, b->offsets_generation))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups * m, kt, o, &st))) return rc;
     const size_t G = (size_t)b->n_groups;
@@ -412,8 +511,7 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     table.insert(table.end(), yptr.begin(), yptr.end());
     table.insert(table.end(), pptr.begin(), pptr.end());
     if ((rc = ensure_scratch(ctx, 6, sizeof(void *) * table.size(), &tab))) return rc;
-    POLS_HIP(hipMemcpyAsync(tab, table.data(), sizeof(void *) * table.size(), hipMemcpyHostToDevice, ctx->stream));
-    POLS_HIP(hipStreamSynchronize(ctx->stream));                       // `table` is a local
+    if ((rc = upload_small(ctx, tab, table.data(), sizeof(void *) * table.size()))) return rc;   // `table` is a local: pinned ring
     const size_t gram_b = round256(mat * G), part_b = round256(mat * G * (size_t)splits), c64_b = round256(sizeof(double) * G * kt * m);
     const bool nulls = p->null_policy != POLS_NULL_IGNORE;
     const size_t mask_b = nulls ? round256((size_t)b->n_rows) + round256(sizeof(double) * G) : 0;
@@ -527,7 +625,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     }
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
-    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows, b->offsets_generation))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
     auto finish = [&](double *gram) -> int {
@@ -555,8 +653,8 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     const double pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : 0.0;
     K6Args ka;
     int fix_workers = 0;
-    auto prepare_fix = [&]() -> int {                           // arguments + work area of the fix-up pass
-        const int workers = (int)std::min<int64_t>(b->n_groups, 64);
+    auto prepare_fix = [&](int max_workers = 64) -> int {       // arguments + work area of the fix-up pass
+        const int workers = (int)std::min<int64_t>(b->n_groups, max_workers);
         const int64_t stride = std::max<int64_t>(1, max_rows) * (kt + 1);
         void *wk = nullptr;
         int w_use = workers;
@@ -590,8 +688,55 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         return k6_launch(ctx, b->dtype, ka, fix_workers);
     };
 
-    // Streamed three-launch path: elastic net always; OLS / ridge when the group does not fit the fused kernels
-    // (16..31 features, or rows beyond both K1's registers and K1m's LDS tile).  POLS_STATIC_ENGINE=stream forces it.
+    // solve_ridge_svd with a caller-supplied rcond (ls.rs:143-148): singular values below rcond * s_max are dropped on EVERY
+    // group, full rank or not -- a truncated solve is not the normal-equation solution, so the Jacobi-SVD kernel takes all of
+    // them (one workgroup per group from a pool of up to 2 048 workers; an opt-in, rarely used form of the call).
+    if (!enet && !ols_branch && m == POLS_SOLVE_SVD && p->has_rcond) {
+        if ((rc = prepare_fix(2048))) return rc;
+        hipLaunchKernelGGL(mark_fallback_kernel, dim3((unsigned)((b->n_groups + 255) / 256)), dim3(256), 0, ctx->stream, d_offs,
+                           b->n_groups, st.status, ctx->fb_flag, ctx->epoch, 0);
+        POLS_HIP(hipGetLastError());
+        ctx->last_kernel = "k6_small_svd_all_groups";
+        if ((rc = k6_launch(ctx, b->dtype, ka, fix_workers))) return rc;
+        return finish(nullptr);
+    }
+
+    // K2 (k2_resident.hip): rows resident in registers, X'X on the matrix cores, the solver in the same workgroup -- X is read
+    // once whatever the solver.  Elastic net / lasso, explicit LU, and OLS / ridge beyond K1's eight columns or resident rows,
+    // whenever the largest group fits; POLS_STATIC_ENGINE=stream | nok2 go back to the three-launch path / K1m.
+    {
+        const bool f32 = b->dtype == POLS_F32;
+        const int vec = f32 ? 4 : 2;
+        const bool aligned = ctx->offs_aligned[f32 ? 1 : 0];
+        const bool k2_ok = !nulls && kt <= K2_KMAX && k2_fits(b->dtype, kt, max_rows, aligned) && ctx->opt.static_engine != 1 &&
+                           ctx->opt.static_engine != 3;
+        const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
+        // POLS_K1_ENGINE=valu | mfma keep the K1 / K1m kernels reachable for the shapes they cover (A/B measurements, tests)
+        const bool legacy_forced = (ctx->opt.k1_engine == 2 && kt <= K1M_MAX_KT) || (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT);
+        const bool want = enet || m == POLS_SOLVE_LU || ctx->opt.static_engine == 2 || (!k1_resident && !legacy_forced);
+        if (k2_ok && want) {
+            K2Args a2;
+            std::memset(&a2, 0, sizeof(a2));
+            a2.y = st.y; a2.w = st.w;
+            for (int j = 0; j < b->n_features; ++j) a2.x[j] = st.x[j];
+            a2.offs = d_offs; a2.n_groups = b->n_groups; a2.n_rows = b->n_rows;
+            a2.coef = st.coef; a2.pred = st.pred; a2.resid = st.resid; a2.status = st.status;
+            a2.k_user = b->n_features; a2.kt = kt;
+            a2.solver = enet ? (m == POLS_SOLVE_CD_ACTIVE_SET ? K2_CD_ACTIVE_SET : K2_CD) : (m == POLS_SOLVE_LU ? K2_LU : K2_CHOL);
+            // solve_ridge (None / "chol"): Cholesky, and on failure LU (ls.rs:358-363); "svd" and the OLS branch flag for the SVD pass
+            a2.lu_fallback = (!enet && !ols_branch && m != POLS_SOLVE_SVD) ? 1 : 0;
+            a2.alpha = enet ? alpha : ridge_alpha;
+            a2.l1_ratio = enet_l1; a2.tol = p->tol; a2.max_iter = p->max_iter; a2.positive = positive ? 1 : 0;
+            a2.pivot_tol = pivot_tol;
+            a2.fb_flag = enet ? nullptr : ctx->fb_flag; a2.epoch = ctx->epoch;
+            if ((rc = k2_launch(ctx, b->dtype, a2, max_rows))) return rc;
+            if ((rc = svd_fixup())) return rc;
+            return finish(nullptr);
+        }
+    }
+
+    // Streamed three-launch path: elastic net / 16..31 features when the group does not fit K2's registers; OLS / ridge when
+    // it fits neither the fused kernels nor K1m's LDS tile.  POLS_STATIC_ENGINE=stream forces it.
     bool stream = enet;
     if (!enet) {
         const bool f32 = b->dtype == POLS_F32;
@@ -601,7 +746,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
         // null policies: the register-resident K1 has a NULLS family; everything else goes through the streamed kernels
         stream = (nulls && !k1_resident) || kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
-        if (const char *force = std::getenv("POLS_STATIC_ENGINE")) stream = stream || !std::strcmp(force, "stream");
+        stream = stream || ctx->opt.static_engine == 1;
     }
     if (stream) {
         // one streaming Gram pass, the small solve (Gram-form CD or Cholesky), then (only if asked for) a prediction pass
@@ -634,6 +779,8 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         } else {
             ca.alpha = ridge_alpha;
             ca.pivot_tol = pivot_tol;
+            ca.solver = (m == POLS_SOLVE_LU) ? 1 : 0;
+            ca.lu_fallback = (!ols_branch && m != POLS_SOLVE_SVD) ? 1 : 0;
             ca.fb_flag = ctx->fb_flag; ca.epoch = ctx->epoch;
             if ((rc = gram_solve_launch(ctx, b->dtype, ca))) return rc;
         }
@@ -670,7 +817,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     if ((rc = prepare_fix())) return rc;
     // Opt-in (POLS_FUSED_FIXUP=1): measured on cfg2 it saves 1 % end to end (74.3 vs 75.2 us per call -- the no-op fix-up dispatch
     // mostly overlaps the next call's ramp-up) but the polling tail lengthens the solver kernel itself by ~2 us.
-    if (std::getenv("POLS_FUSED_FIXUP")) {
+    if (ctx->opt.fused_fixup) {
         void *tg = nullptr;                                   // persistent tag words; a fresh (or re-grown) buffer is cleared once
         const void *before = ctx->scratch[8].ptr;
         if ((rc = ensure_scratch(ctx, 8, sizeof(int32_t) * (size_t)b->n_groups, &tg))) return rc;
@@ -833,7 +980,7 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, con
     if (b->add_intercept || b->weights)
         return fail(POLS_ERR_INVALID, "dynamic models take pre-processed columns: apply sqrt(w) / append the ones column "
                                       "before the call, exactly like polars_ols/least_squares.py:184-196 does for the plugin");
-    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, d_offs, max_rows))) return rc;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, d_offs, max_rows, b->offsets_generation))) return rc;
     return stage_inputs(ctx, b, b->n_rows, b->n_features, o, st);
 }
 
@@ -853,8 +1000,7 @@ static int upload_column_table(pols_ctx *ctx, const Staged &st, int k, K4Args *a
     int rc = dynamic_slot6(ctx, &d);
     if (rc) return rc;
     char *tab = static_cast<char *>(d) + sizeof(double) * K4Y_KMAX;
-    POLS_HIP(hipMemcpyAsync(tab, st.x.data(), sizeof(void *) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
-    POLS_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = upload_small(ctx, tab, st.x.data(), sizeof(void *) * (size_t)k))) return rc;
     a->xtab = reinterpret_cast<const void *const *>(tab);
     return POLS_OK;
 }
@@ -881,8 +1027,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     if (p->initial_state_mean) {
         void *d = nullptr;
         if ((rc = dynamic_slot6(ctx, &d))) return rc;
-        POLS_HIP(hipMemcpyAsync(d, p->initial_state_mean, sizeof(double) * b->n_features, hipMemcpyHostToDevice, ctx->stream));
-        POLS_HIP(hipStreamSynchronize(ctx->stream));   // the host array belongs to the caller
+        if ((rc = upload_small(ctx, d, p->initial_state_mean, sizeof(double) * b->n_features))) return rc;   // the host array belongs to the caller
         a.mean0 = static_cast<const double *>(d);
     }
     // Long sequences: the chunk-parallel information-form scan (K3s); short ones: the wave-per-sequence P-form
@@ -891,10 +1036,8 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     // kernels that propagate the inverse (k4x_inverse.hip).
     const bool wide = b->n_features > K4_KMAX, xwide = b->n_features > POLS_MAX_FEATURES;
     bool scan = max_rows > 4096 || wide;
-    if (const char *force = std::getenv("POLS_RLS_ENGINE")) {
-        if (!std::strcmp(force, "seq") && !wide) scan = false;
-        if (!std::strcmp(force, "scan")) scan = true;
-    }
+    if (ctx->opt.rls_engine == 1 && !wide) scan = false;
+    if (ctx->opt.rls_engine == 2) scan = true;
     if (scan) {
         const int k = b->n_features;
         K4Args s4;
@@ -938,7 +1081,7 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     // uncoalesced and more concurrent lanes cost more in the memory system than they win in parallelism)
     const int64_t chunk_len = std::min<int64_t>(std::max(max_chunk, min_chunk), std::max<int64_t>(min_chunk, N / 16384));
     auto &cc = ctx->chunk_cache;
-    if (!hv && cc.tab && cc.tab == ctx->scratch[4].ptr && cc.offs_sum == ctx->offs_sum && cc.n_groups == b->n_groups &&
+    if (!hv && cc.tab && cc.tab == ctx->scratch[10].ptr && cc.offs_id == ctx->offs_id && cc.n_groups == b->n_groups &&
         cc.n_rows == N && cc.mp == mp && cc.chunk_len == (int32_t)chunk_len) {      // same frame as the last call
         void *tot = nullptr;
         if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)slots * std::max<size_t>(1, (size_t)cc.n_chunks), &tot))) return rc;
@@ -987,16 +1130,16 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     const size_t b_chunks = round256(sizeof(K4Chunk) * chunks.size());
     const size_t b_cnt = hv ? round256(sizeof(int32_t) * (size_t)N) : 0;
     void *tab = nullptr, *tot = nullptr;
-    if ((rc = ensure_scratch(ctx, 4, b_groups + b_chunks + 2 * b_cnt + 256, &tab))) return rc;
+    cc.tab = nullptr;                                  // the slot is about to be rewritten (and possibly re-allocated)
+    if ((rc = ensure_scratch(ctx, 10, b_groups + b_chunks + 2 * b_cnt + 256, &tab))) return rc;   // slot 10 belongs to these tables alone
     if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)slots * std::max<size_t>(1, chunks.size()), &tot))) return rc;
     char *tp = static_cast<char *>(tab);
-    POLS_HIP(hipMemcpyAsync(tp, groups.data(), sizeof(K4Group) * groups.size(), hipMemcpyHostToDevice, ctx->stream));
-    POLS_HIP(hipMemcpyAsync(tp + b_groups, chunks.data(), sizeof(K4Chunk) * chunks.size(), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload_small(ctx, tp, groups.data(), sizeof(K4Group) * groups.size()))) return rc;   // locals: through the pinned ring
+    if ((rc = upload_small(ctx, tp + b_groups, chunks.data(), sizeof(K4Chunk) * chunks.size()))) return rc;
     if (hv) {
-        POLS_HIP(hipMemcpyAsync(tp + b_groups + b_chunks, cnt.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
-        POLS_HIP(hipMemcpyAsync(tp + b_groups + b_chunks + b_cnt, vidx.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload_small(ctx, tp + b_groups + b_chunks, cnt.data(), sizeof(int32_t) * (size_t)N))) return rc;
+        if ((rc = upload_small(ctx, tp + b_groups + b_chunks + b_cnt, vidx.data(), sizeof(int32_t) * (size_t)N))) return rc;
     }
-    POLS_HIP(hipStreamSynchronize(ctx->stream));   // the vectors above are locals
     a->groups = reinterpret_cast<const K4Group *>(tp);
     a->chunks = reinterpret_cast<const K4Chunk *>(tp + b_groups);
     a->cnt = hv ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks) : nullptr;
@@ -1007,7 +1150,7 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     a->chunk_len = (int32_t)chunk_len;
     cc.tab = nullptr;
     if (!hv) {
-        cc.offs_sum = ctx->offs_sum; cc.n_groups = b->n_groups; cc.n_rows = N; cc.mp = mp; cc.n_chunks = a->n_chunks;
+        cc.offs_id = ctx->offs_id; cc.n_groups = b->n_groups; cc.n_rows = N; cc.mp = mp; cc.n_chunks = a->n_chunks;
         cc.chunk_len = (int32_t)chunk_len; cc.tab = tab; cc.b_groups = b_groups;
     }
     return POLS_OK;
@@ -1063,7 +1206,7 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
     if (b->n_rows == 0) return POLS_OK;
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
-    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows))) return rc;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows, b->offsets_generation))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_rows, kt, &o, &st))) return rc;
     const void *d_coef = coef;
@@ -1077,8 +1220,7 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
     if (kt > POLS_MAX_FEATURES) {                                  // wide frames: column pointers through a device table
         void *tab = nullptr;
         if ((rc = ensure_scratch(ctx, 6, sizeof(void *) * (size_t)b->n_features, &tab))) return rc;
-        POLS_HIP(hipMemcpyAsync(tab, st.x.data(), sizeof(void *) * (size_t)b->n_features, hipMemcpyHostToDevice, ctx->stream));
-        POLS_HIP(hipStreamSynchronize(ctx->stream));
+        if ((rc = upload_small(ctx, tab, st.x.data(), sizeof(void *) * (size_t)b->n_features))) return rc;
         WideArgs wa;
         std::memset(&wa, 0, sizeof(wa));
         wa.cols = static_cast<const void *const *>(tab);
@@ -1125,10 +1267,8 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
     const int64_t k1_resident_rows = 256 * 2 * vec;
     const bool k1_ok = kt <= 8 && max_group_rows <= k1_resident_rows;
     bool use_mfma = fits && !k1_ok && (max_group_rows > 64 * 2 * vec || kt > K1_MAX_KT);
-    if (const char *force = std::getenv("POLS_K1_ENGINE")) {
-        if (!std::strcmp(force, "valu") && kt <= K1_MAX_KT) use_mfma = false;
-        if (!std::strcmp(force, "mfma") && fits) use_mfma = true;
-    }
+    if (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT) use_mfma = false;
+    if (ctx->opt.k1_engine == 2 && fits) use_mfma = true;
     if (use_mfma) return f32 ? k1m_launch_t<float>(ctx, kt, a, max_group_rows) : k1m_launch_t<double>(ctx, kt, a, max_group_rows);
     if (kt > K1_MAX_KT)
         return fail(POLS_ERR_UNSUPPORTED, "%d features with %lld-row groups: tile exceeds LDS and the streamed engine stops at %d features",

@@ -38,6 +38,30 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
+// Tuning / diagnostic knobs.  Parsed ONCE from the POLS_* environment variables in pols_create() (a launch path never calls
+// getenv) and changeable afterwards through pols_set_option(); every field's default is the shipped behaviour.
+struct Options {
+    bool timeline = false;        // POLS_TIMELINE       s_memtime phase stamps of K1 / K1m (debug)
+    bool k1_noocc4 = false;       // POLS_K1_NOOCC4      do not hold the ragged one-chunk wave kernel to 128 VGPRs
+    bool k1_nofast = false;       // POLS_K1_NOFAST      never take the FAST (aligned, resident) specialisations
+    bool k1_notiny = false;       // POLS_K1_NOTINY      never take K1t (four groups per wave)
+    bool k1_norc1 = false;        // POLS_K1_NORC1       never take the one-chunk-per-lane wave kernel
+    bool k1_shape_team = false;   // POLS_K1_SHAPE=team  f32: 256-thread teams instead of wave-per-group
+    bool k1_f64_team256 = false;  // POLS_K1_F64_TEAM=256
+    bool kg_noyv = false;         // POLS_KG_NOYV        streamed Gram: keep the target in a second MFMA tile at 16 columns
+    bool fused_fixup = false;     // POLS_FUSED_FIXUP    K1 wave kernels carry the fix-up pass as trailing workgroups
+    int k1_passes = 0;            // POLS_K1_PASSES      0: default
+    int k1t_rc4 = -1;             // POLS_K1T_RC4        -1: default rule
+    int static_engine = 0;        // POLS_STATIC_ENGINE  0 auto, 1 "stream" (three launches), 2 "k2" (wherever it fits), 3 "nok2"
+    int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq", 2 "scan"
+    int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"
+    int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
+    int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1
+};
+void options_from_env(Options &o);
+// key: the variable's name with or without the POLS_ prefix (case-insensitive); value NULL = back to the default.  False = unknown key.
+bool options_set(Options &o, const char *key, const char *value);
+
 }  // namespace pols
 
 struct pols_ctx {
@@ -45,9 +69,13 @@ struct pols_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int num_cus = 0;
-    // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] timeline stamps,
-    // [4] chunk / group tables, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean
-    pols::Scratch scratch[10];  // [8] fused fix-up tags, [9] group-key ingestion (K9)
+    // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] fix-up work area,
+    // [4] staged targets / statistics of HOST batches, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean,
+    // [7] status words, [8] fused fix-up tags, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
+    // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
+    // [13] collective staging
+    pols::Scratch scratch[16];
+    pols::Options opt;
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
     int timing_tick = 0;
@@ -55,11 +83,20 @@ struct pols_ctx {
     std::vector<pols::TimedLaunch> timed;   // pool of event pairs
     size_t timed_used = 0;
     std::string last_kernel;
-    // cache of the last uploaded group_offsets (host pointer + size + checksum) so steady-state
-    // calls on the same frame do not re-upload metadata
+    // cache of the last uploaded group_offsets so steady-state calls on the same frame do not re-upload metadata.  A hit is
+    // either PROMISED by the caller (same host pointer, count and non-zero pols_batch.offsets_generation) or VERIFIED: same
+    // count, same content hash AND a memcmp against the host copy kept here -- a hash collision cannot alias two frames.
     const int64_t *offs_host = nullptr;
-    int64_t offs_n = 0;
+    uint64_t offs_generation = 0;
+    std::vector<int64_t> offs_copy;
+    int64_t offs_n = -1;
     uint64_t offs_sum = 0;
+    uint64_t offs_id = 0;                    // bumps whenever different offsets are uploaded (keys the chunk-table cache)
+    // pinned staging ring for small host -> device uploads (offsets, pointer tables): the copy is asynchronous and the
+    // caller's array may be freed on return; a slot is reused only after the event recorded behind its copy has completed
+    struct PinnedSlot { void *ptr = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+    PinnedSlot pinned[4];
+    int pinned_next = 0;
     int64_t offs_max_rows = 0;
     int64_t offs_wave_overflow = 0;          // sum over groups of the rows beyond 1 021 (see k1_launch_kw)
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag
@@ -68,15 +105,19 @@ struct pols_ctx {
     bool last_fused = false;                 // the last K1 launch carried its own fix-up workers
     // cache of the chunk tables of the dynamic kernels (scratch slot 4) for mask-free batches: rebuilt only when the
     // offsets, min_periods or the chunk length change
-    struct { uint64_t offs_sum = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;
+    struct { uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;
              const void *tab = nullptr; size_t b_groups = 0; } chunk_cache;
 };
 
 namespace pols {
 
 int ensure_scratch(pols_ctx *ctx, int slot, size_t bytes, void **out);
-// uploads group offsets (cached), returns device pointer and max group size
-int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const int64_t **d_offs, int64_t *max_rows);
+// uploads group offsets (cached), returns device pointer and max group size; generation: pols_batch.offsets_generation
+int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const int64_t **d_offs, int64_t *max_rows,
+                   uint64_t generation = 0);
+// asynchronous upload of a small host array through the context's pinned ring (no stream synchronisation; `src` may be
+// freed on return)
+int upload_small(pols_ctx *ctx, void *dst_device, const void *src, size_t bytes);
 // timing helpers: no-ops unless ctx->timing
 void timing_begin(pols_ctx *ctx);
 void timing_end(pols_ctx *ctx);

@@ -47,7 +47,6 @@ __device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Ch
 
 template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false, bool LOADED = false>
 __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_t s, int64_t e, Chunk<T, KT, HAS_W> &c) {
-    using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
     const int ku = a.k_user;
     if (LOADED) {
@@ -711,10 +710,10 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         aa.n_k1_blocks = (int32_t)blocks;
         blocks += a.n_k1_blocks;                             // a.n_k1_blocks carries the number of fix-up workers on entry
     }
-    const bool timeline = std::getenv("POLS_TIMELINE") != nullptr;
+    const bool timeline = ctx->opt.timeline;
     if (timeline) {
         void *d = nullptr;
-        int rc = ensure_scratch(ctx, 3, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);
+        int rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);   // slot 3 holds the fix-up work area
         if (rc) return rc;
         aa.dbg = static_cast<unsigned long long *>(d);
     }
@@ -722,7 +721,7 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !FUSED && !NULLS;
     void (*kern)(const K1Args) = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
     if constexpr (OCC4) {
-        if (!std::getenv("POLS_K1_NOOCC4")) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
+        if (!ctx->opt.k1_noocc4) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
     }
     if (timing_pair(ctx, &ev0, &ev1))
         hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, ev0, ev1, 0, aa);
@@ -739,24 +738,23 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 #ifdef K1_NULLS_TU
     // the null-policy family: the row masks live next to the resident rows; single-pass Gram only.  FAST as below: every load of
     // every resident chunk is in flight before the masks are built (POLS_K1_NOFAST=1: the general code)
-    const bool fastn = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC && std::getenv("POLS_K1_NOFAST") == nullptr;
+    const bool fastn = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC && !ctx->opt.k1_nofast;
     return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 1, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 1, true>(ctx, a);
 #else
     // FAST needs every group aligned to the vector width and resident; the offsets scan in upload_offsets() knows
     const bool fast = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC &&
-                      std::getenv("POLS_K1_NOFAST") == nullptr;
+                      !ctx->opt.k1_nofast;
     // (f32 wave-per-group: the multi-pass form was tried -- 216 -> 187 VGPRs with three passes, still two waves per SIMD because the
     // 16 resident rows alone are 144 registers -- and dropped.)
     if constexpr (sizeof(T) == 8 && TEAM == 256 && RC == 2 && KT >= 6) {
         // f64, 6+ columns: the full accumulator set costs a workgroup per CU; POLS_K1_PASSES=1|2|3 overrides
-        int npass = 2;
-        if (const char *env = std::getenv("POLS_K1_PASSES")) npass = std::atoi(env);
+        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : 2;
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
     }
     if constexpr (TEAM == 64) {
         // wave-per-group: the launch can carry its own fix-up workers (a.n_k1_blocks = how many the host prepared for)
-        if (fast && a.n_k1_blocks > 0 && a.tags && !std::getenv("POLS_TIMELINE"))
+        if (fast && a.n_k1_blocks > 0 && a.tags && !ctx->opt.timeline)
             return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 1, false, true>(ctx, a);
     }
     return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false>(ctx, a);
@@ -769,15 +767,14 @@ template <typename T, int KT, bool HAS_W>
 static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
 #ifndef K1_NULLS_TU
-    if (!std::getenv("POLS_K1_NOTINY") && !std::getenv("POLS_TIMELINE")) {
+    if (!ctx->opt.k1_notiny && !ctx->opt.timeline) {
         const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
         if (need <= 16 * 1 * VEC) return k1t_launch<T, KT, HAS_W, 16, 1>(ctx, a);      // one chunk per lane: a third fewer registers
         if (need <= 16 * 2 * VEC) return k1t_launch<T, KT, HAS_W, 16, 2>(ctx, a);
         // four chunks per lane (128 f64 / 256 f32 rows): f64 with 6+ columns has the registers for it since the two-pass form;
         // f32 only on request (POLS_K1T_RC4=1: A/B against the one-chunk wave kernel)
         if (need <= 16 * 4 * VEC) {
-            const char *r4 = std::getenv("POLS_K1T_RC4");
-            const bool want = r4 ? std::atoi(r4) != 0 : (sizeof(T) == 8 && KT >= 6);
+            const bool want = ctx->opt.k1t_rc4 >= 0 ? ctx->opt.k1t_rc4 != 0 : (sizeof(T) == 8 && KT >= 6);
             if (want) return k1t_launch<T, KT, HAS_W, 16, 4>(ctx, a);
         }
         // (SUB = 32, two groups per wave up to 256 / 128 rows, measured SLOWER than one wave per group: 1 022 vs 910 us on 500 000
@@ -787,15 +784,14 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 #endif
     if constexpr (sizeof(T) == 4) {
         // up to 256 f32 rows (a year of trading days): one chunk per lane -- ~36 registers fewer, four waves per SIMD instead of three
-        if (max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= 64 * 1 * VEC && !std::getenv("POLS_K1_NORC1"))
+        if (max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= 64 * 1 * VEC && !ctx->opt.k1_norc1)
             return k1_launch_variant<T, KT, HAS_W, 64, 1>(ctx, a, max_rows);
     }
     if (max_rows <= 64 * 2 * VEC) return k1_launch_variant<T, KT, HAS_W, 64, 2>(ctx, a, max_rows);
     if constexpr (sizeof(T) == 4) {
         // wave-per-group with 16 rows per lane: no LDS, no barriers, one reduction + one solve per group and
         // twice the groups in flight per CU (2 waves/SIMD x 4 SIMDs = 8) -- POLS_K1_SHAPE=team forces 256 threads
-        const char *shape = std::getenv("POLS_K1_SHAPE");
-        const bool want_wave = !(shape && !std::strcmp(shape, "team"));
+        const bool want_wave = !ctx->opt.k1_shape_team;
         // (unaligned group starts: the chunk grid begins up to VEC - 1 rows before the group)
         // Ragged frames (what `.over(key)` delivers): groups up to 1/8 beyond the 1 024 resident rows stay with the wave kernel, their
         // overflow rows streamed twice -- 83.7 us against 101.2 us for the 256-thread team on 10 000 groups of 950..1 100 rows
@@ -817,13 +813,12 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // every group -- plus the up to VEC - 1 rows its chunk grid starts early -- stays resident; groups of up to 512 rows use half
         // the resident chunks (10 000 groups of 900..1 020 rows: 165 -> 148 us; 50 000 groups of 400..500 rows: 126 -> 78 us).
         if constexpr (KT >= 6) {
-            const char *t = std::getenv("POLS_K1_F64_TEAM");
-            const bool al = ctx->offs_aligned[0] && !std::getenv("POLS_K1_NOFAST");
+            const bool al = ctx->offs_aligned[0] && !ctx->opt.k1_nofast;
             const int64_t need = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1);
-            if (!(t && std::atoi(t) == 256) && need <= 128 * 4 * VEC && !std::getenv("POLS_TIMELINE")) {
-                const char *pp = std::getenv("POLS_K1_PASSES");
-                if (pp && std::atoi(pp) == 3 && al) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
-                if (!pp || std::atoi(pp) == 2) {
+            if (!ctx->opt.k1_f64_team256 && need <= 128 * 4 * VEC && !ctx->opt.timeline) {
+                const int pp = ctx->opt.k1_passes;
+                if (pp == 3 && al) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
+                if (pp == 0 || pp == 2) {
                     if (need <= 128 * 2 * VEC)
                         return al ? k1_launch_fast<T, KT, HAS_W, 128, 2, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, 128, 2, false, 2>(ctx, a);
                     return al ? k1_launch_fast<T, KT, HAS_W, 128, 4, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, 128, 4, false, 2>(ctx, a);

@@ -336,10 +336,10 @@ static int k1m_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     std::snprintf(name, sizeof(name), "k1m_gram_mfma_%s_k%d%s_lds%zu", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", lds);
     ctx->last_kernel = name;
     K1Args aa = a;
-    const bool timeline = std::getenv("POLS_TIMELINE") != nullptr;
+    const bool timeline = ctx->opt.timeline;
     if (timeline) {
         void *d = nullptr;
-        int rc = ensure_scratch(ctx, 3, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);
+        int rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);
         if (rc) return rc;
         aa.dbg = static_cast<unsigned long long *>(d);
     }

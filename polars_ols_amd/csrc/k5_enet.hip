@@ -53,6 +53,9 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) { acc[p][0] = acc_t{0, 0, 0, 0}; acc[p][1] = acc_t{0, 0, 0, 0}; }
     T xy0 = T(0), xy1 = T(0);                       // YV: this lane's share of (X'y)[zc]
+    double accd[NPAIR][4], xyd = 0.0;               // f64 totals (f32: flushed per chunk; f64: filled once at the end)
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) { accd[p][0] = 0.0; accd[p][1] = 0.0; accd[p][2] = 0.0; accd[p][3] = 0.0; }
 
     if (tid < 2 * K1M_CONST_ELEMS) zeros[tid] = (tid < K1M_CONST_ELEMS) ? T(0) : T(1);
     __shared__ int nfit_s;
@@ -169,7 +172,25 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
                     acc[p][1] = M::mma(v1[ti], v1[tj], acc[p][1]);
                 }
         }
+        if constexpr (sizeof(T) == 4) {
+            // f32: every chunk's tile (at most 64 rows per wave) is flushed into f64 running sums, so the Gram matrix of an f32
+            // frame carries f64-summation error -- what holds the f32 paths fed from here to the 1e-4 parity bound
+#pragma unroll
+            for (int p = 0; p < NPAIR; ++p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accd[p][r] += (double)acc[p][0][r] + (double)acc[p][1][r];
+                acc[p][0] = acc_t{0, 0, 0, 0}; acc[p][1] = acc_t{0, 0, 0, 0};
+            }
+            if constexpr (YV) { xyd += (double)xy0 + (double)xy1; xy0 = T(0); xy1 = T(0); }
+        }
         __syncthreads();   // the next chunk's DMA overwrites the tile
+    }
+    if constexpr (sizeof(T) == 8) {
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accd[p][r] = acc[p][0][r] + acc[p][1][r];
+        if constexpr (YV) xyd = xy0 + xy1;
     }
 
     if (HAS_W && a.nvalid) {
@@ -178,18 +199,17 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
         if (tid == 0) a.nvalid[g] = (double)nfit_s;
     }
     // ---- cross-wave sum (fixed order) and write-out of the (symmetric) Gram matrix in f64
-    T *part = tile;    // [pair][wave][reg * 64 + lane]
+    double *part = reinterpret_cast<double *>(tile);    // [pair][wave][reg * 64 + lane], f64
     if constexpr (YV) {                                     // X'y: fold the four row-quarters of the wave, then the waves
-        T xy = xy0 + xy1;
+        double xy = xyd;
         xy += __shfl_xor(xy, 16);
         xy += __shfl_xor(xy, 32);
         if (lane < 16) part[NPAIR * 4 * 256 + wave * 16 + lane] = xy;
     }
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
-        const acc_t t = acc[p][0] + acc[p][1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[(p * 4 + wave) * 256 + r * 64 + lane] = t[r];
+        for (int r = 0; r < 4; ++r) part[(p * 4 + wave) * 256 + r * 64 + lane] = accd[p][r];
     }
     __syncthreads();
     double *G = a.gram + (size_t)g * NZ * NZ;
@@ -203,7 +223,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
         for (int tj = ti; tj < NT; ++tj, ++p) {
             double v = 0.0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += (double)part[(p * 4 + w) * 256 + tid];
+            for (int w = 0; w < 4; ++w) v += part[(p * 4 + w) * 256 + tid];
             const int i = 16 * ti + drow, j = 16 * tj + dcol;
             if (i < NZ && j < NZ) {
                 if (!HAS_W && icpt && i == kt - 1 && j == kt - 1) v = (double)(e - s);   // the ones block also fed pad rows
@@ -215,7 +235,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
         if (tid < 16) {
             double v = 0.0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += (double)part[NPAIR * 4 * 256 + w * 16 + tid];
+            for (int w = 0; w < 4; ++w) v += part[NPAIR * 4 * 256 + w * 16 + tid];
             G[tid * NZ + kt] = v;
             G[kt * NZ + tid] = v;
         }
@@ -228,7 +248,8 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     const int ncols = a.k_user + 1 + (HAS_W ? 1 : 0);
     const int rs = k1m_row_stride<T>(KG_CR);
     const int npair = NT * (NT + 1) / 2;
-    const int tile_elems = std::max(ncols * rs, npair * 4 * 256 + (YV ? 64 : 0));
+    // the tile is re-used for the cross-wave partial tiles, which are f64 whatever T is
+    const int tile_elems = std::max(ncols * rs, (int)((npair * 4 * 256 + (YV ? 64 : 0)) * (sizeof(double) / sizeof(T))));
     const size_t lds = sizeof(T) * ((size_t)tile_elems + 2 * K1M_CONST_ELEMS);
     static OncePerDevice attr_once;
     if (attr_once.needed(ctx->device)) {
@@ -251,7 +272,7 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
     if (a.kt + 1 > 32) return fail(POLS_ERR_UNSUPPORTED, "gram_stream: %d features (incl. intercept) > 31", a.kt);
     const bool two = a.kt + 1 > 16, w = a.w != nullptr || a.null_policy != POLS_NULL_IGNORE;   // null policies ride on the sqrt(w) prep pass
-    if (a.kt == 16 && std::getenv("POLS_KG_NOYV") == nullptr) {   // the target would be alone in the second tile: X'y on the VALU
+    if (a.kt == 16 && !ctx->opt.kg_noyv) {   // the target would be alone in the second tile: X'y on the VALU
         if (dtype == POLS_F32) return w ? gram_stream_launch_t<float, 1, true, true>(ctx, a) : gram_stream_launch_t<float, 1, false, true>(ctx, a);
         return w ? gram_stream_launch_t<double, 1, true, true>(ctx, a) : gram_stream_launch_t<double, 1, false, true>(ctx, a);
     }
@@ -373,7 +394,7 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
     double bi = (lane < kt) ? G[lane * NZ + kt] : 0.0;          // X'y, one entry per lane
     __builtin_amdgcn_wave_barrier();
     bool ok = true;
-    for (int j = 0; j < kt; ++j) {
+    for (int j = 0; j < kt && a.solver != 1; ++j) {
         double d = L[j * kt + j];
         const double gjj = d;
         for (int p = 0; p < j; ++p) d -= L[j * kt + p] * L[j * kt + p];
@@ -398,6 +419,50 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
         if (lane == p) bi *= rinv[p];
         const double bp = __shfl(bi, p);
         if (lane < p) bi -= L[p * kt + lane] * bp;
+    }
+    // solve_method = "lu" (solve_ols_lu, ls.rs:264-273), or solve_ridge's Cholesky -> LU fallback (ls.rs:358-363): partial-pivot LU
+    // of the same matrix, lane i owns row i (the factor's storage is re-initialised from the Gram matrix)
+    if (a.solver == 1 || (!ok && a.lu_fallback)) {
+        for (int q = lane; q < kt * kt; q += 64) {
+            const int i = q / kt, j = q - i * kt;
+            L[q] = G[i * NZ + j] + (i == j ? a.alpha : 0.0);
+        }
+        bi = (lane < kt) ? G[lane * NZ + kt] : 0.0;            // the right-hand side rides along in registers, permuted with the rows
+        __builtin_amdgcn_wave_barrier();
+        ok = true;
+        for (int j = 0; j < kt; ++j) {
+            double v = (lane >= j && lane < kt) ? fabs(L[lane * kt + j]) : -1.0;
+            int idx = lane;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(v, off);
+                const int oi = __shfl_xor(idx, off);
+                if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+            }
+            const int pr = __shfl(idx, 0);
+            const double piv = L[pr * kt + j];
+            ok = ok && (fabs(piv) > 0.0);
+            const double bj = __shfl(bi, j), bp = __shfl(bi, pr);
+            if (pr != j) {
+                if (lane >= j && lane < kt) { const double t = L[j * kt + lane]; L[j * kt + lane] = L[pr * kt + lane]; L[pr * kt + lane] = t; }
+                if (lane == j) bi = bp;
+                if (lane == pr) bi = bj;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double brow = __shfl(bi, j);
+            if (lane > j && lane < kt) {
+                const double f = L[lane * kt + j] / piv;
+                for (int c = j + 1; c < kt; ++c) L[lane * kt + c] = fma(-f, L[j * kt + c], L[lane * kt + c]);
+                bi = fma(-f, brow, bi);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int p = kt - 1; p >= 0; --p) {
+            if (lane == p) bi /= L[p * kt + p];
+            const double bp = __shfl(bi, p);
+            if (lane < p) bi = fma(-L[lane * kt + p], bp, bi);
+        }
+        ok = ok && __all(lane >= kt || ((bi == bi) && fabs(bi) <= 1.7e308));
     }
     int st = POLS_GROUP_OK;
     if (n == 0) { bi = 0.0; st = POLS_GROUP_EMPTY; }

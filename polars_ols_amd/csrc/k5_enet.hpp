@@ -47,6 +47,8 @@ struct CdArgs {
     int64_t max_iter;
     int32_t positive, active_set, kt;
     const double *nvalid;   // per-group number of fit rows under a null policy, or nullptr = offs[g + 1] - offs[g]
+    int32_t solver;         // gram_solve only: 0 Cholesky, 1 partial-pivot LU (solve_method = "lu", ls.rs:264-273)
+    int32_t lu_fallback;    // gram_solve only: a failed Cholesky is retried with LU (solve_ridge, ls.rs:358-363)
 };
 
 struct PredictArgs {

@@ -315,10 +315,8 @@ static int move_columns(pols_ctx *ctx, pols_layout *L, int dtype_bytes, const vo
     // fit an XCD's 4 MB L2 next to the streams passing through it; gather in group order otherwise.  POLS_K9_TAKE=gather|scatter
     // overrides (profiling).
     bool scatter = to_group_order && dtype_bytes <= 8 && L->n_groups <= 12288;
-    if (const char *e = getenv("POLS_K9_TAKE")) {
-        if (!strcmp(e, "gather")) scatter = false;
-        if (!strcmp(e, "scatter")) scatter = to_group_order && dtype_bytes <= 8;
-    }
+    if (ctx->opt.k9_take == 1) scatter = false;
+    if (ctx->opt.k9_take == 2) scatter = to_group_order && dtype_bytes <= 8;
     int rc = (to_group_order && !scatter) ? POLS_OK : ensure_inverse(ctx, L);
     if (rc) return rc;
     const uint32_t *index = (to_group_order && !scatter) ? L->order : L->inverse;

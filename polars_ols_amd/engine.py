@@ -81,6 +81,10 @@ class Engine:
         L.check(n)
         return np.frombuffer(buf, dtype=np.float32, count=n).copy()
 
+    def set_option(self, key: str, value: Optional[str]) -> None:
+        """Tuning / diagnostic knob (``pols_set_option``): the name of a POLS_* variable and its value, ``None`` = default."""
+        L.check(self._lib.pols_set_option(self._h, key.encode(), None if value is None else str(value).encode()))
+
     @property
     def last_kernel(self) -> str:
         return self._lib.pols_last_kernel_name(self._h).decode()
@@ -366,8 +370,13 @@ class Layout:
 class Plan:
     """A marshalled call: ctypes structs + references that keep every borrowed buffer alive."""
 
+    _generation = 0
+
     def __init__(self, eng: Engine, fn, batch, params, out, results: Dict, keep):
         self._eng, self._fn, self._b, self._p, self._o, self.results, self._keep = eng, fn, batch, params, out, results, keep
+        # the plan keeps its offsets array alive and never rewrites it: promise that to the library (O(1) offsets check per run)
+        Plan._generation += 1
+        batch.offsets_generation = Plan._generation
         self._args = (eng._h, C.byref(batch), C.byref(params), C.byref(out))
 
     def set_output(self, key: str, buf) -> None:

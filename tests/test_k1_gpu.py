@@ -12,13 +12,6 @@ pytestmark = pytest.mark.gpu
 TOL = {np.float32: 1e-4, np.float64: 1e-6}
 
 
-@pytest.fixture(params=["valu", "mfma"])
-def engine_kind(request, monkeypatch):
-    """A/B both engines of the static path: K1 (register-resident VALU Gram) and K1m (LDS tile + MFMA Gram)."""
-    monkeypatch.setenv("POLS_K1_ENGINE", request.param)
-    return request.param
-
-
 @pytest.fixture(scope="module")
 def eng():
     from polars_ols_amd import Engine
@@ -26,6 +19,15 @@ def eng():
     e = Engine(0)
     yield e
     e.close()
+
+
+@pytest.fixture(params=["valu", "mfma"])
+def engine_kind(request, eng):
+    """A/B both engines of the static path: K1 (register-resident VALU Gram) and K1m (LDS tile + MFMA Gram); shapes neither
+    takes by default go to K2 / the streamed kernels whatever the knob says."""
+    eng.set_option("K1_ENGINE", request.param)
+    yield request.param
+    eng.set_option("K1_ENGINE", None)
 
 
 def _cuda(a):
@@ -112,18 +114,23 @@ def test_ridge_weights_intercept_cfg3_shape(eng, engine_kind, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k", [12, 15])
-def test_wide_features_mfma_engine(eng, dtype, k):
-    """11..15 features: only the MFMA Gram engine (one 16x16 tile holds [X | y])."""
+@pytest.mark.parametrize("engine", [None, "mfma"])
+def test_wide_features_mfma_engines(eng, dtype, k, engine):
+    """9..15 features: K2 (rows resident in registers, one 16x16 MFMA tile holds [X | y]) by default, K1m (LDS tile) on request."""
     from oracle import orc
 
     rng = np.random.default_rng(k)
     offs = _ragged_offsets(rng, 21, 300, 900)
     y, cols, w = _frame(rng, offs, k - 1, dtype, weights=True)
-    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=True,
-                            alpha=0.5, want=("coef", "pred", "resid"))
+    eng.set_option("K1_ENGINE", engine)
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=True,
+                                alpha=0.5, want=("coef", "pred", "resid"))
+    finally:
+        eng.set_option("K1_ENGINE", None)
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True, alpha=0.5)
     _check(out, ref, dtype)
-    assert eng.last_kernel.startswith("k1m_")
+    assert eng.last_kernel.startswith("k1m_" if engine else "k2_gram_mfma_resident"), eng.last_kernel
 
 
 @pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])
@@ -369,3 +376,26 @@ def test_many_tiny_groups_four_per_wave(eng, dtype, lo, hi, tag):
     ref = orc.batched_least_squares(np.concatenate(yh), [np.concatenate(c) for c in ch], np.array(oh, dtype=np.int64), add_intercept=True)
     rt = TOL[dtype]
     assert np.allclose(out["coef"].cpu().numpy()[pick], ref["coef"], rtol=rt, atol=rt)
+
+
+@pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])
+@pytest.mark.parametrize("mem", ["host", "device"])
+def test_configs0_single_group_coefficients(eng, method, mem):
+    """BASELINE configs[0]: ONE group, 10 000 rows x 4 f64 features, mode="coefficients" -- the call the reference's plugin
+    receives per group (src/expressions.rs:430-446 -> _get_least_squares_coefficients :351-388), every solve_method, against the
+    oracle's restatement of the same dispatch at 1e-6 (and lstsq, which the oracle matches to 1e-12 on this shape)."""
+    from oracle import orc
+    from refdata import make_data
+
+    d = make_data(n_samples=10_000, n_features=4)
+    cols = [d[f"x{i + 1}"] for i in range(4)]
+    y = d["y"]
+    ref = orc.get_coefficients(y, d["x"], solve_method=method)
+    if mem == "device":
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], [0, 10_000], solve_method=method, want=("coef", "status"))
+    else:
+        out = eng.least_squares(y, cols, [0, 10_000], solve_method=method, want=("coef", "status"))
+    coef = out["coef"].cpu().numpy() if hasattr(out["coef"], "cpu") else out["coef"]
+    assert coef.shape == (1, 4) and int(np.asarray(out["status"].cpu() if hasattr(out["status"], "cpu") else out["status"])[0]) == 0
+    assert np.allclose(coef[0], ref, rtol=1e-6, atol=1e-6)
+    assert np.allclose(coef[0], np.linalg.lstsq(d["x"], y, rcond=None)[0], rtol=1e-9, atol=1e-9)

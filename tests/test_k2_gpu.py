@@ -1,0 +1,224 @@
+"""GPU parity of K2 (rows resident in registers, X'X on the matrix cores, solver in the same workgroup: X read once) through the
+C-ABI against the CPU oracle: OLS / ridge beyond K1's eight columns, solve_method="lu" (src/least_squares.rs:264-273), the
+Cholesky -> LU fallback of solve_ridge (:358-363), elastic net / lasso / non-negative (:386-492) -- every workgroup shape, ragged
+and unaligned groups, weights, intercept, empty groups, groups flagged for the SVD pass.
+
+Tolerances (BASELINE.json north_star): 1e-6 for f64, 1e-4 for f32, |a - b| <= tol + tol |b| (tests/test_ols.py:73)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 1e-4, np.float64: 1e-6}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from polars_ols_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _cuda(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _np(t):
+    return t.double().cpu().numpy() if hasattr(t, "cpu") else np.asarray(t, dtype=np.float64)
+
+
+def _offsets(rng, n_groups, lo, hi):
+    sizes = rng.integers(lo, hi + 1, size=n_groups)
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def _frame(rng, offs, k, dtype, weights=False, sparsity=0.0):
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    kk = max(1, int(k * (1 - sparsity)))
+    beta = rng.uniform(0.5, 1.5, size=kk)
+    y = (sum(b * c.astype(np.float64) for b, c in zip(beta, cols[:kk])) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    w = rng.uniform(0.2, 2.0, N).astype(dtype) if weights else None
+    return y, cols, w
+
+
+def _check(out, ref, dtype, keys=("coef", "pred", "resid")):
+    tol = TOL[dtype]
+    for k in keys:
+        got = _np(out[k])
+        assert got.shape == ref[k].shape, k
+        assert np.allclose(got, ref[k], rtol=tol, atol=tol), (k, float(np.abs(got - ref[k]).max()))
+
+
+# (lo, hi) group sizes chosen to land on every workgroup shape: one wave (1 or 2 chunks per lane), four waves, eight waves
+SHAPES = [(8, 60, "_w1_rc1"), (70, 250, "_w1_rc2"), (300, 510, "_w4_rc1"), (600, 1000, "_w4_rc2"), (1100, 2040, "_w8_rc2")]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("lo,hi,shape", SHAPES)
+@pytest.mark.parametrize("kt,weights,icpt,alpha", [(9, False, True, 0.0), (12, True, False, 0.7), (16, False, True, 0.0), (16, True, False, 2.0)])
+def test_ols_ridge_every_shape(eng, dtype, lo, hi, shape, kt, weights, icpt, alpha):
+    """9..16 columns (the intercept counted): Cholesky on the register-resident rows' Gram matrix, fused predictions."""
+    from oracle import orc
+
+    rng = np.random.default_rng(hi + kt)
+    if dtype == np.float32:                                   # an f32 lane holds twice the rows of an f64 lane
+        lo, hi = 2 * lo, 2 * hi
+    offs = _offsets(rng, 23, lo, hi)
+    y, cols, w = _frame(rng, offs, kt - int(icpt), dtype, weights=weights)
+    kw = dict(alpha=alpha, l1_ratio=0.0) if alpha else {}
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                            want=("coef", "pred", "resid", "status"), **kw)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert eng.last_kernel.startswith("k2_gram_mfma_resident") and shape in eng.last_kernel and eng.last_kernel.endswith("_chol"), eng.last_kernel
+    assert int(_np(out["status"]).sum()) == 0
+    _check(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,alpha,icpt", [(2, 0.0, False), (5, 0.3, True), (8, 0.0, True), (13, 1.5, False), (16, 0.0, False)])
+def test_solve_method_lu(eng, dtype, k, alpha, icpt):
+    """solve_method="lu" is a partial-pivot LU of X'X + alpha I (solve_ols_lu, ls.rs:264-273; reached through solve_ridge,
+    ex.rs:374-375), not an alias of the Cholesky kernel."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k)
+    offs = _offsets(rng, 31, 30, 900)
+    y, cols, w = _frame(rng, offs, k - int(icpt), dtype, weights=True)
+    kw = dict(alpha=alpha, l1_ratio=0.0, solve_method="lu")
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=icpt,
+                            want=("coef", "pred", "resid", "status"), **kw)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert eng.last_kernel.startswith("k2_gram_mfma_resident") and eng.last_kernel.endswith("_lu"), eng.last_kernel
+    assert int(_np(out["status"]).sum()) == 0
+    _check(out, ref, dtype)
+
+
+def test_lu_on_groups_beyond_the_registers(eng):
+    """Groups too long for K2 take the streamed Gram pass; "lu" is still an LU there (gram_solve's LU branch)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(4)
+    offs = np.array([0, 9_000, 9_007, 21_000], dtype=np.int64)
+    y, cols, w = _frame(rng, offs, 5, np.float64, weights=True)
+    kw = dict(alpha=0.4, l1_ratio=0.0, solve_method="lu")
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), want=("coef", "pred", "status"), **kw)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream")
+    assert int(_np(out["status"]).sum()) == 0
+    _check(out, ref, np.float64, keys=("coef", "pred"))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("engine", [None, "stream"])
+@pytest.mark.parametrize("k,alpha,l1,positive,method,weights,icpt", [
+    (2, 0.1, 0.5, False, "cd", False, False),
+    (8, 0.05, 1.0, False, None, False, True),          # lasso + intercept
+    (8, 0.3, 0.5, True, "cd", True, False),            # non-negative + weights
+    (15, 0.01, 0.5, False, "cd_active_set", False, True),
+    (16, 0.001, 0.5, False, "cd", False, False),       # BASELINE configs[4]'s feature count: X'y on the VALU
+    (16, 0.2, 0.9, False, "cd_active_set", True, False),
+])
+def test_elastic_net_both_engines(eng, dtype, engine, k, alpha, l1, positive, method, weights, icpt):
+    """The fused kernel and the three-launch path land on the oracle's fixed point (tol = 1e-10: the unique minimiser)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k + int(100 * alpha))
+    offs = _offsets(rng, 29, 40, 1900)
+    y, cols, w = _frame(rng, offs, k - int(icpt), dtype, weights=weights, sparsity=0.5)
+    kw = dict(alpha=alpha, l1_ratio=l1, positive=positive, solve_method=method, tol=1e-10, max_iter=20_000)
+    eng.set_option("STATIC_ENGINE", engine)
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
+                                add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream" if engine else "k2_gram_mfma_resident"), eng.last_kernel
+    assert int(_np(out["status"]).sum()) == 0
+    _check(out, ref, dtype)
+
+
+def test_elastic_net_default_tolerance_same_sweeps(eng):
+    """Default tol = 1e-5 / max_iter = 1000 on BASELINE configs[4]'s shape: the stop rule fires on the same sweep as the oracle's."""
+    from oracle import orc
+    from refdata import synthetic_groups
+
+    d = synthetic_groups(300, 2000, 16, seed=5, dtype=np.float64)
+    out = eng.least_squares(_cuda(d["y"]), [_cuda(c) for c in d["cols"]], d["offsets"], alpha=0.001, l1_ratio=0.5,
+                            want=("coef", "pred", "resid"))
+    ref = orc.batched_least_squares(d["y"], d["cols"], d["offsets"], alpha=0.001, l1_ratio=0.5)
+    assert "_k16yv_w8_rc2" in eng.last_kernel and eng.last_kernel.endswith("_cd"), eng.last_kernel
+    _check(out, ref, np.float64)
+
+
+def test_max_iter_reached_is_reported(eng):
+    rng = np.random.default_rng(0)
+    offs = np.array([0, 500], dtype=np.int64)
+    y, cols, _ = _frame(rng, offs, 6, np.float64)
+    cols[1] = cols[0] + 1e-3 * cols[1]                                          # strongly correlated pair: slow CD
+    out = eng.least_squares(y, cols, offs, alpha=1e-6, l1_ratio=0.5, tol=1e-14, max_iter=3, want=("coef", "status"))
+    assert eng.last_kernel.startswith("k2_") and out["status"][0] == 3          # POLS_GROUP_NOT_CONVERGED
+
+
+def test_empty_tiny_and_flagged_groups(eng):
+    """Empty groups give zeros (ex.rs:357-359); a rank-deficient group on the OLS branch is flagged and re-solved by the Jacobi-SVD
+    pass (minimum norm, like the reference's dgelsd), its neighbours are untouched."""
+    from oracle import orc
+
+    rng = np.random.default_rng(12)
+    offs = np.array([0, 0, 40, 40, 43, 700, 700, 1500], dtype=np.int64)
+    k = 11
+    y, cols, _ = _frame(rng, offs, k, np.float64)
+    cols[7][43:700] = cols[2][43:700]                                           # group 4: two identical columns
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "status"))
+    assert eng.last_kernel.startswith("k2_")
+    st = _np(out["status"]).astype(int)
+    assert list(st) == [2, 0, 2, 1, 1, 2, 0], st                                # 3 rows x 11 columns and the twin columns: fallback
+    coef = _np(out["coef"])
+    assert np.array_equal(coef[[0, 2, 5]], np.zeros((3, k)))
+    ref = orc.batched_least_squares(y, cols, offs)
+    for g in (1, 6):
+        assert np.allclose(coef[g], ref["coef"][g], rtol=1e-6, atol=1e-9)
+    X = np.stack([c[43:700] for c in cols], axis=1)
+    mn = np.linalg.lstsq(X, y[43:700], rcond=None)[0]
+    assert np.allclose(coef[4], mn, rtol=1e-6, atol=1e-8)                        # dgelsd's minimum-norm solution
+    assert np.allclose(_np(out["pred"])[43:700], X @ mn, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_forced_on_k1_shapes_matches_k1(eng, dtype):
+    """POLS_STATIC_ENGINE=k2 runs K2 on the shapes K1 owns by default (<= 8 columns): both agree with the oracle."""
+    from oracle import orc
+    from refdata import synthetic_groups
+
+    d = synthetic_groups(64, 1000, 8, seed=3, dtype=dtype, with_weights=True)
+    args = (_cuda(d["y"]), [_cuda(c) for c in d["cols"]], d["offsets"])
+    kw = dict(weights=_cuda(d["w"]), alpha=1.0, l1_ratio=0.0, want=("coef", "pred", "resid"))
+    a = eng.least_squares(*args, **kw)
+    k1_name = eng.last_kernel
+    eng.set_option("STATIC_ENGINE", "k2")
+    try:
+        b = eng.least_squares(*args, **kw)
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
+    assert k1_name.startswith("k1_") and eng.last_kernel.startswith("k2_"), (k1_name, eng.last_kernel)
+    ref = orc.batched_least_squares(d["y"], d["cols"], d["offsets"], weights=d["w"], alpha=1.0, l1_ratio=0.0)
+    _check(a, ref, dtype)
+    _check(b, ref, dtype)
+
+
+def test_host_path_and_determinism(eng):
+    rng = np.random.default_rng(8)
+    offs = _offsets(rng, 37, 100, 1500)
+    y, cols, w = _frame(rng, offs, 12, np.float64, weights=True)
+    kw = dict(weights=w, alpha=0.01, l1_ratio=0.5, want=("coef", "pred"))
+    a = eng.least_squares(y, cols, offs, **kw)
+    b = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), alpha=0.01, l1_ratio=0.5, want=("coef", "pred"))
+    c = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), alpha=0.01, l1_ratio=0.5, want=("coef", "pred"))
+    assert np.array_equal(a["coef"], _np(b["coef"])) and np.array_equal(a["pred"], _np(b["pred"]))
+    assert np.array_equal(_np(b["pred"]), _np(c["pred"]))                       # fixed reduction order: run-to-run identical

@@ -16,10 +16,11 @@ def eng():
 
 
 @pytest.fixture(params=["seq", "scan"])
-def rls_engine(request, monkeypatch):
+def rls_engine(request, eng):
     """K3 (wave-per-sequence P-form recursion) and K3s (chunk-parallel information-form scan) must both match."""
-    monkeypatch.setenv("POLS_RLS_ENGINE", request.param)
-    return request.param
+    eng.set_option("RLS_ENGINE", request.param)
+    yield request.param
+    eng.set_option("RLS_ENGINE", None)
 
 
 def _cuda(a):

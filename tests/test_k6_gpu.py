@@ -72,7 +72,7 @@ def test_degenerate_groups_do_not_disturb_healthy_ones(eng, dtype):
     out = eng.least_squares(yd, cd, offs, want=("coef", "pred", "status"))
     st = _np(out["status"]).astype(int)
     assert list(st) == [0, 1, 1, 1, 1, 0]                            # groups 1 and 4 have n < k
-    tol = 1e-6 if dtype == np.float64 else 2e-4
+    tol = 1e-6 if dtype == np.float64 else 1e-4
     coef, pred = _np(out["coef"]), _np(out["pred"])
     for g in (0, 5):                                                 # healthy groups: the reference's QR answer
         sl = slice(offs[g], offs[g + 1])
@@ -136,7 +136,7 @@ def test_ridge_on_collinear_data_needs_no_fallback(eng):
     assert out["status"][0] == 0 and np.allclose(out["coef"], ref["coef"], rtol=1e-6, atol=1e-8)
 
 
-def test_fused_fixup_matches_two_launch_form(eng, monkeypatch):
+def test_fused_fixup_matches_two_launch_form(eng):
     """POLS_FUSED_FIXUP=1: the wave-per-group launch carries its own fix-up workgroups (per-group epoch tags); the result must be
     bit-identical to the default two-dispatch form, flagged groups included."""
     import torch
@@ -151,9 +151,40 @@ def test_fused_fixup_matches_two_launch_form(eng, monkeypatch):
     offs = np.arange(G + 1, dtype=np.int64) * n
     ref = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
     torch.cuda.synchronize()
-    monkeypatch.setenv("POLS_FUSED_FIXUP", "1")
-    for _ in range(5):
-        out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
-        torch.cuda.synchronize()
-        assert np.nonzero(out["status"].cpu().numpy() == 1)[0].tolist() == flagged
-        assert torch.equal(out["coef"], ref["coef"]) and torch.equal(out["pred"], ref["pred"])
+    eng.set_option("FUSED_FIXUP", "1")
+    try:
+        for _ in range(5):
+            out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
+            torch.cuda.synchronize()
+            assert np.nonzero(out["status"].cpu().numpy() == 1)[0].tolist() == flagged
+            assert torch.equal(out["coef"], ref["coef"]) and torch.equal(out["pred"], ref["pred"])
+    finally:
+        eng.set_option("FUSED_FIXUP", None)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("rcond", [0.1, 0.5, 1e-3])
+def test_ridge_svd_honours_rcond_on_every_group(eng, dtype, rcond):
+    """solve_ridge_svd (ls.rs:106-168): singular values below rcond * s_max are dropped (:143-148) on FULL-RANK groups too -- a
+    truncated solve is not the normal-equation solution, so every group goes through the Jacobi-SVD kernel."""
+    from oracle import orc
+
+    rng = np.random.default_rng(7)
+    sizes = np.array([300, 0, 41, 900, 7])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N, k = int(offs[-1]), 5
+    scale = np.array([1.0, 0.6, 0.3, 0.05, 2.0])                     # a spread of singular values: rcond cuts some of them
+    cols = [(scale[j] * rng.standard_normal(N)).astype(dtype) for j in range(k)]
+    y = (sum(c.astype(np.float64) for c in cols) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    kw = dict(alpha=0.5, l1_ratio=0.0, solve_method="svd", rcond=rcond)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "resid", "status"), **kw)
+    assert eng.last_kernel == "k6_small_svd_all_groups"
+    ref = orc.batched_least_squares(y, cols, offs, **kw)
+    plain = orc.batched_least_squares(y, cols, offs, alpha=0.5, l1_ratio=0.0)
+    if rcond >= 0.1:                                                 # the truncation really changes the answer
+        assert np.abs(ref["coef"] - plain["coef"]).max() > 1e-2
+    tol = 1e-6 if dtype == np.float64 else 1e-4
+    st = _np(out["status"]).astype(int)
+    assert list(st) == [1, 2, 1, 1, 1]                               # every non-empty group took the SVD pass
+    for key in ("coef", "pred", "resid"):
+        assert np.allclose(_np(out[key]), ref[key], rtol=tol, atol=tol), (key, float(np.abs(_np(out[key]) - ref[key]).max()))

@@ -193,7 +193,9 @@ def test_rolling_drop_window(golden, win, mp, woodbury):
     c = orc.solve_rolling_ols(np.nan_to_num(y), x, win, min_periods=mp, use_woodbury=woodbury,
                               is_valid=valid, null_policy="drop_window")
     exp = z[f"roll_{win}_{mp}"]
-    assert np.allclose(c, exp, rtol=1e-3, atol=1e-3, equal_nan=True)
+    # brute-force per-window lstsq (statsmodels RollingOLS semantics, tests/test_ols.py:751-764): the incremental add / subtract
+    # state of ls.rs:707-734 (and the Woodbury form :737-787) agrees to 1e-8 on EVERY row, 2-row windows included
+    assert np.allclose(c, exp, rtol=1e-8, atol=1e-8, equal_nan=True)
 
 
 @pytest.mark.parametrize("mp,expected", [(999, 2), (1000, 1), (1001, 0)])
@@ -235,3 +237,16 @@ def test_svd_min_norm_wide_and_collinear():
 
 def test_empty_features_gives_zeros():
     assert np.array_equal(orc.get_coefficients(np.zeros(0), np.zeros((0, 3))), np.zeros(3))
+
+
+@pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])
+def test_configs0_oracle_matches_lstsq(method):
+    """BASELINE configs[0] (ONE group, 10 000 rows x 4 f64 features, mode="coefficients"): the oracle's restatement of the
+    dispatcher (src/expressions.rs:351-388) -> solve_ols / solve_ridge agrees with LAPACK's lstsq to 1e-12 for every
+    solve_method."""
+    d = make_data(n_samples=10_000, n_features=4)
+    exp = np.linalg.lstsq(d["x"], d["y"], rcond=None)[0]
+    got = orc.get_coefficients(d["y"], d["x"], solve_method=method)
+    assert np.allclose(got, exp, rtol=1e-12, atol=1e-12), float(np.abs(got - exp).max())
+    out = orc.batched_least_squares(d["y"], [d[f"x{i + 1}"] for i in range(4)], [0, 10_000], solve_method=method, want=("coef",))
+    assert np.allclose(out["coef"][0], exp, rtol=1e-12, atol=1e-12)
