@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256) mark_fallback_kernel(const int64_t *offs,
     if (g == 0) *fb_flag = epoch;
     if (g >= n_groups) return;
     if (only_if_not_empty) { if (status[g] != POLS_GROUP_EMPTY) status[g] = POLS_GROUP_FALLBACK; }
-    else status[g] = (offs[g + 1] == offs[g]) ? POLS_GROUP_EMPTY : POLS_GROUP_FALLBACK;
+    else status[g] = POLS_GROUP_FALLBACK;     // empty groups too: the SVD pass writes their zero coefficients and marks them EMPTY
+    (void)offs;
 }
 
 // ------------------------------------------------------------------ errors
@@ -159,6 +160,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_F64_TEAM")) o.k1_f64_team256 = on && std::atoi(v) == 256;
     else if (ieq(key, "KG_NOYV")) o.kg_noyv = on;
     else if (ieq(key, "FUSED_FIXUP")) o.fused_fixup = on;
+    else if (ieq(key, "K2_NOPREFETCH")) o.k2_noprefetch = on;
     else if (ieq(key, "K1_PASSES")) o.k1_passes = on ? std::atoi(v) : d.k1_passes;
     else if (ieq(key, "K1T_RC4")) o.k1t_rc4 = on ? (std::atoi(v) != 0) : d.k1t_rc4;
     else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
@@ -172,7 +174,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
-                                       "KG_NOYV", "FUSED_FIXUP", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
+                                       "KG_NOYV", "FUSED_FIXUP", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "K1_ENGINE", "K9_TAKE"};
     char name[64];
     for (const char *k : keys) {
@@ -708,17 +710,23 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool f32 = b->dtype == POLS_F32;
         const int vec = f32 ? 4 : 2;
         const bool aligned = ctx->offs_aligned[f32 ? 1 : 0];
-        const bool k2_ok = !nulls && kt <= K2_KMAX && k2_fits(b->dtype, kt, max_rows, aligned) && ctx->opt.static_engine != 1 &&
+        const bool k2_ok = !nulls && kt <= K2_KMAX && k2_fits(b->dtype, kt, max_rows, aligned) && b->n_rows >= vec && ctx->opt.static_engine != 1 &&
                            ctx->opt.static_engine != 3;
         const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
         // POLS_K1_ENGINE=valu | mfma keep the K1 / K1m kernels reachable for the shapes they cover (A/B measurements, tests)
         const bool legacy_forced = (ctx->opt.k1_engine == 2 && kt <= K1M_MAX_KT) || (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT);
-        const bool want = enet || m == POLS_SOLVE_LU || ctx->opt.static_engine == 2 || (!k1_resident && !legacy_forced);
+        // OLS / ridge with 9..15 columns whose tile fits LDS stay with K1m: its solve runs unrolled on wave-uniform values in every
+        // lane (~1.5k cycles), K2's lane-cooperative register Cholesky pays ~40 cycles per cross-lane broadcast (11k cycles at 16
+        // padded columns) -- measured 3.7 against 1.6 TB/s on 10 000 x 1 000 x (8 + intercept) f32.  K2 takes what K1m cannot:
+        // 16 columns, tiles beyond LDS, and every solver that is not a Cholesky.
+        const bool k1m_takes = kt <= K1M_MAX_KT && (f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
+                                                        : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows));
+        const bool want = enet || m == POLS_SOLVE_LU || ctx->opt.static_engine == 2 || (!k1_resident && !legacy_forced && !k1m_takes);
         if (k2_ok && want) {
             K2Args a2;
             std::memset(&a2, 0, sizeof(a2));
             a2.y = st.y; a2.w = st.w;
-            for (int j = 0; j < b->n_features; ++j) a2.x[j] = st.x[j];
+            for (int j = 0; j < K2_KMAX; ++j) a2.x[j] = j < b->n_features ? st.x[j] : st.y;   // unused slots: any loadable column
             a2.offs = d_offs; a2.n_groups = b->n_groups; a2.n_rows = b->n_rows;
             a2.coef = st.coef; a2.pred = st.pred; a2.resid = st.resid; a2.status = st.status;
             a2.k_user = b->n_features; a2.kt = kt;
@@ -812,6 +820,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.k_user = b->n_features;
     a.null_policy = pol;
+    a.nt_loads = ctx->opt.k1_nt_loads > 0 ? 1 : 0;
     // The wave-per-group kernels can carry the fix-up pass as trailing workgroups of the same launch (no second dispatch in the
     // common no-flag case); everything is prepared for it here and k1_launch says whether the chosen variant took it.
     if ((rc = prepare_fix())) return rc;

@@ -57,6 +57,7 @@ struct Options {
     int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
     int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1
+    bool k2_noprefetch = false;   // POLS_K2_NOPREFETCH  eight-wave K2: one workgroup per group, no next-group prefetch into LDS
 };
 void options_from_env(Options &o);
 // key: the variable's name with or without the POLS_ prefix (case-insensitive); value NULL = back to the default.  False = unknown key.
@@ -283,6 +284,18 @@ __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v) {
 }
 __device__ __forceinline__ void store_stream(double2 *dst, const double2 &v) {
     __builtin_nontemporal_store(v.x, &dst->x); __builtin_nontemporal_store(v.y, &dst->y);
+}
+
+// Streaming 16-byte load of an input this launch reads exactly once (`nt`: no L2 allocation priority for the line).
+__device__ __forceinline__ float4 load_stream(const float4 *p) {
+    using F = __attribute__((ext_vector_type(4))) float;
+    const F v = __builtin_nontemporal_load(reinterpret_cast<const F *>(p));
+    return float4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ double2 load_stream(const double2 *p) {
+    using D = __attribute__((ext_vector_type(2))) double;
+    const D v = __builtin_nontemporal_load(reinterpret_cast<const D *>(p));
+    return double2{v.x, v.y};
 }
 
 template <typename T> __device__ __forceinline__ T vget(const typename Vec16<T>::type &v, int i);

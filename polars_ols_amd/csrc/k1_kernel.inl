@@ -36,6 +36,16 @@ template <typename T, int KT, bool HAS_W>
 __device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
     const int ku = a.k_user;
+    if (a.nt_loads) {                                        // wave-uniform
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            if (j < ku) c.x[j] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
+            else c.x[j] = vsplat<T>(T(1));
+        }
+        c.y = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
+        if constexpr (HAS_W) c.sw = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         if (j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);

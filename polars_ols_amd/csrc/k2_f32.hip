@@ -1,3 +1,3 @@
-// K2 (register-resident rows + MFMA Gram, every static solver) f32 instantiations.
+// K2 (register-resident rows + MFMA Gram, every static solver): float instantiations without sample weights.
 #include "k2_kernel.inl"
-namespace pols { template int k2_launch_t<float>(pols_ctx *, const K2Args &, int64_t); }
+namespace pols { template int k2_launch_t<float, false>(pols_ctx *, const K2Args &, int64_t); }

@@ -1,0 +1,3 @@
+// K2 (register-resident rows + MFMA Gram, every static solver): float instantiations with sample weights.
+#include "k2_kernel.inl"
+namespace pols { template int k2_launch_t<float, true>(pols_ctx *, const K2Args &, int64_t); }

@@ -1,3 +1,3 @@
-// K2 (register-resident rows + MFMA Gram, every static solver) f64 instantiations (BASELINE configs[4]: 2 000 x 16 f64 elastic net).
+// K2 (register-resident rows + MFMA Gram, every static solver): double instantiations without sample weights.
 #include "k2_kernel.inl"
-namespace pols { template int k2_launch_t<double>(pols_ctx *, const K2Args &, int64_t); }
+namespace pols { template int k2_launch_t<double, false>(pols_ctx *, const K2Args &, int64_t); }

@@ -3,7 +3,7 @@
 
 namespace pols {
 
-template <typename T> int k2_launch_t(pols_ctx *ctx, const K2Args &a, int64_t need);
+template <typename T, bool HAS_W> int k2_launch_t(pols_ctx *ctx, const K2Args &a, int64_t need);
 
 // rows the chunk grid of the largest group spans: a group that does not start on a 16-byte boundary begins up to VEC - 1 rows early
 static int64_t k2_need(int dtype, int64_t max_group_rows, bool offsets_aligned) {
@@ -13,14 +13,15 @@ static int64_t k2_need(int dtype, int64_t max_group_rows, bool offsets_aligned) 
 
 bool k2_fits(int dtype, int kt, int64_t max_group_rows, bool offsets_aligned) {
     const int vec = dtype == POLS_F32 ? 4 : 2;
-    return kt >= 1 && kt <= K2_KMAX && k2_need(dtype, max_group_rows, offsets_aligned) <= (int64_t)512 * 2 * vec;
+    return kt >= 1 && kt <= K2_KMAX && k2_need(dtype, max_group_rows, offsets_aligned) <= (int64_t)512 * 2 * vec;   // (+ n_rows >= vec: caller)
 }
 
 int k2_launch(pols_ctx *ctx, int dtype, const K2Args &a, int64_t max_group_rows) {
     if (a.kt < 1 || a.kt > K2_KMAX) return fail(POLS_ERR_UNSUPPORTED, "k2: %d columns > %d", a.kt, K2_KMAX);
     const bool aligned = ctx->offs_aligned[dtype == POLS_F32 ? 1 : 0];
     const int64_t need = k2_need(dtype, max_group_rows, aligned);
-    return dtype == POLS_F32 ? k2_launch_t<float>(ctx, a, need) : k2_launch_t<double>(ctx, a, need);
+    if (a.w) return dtype == POLS_F32 ? k2_launch_t<float, true>(ctx, a, need) : k2_launch_t<double, true>(ctx, a, need);
+    return dtype == POLS_F32 ? k2_launch_t<float, false>(ctx, a, need) : k2_launch_t<double, false>(ctx, a, need);
 }
 
 }  // namespace pols

@@ -43,6 +43,7 @@ struct K2Args {
     double pivot_tol;                    // see K1Args::pivot_tol
     int32_t *fb_flag;                    // see K1Args::fb_flag
     int32_t epoch;
+    unsigned long long *dbg;             // POLS_TIMELINE=1: 8 s_memtime stamps per group (debug only)
 };
 
 // true when some variant keeps every row of the largest group resident (dtype, columns, rows)

@@ -114,23 +114,24 @@ def test_ridge_weights_intercept_cfg3_shape(eng, engine_kind, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k", [12, 15])
-@pytest.mark.parametrize("engine", [None, "mfma"])
+@pytest.mark.parametrize("engine", [None, "k2"])
 def test_wide_features_mfma_engines(eng, dtype, k, engine):
-    """9..15 features: K2 (rows resident in registers, one 16x16 MFMA tile holds [X | y]) by default, K1m (LDS tile) on request."""
+    """9..15 features whose tile fits LDS: K1m (LDS tile, one 16x16 MFMA tile holds [X | y]) by default, K2 (rows resident in
+    registers) on request."""
     from oracle import orc
 
     rng = np.random.default_rng(k)
     offs = _ragged_offsets(rng, 21, 300, 900)
     y, cols, w = _frame(rng, offs, k - 1, dtype, weights=True)
-    eng.set_option("K1_ENGINE", engine)
+    eng.set_option("STATIC_ENGINE", engine)
     try:
         out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=True,
                                 alpha=0.5, want=("coef", "pred", "resid"))
     finally:
-        eng.set_option("K1_ENGINE", None)
+        eng.set_option("STATIC_ENGINE", None)
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True, alpha=0.5)
     _check(out, ref, dtype)
-    assert eng.last_kernel.startswith("k1m_" if engine else "k2_gram_mfma_resident"), eng.last_kernel
+    assert eng.last_kernel.startswith("k2_gram_mfma_resident" if engine else "k1m_"), eng.last_kernel
 
 
 @pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])

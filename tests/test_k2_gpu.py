@@ -55,7 +55,7 @@ def _check(out, ref, dtype, keys=("coef", "pred", "resid")):
 
 
 # (lo, hi) group sizes chosen to land on every workgroup shape: one wave (1 or 2 chunks per lane), four waves, eight waves
-SHAPES = [(8, 60, "_w1_rc1"), (70, 250, "_w1_rc2"), (300, 510, "_w4_rc1"), (600, 1000, "_w4_rc2"), (1100, 2040, "_w8_rc2")]
+SHAPES = [(20, 60, "_w1_rc1"), (70, 250, "_w1_rc2"), (300, 510, "_w4_rc1"), (600, 1000, "_w4_rc2"), (1100, 2040, "_w8_rc2")]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -71,8 +71,12 @@ def test_ols_ridge_every_shape(eng, dtype, lo, hi, shape, kt, weights, icpt, alp
     offs = _offsets(rng, 23, lo, hi)
     y, cols, w = _frame(rng, offs, kt - int(icpt), dtype, weights=weights)
     kw = dict(alpha=alpha, l1_ratio=0.0) if alpha else {}
-    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
-                            want=("coef", "pred", "resid", "status"), **kw)
+    eng.set_option("STATIC_ENGINE", "k2")                   # 9..15 columns that fit K1m's LDS tile go there by default
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                                want=("coef", "pred", "resid", "status"), **kw)
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
     assert eng.last_kernel.startswith("k2_gram_mfma_resident") and shape in eng.last_kernel and eng.last_kernel.endswith("_chol"), eng.last_kernel
     assert int(_np(out["status"]).sum()) == 0
@@ -175,7 +179,11 @@ def test_empty_tiny_and_flagged_groups(eng):
     k = 11
     y, cols, _ = _frame(rng, offs, k, np.float64)
     cols[7][43:700] = cols[2][43:700]                                           # group 4: two identical columns
-    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "status"))
+    eng.set_option("STATIC_ENGINE", "k2")
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "status"))
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
     assert eng.last_kernel.startswith("k2_")
     st = _np(out["status"]).astype(int)
     assert list(st) == [2, 0, 2, 1, 1, 2, 0], st                                # 3 rows x 11 columns and the twin columns: fallback
@@ -222,3 +230,32 @@ def test_host_path_and_determinism(eng):
     c = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), alpha=0.01, l1_ratio=0.5, want=("coef", "pred"))
     assert np.array_equal(a["coef"], _np(b["coef"])) and np.array_equal(a["pred"], _np(b["pred"]))
     assert np.array_equal(_np(b["pred"]), _np(c["pred"]))                       # fixed reduction order: run-to-run identical
+
+
+@pytest.mark.parametrize("dtype,kt,weights,icpt,kw", [
+    (np.float64, 12, True, True, dict(alpha=0.3, l1_ratio=0.0)),
+    (np.float64, 16, False, False, dict(alpha=0.01, l1_ratio=0.5, tol=1e-10, max_iter=20_000)),
+    (np.float32, 9, True, False, {}),
+])
+def test_persistent_workgroups_and_prefetch(eng, dtype, kt, weights, icpt, kw):
+    """More groups than the chip holds eight-wave workgroups: every workgroup walks several groups and the first chunks of its
+    next group arrive through the LDS prefetch buffer (ragged, unaligned groups: prefetched and directly loaded chunks mix)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(kt)
+    lo, hi = (1100, 2040) if dtype == np.float64 else (2200, 4080)
+    offs = _offsets(rng, 700, lo, hi)
+    y, cols, w = _frame(rng, offs, kt - int(icpt), dtype, weights=weights, sparsity=0.3)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                            want=("coef", "pred", "resid", "status"), **kw)
+    assert "_w8_rc2" in eng.last_kernel, eng.last_kernel
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert int(_np(out["status"]).sum()) == 0
+    _check(out, ref, dtype)
+    eng.set_option("K2_NOPREFETCH", "1")
+    try:
+        out2 = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                                 want=("coef", "pred"), **kw)
+    finally:
+        eng.set_option("K2_NOPREFETCH", None)
+    assert np.array_equal(_np(out["coef"]), _np(out2["coef"])) and np.array_equal(_np(out["pred"]), _np(out2["pred"]))

@@ -56,8 +56,12 @@ def test_elastic_net_tight_tolerance(eng, dtype, tol, k, alpha, l1, positive, me
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     y, cols, w = _frame(rng, offs, k - int(icpt), dtype, weights=weights)
     kw = dict(alpha=alpha, l1_ratio=l1, positive=positive, solve_method=method, tol=1e-10, max_iter=20_000)
-    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
-                            add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    eng.set_option("STATIC_ENGINE", "stream")             # the three-launch path (K2 takes these shapes by default: tests/test_k2_gpu.py)
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
+                                add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
     assert eng.last_kernel.startswith("k5_gram_stream")
     assert int(_np(out["status"]).sum()) == 0
@@ -204,8 +208,12 @@ def test_static_ols_ridge_wide_features_streamed(eng, dtype, tol, k, alpha, weig
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     y, cols, w = _frame(rng, offs, k - int(icpt), dtype, sparsity=0.0, weights=weights)
     kw = dict(alpha=alpha, l1_ratio=0.0) if alpha else {}
-    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
-                            add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    eng.set_option("STATIC_ENGINE", "stream")             # 16 columns fit K2 by default; this test is about the streamed kernels
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
+                                add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
     assert eng.last_kernel.startswith("k5_gram_stream") and int(_np(out["status"]).sum()) == 0
     for key in ("coef", "pred", "resid"):

@@ -69,7 +69,7 @@ def _ragged(seed, dtype, G=37, k=4, lo=12, hi=700):
     return {"y": y, "cols": cols, "offsets": offs, "w": w}
 
 
-@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-6), (np.float32, 2e-3)])
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("weights", [False, True])
 @pytest.mark.parametrize("add_intercept", [False, True])
 @pytest.mark.parametrize("alpha", [0.0, 2.5])
@@ -101,7 +101,7 @@ def test_statistics_wide_features_and_large_groups(engine):
     _check(res, exp, 1e-6, 1e-6)
 
 
-@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-6), (np.float32, 2e-3)])
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("k,weights,add_intercept,alpha", [(32, False, False, 0.0), (60, True, True, 1.5), (126, False, True, 0.0)])
 def test_statistics_wide_32_to_127_columns(engine, dtype, rtol, k, weights, add_intercept, alpha):
     """The K8 kernels solve, the wide statistics kernel works from their Gram matrix (sweep-operator inverse in LDS)."""
