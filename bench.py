@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg4r|cfg5|ref100] [--mem device|host]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input, with the input columns already resident
-in HBM when the timed region starts.  Default workload = BASELINE.json configs[1] (the configuration the metric is
-quoted on): 10 000 groups x 1 000 rows x 8 features, f32, OLS, mode="predictions".  One process per GPU; groups are
-independent, so every rank owns its own shard of groups (weak scaling, no data-path collective); for N > 1 the per-group
-coefficient tables are all-gathered over RCCL/xGMI (the "reassemble the coefficients column" step of north_star), eight
-steps' tables per collective, on a side stream so it overlaps the following kernels.  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic input, with the input columns already resident in HBM when the
+timed region starts.  Default workload = BASELINE.json configs[1] (the configuration the metric is quoted on): 10 000 groups x
+1 000 rows x 8 features, f32, OLS, mode="predictions".  Prints ONE JSON line on rank 0.
 
---config selects the other BASELINE configs for the numbers quoted in DESIGN.md (same JSON shape):
+N > 1: one process per GPU.  The frame's groups are partitioned with the product's own partitioner
+(polars_ols_amd.distributed.shard_for_rank: contiguous group ranges balanced by rows); every rank solves its shard -- no data-path
+collective -- and the per-group coefficient tables are re-assembled on every rank through the product's communicator
+(pols_comm_allgather_rows: RCCL over xGMI behind the C-ABI), eight steps' tables per collective, on a side stream so that it
+overlaps the following kernels.  torch.distributed carries the rendezvous (the communicator's 128-byte id), the barriers and the
+max-over-ranks of the elapsed time; if its RCCL backend or the product's communicator cannot be built, or a gather fails, the run
+FAILS -- a multi-GPU line is never printed without its collective.
+
+--config selects the other BASELINE configs (same JSON shape):
+  cfg1  configs[0]: ONE group, 10 000 rows x 4 f64 features, mode="coefficients" (the reference's own per-plugin-call shape)
   cfg3  10 000 x 1 000 x 8, f64, ridge alpha = 1 + sample_weights, predictions
   cfg4  1 000 000-row RLS, 6 features, half_life = 21, f64 (ONE sequence: a dependency chain, replicas only)
   cfg4r the other reading of configs[3]: 1 000 000-row rolling OLS, window = 252, 6 features, f64
   ref100 the reference's own benchmark shape: ONE 10 000 x 100 f64 OLS problem (published: 17.6 ms per call, M2 Max)
   cfg5  100 000 groups x 2 000 rows x 16 feats elastic net alpha = 0.001 l1_ratio = 0.5, f64; the groups are SPLIT
         across the ranks (strong scaling: 100 000 / N per GPU)
+--mem host (cfg1 / cfg2 / cfg3): the columns are host numpy arrays handed to the C-ABI as POLS_MEM_HOST -- the PCIe-inclusive
+  rate ("data": "synthetic, host-resident"); never the headline value.
 """
 from __future__ import annotations
 
@@ -40,33 +48,64 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(rows: int, feats: int, target_seconds: float = 12.0) -> dict:
-    """Reference-equivalent CPU path (oracle/pols_oracle.c: per group the column->row-major marshal of
-    src/expressions.rs:22-63, pivoted-QR solve_ols of src/least_squares.rs:195-240 and X.beta), OpenMP over
-    groups on all host cores like Polars' rayon pool.  Bounded sample; f64 because the reference casts to f64."""
+# ------------------------------------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+
+def _thread_ladder(cores: int):
+    return sorted({t for t in (1, 8, 32, cores) if t <= cores})
+
+
+def cpu_baseline(cfg: str, target_seconds: float = 10.0) -> dict:
+    """The reference-equivalent CPU path for this config (oracle/pols_oracle.c restates src/least_squares.rs + the marshalling of
+    src/expressions.rs:22-63), timed INSIDE liborc on a bounded sample: buffers pre-allocated and first-touched outside the clock,
+    groups dealt to OpenMP threads in static ranges (Polars' rayon pool analogue), f64 like the reference.  Reports the all-core
+    rate with the column -> row-major marshalling copy (what a plugin call really does) plus, in `sample`, the rates at 1 / 8 / 32
+    threads and the solve-only rate (pre-marshalled matrices: the variant that flatters the reference)."""
     from oracle import orc
     from refdata import synthetic_groups
 
     cores = orc.max_threads()
-    sample_groups = max(2_000, 64 * cores)
-    d = synthetic_groups(sample_groups, rows, feats, seed=1, dtype=np.float64)
-    orc.batched_least_squares(d["y"], d["cols"], d["offsets"], n_threads=cores, want=("pred",))  # warm-up
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        orc.batched_least_squares(d["y"], d["cols"], d["offsets"], n_threads=cores, want=("pred",))
-        reps += 1
-        if time.perf_counter() - t0 > target_seconds:
-            break
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    orc.batched_least_squares(d["y"], d["cols"], d["offsets"], n_threads=1, want=("pred",))
-    dt1 = time.perf_counter() - t1
-    return {"value": sample_groups * reps / dt, "unit": "regressions/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} passes over {sample_groups} groups x {rows} rows x {feats} feats f64 "
-                      f"(marshal + pivoted-QR + predictions), OpenMP {cores} threads; "
-                      f"1-thread rate {sample_groups / dt1:.0f}/s"}
+    if cfg in ("cfg4", "cfg4r"):
+        n, k = 200_000, 6
+        rng = np.random.default_rng(1)
+        cols = [rng.standard_normal(n) for _ in range(k)]
+        y = np.sum(cols, axis=0) + 0.1 * rng.standard_normal(n)
+        kind = "rls" if cfg == "cfg4" else "rolling"
+        orc.bench_dynamic(kind, y, cols, passes=1)
+        sec = orc.bench_dynamic(kind, y, cols, passes=3)
+        return {"value": 3 * n / sec, "unit": "rows/s", "cores": 1, "kind": "port",
+                "sample": f"3 passes over ONE {n}-row sequence x {k} feats f64, "
+                          f"{'solve_recursive_least_squares half_life=21' if kind == 'rls' else 'solve_rolling_ols window=252'} + "
+                          f"dynamic predictions, timed inside liborc; a sequence is a dependency chain: one core"}
+    shapes = {"cfg1": (1, 10_000, 4, {}, False), "cfg2": (max(2_048, 32 * cores), 1_000, 8, {}, False),
+              "cfg3": (max(2_048, 32 * cores), 1_000, 8, dict(alpha=1.0, l1_ratio=0.0), True),
+              "cfg5": (max(1_024, 8 * cores), 2_000, 16, dict(alpha=0.001, l1_ratio=0.5), False),
+              "ref100": (1, 10_000, 100, {}, False)}
+    G, n, k, kw, weighted = shapes[cfg]
+    d = synthetic_groups(G, n, k, seed=1, dtype=np.float64, with_weights=weighted)
+    w = d.get("w")
+    method = {"cfg1": "pivoted-QR solve_ols", "cfg2": "pivoted-QR solve_ols", "ref100": "pivoted-QR solve_ols",
+              "cfg3": "solve_ridge (X'X + aI, Cholesky)", "cfg5": "solve_elastic_net (residual-form cyclic CD)"}[cfg]
 
+    def rate(threads, solve_only=False, budget=target_seconds / 6):
+        t = min(threads, G)
+        one = orc.bench_static(d["y"], d["cols"], d["offsets"], weights=w, passes=1, n_threads=t, solve_only=solve_only, **kw)
+        passes = int(max(1, min(200, budget / max(one, 1e-6))))
+        sec = orc.bench_static(d["y"], d["cols"], d["offsets"], weights=w, passes=passes, n_threads=t, solve_only=solve_only, **kw)
+        return G * passes / sec, passes
+
+    ladder = _thread_ladder(cores if G > 1 else 1)
+    rates = {t: rate(t)[0] for t in ladder}
+    best = max(ladder, key=lambda t: rates[t])               # past the socket's memory-bandwidth knee more threads are slower:
+    full, passes = rate(best, budget=target_seconds / 3)     # the baseline is the BEST thread count, stated in `cores`
+    solve_only, _ = rate(best, solve_only=True)
+    scal = ", ".join(f"{t} thr {rates[t]:.0f}/s" for t in ladder)
+    return {"value": full, "unit": "regressions/s" if G > 1 else "problems/s", "cores": best, "kind": "port",
+            "sample": f"{passes} passes over {G} groups x {n} rows x {k} feats f64, marshal (ex.rs:22-63) + {method} + predictions, "
+                      f"timed inside liborc, static OpenMP ranges, best of the thread ladder ({orc.max_threads()} hardware threads); "
+                      f"scaling: {scal}; solve-only (pre-marshalled) {solve_only:.0f}/s at {best} threads"}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
 
 def make_columns(n: int, feats: int, tdt, seed: int, weights: bool = False):
     gen = torch.Generator(device="cuda").manual_seed(seed)
@@ -82,44 +121,61 @@ def make_columns(n: int, feats: int, tdt, seed: int, weights: bool = False):
     return y, cols, w
 
 
-def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str):
-    """Returns (plan, units_per_step_per_rank, unit_name, algorithmic_bytes_per_launch, workload_text, dtype, coef, scaling)."""
+def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: str):
+    """Returns dict(plan, units, unit, alg_bytes, text, dtype, coef, scaling, shard)."""
+    from polars_ols_amd.distributed import shard_for_rank
+
+    host = mem == "host"
+
+    def to_mem(t):
+        return t.cpu().numpy() if host else t
+
+    def grouped(G_total, n, k, tdt, b, **kw):
+        # the GLOBAL frame's offsets, partitioned by the product's partitioner; this rank generates only its shard
+        shard = shard_for_rank(np.arange(G_total + 1, dtype=np.int64) * n, world, rank)
+        G = shard.group_hi - shard.group_lo
+        y, cols, w = make_columns(G * n, k, tdt, 1234 + rank, weights=kw.pop("weights", False))
+        want = kw.pop("want", ("pred", "coef"))
+        out = None
+        if not host:
+            out = {"coef": torch.empty(G, k, device="cuda", dtype=tdt)}
+            if "pred" in want:
+                out["pred"] = torch.empty(G * n, device="cuda", dtype=tdt)
+        plan = eng.plan_least_squares(to_mem(y), [to_mem(c) for c in cols], shard.offsets, weights=None if w is None else to_mem(w),
+                                      want=want, out=out, **kw)
+        nbytes = b * n * (k + 1 + (1 if w is not None else 0)) * G + (b * n * G if "pred" in want else 0)
+        return plan, G, nbytes, (out or plan.results).get("coef"), shard
+
+    if cfg == "cfg1":
+        plan, G, nbytes, coef, shard = grouped(1, 10_000, 4, torch.float64, 8, want=("coef",))
+        text = "BASELINE configs[0]: ONE group, 10000 rows x 4 feats f64 OLS mode=coefficients (the per-plugin-call shape)"
+        return dict(plan=plan, units=1, unit="problems/s", alg_bytes=nbytes, text=text, dtype="f64", coef=None, scaling="weak", shard=shard)
     if cfg == "cfg2":
-        G, n, k = 10_000, 1_000, 8
+        G_per, n, k = 10_000, 1_000, 8
         tdt = torch.float32 if dtype_flag == "f32" else torch.float64
         b = 4 if dtype_flag == "f32" else 8
-        y, cols, _ = make_columns(G * n, k, tdt, 1234 + rank)
-        out = {"pred": torch.empty(G * n, device="cuda", dtype=tdt), "coef": torch.empty(G, k, device="cuda", dtype=tdt)}
-        plan = eng.plan_least_squares(y, cols, np.arange(G + 1, dtype=np.int64) * n, want=("pred", "coef"), out=out)
+        plan, G, nbytes, coef, shard = grouped(G_per * world, n, k, tdt, b)
         text = (f"BASELINE configs[1]: {G} groups x {n} rows x {k} feats {dtype_flag} OLS mode=predictions "
-                f"(+coefficients), inputs resident in HBM, per GPU")
-        return plan, G, "regressions/s", b * n * (k + 1) * G + b * n * G, text, dtype_flag, out["coef"], "weak"
+                f"(+coefficients), inputs resident in {'host memory (POLS_MEM_HOST)' if host else 'HBM'}, per GPU")
+        return dict(plan=plan, units=G, unit="regressions/s", alg_bytes=nbytes, text=text, dtype=dtype_flag, coef=coef, scaling="weak", shard=shard)
     if cfg == "cfg3":
-        G, n, k = 10_000, 1_000, 8
-        y, cols, w = make_columns(G * n, k, torch.float64, 1234 + rank, weights=True)
-        out = {"pred": torch.empty(G * n, device="cuda", dtype=torch.float64),
-               "coef": torch.empty(G, k, device="cuda", dtype=torch.float64)}
-        plan = eng.plan_least_squares(y, cols, np.arange(G + 1, dtype=np.int64) * n, weights=w, alpha=1.0, l1_ratio=0.0,
-                                      want=("pred", "coef"), out=out)
+        G_per, n, k = 10_000, 1_000, 8
+        plan, G, nbytes, coef, shard = grouped(G_per * world, n, k, torch.float64, 8, weights=True, alpha=1.0, l1_ratio=0.0)
         text = f"BASELINE configs[2]: {G} groups x {n} rows x {k} feats f64 ridge alpha=1.0 + sample_weights, predictions, per GPU"
-        return plan, G, "regressions/s", 8 * n * (k + 2) * G + 8 * n * G, text, "f64", out["coef"], "weak"
-    if cfg == "cfg4":
+        return dict(plan=plan, units=G, unit="regressions/s", alg_bytes=nbytes, text=text, dtype="f64", coef=coef, scaling="weak", shard=shard)
+    if cfg in ("cfg4", "cfg4r"):
         n, k = 1_000_000, 6
         y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
-        out = {"pred": torch.empty(n, device="cuda", dtype=torch.float64),
-               "coef": torch.empty(n, k, device="cuda", dtype=torch.float64)}
-        plan = eng.plan_recursive_least_squares(y, cols, np.array([0, n], dtype=np.int64), half_life=21.0, out=out)
-        text = f"BASELINE configs[3]: ONE {n}-row sequence, {k} feats f64 RLS half_life=21 (coefficients + predictions); replicas only"
-        return plan, n, "rows/s", 8 * n * (k + 1) + 8 * n * (k + 1), text, "f64", None, "weak"
-    if cfg == "cfg4r":
-        n, k = 1_000_000, 6
-        y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
-        out = {"pred": torch.empty(n, device="cuda", dtype=torch.float64),
-               "coef": torch.empty(n, k, device="cuda", dtype=torch.float64)}
-        plan = eng.plan_rolling_least_squares(y, cols, np.array([0, n], dtype=np.int64), window_size=252, min_periods=6,
-                                              null_policy="drop", out=out)
-        text = f"BASELINE configs[3], second reading: ONE {n}-row sequence, {k} feats f64 rolling OLS window=252 (coefficients + predictions); replicas only"
-        return plan, n, "rows/s", 8 * n * (k + 1) + 8 * n * (k + 1), text, "f64", None, "weak"
+        out = {"pred": torch.empty(n, device="cuda", dtype=torch.float64), "coef": torch.empty(n, k, device="cuda", dtype=torch.float64)}
+        if cfg == "cfg4":
+            plan = eng.plan_recursive_least_squares(y, cols, np.array([0, n], dtype=np.int64), half_life=21.0, out=out)
+            text = f"BASELINE configs[3]: ONE {n}-row sequence, {k} feats f64 RLS half_life=21 (coefficients + predictions); replicas only"
+        else:
+            plan = eng.plan_rolling_least_squares(y, cols, np.array([0, n], dtype=np.int64), window_size=252, min_periods=6,
+                                                  null_policy="drop", out=out)
+            text = f"BASELINE configs[3], second reading: ONE {n}-row sequence, {k} feats f64 rolling OLS window=252 (coefficients + predictions); replicas only"
+        return dict(plan=plan, units=n, unit="rows/s", alg_bytes=8 * n * (k + 1) + 8 * n * (k + 1), text=text, dtype="f64", coef=None,
+                    scaling="weak", shard=None)
     if cfg == "ref100":
         n, k = 10_000, 100
         y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
@@ -127,19 +183,14 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str):
         plan = eng.plan_least_squares(y, cols, np.array([0, n], dtype=np.int64), want=("pred", "coef"), out=out)
         text = (f"the reference's own benchmark shape (tests/benchmark.py:219, README.md:229): ONE problem, {n} rows x {k} feats f64 OLS, "
                 f"predictions; published 17.6 ms per call on an M2 Max incl. Polars overhead")
-        return plan, 1, "problems/s", 8 * n * (k + 1) + 8 * n, text, "f64", None, "weak"
+        return dict(plan=plan, units=1, unit="problems/s", alg_bytes=8 * n * (k + 1) + 8 * n, text=text, dtype="f64", coef=None, scaling="weak", shard=None)
     if cfg == "cfg5":
         Gtot, n, k = 100_000, 2_000, 16
-        G = Gtot // world
-        y, cols, _ = make_columns(G * n, k, torch.float64, 1234 + rank)
-        out = {"coef": torch.empty(G, k, device="cuda", dtype=torch.float64),
-               "pred": torch.empty(G * n, device="cuda", dtype=torch.float64)}
-        plan = eng.plan_least_squares(y, cols, np.arange(G + 1, dtype=np.int64) * n, alpha=0.001, l1_ratio=0.5,
-                                      want=("coef", "pred"), out=out)
+        plan, G, nbytes, coef, shard = grouped(Gtot, n, k, torch.float64, 8, alpha=0.001, l1_ratio=0.5, want=("coef", "pred"))
         text = (f"BASELINE configs[4]: {Gtot} groups x {n} rows x {k} feats f64 elastic net alpha=0.001 l1_ratio=0.5, "
-                f"predictions (+coefficients), groups split over {world} GPU(s): {G} per GPU")
+                f"predictions (+coefficients), groups split over {world} GPU(s): {G} on this one")
         # whole path, one launch: X and y read once (8 n (k + 1) bytes per group), predictions written (8 n)
-        return plan, G, "regressions/s", 8 * n * (k + 1) * G + 8 * n * G, text, "f64", out["coef"], "strong"
+        return dict(plan=plan, units=G, unit="regressions/s", alg_bytes=nbytes, text=text, dtype="f64", coef=coef, scaling="strong", shard=shard)
     raise SystemExit(f"unknown --config {cfg}")
 
 
@@ -150,7 +201,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg4r", "cfg5", "ref100"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4r", "cfg5", "ref100"])
+    ap.add_argument("--mem", default="device", choices=["device", "host"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,84 +210,74 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.mem == "host" and (world > 1 or args.config not in ("cfg1", "cfg2", "cfg3")):
+        raise SystemExit("--mem host: cfg1 / cfg2 / cfg3 on one GPU")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or os.environ.get("POLS_BENCH_FORCE_COLLECTIVE") == "1":   # the env knob exercises the N > 1 code on one GPU
+    force_collective = os.environ.get("POLS_BENCH_FORCE_COLLECTIVE") == "1"   # exercises the N > 1 code path on one GPU
+    if world > 1 or force_collective:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend_note = None
-        try:
-            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        except Exception as exc:  # RCCL unavailable: keep the ranks in step over gloo (barrier + max), skip the coefficient gather
-            backend_note = f"nccl init failed ({type(exc).__name__}); gloo used for barriers only"
-            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        # no fallback: if RCCL cannot initialise, the multi-GPU run fails here
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist = dist_mod
 
     from polars_ols_amd import Engine
+    from polars_ols_amd.distributed import CoefficientRing, create_comm
 
     eng = Engine(local_rank)
-    # run the engine on a torch-visible stream so torch events / RCCL can order against it
+    # run the engine on a torch-visible stream so torch events can order the collective's stream against it
     eng_stream = torch.cuda.Stream()
     eng.set_stream(eng_stream.cuda_stream)
-    plan, units, unit_name, alg_bytes, text, dtype_name, coef, scaling = build_workload(args.config, eng, rank, world, args.dtype)
+    wl = build_workload(args.config, eng, rank, world, args.dtype, args.mem)
+    plan, coef, shard = wl["plan"], wl["coef"], wl["shard"]
     torch.cuda.synchronize()                                                           # inputs are resident
-    on_gloo = dist is not None and dist.get_backend() == "gloo"
-    gather = dist is not None and coef is not None and not on_gloo
-    collective_note = "none" if not on_gloo else backend_note
+    gather = dist is not None and coef is not None
+    collective = {"kind": "none", "backend": None, "bytes_per_step_per_rank": 0}
     RING = 8
+    ring = None
     if gather:
-        # Reassembling the coefficient column is the one exchange step of the path (north_star).  Fewer, larger collectives:
-        # the coefficient tables of RING consecutive steps go into one ring buffer and ONE all-gather moves the whole ring
-        # (RING x 320 KB per rank at cfg2) on a side stream while the next steps' kernels run.  Two rings alternate; a ring
-        # is rewritten only after the gather that read it has finished -- checked on the HOST (the event is long complete in
-        # steady state), not with a barrier packet on the engine stream, which would open a bubble per step.
-        rings = [torch.empty((RING,) + tuple(coef.shape), device="cuda", dtype=coef.dtype) for _ in range(2)]
-        slots = [[ring[i] for i in range(RING)] for ring in rings]      # views made once, not per step
-        gathered = torch.empty((world * RING,) + tuple(coef.shape), device="cuda", dtype=coef.dtype)
+        # the product's communicator, on its own context / side stream so that a gather overlaps the next steps' kernels
         side = torch.cuda.Stream()
+        eng_comm = Engine(local_rank)
+        eng_comm.set_stream(side.cuda_stream)
+        comm = create_comm(eng_comm)                                                   # raises if RCCL / the communicator fails
+        counts = shard.group_counts                                                    # groups per rank (from the partitioner)
+        k = coef.shape[1]
+        gathered = torch.empty((RING * sum(counts), k), device="cuda", dtype=coef.dtype)
         produced = [torch.cuda.Event(), torch.cuda.Event()]
         consumed = [torch.cuda.Event(), torch.cuda.Event()]
         for ev in consumed:
             ev.record(side)
-        collective_note = f"all_gather(coefficient tables of {RING} steps) on a side stream, overlapped"
-    step_no = [0]
 
-    def exchange(r, used=RING):
-        nonlocal collective_note, gather
-        try:
+        def do_gather(ring_view, used):
+            # ONE collective for `used` steps' tables: every rank contributes used * (its groups) rows of k coefficients
+            comm.allgather_rows(ring_view.reshape(used * counts[rank], k), [used * c for c in counts], out=gathered[: used * sum(counts)])
+
+        def mark_produced(r):
             produced[r].record(eng_stream)
             side.wait_event(produced[r])
-            with torch.cuda.stream(side):
-                # a partly filled ring (the flush after the last step) moves only the slots that were written
-                dist.all_gather_into_tensor(gathered[: world * used], rings[r][:used])
-                consumed[r].record(side)
-        except Exception as exc:  # keep the benchmark alive: report the failure instead of dying
-            gather = False
-            collective_note = f"all_gather failed: {type(exc).__name__}: {exc}"[:200]
+
+        ring = CoefficientRing(lambda n: torch.empty((n,) + tuple(coef.shape), device="cuda", dtype=coef.dtype), RING, do_gather,
+                               produced=mark_produced, wait_consumed=lambda r: consumed[r].synchronize(),
+                               consumed=lambda r: consumed[r].record(side))
+        collective = {"kind": f"pols_comm_allgather_rows (RCCL behind the C-ABI) of {RING} steps' coefficient tables, side stream",
+                      "backend": dist.get_backend(), "bytes_per_step_per_rank": int(coef.numel() * coef.element_size()) * (world - 1)}
 
     def step():
-        i = step_no[0]
-        step_no[0] += 1
-        if not gather:
+        if ring is None:
             plan.run()
             return
-        slot, r = i % RING, (i // RING) & 1
-        if slot == 0:
-            consumed[r].synchronize()
-        plan.set_output("coef", slots[r][slot])
+        plan.set_output("coef", ring.begin_step())
         plan.run()
-        if slot == RING - 1:
-            exchange(r)
+        ring.end_step()
 
     def flush():
-        """gather the partly filled ring so that every timed step's coefficients have been reassembled"""
-        i = step_no[0]
-        if gather and i % RING != 0:
-            exchange((i // RING) & 1, i % RING)
-        step_no[0] = ((i + RING - 1) // RING) * RING
+        if ring is not None:
+            ring.flush()
 
     for _ in range(args.warmup):
         step()
@@ -245,7 +287,7 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     # per-launch HIP events inside the timed region, stamped by the kernel's own dispatch packet (hipExtLaunchKernelGGL); every
-    # 4th launch is sampled: an event pair costs ~5 us on the stream's timeline, 6 % of this kernel
+    # 4th launch is sampled: an event pair costs ~5 us on the stream's timeline, 6 % of the headline kernel
     eng.timing(4)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -259,35 +301,44 @@ def main() -> None:
     kernel_ms = eng.timing_collect()
     eng.timing(False)
 
+    total_units = float(wl["units"])
     if dist:
-        t = torch.tensor([elapsed], device="cpu" if on_gloo else "cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        u = torch.tensor([float(wl["units"])], device="cuda", dtype=torch.float64)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_units = float(u.item())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * units * args.steps / elapsed
+        value = total_units * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their own runs,
-        # gfx950 correction applied) for this exact kernel + workload; committed under profiles/.  null if absent.
+        achieved = wl["alg_bytes"] / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 correction
+        # applied) for this exact kernel + workload; committed under profiles/ (pmc_traffic.json).  null if absent.
         traffic = None
         try:
             pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-            traffic = pmc.get(eng.last_kernel, {}).get("traffic_bytes") if args.config == "cfg2" else None
+            entry = pmc.get(eng.last_kernel, {})
+            if entry.get("config", "cfg2") == args.config and args.mem == "device" and world == 1:
+                traffic = entry.get("traffic_bytes")
         except Exception:
             traffic = None
+        unit_name = wl["unit"]
         line = {
-            "metric": "group_regressions_per_sec" if unit_name == "regressions/s" else ("rolling_rows_per_sec" if args.config == "cfg4r" else ("single_problems_per_sec" if args.config == "ref100" else "rls_rows_per_sec")),
+            "metric": {"regressions/s": "group_regressions_per_sec", "problems/s": "single_problems_per_sec"}.get(
+                unit_name, "rolling_rows_per_sec" if args.config == "cfg4r" else "rls_rows_per_sec"),
             "value": value, "unit": unit_name, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": text, "units_per_gpu_per_step": units,
-                       "sharding": "groups" if world > 1 else "none",
-                       "collective": collective_note},
+            "scaling": wl["scaling"], "vs_baseline": None, "dtype": wl["dtype"],
+            "data": "synthetic" if args.mem == "device" else "synthetic, host-resident (PCIe-inclusive)",
+            "config": {"workload": wl["text"], "units_per_gpu_per_step": wl["units"],
+                       "sharding": "groups (shard_for_rank: contiguous ranges balanced by rows)" if world > 1 else "none",
+                       "world_size": world, "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": eng.last_kernel,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": wl["alg_bytes"]},
         }
         if args.config == "ref100":
             # BASELINE.md section 2 holds a published number for exactly this shape: 17.6 ms per call (OLS QR, 10 000 x 100, M2 Max,
@@ -296,8 +347,11 @@ def main() -> None:
         if args.config in ("cfg4", "cfg4r"):
             line["roofline"]["note"] = ("single sequence: bound by the serial rank-1 update chain, not by HBM; "
                                         "achieved/peak only shows how far from memory-bound it is")
-        if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
-            line["cpu_baseline"] = cpu_baseline(1_000, 8)
+        if args.config in ("cfg1", "ref100") or args.mem == "host":
+            line["roofline"]["note"] = ("one small problem / host-resident data: launch- or PCIe-bound; achieved/peak only shows how far "
+                                        "from HBM-bound it is")
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

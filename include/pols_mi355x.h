@@ -262,6 +262,41 @@ int pols_layout_untake(pols_ctx *ctx, pols_layout *layout, int element_bytes, co
  * coefficient struct over the frame (mode="coefficients" under `.over`, README.md:91). */
 int pols_layout_row_groups(pols_ctx *ctx, pols_layout *layout, int64_t *out, int mem);
 
+/* ---- more than one GPU ------------------------------------------------------------------------------------------------
+ * Groups are independent in the reference -- every plugin call sees one group's rows, nothing in src/least_squares.rs carries
+ * state across groups, and Polars runs the calls concurrently on its rayon pool (README.md:19) -- so the data path has NO
+ * collective: each GPU owns a contiguous range of groups (balanced by rows) and runs the same entries on its shard through its
+ * own pols_ctx.  The one exchange step is what Polars does when it concatenates the per-group outputs: re-assembling an output
+ * column.  These entries do that over RCCL / xGMI.  RCCL is bound at run time (librccl.so.1; an instance the process already
+ * holds is reused), so single-GPU callers never load it.
+ *
+ *   one process per GPU (MPI / torch.distributed launch):  rank 0 calls pols_comm_unique_id, ships the 128 bytes to every rank
+ *       out of band, every rank calls pols_comm_create with its own context.
+ *   one process, several GPUs (what a Polars plugin process is):  pols_create per device, then ONE pols_comm_create_all; the
+ *       per-device collective calls of one exchange are bracketed by pols_comm_group_begin / _end (or issued from one host
+ *       thread per device).
+ * Collectives are asynchronous on the context's stream (ordered behind the kernels that produced `local`). */
+typedef struct pols_comm pols_comm;
+#define POLS_COMM_ID_BYTES 128
+/* bounds_out[0 .. world_size]: rank r owns groups [bounds_out[r], bounds_out[r + 1]); boundary r is the first group boundary whose
+ * cumulative row count reaches r / world_size of the rows.  A pure function of the offsets: no communication needed to agree. */
+int pols_partition_groups(const int64_t *group_offsets, int64_t n_groups, int world_size, int64_t *bounds_out);
+int pols_comm_unique_id(void *id_out /* POLS_COMM_ID_BYTES */);
+int pols_comm_create(pols_ctx *ctx, const void *id, int world_size, int rank, pols_comm **out);
+int pols_comm_create_all(pols_ctx *const *ctxs, int n, pols_comm **out /* n communicators, rank i on ctxs[i]'s device */);
+void pols_comm_destroy(pols_comm *comm);
+int pols_comm_world_size(const pols_comm *comm);
+int pols_comm_rank(const pols_comm *comm);
+int pols_comm_group_begin(void);
+int pols_comm_group_end(void);
+/* Every rank receives all rows, in rank order (= group order, the shards being contiguous ranges): `local` holds counts[rank]
+ * rows of row_bytes bytes (a [groups x k] coefficient table: row_bytes = k * sizeof(element)), `out` sum(counts) rows; both
+ * DEVICE.  One ncclAllGather when every shard has the same size, otherwise one grouped broadcast per owner (all-gatherv). */
+int pols_comm_allgather_rows(pols_comm *comm, const void *local, const int64_t *counts, int64_t row_bytes, void *out);
+/* Per-row outputs (predictions / residuals) to ONE root, in frame order: grouped ncclSend / ncclRecv -- over point-to-point xGMI
+ * the root pulls from its peers over distinct links at once, where a ring all-gather would be bound by one link. */
+int pols_comm_gather_rows(pols_comm *comm, const void *local, const int64_t *counts, int64_t row_bytes, int root, void *out_on_root);
+
 #ifdef __cplusplus
 }
 #endif

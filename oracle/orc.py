@@ -285,3 +285,32 @@ def batched_rolling(y, x_cols, group_offsets, window_size, min_periods=None, use
 
 def max_threads() -> int:
     return int(lib().orc_max_threads())
+
+
+# ------------------------------------------------------------------ CPU baseline harness (timed inside C)
+
+def bench_static(y, x_cols, group_offsets, weights=None, add_intercept=False, solve_only=False, passes=1, n_threads=0, **kwargs) -> float:
+    """Wall seconds of ``passes`` repetitions of the grouped static path, timed INSIDE liborc with pre-allocated, first-touched
+    buffers (orc_bench_static)."""
+    y = _f64(y)
+    cols, colp = _col_ptrs(x_cols)
+    offs = np.ascontiguousarray(group_offsets, dtype=np.int64)
+    w = _f64(weights) if weights is not None else None
+    p = make_params(**kwargs)
+    fn = lib().orc_bench_static
+    fn.restype = C.c_double
+    sec = fn(_p(y), colp, _p(w), C.c_int64(len(y)), C.c_int(len(cols)), _p(offs, C.c_int64), C.c_int64(len(offs) - 1),
+             C.c_int(int(bool(add_intercept))), C.byref(p), C.c_int(int(bool(solve_only))), C.c_int(int(passes)), C.c_int(int(n_threads)))
+    if sec < 0:
+        raise RuntimeError("reference would panic")
+    return float(sec)
+
+
+def bench_dynamic(kind: str, y, x_cols, half_life=21.0, window=252, min_periods=6, passes=1) -> float:
+    """Wall seconds of ``passes`` runs of ONE sequence: kind "rls" or "rolling" (orc_bench_dynamic)."""
+    y = _f64(y)
+    cols, colp = _col_ptrs(x_cols)
+    fn = lib().orc_bench_dynamic
+    fn.restype = C.c_double
+    return float(fn(C.c_int(0 if kind == "rls" else 1), _p(y), colp, C.c_int64(len(y)), C.c_int(len(cols)), C.c_double(half_life),
+                    C.c_int64(window), C.c_int64(min_periods), C.c_int(int(passes))))

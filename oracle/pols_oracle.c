@@ -806,6 +806,48 @@ int orc_batched_least_squares(const double *y, const double *const *x_cols,
     return err;
 }
 
+/* The same driver with groups dealt to the threads in contiguous static ranges and no residual output: the CPU-baseline
+ * harness (orc_bench_static) calls this one, so that a thread re-visits the rows it first-touched. */
+int orc_batched_least_squares_static(const double *y, const double *const *x_cols, const double *weights, int64_t n_rows, int k,
+                                     const int64_t *offs, int64_t n_groups, int add_intercept, const orc_ols_params *p,
+                                     double *coef_out, double *pred_out, int n_threads) {
+    (void)n_rows;
+    const int kt = k + (add_intercept ? 1 : 0);
+    int err = 0;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t s = offs[g], n = offs[g + 1] - offs[g];
+        double *xf = tls_alloc(3, (size_t)n * kt), *yf = tls_alloc(4, (size_t)n), *sw = NULL;
+        double beta[256];
+        if (kt > 256) continue;
+        if (weights) {
+            sw = tls_alloc(5, (size_t)n);
+            for (int64_t i = 0; i < n; ++i) sw[i] = sqrt(weights[s + i]);
+        }
+        for (int j = 0; j < k; ++j) {                      /* plugin marshalling, ex.rs:22-63 */
+            const double *c = x_cols[j] + s;
+            if (sw) for (int64_t i = 0; i < n; ++i) xf[i * kt + j] = c[i] * sw[i];
+            else    for (int64_t i = 0; i < n; ++i) xf[i * kt + j] = c[i];
+        }
+        if (add_intercept) for (int64_t i = 0; i < n; ++i) xf[i * kt + k] = sw ? sw[i] : 1.0;
+        for (int64_t i = 0; i < n; ++i) yf[i] = sw ? y[s + i] * sw[i] : y[s + i];
+        if (orc_get_coefficients(yf, xf, n, kt, p, beta) < 0) err = -1;
+        if (coef_out) for (int j = 0; j < kt; ++j) coef_out[g * kt + j] = beta[j];
+        if (pred_out) {
+            for (int64_t i = 0; i < n; ++i) {
+                double a = 0.0;
+                for (int j = 0; j < kt; ++j) a += xf[i * kt + j] * beta[j];
+                if (sw) a *= 1.0 / sw[i];
+                pred_out[s + i] = a;
+            }
+        }
+    }
+    return err;
+}
+
 int orc_batched_rls(const double *y, const double *const *x_cols, int64_t n_rows, int k,
                     const int64_t *offs, int64_t n_groups, int has_half_life, double half_life,
                     double initial_state_covariance, const double *mean0, const uint8_t *valid,
@@ -949,4 +991,99 @@ int orc_feature_metrics(const double *x, const double *y, int64_t n, int k, doub
     }
     free(xtx); free(xty); free(inv); free(coef);
     return 0;
+}
+
+
+/* ---- CPU baseline harness (bench.py's cpu_baseline leg) --------------------------------------------------------------------
+ * `passes` repetitions of the grouped static path with EVERY buffer allocated and first-touched (by the thread that will use it)
+ * before the clock starts, groups dealt to threads in contiguous static ranges -- what the timed region holds is the reference's
+ * per-group work only: [marshal ->] dispatch -> solve -> predictions.  solve_only = 1 times _get_least_squares_coefficients +
+ * make_predictions on matrices marshalled (and sqrt(w)-scaled) beforehand: the variant that flatters the reference.
+ * Returns wall seconds for all passes (< 0: the reference would have panicked). */
+double orc_bench_static(const double *y, const double *const *x_cols, const double *weights, int64_t n_rows, int k,
+                        const int64_t *offs, int64_t n_groups, int add_intercept, const orc_ols_params *p,
+                        int solve_only, int passes, int n_threads) {
+    const int kt = k + (add_intercept ? 1 : 0);
+    double *pred = dalloc((size_t)n_rows), *coef = dalloc((size_t)n_groups * kt);
+    double *xf_all = solve_only ? dalloc((size_t)n_rows * kt) : NULL, *yf_all = solve_only ? dalloc((size_t)n_rows) : NULL;
+    int err = 0;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    /* first touch + (solve_only) the marshalling pass, outside the clock */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t s = offs[g], n = offs[g + 1] - offs[g];
+        for (int64_t i = 0; i < n; ++i) pred[s + i] = 0.0;
+        for (int j = 0; j < kt; ++j) coef[g * kt + j] = 0.0;
+        if (solve_only) {
+            double *xf = xf_all + s * kt, *yf = yf_all + s;
+            for (int64_t i = 0; i < n; ++i) {
+                const double sw = weights ? sqrt(weights[s + i]) : 1.0;
+                for (int j = 0; j < k; ++j) xf[i * kt + j] = x_cols[j][s + i] * sw;
+                if (add_intercept) xf[i * kt + k] = sw;
+                yf[i] = y[s + i] * sw;
+            }
+        }
+    }
+    double t0 = 0.0, t1 = 0.0;
+#ifdef _OPENMP
+    t0 = omp_get_wtime();
+#endif
+    for (int pass = 0; pass < passes; ++pass) {
+        if (!solve_only) {
+            const int rc = orc_batched_least_squares_static(y, x_cols, weights, n_rows, k, offs, n_groups, add_intercept, p, coef, pred, n_threads);
+            if (rc < 0) err = rc;
+        } else {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+            for (int64_t g = 0; g < n_groups; ++g) {
+                const int64_t s = offs[g], n = offs[g + 1] - offs[g];
+                const double *xf = xf_all + s * kt;
+                double beta[256];
+                if (kt > 256) continue;
+                if (orc_get_coefficients(yf_all + s, xf, n, kt, p, beta) < 0) err = -1;
+                for (int j = 0; j < kt; ++j) coef[g * kt + j] = beta[j];
+                for (int64_t i = 0; i < n; ++i) {
+                    double a = 0.0;
+                    for (int j = 0; j < kt; ++j) a += xf[i * kt + j] * beta[j];
+                    pred[s + i] = a;
+                }
+            }
+        }
+    }
+#ifdef _OPENMP
+    t1 = omp_get_wtime();
+#endif
+    free(pred); free(coef); free(xf_all); free(yf_all);
+    return err < 0 ? -1.0 : t1 - t0;
+}
+
+/* One sequence of the dynamic models, `passes` times, buffers pre-allocated: kind 0 = solve_recursive_least_squares + dynamic
+ * make_predictions, kind 1 = solve_rolling_ols (drop-family deque) + predictions.  The reference runs a sequence on ONE core. */
+double orc_bench_dynamic(int kind, const double *y, const double *const *x_cols, int64_t n, int k, double half_life,
+                         int64_t window, int64_t min_periods, int passes) {
+    double *xf = dalloc((size_t)n * k), *cf = dalloc((size_t)n * k), *pr = dalloc((size_t)n);
+    orc_construct_features(x_cols, n, k, xf);
+    for (int64_t i = 0; i < n * k; ++i) cf[i] = 0.0;
+    for (int64_t i = 0; i < n; ++i) pr[i] = 0.0;
+    double t0 = 0.0, t1 = 0.0;
+#ifdef _OPENMP
+    t0 = omp_get_wtime();
+#endif
+    for (int pass = 0; pass < passes; ++pass) {
+        if (kind == 0) orc_solve_rls(y, xf, n, k, 1, half_life, 10.0, NULL, NULL, cf);
+        else orc_solve_rolling_ols(y, xf, n, k, window, min_periods, -1, 0.0, NULL, ORC_NULL_DROP, cf);
+        orc_predict_dynamic(xf, cf, n, k, pr);
+    }
+#ifdef _OPENMP
+    t1 = omp_get_wtime();
+#endif
+    free(xf); free(cf); free(pr);
+    return t1 - t0;
 }

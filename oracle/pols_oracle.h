@@ -152,6 +152,19 @@ double orc_student_t_two_sided_p(double t, double df);
 
 int orc_max_threads(void);
 
+/* ---- CPU baseline harness (bench.py) ---- */
+int orc_batched_least_squares_static(const double *y, const double *const *x_cols, const double *weights, int64_t n_rows, int k,
+                                     const int64_t *group_offsets, int64_t n_groups, int add_intercept, const orc_ols_params *p,
+                                     double *coef_out, double *pred_out, int n_threads);
+/* wall seconds of `passes` repetitions, buffers pre-allocated and first-touched outside the clock; solve_only = 1 excludes the
+ * column -> row-major marshalling copy (src/expressions.rs:22-63) from the timed region */
+double orc_bench_static(const double *y, const double *const *x_cols, const double *weights, int64_t n_rows, int k,
+                        const int64_t *group_offsets, int64_t n_groups, int add_intercept, const orc_ols_params *p,
+                        int solve_only, int passes, int n_threads);
+/* kind 0: RLS (half_life), kind 1: rolling OLS (window, min_periods, "drop"), ONE sequence on one core */
+double orc_bench_dynamic(int kind, const double *y, const double *const *x_cols, int64_t n, int k, double half_life,
+                         int64_t window, int64_t min_periods, int passes);
+
 #ifdef __cplusplus
 }
 #endif

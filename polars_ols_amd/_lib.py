@@ -79,7 +79,11 @@ EXPORTS = [
     "pols_least_squares_statistics", "pols_multi_target_least_squares",
     "pols_layout_create", "pols_layout_destroy", "pols_layout_n_rows", "pols_layout_n_groups", "pols_layout_is_identity",
     "pols_layout_group_offsets", "pols_layout_group_keys", "pols_layout_take", "pols_layout_untake", "pols_layout_row_groups",
+    "pols_partition_groups", "pols_comm_unique_id", "pols_comm_create", "pols_comm_create_all", "pols_comm_destroy",
+    "pols_comm_world_size", "pols_comm_rank", "pols_comm_group_begin", "pols_comm_group_end", "pols_comm_allgather_rows",
+    "pols_comm_gather_rows",
 ]
+POLS_COMM_ID_BYTES = 128
 
 
 def build(force: bool = False, jobs: int = 8) -> Path:
@@ -138,6 +142,15 @@ def lib() -> C.CDLL:
         for fn in (L.pols_layout_take, L.pols_layout_untake):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int]
         L.pols_layout_row_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pols_partition_groups.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.c_int, C.POINTER(C.c_int64)]
+        L.pols_comm_unique_id.argtypes = [C.c_void_p]
+        L.pols_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pols_comm_create_all.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+        L.pols_comm_destroy.argtypes, L.pols_comm_destroy.restype = [C.c_void_p], None
+        L.pols_comm_world_size.argtypes = [C.c_void_p]
+        L.pols_comm_rank.argtypes = [C.c_void_p]
+        L.pols_comm_allgather_rows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p]
+        L.pols_comm_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 

@@ -820,7 +820,6 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.k_user = b->n_features;
     a.null_policy = pol;
-    a.nt_loads = ctx->opt.k1_nt_loads > 0 ? 1 : 0;
     // The wave-per-group kernels can carry the fix-up pass as trailing workgroups of the same launch (no second dispatch in the
     // common no-flag case); everything is prepared for it here and k1_launch says whether the chosen variant took it.
     if ((rc = prepare_fix())) return rc;

@@ -32,27 +32,19 @@ template <> __device__ __forceinline__ void vset<float>(float4 &v, int i, float 
 template <> __device__ __forceinline__ void vset<double>(double2 &v, int i, double x) { if (i == 0) v.x = x; else v.y = x; }
 
 // the 16-byte loads of one chunk, nothing else: the FAST kernels issue these for ALL resident chunks back to back
-template <typename T, int KT, bool HAS_W>
+template <typename T, int KT, bool HAS_W, bool NT = false>
 __device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
     const int ku = a.k_user;
-    if (a.nt_loads) {                                        // wave-uniform
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            if (j < ku) c.x[j] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
-            else c.x[j] = vsplat<T>(T(1));
-        }
-        c.y = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
-        if constexpr (HAS_W) c.sw = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
-        return;
-    }
+    // NT: streaming (`nt`) loads, a compile-time choice -- a run-time branch around the two forms cost the plain path 8 us of 73
+    auto ld = [](const V *p) -> V { if constexpr (NT) return load_stream(p); else return *p; };
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-        if (j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
+        if (j < ku) c.x[j] = ld(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
         else c.x[j] = vsplat<T>(T(1));
     }
-    c.y = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
-    if constexpr (HAS_W) c.sw = *reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0);
+    c.y = ld(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
+    if constexpr (HAS_W) c.sw = ld(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
 }
 
 template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false, bool LOADED = false>
@@ -366,7 +358,7 @@ __device__ __forceinline__ void k1_fixup_worker(const K1Args &a) {
     k6_process<T>(a.fix, worker, n_workers);
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false>
 __device__ __forceinline__ void k1_body(const K1Args &a) {
     static_assert(!FUSED || TEAM == 64, "the fused fix-up counts solver WAVES");
     if constexpr (FUSED) {
@@ -413,7 +405,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 #pragma unroll
             for (int rc = 0; rc < RC; ++rc) {
                 const int64_t c = (int64_t)rc * TEAM + tid;
-                load_chunk_raw<T, KT, HAS_W>(a, base + (c < nch ? c : 0) * VEC, res[rc]);
+                load_chunk_raw<T, KT, HAS_W, NT>(a, base + (c < nch ? c : 0) * VEC, res[rc]);
             }
         }
         if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
@@ -560,9 +552,9 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 #undef K1_STAMP
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, NT>(a);
 }
 // The same body held to 128 VGPRs (four waves per SIMD): the ragged one-chunk-per-lane wave kernel needs 130.
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
@@ -713,7 +705,6 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     const int64_t teams_per_block = block_threads / TEAM;
     int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
-    ctx->last_kernel = name;
     K1Args aa = a;
     ctx->last_fused = FUSED;
     if constexpr (FUSED) {
@@ -730,9 +721,17 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     hipEvent_t ev0, ev1;
     constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !FUSED && !NULLS;
     void (*kern)(const K1Args) = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
+    // the f32 wave-per-group FAST kernel (BASELINE configs[1]) reads its columns with `nt` (streaming) loads: every line is used
+    // once, so it should not compete for L2 with lines that are -- 73.2-73.3 against 74.3-75.0 us per 400 MB launch
+    // (POLS_K1_NT_LOADS=0 selects the plain-load build of the same kernel)
+    constexpr bool HAS_NT = sizeof(T) == 4 && TEAM == 64 && RC == 4 && FAST && NPASS == 1 && !NULLS && !FUSED;
+    if constexpr (HAS_NT) {
+        if (ctx->opt.k1_nt_loads != 0) { kern = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, true>; std::strcat(name, "_nt"); }
+    }
     if constexpr (OCC4) {
         if (!ctx->opt.k1_noocc4) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
     }
+    ctx->last_kernel = name;
     if (timing_pair(ctx, &ev0, &ev1))
         hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, ev0, ev1, 0, aa);
     else

@@ -36,7 +36,8 @@ def partition_groups(offsets: Sequence[int], world: int) -> List[int]:
     """Boundaries b[0..world] (group indices) of contiguous ranges with near-equal ROW counts.
 
     Deterministic and identical on every rank (pure function of the offsets), so no communication is needed to
-    agree on the partition."""
+    agree on the partition.  The C-ABI carries the same function for non-Python hosts (``pols_partition_groups``;
+    tests/test_distributed_cpu.py checks the two against each other)."""
     offs = np.asarray(offsets, dtype=np.int64)
     G = len(offs) - 1
     total = int(offs[-1])
@@ -96,6 +97,66 @@ def gather_rows(local_rows: torch.Tensor, shard: Shard, dst: int = 0, group=None
     if rank != dst:
         return None
     return torch.cat([bufs[r][: shard.row_counts[r]] for r in range(world)], dim=0)
+
+
+def create_comm(eng, group=None):
+    """The product's own communicator (``pols_comm_*`` over RCCL / xGMI, polars_ols_amd.engine.Comm) for an initialised
+    ``torch.distributed`` job: rank 0 makes the unique id, ``torch.distributed`` -- whatever its backend -- only carries those 128
+    bytes to the other ranks.  Failing to build it raises: a multi-GPU run never continues without its collective."""
+    from .engine import Comm
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return Comm(eng, world, rank, box[0])
+
+
+class CoefficientRing:
+    """Fewer, larger collectives for the per-step coefficient tables (the one exchange step of the path): the tables of ``n_slots``
+    consecutive steps are written into one ring buffer and ONE all-gather moves the whole ring -- a ring all-gather over
+    point-to-point xGMI pays per-hop latency seven times whatever the payload.  Two rings alternate; a ring is rewritten only
+    after the gather that read it has finished.
+
+    ``gather(ring_view, n_used) -> None`` performs the collective on ``ring_view`` (the first ``n_used`` slots of a ring);
+    ``produced(r)`` is called right before it (order the collective behind the kernels that filled ring r), ``consumed(r)`` right
+    after it, and ``wait_consumed(r)`` before ring r is rewritten.  The stream / event plumbing lives in those callbacks, so the same logic runs under gloo on the CPU
+    (tests/test_distributed_cpu.py) and over RCCL in bench.py."""
+
+    def __init__(self, make_ring, n_slots: int, gather, produced=None, wait_consumed=None, consumed=None):
+        self.n_slots = int(n_slots)
+        self.rings = [make_ring(self.n_slots) for _ in range(2)]
+        self._gather, self._produced, self._wait, self._consumed = gather, produced, wait_consumed, consumed
+        self.step_no = 0
+        self.exchanges = 0
+
+    def begin_step(self):
+        """The buffer this step's table goes to."""
+        i = self.step_no
+        slot, r = i % self.n_slots, (i // self.n_slots) & 1
+        if slot == 0 and self._wait is not None:
+            self._wait(r)
+        return self.rings[r][slot]
+
+    def end_step(self):
+        i = self.step_no
+        self.step_no += 1
+        if i % self.n_slots == self.n_slots - 1:
+            self._exchange((i // self.n_slots) & 1, self.n_slots)
+
+    def flush(self):
+        """Gather the partly filled ring so that every step's table has been reassembled; the next step starts a fresh ring."""
+        i = self.step_no
+        if i % self.n_slots:
+            self._exchange((i // self.n_slots) & 1, i % self.n_slots)
+        self.step_no = ((i + self.n_slots - 1) // self.n_slots) * self.n_slots
+
+    def _exchange(self, r: int, used: int):
+        if self._produced is not None:
+            self._produced(r)
+        self._gather(self.rings[r][:used], used)           # raises on failure: the caller does not continue without the collective
+        if self._consumed is not None:
+            self._consumed(r)                              # e.g. record an event behind the collective on its stream
+        self.exchanges += 1
 
 
 def slice_columns(columns: Sequence, shard: Shard):

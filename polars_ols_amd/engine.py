@@ -367,6 +367,71 @@ class Layout:
         return out
 
 
+class Comm:
+    """``pols_comm``: the exchange step of the multi-GPU path (re-assembling an output column over RCCL / xGMI) behind the C-ABI.
+    One process per GPU: rank 0 makes ``Comm.unique_id()``, ships the 128 bytes to the other ranks (any channel), every rank builds
+    ``Comm(engine, world, rank, uid)``.  Collectives run on the engine's stream."""
+
+    def __init__(self, eng: Engine, world: int, rank: int, unique_id: bytes):
+        self._eng, self._lib = eng, eng._lib
+        assert len(unique_id) == L.POLS_COMM_ID_BYTES
+        buf = (C.c_char * L.POLS_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        L.check(self._lib.pols_comm_create(eng._h, buf, int(world), int(rank), C.byref(h)))
+        self._h, self.world, self.rank = h, int(world), int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * L.POLS_COMM_ID_BYTES)()
+        L.check(L.lib().pols_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pols_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _counts(self, counts):
+        if len(counts) != self.world:
+            raise ValueError("one count per rank")
+        return (C.c_int64 * self.world)(*[int(c) for c in counts])
+
+    def allgather_rows(self, local, counts, out=None):
+        """Every rank receives all rows in rank order; ``local`` is this rank's [counts[rank], ...] CUDA tensor."""
+        local = local.contiguous()
+        row_bytes = local.element_size() * int(np.prod(local.shape[1:])) if local.ndim > 1 else local.element_size()
+        total = int(sum(int(c) for c in counts))
+        if out is None:
+            out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        L.check(self._lib.pols_comm_allgather_rows(self._h, C.c_void_p(local.data_ptr()), self._counts(counts), C.c_int64(row_bytes),
+                                                   C.c_void_p(out.data_ptr())))
+        return out
+
+    def gather_rows(self, local, counts, root: int = 0, out=None):
+        """Rows of every rank on ``root`` (rank order); ``None`` elsewhere."""
+        local = local.contiguous()
+        row_bytes = local.element_size() * int(np.prod(local.shape[1:])) if local.ndim > 1 else local.element_size()
+        if self.rank == root and out is None:
+            out = torch.empty((int(sum(int(c) for c in counts)),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        L.check(self._lib.pols_comm_gather_rows(self._h, C.c_void_p(local.data_ptr()), self._counts(counts), C.c_int64(row_bytes),
+                                                C.c_int(root), C.c_void_p(out.data_ptr() if self.rank == root else 0)))
+        return out if self.rank == root else None
+
+
+def partition_groups_native(offsets, world: int):
+    """``pols_partition_groups``: boundaries b[0..world] of contiguous group ranges with near-equal row counts."""
+    offs = np.ascontiguousarray(offsets, dtype=np.int64)
+    b = (C.c_int64 * (world + 1))()
+    L.check(L.lib().pols_partition_groups(offs.ctypes.data_as(C.POINTER(C.c_int64)), len(offs) - 1, int(world), b))
+    return [int(v) for v in b]
+
+
 class Plan:
     """A marshalled call: ctypes structs + references that keep every borrowed buffer alive."""
 

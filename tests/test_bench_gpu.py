@@ -31,7 +31,8 @@ def test_bench_line_contract():
         assert key in d, key
     assert d["metric"] == "group_regressions_per_sec" and d["unit"] == "regressions/s" and d["dtype"] == "f32"
     assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert "10000 groups x 1000 rows x 8 feats" in d["config"]["workload"] and d["config"]["collective"] == "none"
+    assert "10000 groups x 1000 rows x 8 feats" in d["config"]["workload"] and d["config"]["collective"]["kind"] == "none"
+    assert d["config"]["world_size"] == 1
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"].startswith("k1_gram_chol_f32_k8")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
@@ -41,8 +42,45 @@ def test_bench_line_contract():
 
 def test_bench_collective_path_on_one_gpu():
     d = _run({"POLS_BENCH_FORCE_COLLECTIVE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"}, "--no-cpu-baseline")
-    assert d["config"]["collective"].startswith("all_gather(coefficient tables of 8 steps)"), d["config"]
+    c = d["config"]["collective"]
+    assert c["kind"].startswith("pols_comm_allgather_rows") and c["backend"] == "nccl", d["config"]
     assert d["value"] > 1e7
+
+
+@pytest.mark.parametrize("cfg,metric,kernel", [("cfg1", "single_problems_per_sec", "k5_gram_stream"), ("cfg5", "group_regressions_per_sec", "k2_gram_mfma_resident_f64_k16yv_w8_rc2_cd")])
+def test_bench_other_configs(cfg, metric, kernel):
+    """--config cfg1 (BASELINE configs[0]: the per-plugin-call shape) and cfg5 (configs[4]: the whole fused path's bytes)."""
+    d = _run({}, "--no-cpu-baseline", "--config", cfg)
+    assert d["metric"] == metric and d["dtype"] == "f64" and d["roofline"]["kernel"].startswith(kernel), d["roofline"]
+    if cfg == "cfg5":
+        assert d["roofline"]["algorithmic_bytes_per_launch"] == 100_000 * (2_000 * 17 * 8 + 2_000 * 8)   # X, y in; predictions out
+        assert d["ms_per_step"] < 9.0
+
+
+def test_bench_host_memory_mode():
+    """--mem host: the same workload with host numpy columns through POLS_MEM_HOST -- the PCIe-inclusive rate, labelled as such."""
+    d = _run({}, "--no-cpu-baseline", "--mem", "host")
+    assert "host-resident" in d["data"] and "host memory" in d["config"]["workload"] and d["value"] > 1e5
+
+
+def test_comm_world_of_one(tmp_path):
+    """pols_comm_* on a 1-rank world (all a single GPU can run): create from a unique id, all-gather and gather are copies."""
+    import numpy as np
+    import torch
+
+    from polars_ols_amd import Engine
+    from polars_ols_amd.engine import Comm
+
+    eng = Engine(0)
+    comm = Comm(eng, 1, 0, Comm.unique_id())
+    assert comm.world == 1 and comm.rank == 0
+    local = torch.randn(1000, 8, device="cuda", dtype=torch.float64)
+    out = comm.allgather_rows(local, [1000])
+    root = comm.gather_rows(local[:, 0].contiguous(), [1000], root=0)
+    eng.synchronize()
+    assert torch.equal(out, local) and torch.equal(root, local[:, 0])
+    comm.close()
+    eng.close()
 
 
 def test_native_cabi_harness(tmp_path):

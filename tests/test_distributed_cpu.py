@@ -96,3 +96,95 @@ def test_more_ranks_than_groups():
     offs = np.array([0, 10, 20], dtype=np.int64)
     shards = [shard_for_rank(offs, 4, r) for r in range(4)]
     assert sum(s.group_hi - s.group_lo for s in shards) == 2
+
+
+def _ring_worker(rank, world, port, q, steps):
+    """bench.py's step / exchange / flush logic (CoefficientRing), with gloo's all_gather standing in for
+    pols_comm_allgather_rows and no streams: every step writes a recognisable table; every gathered block is checked."""
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    from polars_ols_amd.distributed import CoefficientRing, _all_gather_ragged, shard_for_rank
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    offs = np.concatenate([[0], np.cumsum(np.random.default_rng(4).integers(1, 50, size=23))]).astype(np.int64)
+    sh = shard_for_rank(offs, world, rank)
+    G, k, RING = sh.group_hi - sh.group_lo, 3, 4
+    seen, order = [], []
+
+    def gather(view, used):                                   # view: [used, G, k]
+        full = _all_gather_ragged(view.reshape(used * G, k), [used * c for c in sh.group_counts])
+        seen.append((used, full.clone()))
+
+    ring = CoefficientRing(lambda n: torch.zeros((n, G, k), dtype=torch.float64), RING, gather,
+                           produced=lambda r: order.append(("produced", r)), wait_consumed=lambda r: order.append(("wait", r)),
+                           consumed=lambda r: order.append(("consumed", r)))
+    for step in range(steps):
+        buf = ring.begin_step()
+        buf[:] = 1000.0 * step + 10.0 * rank + torch.arange(G * k, dtype=torch.float64).reshape(G, k) / 1000.0   # "plan.run()"
+        ring.end_step()
+    ring.flush()
+    # every step's table of every rank arrived, in step order within a gather and rank order within the world
+    got_steps = 0
+    for used, full in seen:
+        pos = 0
+        for r in range(world):
+            Gr = sh.group_counts[r]
+            block = full[pos:pos + used * Gr].reshape(used, Gr, k)
+            for u in range(used):
+                exp = 1000.0 * (got_steps + u) + 10.0 * r + torch.arange(Gr * k, dtype=torch.float64).reshape(Gr, k) / 1000.0
+                assert torch.equal(block[u], exp), (rank, r, got_steps + u)
+            pos += used * Gr
+        got_steps += used
+    assert got_steps == steps and ring.exchanges == len(seen) == -(-steps // RING)
+    # a ring is waited for before it is rewritten, and marked consumed right behind its gather
+    assert order[0] == ("wait", 0) and all(order[i + 1] == ("consumed", order[i][1]) for i, o in enumerate(order) if o[0] == "produced")
+    assert ring.step_no % RING == 0                            # flush leaves the next step on a fresh ring
+    q.put(len(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [4, 11])
+def test_bench_ring_logic_world2(steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, q, steps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == -(-steps // 4)
+
+
+def test_native_partition_matches_python():
+    """pols_partition_groups (the C-ABI's partitioner, what a non-Python host calls) == distributed.partition_groups."""
+    from polars_ols_amd.engine import partition_groups_native
+
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        sizes = rng.integers(0, 2_000, size=int(rng.integers(1, 300)))
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        for world in (1, 2, 3, 8):
+            assert partition_groups_native(offs, world) == partition_groups(offs, world)
+    offs = np.arange(100_001, dtype=np.int64) * 2_000           # BASELINE configs[4]
+    assert partition_groups_native(offs, 8) == [12_500 * r for r in range(9)]
+
+
+def test_comm_entries_fail_cleanly_without_a_gpu():
+    import ctypes as C
+
+    from polars_ols_amd import _lib
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.pols_comm_create(None, None, 2, 0, C.byref(h)) == -1 and not h.value    # POLS_ERR_INVALID: no context without a GPU
+    assert L.pols_comm_world_size(None) == -1 and L.pols_comm_rank(None) == -1
+    L.pols_comm_destroy(None)
