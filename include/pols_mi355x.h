@@ -262,6 +262,61 @@ int pols_layout_untake(pols_ctx *ctx, pols_layout *layout, int element_bytes, co
  * coefficient struct over the frame (mode="coefficients" under `.over`, README.md:91). */
 int pols_layout_row_groups(pols_ctx *ctx, pols_layout *layout, int64_t *out, int mem);
 
+/* ---- Arrow C Data Interface entry: what the reference's plugin functions do AROUND the solver ---------------------------------
+ * `#[polars_expr] fn least_squares(inputs: &[Series], kwargs)` / `least_squares_coefficients` (src/expressions.rs:390-446) receive
+ * their Series over the Arrow C Data Interface (one ArrowArray per chunk: values + optional validity BITMAP + element offset),
+ * cast them to Float64 with nulls -> NaN and rechunk (convert_polars_to_ndarray :66-103), and return a Series the same way
+ * (Float64 with a validity mask :145-158, or a struct of per-feature coefficients with NaN -> null :114-143).  This entry takes
+ * the arrays exactly as Polars holds them -- any numeric primitive type, null bitmaps, sliced (offset != 0) and multi-chunk
+ * columns -- and hands back a released-by-callback ArrowArray / ArrowSchema pair.  The structs below are the interface's own ABI
+ * (https://arrow.apache.org/docs/format/CDataInterface.html); the guard is the one every implementation uses. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char *format;
+    const char *name;
+    const char *metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema **children;
+    struct ArrowSchema *dictionary;
+    void (*release)(struct ArrowSchema *);
+    void *private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void **buffers;
+    struct ArrowArray **children;
+    struct ArrowArray *dictionary;
+    void (*release)(struct ArrowArray *);
+    void *private_data;
+};
+#endif
+
+typedef struct {
+    const struct ArrowSchema *schema;         /* format: g f l L i I s S c C (what the reference can cast to Float64) */
+    const struct ArrowArray *const *chunks;   /* the Series' chunks, in order; host memory; borrowed for the duration of the call */
+    int32_t n_chunks;
+} pols_arrow_column;
+
+typedef enum { POLS_MODE_PREDICTIONS = 0, POLS_MODE_RESIDUALS = 1, POLS_MODE_COEFFICIENTS = 2 } pols_output_mode;
+
+/* target / features / weights: inputs[0], inputs[1..] and the sample_weights expression of polars_ols/least_squares.py:163-239
+ * (sqrt(w) scaling, the "const" column and the 1/sqrt(w) un-scaling are fused, as in pols_least_squares).  group_offsets NULL
+ * = one group holding every row (the per-group call a plugin receives); otherwise rows sorted by group as in pols_batch.
+ * Every input Float32 -> computed and returned in f32; anything else -> f64 (the reference's Float64).
+ * out / out_schema: caller-allocated structs, filled in; the caller releases them through their `release` callbacks.
+ *   predictions / residuals: a primitive array of n_rows values named after the target; nulls where null_policy "drop" masks
+ *                            the rows it left out of the fit (residuals: also where the target is null)
+ *   coefficients:            a struct array "coefficients" of n_groups rows, one field per feature (+ "const"), NaN -> null */
+int pols_least_squares_arrow(pols_ctx *ctx, const pols_arrow_column *target, const pols_arrow_column *features, int32_t n_features,
+                             const pols_arrow_column *weights, const int64_t *group_offsets, int64_t n_groups, int32_t add_intercept,
+                             const pols_ols_params *p, int32_t mode, struct ArrowArray *out, struct ArrowSchema *out_schema);
+
 /* ---- more than one GPU ------------------------------------------------------------------------------------------------
  * Groups are independent in the reference -- every plugin call sees one group's rows, nothing in src/least_squares.rs carries
  * state across groups, and Polars runs the calls concurrently on its rayon pool (README.md:19) -- so the data path has NO

@@ -65,6 +65,10 @@ class Out(C.Structure):
     _fields_ = [("coef", C.c_void_p), ("pred", C.c_void_p), ("resid", C.c_void_p), ("status", C.c_void_p)]
 
 
+class ArrowColumn(C.Structure):       # pols_arrow_column
+    _fields_ = [("schema", C.c_void_p), ("chunks", C.POINTER(C.c_void_p)), ("n_chunks", C.c_int32)]
+
+
 class StatsOut(C.Structure):
     _fields_ = [("r2", C.c_void_p), ("mae", C.c_void_p), ("mse", C.c_void_p),
                 ("std_err", C.c_void_p), ("t_values", C.c_void_p), ("p_values", C.c_void_p)]
@@ -81,7 +85,7 @@ EXPORTS = [
     "pols_layout_group_offsets", "pols_layout_group_keys", "pols_layout_take", "pols_layout_untake", "pols_layout_row_groups",
     "pols_partition_groups", "pols_comm_unique_id", "pols_comm_create", "pols_comm_create_all", "pols_comm_destroy",
     "pols_comm_world_size", "pols_comm_rank", "pols_comm_group_begin", "pols_comm_group_end", "pols_comm_allgather_rows",
-    "pols_comm_gather_rows",
+    "pols_comm_gather_rows", "pols_least_squares_arrow",
 ]
 POLS_COMM_ID_BYTES = 128
 
@@ -142,6 +146,8 @@ def lib() -> C.CDLL:
         for fn in (L.pols_layout_take, L.pols_layout_untake):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int]
         L.pols_layout_row_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pols_least_squares_arrow.argtypes = [C.c_void_p, C.POINTER(ArrowColumn), C.POINTER(ArrowColumn), C.c_int32, C.POINTER(ArrowColumn),
+                                               C.POINTER(C.c_int64), C.c_int64, C.c_int32, C.POINTER(OlsParams), C.c_int32, C.c_void_p, C.c_void_p]
         L.pols_partition_groups.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.c_int, C.POINTER(C.c_int64)]
         L.pols_comm_unique_id.argtypes = [C.c_void_p]
         L.pols_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

@@ -367,6 +367,75 @@ class Layout:
         return out
 
 
+class _ArrowExport:
+    """One column (``pyarrow`` Array / ChunkedArray) exported through the Arrow C Data Interface as a ``pols_arrow_column``: a
+    named schema plus one ArrowArray struct per chunk.  The structs are re-imported (which releases them) on ``close()``."""
+
+    def __init__(self, name: str, col):
+        import pyarrow as pa
+
+        self._pa = pa
+        chunks = list(col.chunks) if isinstance(col, pa.ChunkedArray) else [col]
+        typ = col.type
+        self._schema = (C.c_byte * 72)()
+        pa.field(name, typ)._export_to_c(C.addressof(self._schema))
+        self._arrays = []
+        for ch in chunks:
+            a = (C.c_byte * 80)()
+            ch._export_to_c(C.addressof(a))
+            self._arrays.append(a)
+        self._ptrs = (C.c_void_p * max(1, len(chunks)))(*[C.addressof(a) for a in self._arrays])
+        self._type = typ
+        self.column = L.ArrowColumn(schema=C.addressof(self._schema), chunks=self._ptrs, n_chunks=len(chunks))
+
+    def close(self):
+        pa = self._pa
+        for a in self._arrays:                               # importing takes ownership back and releases on collection
+            pa.Array._import_from_c(C.addressof(a), self._type)
+        self._arrays = []
+        pa.Field._import_from_c(C.addressof(self._schema))
+
+
+def _least_squares_arrow(self, target, features, *, target_name: str = "y", weights=None, offsets=None, add_intercept: bool = False,
+                         mode: str = "predictions", alpha: float = 0.0, l1_ratio: Optional[float] = None, max_iter: int = 1000,
+                         tol: float = 1e-5, positive: bool = False, solve_method: Optional[str] = None, rcond: Optional[float] = None,
+                         null_policy: str = "ignore"):
+    """``pols_least_squares_arrow``: the plugin bodies of src/expressions.rs:390-446 on Arrow columns as Polars holds them.
+    ``target`` / ``weights``: pyarrow Array or ChunkedArray; ``features``: dict name -> column (or a list of columns, named by
+    index).  Returns a pyarrow Array: predictions / residuals (nullable) or the ``coefficients`` struct."""
+    import pyarrow as pa
+
+    feats = list(features.items()) if isinstance(features, dict) else [("", f) for f in features]
+    ex_t = _ArrowExport(target_name, target)
+    ex_f = [_ArrowExport(n, f) for n, f in feats]
+    ex_w = _ArrowExport("sample_weights", weights) if weights is not None else None
+    try:
+        fcols = (L.ArrowColumn * len(ex_f))(*[e.column for e in ex_f])
+        p = L.OlsParams()
+        self._lib.pols_ols_params_default(C.byref(p))
+        p.alpha = float(alpha if alpha is not None else 0.0)
+        p.has_l1_ratio, p.l1_ratio = int(l1_ratio is not None), float(l1_ratio) if l1_ratio is not None else 0.0
+        p.max_iter, p.tol, p.positive = int(max_iter), float(tol), int(bool(positive))
+        p.solve_method = L.SOLVE_METHODS[solve_method]
+        p.has_rcond, p.rcond = int(rcond is not None), float(rcond) if rcond is not None else 0.0
+        p.null_policy = L.NULL_POLICIES[null_policy]
+        offs = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int64)
+        out_a, out_s = (C.c_byte * 80)(), (C.c_byte * 72)()
+        rc = self._lib.pols_least_squares_arrow(
+            self._h, C.byref(ex_t.column), fcols, len(ex_f), C.byref(ex_w.column) if ex_w else None,
+            offs.ctypes.data_as(C.POINTER(C.c_int64)) if offs is not None else None, 0 if offs is None else len(offs) - 1,
+            int(bool(add_intercept)), C.byref(p), {"predictions": 0, "residuals": 1, "coefficients": 2}[mode],
+            C.addressof(out_a), C.addressof(out_s))
+        L.check(rc)
+        return pa.Array._import_from_c(C.addressof(out_a), C.addressof(out_s))
+    finally:
+        for e in [ex_t] + ex_f + ([ex_w] if ex_w else []):
+            e.close()
+
+
+Engine.least_squares_arrow = _least_squares_arrow
+
+
 class Comm:
     """``pols_comm``: the exchange step of the multi-GPU path (re-assembling an output column over RCCL / xGMI) behind the C-ABI.
     One process per GPU: rank 0 makes ``Comm.unique_id()``, ships the 128 bytes to the other ranks (any channel), every rank builds
