@@ -36,15 +36,26 @@ template <typename T, int KT, bool HAS_W, bool NT = false>
 __device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
     const int ku = a.k_user;
-    // NT: streaming (`nt`) loads, a compile-time choice -- a run-time branch around the two forms cost the plain path 8 us of 73
-    auto ld = [](const V *p) -> V { if constexpr (NT) return load_stream(p); else return *p; };
+    // NT: streaming (`nt`) loads, a compile-time choice -- a run-time branch around the two forms cost the plain path 8 us of 73.
+    // (Written out twice on purpose: routing the loads through a small lambda kept the chunk in scratch memory in the ragged
+    // kernels -- 736 bytes per lane, 4x slower.)
+    if constexpr (NT) {
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        if (j < ku) c.x[j] = ld(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
-        else c.x[j] = vsplat<T>(T(1));
+        for (int j = 0; j < KT; ++j) {
+            if (j < ku) c.x[j] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
+            else c.x[j] = vsplat<T>(T(1));
+        }
+        c.y = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
+        if constexpr (HAS_W) c.sw = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
+    } else {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            if (j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
+            else c.x[j] = vsplat<T>(T(1));
+        }
+        c.y = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
+        if constexpr (HAS_W) c.sw = *reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0);
     }
-    c.y = ld(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
-    if constexpr (HAS_W) c.sw = ld(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
 }
 
 template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false, bool LOADED = false>

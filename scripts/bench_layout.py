@@ -34,9 +34,9 @@ def main():
     lay = Layout(eng, key)
     res["take_9_f32_columns_ms"] = timed(lambda: lay.take(cols))
     for mode in ("gather", "scatter"):
-        os.environ["POLS_K9_TAKE"] = mode
+        eng.set_option("K9_TAKE", mode)
         res[f"take_9_f32_columns_{mode}_ms"] = timed(lambda: lay.take(cols))
-    os.environ.pop("POLS_K9_TAKE")
+    eng.set_option("K9_TAKE", None)
     cols64 = [c.double() for c in cols[:3]]
     res["take_3_f64_columns_ms"] = timed(lambda: lay.take(cols64))
     moved = lay.take(cols)

@@ -10,7 +10,7 @@ cols = [torch.randn(N, generator=g, device="cuda", dtype=torch.float32) for _ in
 y = sum(cols) + 0.1 * torch.randn(N, generator=g, device="cuda", dtype=torch.float32)
 offs = np.arange(groups + 1, dtype=np.int64) * rows
 for engine in ("valu", "mfma"):
-    os.environ["POLS_K1_ENGINE"] = engine
+    eng.set_option("K1_ENGINE", engine)
     a = eng.least_squares(y, cols, offs, want=("coef", "pred"))
     b = eng.least_squares(y, cols, offs, want=("coef", "pred"))
     torch.cuda.synchronize()

@@ -13,11 +13,11 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     for g in flagged:                                     # two identical columns -> rank deficient -> flagged
         cols[5][g * n:(g + 1) * n] = cols[2][g * n:(g + 1) * n]
     offs = np.arange(G + 1, dtype=np.int64) * n
-    os.environ["POLS_FUSED_FIXUP"] = "1"
+    eng.set_option("FUSED_FIXUP", "1")
     out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
     kern = eng.last_kernel
     torch.cuda.synchronize()
-    del os.environ["POLS_FUSED_FIXUP"]
+    eng.set_option("FUSED_FIXUP", None)
     ref = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
     torch.cuda.synchronize()
     st = out["status"].cpu().numpy()

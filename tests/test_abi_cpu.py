@@ -115,3 +115,26 @@ def test_header_is_plain_c_and_links(tmp_path):
                     f"-L{_lib.LIB_PATH.parent}", "-lpols_mi355x", f"-Wl,-rpath,{_lib.LIB_PATH.parent}"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[-4:] == ["1", "10", "1000000", "1024"], out
+
+
+def test_hot_kernels_keep_their_arrays_in_registers():
+    """The code objects' own metadata (no GPU, no recompilation): none of the HBM-bound static kernels may hold an array in scratch
+    memory -- private_segment_fixed_size 0.  A lambda around K1's loads once put the ragged kernels' chunks in scratch (736 bytes per
+    lane, 4x slower) without a single compiler warning; this pins it.  Allowed: the fused-fix-up K1 builds (an SGPR spill slot) and
+    the ragged one-chunk kernel that is deliberately held to 128 VGPRs."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "scripts"))
+    from check_scratch import LLVM, kernel_scratch
+
+    if not (LLVM / "llvm-objdump").exists():
+        pytest.skip("ROCm LLVM tools not present")
+    if not _lib.LIB_PATH.exists():
+        _lib.build()
+    ks = kernel_scratch(_lib.LIB_PATH)
+    assert len(ks) > 500, len(ks)
+    hot = ("pols::k1_kernel<", "pols::k1t_kernel<", "pols::k1m_kernel<", "pols::k2_kernel<", "pols::gram_stream_kernel<",
+           "pols::predict_kernel<", "pols::gram_solve_kernel<", "pols::take_kernel<", "pols::arrow_ingest_kernel<")
+    bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0
+           and not k.rstrip().endswith("true, false>(pols::K1Args)")}          # FUSED = true, NT = false: the fused fix-up builds
+    assert not bad, sorted(bad.items())[:5]
