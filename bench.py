@@ -168,11 +168,13 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
         y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
         out = {"pred": torch.empty(n, device="cuda", dtype=torch.float64), "coef": torch.empty(n, k, device="cuda", dtype=torch.float64)}
         if cfg == "cfg4":
-            plan = eng.plan_recursive_least_squares(y, cols, np.array([0, n], dtype=np.int64), half_life=21.0, out=out)
+            # null_free: the synthetic columns hold no nulls, which a Polars caller reads off null_count (the reference's own
+            # validity mask is then an all-true bitmap, src/expressions.rs:201-228); without it the entry scans the columns
+            plan = eng.plan_recursive_least_squares(y, cols, np.array([0, n], dtype=np.int64), half_life=21.0, out=out, null_free=True)
             text = f"BASELINE configs[3]: ONE {n}-row sequence, {k} feats f64 RLS half_life=21 (coefficients + predictions); replicas only"
         else:
             plan = eng.plan_rolling_least_squares(y, cols, np.array([0, n], dtype=np.int64), window_size=252, min_periods=6,
-                                                  null_policy="drop", out=out)
+                                                  null_policy="drop", out=out, null_free=True)
             text = f"BASELINE configs[3], second reading: ONE {n}-row sequence, {k} feats f64 rolling OLS window=252 (coefficients + predictions); replicas only"
         return dict(plan=plan, units=n, unit="rows/s", alg_bytes=8 * n * (k + 1) + 8 * n * (k + 1), text=text, dtype="f64", coef=None,
                     scaling="weak", shard=None)

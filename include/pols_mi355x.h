@@ -136,7 +136,7 @@ typedef struct {
     double half_life;
     int32_t has_half_life;
     double initial_state_covariance;        /* default 10.0 */
-    const double *initial_state_mean;       /* HOST, n_features values, or NULL */
+    const double *initial_state_mean;       /* HOST, n_features + add_intercept values, or NULL */
     int32_t null_policy;                    /* default "drop" */
 } pols_rls_params;
 void pols_rls_params_default(pols_rls_params *p);
@@ -168,6 +168,10 @@ typedef struct {
                                      (group_offsets pointer, n_groups, offsets_generation) always names the same content and bumps
                                      the value whenever it rewrites the array -- repeated calls on one frame then cost O(1) on
                                      the host instead of a pass over the offsets */
+    int32_t null_free;            /* non-zero: the caller KNOWS that no target / feature value is null (= NaN here) -- what a Polars
+                                     / Arrow caller reads off null_count == 0 for free.  The null policy then has nothing to do:
+                                     the static entry takes its policy-free kernels and the dynamic entries skip their validity
+                                     scan (one pass over the columns + one stream synchronisation per call).  0 = unknown */
 } pols_batch;
 
 typedef struct {
@@ -188,7 +192,13 @@ typedef struct {
 int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o);
 
 /* Replaces solve_recursive_least_squares (src/least_squares.rs:568-598) + the
- * dynamic make_predictions (src/expressions.rs:184,640-645); one sequence per group. */
+ * dynamic make_predictions (src/expressions.rs:184,640-645); one sequence per group.
+ * RAW columns go in (both dynamic entries): b->weights, b->add_intercept and the null policy are honoured on the device --
+ * sqrt(w) scaling of target and features with a null weight acting as 1e-24 (polars_ols/least_squares.py:190-196), the ones
+ * column appended LAST, compute_is_valid_mask for p->null_policy from the NaNs (= nulls) of the scaled columns
+ * (src/expressions.rs:201-228; skipped when b->valid is given or b->null_free is set), nulls -> 0 (ex.rs:603, 629, 656, 683),
+ * predictions masked by the validity (ex.rs:640-645, 695-700) and un-scaled by 1 / sqrt(w) (ls.py:234-235).  coef has
+ * kt = n_features + add_intercept columns; p->initial_state_mean has kt values. */
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o);
 
 /* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions. */

@@ -58,7 +58,7 @@ class Batch(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("mem", C.c_int32), ("n_rows", C.c_int64), ("n_groups", C.c_int64),
                 ("group_offsets", C.POINTER(C.c_int64)), ("n_features", C.c_int32), ("y", C.c_void_p),
                 ("x_cols", C.POINTER(C.c_void_p)), ("weights", C.c_void_p), ("valid", C.c_void_p),
-                ("add_intercept", C.c_int32), ("offsets_generation", C.c_uint64)]
+                ("add_intercept", C.c_int32), ("offsets_generation", C.c_uint64), ("null_free", C.c_int32)]
 
 
 class Out(C.Structure):

@@ -15,6 +15,7 @@
 #include "k6_svd.hpp"
 #include "k7_stats.hpp"
 #include "k8_wide.hpp"
+#include "dyn_prep.hpp"
 
 namespace pols {
 template <typename T> bool k1m_fits(int k_user, bool has_w, int64_t max_rows);   // k1m_f32.hip / k1m_f64.hip
@@ -592,7 +593,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     // drop family.  They are fused into the streamed path's staging / prediction passes -- no compaction, no copies.
     const int pol = p->null_policy;
     if (pol < POLS_NULL_IGNORE || pol > POLS_NULL_DROP_WINDOW) return fail(POLS_ERR_INVALID, "unknown null_policy %d", pol);
-    const bool nulls = pol != POLS_NULL_IGNORE;
+    const bool nulls = pol != POLS_NULL_IGNORE && !(b->null_free && !b->valid);   // nothing null: every policy is the identity
     if (b->valid && (pol == POLS_NULL_IGNORE || pol == POLS_NULL_ZERO))
         return fail(POLS_ERR_INVALID, "a validity mask needs a drop-family null_policy");
 
@@ -979,17 +980,80 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
     return unstage_outputs(ctx, b, b->n_groups, kt, &oo, info.st);
 }
 
-// Dynamic models share the staging of a batch whose coefficient output has one row per input row.
-static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, pols_out *o, const int64_t **d_offs, int64_t *max_rows,
-                            Staged *st) {
+// Dynamic models share the staging of a batch whose coefficient output has one row per input row, and the pre-processing the
+// reference's Python layer / plugin bodies do around the solver (dyn_prep.hpp): validity from the null policy, sqrt(w) scaling, the
+// ones column, nulls -> 0 -- on the device, behind the boundary.
+struct DynState {
+    int k = 0;                       // columns the kernels see: n_features + add_intercept
+    bool post = false;               // predictions need the 1 / sqrt(w) un-scaling and / or the validity mask
+    DynPrepArgs pa;
+    pols_batch tables;               // the batch as build_chunk_tables should see it (validity bytes may now live on the device)
+};
+
+static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, int null_policy, pols_out *o, const int64_t **d_offs, int64_t *max_rows,
+                            Staged *st, DynState *ds) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if ((rc = check_batch(b, o, K4Y_KMAX))) return rc;
-    if (b->add_intercept || b->weights)
-        return fail(POLS_ERR_INVALID, "dynamic models take pre-processed columns: apply sqrt(w) / append the ones column "
-                                      "before the call, exactly like polars_ols/least_squares.py:184-196 does for the plugin");
+    if (null_policy < POLS_NULL_IGNORE || null_policy > POLS_NULL_DROP_WINDOW) return fail(POLS_ERR_INVALID, "unknown null_policy %d", null_policy);
+    const int k = b->n_features + (b->add_intercept ? 1 : 0);
+    ds->k = k;
+    ds->tables = *b;
+    std::memset(&ds->pa, 0, sizeof(ds->pa));
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, d_offs, max_rows, b->offsets_generation))) return rc;
-    return stage_inputs(ctx, b, b->n_rows, b->n_features, o, st);
+    if ((rc = stage_inputs(ctx, b, b->n_rows, k, o, st))) return rc;
+    if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
+    const bool scan = st->valid == nullptr && !b->null_free;   // no validity bytes from the caller: a null is a NaN, the policy decides
+    const bool has_w = st->w != nullptr, icpt = b->add_intercept != 0;
+    bool some_invalid = !scan, some_null = false;
+    const size_t sz = dtype_size(b->dtype), colb = round256(sz * (size_t)b->n_rows), vb = round256((size_t)b->n_rows);
+    char *base = nullptr;
+    DynPrepArgs &pa = ds->pa;
+    if (scan || has_w || icpt) {
+        // slot 14: [flags][validity bytes][feature pointers in][column pointers out][sqrt(w)][target][k columns]
+        void *d = nullptr;
+        const size_t tabb = round256(sizeof(void *) * (size_t)std::max(k, 1));
+        if ((rc = ensure_scratch(ctx, 14, 256 + vb + 2 * tabb + colb * (size_t)(k + 2), &d))) return rc;
+        base = static_cast<char *>(d);
+        char *cols = base + 256 + vb + 2 * tabb;
+        std::vector<void *> outp((size_t)k);
+        for (int j = 0; j < k; ++j) outp[(size_t)j] = cols + colb * (size_t)(2 + j);
+        if ((rc = upload_small(ctx, base + 256 + vb, st->x.data(), sizeof(void *) * (size_t)b->n_features))) return rc;
+        if ((rc = upload_small(ctx, base + 256 + vb + tabb, outp.data(), sizeof(void *) * (size_t)k))) return rc;
+        pa.y = st->y; pa.w = st->w;
+        pa.xtab = reinterpret_cast<const void *const *>(base + 256 + vb);
+        pa.k_user = b->n_features; pa.add_intercept = icpt ? 1 : 0; pa.null_policy = null_policy; pa.n_rows = b->n_rows;
+        pa.valid_out = reinterpret_cast<uint8_t *>(base + 256);
+        pa.flags = reinterpret_cast<int32_t *>(base);
+        pa.sw_out = has_w ? cols : nullptr;
+        pa.y_out = cols + colb;
+        pa.xout = reinterpret_cast<void *const *>(base + 256 + vb + tabb);
+        if (scan) {
+            POLS_HIP(hipMemsetAsync(base, 0, 256, ctx->stream));
+            if ((rc = dyn_scan_launch(ctx, b->dtype, pa))) return rc;
+            int32_t flags[2] = {0, 0};
+            POLS_HIP(hipMemcpyAsync(flags, base, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+            POLS_HIP(hipStreamSynchronize(ctx->stream));   // the host decides which path runs (mask-free tables are cached)
+            some_invalid = flags[0] > 0;
+            some_null = flags[1] > 0;
+            if (some_invalid) {
+                st->valid = pa.valid_out;
+                ds->tables.valid = pa.valid_out;
+                ds->tables.mem = POLS_MEM_DEVICE;
+            }
+        }
+        if (has_w || icpt || some_invalid || some_null) {
+            // (rows left out of the fit hold the nulls that put them there: zero-filled too, so that no kernel ever multiplies a NaN by 0)
+            if ((rc = dyn_rewrite_launch(ctx, b->dtype, pa))) return rc;
+            st->y = pa.y_out;
+            st->x.assign(outp.begin(), outp.end());
+        }
+    }
+    ds->post = (has_w || st->valid != nullptr) && st->pred != nullptr;
+    pa.pred = st->pred;
+    pa.valid_post = st->valid;
+    if (!has_w) pa.sw_out = nullptr;
+    return POLS_OK;
 }
 
 static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, int slots, K4Args *a, int64_t min_chunk = 64, int64_t max_chunk = 512);
@@ -1018,40 +1082,42 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
     Staged st;
-    int rc = dynamic_prologue(ctx, b, o, &d_offs, &max_rows, &st);
+    DynState ds;
+    int rc = dynamic_prologue(ctx, b, p->null_policy, o, &d_offs, &max_rows, &st, &ds);
     if (rc) return rc;
     if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
     if (o->resid) return fail(POLS_ERR_INVALID, "rls: residuals are target - predictions in the caller (least_squares.py:239)");
+    const int kf = ds.k;                                  // features the kernels see (the intercept column included)
     K3Args a;
     std::memset(&a, 0, sizeof(a));
     a.y = st.y; a.valid = st.valid;
-    for (int j = 0; j < std::min<int>(b->n_features, POLS_MAX_FEATURES); ++j) a.x[j] = st.x[j];
+    for (int j = 0; j < std::min<int>(kf, POLS_MAX_FEATURES); ++j) a.x[j] = st.x[j];
     a.offs = d_offs;
     a.n_groups = b->n_groups;
     a.coef = st.coef; a.pred = st.pred;
-    a.k = b->n_features;
+    a.k = kf;
     a.forgetting_factor = p->has_half_life ? std::exp(std::log(0.5) / p->half_life) : 1.0;   // ls.rs:513-517
     a.initial_state_covariance = p->initial_state_covariance;
     if (p->initial_state_mean) {
         void *d = nullptr;
         if ((rc = dynamic_slot6(ctx, &d))) return rc;
-        if ((rc = upload_small(ctx, d, p->initial_state_mean, sizeof(double) * b->n_features))) return rc;   // the host array belongs to the caller
+        if ((rc = upload_small(ctx, d, p->initial_state_mean, sizeof(double) * kf))) return rc;   // the host array belongs to the caller (kf values)
         a.mean0 = static_cast<const double *>(d);
     }
     // Long sequences: the chunk-parallel information-form scan (K3s); short ones: the wave-per-sequence P-form
     // recursion (K3).  POLS_RLS_ENGINE=seq|scan forces one.
     // More than 8 features: the wave-per-chunk scan (k4w_wide.hip), whatever the length; more than 32: the workgroup-per-chunk
     // kernels that propagate the inverse (k4x_inverse.hip).
-    const bool wide = b->n_features > K4_KMAX, xwide = b->n_features > POLS_MAX_FEATURES;
+    const bool wide = kf > K4_KMAX, xwide = kf > POLS_MAX_FEATURES;
     bool scan = max_rows > 4096 || wide;
     if (ctx->opt.rls_engine == 1 && !wide) scan = false;
     if (ctx->opt.rls_engine == 2) scan = true;
     if (scan) {
-        const int k = b->n_features;
+        const int k = kf;
         K4Args s4;
         std::memset(&s4, 0, sizeof(s4));
         const int64_t minc = k > 128 ? hbm_state_chunk(b->n_rows) : 64;
-        if ((rc = build_chunk_tables(ctx, b, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, minc, std::max<int64_t>(512, minc)))) return rc;
+        if ((rc = build_chunk_tables(ctx, &ds.tables, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, minc, std::max<int64_t>(512, minc)))) return rc;
         s4.y = st.y; s4.valid = st.valid;
         if ((rc = upload_column_table(ctx, st, k, &s4))) return rc;
         s4.coef = st.coef; s4.pred = st.pred;
@@ -1063,7 +1129,8 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     } else {
         if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
     }
-    return unstage_outputs(ctx, b, b->n_rows, b->n_features, o, st);
+    if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+    return unstage_outputs(ctx, b, b->n_rows, kf, o, st);
 }
 
 // Host-side tables shared by the chunk-parallel dynamic kernels (K4 rolling, K3s RLS scan): validity prefix
@@ -1169,11 +1236,12 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
     Staged st;
-    int rc = dynamic_prologue(ctx, b, o, &d_offs, &max_rows, &st);
+    DynState ds;
+    int rc = dynamic_prologue(ctx, b, p->null_policy, o, &d_offs, &max_rows, &st, &ds);
     if (rc) return rc;
     if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
     if (o->resid) return fail(POLS_ERR_INVALID, "rolling: residuals are target - predictions in the caller (least_squares.py:239)");
-    const int k = b->n_features;
+    const int k = ds.k;                                   // features the kernels see (the intercept column included)
     const bool wide = k > K4_KMAX, xwide = k > POLS_MAX_FEATURES;                               // k4w_wide.hip / k4x_inverse.hip
     if (p->window_size < 1) return fail(POLS_ERR_INVALID, "window_size must be >= 1");
     const int64_t w = p->window_size;
@@ -1186,7 +1254,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     K4Args a;
     std::memset(&a, 0, sizeof(a));
     const int64_t minc = k > 128 ? hbm_state_chunk(b->n_rows) : 64;
-    if ((rc = build_chunk_tables(ctx, b, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, minc, std::max<int64_t>(512, minc)))) return rc;
+    if ((rc = build_chunk_tables(ctx, &ds.tables, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, minc, std::max<int64_t>(512, minc)))) return rc;
     a.y = st.y; a.valid = st.valid;
     if ((rc = upload_column_table(ctx, st, k, &a))) return rc;
     a.coef = st.coef; a.pred = st.pred;
@@ -1195,6 +1263,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     if (wide) { a.tot_cs = k * k + k; a.tot_qs = 1; }
     else { a.tot_cs = 1; a.tot_qs = a.n_chunks; }
     if ((rc = k > K4X_KMAX ? k4y_launch(ctx, b->dtype, a) : xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a)))) return rc;
+    if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, k, o, st);
 }
 

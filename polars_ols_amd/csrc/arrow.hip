@@ -266,6 +266,12 @@ static int arrow_ls(pols_ctx *ctx, const pols_arrow_column *target, const pols_a
     b.mem = POLS_MEM_DEVICE;
     b.n_rows = n_rows; b.n_groups = n_groups; b.group_offsets = group_offsets;
     b.n_features = n_features; b.y = dy; b.x_cols = dx.data(); b.weights = dw; b.add_intercept = add_intercept;
+    auto no_nulls = [](const pols_arrow_column *c) {
+        for (int i = 0; i < c->n_chunks; ++i) if (c->chunks[i]->null_count != 0) return false;   // (-1 = not computed: unknown)
+        return true;
+    };
+    b.null_free = no_nulls(target) ? 1 : 0;                   // Arrow carries the null counts: the policy-free kernels for free
+    for (int j = 0; j < n_features && b.null_free; ++j) b.null_free = no_nulls(&features[j]) ? 1 : 0;
     pols_out o;
     std::memset(&o, 0, sizeof(o));
     if (mode == POLS_MODE_COEFFICIENTS) o.coef = dout;

@@ -1,0 +1,73 @@
+// dyn_prep.hip -- see dyn_prep.hpp.  HBM-bound element-wise passes: one thread per row walks the columns (consecutive lanes =
+// consecutive rows of every column: coalesced), nothing to tile.
+#include "dyn_prep.hpp"
+
+namespace pols {
+
+template <typename T>
+__global__ void __launch_bounds__(256) dyn_scan_kernel(const DynPrepArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int invalid = 0, nulls = 0;
+    if (r < a.n_rows) {
+        const T yv = static_cast<const T *>(a.y)[r];
+        bool ynull = yv != yv, xnull = false;
+        for (int j = 0; j < a.k_user; ++j) { const T v = static_cast<const T *>(a.xtab[j])[r]; xnull = xnull || (v != v); }
+        if (a.w) { const T wv = static_cast<const T *>(a.w)[r]; (void)wv; }   // a null weight is a weight of 1e-24, not a dropped row (ls.py:193)
+        const int pol = a.null_policy;
+        bool ok = true;                                                         // "ignore" / "zero": every row is kept (ex.rs:221-226)
+        if (pol == POLS_NULL_DROP || pol == POLS_NULL_DROP_ZERO || pol == POLS_NULL_DROP_WINDOW) ok = !ynull && !xnull;   // :209-216
+        else if (pol == POLS_NULL_DROP_Y_ZERO_X) ok = !ynull;                                                             // :217-220
+        a.valid_out[r] = ok ? 1 : 0;
+        invalid = ok ? 0 : 1;
+        nulls = (ok && (ynull || xnull)) ? 1 : 0;
+    }
+    const unsigned long long bi = __ballot(invalid), bn = __ballot(nulls);
+    if ((threadIdx.x & 63) == 0) {
+        if (bi) atomicAdd(&a.flags[0], __popcll(bi));
+        if (bn) atomicAdd(&a.flags[1], __popcll(bn));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) dyn_rewrite_kernel(const DynPrepArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_rows) return;
+    T sw = T(1);
+    if (a.w) {
+        T wv = static_cast<const T *>(a.w)[r];
+        if (wv != wv) wv = (T)1e-24;                                            // sqrt_w.fill_null(1e-12)  (ls.py:193)
+        sw = sqrt(wv);
+        static_cast<T *>(a.sw_out)[r] = sw;
+    }
+    T yv = static_cast<const T *>(a.y)[r];
+    static_cast<T *>(a.y_out)[r] = (yv != yv) ? T(0) : yv * sw;                 // NullPolicy::Zero conversion (ex.rs:603, 629, 656, 683)
+    for (int j = 0; j < a.k_user; ++j) {
+        T v = static_cast<const T *>(a.xtab[j])[r];
+        static_cast<T *>(a.xout[j])[r] = (v != v) ? T(0) : v * sw;
+    }
+    if (a.add_intercept) static_cast<T *>(a.xout[a.k_user])[r] = sw;            // the "const" column, scaled like every feature (ls.py:188-196)
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) dyn_post_kernel(const DynPrepArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_rows) return;
+    T p = static_cast<T *>(a.pred)[r];
+    if (a.sw_out) p *= T(1) / static_cast<const T *>(a.sw_out)[r];              // predictions *= 1 / sqrt_w  (ls.py:234-235)
+    p = nan_if<T>((a.valid_post && !a.valid_post[r]) ? 1u : 0u, p);             // make_predictions(.., is_valid)  (ex.rs:640-645)
+    static_cast<T *>(a.pred)[r] = p;
+}
+
+#define DYN_LAUNCH(kernel)                                                                                              \
+    if (a.n_rows == 0) return POLS_OK;                                                                                  \
+    const unsigned blocks = (unsigned)((a.n_rows + 255) / 256);                                                         \
+    if (dtype == POLS_F32) hipLaunchKernelGGL(kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, a);               \
+    else hipLaunchKernelGGL(kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, a);                                \
+    POLS_HIP(hipGetLastError());                                                                                        \
+    return POLS_OK;
+
+int dyn_scan_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a) { DYN_LAUNCH(dyn_scan_kernel) }
+int dyn_rewrite_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a) { DYN_LAUNCH(dyn_rewrite_kernel) }
+int dyn_post_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a) { DYN_LAUNCH(dyn_post_kernel) }
+
+}  // namespace pols

@@ -90,7 +90,7 @@ class Engine:
         return self._lib.pols_last_kernel_name(self._h).decode()
 
     # ------------------------------------------------------------------ marshalling
-    def _batch(self, y, x_cols: Sequence, offsets, weights, valid, add_intercept: bool):
+    def _batch(self, y, x_cols: Sequence, offsets, weights, valid, add_intercept: bool, null_free: bool = False):
         dev = _is_torch(y)
         cols = list(x_cols)
         if len(cols) == 0:
@@ -126,7 +126,7 @@ class Engine:
         b = L.Batch(dtype=dtype, mem=L.POLS_MEM_DEVICE if dev else L.POLS_MEM_HOST, n_rows=n,
                     n_groups=len(offs) - 1, group_offsets=offs.ctypes.data_as(C.POINTER(C.c_int64)),
                     n_features=len(cols), y=ptr(keep[0]), x_cols=colp, weights=ptr(w), valid=ptr(v),
-                    add_intercept=int(bool(add_intercept)))
+                    add_intercept=int(bool(add_intercept)), null_free=int(bool(null_free)))
         return b, (keep, w, v, offs, colp), dev, dt
 
     def _alloc(self, dev: bool, dt, shape, like=None):
@@ -145,9 +145,9 @@ class Engine:
                            add_intercept: bool = False, want: Sequence[str] = ("pred",), out: Optional[Dict] = None,
                            alpha: float = 0.0, l1_ratio: Optional[float] = None, max_iter: int = 1000,
                            tol: float = 1e-5, positive: bool = False, solve_method: Optional[str] = None,
-                           rcond: Optional[float] = None, null_policy: str = "ignore") -> "Plan":
+                           rcond: Optional[float] = None, null_policy: str = "ignore", null_free: bool = False) -> "Plan":
         """Marshal once, launch many times (``plan.run()``): the buffers are borrowed, nothing is copied."""
-        b, keep, dev, dt = self._batch(y, x_cols, offsets, weights, valid, add_intercept)
+        b, keep, dev, dt = self._batch(y, x_cols, offsets, weights, valid, add_intercept, null_free)
         kt = b.n_features + b.add_intercept
         res: Dict = dict(out or {})
         yy = keep[0][0]
@@ -230,18 +230,22 @@ class Engine:
         res: Dict = dict(out or {})
         yy = keep[0][0]
         if "coef" in want and "coef" not in res:
-            res["coef"] = self._alloc(dev, dt, (b.n_rows, b.n_features), yy)
+            res["coef"] = self._alloc(dev, dt, (b.n_rows, b.n_features + b.add_intercept), yy)
         if "pred" in want and "pred" not in res:
             res["pred"] = self._alloc(dev, dt, (b.n_rows,), yy)
         o = L.Out(coef=self._ptr(res.get("coef")), pred=self._ptr(res.get("pred")), resid=None, status=None)
         return res, o
 
-    def plan_recursive_least_squares(self, y, x_cols: Sequence, offsets, *, valid=None, want: Sequence[str] = ("coef", "pred"),
+    def plan_recursive_least_squares(self, y, x_cols: Sequence, offsets, *, weights=None, valid=None, add_intercept: bool = False,
+                                     null_free: bool = False, want: Sequence[str] = ("coef", "pred"),
                                      out: Optional[Dict] = None, half_life: Optional[float] = None,
                                      initial_state_covariance: Optional[float] = 10.0, initial_state_mean=None,
                                      null_policy: str = "drop") -> "Plan":
-        """solve_recursive_least_squares (src/least_squares.rs:568-598) for every group; ``coef`` is n_rows x k."""
-        b, keep, dev, dt = self._batch(y, x_cols, offsets, None, valid, False)
+        """solve_recursive_least_squares (src/least_squares.rs:568-598) for every group; ``coef`` is n_rows x kt.  Raw columns
+        go in: sqrt(w) scaling, the ones column, the null policy's validity mask (NaN = null unless ``valid`` is given), the
+        zero-filling and the 1/sqrt(w) un-scaling of the predictions all happen on the device behind the C-ABI.
+        ``null_free=True`` promises that no value is null / NaN (a Polars caller knows from null_count): no validity scan."""
+        b, keep, dev, dt = self._batch(y, x_cols, offsets, weights, valid, add_intercept, null_free)
         res, o = self._dynamic_outputs(b, keep, dev, dt, want, out)
         p = L.RlsParams()
         self._lib.pols_rls_params_default(C.byref(p))
@@ -250,7 +254,7 @@ class Engine:
         p.initial_state_covariance = float(10.0 if initial_state_covariance is None else initial_state_covariance)
         mean = None
         if initial_state_mean is not None:
-            mean = np.ascontiguousarray(np.broadcast_to(np.asarray(initial_state_mean, dtype=np.float64), (b.n_features,)))
+            mean = np.ascontiguousarray(np.broadcast_to(np.asarray(initial_state_mean, dtype=np.float64), (b.n_features + b.add_intercept,)))
             p.initial_state_mean = mean.ctypes.data_as(C.POINTER(C.c_double))
         p.null_policy = L.NULL_POLICIES[null_policy]
         return Plan(self, self._lib.pols_recursive_least_squares, b, p, o, res, (keep, mean))
@@ -258,12 +262,14 @@ class Engine:
     def recursive_least_squares(self, y, x_cols: Sequence, offsets, **kwargs) -> Dict:
         return self.plan_recursive_least_squares(y, x_cols, offsets, **kwargs).run()
 
-    def plan_rolling_least_squares(self, y, x_cols: Sequence, offsets, *, window_size: int, valid=None,
-                                   want: Sequence[str] = ("coef", "pred"), out: Optional[Dict] = None,
+    def plan_rolling_least_squares(self, y, x_cols: Sequence, offsets, *, window_size: int, weights=None, valid=None,
+                                   add_intercept: bool = False, null_free: bool = False, want: Sequence[str] = ("coef", "pred"),
+                                   out: Optional[Dict] = None,
                                    min_periods: Optional[int] = None, use_woodbury: Optional[bool] = None,
                                    alpha: Optional[float] = None, null_policy: str = "drop_window") -> "Plan":
-        """solve_rolling_ols (src/least_squares.rs:848-1032) for every group; ``coef`` is n_rows x k, NaN where undefined."""
-        b, keep, dev, dt = self._batch(y, x_cols, offsets, None, valid, False)
+        """solve_rolling_ols (src/least_squares.rs:848-1032) for every group; ``coef`` is n_rows x kt, NaN where undefined.
+        Raw columns in, like plan_recursive_least_squares."""
+        b, keep, dev, dt = self._batch(y, x_cols, offsets, weights, valid, add_intercept, null_free)
         res, o = self._dynamic_outputs(b, keep, dev, dt, want, out)
         p = L.RollingParams()
         self._lib.pols_rolling_params_default(C.byref(p))

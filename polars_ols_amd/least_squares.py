@@ -268,7 +268,8 @@ class _Groups:
         return _to_index(np.repeat(np.arange(len(self.offsets) - 1, dtype=np.int64), np.diff(self.offsets)), like)
 
 
-def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], sample_weights, add_intercept: bool):
+def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], sample_weights, add_intercept: bool,
+                      fill_null_weights: bool = True):
     """least_squares.py:163-196 up to (not including) the sqrt_w multiplications, which the kernels fuse:
     returns (y, x columns, feature names, add_intercept flag for the engine, weights or None)."""
     names = [f.output_name for f in features]
@@ -283,7 +284,8 @@ def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], samp
     if sample_weights is not None:
         w = parse_into_expr(sample_weights)._column(frame)
         # sqrt_w = w.sqrt().fill_null(1e-12)  (:193): a null weight acts as weight 1e-24
-        w = torch.nan_to_num(w, nan=_EPSILON ** 2) if _is_torch(w) else np.where(np.isnan(w), _EPSILON ** 2, w)
+        if fill_null_weights:                                  # (the dynamic entries do this fill on the device: dyn_prep.hip)
+            w = torch.nan_to_num(w, nan=_EPSILON ** 2) if _is_torch(w) else np.where(np.isnan(w), _EPSILON ** 2, w)
     return target._column(frame), [f._column(frame) for f in features], names, icpt, w
 
 
@@ -377,55 +379,29 @@ def _apply_dynamic(frame: Frame, over, eng: Optional[Engine], target: Expr, feat
                    add_intercept: bool, mode: str, kind: str, kw):
     """compute_recursive_least_squares / compute_rolling_least_squares bodies (ls.py:332-409 around
     src/expressions.rs:593-701): the plugin gets sqrt_w-scaled, intercept-extended columns, a validity mask from the
-    null policy, and zero-filled data (NullPolicy::Zero conversion, ex.rs:603,629,656,683)."""
-    y, xs, names, icpt, w = _pre_process_data(frame, target, features, sample_weights, add_intercept)
+    null policy, and zero-filled data (NullPolicy::Zero conversion, ex.rs:603,629,656,683).  All of that is done by the
+    C-ABI entries themselves (csrc/dyn_prep.hip); this function only lays the groups out and hands the raw columns over."""
+    y, xs, names, icpt, w = _pre_process_data(frame, target, features, sample_weights, add_intercept, fill_null_weights=False)
     n = y.shape[0]
     eng = eng or default_engine(y.device.index or 0 if _is_torch(y) else 0)
-    xs = list(xs) + ([_ones_like(y)] if icpt else [])
-    sw = None
-    y_fit = y
-    if w is not None:
-        sw = torch.sqrt(w) if _is_torch(w) else np.sqrt(w)
-        y_fit, xs = y * sw, [c * sw for c in xs]
     policy = kw.null_policy
-    # compute_is_valid_mask (ex.rs:201-228)
-    if policy in ("drop", "drop_zero", "drop_window"):
-        valid = ~_isnan(y_fit)
-        for c in xs:
-            valid = valid & ~_isnan(c)
-    elif policy == "drop_y_zero_x":
-        valid = ~_isnan(y_fit)
-    else:
-        valid = None
-    y0, xs0 = _nan_to_zero(y_fit), [_nan_to_zero(c) for c in xs]
     grp = _Groups(eng, None if over is None else (frame[over] if isinstance(over, str) else over), n)
-    offs = grp.offsets
-    moved = grp.take([y0, valid] + list(xs0))
-    y0, valid_s, xs0 = moved[0], moved[1], moved[2:]
+    moved = grp.take([y, w] + list(xs))                        # raw columns: everything else happens behind the C-ABI
+    ys, ws, xss = moved[0], moved[1], moved[2:]
     want = ("coef",) if mode == "coefficients" else ("pred",)
-    vbytes = None if valid_s is None else (valid_s.to(torch.uint8) if _is_torch(valid_s) else valid_s.astype(np.uint8))
     if kind == "rls":
         mean = kw.initial_state_mean if mode == "coefficients" else None      # quirk: ex.rs:636 passes None for predictions
-        out = eng.recursive_least_squares(y0, xs0, offs, valid=vbytes, want=want, half_life=kw.half_life,
+        out = eng.recursive_least_squares(ys, xss, grp.offsets, weights=ws, add_intercept=icpt, want=want, half_life=kw.half_life,
                                           initial_state_covariance=kw.initial_state_covariance,
                                           initial_state_mean=mean, null_policy=policy)
     else:
-        out = eng.rolling_least_squares(y0, xs0, offs, valid=vbytes, want=want, window_size=kw.window_size,
-                                        min_periods=kw.min_periods, use_woodbury=kw.use_woodbury, alpha=kw.alpha,
-                                        null_policy=policy)
-    res = out["coef"] if mode == "coefficients" else out["pred"]
-    res = grp.untake(res)
+        out = eng.rolling_least_squares(ys, xss, grp.offsets, weights=ws, add_intercept=icpt, want=want,
+                                        window_size=kw.window_size, min_periods=kw.min_periods, use_woodbury=kw.use_woodbury,
+                                        alpha=kw.alpha, null_policy=policy)
+    res = grp.untake(out["coef"] if mode == "coefficients" else out["pred"])
     if mode == "coefficients":
         return "coefficients", Coefficients(names, res)
-    pred = res
-    if valid is not None:                                      # make_predictions masks with is_valid (ex.rs:640-645)
-        nan = float("nan")
-        pred = torch.where(valid, pred, torch.full_like(pred, nan)) if _is_torch(pred) else np.where(valid, pred, nan)
-    if sw is not None:
-        pred = pred * (1.0 / sw)
-    if mode == "residuals":
-        pred = y - pred
-    return target.output_name, pred
+    return target.output_name, (y - res if mode == "residuals" else res)
 
 
 # ---- the reference's module-level functions (least_squares.py:242-491) -------------------------------------------
