@@ -316,6 +316,76 @@ static int check_batch(const pols_batch *b, const pols_out *o, int max_features 
     return POLS_OK;
 }
 
+// handle_nulls (src/expressions.rs:255-296) for the entries that work on FILTERED rows: the batch as the policy leaves it --
+// device columns compacted inside every group (dyn_prep.hip: count pass, host prefix over the per-group counts, scatter pass),
+// new host offsets, nothing null any more (weights included: a null weight is 1e-24, least_squares.py:193).
+struct Compacted {
+    pols_batch bb;
+    std::vector<int64_t> offs;
+    std::vector<const void *> xcols;
+};
+
+static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compacted *c) {
+    int rc;
+    const int64_t *d_offs = nullptr;
+    int64_t max_rows = 0;
+    Staged st;
+    if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows, b->offsets_generation))) return rc;
+    if ((rc = stage_inputs(ctx, b, 0, 0, nullptr, &st))) return rc;
+    const int k = b->n_features, ncols = 1 + k + (st.w ? 1 : 0);
+    const size_t G = (size_t)b->n_groups, N = (size_t)b->n_rows;
+    const size_t sz = dtype_size(b->dtype), colb = round256(sz * std::max<size_t>(N, 1));
+    const size_t cntb = round256(sizeof(unsigned long long) * G), vb = round256(std::max<size_t>(N, 1));
+    const size_t tabb = round256(sizeof(void *) * (size_t)ncols), offb = round256(sizeof(int64_t) * (G + 1));
+    void *d = nullptr;
+    if ((rc = ensure_scratch(ctx, 14, cntb + vb + 2 * tabb + offb + colb * (size_t)ncols, &d))) return rc;
+    char *base = static_cast<char *>(d);
+    char *cols = base + cntb + vb + 2 * tabb + offb;
+    std::vector<const void *> inp((size_t)ncols);
+    std::vector<void *> outp((size_t)ncols);
+    inp[0] = st.y;
+    for (int j = 0; j < k; ++j) inp[(size_t)(1 + j)] = st.x[(size_t)j];
+    if (st.w) inp[(size_t)(1 + k)] = st.w;
+    for (int j = 0; j < ncols; ++j) outp[(size_t)j] = cols + colb * (size_t)j;
+    if ((rc = upload_small(ctx, base + cntb + vb, inp.data(), sizeof(void *) * (size_t)ncols))) return rc;
+    if ((rc = upload_small(ctx, base + cntb + vb + tabb, outp.data(), sizeof(void *) * (size_t)ncols))) return rc;
+    CompactArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.in = reinterpret_cast<const void *const *>(base + cntb + vb);
+    ca.out = reinterpret_cast<void *const *>(base + cntb + vb + tabb);
+    ca.n_cols = ncols;
+    ca.w_col = st.w ? 1 + k : -1;
+    ca.drop = (policy == POLS_NULL_DROP || policy == POLS_NULL_DROP_ZERO || policy == POLS_NULL_DROP_WINDOW || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;
+    ca.n_mask = policy == POLS_NULL_DROP_Y_ZERO_X ? 1 : 1 + k;                                 // ex.rs:209-220
+    ca.zero_fill = (policy == POLS_NULL_ZERO || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;   // ex.rs:264-283
+    ca.valid_in = st.valid;
+    ca.offs = d_offs;
+    ca.offs_out = reinterpret_cast<const int64_t *>(base + cntb + vb + 2 * tabb);
+    ca.counts = reinterpret_cast<unsigned long long *>(base);
+    ca.vbytes = reinterpret_cast<uint8_t *>(base + cntb);
+    ca.n_groups = b->n_groups;
+    if ((rc = compact_count_launch(ctx, b->dtype, ca))) return rc;
+    std::vector<unsigned long long> counts(G);
+    POLS_HIP(hipMemcpyAsync(counts.data(), ca.counts, sizeof(unsigned long long) * G, hipMemcpyDeviceToHost, ctx->stream));
+    POLS_HIP(hipStreamSynchronize(ctx->stream));       // the compacted offsets are a HOST array of the batch: the host needs the counts
+    c->offs.assign(G + 1, 0);
+    for (size_t g = 0; g < G; ++g) c->offs[g + 1] = c->offs[g] + (int64_t)counts[g];
+    if ((rc = upload_small(ctx, base + cntb + vb + 2 * tabb, c->offs.data(), sizeof(int64_t) * (G + 1)))) return rc;
+    if ((rc = compact_scatter_launch(ctx, b->dtype, ca))) return rc;
+    c->xcols.assign(outp.begin() + 1, outp.begin() + 1 + k);
+    c->bb = *b;
+    c->bb.mem = POLS_MEM_DEVICE;
+    c->bb.n_rows = c->offs[G];
+    c->bb.group_offsets = c->offs.data();
+    c->bb.offsets_generation = 0;
+    c->bb.y = outp[0];
+    c->bb.x_cols = c->xcols.data();
+    c->bb.weights = st.w ? outp[(size_t)(1 + k)] : nullptr;
+    c->bb.valid = nullptr;
+    c->bb.null_free = 1;
+    return POLS_OK;
+}
+
 }  // namespace pols
 
 using namespace pols;
@@ -591,9 +661,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
     // Null policies (src/expressions.rs:201-296): a null is a NaN; `valid` (optional) additionally drops rows under the
     // drop family.  They are fused into the streamed path's staging / prediction passes -- no compaction, no copies.
-    const int pol = p->null_policy;
-    if (pol < POLS_NULL_IGNORE || pol > POLS_NULL_DROP_WINDOW) return fail(POLS_ERR_INVALID, "unknown null_policy %d", pol);
-    const bool nulls = pol != POLS_NULL_IGNORE && !(b->null_free && !b->valid);   // nothing null: every policy is the identity
+    if (p->null_policy < POLS_NULL_IGNORE || p->null_policy > POLS_NULL_DROP_WINDOW) return fail(POLS_ERR_INVALID, "unknown null_policy %d", p->null_policy);
+    const int pol = (b->null_free && !b->valid) ? POLS_NULL_IGNORE : p->null_policy;   // nothing null: every policy is the identity
+    const bool nulls = pol != POLS_NULL_IGNORE;
     if (b->valid && (pol == POLS_NULL_IGNORE || pol == POLS_NULL_ZERO))
         return fail(POLS_ERR_INVALID, "a validity mask needs a drop-family null_policy");
 
@@ -883,10 +953,43 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
     if (rc) return rc;
     if ((rc = check_batch(b, o, K8_KMAX))) return rc;
     if (!p || !s) return fail(POLS_ERR_INVALID, "params / stats is NULL");
-    if (p->null_policy != POLS_NULL_IGNORE || b->valid)
-        return fail(POLS_ERR_UNSUPPORTED, "statistics: filter / zero-fill nulls before the call (what handle_nulls does above the "
-                                          "reference's statistics code, src/expressions.rs:469-471)");
+    if (p->null_policy < POLS_NULL_IGNORE || p->null_policy > POLS_NULL_DROP_WINDOW) return fail(POLS_ERR_INVALID, "unknown null_policy %d", p->null_policy);
+    if (b->valid && (p->null_policy == POLS_NULL_IGNORE || p->null_policy == POLS_NULL_ZERO))
+        return fail(POLS_ERR_INVALID, "a validity mask needs a drop-family null_policy");
     if (b->n_groups == 0) return POLS_OK;
+    if ((p->null_policy != POLS_NULL_IGNORE && !b->null_free) || b->valid) {
+        // The statistics are those of the rows handle_nulls leaves (src/expressions.rs:469-471): filter / zero-fill on the device,
+        // then this very entry on the filtered batch.  Outputs are per group, so they land where the caller wants them.
+        Compacted c;
+        if ((rc = compact_nulls(ctx, b, p->null_policy, &c))) return rc;
+        pols_ols_params pp = *p;
+        pp.null_policy = POLS_NULL_IGNORE;
+        if (b->mem == POLS_MEM_DEVICE) return pols_least_squares_statistics(ctx, &c.bb, &pp, o, s);
+        const int kt = b->n_features + (b->add_intercept ? 1 : 0);
+        const size_t G = (size_t)b->n_groups, sz = dtype_size(b->dtype);
+        const size_t coefb = round256(sz * G * kt), statb = round256(sizeof(int32_t) * G), vecb = round256(sizeof(double) * G),
+                     matb = round256(sizeof(double) * G * kt);
+        void *d = nullptr;
+        if ((rc = ensure_scratch(ctx, 15, coefb + statb + 3 * vecb + 3 * matb, &d))) return rc;
+        char *q = static_cast<char *>(d);
+        pols_out od;
+        std::memset(&od, 0, sizeof(od));
+        if (o->coef) od.coef = q;
+        if (o->status) od.status = reinterpret_cast<int32_t *>(q + coefb);
+        q += coefb + statb;
+        double *const user[6] = {s->r2, s->mae, s->mse, s->std_err, s->t_values, s->p_values};
+        double *dev[6];
+        for (int i = 0; i < 6; ++i) { dev[i] = user[i] ? reinterpret_cast<double *>(q) : nullptr; q += i < 3 ? vecb : matb; }
+        pols_stats_out sd;
+        sd.r2 = dev[0]; sd.mae = dev[1]; sd.mse = dev[2]; sd.std_err = dev[3]; sd.t_values = dev[4]; sd.p_values = dev[5];
+        if ((rc = pols_least_squares_statistics(ctx, &c.bb, &pp, &od, &sd))) return rc;
+        if (o->coef) POLS_HIP(hipMemcpyAsync(o->coef, od.coef, sz * G * kt, hipMemcpyDeviceToHost, ctx->stream));
+        if (o->status) POLS_HIP(hipMemcpyAsync(o->status, od.status, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+        for (int i = 0; i < 6; ++i)
+            if (user[i]) POLS_HIP(hipMemcpyAsync(user[i], dev[i], sizeof(double) * G * (i < 3 ? 1 : kt), hipMemcpyDeviceToHost, ctx->stream));
+        POLS_HIP(hipStreamSynchronize(ctx->stream));
+        return POLS_OK;
+    }
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
     const size_t sz = dtype_size(b->dtype);
     const bool host = b->mem == POLS_MEM_HOST;
@@ -1247,7 +1350,6 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     const int64_t w = p->window_size;
     const int64_t mp = p->min_periods >= 0 ? p->min_periods : std::min<int64_t>(k, w);          // ls.rs:860
     if (mp < 1) return fail(POLS_ERR_INVALID, "min_periods must be >= 1 (the reference indexes row min_periods - 1, ls.rs:941-943)");
-    if (mp > w) return fail(POLS_ERR_UNSUPPORTED, "min_periods > window_size: the reference's warm-up then keeps rows the window never drops (ls.rs:869-876 warns); not reproduced");
     const bool drop = p->null_policy == POLS_NULL_DROP || p->null_policy == POLS_NULL_DROP_ZERO ||
                       p->null_policy == POLS_NULL_DROP_Y_ZERO_X;                                // ls.rs:947-950
 

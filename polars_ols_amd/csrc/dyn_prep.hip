@@ -58,6 +58,64 @@ __global__ void __launch_bounds__(256) dyn_post_kernel(const DynPrepArgs a) {
     static_cast<T *>(a.pred)[r] = p;
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) compact_count_kernel(const CompactArgs a) {
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    unsigned cnt = 0;
+    for (int64_t r = s + threadIdx.x; r < e; r += 256) {
+        bool ok = !a.valid_in || a.valid_in[r];
+        if (a.drop)
+            for (int c = 0; c < a.n_mask; ++c) { const T v = static_cast<const T *>(a.in[c])[r]; ok = ok && (v == v); }
+        a.vbytes[r] = ok ? 1 : 0;
+        cnt += ok ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.counts[g], (unsigned long long)cnt);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) compact_scatter_kernel(const CompactArgs a) {
+    __shared__ unsigned wave_cnt[4];
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    int64_t base = a.offs_out[g];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r0 = s; r0 < e; r0 += 256) {                 // (uniform trip count: the barriers below are reached by every lane)
+        const int64_t r = r0 + threadIdx.x;
+        const bool ok = r < e && a.vbytes[r];
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = 0, total = 0;
+        for (int w = 0; w < 4; ++w) { before += w < wave ? wave_cnt[w] : 0u; total += wave_cnt[w]; }
+        if (ok) {
+            const int64_t pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));   // stable: the rows keep their order
+            for (int c = 0; c < a.n_cols; ++c) {
+                T v = static_cast<const T *>(a.in[c])[r];
+                if (v != v) v = (c == a.w_col) ? (T)1e-24 : (a.zero_fill ? T(0) : v);
+                static_cast<T *>(a.out[c])[pos] = v;
+            }
+        }
+        base += total;
+        __syncthreads();
+    }
+}
+
+#define COMPACT_LAUNCH(kernel)                                                                                          \
+    if (a.n_groups == 0) return POLS_OK;                                                                                \
+    if (dtype == POLS_F32) hipLaunchKernelGGL(kernel<float>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a); \
+    else hipLaunchKernelGGL(kernel<double>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);                  \
+    POLS_HIP(hipGetLastError());                                                                                        \
+    return POLS_OK;
+
+int compact_count_launch(pols_ctx *ctx, int dtype, const CompactArgs &a) {
+    if (a.n_groups == 0) return POLS_OK;
+    POLS_HIP(hipMemsetAsync(a.counts, 0, sizeof(unsigned long long) * (size_t)a.n_groups, ctx->stream));
+    COMPACT_LAUNCH(compact_count_kernel)
+}
+int compact_scatter_launch(pols_ctx *ctx, int dtype, const CompactArgs &a) { COMPACT_LAUNCH(compact_scatter_kernel) }
+
 #define DYN_LAUNCH(kernel)                                                                                              \
     if (a.n_rows == 0) return POLS_OK;                                                                                  \
     const unsigned blocks = (unsigned)((a.n_rows + 255) / 256);                                                         \

@@ -25,6 +25,26 @@ struct DynPrepArgs {
     const uint8_t *valid_post;           // post: validity bytes or nullptr (no masking)
 };
 
+// handle_nulls for the entries that work on FILTERED rows (mode="statistics", src/expressions.rs:469-471; the multi-target fit,
+// :539-548): rows the policy drops leave (stable compaction inside every group), surviving nulls become 0 where the policy says
+// so.  Two passes, one workgroup per group: count (validity bytes + rows kept per group), then -- once the host has turned the
+// counts into the compacted offsets it needs anyway -- scatter.
+struct CompactArgs {
+    const void *const *in;       // DEVICE table of n_cols column pointers; the columns that decide validity come first
+    void *const *out;            // DEVICE table of n_cols compacted column pointers
+    int32_t n_cols, n_mask;      // columns [0, n_mask) are checked for nulls (NaN) when `drop`
+    int32_t w_col;               // index of the sample-weights column (null -> 1e-24, least_squares.py:193) or -1
+    int32_t drop, zero_fill;
+    const uint8_t *valid_in;     // caller's validity bytes (ANDed in) or nullptr
+    const int64_t *offs;         // DEVICE group offsets of the input
+    const int64_t *offs_out;     // DEVICE group offsets of the output (scatter pass)
+    unsigned long long *counts;  // rows kept per group (count pass; zeroed by the launcher)
+    uint8_t *vbytes;             // n_rows validity bytes: written by the count pass, read by the scatter pass
+    int64_t n_groups;
+};
+int compact_count_launch(pols_ctx *ctx, int dtype, const CompactArgs &a);
+int compact_scatter_launch(pols_ctx *ctx, int dtype, const CompactArgs &a);
+
 int dyn_scan_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_rewrite_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_post_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);

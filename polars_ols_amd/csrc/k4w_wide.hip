@@ -202,9 +202,15 @@ __global__ void __launch_bounds__(64) kw_rolling_walk_kernel(const K4Args a) {
         return;
     }
     const int64_t j_min = drop ? 0 : max(mpv - w, (int64_t)0);
+    // min_periods > window under the drop family (ls.rs:869-876 only warns): the warm-up sums c0 > w valid rows but its deque
+    // keeps the FIRST w of them (:917-919), so the first w slides pop ranks 0 .. w-1 (rank R - c0 leaves as rank R enters) and
+    // ranks [w, c0) are never subtracted at all; afterwards the deque is an ordinary w-row window again.
+    const int64_t c0 = drop ? cx.cnt(mpv - 1) : 0;
+    const bool longwarm = drop && c0 > w;
     auto old_of = [&](int64_t i) -> int64_t {
         if (!drop) return i - w;
-        const int64_t r = cx.cnt(i) - 1 - w;
+        const int64_t R = cx.cnt(i) - 1;
+        const int64_t r = (longwarm && R - c0 < w) ? R - c0 : R - w;
         return r < 0 ? -1 : cx.vidx(r);
     };
     auto gate = [&](int64_t i) -> bool {                       // n_valid_window >= n_valid (:994-997, 1013, 1022)
@@ -218,6 +224,10 @@ __global__ void __launch_bounds__(64) kw_rolling_walk_kernel(const K4Args a) {
         if (o >= j_min && i >= mpv) {
             cx.prefix(o, S, -1.0, nacc);
             cx.prefix(j_min - 1, S, 1.0, nacc);
+        }
+        if (longwarm && i >= mpv && cx.cnt(i) - 1 - c0 >= w) {  // the warm-up rows the deque never held stay in the sums
+            cx.prefix(cx.vidx(c0 - 1), S, 1.0, nacc);
+            cx.prefix(cx.vidx(w - 1), S, -1.0, nacc);
         }
     };
 

@@ -123,23 +123,30 @@ class Coefficients:
 class Expr:
     """A column reference (optionally scaled) or a deferred least-squares expression."""
 
-    def __init__(self, name: Optional[str] = None, scale: float = 1.0, fn=None, over=None, alias: Optional[str] = None):
+    def __init__(self, name: Optional[str] = None, scale: float = 1.0, fn=None, over=None, alias: Optional[str] = None,
+                 factors: Tuple[str, ...] = ()):
         self._name, self._scale, self._fn, self._over, self._alias = name, scale, fn, over, alias
+        self._factors = tuple(factors)                         # further columns multiplied in (formula interactions ``a:b``)
 
-    # column arithmetic that the reference's own tests use on features (e.g. ``-pl.col("x2")``, test_ols.py:615)
+    # column arithmetic that the reference's own tests use on features (e.g. ``-pl.col("x2")``, test_ols.py:615) and that
+    # its formula front-end builds for interaction terms (utils.py:104-106)
     def __neg__(self):
-        return Expr(self._name, -self._scale)
+        return Expr(self._name, -self._scale, alias=self._alias, factors=self._factors)
 
-    def __mul__(self, c: float):
-        return Expr(self._name, self._scale * float(c))
+    def __mul__(self, c):
+        if isinstance(c, Expr):
+            if c._fn is not None or self._fn is not None:
+                raise TypeError("cannot multiply deferred least-squares expressions")
+            return Expr(self._name, self._scale * c._scale, alias=self._alias, factors=self._factors + (c._name,) + c._factors)
+        return Expr(self._name, self._scale * float(c), alias=self._alias, factors=self._factors)
 
     __rmul__ = __mul__
 
     def alias(self, name: str) -> "Expr":
-        return Expr(self._name, self._scale, self._fn, self._over, name)
+        return Expr(self._name, self._scale, self._fn, self._over, name, self._factors)
 
     def over(self, key) -> "Expr":
-        return Expr(self._name, self._scale, self._fn, key, self._alias)
+        return Expr(self._name, self._scale, self._fn, key, self._alias, self._factors)
 
     @property
     def least_squares(self) -> "LeastSquares":
@@ -151,6 +158,8 @@ class Expr:
 
     def _column(self, frame: "Frame"):
         c = frame[self._name]
+        for f in self._factors:
+            c = c * frame[f]
         return c if self._scale == 1.0 else c * self._scale
 
 
@@ -313,7 +322,6 @@ class Statistics(dict):
 
 def _static_statistics(eng: Engine, y, xs, offs, w, icpt: bool, kw: OLSKwargs, names, keys) -> Statistics:
     d = kw.to_dict()
-    d.pop("null_policy")
     out = eng.least_squares_statistics(y, xs, offs, weights=w, add_intercept=icpt, **d)
     st = out["status"]
     bad = bool((st == 4).any())
@@ -342,33 +350,9 @@ def _apply_static(frame: Frame, over, eng: Optional[Engine], target: Expr, featu
         d = kw.to_dict()
         out = eng.least_squares(y_s, xs_s, offs, weights=w_s, add_intercept=icpt, want=want, **d)
         coef, pred = out.get("coef"), out.get("pred") if mode == "predictions" else out.get("resid")
-    elif policy in ("ignore", "zero"):
-        if policy == "zero":                                   # handle_nulls Zero (ex.rs:264-271)
-            y_s, xs_s = _nan_to_zero(y_s), [_nan_to_zero(c) for c in xs_s]
-        return "statistics", _static_statistics(eng, y_s, xs_s, offs, w_s, icpt, kw, names, keys)
     else:
-        # statistics under the drop family (ex.rs:469-471): the statistics kernel sees the valid rows only.  The reference
-        # hands the plugin sqrt_w-scaled columns (ls.py:190-196), so do the scaling here and fit unweighted.
-        if w_s is not None:
-            sw = torch.sqrt(w_s) if _is_torch(w_s) else np.sqrt(w_s)
-            y_f, xs_f = y_s * sw, [c * sw for c in xs_s] + ([sw] if icpt else [])
-        else:
-            y_f, xs_f = y_s, list(xs_s) + ([_ones_like(y_s)] if icpt else [])
-        valid = ~_isnan(y_f)
-        if policy != "drop_y_zero_x":
-            for c in xs_f:
-                valid = valid & ~_isnan(c)
-        vnp = valid.cpu().numpy() if _is_torch(valid) else valid
-        vidx = np.nonzero(vnp)[0]
-        gid_h = grp.gid_sorted(vnp)
-        full_counts = np.bincount(gid_h[vnp], minlength=len(offs) - 1)        # valid rows per group
-        offs_v = np.concatenate([[0], np.cumsum(full_counts)]).astype(np.int64)
-        vi = _to_index(vidx, y_f)
-        y_v = _take(y_f, vi)
-        xs_v = [_take(c, vi) for c in xs_f]
-        if policy == "drop_y_zero_x":
-            xs_v = [_nan_to_zero(c) for c in xs_v]
-        return "statistics", _static_statistics(eng, y_v, xs_v, offs_v, None, False, kw, names, keys)
+        # handle_nulls ahead of the statistics code (ex.rs:469-471): the entry filters / zero-fills on the device itself
+        return "statistics", _static_statistics(eng, y_s, xs_s, offs, w_s, icpt, kw, names, keys)
     if mode == "coefficients":
         # without .over the single struct broadcasts to every row of the frame, like a Polars scalar (gid is all zeros)
         return "coefficients", Coefficients(names, coef, keys, grp.gid_frame(coef))
@@ -512,27 +496,111 @@ def compute_rolling_least_squares(target, *features, sample_weights=None, add_in
     return Expr(t._name, fn=lambda frame, over, eng: _apply_dynamic(frame, over, eng, t, fs, sample_weights, add_intercept, mode, "rolling", kw))
 
 
+_FORMULA_TOKEN = re.compile(r"\s*(?:(?P<name>[A-Za-z_][A-Za-z_0-9.]*)|(?P<num>\d+)|(?P<op>[+\-:*]))")
+
+
+def _formula_terms(side: str) -> List[Tuple[str, ...]]:
+    """One side of a patsy formula -> its term list in written order, each term a tuple of factor (column) names; the
+    intercept is the empty tuple.  Grammar (patsy's operators on plain columns): ``+`` adds terms, ``-`` removes them,
+    ``a:b`` is the interaction (product column), ``a*b`` = ``a + b + a:b``, ``1`` / ``0`` add / remove the intercept.
+    Anything else patsy understands (function calls like ``log(x)`` / ``C(g)`` / ``I(..)``, parentheses, ``**``, ``/``,
+    ``%in%``) raises NotImplementedError: the reference supports column-only formulas too (utils.py:66-72, 96-100)."""
+    toks: List[Tuple[str, str]] = []
+    pos = 0
+    side = side.rstrip()
+    while pos < len(side):
+        m = _FORMULA_TOKEN.match(side, pos)
+        if not m:
+            raise NotImplementedError(f"formula syntax not supported at {side[pos:].strip()[:12]!r}: only column names joined by + - : * (and 0 / 1)")
+        kind = m.lastgroup
+        toks.append((kind, m.group(kind)))
+        pos = m.end()
+    i = 0
+
+    def atom() -> List[Tuple[str, ...]]:
+        nonlocal i
+        if i >= len(toks) or toks[i][0] == "op":
+            raise ValueError("formula: expected a column name")
+        kind, v = toks[i]
+        i += 1
+        if kind == "num":
+            if v not in ("0", "1"):
+                raise NotImplementedError(f"formula: numeric term {v!r} (only 0 and 1 carry a meaning)")
+            return [("<0>",)] if v == "0" else [()]
+        return [(v,)]
+
+    def interaction() -> List[Tuple[str, ...]]:
+        nonlocal i
+        left = atom()
+        while i < len(toks) and toks[i] == ("op", ":"):
+            i += 1
+            right = atom()
+            if left[0] in ((), ("<0>",)) or right[0] in ((), ("<0>",)):
+                raise ValueError("formula: the intercept cannot take part in an interaction")
+            left = [left[0] + tuple(f for f in right[0] if f not in left[0])]
+        return left
+
+    def product() -> List[Tuple[str, ...]]:
+        nonlocal i
+        left = interaction()
+        while i < len(toks) and toks[i] == ("op", "*"):
+            i += 1
+            right = interaction()
+            if any(t in ((), ("<0>",)) for t in left + right):
+                raise ValueError("formula: the intercept cannot take part in an interaction")
+            left = left + right + [a + tuple(f for f in b if f not in a) for a in left for b in right]
+        return left
+
+    terms: List[Tuple[str, ...]] = [()]                        # patsy starts every RHS with the intercept
+    sign = "+"
+    if toks and toks[0] in (("op", "+"), ("op", "-")):
+        sign = toks[0][1]
+        i = 1
+    while True:
+        for t in product():
+            if t == ("<0>",):                                  # "+ 0" removes the intercept, "- 0" adds it
+                t, add = (), sign == "-"
+            else:
+                add = sign == "+"
+            if add and t not in terms:
+                terms.append(t)
+            elif not add and t in terms:
+                terms.remove(t)
+        if i >= len(toks):
+            break
+        if toks[i] not in (("op", "+"), ("op", "-")):
+            raise ValueError(f"formula: unexpected {toks[i][1]!r}")
+        sign = toks[i][1]
+        i += 1
+    return terms
+
+
+def _term_expr(term: Tuple[str, ...]) -> Expr:
+    """utils.py:101-106: one factor -> the column; several -> their product, named ``a:b``."""
+    return col(term[0]) if len(term) == 1 else Expr(term[0], factors=term[1:], alias=":".join(term))
+
+
 def _parse_formula(formula: str, include_dependent_variable: bool) -> Tuple[List[Expr], bool]:
-    """Additive patsy formulas only ("y ~ x1 + x2 - 1"): what the reference's README / tests use
-    (utils.py:61-108 delegates to patsy, which is absent here)."""
-    lhs, rhs = (formula.split("~", 1) + [None])[:2] if "~" in formula else (None, formula)
-    if rhs is None:
-        lhs, rhs = None, lhs
-    add_intercept = True
-    terms: List[str] = []
-    for sign, term in re.findall(r"([+-]?)\s*([A-Za-z_][A-Za-z_0-9]*|[01])", rhs):
-        if term in ("0", "1"):
-            if term == "0" or sign == "-":
-                add_intercept = False
-            continue
-        if sign == "-":
-            raise ValueError(f"cannot remove term '{term}'")
-        terms.append(term)
-    exprs = [col(t) for t in terms]
+    """build_expressions_from_patsy_formula (utils.py:61-108) without patsy (absent here): same term lists for formulas over
+    plain columns (``y ~ x1 + x2:x3 - 1``), NotImplementedError for the rest.  The intercept flag follows the reference's
+    rule TO THE LETTER: ``add_intercept = "-1" not in formula`` (utils.py:94) -- a literal substring test, so ``"x1 + x2 -1"``
+    drops the intercept while ``"x1 + x2 - 1"`` (with a space) and ``"x1 + x2 + 0"`` keep it, whatever patsy's own reading."""
+    if "(" in formula or ")" in formula:
+        raise NotImplementedError("formula: function calls / categories / parentheses are not supported (utils.py:66-72, 96-100)")
+    if "**" in formula:
+        raise NotImplementedError("formula: '**' is not supported")
+    parts = formula.split("~")
+    if len(parts) > 2:
+        raise ValueError("formula: more than one '~'")
+    lhs, rhs = (parts[0], parts[1]) if len(parts) == 2 else ("", parts[0])
+    lhs_terms = [t for t in _formula_terms(lhs) if t != ()] if lhs.strip() else []
+    rhs_terms = [t for t in _formula_terms(rhs) if t != ()]    # the intercept term has no factors: skipped (utils.py:101-106)
     if include_dependent_variable:
-        assert lhs is not None and lhs.strip(), "formula needs a dependent variable"
-        exprs = [col(lhs.strip())] + exprs
-    return exprs, add_intercept
+        assert len(lhs_terms) == 1, "must provide exactly one LHS variable"
+    else:
+        assert len(lhs_terms) == 0, "can not provide LHS variables in this context"
+    add_intercept = "-1" not in formula
+    return [_term_expr(t) for t in lhs_terms + rhs_terms], add_intercept
 
 
 def compute_least_squares_from_formula(formula: str, sample_weights=None, mode: str = "predictions", **kwargs) -> Expr:

@@ -5,21 +5,33 @@ import numpy as np
 import pytest
 
 
-def test_formula_parser_matches_patsy_for_additive_formulas():            # utils.py:61-108 (patsy is absent: additive subset)
-    from polars_ols_amd.least_squares import _parse_formula
+def test_formula_parser_matches_the_reference_front_end():                  # utils.py:61-108 (patsy is absent here)
+    from polars_ols_amd.least_squares import Frame, _parse_formula
 
     exprs, icpt = _parse_formula("y ~ x1 + x2", include_dependent_variable=True)
     assert [e.output_name for e in exprs] == ["y", "x1", "x2"] and icpt
-    exprs, icpt = _parse_formula("y ~ x1 + x2 - 1", include_dependent_variable=True)
+    # the intercept rule is the reference's literal substring test `"-1" not in formula` (utils.py:94)
+    exprs, icpt = _parse_formula("y ~ x1 + x2 -1", include_dependent_variable=True)
     assert [e.output_name for e in exprs] == ["y", "x1", "x2"] and not icpt
-    exprs, icpt = _parse_formula("x1 + x2 + 0", include_dependent_variable=False)
-    assert [e.output_name for e in exprs] == ["x1", "x2"] and not icpt
+    for f in ("x1 + x2 - 1", "x1 + x2 + 0", "x1 + x2"):                  # "- 1" with a space and "+ 0" KEEP it there too
+        exprs, icpt = _parse_formula(f, include_dependent_variable=False)
+        assert [e.output_name for e in exprs] == ["x1", "x2"] and icpt, f
     exprs, icpt = _parse_formula("x1", include_dependent_variable=False)
     assert [e.output_name for e in exprs] == ["x1"] and icpt
-    with pytest.raises(ValueError):
-        _parse_formula("y ~ x1 - x2", include_dependent_variable=True)
-    with pytest.raises(AssertionError):
+    # interactions (utils.py:104-106: product column named "a:b"), the docstring example of the reference (:73-78)
+    exprs, icpt = _parse_formula("y ~ x1 + x2 + x3:x4", include_dependent_variable=True)
+    assert [e.output_name for e in exprs] == ["y", "x1", "x2", "x3:x4"]
+    fr = Frame(x3=np.array([1.0, 2.0, 3.0]), x4=np.array([2.0, 0.5, -1.0]))
+    assert np.array_equal(exprs[-1]._column(fr), np.array([2.0, 1.0, -3.0]))
+    exprs, _ = _parse_formula("y ~ a*b + c:a:c - b", include_dependent_variable=True)      # a*b = a + b + a:b; "- b" removes a term
+    assert [e.output_name for e in exprs] == ["y", "a", "a:b", "c:a"]
+    for bad in ("y ~ log(x1)", "y ~ C(group)", "y ~ x1 ** 2", "y ~ x1 / x2", "y ~ (x1 + x2):x3", "y ~ x1 + 2"):
+        with pytest.raises(NotImplementedError):
+            _parse_formula(bad, include_dependent_variable=True)
+    with pytest.raises(AssertionError):                                     # "must provide exactly one LHS variable"
         _parse_formula("x1 + x2", include_dependent_variable=True)
+    with pytest.raises(AssertionError):                                     # "can not provide LHS variables in this context"
+        _parse_formula("y ~ x1 + x2", include_dependent_variable=False)
 
 
 def test_kwargs_validation_and_defaults():                                 # least_squares.py:73-77, 101-160

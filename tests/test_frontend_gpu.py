@@ -70,7 +70,7 @@ def test_least_squares_namespace_equivalences():               # :544-558
         col("y").least_squares.ols(col("x1"), col("x2")).alias("ols"),
         col("y").least_squares.ridge(col("x1"), col("x2"), alpha=0.0).alias("ridge"),
         col("y").least_squares.wls(col("x1"), col("x2"), sample_weights=col("sample_weight")).alias("wls"),
-        col("y").least_squares.from_formula("x1 + x2 - 1").alias("formula"),
+        col("y").least_squares.from_formula("x1 + x2 -1").alias("formula"),
     )
     for k in ("ridge", "wls", "formula"):
         assert np.allclose(out[k], out["ols"], rtol=1e-9, atol=1e-9)
@@ -327,3 +327,18 @@ def test_elastic_net_wide(n_features, sparsity, alpha, solve_method):    # tests
     ref = orc.batched_least_squares(d["y"], [d[f"x{i + 1}"] for i in range(n_features)], [0, len(d["y"])], alpha=alpha, l1_ratio=0.5,
                                     max_iter=1_000, tol=0.0001, solve_method=solve_method)
     assert np.allclose(pred, ref["pred"], rtol=1.0e-4, atol=1.0e-4)
+
+
+def test_formula_interaction_terms():                          # utils.py:73-78, 101-106: "x1:x2" is the product column
+    from polars_ols_amd import col
+
+    d = make_data(n_samples=2_000, n_features=2)
+    df = _df(d)
+    c = df.select(col("y").least_squares.from_formula("x1 + x2 + x1:x2", mode="coefficients"))["coefficients"]
+    assert c.names == ["x1", "x2", "x1:x2", "const"]
+    X = np.column_stack([d["x1"], d["x2"], d["x1"] * d["x2"], np.ones(2_000)])
+    exp = np.linalg.lstsq(X, d["y"], rcond=None)[0]
+    assert np.allclose(c.values[0], exp, rtol=1e-6, atol=1e-8)
+    fit = df.with_columns(col("y").least_squares.from_formula("x1 + x1:x2 -1", mode="coefficients").alias("b"))
+    p = fit.select(col("b").least_squares.predict_from_formula("x1 + x1:x2 -1", name="p"))["p"]
+    assert np.allclose(p, X[:, [0, 2]] @ np.linalg.lstsq(X[:, [0, 2]], d["y"], rcond=None)[0], rtol=1e-6, atol=1e-8)

@@ -229,3 +229,28 @@ def test_rolling_cfg4_full_size(eng):
     assert sane.sum() > n - 20
     assert np.allclose(c[sane], ref["coef"][sane], rtol=1e-6, atol=1e-6)
     assert np.allclose(p[sane], ref["pred"][sane], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("policy", ["drop", "drop_window"])
+@pytest.mark.parametrize("k,window,min_periods,null_frac", [(2, 5, 10, 0.0), (2, 5, 10, 0.2), (3, 8, 30, 0.1), (4, 6, 7, 0.3),
+                                                            (40, 50, 90, 0.1), (70, 80, 100, 0.0)])
+def test_rolling_min_periods_beyond_the_window(eng, policy, k, window, min_periods, null_frac):
+    """min_periods > window_size (ls.rs:869-876 only warns): the warm-up sums min_periods valid rows, the deque keeps the first
+    `window` of them (:917-919), so under the drop family rows [window, min_periods) are never subtracted; under drop_window
+    rows older than min_periods_valid - window stay and the n_valid_window gate (:1013) never opens again."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 31 + window)
+    sizes = rng.integers(min_periods // 2, 900, size=9)
+    sizes[3] = 1500
+    y, cols, offs, valid = _frame(rng, sizes, k, null_frac=null_frac)
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid),
+                                    window_size=window, min_periods=min_periods, null_policy=policy)
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, null_policy=policy, is_valid=valid)
+    got_c, got_p = _np(out["coef"]), _np(out["pred"])
+    assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
+    sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+    assert sane.sum() > 0.5 * len(y)
+    tol = 1e-6 if k < 32 else 1e-5
+    assert np.allclose(got_c[sane], ref["coef"][sane], rtol=tol, atol=tol), float(np.abs(got_c[sane] - ref["coef"][sane]).max())
+    assert np.allclose(got_p[sane], ref["pred"][sane], rtol=tol, atol=tol)

@@ -249,3 +249,39 @@ def test_multi_target_rejects_unsupported():                         # least_squ
         compute_multi_target_least_squares(struct("y", "y2"), col("x1"), ols_kwargs=OLSKwargs(solve_method="chol"))
     with pytest.raises(NotImplementedError):
         compute_multi_target_least_squares(struct("y", "y2"), col("x1"), mode="coefficients")
+
+
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("policy", ["drop", "zero", "drop_y_zero_x", "drop_zero"])
+@pytest.mark.parametrize("weights,add_intercept,k", [(False, False, 4), (True, True, 4), (False, True, 36)])
+def test_statistics_null_policies_behind_the_cabi(engine, dtype, rtol, policy, weights, add_intercept, k):
+    """handle_nulls ahead of the statistics code (src/expressions.rs:469-471, 255-296): the entry filters / zero-fills the rows
+    on the device (csrc/dyn_prep.hip: compact_*); expectation = the oracle on the numpy-filtered frame.  Host and device batches."""
+    import torch
+
+    d = _ragged(70 + k, dtype, G=11, k=k, lo=4 * k, hi=9 * k)
+    rng = np.random.default_rng(k)
+    n = len(d["y"])
+    d["y"][rng.random(n) < 0.04] = np.nan
+    for c in d["cols"][:3]:
+        c[rng.random(n) < 0.03] = np.nan
+    w = d["w"] if weights else None
+    # the reference's filter, in numpy
+    null_y = np.isnan(d["y"])
+    null_x = np.zeros(n, dtype=bool)
+    for c in d["cols"]:
+        null_x |= np.isnan(c)
+    keep = ~null_y & ~null_x if policy in ("drop", "drop_zero") else (~null_y if policy == "drop_y_zero_x" else np.ones(n, dtype=bool))
+    gid = np.repeat(np.arange(len(d["offsets"]) - 1), np.diff(d["offsets"]))
+    f = {"y": d["y"][keep], "cols": [c[keep] for c in d["cols"]],
+         "offsets": np.concatenate([[0], np.cumsum(np.bincount(gid[keep], minlength=len(d["offsets"]) - 1))]).astype(np.int64)}
+    if policy in ("zero", "drop_y_zero_x"):
+        f["y"], f["cols"] = np.nan_to_num(f["y"]), [np.nan_to_num(c) for c in f["cols"]]
+    exp = _oracle_stats(f, weights=None if w is None else w[keep], add_intercept=add_intercept)
+    res = engine.least_squares_statistics(d["y"], d["cols"], d["offsets"], weights=w, add_intercept=add_intercept, null_policy=policy)
+    _check(res, exp, rtol, rtol)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    dev = engine.least_squares_statistics(t(d["y"]), [t(c) for c in d["cols"]], d["offsets"], weights=None if w is None else t(w),
+                                          add_intercept=add_intercept, null_policy=policy)
+    torch.cuda.synchronize()
+    _check({k_: v.cpu().numpy() for k_, v in dev.items()}, exp, rtol, rtol)
