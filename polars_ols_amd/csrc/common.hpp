@@ -58,6 +58,8 @@ struct Options {
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
     int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1
     bool k2_noprefetch = false;   // POLS_K2_NOPREFETCH  eight-wave K2: one workgroup per group, no next-group prefetch into LDS
+    int k1_persist_sub = 0;       // POLS_K1_PERSIST_SUB 0: default rule, 64 / 32 / 16 lanes per group
+    int k1_persist = -1;          // POLS_K1_PERSIST     -1: default rule (enough groups), 0 never, 1 whenever the groups fit K1p
 };
 void options_from_env(Options &o);
 // key: the variable's name with or without the POLS_ prefix (case-insensitive); value NULL = back to the default.  False = unknown key.
@@ -99,6 +101,7 @@ struct pols_ctx {
     PinnedSlot pinned[4];
     int pinned_next = 0;
     int64_t offs_max_rows = 0;
+    int64_t offs_tail_group = -1;            // last group with rows (K1p hands it to one wave when n_rows is not a multiple of the vector width)
     int64_t offs_wave_overflow = 0;          // sum over groups of the rows beyond 1 021 (see k1_launch_kw)
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag
     int32_t epoch = 0;

@@ -44,6 +44,7 @@ struct K1Args {
     int32_t epoch;
     double pivot_tol;                    // flag the group for the SVD fallback when a Cholesky pivot d_j <= pivot_tol * G_jj
     int32_t k_user;                      // KT - add_intercept
+    int64_t skip_group;                  // K1p: the group a single wave handles after the persistent loop (or -1)
     unsigned long long *dbg;             // POLS_TIMELINE=1: 8 s_memtime stamps per group (debug only)
     // Fused fix-up (wave-per-group FAST kernels): the grid carries `gridDim.x - n_k1_blocks` trailing fix-up workgroups.  They
     // are dispatched last; each polls the TAGS of its own groups -- one word per group, (epoch << 3 | status), stored

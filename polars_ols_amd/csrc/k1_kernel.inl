@@ -705,6 +705,334 @@ static int k1t_launch(pols_ctx *ctx, const K1Args &a) {
 }
 #endif
 
+#ifndef K1_NULLS_TU
+// K1p: groups of up to a few hundred rows, PERSISTENT waves, 64 / SUB groups per wave, the next groups' rows in flight while these
+// are reduced and solved.
+//  * Timeline of the one-shot wave-per-group kernel on 500 000 groups of 130..252 rows: 14k cycles per group, ~1 000 VALU
+//    instructions of 4 issue cycles each, four waves per SIMD -- the SIMD's issue slots are what is full, not the memory pipe
+//    (4.45 TB/s).  A quarter of those instructions are the K x K Cholesky every lane repeats on wave-uniform values, another
+//    fifth the wave reduction.  With SUB = 32 (16) lanes per group the same instruction stream reduces and solves 2 (4) groups.
+//  * Fewer, fatter waves cannot hide their own load latency, so each wave walks the groups w, w + n_waves, ... and, as soon as it
+//    has moved its rows from the LDS staging area into registers, issues the `global_load_lds` DMA of its NEXT rows (and of the
+//    offsets after those) into the same area -- no VGPRs held by data in flight, nothing for the compiler's s_waitcnt
+//    bookkeeping to trip over: no loads inside the loop's control flow (they would force vmcnt(0) at every join), no LDS reads
+//    between the DMA issue and the loop top (the compiler waits for outstanding LDS DMA before any LDS read), outputs stored
+//    one iteration late (right behind the DMA in the queue, so that the loop-top wait never sees a young store).
+//  * Loads are unconditional and branch-free: lanes without a chunk re-read chunk 0, rows outside [s, e) -- ragged heads / tails,
+//    a neighbour's rows -- are zeroed in registers, so ragged frames take the same code.  No barriers: waves never meet.
+template <typename T, int KT, bool HAS_W, int SUB, int RC>
+__device__ __forceinline__ void k1p_issue(const K1Args &a, int64_t s, int64_t e, typename Vec16<T>::type *stage, int sub) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NCOL = KT + 1 + (HAS_W ? 1 : 0);
+    const int ku = a.k_user;
+    const int64_t base = s - (s % VEC);
+    const int64_t nch = (e - base + VEC - 1) / VEC;
+#pragma unroll
+    for (int rc = 0; rc < RC; ++rc) {
+        const int64_t c = (int64_t)rc * SUB + sub;
+        int64_t rl = base + (c < nch ? c : 0) * VEC;         // lanes without a chunk re-read chunk 0 (masking them off with EXEC measured
+                                                             // no faster at 32 lanes per group, 10 % slower at 64)
+        if (rl > a.n_rows - VEC) rl = a.n_rows - VEC;        // (the one chunk that crosses the end of the columns: see skip_group)
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            if (j < ku || j >= KT) {                         // slots [ku, KT) are the ones column: nothing to load
+                const T *src = static_cast<const T *>(j < ku ? a.x[j] : (j == KT ? a.y : a.w));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + rl),
+                                                 (__attribute__((address_space(3))) void *)(stage + (rc * NCOL + j) * 64), 16, 0, 0);
+            }
+        }
+    }
+}
+
+// offs[g], offs[g + 1] of every lane's group, DMA'd like the rows (16 bytes per lane into the wave's offsets slot)
+__device__ __forceinline__ void k1p_issue_offsets(const K1Args &a, int64_t g, longlong2 *slot) {
+    const int64_t gi = g < a.n_groups ? g : a.n_groups - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.offs + gi),
+                                     (__attribute__((address_space(3))) void *)slot, 16, 0, 0);
+}
+
+__device__ __forceinline__ float k1p_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double k1p_readlane(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void k1p_swap_rows(float &a, float &b) {      // a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void k1p_swap_rows(double &a, double &b) {
+    const unsigned long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
+    b = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+
+// Every lane ends up with the totals of its own team (SUB lanes) in acc[].
+template <typename T, int NACC, int SUB>
+__device__ __forceinline__ void k1p_team_allreduce(T (&acc)[NACC]) {
+    if constexpr (SUB == 64) {
+        // reduce-scatter over the wave, then v_readlane: row r holds the totals of the entries 4i + rs_perm(r)
+        constexpr int NACC4 = (NACC + 3) / 4;
+        T u[NACC4];
+        wave_reduce_scatter<T, NACC>(acc, u);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+            const int pq = q & 3;
+            acc[q] = k1p_readlane(u[q >> 2], 16 * (pq == 1 ? 2 : (pq == 2 ? 1 : pq)));
+        }
+    } else if constexpr (SUB == 32) {
+        // a team is two 16-lane rows: pair_rows leaves entry 2i in the team's even row and 2i + 1 in its odd row (half the values to
+        // all-reduce inside the rows), one row swap of the result with itself hands both back to both rows
+#pragma unroll
+        for (int i = 0; i < (NACC + 1) / 2; ++i) {
+            T w = acc[2 * i];
+            pair_rows(w, 2 * i + 1 < NACC ? acc[2 * i + 1] : T(0));
+            w = row_allreduce(w);
+            T w2 = w;
+            k1p_swap_rows(w, w2);
+            acc[2 * i] = w;
+            if (2 * i + 1 < NACC) acc[2 * i + 1] = w2;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc[q] = row_allreduce(acc[q]);
+    }
+}
+
+// what a group leaves behind for the NEXT iteration to store
+template <typename T, int RC>
+struct K1pPending {
+    using V = typename Vec16<T>::type;
+    V p[RC], r[RC];
+    T bv;
+    int st;
+    int64_t g, s, e;
+    bool have;
+};
+
+template <typename T, int KT, int SUB, int RC>
+__device__ __forceinline__ void k1p_flush(const K1Args &a, const K1pPending<T, RC> &pd, int sub) {
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N;
+    if (!pd.have) return;
+    if (sub == 0) {
+        if (a.status) a.status[pd.g] = pd.st;
+        if (pd.st == POLS_GROUP_FALLBACK && a.fb_flag) *a.fb_flag = a.epoch;
+    }
+    if (a.coef && sub < KT) static_cast<T *>(a.coef)[pd.g * KT + sub] = pd.bv;
+    T *pred = static_cast<T *>(a.pred);
+    T *resid = static_cast<T *>(a.resid);
+    if (!pred && !resid) return;
+    const int64_t base = pd.s - (pd.s % VEC);
+#pragma unroll
+    for (int rc = 0; rc < RC; ++rc) {
+        const int64_t row0 = base + ((int64_t)rc * SUB + sub) * VEC;
+        if (row0 >= pd.s && row0 + VEC <= pd.e) {
+            if (pred) store_stream(reinterpret_cast<V *>(pred + row0), pd.p[rc]);
+            if (resid) store_stream(reinterpret_cast<V *>(resid + row0), pd.r[rc]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int64_t rr = row0 + v;
+                if (rr >= pd.s && rr < pd.e) {
+                    if (pred) pred[rr] = vget<T>(pd.p[rc], v);
+                    if (resid) resid[rr] = vget<T>(pd.r[rc], v);
+                }
+            }
+        }
+    }
+}
+
+// rows in registers (rows outside [s, e) zeroed) -> Gram, team reduction, Cholesky, predictions; everything is left in `pd`
+template <typename T, int KT, bool HAS_W, int SUB, int RC>
+__device__ __forceinline__ void k1p_solve(const K1Args &a, int64_t g, int64_t s, int64_t e, bool live, Chunk<T, KT, HAS_W> (&res)[RC],
+                                          K1pPending<T, RC> &pd, int sub, unsigned long long *tl = nullptr) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NZ = KT + 1;
+    constexpr int NACC = NZ * (NZ + 1) / 2;
+    T acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = T(0);
+#pragma unroll
+    for (int rc = 0; rc < RC; ++rc) gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
+    if (tl) tl[0] = __builtin_amdgcn_s_memtime();
+    k1p_team_allreduce<T, NACC, SUB>(acc);
+    if (tl) tl[1] = __builtin_amdgcn_s_memtime();
+    T beta[KT];
+    int st = POLS_GROUP_OK;
+    if (e == s) {                                            // features.is_empty() -> zeros (ex.rs:357-359)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) beta[j] = T(0);
+        st = POLS_GROUP_EMPTY;
+    } else if (!chol_solve<T, KT>(acc, (T)a.alpha, beta, (T)a.pivot_tol)) {
+        st = POLS_GROUP_FALLBACK;                            // K6 re-solves this group
+    }
+    T bv = T(0);
+#pragma unroll
+    for (int j = 0; j < KT; ++j) bv = (sub == j) ? beta[j] : bv;
+    pd.bv = bv; pd.st = st; pd.g = g; pd.s = s; pd.e = e; pd.have = live;
+#pragma unroll
+    for (int rc = 0; rc < RC; ++rc) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            T pr = T(0);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) pr = fma(vget<T>(res[rc].x[j], v), beta[j], pr);   // make_predictions on the FIT features (ex.rs:398-405)
+            if constexpr (HAS_W) pr *= T(1) / vget<T>(res[rc].sw, v);                         // predictions *= 1/sqrt_w (ls.py:234-235)
+            vset<T>(pd.p[rc], v, pr);
+            vset<T>(pd.r[rc], v, vget<T>(res[rc].y, v) - pr);                                 // ORIGINAL target - predictions (ls.py:239)
+        }
+    }
+}
+
+template <typename T, int KT, bool HAS_W, int SUB, int RC, bool TL = false>
+__global__ void __launch_bounds__(256) k1p_kernel(const K1Args a) {
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NCOL = KT + 1 + (HAS_W ? 1 : 0);
+    constexpr int GPW = 64 / SUB;                            // groups per wave
+    __shared__ __attribute__((aligned(16))) V stage_s[4][RC * NCOL * 64];
+    __shared__ __attribute__((aligned(16))) longlong2 offs_s[4][64];
+    const int lane = threadIdx.x & 63, sub = lane & (SUB - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    V *stage = stage_s[wave];
+    longlong2 *oslot = offs_s[wave];
+    const int64_t step = (int64_t)gridDim.x * 4 * GPW;       // groups all waves take per round
+    const int64_t G = a.n_groups;
+    const int ku = a.k_user;
+    int64_t g = ((int64_t)blockIdx.x * 4 + wave) * GPW + lane / SUB;   // this lane's group
+    K1pPending<T, RC> pd;
+    pd.have = false;
+    int64_t s = 0, e = 0;
+    if (g < G) { s = a.offs[g]; e = a.offs[g + 1]; }
+    unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0}, tl[2] = {0, 0};   // TL: cycles per phase, summed over this wave's iterations
+    k1p_issue<T, KT, HAS_W, SUB, RC>(a, s, e, stage, sub);
+    k1p_issue_offsets(a, g + step, oslot);
+    const int64_t g_wave0 = ((int64_t)blockIdx.x * 4 + wave) * GPW;   // wave-uniform loop control
+#pragma unroll 1
+    for (int64_t gw = g_wave0; gw < G; gw += step, g += step) {
+        const int64_t base = s - (s % VEC);
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if constexpr (TL) t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // these groups' rows have landed; nothing younger than a whole iteration is
+                                                             // outstanding (the previous outputs were stored right behind the DMA)
+        if constexpr (TL) t1 = __builtin_amdgcn_s_memtime();
+        Chunk<T, KT, HAS_W> res[RC];
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+#pragma unroll
+            for (int j = 0; j < KT; ++j) res[rc].x[j] = j < ku ? stage[(rc * NCOL + j) * 64 + lane] : vsplat<T>(T(1));
+            res[rc].y = stage[(rc * NCOL + KT) * 64 + lane];
+            if constexpr (HAS_W) res[rc].sw = stage[(rc * NCOL + KT + 1) * 64 + lane];
+        }
+        const longlong2 on = oslot[lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and are in registers: the staging area is free again
+        if constexpr (TL) t2 = __builtin_amdgcn_s_memtime();
+        const bool live_n = g + step < G;
+        const int64_t sn = live_n ? on.x : 0, en = live_n ? on.y : 0;
+        if (gw + step < G) {
+            k1p_issue<T, KT, HAS_W, SUB, RC>(a, sn, en, stage, sub);
+            k1p_issue_offsets(a, g + 2 * step, oslot);
+        }
+        unsigned long long t2b = 0;
+        if constexpr (TL) t2b = __builtin_amdgcn_s_memtime();
+        k1p_flush<T, KT, SUB, RC>(a, pd, sub);               // the previous groups' outputs, behind the DMA in the queue
+        if constexpr (TL) t3 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+            const int64_t row0 = base + ((int64_t)rc * SUB + sub) * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {                  // ragged heads / tails, lanes without a chunk: zero rows
+                const bool in = (row0 + v >= s) && (row0 + v < e);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) vset<T>(res[rc].x[j], v, in ? vget<T>(res[rc].x[j], v) : T(0));
+                vset<T>(res[rc].y, v, in ? vget<T>(res[rc].y, v) : T(0));
+                if constexpr (HAS_W) vset<T>(res[rc].sw, v, in ? vget<T>(res[rc].sw, v) : T(1));
+            }
+            if constexpr (HAS_W) load_chunk<T, KT, HAS_W, true, false, true>(a, row0, s, e, res[rc]);   // the sqrt(w) scaling only
+        }
+        k1p_solve<T, KT, HAS_W, SUB, RC>(a, g, s, e, g < G && g != a.skip_group, res, pd, sub, TL ? tl : nullptr);
+        if constexpr (TL) {
+            t4 = __builtin_amdgcn_s_memtime();
+            tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t2b - t2; tsum[3] += t3 - t2b; tsum[4] += tl[1] - t3; tsum[5] += t4 - tl[1];
+            tsum[6] += 1;
+        }
+        s = sn; e = en;
+    }
+    k1p_flush<T, KT, SUB, RC>(a, pd, sub);
+    if constexpr (TL) {
+        if (a.dbg && lane == 0) {
+            unsigned long long *d = a.dbg + ((int64_t)blockIdx.x * 4 + wave) * 8;
+            unsigned long long c = 0;
+            d[0] = 0;
+            for (int i = 0; i < 6; ++i) { c += tsum[i]; d[i + 1] = c; }
+            d[7] = tsum[6];
+        }
+    }
+    // The group whose last chunk crosses the end of the columns (n_rows not a multiple of the vector width) cannot be DMA'd in
+    // 16-byte pieces: one wave takes it here, after the loop, with guarded scalar loads (loads inside the loop's control flow
+    // would make every iteration wait for the DMA in flight).
+    if (a.skip_group >= 0 && blockIdx.x == 0 && wave == 0) {
+        const int64_t gs = a.skip_group;
+        const bool mine = lane < SUB;                        // team 0 takes it; the other teams compute on zeros and store nothing
+        const int64_t s1 = a.offs[gs], e1 = mine ? a.offs[gs + 1] : s1;
+        const int64_t base = s1 - (s1 % VEC);
+        Chunk<T, KT, HAS_W> res[RC];
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+            const int64_t row0 = base + ((int64_t)rc * SUB + sub) * VEC;
+            const bool has = row0 < e1;
+            load_chunk<T, KT, HAS_W, false>(a, has ? row0 : base, s1, has ? e1 : s1, res[rc]);   // [s, s): every row outside -> zeros
+        }
+        k1p_solve<T, KT, HAS_W, SUB, RC>(a, gs, s1, e1, mine, res, pd, sub);
+        k1p_flush<T, KT, SUB, RC>(a, pd, sub);
+    }
+}
+
+template <typename T, int KT, bool HAS_W, int SUB, int RC>
+static int k1p_launch(pols_ctx *ctx, const K1Args &a) {
+    char name[96];
+    std::snprintf(name, sizeof(name), "k1p_gram_chol_persistent_%s_k%d%s_sub%d_rc%d", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", SUB, RC);
+    static int occ = 0;                                      // resident blocks per CU of this variant (registers and LDS decide)
+    if (occ == 0) {
+        int o = 0;
+        POLS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k1p_kernel<T, KT, HAS_W, SUB, RC>, 256, 0));
+        occ = o > 0 ? o : 1;
+    }
+    constexpr int GPW = 64 / SUB;
+    const int64_t want = (a.n_groups + 4 * GPW - 1) / (4 * GPW);
+    const int64_t blocks = std::min<int64_t>(want, (int64_t)ctx->num_cus * occ);
+    ctx->last_kernel = name;
+    ctx->last_fused = false;
+    K1Args aa = a;
+    aa.n_k1_blocks = 0;
+    aa.skip_group = (a.n_rows % Vec16<T>::N == 0) ? -1 : ctx->offs_tail_group;   // the chunk grid crosses the end of the columns
+    if constexpr (KT == 8 && !HAS_W) {
+        if (ctx->opt.timeline) {                             // phase cycles summed per persistent wave (debug): 7 "stamps" = 6 phases
+            void *d = nullptr;
+            int rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)blocks * 4, &d);
+            if (rc) return rc;
+            aa.dbg = static_cast<unsigned long long *>(d);
+            hipLaunchKernelGGL((k1p_kernel<T, KT, HAS_W, SUB, RC, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+            POLS_HIP(hipGetLastError());
+            std::fprintf(stderr, "[timeline] per persistent wave (%lld waves, ~%.1f iterations each): wait | lds->regs | issue DMA | flush stores | zero+gram+reduce | solve+predict\n",
+                         (long long)blocks * 4, (double)a.n_groups / ((double)blocks * 4 * GPW));
+            return report_timeline(ctx, aa.dbg, blocks * 4, 7, name);
+        }
+    }
+    hipEvent_t ev0, ev1;
+    if (timing_pair(ctx, &ev0, &ev1))
+        hipExtLaunchKernelGGL((k1p_kernel<T, KT, HAS_W, SUB, RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
+    else
+        hipLaunchKernelGGL((k1p_kernel<T, KT, HAS_W, SUB, RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, aa);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+#endif
+
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
@@ -786,6 +1114,26 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 template <typename T, int KT, bool HAS_W>
 static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
+#ifndef K1_NULLS_TU
+    if constexpr (sizeof(T) == 4) {
+        // a few hundred rows per group and enough groups to keep every persistent wave busy for several rounds: K1p
+        const int64_t need = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1);
+        const bool many = a.n_groups >= (int64_t)ctx->num_cus * 16 * 4;
+        const int ps = ctx->opt.k1_persist_sub;              // POLS_K1_PERSIST_SUB=64|32|16: A/B the team width
+        if (ctx->opt.k1_persist != 0 && a.n_rows >= VEC && a.n_groups > 0 && (many || ctx->opt.k1_persist > 0)) {
+            // 500 000 groups of 40..120 rows: 383 us (16 lanes per group) against 495 us for K1t; 130..252 rows: 815 us (32 lanes)
+            // against 850 us for the one-shot wave.  Up to 64 rows K1t's four groups per wave win (210 vs 320 us on 12..40 rows),
+            // beyond 256 rows the staging area limits a CU to eight waves and the one-shot wave kernel wins (110 vs 125 us).
+            // (two 4-wave blocks per CU need 2 x 4 x (2 * columns + 1) KiB of LDS <= 160 KiB: up to 9 staged columns)
+            const bool forced = ctx->opt.k1_persist > 0;
+            constexpr bool two_blocks = 2 * (KT + 1 + (HAS_W ? 1 : 0)) + 1 <= 20;
+            if (need <= 16 * 2 * VEC && (ps == 16 || (ps == 0 && (forced || (two_blocks && need > 16 * 1 * VEC))))) return k1p_launch<T, KT, HAS_W, 16, 2>(ctx, a);
+            if (need <= 32 * 2 * VEC && (ps == 32 || (ps == 0 && (forced || (two_blocks && need > 16 * 2 * VEC))))) return k1p_launch<T, KT, HAS_W, 32, 2>(ctx, a);
+            if (need <= 64 * 1 * VEC && ps == 64) return k1p_launch<T, KT, HAS_W, 64, 1>(ctx, a);
+            if (need <= 64 * 2 * VEC && (ps == 64 || (ps == 0 && forced))) return k1p_launch<T, KT, HAS_W, 64, 2>(ctx, a);
+        }
+    }
+#endif
 #ifndef K1_NULLS_TU
     if (!ctx->opt.k1_notiny && !ctx->opt.timeline) {
         const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);

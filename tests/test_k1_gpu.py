@@ -340,7 +340,7 @@ def test_contexts_are_independent_across_host_threads():
 @pytest.mark.parametrize("dtype,lo,hi,tag", [(np.float32, 12, 40, "sub16_rc1"), (np.float32, 40, 120, "sub16_rc2"), (np.float64, 12, 30, "sub16_rc1"),
                                              (np.float64, 20, 60, "sub16_rc2")])
 def test_many_tiny_groups_four_per_wave(eng, dtype, lo, hi, tag):
-    """K1t at scale: 300 000 ragged groups, four per wave.  Size-independent checks on every group (X'(y - yhat) = 0 through a
+    """K1t (K1p beyond 64 f32 rows: the same four groups per wave, persistent) at scale: 300 000 ragged groups.  Size-independent checks on every group (X'(y - yhat) = 0 through a
     segmented sum, pred + resid == y, exact scaling in y) and oracle parity on a sample that includes both ends of the frame."""
     import torch
     from oracle import orc
@@ -355,7 +355,8 @@ def test_many_tiny_groups_four_per_wave(eng, dtype, lo, hi, tag):
     cols = [torch.randn(N, generator=g, device="cuda", dtype=tdt) for _ in range(k)]
     y = sum(cols) * 0.5 + 0.1 * torch.randn(N, generator=g, device="cuda", dtype=tdt) + 0.3
     out = eng.least_squares(y, cols, offs, add_intercept=True, want=("coef", "pred", "resid", "status"))
-    assert tag in eng.last_kernel and eng.last_kernel.startswith("k1t_"), eng.last_kernel
+    family = "k1p_" if (dtype == np.float32 and hi > 64) else "k1t_"
+    assert tag in eng.last_kernel and eng.last_kernel.startswith(family), eng.last_kernel
     assert int(out["status"].abs().sum()) == 0
     tol = 1e-4 if dtype == np.float32 else 1e-9
     assert torch.allclose(out["pred"] + out["resid"], y, atol=10 * tol)
@@ -400,3 +401,70 @@ def test_configs0_single_group_coefficients(eng, method, mem):
     assert coef.shape == (1, 4) and int(np.asarray(out["status"].cpu() if hasattr(out["status"], "cpu") else out["status"])[0]) == 0
     assert np.allclose(coef[0], ref, rtol=1e-6, atol=1e-6)
     assert np.allclose(coef[0], np.linalg.lstsq(d["x"], y, rcond=None)[0], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("lo,hi,sub", [(100, 250, 32), (100, 250, 64), (130, 252, 32), (30, 60, 16), (30, 60, 32), (30, 60, 64), (40, 120, 16),
+                                        (200, 500, 64)])
+@pytest.mark.parametrize("k,weights,icpt", [(8, False, False), (5, True, True), (1, False, False), (9, True, True)])
+def test_persistent_wave_kernel_ragged_frames(eng, lo, hi, sub, k, weights, icpt):
+    """K1p (persistent waves, 64 / sub groups per wave, next groups' rows DMA'd into LDS while these are solved): ragged,
+    unaligned groups -- incl. empty ones, a rank-deficient one, and a last chunk that crosses the end of the columns -- against
+    the oracle; more groups than persistent waves so that every wave walks several rounds."""
+    from oracle import orc
+
+    rng = np.random.default_rng(lo * 7 + k)
+    G = 40_000 if hi <= 260 else 12_000
+    sizes = rng.integers(lo, hi + 1, size=G)
+    sizes[[5, 777, G - 2]] = 0
+    if sizes.sum() % 4 == 0:
+        sizes[G - 1] += 1                                            # the last chunk crosses the end of the columns
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, np.float32, weights=weights)
+    if k > 1:
+        s, e = offs[11], offs[12]
+        cols[1][s:e] = cols[0][s:e]                                  # rank-deficient group: flagged, re-solved by the SVD pass
+    eng.set_option("K1_PERSIST", "1")
+    eng.set_option("K1_PERSIST_SUB", str(sub))
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                                want=("coef", "pred", "resid", "status"))
+        name = eng.last_kernel
+    finally:
+        eng.set_option("K1_PERSIST", None)
+        eng.set_option("K1_PERSIST_SUB", None)
+    assert name.startswith(f"k1p_gram_chol_persistent_f32_k{k + int(icpt)}") and f"_sub{sub}_" in name, name
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
+    st = out["status"].cpu().numpy()
+    assert list(st[[5, 777, G - 2]]) == [2, 2, 2]
+    keep = np.ones(len(y), dtype=bool)
+    gk = np.ones(G, dtype=bool)
+    if k > 1:
+        keep[offs[11]:offs[12]] = False                              # minimum-norm solution there: compared through the fit only
+        gk[11] = False
+        assert st[11] == 1 and (np.delete(st, [5, 11, 777, G - 2]) == 0).all()
+    got_c, got_p, got_r = (out[q].double().cpu().numpy() for q in ("coef", "pred", "resid"))
+    assert np.allclose(got_c[gk], ref["coef"][gk], rtol=1e-4, atol=1e-4), float(np.abs(got_c[gk] - ref["coef"][gk]).max())
+    assert np.allclose(got_p[keep], ref["pred"][keep], rtol=1e-4, atol=2e-4), float(np.abs(got_p[keep] - ref["pred"][keep]).max())
+    assert np.allclose(got_r[keep], ref["resid"][keep], rtol=1e-4, atol=2e-4)
+
+
+def test_persistent_wave_kernel_matches_one_shot_kernel_bitwise(eng):
+    """Same arithmetic in the same order as the one-shot wave kernel: identical bits on an aligned frame."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    offs = np.arange(0, 30_001 * 200, 200, dtype=np.int64)
+    y, cols, _ = _frame(rng, offs, 8, np.float32)
+    yy, cc = _cuda(y), [_cuda(c) for c in cols]
+    eng.set_option("K1_PERSIST", "0")
+    a = eng.least_squares(yy, cc, offs, want=("coef", "pred"))
+    ka = eng.last_kernel
+    eng.set_option("K1_PERSIST", "1")
+    eng.set_option("K1_PERSIST_SUB", "64")
+    b = eng.least_squares(yy, cc, offs, want=("coef", "pred"))
+    kb = eng.last_kernel
+    eng.set_option("K1_PERSIST", None)
+    eng.set_option("K1_PERSIST_SUB", None)
+    eng.synchronize()
+    assert ka.startswith("k1_gram_chol_f32_k8_team64_rc1") and kb.startswith("k1p_"), (ka, kb)
+    assert torch.equal(a["coef"], b["coef"]) and torch.equal(a["pred"], b["pred"])
