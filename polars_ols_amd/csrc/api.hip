@@ -324,6 +324,18 @@ static int check_batch(const pols_batch *b, const pols_out *o, int max_features 
     return POLS_OK;
 }
 
+// Shapes the register-resident VALU engine (K1) takes: up to 8 columns whenever the largest group fits its biggest team, and 9-10
+// columns (8 features + intercept, the smoke() shape) while every row stays resident in the wave / two-wave kernels whose Gram
+// is accumulated in passes -- 10 000 x 1 000 x (8 + 1) f32: 77.8 us = 5.1 TB/s against 110 us for the LDS-tile engine (K1m),
+// f64 153.8 against 243.5 us (scripts/bench_k9.py).
+static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_rows) {
+    const int vec = f32 ? 4 : 2;
+    if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
+    const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
+    if (kt <= K1_MAX_KT) return need <= 1024;
+    return kt <= K1W_MAX_KT && need <= (int64_t)256 * 2 * vec;   // 11-12 columns: up to the 256-thread team's resident rows
+}
+
 // handle_nulls (src/expressions.rs:255-296) for the entries that work on FILTERED rows: the batch as the policy leaves it --
 // device columns compacted inside every group (dyn_prep.hip: count pass, host prefix over the per-group counts, scatter pass),
 // new host offsets, nothing null any more (weights included: a null weight is 1e-24, least_squares.py:193).
@@ -791,9 +803,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool aligned = ctx->offs_aligned[f32 ? 1 : 0];
         const bool k2_ok = !nulls && kt <= K2_KMAX && k2_fits(b->dtype, kt, max_rows, aligned) && b->n_rows >= vec && ctx->opt.static_engine != 1 &&
                            ctx->opt.static_engine != 3;
-        const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
+        const bool k1_resident = nulls ? (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) : k1_valu_takes(ctx, f32, kt, max_rows);
         // POLS_K1_ENGINE=valu | mfma keep the K1 / K1m kernels reachable for the shapes they cover (A/B measurements, tests)
         const bool legacy_forced = (ctx->opt.k1_engine == 2 && kt <= K1M_MAX_KT) || (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT);
+        (void)K1W_MAX_KT;
         // OLS / ridge with 9..15 columns whose tile fits LDS stay with K1m: its solve runs unrolled on wave-uniform values in every
         // lane (~1.5k cycles), K2's lane-cooperative register Cholesky pays ~40 cycles per cross-lane broadcast (11k cycles at 16
         // padded columns) -- measured 3.7 against 1.6 TB/s on 10 000 x 1 000 x (8 + intercept) f32.  K2 takes what K1m cannot:
@@ -830,7 +843,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const int vec = f32 ? 4 : 2;
         const bool fits_lds = f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
                                   : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows);
-        const bool k1_resident = kt <= 8 && max_rows <= (int64_t)256 * 2 * vec;
+        const bool k1_resident = nulls ? (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) : k1_valu_takes(ctx, f32, kt, max_rows);
         // null policies: the register-resident K1 has a NULLS family; everything else goes through the streamed kernels
         stream = (nulls && !k1_resident) || kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
         stream = stream || ctx->opt.static_engine == 1;
@@ -1451,15 +1464,14 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
     // kernel with the same access pattern reaches whenever a group's rows stay register-resident (k <= 8:
     // <= 2048 rows f32, <= 1024 rows f64); K1m reads HBM once for any group whose tile fits LDS and carries up
     // to 15 features, at ~65 % of that bandwidth (LDS caps it at 4 groups in flight per CU).
-    const int64_t k1_resident_rows = 256 * 2 * vec;
-    const bool k1_ok = kt <= 8 && max_group_rows <= k1_resident_rows;
+    const bool k1_ok = k1_valu_takes(ctx, f32, kt, max_group_rows);
     bool use_mfma = fits && !k1_ok && (max_group_rows > 64 * 2 * vec || kt > K1_MAX_KT);
     if (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT) use_mfma = false;
     if (ctx->opt.k1_engine == 2 && fits) use_mfma = true;
-    if (use_mfma) return f32 ? k1m_launch_t<float>(ctx, kt, a, max_group_rows) : k1m_launch_t<double>(ctx, kt, a, max_group_rows);
-    if (kt > K1_MAX_KT)
-        return fail(POLS_ERR_UNSUPPORTED, "%d features with %lld-row groups: tile exceeds LDS and the streamed engine stops at %d features",
+    if (kt > K1_MAX_KT && !k1_ok && !use_mfma)
+        return fail(POLS_ERR_UNSUPPORTED, "%d features with %lld-row groups: tile exceeds LDS and the resident engine stops at %d features",
                     kt, (long long)max_group_rows, K1_MAX_KT);
+    if (use_mfma) return f32 ? k1m_launch_t<float>(ctx, kt, a, max_group_rows) : k1m_launch_t<double>(ctx, kt, a, max_group_rows);
     return f32 ? k1_launch_t<float>(ctx, kt, a, max_group_rows) : k1_launch_t<double>(ctx, kt, a, max_group_rows);
 }
 }  // namespace pols

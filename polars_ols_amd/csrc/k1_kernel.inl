@@ -1096,9 +1096,23 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     // 16 resident rows alone are 144 registers -- and dropped.)
     if constexpr (sizeof(T) == 8 && TEAM == 256 && RC == 2 && KT >= 6) {
         // f64, 6+ columns: the full accumulator set costs a workgroup per CU; POLS_K1_PASSES=1|2|3 overrides
-        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : 2;
+        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 10 ? 3 : 2);
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
+        if constexpr (KT >= 9) {                             // ragged frames whose rows all stay resident: the same passes, general loads
+            const bool resident = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC && !fast;
+            if (resident && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
+            if (resident && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
+        }
+    }
+    if constexpr (TEAM == 64 && KT >= 9) {
+        // 9-10 columns (8 features + intercept: the smoke() shape): 55-66 accumulators next to the resident rows do not fit the
+        // register file; the multi-pass Gram (a third of them live at a time, totals in LDS, row-cooperative Cholesky there)
+        // does.  POLS_K1_PASSES=1 goes back to the single pass.
+        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : 3;
+        const bool resident = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        if (npass == 3 && resident) return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
+        if (npass == 2 && resident) return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
     }
     if constexpr (TEAM == 64) {
         // wave-per-group: the launch can carry its own fix-up workers (a.n_k1_blocks = how many the host prepared for)
@@ -1183,8 +1197,11 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if constexpr (KT >= 6) {
             const bool al = ctx->offs_aligned[0] && !ctx->opt.k1_nofast;
             const int64_t need = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1);
-            if (!ctx->opt.k1_f64_team256 && need <= 128 * 4 * VEC && !ctx->opt.timeline) {
-                const int pp = ctx->opt.k1_passes;
+            // (10 columns: the two-wave team's 8 resident rows x 11 columns leave one wave per SIMD -- the 256-thread team with 4 rows
+            // per lane and the three-pass Gram keeps its registers under 168)
+            const bool team128 = KT < 10 || need <= 128 * 2 * VEC;
+            if (!ctx->opt.k1_f64_team256 && team128 && need <= 128 * 4 * VEC && !ctx->opt.timeline) {
+                const int pp = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 10 ? 3 : 0);   // 10 columns: 66 f64 accumulators -> three passes
                 if (pp == 3 && al) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
                 if (pp == 0 || pp == 2) {
                     if (need <= 128 * 2 * VEC)
@@ -1202,6 +1219,28 @@ template <typename T, int KT>
 static int k1_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     return a.w ? k1_launch_kw<T, KT, true>(ctx, a, max_rows) : k1_launch_kw<T, KT, false>(ctx, a, max_rows);
 }
+
+#ifndef K1_NULLS_TU
+// 11-12 columns: only the multi-pass forms exist (91 accumulators at 12 features + target), picked so that the resident rows of a
+// lane stay at 4-8 x 13 values: one wave up to 512 f32 / 256 f64 rows, two waves up to 1 024 / 512, the 256-thread team beyond.
+template <typename T, int KT>
+static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
+    constexpr int VEC = Vec16<T>::N;
+    const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
+    const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
+#define K1W_GO(TEAM, RC)                                                                                                       \
+    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, 3>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, 3>(ctx, a)) \
+               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, 3>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, 3>(ctx, a))
+    if constexpr (sizeof(T) == 4) {
+        if (need <= 64 * 1 * VEC) { K1W_GO(64, 1); }
+    }
+    if (need <= 64 * 2 * VEC) { K1W_GO(64, 2); }
+    if (need <= 128 * 2 * VEC) { K1W_GO(128, 2); }
+    if (need <= 256 * 2 * VEC) { K1W_GO(256, 2); }
+#undef K1W_GO
+    return fail(POLS_ERR_UNSUPPORTED, "k1: %d columns with %lld-row groups do not stay resident", KT, (long long)max_rows);
+}
+#endif
 
 #ifdef K1_NULLS_TU
 #define K1_LAUNCH_NAME k1n_launch_t
@@ -1221,7 +1260,11 @@ int K1_LAUNCH_NAME(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
         case 8: return k1_launch_kt<T, 8>(ctx, a, max_rows);
         case 9: return k1_launch_kt<T, 9>(ctx, a, max_rows);
         case 10: return k1_launch_kt<T, 10>(ctx, a, max_rows);
-        default: return fail(POLS_ERR_UNSUPPORTED, "k1: %d features (incl. intercept) > %d", kt, K1_MAX_KT);
+#ifndef K1_NULLS_TU
+        case 11: return k1_launch_wide_kt<T, 11>(ctx, a, max_rows);
+        case 12: return k1_launch_wide_kt<T, 12>(ctx, a, max_rows);
+#endif
+        default: return fail(POLS_ERR_UNSUPPORTED, "k1: %d features (incl. intercept) > %d", kt, K1W_MAX_KT);
     }
 }
 

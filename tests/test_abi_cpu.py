@@ -133,7 +133,7 @@ def test_hot_kernels_keep_their_arrays_in_registers():
         _lib.build()
     ks = kernel_scratch(_lib.LIB_PATH)
     assert len(ks) > 500, len(ks)
-    hot = ("pols::k1_kernel<", "pols::k1t_kernel<", "pols::k1m_kernel<", "pols::k2_kernel<", "pols::gram_stream_kernel<",
+    hot = ("pols::k1_kernel<", "pols::k1t_kernel<", "pols::k1p_kernel<", "pols::k1m_kernel<", "pols::k2_kernel<", "pols::gram_stream_kernel<",
            "pols::predict_kernel<", "pols::gram_solve_kernel<", "pols::take_kernel<", "pols::arrow_ingest_kernel<")
     bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0
            and not k.rstrip().endswith("true, false>(pols::K1Args)")}          # FUSED = true, NT = false: the fused fix-up builds
