@@ -1129,6 +1129,8 @@ template <typename T, int KT, bool HAS_W>
 static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
 #ifndef K1_NULLS_TU
+    // (f64: measured no better than K1t -- 870 vs 828 us on 500 000 groups of 40..120 rows with 32 lanes per group, 559 vs 450 us on
+    // 12..40 rows with 16: 45 f64 accumulators + 8 resident rows leave one or two waves per SIMD -- so not instantiated)
     if constexpr (sizeof(T) == 4) {
         // a few hundred rows per group and enough groups to keep every persistent wave busy for several rounds: K1p
         const int64_t need = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1);
