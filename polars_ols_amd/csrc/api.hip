@@ -333,7 +333,7 @@ static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_row
     if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
     const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
     if (kt <= K1_MAX_KT) return need <= 1024;
-    return kt <= K1W_MAX_KT && need <= (int64_t)256 * 2 * vec;   // 11-12 columns: up to the 256-thread team's resident rows
+    return kt <= K1W_MAX_KT && need <= (int64_t)256 * 2 * vec;   // 11-15 columns: up to the 256-thread team's resident rows
 }
 
 // handle_nulls (src/expressions.rs:255-296) for the entries that work on FILTERED rows: the batch as the policy leaves it --

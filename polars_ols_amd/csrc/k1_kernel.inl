@@ -461,7 +461,8 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
         gram_pass<T, KT, HAS_W, RC, TEAM, 0, (QS < NACC ? QS : NACC)>(res, nch, tid, lane, wave, mypart);
         if constexpr (QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, QS, (2 * QS < NACC ? 2 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
         if constexpr (2 * QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, 2 * QS, (3 * QS < NACC ? 3 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
-        static_assert(3 * QS >= NACC, "at most three passes");
+        if constexpr (3 * QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, 3 * QS, (4 * QS < NACC ? 4 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
+        static_assert(4 * QS >= NACC, "at most four passes");
     }
     if constexpr (WAVES > 1) __syncthreads();
     K1_STAMP(3);
@@ -1037,7 +1038,7 @@ template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
     std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s%s%s", sizeof(T) == 4 ? "f32" : "f64", KT,
-                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : "_p3"), NULLS ? "_nulls" : "");
+                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : (NPASS == 3 ? "_p3" : "_p4")), NULLS ? "_nulls" : "");
     // (one team per workgroup -- a finished wave's slot refilled at once instead of waiting for its block-mates -- measured no
     // different: 74.4 vs 74.0 us on configs[1])
     const int block_threads = 256;
@@ -1223,21 +1224,32 @@ static int k1_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 }
 
 #ifndef K1_NULLS_TU
-// 11-12 columns: only the multi-pass forms exist (91 accumulators at 12 features + target), picked so that the resident rows of a
-// lane stay at 4-8 x 13 values: one wave up to 512 f32 / 256 f64 rows, two waves up to 1 024 / 512, the 256-thread team beyond.
+// 11-15 columns: only the multi-pass forms exist (91 accumulators at 12 features + target: three passes; 136 at 15: four), picked so
+// that the resident rows of a lane stay at 4-8 x (k + 1) values.  11-12 columns: one wave up to 512 f32 / 256 f64 rows, two waves
+// up to 1 024 / 512, the 256-thread team beyond.  13-15 columns: one chunk per lane (one wave, two waves, four) before two.
 template <typename T, int KT>
 static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
+    constexpr int NP = KT <= 12 ? 3 : 4;
     const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
     const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
 #define K1W_GO(TEAM, RC)                                                                                                       \
-    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, 3>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, 3>(ctx, a)) \
-               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, 3>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, 3>(ctx, a))
-    if constexpr (sizeof(T) == 4) {
+    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NP>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NP>(ctx, a)) \
+               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NP>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NP>(ctx, a))
+    if constexpr (KT <= 12) {
+        if constexpr (sizeof(T) == 4) {
+            if (need <= 64 * 1 * VEC) { K1W_GO(64, 1); }
+        }
+        if (need <= 64 * 2 * VEC) { K1W_GO(64, 2); }
+        if (need <= 128 * 2 * VEC) { K1W_GO(128, 2); }
+    } else {
         if (need <= 64 * 1 * VEC) { K1W_GO(64, 1); }
+        if constexpr (sizeof(T) == 8) {
+            if (need <= 64 * 2 * VEC) { K1W_GO(64, 2); }         // f64, up to 256 rows: one wave with two chunks per lane
+        }
+        if (need <= 128 * 1 * VEC) { K1W_GO(128, 1); }
+        if (need <= 256 * 1 * VEC) { K1W_GO(256, 1); }
     }
-    if (need <= 64 * 2 * VEC) { K1W_GO(64, 2); }
-    if (need <= 128 * 2 * VEC) { K1W_GO(128, 2); }
     if (need <= 256 * 2 * VEC) { K1W_GO(256, 2); }
 #undef K1W_GO
     return fail(POLS_ERR_UNSUPPORTED, "k1: %d columns with %lld-row groups do not stay resident", KT, (long long)max_rows);
@@ -1265,6 +1277,9 @@ int K1_LAUNCH_NAME(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
 #ifndef K1_NULLS_TU
         case 11: return k1_launch_wide_kt<T, 11>(ctx, a, max_rows);
         case 12: return k1_launch_wide_kt<T, 12>(ctx, a, max_rows);
+        case 13: return k1_launch_wide_kt<T, 13>(ctx, a, max_rows);
+        case 14: return k1_launch_wide_kt<T, 14>(ctx, a, max_rows);
+        case 15: return k1_launch_wide_kt<T, 15>(ctx, a, max_rows);
 #endif
         default: return fail(POLS_ERR_UNSUPPORTED, "k1: %d features (incl. intercept) > %d", kt, K1W_MAX_KT);
     }

@@ -116,8 +116,8 @@ def test_ridge_weights_intercept_cfg3_shape(eng, engine_kind, dtype):
 @pytest.mark.parametrize("k", [12, 15])
 @pytest.mark.parametrize("engine", [None, "k2"])
 def test_wide_features_mfma_engines(eng, dtype, k, engine):
-    """11..12 columns while the rows stay resident: K1 with the three-pass Gram; 13..15 columns whose tile fits LDS: K1m (LDS tile,
-    one 16x16 MFMA tile holds [X | y]); K2 (rows resident in registers, MFMA Gram) on request."""
+    """11..15 columns while the rows stay resident: K1 with the three- / four-pass Gram (K1m, the LDS-tile engine, takes them once
+    they no longer do, and under POLS_K1_ENGINE=mfma); K2 (rows resident in registers, MFMA Gram) on request."""
     from oracle import orc
 
     rng = np.random.default_rng(k)
@@ -131,7 +131,7 @@ def test_wide_features_mfma_engines(eng, dtype, k, engine):
         eng.set_option("STATIC_ENGINE", None)
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True, alpha=0.5)
     _check(out, ref, dtype)
-    assert eng.last_kernel.startswith("k2_gram_mfma_resident" if engine else ("k1m_" if k > 12 else f"k1_gram_chol_{'f32' if dtype == np.float32 else 'f64'}_k12_w_team")), eng.last_kernel
+    assert eng.last_kernel.startswith("k2_gram_mfma_resident" if engine else f"k1_gram_chol_{'f32' if dtype == np.float32 else 'f64'}_k{k}_w_team"), eng.last_kernel
 
 
 @pytest.mark.parametrize("method", ["qr", "svd", "chol", "lu", None])
@@ -471,7 +471,7 @@ def test_persistent_wave_kernel_matches_one_shot_kernel_bitwise(eng):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("k,icpt", [(8, True), (9, True), (10, False), (10, True), (12, False)])
+@pytest.mark.parametrize("k,icpt", [(8, True), (9, True), (10, False), (10, True), (12, False), (13, False), (14, True)])
 @pytest.mark.parametrize("lo,hi", [(1000, 1000), (600, 1010), (150, 250), (300, 500)])
 def test_nine_and_ten_columns_take_the_multi_pass_valu_kernels(eng, dtype, k, icpt, lo, hi):
     """8 features + intercept (the smoke() shape) and 10 columns while the rows stay resident: K1 with the Gram accumulated in
@@ -486,7 +486,7 @@ def test_nine_and_ten_columns_take_the_multi_pass_valu_kernels(eng, dtype, k, ic
     name = eng.last_kernel
     assert name.startswith(f"k1_gram_chol_{'f32' if dtype == np.float32 else 'f64'}_k{k + int(icpt)}_w_team"), name
     if hi > 256:
-        assert name.endswith("_p3") or name.endswith("_p2"), name
+        assert name.endswith("_p4") or name.endswith("_p3") or name.endswith("_p2"), name
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
     _check(out, ref, dtype)
     assert int(out["status"].abs().sum()) == 0
