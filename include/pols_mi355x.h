@@ -96,7 +96,9 @@ int pols_create(int device_id, pols_ctx **out);
 void pols_destroy(pols_ctx *ctx);
 /* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream).  The handle is used as
  * given: NULL is HIP's null (legacy default) stream -- which is what torch's default stream is.
- * pols_use_private_stream() goes back to the context's own stream. */
+ * pols_use_private_stream() goes back to the context's own stream.  A context's scratch buffers are shared by all of its
+ * calls: when the stream CHANGES the new stream is made to wait (one event) for what the old one still has in flight, so
+ * calls of one context issued under different streams execute in issue order; use one context per stream for concurrency. */
 int pols_set_stream(pols_ctx *ctx, void *hip_stream);
 int pols_use_private_stream(pols_ctx *ctx);
 int pols_synchronize(pols_ctx *ctx);

@@ -465,20 +465,28 @@ void pols_destroy(pols_ctx *ctx) {
         if (ps.done) hipEventDestroy(ps.done);
         if (ps.ptr) hipHostFree(ps.ptr);
     }
+    if (ctx->switch_event) hipEventDestroy(ctx->switch_event);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
 int pols_set_stream(pols_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
-    ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL == HIP's null stream (torch's default stream)
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);   // NULL == HIP's null stream (torch's default stream)
+    if (next != ctx->stream) {
+        // The context's scratch buffers (offsets, Gram matrices, status, staging) are shared by every call: work launched on the
+        // new stream must not overtake what is still in flight on the old one.  One event per switch, nothing in steady state.
+        if (!ctx->switch_event) POLS_HIP(hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
+        POLS_HIP(hipEventRecord(ctx->switch_event, ctx->stream));
+        POLS_HIP(hipStreamWaitEvent(next, ctx->switch_event, 0));
+    }
+    ctx->stream = next;
     return POLS_OK;
 }
 
 int pols_use_private_stream(pols_ctx *ctx) {
     if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
-    ctx->stream = ctx->own_stream;
-    return POLS_OK;
+    return pols_set_stream(ctx, ctx->own_stream);
 }
 
 int pols_synchronize(pols_ctx *ctx) {

@@ -71,12 +71,13 @@ struct pols_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t switch_event = nullptr;       // pols_set_stream: the new stream waits for what the old one still has in flight
     int num_cus = 0;
     // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] fix-up work area,
     // [4] staged targets / statistics of HOST batches, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean,
     // [7] status words, [8] fused fix-up tags, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
-    // [13] collective staging
+    // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
     pols::Scratch scratch[16];
     pols::Options opt;
     bool timing = false;

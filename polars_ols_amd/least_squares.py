@@ -626,7 +626,7 @@ def predict(coefficients: Coefficients, *features, frame: Frame, null_policy: st
         add_intercept = False
     rows = coefficients.to_rows()
     assert rows.shape[1] == len(xs) + int(add_intercept), "number of coefficients must match number of features!"  # ex.rs:717-721
-    eng = engine or default_engine(0)
+    eng = engine or default_engine((xs[0].device.index or 0) if _is_torch(xs[0]) else 0)   # the engine of the columns' device
     valid = None
     if null_policy == "drop":
         valid = ~_isnan(xs[0])

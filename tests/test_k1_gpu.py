@@ -490,3 +490,28 @@ def test_nine_and_ten_columns_take_the_multi_pass_valu_kernels(eng, dtype, k, ic
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
     _check(out, ref, dtype)
     assert int(out["status"].abs().sum()) == 0
+
+
+def test_calls_under_alternating_torch_streams_stay_ordered(eng):
+    """The context's scratch (offsets, Gram matrices, status words) is shared by its calls: launches issued under different
+    torch streams must not overlap on it -- pols_set_stream makes the new stream wait for the old one."""
+    import torch
+    from oracle import orc
+
+    rng = np.random.default_rng(5)
+    frames = []
+    for i, (G, n, k) in enumerate(((3000, 1000, 8), (40_000, 64, 4), (2000, 1500, 12))):
+        offs = np.arange(0, (G + 1) * n, n, dtype=np.int64)
+        y, cols, _ = _frame(rng, offs, k, np.float32)
+        frames.append((offs, y, cols, _cuda(y), [_cuda(c) for c in cols]))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):
+        for i, (offs, y, cols, yy, cc) in enumerate(frames):
+            with torch.cuda.stream(streams[(i + rep) % 3]):
+                outs.append((i, eng.least_squares(yy, cc, offs, want=("coef",))["coef"]))
+    torch.cuda.synchronize()
+    refs = [orc.batched_least_squares(y, cols, offs)["coef"] for offs, y, cols, _, _ in frames]
+    for i, c in outs:
+        assert np.allclose(c.double().cpu().numpy(), refs[i], rtol=1e-4, atol=1e-4)
