@@ -333,7 +333,12 @@ static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_row
     if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
     const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
     if (kt <= K1_MAX_KT) return need <= 1024;
-    return kt <= K1W_MAX_KT && need <= (int64_t)256 * 2 * vec;   // 11-15 columns: up to the 256-thread team's resident rows
+    if (kt <= K1W_MAX_KT) return need <= (int64_t)256 * 2 * vec;   // 11-15 columns: up to the 256-thread team's resident rows
+    // 16-31 columns: one chunk per lane.  f64 only where it measured faster than the alternatives (scripts/bench_k16.py, 50 000 x 200
+    // rows): 17-24 columns (867 vs 1 189 us at 20, 1 122 vs 1 418 at 24; at 16 K2 wins 433 vs 506, at 31 the 15-pass kernel is down
+    // to one wave per SIMD and loses 2 686 vs 1 923)
+    if (!f32 && (kt < 17 || kt > 24)) return false;
+    return kt <= K1X_MAX_KT && need <= (int64_t)256 * 1 * vec;
 }
 
 // handle_nulls (src/expressions.rs:255-296) for the entries that work on FILTERED rows: the batch as the policy leaves it --
@@ -853,8 +858,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
                                   : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows);
         const bool k1_resident = nulls ? (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) : k1_valu_takes(ctx, f32, kt, max_rows);
         // null policies: the register-resident K1 has a NULLS family; everything else goes through the streamed kernels
-        stream = (nulls && !k1_resident) || kt > K1M_MAX_KT || (!k1_resident && !fits_lds);
+        stream = (nulls && !k1_resident) || (!k1_resident && (kt > K1M_MAX_KT || !fits_lds));
         stream = stream || ctx->opt.static_engine == 1;
+        stream = stream || (m == POLS_SOLVE_LU && kt > K1M_MAX_KT);   // explicit LU beyond K2's 16 columns: the streamed solver has one
     }
     if (stream) {
         // one streaming Gram pass, the small solve (Gram-form CD or Cholesky), then (only if asked for) a prediction pass
@@ -1454,6 +1460,11 @@ namespace pols {
 template <typename T> int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
 template <typename T> int k1n_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);   // null-policy family (k1n_*.hip)
 template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
+// 16..31 columns, resident multi-pass: four column counts per translation unit (k1w_f32_a.hip ... k1w_f64_d.hip)
+#define K1W_DECL(name) int name(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
+K1W_DECL(k1w_launch_f32_a) K1W_DECL(k1w_launch_f32_b) K1W_DECL(k1w_launch_f32_c) K1W_DECL(k1w_launch_f32_d)
+K1W_DECL(k1w_launch_f64_a) K1W_DECL(k1w_launch_f64_b) K1W_DECL(k1w_launch_f64_c) K1W_DECL(k1w_launch_f64_d)
+#undef K1W_DECL
 
 // Engine choice for the static least-squares path:
 //   K1m (LDS tile + MFMA Gram)   groups whose tile fits the 160 KiB LDS and are big enough to fill a workgroup;
@@ -1480,6 +1491,12 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
         return fail(POLS_ERR_UNSUPPORTED, "%d features with %lld-row groups: tile exceeds LDS and the resident engine stops at %d features",
                     kt, (long long)max_group_rows, K1_MAX_KT);
     if (use_mfma) return f32 ? k1m_launch_t<float>(ctx, kt, a, max_group_rows) : k1m_launch_t<double>(ctx, kt, a, max_group_rows);
+    if (kt > K1W_MAX_KT) {
+        using Fn = int (*)(pols_ctx *, int, const K1Args &, int64_t);
+        static const Fn wide[2][4] = {{k1w_launch_f32_a, k1w_launch_f32_b, k1w_launch_f32_c, k1w_launch_f32_d},
+                                      {k1w_launch_f64_a, k1w_launch_f64_b, k1w_launch_f64_c, k1w_launch_f64_d}};
+        return wide[f32 ? 0 : 1][(kt - 16) / 4](ctx, kt, a, max_group_rows);
+    }
     return f32 ? k1_launch_t<float>(ctx, kt, a, max_group_rows) : k1_launch_t<double>(ctx, kt, a, max_group_rows);
 }
 }  // namespace pols

@@ -61,6 +61,7 @@ struct K1Args {
 int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_group_rows, bool aligned16);
 
 constexpr int K1_MAX_KT = 10;    // register-resident VALU engine: every variant (null-policy family, streamed overflow, K1t, K1p)
+constexpr int K1X_MAX_KT = 31;   // ... with the row-resident Cholesky and up to 15 passes, one chunk per lane (k1w_*.hip)
 constexpr int K1W_MAX_KT = 15;   // ... its multi-pass resident forms only (three passes up to 12 columns, four beyond)
 constexpr int K1M_MAX_KT = 15;   // LDS tile + MFMA engine: [X | y] must fit one 16 x 16 tile
 

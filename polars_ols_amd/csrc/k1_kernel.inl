@@ -4,6 +4,15 @@
 
 namespace pols {
 
+// one lane's value to every lane (wave-uniform result)
+__device__ __forceinline__ float k1p_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double k1p_readlane(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <int NZ>
 __host__ __device__ constexpr int tri_index(int i, int j) {  // packed upper triangle, i <= j < NZ
     return i * NZ - (i * (i - 1)) / 2 + (j - i);
@@ -210,6 +219,16 @@ __device__ __forceinline__ void gram_pass(const Chunk<T, KT, HAS_W> (&res)[RC], 
     }
 }
 
+// every pass of QS packed entries, first to last (compile-time recursion: each pass is its own fully unrolled code)
+template <typename T, int KT, bool HAS_W, int RC, int TEAM, int QS, int Q0>
+__device__ __forceinline__ void gram_passes(const Chunk<T, KT, HAS_W> (&res)[RC], int64_t nch, int tid, int lane, int wave, T *mypart) {
+    constexpr int NACC = (KT + 1) * (KT + 2) / 2;
+    if constexpr (Q0 < NACC) {
+        gram_pass<T, KT, HAS_W, RC, TEAM, Q0, (Q0 + QS < NACC ? Q0 + QS : NACC)>(res, nch, tid, lane, wave, mypart);
+        gram_passes<T, KT, HAS_W, RC, TEAM, QS, Q0 + QS>(res, nch, tid, lane, wave, mypart);
+    }
+}
+
 // 1/sqrt(d).  f32: v_rsq_f32 (1 ulp) + one Newton step instead of the ~25-instruction IEEE sqrt + divide
 // chain (the Cholesky is a serial dependency chain, so instruction latency is what it costs); f64: IEEE.
 __device__ __forceinline__ float inv_sqrt(float d) {
@@ -302,6 +321,54 @@ __device__ __forceinline__ T chol_solve_lds(const T *G, T alpha, T pivot_tol, T 
     for (int p = KT - 1; p >= 0; --p) {                 // backward: beta = L^-T t
         if (lane == p) bi *= rinv[p];
         const T bp = __shfl(bi, p, WIDTH);
+        if (lane < p) bi = fma(-L[p * KT + lane], bp, bi);
+    }
+    return bi;
+}
+
+// 16+ columns: the left-looking form above re-reads O(KT^3) factor entries from LDS one dependent FMA at a time (~60 k cycles at 31
+// columns).  Right-looking, lane i keeps ROW i of the factor in registers (statically indexed): step j broadcasts the pivot
+// (v_readlane), scales column j in every lane, broadcasts L[p][j] (lane p's register j) and updates r[p] -= r[j] * L[p][j] --
+// KT - j independent readlane + FMA pairs per step, ~1 000 instructions at 31 columns.  The transposed access of the backward
+// substitution goes through one LDS copy of the factor.  Returns this lane's coefficient (lanes >= KT: 0).
+template <typename T, int KT>
+__device__ __forceinline__ T chol_solve_rows(const T *G, T alpha, T pivot_tol, T *L, int lane, bool &ok) {
+    constexpr int NZ = KT + 1;
+    const int li = lane < KT ? lane : KT - 1;                // lanes beyond the matrix mirror the last row (their results are unused)
+    T r[KT];
+#pragma unroll
+    for (int p = 0; p < KT; ++p) r[p] = G[li <= p ? tri_index<NZ>(li, p) : tri_index<NZ>(p, li)] + (li == p ? alpha : T(0));
+    T bi = (lane < KT) ? G[tri_index<NZ>(li, KT)] : T(0);
+    T g0 = T(0), myrinv = T(1);
+#pragma unroll
+    for (int p = 0; p < KT; ++p) g0 = (li == p) ? r[p] : g0;  // this lane's original diagonal entry
+    ok = true;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const T d = k1p_readlane(r[j], j);
+        const T gjj = k1p_readlane(g0, j);
+        ok = ok && (d > pivot_tol * gjj);
+        const T ri = inv_sqrt(d);
+        myrinv = (lane == j) ? ri : myrinv;
+        r[j] *= ri;                                          // lanes i >= j: L[i][j]  (lane j: sqrt(d))
+#pragma unroll
+        for (int p = j + 1; p < KT; ++p) r[p] = fma(-r[j], k1p_readlane(r[j], p), r[p]);
+    }
+    if (lane < KT) {
+#pragma unroll
+        for (int p = 0; p < KT; ++p) L[lane * KT + p] = r[p];
+    }
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {                           // forward: t = L^-1 b
+        if (lane == p) bi *= myrinv;
+        const T tp = k1p_readlane(bi, p);
+        if (lane > p && lane < KT) bi = fma(-r[p], tp, bi);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int p = KT - 1; p >= 0; --p) {                      // backward: beta = L^-T t
+        if (lane == p) bi *= myrinv;
+        const T bp = k1p_readlane(bi, p);
         if (lane < p) bi = fma(-L[p * KT + lane], bp, bi);
     }
     return bi;
@@ -444,9 +511,9 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
     // ---- team reduction, fixed order (deterministic): reduce-scatter inside each wave, partials through LDS
     constexpr int NACC4 = (NACC + 3) / 4;
     constexpr int SLOTS = NACC4 * 4;                         // accumulator slots, padded to a multiple of 4
-    __shared__ __attribute__((aligned(16))) T part[(256 / TEAM) * (SLOTS * WAVES + 16)];
-    T *mypart = part + (threadIdx.x / TEAM) * (SLOTS * WAVES + 16);   // one region per team
-    T *bcast = mypart + SLOTS * WAVES;                       // beta broadcast, 16 slots
+    __shared__ __attribute__((aligned(16))) T part[(256 / TEAM) * (SLOTS * WAVES + 32)];
+    T *mypart = part + (threadIdx.x / TEAM) * (SLOTS * WAVES + 32);   // one region per team
+    T *bcast = mypart + SLOTS * WAVES;                       // beta broadcast, 32 slots
     if constexpr (NPASS == 1) {
         T u[NACC4];
         wave_reduce_scatter<T, NACC>(acc, u);
@@ -458,11 +525,8 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
         }
     } else {
         constexpr int QS = (((NACC + NPASS - 1) / NPASS) + 3) & ~3;    // entries per pass, a multiple of 4
-        gram_pass<T, KT, HAS_W, RC, TEAM, 0, (QS < NACC ? QS : NACC)>(res, nch, tid, lane, wave, mypart);
-        if constexpr (QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, QS, (2 * QS < NACC ? 2 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
-        if constexpr (2 * QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, 2 * QS, (3 * QS < NACC ? 3 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
-        if constexpr (3 * QS < NACC) gram_pass<T, KT, HAS_W, RC, TEAM, 3 * QS, (4 * QS < NACC ? 4 * QS : NACC)>(res, nch, tid, lane, wave, mypart);
-        static_assert(4 * QS >= NACC, "at most four passes");
+        static_assert(NPASS * QS >= NACC, "the passes cover the packed triangle");
+        gram_passes<T, KT, HAS_W, RC, TEAM, QS, 0>(res, nch, tid, lane, wave, mypart);
     }
     if constexpr (WAVES > 1) __syncthreads();
     K1_STAMP(3);
@@ -488,7 +552,8 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
             if (e == s) st = POLS_GROUP_EMPTY;
             else {
                 bool ok;
-                bv = chol_solve_lds<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lrinv, lane, ok);
+                if constexpr (KT > 15) bv = chol_solve_rows<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lane, ok);
+                else bv = chol_solve_lds<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lrinv, lane, ok);
                 if (!ok) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
             }
             if (tid == 0 && a.status) a.status[g] = st;
@@ -752,13 +817,6 @@ __device__ __forceinline__ void k1p_issue_offsets(const K1Args &a, int64_t g, lo
                                      (__attribute__((address_space(3))) void *)slot, 16, 0, 0);
 }
 
-__device__ __forceinline__ float k1p_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ double k1p_readlane(double v, int l) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 __device__ __forceinline__ void k1p_swap_rows(float &a, float &b) {      // a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
@@ -1037,8 +1095,10 @@ static int k1p_launch(pols_ctx *ctx, const K1Args &a) {
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
+    char passes[8] = "";
+    if (NPASS > 1) std::snprintf(passes, sizeof(passes), "_p%d", NPASS);
     std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d%s%s%s", sizeof(T) == 4 ? "f32" : "f64", KT,
-                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", NPASS == 1 ? "" : (NPASS == 2 ? "_p2" : (NPASS == 3 ? "_p3" : "_p4")), NULLS ? "_nulls" : "");
+                  HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", passes, NULLS ? "_nulls" : "");
     // (one team per workgroup -- a finished wave's slot refilled at once instead of waiting for its block-mates -- measured no
     // different: 74.4 vs 74.0 us on configs[1])
     const int block_threads = 256;
@@ -1230,7 +1290,9 @@ static int k1_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 template <typename T, int KT>
 static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
-    constexpr int NP = KT <= 12 ? 3 : 4;
+    constexpr int NACC = (KT + 1) * (KT + 2) / 2;
+    // passes: three up to 12 columns, four up to 15; beyond, ~60 f32 / ~36 f64 accumulators live at a time (31 columns: 528 entries)
+    constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + 59) / 60 : (NACC + 35) / 36));
     const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
     const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
 #define K1W_GO(TEAM, RC)                                                                                                       \
@@ -1242,20 +1304,27 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         }
         if (need <= 64 * 2 * VEC) { K1W_GO(64, 2); }
         if (need <= 128 * 2 * VEC) { K1W_GO(128, 2); }
-    } else {
+    } else if constexpr (KT <= 15) {
         if (need <= 64 * 1 * VEC) { K1W_GO(64, 1); }
         if constexpr (sizeof(T) == 8) {
             if (need <= 64 * 2 * VEC) { K1W_GO(64, 2); }         // f64, up to 256 rows: one wave with two chunks per lane
         }
         if (need <= 128 * 1 * VEC) { K1W_GO(128, 1); }
         if (need <= 256 * 1 * VEC) { K1W_GO(256, 1); }
+    } else {                                                 // 16-31 columns: one chunk per lane (4 f32 / 2 f64 rows x up to 32 values)
+        if (need <= 64 * 1 * VEC) { K1W_GO(64, 1); }
+        if (need <= 128 * 1 * VEC) { K1W_GO(128, 1); }
+        if (need <= 256 * 1 * VEC) { K1W_GO(256, 1); }
     }
-    if (need <= 256 * 2 * VEC) { K1W_GO(256, 2); }
+    if constexpr (KT <= 15) {
+        if (need <= 256 * 2 * VEC) { K1W_GO(256, 2); }
+    }
 #undef K1W_GO
     return fail(POLS_ERR_UNSUPPORTED, "k1: %d columns with %lld-row groups do not stay resident", KT, (long long)max_rows);
 }
 #endif
 
+#ifndef K1_WIDE_TU
 #ifdef K1_NULLS_TU
 #define K1_LAUNCH_NAME k1n_launch_t
 #else
@@ -1284,5 +1353,6 @@ int K1_LAUNCH_NAME(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
         default: return fail(POLS_ERR_UNSUPPORTED, "k1: %d features (incl. intercept) > %d", kt, K1W_MAX_KT);
     }
 }
+#endif  // K1_WIDE_TU
 
 }  // namespace pols

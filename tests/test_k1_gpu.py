@@ -515,3 +515,44 @@ def test_calls_under_alternating_torch_streams_stay_ordered(eng):
     refs = [orc.batched_least_squares(y, cols, offs)["coef"] for offs, y, cols, _, _ in frames]
     for i, c in outs:
         assert np.allclose(c.double().cpu().numpy(), refs[i], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,icpt", [(16, False), (17, True), (20, True), (24, False), (27, True), (31, False), (30, True)])
+@pytest.mark.parametrize("lo,hi", [(500, 500), (200, 505), (80, 250)])
+def test_sixteen_to_thirtyone_columns_resident_multi_pass(eng, dtype, k, icpt, lo, hi):
+    """16..31 columns while every row stays resident (one chunk per lane: up to 1 024 f32 / 512 f64 rows): K1 with the Gram in up to
+    15 passes and the row-resident right-looking Cholesky -- X is read once, where the streamed path reads it twice.  Aligned and
+    ragged frames, weights, intercept, a rank-deficient group for the SVD fix-up."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 100 + hi)
+    offs = _ragged_offsets(rng, 120, lo, hi)
+    y, cols, w = _frame(rng, offs, k, dtype, weights=True)
+    s, e = offs[7], offs[8]
+    cols[2][s:e] = cols[5][s:e]                                      # rank-deficient group
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=icpt,
+                            want=("coef", "pred", "resid", "status"))
+    name = eng.last_kernel
+    kt = k + int(icpt)
+    if dtype == np.float32 or 17 <= kt <= 24:                        # f64: K2 keeps 16 columns, the streamed path 25+
+        assert name.startswith(f"k1_gram_chol_{'f32' if dtype == np.float32 else 'f64'}_k{kt}_w_team"), name
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
+    st = out["status"].cpu().numpy()
+    assert st[7] == 1 and (np.delete(st, 7) == 0).all(), st[:12]
+    gk = np.ones(len(offs) - 1, dtype=bool)
+    gk[7] = False
+    rows = np.ones(len(y), dtype=bool)
+    rows[s:e] = False
+    tol = TOL[dtype]
+    got_c, got_p, got_r = (out[q].double().cpu().numpy() for q in ("coef", "pred", "resid"))
+    assert np.allclose(got_c[gk], ref["coef"][gk], rtol=tol, atol=tol), float(np.abs(got_c[gk] - ref["coef"][gk]).max())
+    assert np.allclose(got_p[rows], ref["pred"][rows], rtol=tol, atol=3 * tol), float(np.abs(got_p[rows] - ref["pred"][rows]).max())
+    assert np.allclose(got_r[rows], ref["resid"][rows], rtol=tol, atol=3 * tol)
+    # (the rank-deficient group: the reference's pivoted QR does not truncate, so its coefficients -- and through cancellation its
+    # predictions -- are not pinned there, SURVEY 8c; ours come from the SVD fix-up and are the minimum-norm fit)
+    assert np.isfinite(got_p[~rows]).all() and np.isfinite(got_c[7]).all()
+    X7 = np.column_stack([c[s:e] for c in cols] + ([np.ones(e - s)] if icpt else [])).astype(np.float64) * np.sqrt(w[s:e].astype(np.float64))[:, None]
+    fit = np.linalg.lstsq(X7, y[s:e].astype(np.float64) * np.sqrt(w[s:e].astype(np.float64)), rcond=None)[0]
+    exp7 = np.column_stack([c[s:e] for c in cols] + ([np.ones(e - s)] if icpt else [])).astype(np.float64) @ fit
+    assert np.allclose(got_p[~rows], exp7, rtol=10 * tol, atol=(2e-2 if dtype == np.float32 else 1e-6)), float(np.abs(got_p[~rows] - exp7).max())
