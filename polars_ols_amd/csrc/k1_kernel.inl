@@ -1124,7 +1124,9 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     // the f32 wave-per-group FAST kernel (BASELINE configs[1]) reads its columns with `nt` (streaming) loads: every line is used
     // once, so it should not compete for L2 with lines that are -- 73.2-73.3 against 74.3-75.0 us per 400 MB launch
     // (POLS_K1_NT_LOADS=0 selects the plain-load build of the same kernel)
-    constexpr bool HAS_NT = sizeof(T) == 4 && TEAM == 64 && RC == 4 && FAST && NPASS == 1 && !NULLS && !FUSED;
+    // (the f64 two-wave kernel of cfg3 as well: 169-173 against 173-174 us per call)
+    constexpr bool HAS_NT = ((sizeof(T) == 4 && TEAM == 64 && RC == 4 && NPASS == 1) || (sizeof(T) == 8 && TEAM == 128 && RC == 4 && NPASS == 2 && KT <= 8)) &&
+                            FAST && !NULLS && !FUSED;
     if constexpr (HAS_NT) {
         if (ctx->opt.k1_nt_loads != 0) { kern = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, true>; std::strcat(name, "_nt"); }
     }
@@ -1222,6 +1224,9 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             const bool want = ctx->opt.k1t_rc4 >= 0 ? ctx->opt.k1t_rc4 != 0 : (sizeof(T) == 8 && KT >= 6);
             if (want) return k1t_launch<T, KT, HAS_W, 16, 4>(ctx, a);
         }
+        // (SUB = 8, eight groups per wave with two chunks per lane, measured no faster on 500 000 groups of 12..40 rows: 218 vs 214 us --
+        // these frames are bound by lane utilisation in the memory pipe: a 26-row group fills 6.5 of its team's 16 chunk slots, and
+        // the pipe spends its cycles per lane address, used or not)
         // (SUB = 32, two groups per wave up to 256 / 128 rows, measured SLOWER than one wave per group: 1 022 vs 910 us on 500 000
         // f32 groups of 130..252 rows, 1 815 vs 1 217 us on f64 groups of 40..120 -- the kernel template keeps the variant, nothing
         // launches it)
