@@ -639,6 +639,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
 }
 
+// (the null-policy wave kernel with 16 resident rows sits at exactly 256 VGPRs; one more value and the allocator reaches for an AGPR,
+// which halves the occupancy of the unified register file: 80.7 -> 132 us on 10 000 x 1 000 x 8.  Held to two waves per SIMD.)
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k1_kernel_occ2(const K1Args a) {
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
+}
+
 #ifndef K1_NULLS_TU
 // K1t: groups of at most SUB * 2 * VEC rows -- SUB = 16: 128 f32 / 64 f64 rows (per-asset-per-month sized regressions), FOUR groups
 // per wave, one per 16-lane DPP row; SUB = 32: 256 / 128 rows, TWO groups per wave (one more all-reduce step: v_permlane16_swap).  A wave-per-group kernel spends its time in the per-group reduction + Cholesky with most lanes idle (650 M
@@ -1133,6 +1140,8 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     if constexpr (OCC4) {
         if (!ctx->opt.k1_noocc4) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
     }
+    if constexpr (NULLS && sizeof(T) == 4 && TEAM == 64 && RC == 4 && KT <= 8 && !HAS_W && !FUSED)
+        kern = k1_kernel_occ2<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
     ctx->last_kernel = name;
     if (timing_pair(ctx, &ev0, &ev1))
         hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, ev0, ev1, 0, aa);

@@ -14,7 +14,7 @@ LLVM = Path("/opt/rocm/lib/llvm/bin")
 
 
 def kernel_scratch(lib: Path):
-    """{demangled kernel name: (scratch bytes per lane, vgprs)}"""
+    """{demangled kernel name: (scratch bytes per lane, vgprs, agprs)}"""
     out = {}
     with tempfile.TemporaryDirectory() as td:
         tmp = Path(td) / lib.name
@@ -26,8 +26,9 @@ def kernel_scratch(lib: Path):
                 name = re.search(r"\.name:\s+(\S+)", blk)
                 priv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
                 vgpr = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+                agpr = re.match(r"\s*(\d+)", blk)              # the block starts right behind ".agpr_count:"
                 if name and priv:
-                    out[name.group(1)] = (int(priv.group(1)), int(vgpr.group(1)) if vgpr else -1)
+                    out[name.group(1)] = (int(priv.group(1)), int(vgpr.group(1)) if vgpr else -1, int(agpr.group(1)) if agpr else -1)
     if out:
         dem = subprocess.run(["c++filt"], input="\n".join(out), capture_output=True, text=True).stdout.splitlines()
         out = {d: v for d, v in zip(dem, out.values())}
@@ -39,5 +40,5 @@ if __name__ == "__main__":
     ks = kernel_scratch(lib)
     bad = {k: v for k, v in ks.items() if v[0] > 0}
     print(f"{len(ks)} kernels, {len(bad)} with scratch")
-    for k, (p, v) in sorted(bad.items(), key=lambda kv: -kv[1][0]):
+    for k, (p, v, _a) in sorted(bad.items(), key=lambda kv: -kv[1][0]):
         print(f"  {p:6d} B/lane  vgpr={v:3d}  {k[:150]}")

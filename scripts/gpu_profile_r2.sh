@@ -11,7 +11,7 @@ done
 timeout 300 python bench.py --dtype f64 --no-cpu-baseline 2>/dev/null > $O/${TAG}_bench_f64.json; cut -c1-300 $O/${TAG}_bench_f64.json; echo
 timeout 300 python bench.py --mem host --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null > $O/${TAG}_bench_host.json; cut -c1-300 $O/${TAG}_bench_host.json; echo
 cd /tmp && export TMPDIR=/tmp
-for cfg in cfg2 cfg5; do
+for cfg in cfg2 cfg3 cfg5; do
   echo "== rocprofv3 --kernel-trace --stats $cfg"
   rm -rf $O/kt_$cfg; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$cfg -o k -- python $R/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof_$cfg.json 2> $O/kt_$cfg.err
   f=$(find $O/kt_$cfg -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_$cfg.csv && head -5 $O/${TAG}_kernel_stats_$cfg.csv | cut -c1-260
@@ -46,5 +46,11 @@ echo "== side benches"
 timeout 200 python scripts/bench_ragged.py 2>/dev/null | tail -1 > $O/${TAG}_bench_ragged.json; cut -c1-1500 $O/${TAG}_bench_ragged.json; echo
 timeout 120 python scripts/bench_nulls.py 2>/dev/null | tail -1 > $O/${TAG}_bench_nulls.json; cat $O/${TAG}_bench_nulls.json; echo
 timeout 120 python scripts/bench_layout.py 2>/dev/null | tail -1 > $O/${TAG}_bench_layout.json; cut -c1-600 $O/${TAG}_bench_layout.json; echo
+timeout 200 python scripts/bench_k9.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k9.txt; cut -c1-160 $O/${TAG}_bench_k9.txt
+timeout 200 python scripts/bench_k16.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k16.txt; cat $O/${TAG}_bench_k16.txt
+echo "== rocprofv3 --kernel-trace --stats, ragged / small frames (K1p, K1t)"
+cd /tmp; rm -rf $O/kt_ragged; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ragged -o k -- python $R/scripts/bench_ragged.py > /dev/null 2> $O/kt_ragged.err
+f=$(find $O/kt_ragged -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|pols::" "$f" | cut -c1-200 > $O/${TAG}_kernel_stats_ragged.csv && head -14 $O/${TAG}_kernel_stats_ragged.csv
+cd $R
 rm -rf $O/kt_* $O/pmc_FETCH* $O/pmc_WRITE* $O/pmc_mfma
 ls $O

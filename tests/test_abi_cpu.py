@@ -138,3 +138,32 @@ def test_hot_kernels_keep_their_arrays_in_registers():
     bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0
            and not k.rstrip().endswith("true, false>(pols::K1Args)")}          # FUSED = true, NT = false: the fused fix-up builds
     assert not bad, sorted(bad.items())[:5]
+
+
+def test_bench_kernels_keep_two_waves_per_simd():
+    """The kernels BASELINE's configs are measured on sit at the edge of the register file: one value more and the allocator takes
+    an AGPR, which halves the occupancy of gfx950's unified 512-entry file (the null-policy wave kernel went 80.7 -> 132 us that
+    way, unnoticed until a profile run).  Read straight from the built code objects."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "scripts"))
+    from check_scratch import LLVM, kernel_scratch
+
+    if not (LLVM / "llvm-objdump").exists():
+        pytest.skip("ROCm LLVM tools not present")
+    if not _lib.LIB_PATH.exists():
+        _lib.build()
+    ks = kernel_scratch(_lib.LIB_PATH)
+    want = {
+        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, true>(": 256,       # configs[1], nt loads
+        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, false>(": 256,
+        "pols::k1_kernel_occ2<float, 8, false, 64, 4, true, 1, true, false>(": 256,         # configs[1] under a null policy
+        "pols::k1_kernel<double, 8, true, 128, 4, true, 2, false, false, true>(": 256,      # configs[2]
+        "pols::k1_kernel<float, 9, false, 64, 4, true, 3, false, false, false>(": 256,      # smoke(): 8 features + intercept
+        "pols::k2_kernel<double, 16, 8, 2, true, false>(": 256,                             # configs[4]
+    }
+    for key, cap in want.items():
+        hits = [(k, v) for k, v in ks.items() if key in k]
+        assert len(hits) == 1, (key, [k for k, _ in hits][:3])
+        _scratch, vgpr, agpr = hits[0][1]
+        assert agpr == 0 and 0 < vgpr <= cap, (hits[0][0], vgpr, agpr)
