@@ -2,6 +2,10 @@
 #include "k1_gram_chol.hpp"
 #include "k6_body.inl"
 
+#ifndef K1_RAGGED_VECTOR_LOADS
+#define K1_RAGGED_VECTOR_LOADS 1
+#endif
+
 namespace pols {
 
 // one lane's value to every lane (wave-uniform result)
@@ -76,9 +80,22 @@ __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_
     } else if (FAST || (row0 >= s && row0 + VEC <= e)) {
         // whole chunk inside the group: 16-byte loads, all issued before first use
         load_chunk_raw<T, KT, HAS_W>(a, row0, c);
+    } else if (K1_RAGGED_VECTOR_LOADS && sizeof(T) == 4 && e - s <= 512 && row0 + VEC <= a.n_rows) {
+        // ragged head / tail of a SHORT f32 group, the 16 bytes of every column still inside the columns: vector loads, then the rows
+        // outside [s, e) -- a neighbour's -- zeroed in registers.  Measured per shape (scripts/bench_ragged.py): 12..40 rows 218 ->
+        // 203 us, 100..300 rows 111 -> 108 us; but 900..1 020 rows 76 -> 79 us and f64 40..120 rows 828 -> 906 us, hence the limits.
+        load_chunk_raw<T, KT, HAS_W>(a, row0, c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const bool in = (row0 + v >= s) && (row0 + v < e);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) vset<T>(c.x[j], v, in ? vget<T>(c.x[j], v) : T(0));
+            vset<T>(c.y, v, in ? vget<T>(c.y, v) : T(0));
+            if constexpr (HAS_W) vset<T>(c.sw, v, in ? vget<T>(c.sw, v) : T(1));
+        }
     } else {
         // ragged head / tail of a group: guarded scalar loads, rows outside [s, e) contribute zeros
-        // (full 16-byte loads with the neighbouring group's rows zeroed in registers measured 3-4 % SLOWER on ragged frames)
+        // (long groups and f64: full 16-byte loads with the neighbouring group's rows zeroed in registers measured 3-9 % SLOWER)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int64_t r = row0 + v;
