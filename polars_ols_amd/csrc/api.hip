@@ -340,6 +340,13 @@ static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_row
     if (!f32 && (kt < 17 || kt > 24)) return false;
     return kt <= K1X_MAX_KT && need <= (int64_t)256 * 1 * vec;
 }
+// ... and its null-policy family: up to 8 columns like the plain kernels, 9-10 columns (masked three-pass Gram) while resident
+static bool k1_nulls_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_rows) {
+    const int vec = f32 ? 4 : 2;
+    if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
+    const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
+    return kt <= K1_MAX_KT && need <= 1024;
+}
 
 // handle_nulls (src/expressions.rs:255-296) for the entries that work on FILTERED rows: the batch as the policy leaves it --
 // device columns compacted inside every group (dyn_prep.hip: count pass, host prefix over the per-group counts, scatter pass),
@@ -816,7 +823,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool aligned = ctx->offs_aligned[f32 ? 1 : 0];
         const bool k2_ok = !nulls && kt <= K2_KMAX && k2_fits(b->dtype, kt, max_rows, aligned) && b->n_rows >= vec && ctx->opt.static_engine != 1 &&
                            ctx->opt.static_engine != 3;
-        const bool k1_resident = nulls ? (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) : k1_valu_takes(ctx, f32, kt, max_rows);
+        const bool k1_resident = nulls ? k1_nulls_takes(ctx, f32, kt, max_rows) : k1_valu_takes(ctx, f32, kt, max_rows);
         // POLS_K1_ENGINE=valu | mfma keep the K1 / K1m kernels reachable for the shapes they cover (A/B measurements, tests)
         const bool legacy_forced = (ctx->opt.k1_engine == 2 && kt <= K1M_MAX_KT) || (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT);
         (void)K1W_MAX_KT;
@@ -853,10 +860,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     bool stream = enet;
     if (!enet) {
         const bool f32 = b->dtype == POLS_F32;
-        const int vec = f32 ? 4 : 2;
         const bool fits_lds = f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
                                   : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows);
-        const bool k1_resident = nulls ? (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) : k1_valu_takes(ctx, f32, kt, max_rows);
+        const bool k1_resident = nulls ? k1_nulls_takes(ctx, f32, kt, max_rows) : k1_valu_takes(ctx, f32, kt, max_rows);
         // null policies: the register-resident K1 has a NULLS family; everything else goes through the streamed kernels
         stream = (nulls && !k1_resident) || (!k1_resident && (kt > K1M_MAX_KT || !fits_lds));
         stream = stream || ctx->opt.static_engine == 1;

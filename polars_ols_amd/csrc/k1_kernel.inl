@@ -190,7 +190,9 @@ __device__ __forceinline__ void gram_accumulate(T (&acc)[(KT + 1) * (KT + 2) / 2
 
 // The packed entries [Q0, Q1) only: the multi-pass Gram of the f64 team kernel keeps a third of the accumulators live at a
 // time (the guards are compile-time constants under the full unroll).
-template <typename T, int KT, bool HAS_W, int Q0, int Q1>
+// NULLS: masked like gram_rows MODE 1 -- rows outside the fit contribute nothing, a null target that stays counts as 0, the
+// (unused) y'y slot counts the rows left in the fit.
+template <typename T, int KT, bool HAS_W, int Q0, int Q1, bool NULLS = false>
 __device__ __forceinline__ void gram_accumulate_range(T (&acc)[Q1 - Q0], const Chunk<T, KT, HAS_W> &c) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
@@ -198,9 +200,14 @@ __device__ __forceinline__ void gram_accumulate_range(T (&acc)[Q1 - Q0], const C
     for (int v = 0; v < VEC; ++v) {
         T ys = vget<T>(c.y, v);
         if constexpr (HAS_W) ys *= vget<T>(c.sw, v);
+        T mv = T(1);
+        if constexpr (NULLS) {
+            mv = ((c.m >> v) & 1u) ? T(1) : T(0);
+            ys = (ys == ys) ? ys * mv : T(0);
+        }
 #pragma unroll
         for (int i = 0; i < KT; ++i) {
-            const T xi = vget<T>(c.x[i], v);
+            const T xi = NULLS ? vget<T>(c.x[i], v) * mv : vget<T>(c.x[i], v);
 #pragma unroll
             for (int j = i; j < KT; ++j) {
                 constexpr int dummy = 0; (void)dummy;
@@ -211,13 +218,16 @@ __device__ __forceinline__ void gram_accumulate_range(T (&acc)[Q1 - Q0], const C
             if (qy >= Q0 && qy < Q1) acc[qy - Q0] = fma(xi, ys, acc[qy - Q0]);
         }
         const int qq = tri_index<NZ>(KT, KT);
-        if (qq >= Q0 && qq < Q1) acc[qq - Q0] = fma(ys, ys, acc[qq - Q0]);
+        if (qq >= Q0 && qq < Q1) {
+            if constexpr (NULLS) acc[qq - Q0] += mv;
+            else acc[qq - Q0] = fma(ys, ys, acc[qq - Q0]);
+        }
     }
 }
 
 // one pass of the multi-pass Gram: accumulate the entries [Q0, Q1) over the resident chunks, reduce-scatter inside the wave,
 // park the wave partials in LDS at their packed slots (Q0 is a multiple of 4, so slot numbering is unchanged)
-template <typename T, int KT, bool HAS_W, int RC, int TEAM, int Q0, int Q1>
+template <typename T, int KT, bool HAS_W, int RC, int TEAM, int Q0, int Q1, bool NULLS = false>
 __device__ __forceinline__ void gram_pass(const Chunk<T, KT, HAS_W> (&res)[RC], int64_t nch, int tid, int lane, int wave, T *mypart) {
     constexpr int N = Q1 - Q0, N4 = (N + 3) / 4, WAVES = TEAM / 64;
     T acc[N];
@@ -225,7 +235,7 @@ __device__ __forceinline__ void gram_pass(const Chunk<T, KT, HAS_W> (&res)[RC], 
     for (int q = 0; q < N; ++q) acc[q] = T(0);
 #pragma unroll
     for (int rc = 0; rc < RC; ++rc)
-        if ((int64_t)rc * TEAM + tid < nch) gram_accumulate_range<T, KT, HAS_W, Q0, Q1>(acc, res[rc]);
+        if ((int64_t)rc * TEAM + tid < nch) gram_accumulate_range<T, KT, HAS_W, Q0, Q1, NULLS>(acc, res[rc]);
     T u[N4];
     wave_reduce_scatter<T, N>(acc, u);
     const int row = lane >> 4;
@@ -237,12 +247,12 @@ __device__ __forceinline__ void gram_pass(const Chunk<T, KT, HAS_W> (&res)[RC], 
 }
 
 // every pass of QS packed entries, first to last (compile-time recursion: each pass is its own fully unrolled code)
-template <typename T, int KT, bool HAS_W, int RC, int TEAM, int QS, int Q0>
+template <typename T, int KT, bool HAS_W, int RC, int TEAM, int QS, int Q0, bool NULLS = false>
 __device__ __forceinline__ void gram_passes(const Chunk<T, KT, HAS_W> (&res)[RC], int64_t nch, int tid, int lane, int wave, T *mypart) {
     constexpr int NACC = (KT + 1) * (KT + 2) / 2;
     if constexpr (Q0 < NACC) {
-        gram_pass<T, KT, HAS_W, RC, TEAM, Q0, (Q0 + QS < NACC ? Q0 + QS : NACC)>(res, nch, tid, lane, wave, mypart);
-        gram_passes<T, KT, HAS_W, RC, TEAM, QS, Q0 + QS>(res, nch, tid, lane, wave, mypart);
+        gram_pass<T, KT, HAS_W, RC, TEAM, Q0, (Q0 + QS < NACC ? Q0 + QS : NACC), NULLS>(res, nch, tid, lane, wave, mypart);
+        gram_passes<T, KT, HAS_W, RC, TEAM, QS, Q0 + QS, NULLS>(res, nch, tid, lane, wave, mypart);
     }
 }
 
@@ -543,7 +553,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
     } else {
         constexpr int QS = (((NACC + NPASS - 1) / NPASS) + 3) & ~3;    // entries per pass, a multiple of 4
         static_assert(NPASS * QS >= NACC, "the passes cover the packed triangle");
-        gram_passes<T, KT, HAS_W, RC, TEAM, QS, 0>(res, nch, tid, lane, wave, mypart);
+        gram_passes<T, KT, HAS_W, RC, TEAM, QS, 0, NULLS>(res, nch, tid, lane, wave, mypart);
     }
     if constexpr (WAVES > 1) __syncthreads();
     K1_STAMP(3);
@@ -566,7 +576,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int st = POLS_GROUP_OK;
             T bv = T(0);
-            if (e == s) st = POLS_GROUP_EMPTY;
+            if (e == s || (NULLS && gsum[tri_index<NZ>(KT, KT)] == T(0))) st = POLS_GROUP_EMPTY;   // no row left in the fit -> zeros (ex.rs:357-359)
             else {
                 bool ok;
                 if constexpr (KT > 15) bv = chol_solve_rows<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lane, ok);
@@ -1176,6 +1186,19 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     // the null-policy family: the row masks live next to the resident rows; single-pass Gram only.  FAST as below: every load of
     // every resident chunk is in flight before the masks are built (POLS_K1_NOFAST=1: the general code)
     const bool fastn = ctx->offs_aligned[VEC == 4 ? 1 : 0] && max_rows <= (int64_t)RC * TEAM * VEC && !ctx->opt.k1_nofast;
+    if constexpr (KT >= 9) {
+        // 9-10 columns (8 features + intercept under a null policy): three masked passes, like the plain kernels of these widths
+        const bool resident = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        if (resident && ctx->opt.k1_passes != 1)
+            return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3, true>(ctx, a);
+    }
+    if constexpr (sizeof(T) == 8 && KT >= 6 && KT < 9) {
+        // f64, 6+ columns: the single-pass kernel needs 275-400 registers (one wave per SIMD: 300 against 146 us for the plain kernel on
+        // 10 000 x 1 000 x 8); two masked passes over the resident rows like the plain f64 kernels.  POLS_K1_PASSES=1 goes back.
+        const bool resident = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        if (resident && ctx->opt.k1_passes != 1)
+            return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2, true>(ctx, a);
+    }
     return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 1, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 1, true>(ctx, a);
 #else
     // FAST needs every group aligned to the vector width and resident; the offsets scan in upload_offsets() knows

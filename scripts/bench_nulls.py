@@ -31,6 +31,20 @@ def main():
         ms = eng.timing_collect()
         eng.timing(False)
         res[name] = {"kernel": eng.last_kernel, "us": float(np.mean(ms) * 1e3)}
+    # the same in f64 (BASELINE configs[2]'s shape without the weights)
+    cols64 = [c.double() for c in cols]
+    y64, yn64 = y.double(), yn.double()
+    for name, yy, kw in (("f64_plain", y64, {}), ("f64_drop_5pct_null_targets", yn64, {"null_policy": "drop"}),
+                         ("f64_drop_no_nulls", y64, {"null_policy": "drop"})):
+        plan = eng.plan_least_squares(yy, cols64, offs, want=("pred",), **kw)
+        for _ in range(10):
+            plan.run()
+        eng.timing(1)
+        for _ in range(40):
+            plan.run()
+        ms = eng.timing_collect()
+        eng.timing(False)
+        res[name] = {"kernel": eng.last_kernel, "us": float(np.mean(ms) * 1e3)}
     print(json.dumps(res))
 
 
