@@ -1192,6 +1192,13 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (resident && ctx->opt.k1_passes != 1)
             return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3, true>(ctx, a);
     }
+    if constexpr (sizeof(T) == 4 && KT >= 7 && KT < 9 && TEAM == 64 && RC == 4) {
+        // f32 wave kernel with 16 resident rows: with weights, or ragged, the single masked pass needs 267-287 registers (one wave per
+        // SIMD); two passes then
+        const bool resident = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        if (resident && (HAS_W || !fastn) && ctx->opt.k1_passes != 1)
+            return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2, true>(ctx, a);
+    }
     if constexpr (sizeof(T) == 8 && KT >= 6 && KT < 9) {
         // f64, 6+ columns: the single-pass kernel needs 275-400 registers (one wave per SIMD: 300 against 146 us for the plain kernel on
         // 10 000 x 1 000 x 8); two masked passes over the resident rows like the plain f64 kernels.  POLS_K1_PASSES=1 goes back.

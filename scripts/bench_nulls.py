@@ -31,6 +31,23 @@ def main():
         ms = eng.timing_collect()
         eng.timing(False)
         res[name] = {"kernel": eng.last_kernel, "us": float(np.mean(ms) * 1e3)}
+    w = torch.rand(G * n, device="cuda", generator=g) + 0.5
+    offs_r = np.concatenate([[0], np.cumsum(np.random.default_rng(0).integers(900, 1021, size=G))]).astype(np.int64)
+    nr = int(offs_r[-1])
+    for name, yy, oo, kw in (("weights_drop_5pct_null_targets", yn, offs, {"null_policy": "drop", "weights": w}),
+                             ("ragged_900_1020_drop", yn[:nr], offs_r, {"null_policy": "drop"})):
+        cc = [c[:len(yy)] for c in cols]
+        if "weights" in kw:
+            kw = dict(kw, weights=kw["weights"][:len(yy)])
+        plan = eng.plan_least_squares(yy, cc, oo, want=("pred",), **kw)
+        for _ in range(10):
+            plan.run()
+        eng.timing(1)
+        for _ in range(40):
+            plan.run()
+        ms = eng.timing_collect()
+        eng.timing(False)
+        res[name] = {"kernel": eng.last_kernel, "us": float(np.mean(ms) * 1e3)}
     # the same in f64 (BASELINE configs[2]'s shape without the weights)
     cols64 = [c.double() for c in cols]
     y64, yn64 = y.double(), yn.double()
