@@ -228,8 +228,9 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
  * n_targets column pointers (the fields of the reference's target struct), `pred_cols` n_targets output columns (or NULL),
  * `coef` n_groups x n_targets x (n_features + intercept) in the batch dtype (or NULL), `status` n_groups (or NULL); all
  * live where `b->mem` says.  Unconstrained OLS / ridge with solve_method None or "svd" only, like the reference's Python
- * checks (polars_ols/least_squares.py:303-318, reported as POLS_ERR_PANIC).  The joint validity mask over targets and
- * features (ex.rs:539-548) is applied by the caller: null_policy must be "ignore". */
+ * checks (polars_ols/least_squares.py:303-318, reported as POLS_ERR_PANIC).  Null policies as in the plugin body: the joint
+ * validity mask over every target and (unless drop_y_zero_x) every feature (ex.rs:539-548), the fit on the rows it leaves, then
+ * predictions for EVERY row from the zero-filled features, masked to NaN under "drop" (ex.rs:566-585). */
 int pols_multi_target_least_squares(pols_ctx *ctx, const pols_batch *b, const void *const *y_cols, int32_t n_targets,
                                     const pols_ols_params *p, void *const *pred_cols, void *coef, int32_t *status);
 

@@ -354,30 +354,46 @@ static bool k1_nulls_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_ro
 struct Compacted {
     pols_batch bb;
     std::vector<int64_t> offs;
-    std::vector<const void *> xcols;
+    std::vector<const void *> xcols, ycols;    // compacted features / targets (ycols[0] == bb.y)
+    Staged st;                                  // the ORIGINAL rows on the device (for predictions over every row)
+    const int64_t *d_offs = nullptr;            // ... and their offsets
+    const uint8_t *vbytes = nullptr;            // row validity (device)
 };
 
-static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compacted *c) {
+// `targets` (n_targets >= 1 pointers living where b->mem says) replace b->y as the leading columns: the multi-target mask of
+// ex.rs:539-548 is over every target (and, unless drop_y_zero_x, every feature).  n_targets == 0: the single target b->y.
+static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compacted *c, const void *const *targets = nullptr,
+                         int n_targets = 0) {
     int rc;
     const int64_t *d_offs = nullptr;
     int64_t max_rows = 0;
-    Staged st;
+    Staged &st = c->st;
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows, b->offsets_generation))) return rc;
     if ((rc = stage_inputs(ctx, b, 0, 0, nullptr, &st))) return rc;
-    const int k = b->n_features, ncols = 1 + k + (st.w ? 1 : 0);
+    const int m = n_targets > 0 ? n_targets : 1;
+    const int k = b->n_features, ncols = m + k + (st.w ? 1 : 0);
     const size_t G = (size_t)b->n_groups, N = (size_t)b->n_rows;
     const size_t sz = dtype_size(b->dtype), colb = round256(sz * std::max<size_t>(N, 1));
     const size_t cntb = round256(sizeof(unsigned long long) * G), vb = round256(std::max<size_t>(N, 1));
     const size_t tabb = round256(sizeof(void *) * (size_t)ncols), offb = round256(sizeof(int64_t) * (G + 1));
     void *d = nullptr;
-    if ((rc = ensure_scratch(ctx, 14, cntb + vb + 2 * tabb + offb + colb * (size_t)ncols, &d))) return rc;
+    const bool stage_targets = n_targets > 0 && b->mem == POLS_MEM_HOST;      // host targets: uploaded behind the compacted columns
+    if ((rc = ensure_scratch(ctx, 14, cntb + vb + 2 * tabb + offb + colb * (size_t)(ncols + (stage_targets ? m : 0)), &d))) return rc;
     char *base = static_cast<char *>(d);
     char *cols = base + cntb + vb + 2 * tabb + offb;
     std::vector<const void *> inp((size_t)ncols);
     std::vector<void *> outp((size_t)ncols);
-    inp[0] = st.y;
-    for (int j = 0; j < k; ++j) inp[(size_t)(1 + j)] = st.x[(size_t)j];
-    if (st.w) inp[(size_t)(1 + k)] = st.w;
+    for (int t = 0; t < m; ++t) {
+        const void *src = n_targets > 0 ? targets[t] : st.y;
+        if (stage_targets) {
+            char *dst = cols + colb * (size_t)(ncols + t);
+            POLS_HIP(hipMemcpyAsync(dst, targets[t], sz * N, hipMemcpyHostToDevice, ctx->stream));
+            src = dst;
+        }
+        inp[(size_t)t] = src;
+    }
+    for (int j = 0; j < k; ++j) inp[(size_t)(m + j)] = st.x[(size_t)j];
+    if (st.w) inp[(size_t)(m + k)] = st.w;
     for (int j = 0; j < ncols; ++j) outp[(size_t)j] = cols + colb * (size_t)j;
     if ((rc = upload_small(ctx, base + cntb + vb, inp.data(), sizeof(void *) * (size_t)ncols))) return rc;
     if ((rc = upload_small(ctx, base + cntb + vb + tabb, outp.data(), sizeof(void *) * (size_t)ncols))) return rc;
@@ -386,9 +402,9 @@ static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compact
     ca.in = reinterpret_cast<const void *const *>(base + cntb + vb);
     ca.out = reinterpret_cast<void *const *>(base + cntb + vb + tabb);
     ca.n_cols = ncols;
-    ca.w_col = st.w ? 1 + k : -1;
+    ca.w_col = st.w ? m + k : -1;
     ca.drop = (policy == POLS_NULL_DROP || policy == POLS_NULL_DROP_ZERO || policy == POLS_NULL_DROP_WINDOW || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;
-    ca.n_mask = policy == POLS_NULL_DROP_Y_ZERO_X ? 1 : 1 + k;                                 // ex.rs:209-220
+    ca.n_mask = policy == POLS_NULL_DROP_Y_ZERO_X ? m : m + k;                                 // ex.rs:209-220
     ca.zero_fill = (policy == POLS_NULL_ZERO || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;   // ex.rs:264-283
     ca.valid_in = st.valid;
     ca.offs = d_offs;
@@ -404,7 +420,10 @@ static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compact
     for (size_t g = 0; g < G; ++g) c->offs[g + 1] = c->offs[g] + (int64_t)counts[g];
     if ((rc = upload_small(ctx, base + cntb + vb + 2 * tabb, c->offs.data(), sizeof(int64_t) * (G + 1)))) return rc;
     if ((rc = compact_scatter_launch(ctx, b->dtype, ca))) return rc;
-    c->xcols.assign(outp.begin() + 1, outp.begin() + 1 + k);
+    c->xcols.assign(outp.begin() + m, outp.begin() + m + k);
+    c->ycols.assign(outp.begin(), outp.begin() + m);
+    c->d_offs = d_offs;
+    c->vbytes = ca.vbytes;
     c->bb = *b;
     c->bb.mem = POLS_MEM_DEVICE;
     c->bb.n_rows = c->offs[G];
@@ -412,7 +431,7 @@ static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compact
     c->bb.offsets_generation = 0;
     c->bb.y = outp[0];
     c->bb.x_cols = c->xcols.data();
-    c->bb.weights = st.w ? outp[(size_t)(1 + k)] : nullptr;
+    c->bb.weights = st.w ? outp[(size_t)(m + k)] : nullptr;
     c->bb.valid = nullptr;
     c->bb.null_free = 1;
     return POLS_OK;
@@ -977,11 +996,59 @@ int pols_multi_target_least_squares(pols_ctx *ctx, const pols_batch *b, const vo
     if (!(p->solve_method == POLS_SOLVE_AUTO || p->solve_method == POLS_SOLVE_SVD))
         return fail(POLS_ERR_PANIC, "only solve_method='svd' is supported for multi-target regressions");
     if (!(p->alpha >= 0.0)) return fail(POLS_ERR_PANIC, "alpha must be non-negative");
-    if (p->null_policy != POLS_NULL_IGNORE || b->valid)
-        return fail(POLS_ERR_UNSUPPORTED, "multi-target: apply the joint validity mask before the call (src/expressions.rs:539-548)");
+    if (p->null_policy < POLS_NULL_IGNORE || p->null_policy > POLS_NULL_DROP_WINDOW) return fail(POLS_ERR_INVALID, "unknown null_policy %d", p->null_policy);
+    if (b->valid && (p->null_policy == POLS_NULL_IGNORE || p->null_policy == POLS_NULL_ZERO))
+        return fail(POLS_ERR_INVALID, "a validity mask needs a drop-family null_policy");
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
     if (kt + n_targets > K8_KMAX) return fail(POLS_ERR_UNSUPPORTED, "%d columns + %d targets > %d", kt, n_targets, K8_KMAX);
     if (b->n_groups == 0) return POLS_OK;
+    if ((p->null_policy != POLS_NULL_IGNORE && !b->null_free) || b->valid) {
+        // The plugin body under a null policy (src/expressions.rs:521-591): the joint validity mask over every target (and, unless
+        // drop_y_zero_x, every feature), the fit on the rows handle_nulls leaves -- compacted on the device --, then predictions for
+        // EVERY row from the zero-filled features, masked under "drop".
+        Compacted c;
+        if ((rc = compact_nulls(ctx, &bb, p->null_policy, &c, y_cols, n_targets))) return rc;
+        const bool host = b->mem == POLS_MEM_HOST;
+        const size_t G = (size_t)b->n_groups, N = (size_t)b->n_rows, sz = dtype_size(b->dtype);
+        const size_t coefb = round256(sz * G * n_targets * kt), statb = round256(sizeof(int32_t) * G), colb = round256(sz * std::max<size_t>(N, 1));
+        const size_t tabb = round256(sizeof(void *) * (size_t)std::max(b->n_features, n_targets));
+        void *d = nullptr;
+        if ((rc = ensure_scratch(ctx, 15, coefb + statb + 2 * tabb + (host && pred_cols ? colb * (size_t)n_targets : 0), &d))) return rc;
+        char *q = static_cast<char *>(d);
+        void *dcoef = (!host && coef) ? coef : static_cast<void *>(q);
+        int32_t *dstat = (!host && status) ? status : reinterpret_cast<int32_t *>(q + coefb);
+        char *tabs = q + coefb + statb, *preds = tabs + 2 * tabb;
+        pols_ols_params pp = *p;
+        pp.null_policy = POLS_NULL_IGNORE;
+        if ((rc = pols_multi_target_least_squares(ctx, &c.bb, c.ycols.data(), n_targets, &pp, nullptr, dcoef, dstat))) return rc;
+        if (pred_cols) {
+            // (the inner call uploaded the COMPACTED offsets into the slot c.d_offs points to: the original ones again)
+            const int64_t *d_offs = nullptr;
+            int64_t mr = 0;
+            if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &mr, b->offsets_generation))) return rc;
+            std::vector<void *> pt((size_t)n_targets);
+            for (int t = 0; t < n_targets; ++t) pt[(size_t)t] = host ? static_cast<void *>(preds + colb * (size_t)t) : pred_cols[t];
+            if ((rc = upload_small(ctx, tabs, c.st.x.data(), sizeof(void *) * (size_t)b->n_features))) return rc;
+            if ((rc = upload_small(ctx, tabs + tabb, pt.data(), sizeof(void *) * (size_t)n_targets))) return rc;
+            MtPredictArgs ma;
+            std::memset(&ma, 0, sizeof(ma));
+            ma.xtab = reinterpret_cast<const void *const *>(tabs);
+            ma.ptab = reinterpret_cast<void *const *>(tabs + tabb);
+            ma.w = c.st.w; ma.coef = dcoef; ma.vbytes = c.vbytes; ma.offs = d_offs; ma.n_groups = b->n_groups;
+            ma.k_user = b->n_features; ma.kt = kt; ma.m = n_targets;
+            ma.mask_drop = p->null_policy == POLS_NULL_DROP ? 1 : 0;                   // ex.rs:575-583
+            if ((rc = mt_predict_launch(ctx, b->dtype, ma))) return rc;
+            if (host)
+                for (int t = 0; t < n_targets; ++t)
+                    POLS_HIP(hipMemcpyAsync(pred_cols[t], pt[(size_t)t], sz * N, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (host) {
+            if (coef) POLS_HIP(hipMemcpyAsync(coef, dcoef, sz * G * n_targets * kt, hipMemcpyDeviceToHost, ctx->stream));
+            if (status) POLS_HIP(hipMemcpyAsync(status, dstat, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+            POLS_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return POLS_OK;
+    }
     // solve_multi_target (ls.rs:243-260): alpha > 0 -> ridge (SVD form), else minimum-norm least squares: ONE Gram pass over
     // [X | targets] and ONE factorisation serve every target; flagged groups go through the Jacobi pass once as well.
     return wide_static(ctx, &bb, p, &o, kt, false, p->alpha, 0.0, p->alpha == 0.0, y_cols, n_targets, pred_cols);

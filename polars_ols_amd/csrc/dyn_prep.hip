@@ -116,6 +116,45 @@ int compact_count_launch(pols_ctx *ctx, int dtype, const CompactArgs &a) {
 }
 int compact_scatter_launch(pols_ctx *ctx, int dtype, const CompactArgs &a) { COMPACT_LAUNCH(compact_scatter_kernel) }
 
+template <typename T>
+__global__ void __launch_bounds__(256) mt_predict_kernel(const MtPredictArgs a) {
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const T *cg = static_cast<const T *>(a.coef) + (size_t)g * a.m * a.kt;
+    const bool icpt = a.kt != a.k_user;
+    for (int64_t r = s + threadIdx.x; r < e; r += 256) {
+        T sw = T(1);
+        if (a.w) { T wv = static_cast<const T *>(a.w)[r]; if (wv != wv) wv = (T)1e-24; sw = sqrt(wv); }
+        for (int t0 = 0; t0 < a.m; t0 += 4) {                 // four targets per sweep over the features
+            T acc[4] = {T(0), T(0), T(0), T(0)};
+            for (int j = 0; j < a.k_user; ++j) {
+                T xv = static_cast<const T *>(a.xtab[j])[r];
+                xv = (xv != xv) ? T(0) : xv * sw;             // construct_features_array(.., true): nulls -> 0
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t0 + u < a.m) acc[u] = fma(xv, cg[(size_t)(t0 + u) * a.kt + j], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + u >= a.m) break;
+                T pv = acc[u];
+                if (icpt) pv = fma(sw, cg[(size_t)(t0 + u) * a.kt + a.kt - 1], pv);
+                if (a.w) pv *= T(1) / sw;
+                pv = nan_if<T>((a.mask_drop && !a.vbytes[r]) ? 1u : 0u, pv);
+                static_cast<T *>(a.ptab[t0 + u])[r] = pv;
+            }
+        }
+    }
+}
+
+int mt_predict_launch(pols_ctx *ctx, int dtype, const MtPredictArgs &a) {
+    if (a.n_groups == 0) return POLS_OK;
+    if (dtype == POLS_F32) hipLaunchKernelGGL(mt_predict_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(mt_predict_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
 #define DYN_LAUNCH(kernel)                                                                                              \
     if (a.n_rows == 0) return POLS_OK;                                                                                  \
     const unsigned blocks = (unsigned)((a.n_rows + 255) / 256);                                                         \

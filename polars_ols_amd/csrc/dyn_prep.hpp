@@ -45,6 +45,20 @@ struct CompactArgs {
 int compact_count_launch(pols_ctx *ctx, int dtype, const CompactArgs &a);
 int compact_scatter_launch(pols_ctx *ctx, int dtype, const CompactArgs &a);
 
+// Multi-target predictions under the drop policies (src/expressions.rs:566-585): the coefficients were fitted on the filtered rows;
+// every ORIGINAL row is predicted from its zero-filled features and its group's coefficients, "drop" masks the rows left out.
+struct MtPredictArgs {
+    const void *const *xtab;     // DEVICE table of k_user feature column pointers (original rows)
+    const void *w;               // sample weights or nullptr: (sqrt(w) x) . c * (1 / sqrt(w)) like the reference's arithmetic
+    const void *coef;            // n_groups x m x kt, batch dtype
+    void *const *ptab;           // DEVICE table of m prediction column pointers
+    const uint8_t *vbytes;       // row validity from the compaction pass
+    const int64_t *offs;         // DEVICE group offsets (original rows)
+    int64_t n_groups;
+    int32_t k_user, kt, m, mask_drop;
+};
+int mt_predict_launch(pols_ctx *ctx, int dtype, const MtPredictArgs &a);
+
 int dyn_scan_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_rewrite_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_post_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);

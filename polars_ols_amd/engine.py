@@ -177,12 +177,13 @@ class Engine:
 
     def multi_target_least_squares(self, y_cols: Sequence, x_cols: Sequence, offsets, *, weights=None, add_intercept: bool = False,
                                    alpha: float = 0.0, solve_method: Optional[str] = None, rcond: Optional[float] = None,
-                                   want: Sequence[str] = ("pred", "coef")) -> Dict:
+                                   null_policy: str = "ignore", valid=None, want: Sequence[str] = ("pred", "coef")) -> Dict:
         """solve_multi_target (src/least_squares.rs:243-260) for every group: ONE Gram pass and ONE factorisation shared by all
-        targets.  Returns ``pred`` (list of n_targets columns), ``coef`` [n_groups, n_targets, k], ``status`` [n_groups]."""
+        targets.  Returns ``pred`` (list of n_targets columns), ``coef`` [n_groups, n_targets, k], ``status`` [n_groups].
+        Null policies like the plugin body (src/expressions.rs:521-591): joint mask, fit on the rows it leaves, every row predicted."""
         ys = list(y_cols)
         plan = self.plan_least_squares(ys[0], x_cols, offsets, weights=weights, add_intercept=add_intercept, alpha=alpha,
-                                       solve_method=solve_method, rcond=rcond, want=())
+                                       solve_method=solve_method, rcond=rcond, null_policy=null_policy, valid=valid, want=())
         b = plan._b
         dev = b.mem == L.POLS_MEM_DEVICE
         like = plan._keep[0][0]

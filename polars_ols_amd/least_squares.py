@@ -429,46 +429,10 @@ def compute_multi_target_least_squares(targets, *features, sample_weights=None, 
         offs = grp.offsets
         moved = grp.take([w] + list(ys) + list(xs))
         w_s, ys_s, xs_s = moved[0], moved[1:1 + len(ys)], moved[1 + len(ys):]
-        policy = kw.null_policy
-        solver = dict(alpha=kw.alpha, solve_method=kw.solve_method, rcond=kw.rcond)
-        if policy in ("ignore", "zero"):
-            if policy == "zero":
-                ys_s, xs_s = [_nan_to_zero(y) for y in ys_s], [_nan_to_zero(c) for c in xs_s]
-            preds = eng.multi_target_least_squares(ys_s, xs_s, offs, weights=w_s, add_intercept=icpt, want=("pred",), **solver)["pred"]
-        else:
-            # drop family (ex.rs:539-585): fit on the rows where EVERY target (and, unless drop_y_zero_x, every feature) is
-            # non-null, predict every row from the zero-filled features, mask for "drop"
-            if w_s is not None:
-                sw = torch.sqrt(w_s) if _is_torch(w_s) else np.sqrt(w_s)
-                ys_f, xs_f = [y * sw for y in ys_s], [c * sw for c in xs_s] + ([sw] if icpt else [])
-            else:
-                sw = None
-                ys_f, xs_f = ys_s, list(xs_s) + ([_ones_like(ys_s[0])] if icpt else [])
-            valid = ~_isnan(ys_f[0])
-            for y in ys_f[1:]:
-                valid = valid & ~_isnan(y)
-            if policy != "drop_y_zero_x":
-                for c in xs_f:
-                    valid = valid & ~_isnan(c)
-            vnp = valid.cpu().numpy() if _is_torch(valid) else valid
-            counts = np.bincount(grp.gid_sorted(vnp)[vnp], minlength=len(offs) - 1)
-            offs_v = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-            vi = _to_index(np.nonzero(vnp)[0], ys_f[0])
-            xs_v = [_take(c, vi) for c in xs_f]
-            if policy == "drop_y_zero_x":
-                xs_v = [_nan_to_zero(c) for c in xs_v]
-            coef = eng.multi_target_least_squares([_take(y, vi) for y in ys_f], xs_v, offs_v, want=("coef",), **solver)["coef"]
-            gi = grp.gid_sorted(ys_f[0])
-            xs_z = [_nan_to_zero(c) for c in xs_f]
-            preds = []
-            for t in range(len(ts)):
-                pr = eng.predict(xs_z, coef[:, t, :][gi])
-                if sw is not None:
-                    pr = pr * (1.0 / sw)
-                if policy == "drop":
-                    nan = float("nan")
-                    pr = torch.where(valid, pr, torch.full_like(pr, nan)) if _is_torch(pr) else np.where(valid, pr, nan)
-                preds.append(pr)
+        # joint validity mask, fit on the rows it leaves, every row predicted from zero-filled features, "drop" masked
+        # (ex.rs:539-585): all of it inside the entry (csrc/dyn_prep.hip)
+        preds = eng.multi_target_least_squares(ys_s, xs_s, offs, weights=w_s, add_intercept=icpt, want=("pred",), alpha=kw.alpha,
+                                               solve_method=kw.solve_method, rcond=kw.rcond, null_policy=kw.null_policy)["pred"]
         out = {}
         for t, y_s, pr in zip(ts, ys_s, preds):
             val = pr if mode == "predictions" else y_s - pr

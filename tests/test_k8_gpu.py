@@ -245,3 +245,53 @@ def test_multi_target_rank_deficient_group_and_panics(eng):
         assert np.allclose(out["pred"][t], preds[t], rtol=1e-6, atol=1e-7)
     with pytest.raises(Exception):
         eng.multi_target_least_squares(ys, cols, offs, solve_method="chol")
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("policy", ["drop", "zero", "drop_y_zero_x", "drop_zero"])
+@pytest.mark.parametrize("k,m,weights,icpt,alpha", [(3, 2, False, False, 0.0), (5, 3, True, True, 0.7), (40, 5, False, True, 0.0)])
+def test_multi_target_null_policies_behind_the_cabi(eng, dtype, tol, policy, k, m, weights, icpt, alpha):
+    """The plugin body under a null policy (src/expressions.rs:521-591) inside pols_multi_target_least_squares: the joint mask over
+    every target (and, unless drop_y_zero_x, every feature), the fit on the rows it leaves, predictions for EVERY row from the
+    zero-filled features, "drop" masked.  Expectation: those steps in numpy around solve_multi_target's oracle.  Host and device."""
+    import torch
+
+    rng = np.random.default_rng(31 * k + m)
+    sizes = rng.integers(6 * (k + 1), 12 * (k + 1), size=9)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    cols = [rng.standard_normal(n) for _ in range(k)]
+    ys = [sum((j + t + 1) * 0.2 * c for j, c in enumerate(cols)) + 0.3 * t + 0.1 * rng.standard_normal(n) for t in range(m)]
+    w = rng.uniform(0.5, 2.0, size=n) if weights else None
+    for y in ys[:2]:
+        y[rng.random(n) < 0.04] = np.nan
+    for c in cols[:2]:
+        c[rng.random(n) < 0.03] = np.nan
+    ys, cols = [y.astype(dtype) for y in ys], [c.astype(dtype) for c in cols]
+    w = None if w is None else w.astype(dtype)
+    # numpy expectation
+    Y = np.column_stack(ys).astype(np.float64)
+    X = np.column_stack(cols + ([np.ones(n, dtype=dtype)] if icpt else [])).astype(np.float64)
+    sw = np.ones(n) if w is None else np.sqrt(w.astype(np.float64))
+    ynull, xnull = np.isnan(Y).any(axis=1), np.isnan(X).any(axis=1)
+    keep = ~ynull & ~xnull if policy in ("drop", "drop_zero") else (~ynull if policy == "drop_y_zero_x" else np.ones(n, dtype=bool))
+    Xz = np.nan_to_num(X)
+    exp = np.full((n, m), np.nan)
+    for g in range(len(offs) - 1):
+        s, e = offs[g], offs[g + 1]
+        kk = keep[s:e]
+        Xf = (np.nan_to_num(X[s:e]) if policy in ("zero", "drop_y_zero_x") else X[s:e])[kk] * sw[s:e][kk, None]
+        Yf = (np.nan_to_num(Y[s:e]) if policy == "zero" else Y[s:e])[kk] * sw[s:e][kk, None]
+        B = orc.solve_multi_target(Yf, Xf, alpha=alpha)                             # kt x m
+        exp[s:e] = Xz[s:e] @ B
+    if policy == "drop":
+        exp[~keep] = np.nan
+    kw = dict(weights=w, add_intercept=icpt, alpha=alpha, null_policy=policy, want=("pred", "coef"))
+    host = eng.multi_target_least_squares(ys, cols, offs, **kw)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()  # noqa: E731
+    dev = eng.multi_target_least_squares([t(y) for y in ys], [t(c) for c in cols], offs, **dict(kw, weights=t(w)))
+    eng.synchronize()
+    for res in (host, {"pred": [p.cpu().numpy() for p in dev["pred"]]}):
+        got = np.column_stack([np.asarray(p, dtype=np.float64) for p in res["pred"]])
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert np.allclose(got, exp, rtol=tol, atol=10 * tol, equal_nan=True), float(np.nanmax(np.abs(got - exp)))
