@@ -5,6 +5,9 @@
 #ifndef K1_RAGGED_VECTOR_LOADS
 #define K1_RAGGED_VECTOR_LOADS 1
 #endif
+#ifndef K1_SOLVE_ROWS
+#define K1_SOLVE_ROWS 1        // multi-pass team kernels: the row-resident right-looking Cholesky at every width (0: LDS left-looking up to 15 columns)
+#endif
 
 namespace pols {
 
@@ -579,7 +582,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
             if (e == s || (NULLS && gsum[tri_index<NZ>(KT, KT)] == T(0))) st = POLS_GROUP_EMPTY;   // no row left in the fit -> zeros (ex.rs:357-359)
             else {
                 bool ok;
-                if constexpr (KT > 15) bv = chol_solve_rows<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lane, ok);
+                if constexpr (K1_SOLVE_ROWS || KT > 15) bv = chol_solve_rows<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lane, ok);
                 else bv = chol_solve_lds<T, KT>(gsum, (T)a.alpha, (T)a.pivot_tol, lfac, lrinv, lane, ok);
                 if (!ok) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
             }
