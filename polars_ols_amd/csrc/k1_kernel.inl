@@ -5,6 +5,9 @@
 #ifndef K1_RAGGED_VECTOR_LOADS
 #define K1_RAGGED_VECTOR_LOADS 1
 #endif
+#ifndef K1T_F32_TWO_PASS
+#define K1T_F32_TWO_PASS 1
+#endif
 #ifndef K1_SOLVE_ROWS
 #define K1_SOLVE_ROWS 1        // multi-pass team kernels: the row-resident right-looking Cholesky at every width (0: LDS left-looking up to 15 columns)
 #endif
@@ -361,8 +364,24 @@ __device__ __forceinline__ T chol_solve_lds(const T *G, T alpha, T pivot_tol, T 
 // (v_readlane), scales column j in every lane, broadcasts L[p][j] (lane p's register j) and updates r[p] -= r[j] * L[p][j] --
 // KT - j independent readlane + FMA pairs per step, ~1 000 instructions at 31 columns.  The transposed access of the backward
 // substitution goes through one LDS copy of the factor.  Returns this lane's coefficient (lanes >= KT: 0).
-template <typename T, int KT>
+// lane j of every WIDTH-lane team to all of the team's lanes: v_readlane for a whole wave, DPP row_share for 16-lane rows (one
+// instruction per 32 bits either way; j is a constant after unrolling, the switch folds)
+template <int WIDTH, typename T>
+__device__ __forceinline__ T team_bcast(T v, int j) {
+    if constexpr (WIDTH == 64) return k1p_readlane(v, j);
+    else {
+        switch (j) {
+            case 0: return dpp_get<0x150>(v); case 1: return dpp_get<0x151>(v); case 2: return dpp_get<0x152>(v); case 3: return dpp_get<0x153>(v);
+            case 4: return dpp_get<0x154>(v); case 5: return dpp_get<0x155>(v); case 6: return dpp_get<0x156>(v); case 7: return dpp_get<0x157>(v);
+            case 8: return dpp_get<0x158>(v); case 9: return dpp_get<0x159>(v); case 10: return dpp_get<0x15A>(v); case 11: return dpp_get<0x15B>(v);
+            case 12: return dpp_get<0x15C>(v); case 13: return dpp_get<0x15D>(v); case 14: return dpp_get<0x15E>(v); default: return dpp_get<0x15F>(v);
+        }
+    }
+}
+
+template <typename T, int KT, int WIDTH = 64>
 __device__ __forceinline__ T chol_solve_rows(const T *G, T alpha, T pivot_tol, T *L, int lane, bool &ok) {
+    static_assert(WIDTH == 64 || (WIDTH == 16 && KT <= 16), "a wave, or one 16-lane DPP row per group (K1t)");
     constexpr int NZ = KT + 1;
     const int li = lane < KT ? lane : KT - 1;                // lanes beyond the matrix mirror the last row (their results are unused)
     T r[KT];
@@ -375,14 +394,14 @@ __device__ __forceinline__ T chol_solve_rows(const T *G, T alpha, T pivot_tol, T
     ok = true;
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-        const T d = k1p_readlane(r[j], j);
-        const T gjj = k1p_readlane(g0, j);
+        const T d = team_bcast<WIDTH>(r[j], j);
+        const T gjj = team_bcast<WIDTH>(g0, j);
         ok = ok && (d > pivot_tol * gjj);
         const T ri = inv_sqrt(d);
         myrinv = (lane == j) ? ri : myrinv;
         r[j] *= ri;                                          // lanes i >= j: L[i][j]  (lane j: sqrt(d))
 #pragma unroll
-        for (int p = j + 1; p < KT; ++p) r[p] = fma(-r[j], k1p_readlane(r[j], p), r[p]);
+        for (int p = j + 1; p < KT; ++p) r[p] = fma(-r[j], team_bcast<WIDTH>(r[j], p), r[p]);
     }
     if (lane < KT) {
 #pragma unroll
@@ -391,14 +410,14 @@ __device__ __forceinline__ T chol_solve_rows(const T *G, T alpha, T pivot_tol, T
 #pragma unroll
     for (int p = 0; p < KT; ++p) {                           // forward: t = L^-1 b
         if (lane == p) bi *= myrinv;
-        const T tp = k1p_readlane(bi, p);
+        const T tp = team_bcast<WIDTH>(bi, p);
         if (lane > p && lane < KT) bi = fma(-r[p], tp, bi);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int p = KT - 1; p >= 0; --p) {                      // backward: beta = L^-T t
         if (lane == p) bi *= myrinv;
-        const T bp = k1p_readlane(bi, p);
+        const T bp = team_bcast<WIDTH>(bi, p);
         if (lane < p) bi = fma(-L[p * KT + lane], bp, bi);
     }
     return bi;
@@ -694,7 +713,7 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
     const int64_t s = live ? a.offs[g] : 0, e = live ? a.offs[g + 1] : 0;
     const int64_t base = s - (s % VEC);                      // chunk grid aligned to 16 bytes in every column
     const int64_t nch = (e - base + VEC - 1) / VEC;          // <= K1T_SUB * K1T_RC: the host checked the largest group
-    constexpr bool TWO_PASS = sizeof(T) == 8 && KT >= 6 && K1T_SUB == 16;
+    constexpr bool TWO_PASS = (sizeof(T) == 8 || K1T_F32_TWO_PASS) && KT >= 6 && K1T_SUB == 16;
     T acc[TWO_PASS ? 1 : NACC];
     Chunk<T, KT, HAS_W> res[K1T_RC];
     T beta[KT];
@@ -737,7 +756,8 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
         if (e == s) st = POLS_GROUP_EMPTY;
         else {
             bool ok;
-            bv = chol_solve_lds<T, KT, K1T_SUB>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], lr[team], sub, ok);
+            if constexpr (K1_SOLVE_ROWS) bv = chol_solve_rows<T, KT, K1T_SUB>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], sub, ok);
+            else bv = chol_solve_lds<T, KT, K1T_SUB>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], lr[team], sub, ok);
             if (!ok) st = POLS_GROUP_FALLBACK;
         }
         if (sub < KT) bc[team][sub] = bv;
@@ -1265,7 +1285,9 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             // (two 4-wave blocks per CU need 2 x 4 x (2 * columns + 1) KiB of LDS <= 160 KiB: up to 9 staged columns)
             const bool forced = ctx->opt.k1_persist > 0;
             constexpr bool two_blocks = 2 * (KT + 1 + (HAS_W ? 1 : 0)) + 1 <= 20;
-            if (need <= 16 * 2 * VEC && (ps == 16 || (ps == 0 && (forced || (two_blocks && need > 16 * 1 * VEC))))) return k1p_launch<T, KT, HAS_W, 16, 2>(ctx, a);
+            // (16 lanes per group, up to 128 rows: 383-392 us on 500 000 groups of 40..120 rows against 495 us for K1t when this was
+            // written; K1t has since got the two-pass Gram + row-share Cholesky -- 122 instead of 181 registers -- and does 378 us)
+            if (need <= 16 * 2 * VEC && (ps == 16 || (ps == 0 && forced))) return k1p_launch<T, KT, HAS_W, 16, 2>(ctx, a);
             if (need <= 32 * 2 * VEC && (ps == 32 || (ps == 0 && (forced || (two_blocks && need > 16 * 2 * VEC))))) return k1p_launch<T, KT, HAS_W, 32, 2>(ctx, a);
             if (need <= 64 * 1 * VEC && ps == 64) return k1p_launch<T, KT, HAS_W, 64, 1>(ctx, a);
             if (need <= 64 * 2 * VEC && (ps == 64 || (ps == 0 && forced))) return k1p_launch<T, KT, HAS_W, 64, 2>(ctx, a);

@@ -340,7 +340,7 @@ def test_contexts_are_independent_across_host_threads():
 @pytest.mark.parametrize("dtype,lo,hi,tag", [(np.float32, 12, 40, "sub16_rc1"), (np.float32, 40, 120, "sub16_rc2"), (np.float64, 12, 30, "sub16_rc1"),
                                              (np.float64, 20, 60, "sub16_rc2")])
 def test_many_tiny_groups_four_per_wave(eng, dtype, lo, hi, tag):
-    """K1t (K1p beyond 64 f32 rows: the same four groups per wave, persistent) at scale: 300 000 ragged groups.  Size-independent checks on every group (X'(y - yhat) = 0 through a
+    """K1t at scale: 300 000 ragged groups, four per wave.  Size-independent checks on every group (X'(y - yhat) = 0 through a
     segmented sum, pred + resid == y, exact scaling in y) and oracle parity on a sample that includes both ends of the frame."""
     import torch
     from oracle import orc
@@ -355,7 +355,7 @@ def test_many_tiny_groups_four_per_wave(eng, dtype, lo, hi, tag):
     cols = [torch.randn(N, generator=g, device="cuda", dtype=tdt) for _ in range(k)]
     y = sum(cols) * 0.5 + 0.1 * torch.randn(N, generator=g, device="cuda", dtype=tdt) + 0.3
     out = eng.least_squares(y, cols, offs, add_intercept=True, want=("coef", "pred", "resid", "status"))
-    family = "k1p_" if (dtype == np.float32 and hi > 64) else "k1t_"
+    family = "k1t_"
     assert tag in eng.last_kernel and eng.last_kernel.startswith(family), eng.last_kernel
     assert int(out["status"].abs().sum()) == 0
     tol = 1e-4 if dtype == np.float32 else 1e-9
