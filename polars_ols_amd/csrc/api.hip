@@ -163,7 +163,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_NOFAST")) o.k1_nofast = on;
     else if (ieq(key, "K1_NOTINY")) o.k1_notiny = on;
     else if (ieq(key, "K1_NORC1")) o.k1_norc1 = on;
-    else if (ieq(key, "K1_SHAPE")) o.k1_shape_team = on && ieq(v, "team");
+    else if (ieq(key, "K1_SHAPE")) { o.k1_shape_team = on && ieq(v, "team"); o.k1_shape_wave = on && ieq(v, "wave"); }
     else if (ieq(key, "K1_F64_TEAM")) o.k1_f64_team256 = on && std::atoi(v) == 256;
     else if (ieq(key, "KG_NOYV")) o.kg_noyv = on;
     else if (ieq(key, "FUSED_FIXUP")) o.fused_fixup = on;

@@ -47,6 +47,7 @@ struct Options {
     bool k1_notiny = false;       // POLS_K1_NOTINY      never take K1t (four groups per wave)
     bool k1_norc1 = false;        // POLS_K1_NORC1       never take the one-chunk-per-lane wave kernel
     bool k1_shape_team = false;   // POLS_K1_SHAPE=team  f32: 256-thread teams instead of wave-per-group
+    bool k1_shape_wave = false;   // POLS_K1_SHAPE=wave  f32: wave-per-group even where the 256-thread team is the default
     bool k1_f64_team256 = false;  // POLS_K1_F64_TEAM=256
     bool kg_noyv = false;         // POLS_KG_NOYV        streamed Gram: keep the target in a second MFMA tile at 16 columns
     bool fused_fixup = false;     // POLS_FUSED_FIXUP    K1 wave kernels carry the fix-up pass as trailing workgroups

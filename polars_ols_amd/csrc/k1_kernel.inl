@@ -1181,8 +1181,9 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     // the f32 wave-per-group FAST kernel (BASELINE configs[1]) reads its columns with `nt` (streaming) loads: every line is used
     // once, so it should not compete for L2 with lines that are -- 73.2-73.3 against 74.3-75.0 us per 400 MB launch
     // (POLS_K1_NT_LOADS=0 selects the plain-load build of the same kernel)
-    // (the f64 two-wave kernel of cfg3 as well: 169-173 against 173-174 us per call)
-    constexpr bool HAS_NT = ((sizeof(T) == 4 && TEAM == 64 && RC == 4 && NPASS == 1) || (sizeof(T) == 8 && TEAM == 128 && RC == 4 && NPASS == 2 && KT <= 8)) &&
+    // (the f64 two-wave kernel of cfg3 as well: 169-173 against 173-174 us per call; the f32 256-thread team from 8 columns: 71.9 vs
+    // 72.4 us at 8 -- but 57.8 vs 50.4 us at 6 columns, where the plain loads win by far)
+    constexpr bool HAS_NT = ((sizeof(T) == 4 && TEAM == 64 && RC == 4 && NPASS == 1) || (sizeof(T) == 4 && TEAM == 256 && RC == 1 && KT >= 8 && KT <= 10) || (sizeof(T) == 8 && TEAM == 128 && RC == 4 && NPASS == 2 && KT <= 8)) &&
                             FAST && !NULLS && !FUSED;
     if constexpr (HAS_NT) {
         if (ctx->opt.k1_nt_loads != 0) { kern = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, true>; std::strcat(name, "_nt"); }
@@ -1246,6 +1247,12 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             if (resident && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
             if (resident && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
         }
+    }
+    if constexpr (sizeof(T) == 4 && TEAM == 256 && RC == 1 && KT >= 6 && KT <= 10) {
+        // f32, one chunk per lane of a 256-thread team: two passes at 6-8 columns, three at 9-10 (POLS_K1_PASSES=1|2|3 overrides)
+        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 9 ? 3 : 2);
+        if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
+        if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
     }
     if constexpr (TEAM == 64 && KT >= 9) {
         // 9-10 columns (8 features + intercept: the smoke() shape): 55-66 accumulators next to the resident rows do not fit the
@@ -1331,6 +1338,13 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // frame's rows beyond them (each is read twice).
         const int64_t wave_cap = 64 * 4 * VEC;
         const int64_t need = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1);
+        // ALIGNED frames whose groups fit one chunk per lane of a 256-thread team (513..1 024 rows): four resident rows per lane instead
+        // of sixteen -- 68-105 registers, 4-7 waves per SIMD -- and, from 6 columns, the multi-pass Gram + row-resident Cholesky.
+        // Interleaved A/B on 10 000 x 1 000 rows (scripts/ab_headline.py, wall clock per call): 2 columns 26.4 vs 29.9 us, 4: 37.7 vs
+        // 43.7, 6: 50.4 vs 58.3 (6.35 TB/s), 7: 62.3 vs 65.6, 8: 71.9 vs 73.2, 9: 78.6 vs 81.1, 10: 85.8 vs 89.0.  POLS_K1_SHAPE=wave
+        // goes back.  Ragged frames keep the wave kernel (below).
+        if (!ctx->opt.k1_shape_wave && ctx->offs_aligned[1] && !ctx->opt.k1_nofast && need <= 256 * 1 * VEC && a.n_k1_blocks == 0)
+            return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
         if (want_wave && (need <= wave_cap || (need <= 2 * wave_cap && ctx->offs_wave_overflow * 16 <= a.n_rows)))
             return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);

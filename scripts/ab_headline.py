@@ -1,0 +1,39 @@
+"""Interleaved A/B of kernel variants on BASELINE configs[1] in ONE process: wall clock per call over back-to-back launches."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polars_ols_amd.engine import Engine  # noqa: E402
+
+eng = Engine(0)
+G, n, k = 10_000, 1000, int(os.environ.get("K", "8"))
+offs = np.arange(0, (G + 1) * n, n, dtype=np.int64)
+g = torch.Generator(device="cuda").manual_seed(0)
+cols = [torch.randn(G * n, device="cuda", generator=g) for _ in range(k)]
+y = sum(cols) + 0.1 * torch.randn(G * n, device="cuda", generator=g)
+plan = eng.plan_least_squares(y, cols, offs, want=("pred", "coef"))
+variants = {"wave_rc4_nt": {}, "team256_rc1_nt": {"K1_SHAPE": "team"}, "team256_rc1_p2_nt": {"K1_SHAPE": "team", "K1_PASSES": "2"},
+            "team256_rc1_p2": {"K1_SHAPE": "team", "K1_PASSES": "2", "K1_NT_LOADS": "0"}, "team256_rc1_p3_nt": {"K1_SHAPE": "team", "K1_PASSES": "3"}}
+res = {v: [] for v in variants}
+names = {}
+for rnd in range(12):
+    for v, opts in variants.items():
+        for key in ("K1_SHAPE", "K1_PASSES", "K1_NT_LOADS"):
+            eng.set_option(key, opts.get(key))
+        for _ in range(5):
+            plan.run()
+        eng.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            plan.run()
+        e1.record()
+        torch.cuda.synchronize()
+        res[v].append(e0.elapsed_time(e1) * 1e3 / 200)
+        names[v] = eng.last_kernel
+for v in variants:
+    a = np.array(res[v][2:])
+    print(f"{v:20s} median {np.median(a):6.2f} us  min {a.min():6.2f}  max {a.max():6.2f}  {names[v]}")

@@ -155,7 +155,8 @@ def test_bench_kernels_keep_two_waves_per_simd():
         _lib.build()
     ks = kernel_scratch(_lib.LIB_PATH)
     want = {
-        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, true>(": 256,       # configs[1], nt loads
+        "pols::k1_kernel<float, 8, false, 256, 1, true, 2, false, false, true>(": 96,       # configs[1]: 256-thread team, two passes, nt loads
+        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, true>(": 256,       # ... and the wave-per-group form (ragged frames)
         "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, false>(": 256,
         "pols::k1_kernel_occ2<float, 8, false, 64, 4, true, 1, true, false>(": 256,         # configs[1] under a null policy
         "pols::k1_kernel<double, 8, true, 128, 4, true, 2, false, false, true>(": 256,      # configs[2]

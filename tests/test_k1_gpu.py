@@ -486,7 +486,7 @@ def test_nine_and_ten_columns_take_the_multi_pass_valu_kernels(eng, dtype, k, ic
     name = eng.last_kernel
     assert name.startswith(f"k1_gram_chol_{'f32' if dtype == np.float32 else 'f64'}_k{k + int(icpt)}_w_team"), name
     if hi > 256:
-        assert name.endswith("_p4") or name.endswith("_p3") or name.endswith("_p2"), name
+        assert any(tag in name for tag in ("_p2", "_p3", "_p4")), name
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
     _check(out, ref, dtype)
     assert int(out["status"].abs().sum()) == 0

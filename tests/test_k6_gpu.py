@@ -149,6 +149,7 @@ def test_fused_fixup_matches_two_launch_form(eng):
     for g in flagged:
         cols[6][g * n:(g + 1) * n] = cols[1][g * n:(g + 1) * n]
     offs = np.arange(G + 1, dtype=np.int64) * n
+    eng.set_option("K1_SHAPE", "wave")                   # the fused form exists for the wave-per-group kernel: same kernel on both sides
     ref = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
     torch.cuda.synchronize()
     eng.set_option("FUSED_FIXUP", "1")
@@ -160,6 +161,7 @@ def test_fused_fixup_matches_two_launch_form(eng):
             assert torch.equal(out["coef"], ref["coef"]) and torch.equal(out["pred"], ref["pred"])
     finally:
         eng.set_option("FUSED_FIXUP", None)
+        eng.set_option("K1_SHAPE", None)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
