@@ -77,7 +77,7 @@ __device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Ch
     }
 }
 
-template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false, bool LOADED = false>
+template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false, bool LOADED = false, bool VEDGE = false>
 __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_t s, int64_t e, Chunk<T, KT, HAS_W> &c) {
     constexpr int VEC = Vec16<T>::N;
     const int ku = a.k_user;
@@ -86,7 +86,7 @@ __device__ __forceinline__ void load_chunk(const K1Args &a, int64_t row0, int64_
     } else if (FAST || (row0 >= s && row0 + VEC <= e)) {
         // whole chunk inside the group: 16-byte loads, all issued before first use
         load_chunk_raw<T, KT, HAS_W>(a, row0, c);
-    } else if (K1_RAGGED_VECTOR_LOADS && sizeof(T) == 4 && e - s <= 512 && row0 + VEC <= a.n_rows) {
+    } else if (K1_RAGGED_VECTOR_LOADS && sizeof(T) == 4 && (VEDGE || e - s <= 512) && row0 + VEC <= a.n_rows) {
         // ragged head / tail of a SHORT f32 group, the 16 bytes of every column still inside the columns: vector loads, then the rows
         // outside [s, e) -- a neighbour's -- zeroed in registers.  Measured per shape (scripts/bench_ragged.py): 12..40 rows 218 ->
         // 203 us, 100..300 rows 111 -> 108 us; but 900..1 020 rows 76 -> 79 us and f64 40..120 rows 828 -> 906 us, hence the limits.
@@ -549,7 +549,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
             if (c < nch) {
-                load_chunk<T, KT, HAS_W, FAST, NULLS>(a, base + c * VEC, s, e, res[rc]);
+                load_chunk<T, KT, HAS_W, FAST, NULLS, false, (TEAM == 256 && RC <= 2)>(a, base + c * VEC, s, e, res[rc]);
                 if (rc == RC - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
                 if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W, NULLS>(acc, res[rc]);
             }
@@ -1248,11 +1248,15 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             if (resident && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
         }
     }
-    if constexpr (sizeof(T) == 4 && TEAM == 256 && RC == 1 && KT >= 6 && KT <= 10) {
+    if constexpr (sizeof(T) == 4 && TEAM == 256 && (RC == 1 || RC == 2) && KT >= 6 && KT <= 10) {
         // f32, one chunk per lane of a 256-thread team: two passes at 6-8 columns, three at 9-10 (POLS_K1_PASSES=1|2|3 overrides)
         const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 9 ? 3 : 2);
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
+        const bool resident = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        const int npass_r = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 8 && RC == 1 ? 3 : 2);   // ragged, 8 columns, one chunk: 69.8 (three) vs 71.4 us (two)
+        if (!fast && resident && npass_r == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
+        if (!fast && resident && npass_r == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
     }
     if constexpr (TEAM == 64 && KT >= 9) {
         // 9-10 columns (8 features + intercept: the smoke() shape): 55-66 accumulators next to the resident rows do not fit the
@@ -1338,14 +1342,18 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // frame's rows beyond them (each is read twice).
         const int64_t wave_cap = 64 * 4 * VEC;
         const int64_t need = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1);
-        // ALIGNED frames whose groups fit one chunk per lane of a 256-thread team (513..1 024 rows): four resident rows per lane instead
+        // Frames whose groups fit one chunk per lane of a 256-thread team (513..1 024 rows, aligned or ragged): four resident rows per lane instead
         // of sixteen -- 68-105 registers, 4-7 waves per SIMD -- and, from 6 columns, the multi-pass Gram + row-resident Cholesky.
         // Interleaved A/B on 10 000 x 1 000 rows (scripts/ab_headline.py, wall clock per call): 2 columns 26.4 vs 29.9 us, 4: 37.7 vs
         // 43.7, 6: 50.4 vs 58.3 (6.35 TB/s), 7: 62.3 vs 65.6, 8: 71.9 vs 73.2, 9: 78.6 vs 81.1, 10: 85.8 vs 89.0.  POLS_K1_SHAPE=wave
-        // goes back.  Ragged frames keep the wave kernel (below).
-        if (!ctx->opt.k1_shape_wave && ctx->offs_aligned[1] && !ctx->opt.k1_nofast && need <= 256 * 1 * VEC && a.n_k1_blocks == 0)
+        // goes back.  Ragged frames too (their edge chunks take 16-byte loads + rows zeroed in registers): 900..1 020 rows 78.2 -> 71.8 us.
+        if (!ctx->opt.k1_shape_wave && need <= 256 * 1 * VEC && a.n_k1_blocks == 0)
             return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
-        if (want_wave && (need <= wave_cap || (need <= 2 * wave_cap && ctx->offs_wave_overflow * 16 <= a.n_rows)))
+        // (the wave kernel with 16 rows per lane -- and its streamed overflow for frames a little beyond 1 024 rows -- is what
+        // POLS_K1_SHAPE=wave and the fused fix-up still use; by default the two-chunk team takes 1 025..2 048 rows: 950..1 100 rows
+        // 88.2 -> 85.6 us)
+        const bool wave_default = ctx->opt.k1_shape_wave || a.n_k1_blocks > 0;
+        if (want_wave && wave_default && (need <= wave_cap || (need <= 2 * wave_cap && ctx->offs_wave_overflow * 16 <= a.n_rows)))
             return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);

@@ -11,11 +11,15 @@ from polars_ols_amd.engine import Engine  # noqa: E402
 eng = Engine(0)
 G, n, k = 10_000, 1000, int(os.environ.get("K", "8"))
 offs = np.arange(0, (G + 1) * n, n, dtype=np.int64)
+if os.environ.get("RAGGED"):                                  # RAGGED=lo,hi: unequal, unaligned groups
+    lo, hi = (int(v) for v in os.environ["RAGGED"].split(","))
+    offs = np.concatenate([[0], np.cumsum(np.random.default_rng(0).integers(lo, hi + 1, size=G))]).astype(np.int64)
+N = int(offs[-1])
 g = torch.Generator(device="cuda").manual_seed(0)
-cols = [torch.randn(G * n, device="cuda", generator=g) for _ in range(k)]
-y = sum(cols) + 0.1 * torch.randn(G * n, device="cuda", generator=g)
+cols = [torch.randn(N, device="cuda", generator=g) for _ in range(k)]
+y = sum(cols) + 0.1 * torch.randn(N, device="cuda", generator=g)
 plan = eng.plan_least_squares(y, cols, offs, want=("pred", "coef"))
-variants = {"wave_rc4_nt": {}, "team256_rc1_nt": {"K1_SHAPE": "team"}, "team256_rc1_p2_nt": {"K1_SHAPE": "team", "K1_PASSES": "2"},
+variants = {"wave_rc4_nt": {"K1_SHAPE": "wave"}, "default": {}, "team256_rc1_nt": {"K1_SHAPE": "team"}, "team256_rc1_p2_nt": {"K1_SHAPE": "team", "K1_PASSES": "2"},
             "team256_rc1_p2": {"K1_SHAPE": "team", "K1_PASSES": "2", "K1_NT_LOADS": "0"}, "team256_rc1_p3_nt": {"K1_SHAPE": "team", "K1_PASSES": "3"}}
 res = {v: [] for v in variants}
 names = {}

@@ -88,12 +88,13 @@ def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, varian
                             want=("coef", "pred", "resid", "status"))
     ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=True)
     _check(out, ref, dtype)
-    if 120 < hi <= 1000:                                 # up to 1 024 rows, aligned or not: one wave per group (f32), two (f64, 6+ columns)
-        variant = "team64" if (dtype == np.float32 or hi <= 256) else "team128"
+    if 120 < hi <= 1000:                                 # up to 1 024 rows, aligned or not: f32 one wave per group up to 512 rows, the
+        # 256-thread team with one chunk per lane beyond; f64 (6+ columns) two waves per group
+        variant = ("team64" if hi <= 512 else "team256_rc1") if dtype == np.float32 else ("team64" if hi <= 256 else "team128")
     if hi == 120:                                        # up to 128 rows: four groups per wave (f64, 6+ columns: four chunks per lane)
         variant = "sub16_rc2" if dtype == np.float32 else "sub16_rc4"
-    if hi == 1150 and dtype == np.float32:               # a few rows beyond the wave's 1 024 resident ones: streamed by the same wave
-        variant = "team64_rc4"
+    if hi == 1150 and dtype == np.float32:               # beyond one chunk per lane: two chunks per lane of the 256-thread team
+        variant = "team256_rc2"
     big_f64 = hi > 4000 and dtype == np.float64        # neither registers nor the LDS tile hold 5000 f64 rows: streamed path
     ok = eng.last_kernel.startswith("k5_gram_stream") if big_f64 else ((variant in eng.last_kernel) if engine_kind == "valu" else eng.last_kernel.startswith("k1m_"))
     assert ok, eng.last_kernel
