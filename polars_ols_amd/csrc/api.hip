@@ -173,6 +173,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
     else if (ieq(key, "K1_PERSIST")) o.k1_persist = on ? (std::atoi(v) != 0) : d.k1_persist;
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
+    else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
     else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : 0;
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
@@ -184,7 +185,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "FUSED_FIXUP", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
-                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB"};
+                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);

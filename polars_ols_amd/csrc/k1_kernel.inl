@@ -231,6 +231,51 @@ __device__ __forceinline__ void gram_accumulate_range(T (&acc)[Q1 - Q0], const C
     }
 }
 
+// ---- team reductions shared by K1t and K1p
+__device__ __forceinline__ void k1p_swap_rows(float &a, float &b) {      // a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void k1p_swap_rows(double &a, double &b) {
+    const unsigned long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
+    b = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+
+// Every lane ends up with the totals of its own team (SUB lanes) in acc[].
+template <typename T, int NACC, int SUB>
+__device__ __forceinline__ void k1p_team_allreduce(T (&acc)[NACC]) {
+    if constexpr (SUB == 64) {
+        // reduce-scatter over the wave, then v_readlane: row r holds the totals of the entries 4i + rs_perm(r)
+        constexpr int NACC4 = (NACC + 3) / 4;
+        T u[NACC4];
+        wave_reduce_scatter<T, NACC>(acc, u);
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+            const int pq = q & 3;
+            acc[q] = k1p_readlane(u[q >> 2], 16 * (pq == 1 ? 2 : (pq == 2 ? 1 : pq)));
+        }
+    } else if constexpr (SUB == 32) {
+        // a team is two 16-lane rows: pair_rows leaves entry 2i in the team's even row and 2i + 1 in its odd row (half the values to
+        // all-reduce inside the rows), one row swap of the result with itself hands both back to both rows
+#pragma unroll
+        for (int i = 0; i < (NACC + 1) / 2; ++i) {
+            T w = acc[2 * i];
+            pair_rows(w, 2 * i + 1 < NACC ? acc[2 * i + 1] : T(0));
+            w = row_allreduce(w);
+            T w2 = w;
+            k1p_swap_rows(w, w2);
+            acc[2 * i] = w;
+            if (2 * i + 1 < NACC) acc[2 * i + 1] = w2;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc[q] = row_allreduce(acc[q]);
+    }
+}
+
 // one pass of the multi-pass Gram: accumulate the entries [Q0, Q1) over the resident chunks, reduce-scatter inside the wave,
 // park the wave partials in LDS at their packed slots (Q0 is a multiple of 4, so slot numbering is unchanged)
 template <typename T, int KT, bool HAS_W, int RC, int TEAM, int Q0, int Q1, bool NULLS = false>
@@ -713,7 +758,7 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
     const int64_t s = live ? a.offs[g] : 0, e = live ? a.offs[g + 1] : 0;
     const int64_t base = s - (s % VEC);                      // chunk grid aligned to 16 bytes in every column
     const int64_t nch = (e - base + VEC - 1) / VEC;          // <= K1T_SUB * K1T_RC: the host checked the largest group
-    constexpr bool TWO_PASS = (sizeof(T) == 8 || K1T_F32_TWO_PASS) && KT >= 6 && K1T_SUB == 16;
+    constexpr bool TWO_PASS = (sizeof(T) == 8 || K1T_F32_TWO_PASS) && KT >= 6 && (K1T_SUB == 16 || K1T_SUB == 32);
     T acc[TWO_PASS ? 1 : NACC];
     Chunk<T, KT, HAS_W> res[K1T_RC];
     T beta[KT];
@@ -738,8 +783,14 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
 #pragma unroll
             for (int rc = 0; rc < K1T_RC; ++rc)
                 if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, 0, Q1>(p1, res[rc]);
+            if constexpr (K1T_SUB == 32) {                       // a team is two 16-lane rows: the pairing reduction of K1p
+                k1p_team_allreduce<T, Q1, 32>(p1);
 #pragma unroll
-            for (int q = 0; q < Q1; ++q) { const T t = row_allreduce(p1[q]); if ((q % K1T_SUB) == sub) gs[team][q] = t; }
+                for (int q = 0; q < Q1; ++q) if ((q % K1T_SUB) == sub) gs[team][q] = p1[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q1; ++q) { const T t = row_allreduce(p1[q]); if ((q % K1T_SUB) == sub) gs[team][q] = t; }
+            }
         }
         {
             T p2[NACC - Q1];
@@ -748,15 +799,23 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
 #pragma unroll
             for (int rc = 0; rc < K1T_RC; ++rc)
                 if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, Q1, NACC>(p2, res[rc]);
+            if constexpr (K1T_SUB == 32) {
+                k1p_team_allreduce<T, NACC - Q1, 32>(p2);
 #pragma unroll
-            for (int q = 0; q < NACC - Q1; ++q) { const T t = row_allreduce(p2[q]); if (((q + Q1) % K1T_SUB) == sub) gs[team][q + Q1] = t; }
+                for (int q = 0; q < NACC - Q1; ++q) if (((q + Q1) % K1T_SUB) == sub) gs[team][q + Q1] = p2[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NACC - Q1; ++q) { const T t = row_allreduce(p2[q]); if (((q + Q1) % K1T_SUB) == sub) gs[team][q + Q1] = t; }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T bv = T(0);
         if (e == s) st = POLS_GROUP_EMPTY;
         else {
             bool ok;
-            if constexpr (K1_SOLVE_ROWS) bv = chol_solve_rows<T, KT, K1T_SUB>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], sub, ok);
+            // (32-lane teams: the factor lives in the team's FIRST 16-lane row -- KT <= 16 -- whose lanes broadcast among themselves;
+            // the second row runs along on copies of the last matrix row and its results are never read)
+            if constexpr (K1_SOLVE_ROWS || K1T_SUB == 32) bv = chol_solve_rows<T, KT, 16>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], sub, ok);
             else bv = chol_solve_lds<T, KT, K1T_SUB>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], lr[team], sub, ok);
             if (!ok) st = POLS_GROUP_FALLBACK;
         }
@@ -872,50 +931,6 @@ __device__ __forceinline__ void k1p_issue_offsets(const K1Args &a, int64_t g, lo
     const int64_t gi = g < a.n_groups ? g : a.n_groups - 1;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.offs + gi),
                                      (__attribute__((address_space(3))) void *)slot, 16, 0, 0);
-}
-
-__device__ __forceinline__ void k1p_swap_rows(float &a, float &b) {      // a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void k1p_swap_rows(double &a, double &b) {
-    const unsigned long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
-    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
-    a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
-    b = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
-}
-
-// Every lane ends up with the totals of its own team (SUB lanes) in acc[].
-template <typename T, int NACC, int SUB>
-__device__ __forceinline__ void k1p_team_allreduce(T (&acc)[NACC]) {
-    if constexpr (SUB == 64) {
-        // reduce-scatter over the wave, then v_readlane: row r holds the totals of the entries 4i + rs_perm(r)
-        constexpr int NACC4 = (NACC + 3) / 4;
-        T u[NACC4];
-        wave_reduce_scatter<T, NACC>(acc, u);
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) {
-            const int pq = q & 3;
-            acc[q] = k1p_readlane(u[q >> 2], 16 * (pq == 1 ? 2 : (pq == 2 ? 1 : pq)));
-        }
-    } else if constexpr (SUB == 32) {
-        // a team is two 16-lane rows: pair_rows leaves entry 2i in the team's even row and 2i + 1 in its odd row (half the values to
-        // all-reduce inside the rows), one row swap of the result with itself hands both back to both rows
-#pragma unroll
-        for (int i = 0; i < (NACC + 1) / 2; ++i) {
-            T w = acc[2 * i];
-            pair_rows(w, 2 * i + 1 < NACC ? acc[2 * i + 1] : T(0));
-            w = row_allreduce(w);
-            T w2 = w;
-            k1p_swap_rows(w, w2);
-            acc[2 * i] = w;
-            if (2 * i + 1 < NACC) acc[2 * i + 1] = w2;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) acc[q] = row_allreduce(acc[q]);
-    }
 }
 
 // what a group leaves behind for the NEXT iteration to store
@@ -1289,7 +1304,10 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         const int64_t need = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1);
         const bool many = a.n_groups >= (int64_t)ctx->num_cus * 16 * 4;
         const int ps = ctx->opt.k1_persist_sub;              // POLS_K1_PERSIST_SUB=64|32|16: A/B the team width
-        if (ctx->opt.k1_persist != 0 && a.n_rows >= VEC && a.n_groups > 0 && (many || ctx->opt.k1_persist > 0)) {
+        // (since the one-shot K1t got the two-pass Gram + row-share Cholesky its 32-lane form does these frames as fast -- 797 vs 814 us
+        // on 500 000 groups of 130..252 rows -- without a staging area or a minimum number of groups: K1p runs on request only)
+        (void)many;
+        if (ctx->opt.k1_persist > 0 && a.n_rows >= VEC && a.n_groups > 0) {
             // 500 000 groups of 40..120 rows: 383 us (16 lanes per group) against 495 us for K1t; 130..252 rows: 815 us (32 lanes)
             // against 850 us for the one-shot wave.  Up to 64 rows K1t's four groups per wave win (210 vs 320 us on 12..40 rows),
             // beyond 256 rows the staging area limits a CU to eight waves and the one-shot wave kernel wins (110 vs 125 us).
@@ -1315,6 +1333,17 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (need <= 16 * 4 * VEC) {
             const bool want = ctx->opt.k1t_rc4 >= 0 ? ctx->opt.k1t_rc4 != 0 : (sizeof(T) == 8 && KT >= 6);
             if (want) return k1t_launch<T, KT, HAS_W, 16, 4>(ctx, a);
+        }
+        if constexpr (sizeof(T) == 4 && KT >= 6 && KT <= 8) {
+            // (9-10 columns: one wave per group with the three-pass Gram is faster -- 76.7 vs 89.4 us on 50 000 x 200 x (8 + 1))
+            // two groups per wave (32-lane teams, two chunks per lane: up to 256 rows) with the two-pass Gram and the row-share
+            // Cholesky: ~115 registers where the single-pass form needed 181 (and lost to one wave per group)
+            // RAGGED frames only: aligned ones keep the FAST wave kernels (50 000 x 200 x 8: 70.7 vs 73.3 us; x 6: 49.3 vs 54.4), whose
+            // ragged form is what loses (500 000 groups of 130..252 rows: 907 us one wave per group, 814 us K1p, 771 us here)
+            const bool ragged = !ctx->offs_aligned[1] || ctx->opt.k1_nofast;
+            if (ragged && need <= 32 * 2 * VEC && ctx->opt.k1t_sub32 != 0) return k1t_launch<T, KT, HAS_W, 32, 2>(ctx, a);
+            // (three chunks per lane -- up to 384 rows -- measured no better than one wave per group: 109.7 vs 107.9 us on 50 000 groups
+            // of 100..300 rows)
         }
         // (SUB = 8, eight groups per wave with two chunks per lane, measured no faster on 500 000 groups of 12..40 rows: 218 vs 214 us --
         // these frames are bound by lane utilisation in the memory pipe: a 26-row group fills 6.5 of its team's 16 chunk slots, and
