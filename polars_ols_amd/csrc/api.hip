@@ -161,6 +161,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     if (ieq(key, "TIMELINE")) o.timeline = on;
     else if (ieq(key, "K1_NOOCC4")) o.k1_noocc4 = on;
     else if (ieq(key, "K1_NOFAST")) o.k1_nofast = on;
+    else if (ieq(key, "K1_NOEDGE")) o.k1_noedge = on;
     else if (ieq(key, "K1_NOTINY")) o.k1_notiny = on;
     else if (ieq(key, "K1_NORC1")) o.k1_norc1 = on;
     else if (ieq(key, "K1_SHAPE")) { o.k1_shape_team = on && ieq(v, "team"); o.k1_shape_wave = on && ieq(v, "wave"); }
@@ -185,7 +186,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "FUSED_FIXUP", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
-                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32"};
+                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);

@@ -59,6 +59,7 @@ struct Options {
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
     int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1
     bool k2_noprefetch = false;   // POLS_K2_NOPREFETCH  eight-wave K2: one workgroup per group, no next-group prefetch into LDS
+    bool k1_noedge = false;       // POLS_K1_NOEDGE      ragged resident frames: the general chunk-by-chunk code instead of the branch-free EDGE kernels
     int k1t_sub32 = -1;           // POLS_K1T_SUB32      -1: default (on), 0: never two groups per wave in the one-shot kernel
     int k1_persist_sub = 0;       // POLS_K1_PERSIST_SUB 0: default rule, 64 / 32 / 16 lanes per group
     int k1_persist = -1;          // POLS_K1_PERSIST     -1: default rule (enough groups), 0 never, 1 whenever the groups fit K1p

@@ -530,8 +530,14 @@ __device__ __forceinline__ void k1_fixup_worker(const K1Args &a) {
     k6_process<T>(a.fix, worker, n_workers);
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false>
+// EDGE (with FAST): the branch-free form for RAGGED frames whose groups stay resident -- every load of every chunk issued up front
+// like FAST (unconditional, clamped into the columns), then the rows outside [s, e) -- the head / tail chunks' neighbours' rows --
+// zeroed in registers; stores of edge chunks guarded per row.  The general (FAST = false) code loads chunk by chunk inside per-lane
+// branches: with the same group sizes it runs 797 vs 679 us (130..252 rows) and 118 vs 91 us (100..300 rows) behind FAST.
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false,
+          bool EDGE = false>
 __device__ __forceinline__ void k1_body(const K1Args &a) {
+    static_assert(!EDGE || (FAST && !FUSED), "EDGE refines FAST");
     static_assert(!FUSED || TEAM == 64, "the fused fix-up counts solver WAVES");
     if constexpr (FUSED) {
         if ((int)blockIdx.x >= a.n_k1_blocks) { k1_fixup_worker<T>(a); return; }
@@ -577,7 +583,9 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 #pragma unroll
             for (int rc = 0; rc < RC; ++rc) {
                 const int64_t c = (int64_t)rc * TEAM + tid;
-                load_chunk_raw<T, KT, HAS_W, NT>(a, base + (c < nch ? c : 0) * VEC, res[rc]);
+                int64_t r0 = base + (c < nch ? c : 0) * VEC;
+                if constexpr (EDGE) r0 = r0 > a.n_rows - VEC ? a.n_rows - VEC : r0;   // (the one chunk that crosses the end: re-read below)
+                load_chunk_raw<T, KT, HAS_W, NT>(a, r0, res[rc]);
             }
         }
         if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); K1_STAMP(1); }
@@ -585,7 +593,24 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
             if (c < nch) {
-                load_chunk<T, KT, HAS_W, FAST, NULLS, true>(a, base + c * VEC, s, e, res[rc]);
+                if constexpr (EDGE) {
+                    const int64_t row0 = base + c * VEC;
+                    if (row0 + VEC > a.n_rows) {                     // at most one lane per launch
+                        load_chunk<T, KT, HAS_W, false, NULLS>(a, row0, s, e, res[rc]);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const bool in = (row0 + v >= s) && (row0 + v < e);
+#pragma unroll
+                            for (int j = 0; j < KT; ++j) vset<T>(res[rc].x[j], v, in ? vget<T>(res[rc].x[j], v) : T(0));
+                            vset<T>(res[rc].y, v, in ? vget<T>(res[rc].y, v) : T(0));
+                            if constexpr (HAS_W) vset<T>(res[rc].sw, v, in ? vget<T>(res[rc].sw, v) : T(1));
+                        }
+                        load_chunk<T, KT, HAS_W, true, NULLS, true>(a, row0, s, e, res[rc]);
+                    }
+                } else {
+                    load_chunk<T, KT, HAS_W, FAST, NULLS, true>(a, base + c * VEC, s, e, res[rc]);
+                }
                 if constexpr (NPASS == 1) gram_accumulate<T, KT, HAS_W, NULLS>(acc, res[rc]);
             }
         }
@@ -708,7 +733,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 #pragma unroll
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
-            if (c < nch) predict_store<T, KT, HAS_W, FAST, NULLS>(a, res[rc], beta, base + c * VEC, s, e);
+            if (c < nch) predict_store<T, KT, HAS_W, (FAST && !EDGE), NULLS>(a, res[rc], beta, base + c * VEC, s, e);
         }
         if constexpr (!FAST && NPASS == 1) {
             for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
@@ -723,9 +748,10 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 #undef K1_STAMP
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false,
+          bool EDGE = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, NT>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, NT, EDGE>(a);
 }
 // The same body held to 128 VGPRs (four waves per SIMD): the ragged one-chunk-per-lane wave kernel needs 130.
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
@@ -738,6 +764,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k1_kernel_occ2(const K1Args a) {
     k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
+}
+
+// One chunk of a small ragged group, branch-free: the 16-byte loads of every column issued unconditionally (lanes without a chunk
+// re-read the group's first chunk; positions clamped into the columns), then the rows outside [s, e) zeroed in registers.  In
+// these kernels nearly every chunk is a head or a tail, so the guarded per-row path was what every wave executed.
+template <typename T, int KT, bool HAS_W>
+__device__ __forceinline__ void load_chunk_edge(const K1Args &a, int64_t row0, int64_t base, bool has, int64_t s, int64_t e,
+                                                Chunk<T, KT, HAS_W> &c) {
+    constexpr int VEC = Vec16<T>::N;
+    int64_t r0 = has ? row0 : base;
+    r0 = r0 > a.n_rows - VEC ? a.n_rows - VEC : r0;
+    load_chunk_raw<T, KT, HAS_W>(a, r0, c);
+    if (has && row0 + VEC > a.n_rows) {                      // the chunk that crosses the end of the columns: at most one lane per launch
+        load_chunk<T, KT, HAS_W, false>(a, row0, s, e, c);
+        return;
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const bool in = has && (row0 + v >= s) && (row0 + v < e);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) vset<T>(c.x[j], v, in ? vget<T>(c.x[j], v) : T(0));
+        vset<T>(c.y, v, in ? vget<T>(c.y, v) : T(0));
+        if constexpr (HAS_W) vset<T>(c.sw, v, in ? vget<T>(c.sw, v) : T(1));
+    }
+    if constexpr (HAS_W) load_chunk<T, KT, HAS_W, true, false, true>(a, row0, s, e, c);   // the sqrt(w) scaling only
 }
 
 #ifndef K1_NULLS_TU
@@ -774,7 +825,7 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
 #pragma unroll
         for (int rc = 0; rc < K1T_RC; ++rc) {
             const int64_t c = (int64_t)rc * K1T_SUB + sub;
-            if (c < nch) load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, res[rc]);
+            load_chunk_edge<T, KT, HAS_W>(a, base + c * VEC, base, c < nch, s, e, res[rc]);
         }
         {
             T p1[Q1];
@@ -829,10 +880,8 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
 #pragma unroll
     for (int rc = 0; rc < K1T_RC; ++rc) {
         const int64_t c = (int64_t)rc * K1T_SUB + sub;
-        if (c < nch) {
-            load_chunk<T, KT, HAS_W, false>(a, base + c * VEC, s, e, res[rc]);
-            gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
-        }
+        load_chunk_edge<T, KT, HAS_W>(a, base + c * VEC, base, c < nch, s, e, res[rc]);
+        if (c < nch) gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
     }
 #pragma unroll
     for (int q = 0; q < NACC; ++q) {
@@ -1208,6 +1257,17 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     }
     if constexpr (NULLS && sizeof(T) == 4 && TEAM == 64 && RC == 4 && KT <= 8 && !HAS_W && !FUSED)
         kern = k1_kernel_occ2<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
+    if constexpr (!FAST && !FUSED) {
+        // ragged frames whose groups all stay resident: the branch-free EDGE form of the FAST kernel instead of the general code
+        // (POLS_K1_NOEDGE=1 goes back)
+        constexpr int VEC = Vec16<T>::N;
+        const bool resident = ctx->offs_max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        if (resident && a.n_rows >= VEC && !ctx->opt.k1_noedge && !ctx->opt.timeline) {
+            kern = k1_kernel<T, KT, HAS_W, TEAM, RC, true, NPASS, NULLS, false, false, true>;
+            std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d_edge%s%s", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", TEAM, RC,
+                          passes, NULLS ? "_nulls" : "");
+        }
+    }
     ctx->last_kernel = name;
     if (timing_pair(ctx, &ev0, &ev1))
         hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block_threads), 0, ctx->stream, ev0, ev1, 0, aa);
@@ -1324,7 +1384,7 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     }
 #endif
 #ifndef K1_NULLS_TU
-    if (!ctx->opt.k1_notiny && !ctx->opt.timeline) {
+    if (!ctx->opt.k1_notiny && !ctx->opt.timeline && a.n_rows >= VEC) {
         const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
         if (need <= 16 * 1 * VEC) return k1t_launch<T, KT, HAS_W, 16, 1>(ctx, a);      // one chunk per lane: a third fewer registers
         if (need <= 16 * 2 * VEC) return k1t_launch<T, KT, HAS_W, 16, 2>(ctx, a);
@@ -1341,7 +1401,8 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             // RAGGED frames only: aligned ones keep the FAST wave kernels (50 000 x 200 x 8: 70.7 vs 73.3 us; x 6: 49.3 vs 54.4), whose
             // ragged form is what loses (500 000 groups of 130..252 rows: 907 us one wave per group, 814 us K1p, 771 us here)
             const bool ragged = !ctx->offs_aligned[1] || ctx->opt.k1_nofast;
-            if (ragged && need <= 32 * 2 * VEC && ctx->opt.k1t_sub32 != 0) return k1t_launch<T, KT, HAS_W, 32, 2>(ctx, a);
+            // ... and since the wave kernels' ragged form became branch-free (EDGE) they win again: 737 us.  On request only.
+            if (ragged && need <= 32 * 2 * VEC && ctx->opt.k1t_sub32 > 0) return k1t_launch<T, KT, HAS_W, 32, 2>(ctx, a);
             // (three chunks per lane -- up to 384 rows -- measured no better than one wave per group: 109.7 vs 107.9 us on 50 000 groups
             // of 100..300 rows)
         }

@@ -90,7 +90,7 @@ def test_ragged_groups_unaligned_offsets(eng, engine_kind, dtype, lo, hi, varian
     _check(out, ref, dtype)
     if 120 < hi <= 1000:                                 # up to 1 024 rows, aligned or not: f32 one wave per group up to 512 rows, the
         # 256-thread team with one chunk per lane beyond; f64 (6+ columns) two waves per group
-        variant = ("sub32_rc2" if hi <= 256 else ("team64" if hi <= 512 else "team256_rc1")) if dtype == np.float32 else ("team64" if hi <= 256 else "team128")
+        variant = ("team64" if hi <= 512 else "team256_rc1") if dtype == np.float32 else ("team64" if hi <= 256 else "team128")
     if hi == 120:                                        # up to 128 rows: four groups per wave (f64, 6+ columns: four chunks per lane)
         variant = "sub16_rc2" if dtype == np.float32 else "sub16_rc4"
     if hi == 1150 and dtype == np.float32:               # beyond one chunk per lane: two chunks per lane of the 256-thread team
