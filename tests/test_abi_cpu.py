@@ -136,7 +136,7 @@ def test_hot_kernels_keep_their_arrays_in_registers():
     hot = ("pols::k1_kernel<", "pols::k1t_kernel<", "pols::k1p_kernel<", "pols::k1m_kernel<", "pols::k2_kernel<", "pols::gram_stream_kernel<",
            "pols::predict_kernel<", "pols::gram_solve_kernel<", "pols::take_kernel<", "pols::arrow_ingest_kernel<")
     bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0
-           and not k.rstrip().endswith("true, false>(pols::K1Args)")}          # FUSED = true, NT = false: the fused fix-up builds
+           and not k.rstrip().endswith("true, false, false>(pols::K1Args)")}   # FUSED = true, NT = false, EDGE = false: the fused fix-up builds
     assert not bad, sorted(bad.items())[:5]
 
 
@@ -155,12 +155,13 @@ def test_bench_kernels_keep_two_waves_per_simd():
         _lib.build()
     ks = kernel_scratch(_lib.LIB_PATH)
     want = {
-        "pols::k1_kernel<float, 8, false, 256, 1, true, 2, false, false, true>(": 96,       # configs[1]: 256-thread team, two passes, nt loads
-        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, true>(": 256,       # ... and the wave-per-group form (ragged frames)
-        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, false>(": 256,
+        "pols::k1_kernel<float, 8, false, 256, 1, true, 2, false, false, true, false>(": 96,       # configs[1]: 256-thread team, two passes, nt loads
+        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, true, false>(": 256,       # ... and the wave-per-group form (ragged frames)
+        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, false, false>(": 256,
         "pols::k1_kernel_occ2<float, 8, false, 64, 4, true, 1, true, false>(": 256,         # configs[1] under a null policy
-        "pols::k1_kernel<double, 8, true, 128, 4, true, 2, false, false, true>(": 256,      # configs[2]
-        "pols::k1_kernel<float, 9, false, 64, 4, true, 3, false, false, false>(": 256,      # smoke(): 8 features + intercept
+        "pols::k1_kernel<double, 8, true, 128, 4, true, 2, false, false, true, false>(": 256,      # configs[2]
+        "pols::k1_kernel<float, 9, false, 64, 4, true, 3, false, false, false, false>(": 256,
+        "pols::k1_kernel<float, 8, false, 64, 1, true, 1, false, false, false, true>(": 128,    # ragged year-sized groups: the EDGE wave kernel      # smoke(): 8 features + intercept
         "pols::k2_kernel<double, 16, 8, 2, true, false>(": 256,                             # configs[4]
     }
     for key, cap in want.items():
