@@ -1333,6 +1333,15 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (!fast && resident && npass_r == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
         if (!fast && resident && npass_r == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
     }
+    if constexpr (sizeof(T) == 4 && TEAM == 64 && (RC == 1 || RC == 2) && KT >= 7 && KT <= 8) {
+        // f32 wave kernel with 4-8 resident rows per lane, 7-8 columns: the two-pass Gram + row-resident Cholesky with two chunks per
+        // lane (100..300 rows: 108.9 -> 104.4 us ragged, 93.0 -> 90.0 aligned) and for ragged one-chunk frames (130..252 rows: 748 ->
+        // 732 us); aligned one-chunk frames keep the single pass (686 vs 694 us).  POLS_K1_PASSES=1|2 overrides.
+        const bool resident = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : ((RC == 2 || !fast) ? 2 : 1);
+        if (resident && npass == 2)
+            return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
+    }
     if constexpr (TEAM == 64 && KT >= 9) {
         // 9-10 columns (8 features + intercept: the smoke() shape): 55-66 accumulators next to the resident rows do not fit the
         // register file; the multi-pass Gram (a third of them live at a time, totals in LDS, row-cooperative Cholesky there)
