@@ -1532,8 +1532,19 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
 }  // extern "C"
 
 namespace pols {
-template <typename T> int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
-template <typename T> int k1n_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);   // null-policy family (k1n_*.hip)
+// the register-resident kernels, a few column counts per translation unit (k1_f32_a.hip ... k1n_f64_b.hip)
+#define K1P_DECL(name) int name(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
+K1P_DECL(k1_launch_f32_a) K1P_DECL(k1_launch_f32_b) K1P_DECL(k1_launch_f32_c) K1P_DECL(k1_launch_f64_a) K1P_DECL(k1_launch_f64_b)
+K1P_DECL(k1n_launch_f32_a) K1P_DECL(k1n_launch_f32_b) K1P_DECL(k1n_launch_f64_a) K1P_DECL(k1n_launch_f64_b)   // null-policy family
+#undef K1P_DECL
+template <typename T> static int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
+    if constexpr (sizeof(T) == 4) return kt <= 6 ? k1_launch_f32_a(ctx, kt, a, max_rows) : (kt <= 8 ? k1_launch_f32_b(ctx, kt, a, max_rows) : k1_launch_f32_c(ctx, kt, a, max_rows));
+    else return kt <= 7 ? k1_launch_f64_a(ctx, kt, a, max_rows) : k1_launch_f64_b(ctx, kt, a, max_rows);
+}
+template <typename T> static int k1n_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
+    if constexpr (sizeof(T) == 4) return kt <= 7 ? k1n_launch_f32_a(ctx, kt, a, max_rows) : k1n_launch_f32_b(ctx, kt, a, max_rows);
+    else return kt <= 7 ? k1n_launch_f64_a(ctx, kt, a, max_rows) : k1n_launch_f64_b(ctx, kt, a, max_rows);
+}
 template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
 // 16..31 columns, resident multi-pass: four column counts per translation unit (k1w_f32_a.hip ... k1w_f64_d.hip)
 #define K1W_DECL(name) int name(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);

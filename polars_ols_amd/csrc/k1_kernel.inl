@@ -1,4 +1,4 @@
-// k1_kernel.inl -- body of K1 (see k1_gram_chol.hpp for the design notes).  Included by k1_f32.hip / k1_f64.hip.
+// k1_kernel.inl -- body of K1 (see k1_gram_chol.hpp for the design notes).  Included by k1_{f32,f64}_*.hip and k1n_{f32,f64}_*.hip, a few column counts per unit.
 #include "k1_gram_chol.hpp"
 #include "k6_body.inl"
 
@@ -1531,35 +1531,59 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 }
 #endif
 
-#ifndef K1_WIDE_TU
-#ifdef K1_NULLS_TU
-#define K1_LAUNCH_NAME k1n_launch_t
-#else
-#define K1_LAUNCH_NAME k1_launch_t
-#endif
-template <typename T>
-int K1_LAUNCH_NAME(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
+// One translation unit instantiates the column counts [K1_PART_LO, K1_PART_HI] of one dtype (K1_PART_T) under the entry name
+// K1_PART_FN -- the fully unrolled kernels of all 15 column counts in one unit took 5.5 minutes to compile; api.hip picks the unit.
+#ifdef K1_PART_FN
+int K1_PART_FN(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
     switch (kt) {
-        case 1: return k1_launch_kt<T, 1>(ctx, a, max_rows);
-        case 2: return k1_launch_kt<T, 2>(ctx, a, max_rows);
-        case 3: return k1_launch_kt<T, 3>(ctx, a, max_rows);
-        case 4: return k1_launch_kt<T, 4>(ctx, a, max_rows);
-        case 5: return k1_launch_kt<T, 5>(ctx, a, max_rows);
-        case 6: return k1_launch_kt<T, 6>(ctx, a, max_rows);
-        case 7: return k1_launch_kt<T, 7>(ctx, a, max_rows);
-        case 8: return k1_launch_kt<T, 8>(ctx, a, max_rows);
-        case 9: return k1_launch_kt<T, 9>(ctx, a, max_rows);
-        case 10: return k1_launch_kt<T, 10>(ctx, a, max_rows);
-#ifndef K1_NULLS_TU
-        case 11: return k1_launch_wide_kt<T, 11>(ctx, a, max_rows);
-        case 12: return k1_launch_wide_kt<T, 12>(ctx, a, max_rows);
-        case 13: return k1_launch_wide_kt<T, 13>(ctx, a, max_rows);
-        case 14: return k1_launch_wide_kt<T, 14>(ctx, a, max_rows);
-        case 15: return k1_launch_wide_kt<T, 15>(ctx, a, max_rows);
+#if K1_PART_LO <= 1 && 1 <= K1_PART_HI
+        case 1: return k1_launch_kt<K1_PART_T, 1>(ctx, a, max_rows);
 #endif
-        default: return fail(POLS_ERR_UNSUPPORTED, "k1: %d features (incl. intercept) > %d", kt, K1W_MAX_KT);
+#if K1_PART_LO <= 2 && 2 <= K1_PART_HI
+        case 2: return k1_launch_kt<K1_PART_T, 2>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 3 && 3 <= K1_PART_HI
+        case 3: return k1_launch_kt<K1_PART_T, 3>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 4 && 4 <= K1_PART_HI
+        case 4: return k1_launch_kt<K1_PART_T, 4>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 5 && 5 <= K1_PART_HI
+        case 5: return k1_launch_kt<K1_PART_T, 5>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 6 && 6 <= K1_PART_HI
+        case 6: return k1_launch_kt<K1_PART_T, 6>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 7 && 7 <= K1_PART_HI
+        case 7: return k1_launch_kt<K1_PART_T, 7>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 8 && 8 <= K1_PART_HI
+        case 8: return k1_launch_kt<K1_PART_T, 8>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 9 && 9 <= K1_PART_HI
+        case 9: return k1_launch_kt<K1_PART_T, 9>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 10 && 10 <= K1_PART_HI
+        case 10: return k1_launch_kt<K1_PART_T, 10>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 11 && 11 <= K1_PART_HI && !defined(K1_NULLS_TU)
+        case 11: return k1_launch_wide_kt<K1_PART_T, 11>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 12 && 12 <= K1_PART_HI && !defined(K1_NULLS_TU)
+        case 12: return k1_launch_wide_kt<K1_PART_T, 12>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 13 && 13 <= K1_PART_HI && !defined(K1_NULLS_TU)
+        case 13: return k1_launch_wide_kt<K1_PART_T, 13>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 14 && 14 <= K1_PART_HI && !defined(K1_NULLS_TU)
+        case 14: return k1_launch_wide_kt<K1_PART_T, 14>(ctx, a, max_rows);
+#endif
+#if K1_PART_LO <= 15 && 15 <= K1_PART_HI && !defined(K1_NULLS_TU)
+        case 15: return k1_launch_wide_kt<K1_PART_T, 15>(ctx, a, max_rows);
+#endif
+        default: return fail(POLS_ERR_UNSUPPORTED, "k1: %d columns are not in this unit", kt);
     }
 }
-#endif  // K1_WIDE_TU
+#endif
 
 }  // namespace pols
