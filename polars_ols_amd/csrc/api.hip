@@ -342,12 +342,13 @@ static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_row
     if (!f32 && (kt < 17 || kt > 24)) return false;
     return kt <= K1X_MAX_KT && need <= (int64_t)256 * 1 * vec;
 }
-// ... and its null-policy family: up to 8 columns like the plain kernels, 9-10 columns (masked three-pass Gram) while resident
+// ... and its null-policy family: up to 8 columns like the plain kernels, 9-15 columns (masked three- / four-pass Gram) while resident
 static bool k1_nulls_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_rows) {
     const int vec = f32 ? 4 : 2;
     if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
     const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
-    return kt <= K1_MAX_KT && need <= 1024;
+    if (kt <= K1_MAX_KT) return need <= 1024;
+    return kt <= K1W_MAX_KT && need <= (int64_t)256 * 2 * vec;
 }
 
 // handle_nulls (src/expressions.rs:255-296) for the entries that work on FILTERED rows: the batch as the policy leaves it --
@@ -1535,15 +1536,16 @@ namespace pols {
 // the register-resident kernels, a few column counts per translation unit (k1_f32_a.hip ... k1n_f64_b.hip)
 #define K1P_DECL(name) int name(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
 K1P_DECL(k1_launch_f32_a) K1P_DECL(k1_launch_f32_b) K1P_DECL(k1_launch_f32_c) K1P_DECL(k1_launch_f64_a) K1P_DECL(k1_launch_f64_b)
-K1P_DECL(k1n_launch_f32_a) K1P_DECL(k1n_launch_f32_b) K1P_DECL(k1n_launch_f64_a) K1P_DECL(k1n_launch_f64_b)   // null-policy family
+K1P_DECL(k1n_launch_f32_a) K1P_DECL(k1n_launch_f32_b) K1P_DECL(k1n_launch_f32_c)   // null-policy family
+K1P_DECL(k1n_launch_f64_a) K1P_DECL(k1n_launch_f64_b) K1P_DECL(k1n_launch_f64_c)
 #undef K1P_DECL
 template <typename T> static int k1_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
     if constexpr (sizeof(T) == 4) return kt <= 6 ? k1_launch_f32_a(ctx, kt, a, max_rows) : (kt <= 8 ? k1_launch_f32_b(ctx, kt, a, max_rows) : k1_launch_f32_c(ctx, kt, a, max_rows));
     else return kt <= 7 ? k1_launch_f64_a(ctx, kt, a, max_rows) : k1_launch_f64_b(ctx, kt, a, max_rows);
 }
 template <typename T> static int k1n_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
-    if constexpr (sizeof(T) == 4) return kt <= 7 ? k1n_launch_f32_a(ctx, kt, a, max_rows) : k1n_launch_f32_b(ctx, kt, a, max_rows);
-    else return kt <= 7 ? k1n_launch_f64_a(ctx, kt, a, max_rows) : k1n_launch_f64_b(ctx, kt, a, max_rows);
+    if constexpr (sizeof(T) == 4) return kt <= 7 ? k1n_launch_f32_a(ctx, kt, a, max_rows) : (kt <= 10 ? k1n_launch_f32_b(ctx, kt, a, max_rows) : k1n_launch_f32_c(ctx, kt, a, max_rows));
+    else return kt <= 7 ? k1n_launch_f64_a(ctx, kt, a, max_rows) : (kt <= 10 ? k1n_launch_f64_b(ctx, kt, a, max_rows) : k1n_launch_f64_c(ctx, kt, a, max_rows));
 }
 template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
 // 16..31 columns, resident multi-pass: four column counts per translation unit (k1w_f32_a.hip ... k1w_f64_d.hip)
@@ -1560,7 +1562,7 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
     const bool f32 = dtype == POLS_F32;
     const int vec = f32 ? 4 : 2;
     if (a.null_policy != POLS_NULL_IGNORE) {
-        if (kt > K1_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "k1 null-policy kernels stop at %d columns", K1_MAX_KT);
+        if (kt > K1W_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "k1 null-policy kernels stop at %d columns", K1W_MAX_KT);
         return f32 ? k1n_launch_t<float>(ctx, kt, a, max_group_rows) : k1n_launch_t<double>(ctx, kt, a, max_group_rows);
     }
     const bool fits = kt <= K1M_MAX_KT && (f32 ? k1m_fits<float>(a.k_user, a.w != nullptr, max_group_rows)

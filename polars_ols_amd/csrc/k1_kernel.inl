@@ -1490,7 +1490,6 @@ static int k1_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     return a.w ? k1_launch_kw<T, KT, true>(ctx, a, max_rows) : k1_launch_kw<T, KT, false>(ctx, a, max_rows);
 }
 
-#ifndef K1_NULLS_TU
 // 11-15 columns: only the multi-pass forms exist (91 accumulators at 12 features + target: three passes; 136 at 15: four), picked so
 // that the resident rows of a lane stay at 4-8 x (k + 1) values.  11-12 columns: one wave up to 512 f32 / 256 f64 rows, two waves
 // up to 1 024 / 512, the 256-thread team beyond.  13-15 columns: one chunk per lane (one wave, two waves, four) before two.
@@ -1502,9 +1501,14 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + 59) / 60 : (NACC + 35) / 36));
     const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
     const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
+#ifdef K1_NULLS_TU
+    constexpr bool NL = true;     // the null-policy family: the same shapes with the masked Gram passes (11-15 columns)
+#else
+    constexpr bool NL = false;
+#endif
 #define K1W_GO(TEAM, RC)                                                                                                       \
-    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NP>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NP>(ctx, a)) \
-               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NP>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NP>(ctx, a))
+    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NP, NL>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NP, NL>(ctx, a)) \
+               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NP, NL>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NP, NL>(ctx, a))
     if constexpr (KT <= 12) {
         if constexpr (sizeof(T) == 4) {
             if (need <= 64 * 1 * VEC) { K1W_GO(64, 1); }
@@ -1529,7 +1533,6 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 #undef K1W_GO
     return fail(POLS_ERR_UNSUPPORTED, "k1: %d columns with %lld-row groups do not stay resident", KT, (long long)max_rows);
 }
-#endif
 
 // One translation unit instantiates the column counts [K1_PART_LO, K1_PART_HI] of one dtype (K1_PART_T) under the entry name
 // K1_PART_FN -- the fully unrolled kernels of all 15 column counts in one unit took 5.5 minutes to compile; api.hip picks the unit.
@@ -1566,19 +1569,19 @@ int K1_PART_FN(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows) {
 #if K1_PART_LO <= 10 && 10 <= K1_PART_HI
         case 10: return k1_launch_kt<K1_PART_T, 10>(ctx, a, max_rows);
 #endif
-#if K1_PART_LO <= 11 && 11 <= K1_PART_HI && !defined(K1_NULLS_TU)
+#if K1_PART_LO <= 11 && 11 <= K1_PART_HI
         case 11: return k1_launch_wide_kt<K1_PART_T, 11>(ctx, a, max_rows);
 #endif
-#if K1_PART_LO <= 12 && 12 <= K1_PART_HI && !defined(K1_NULLS_TU)
+#if K1_PART_LO <= 12 && 12 <= K1_PART_HI
         case 12: return k1_launch_wide_kt<K1_PART_T, 12>(ctx, a, max_rows);
 #endif
-#if K1_PART_LO <= 13 && 13 <= K1_PART_HI && !defined(K1_NULLS_TU)
+#if K1_PART_LO <= 13 && 13 <= K1_PART_HI
         case 13: return k1_launch_wide_kt<K1_PART_T, 13>(ctx, a, max_rows);
 #endif
-#if K1_PART_LO <= 14 && 14 <= K1_PART_HI && !defined(K1_NULLS_TU)
+#if K1_PART_LO <= 14 && 14 <= K1_PART_HI
         case 14: return k1_launch_wide_kt<K1_PART_T, 14>(ctx, a, max_rows);
 #endif
-#if K1_PART_LO <= 15 && 15 <= K1_PART_HI && !defined(K1_NULLS_TU)
+#if K1_PART_LO <= 15 && 15 <= K1_PART_HI
         case 15: return k1_launch_wide_kt<K1_PART_T, 15>(ctx, a, max_rows);
 #endif
         default: return fail(POLS_ERR_UNSUPPORTED, "k1: %d columns are not in this unit", kt);

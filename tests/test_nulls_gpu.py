@@ -86,7 +86,7 @@ def test_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt, kw):
     out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "resid", "status"),
                             null_policy=policy, **kw)
     coef, pred, resid = _expected(y, cols, offs, w, icpt, "drop_zero" if policy == "drop_window" else policy, **kw)
-    k1 = k + int(icpt) <= 10 and "l1_ratio" not in kw  # register-resident NULLS family (9-10 columns: masked three-pass Gram) vs the streamed / wide kernels
+    k1 = k + int(icpt) <= 15 and "l1_ratio" not in kw  # register-resident NULLS family (9-15 columns: masked three- / four-pass Gram) vs the streamed / wide kernels
     assert eng.last_kernel.startswith("k1_gram_chol") == k1 and (not k1 or eng.last_kernel.endswith("_nulls")), eng.last_kernel
     assert eng.last_kernel.startswith("k8_wide") == (k + int(icpt) > 31)
     if policy != "zero":
@@ -96,6 +96,27 @@ def test_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt, kw):
     assert np.allclose(out["pred"], pred, rtol=tol, atol=tol, equal_nan=True)
     assert np.array_equal(np.isnan(out["resid"]), np.isnan(resid))
     assert np.allclose(out["resid"], resid, rtol=tol, atol=10 * tol, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("policy", ["drop", "zero", "drop_y_zero_x"])
+@pytest.mark.parametrize("k,weights,icpt,kw,lo,hi", [
+    (11, False, False, {}, 80, 250),                   # one wave
+    (11, True, True, {"alpha": 0.5}, 300, 500),        # two waves (f32) / the 256-thread team (f64)
+    (13, False, True, {}, 120, 120),                   # equal groups of a vector multiple: the branch-free aligned form
+    (14, True, False, {"alpha": 0.1}, 200, 900),       # 15 columns with the target: four passes, 256-thread team
+    (15, False, False, {}, 600, 1000),
+])
+def test_null_policies_11_to_15_columns_stay_resident(eng, dtype, tol, policy, k, weights, icpt, kw, lo, hi):
+    """src/expressions.rs:201-296 inside the register-resident kernels at 11-15 columns (masked multi-pass Gram)."""
+    y, cols, offs, w = _frame(100 + k, dtype, k, G=23, lo=lo, hi=hi + 1, null_frac=0.03)
+    w = w if weights else None
+    out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "status"), null_policy=policy, **kw)
+    assert eng.last_kernel.startswith("k1_gram_chol") and eng.last_kernel.endswith("_nulls") and "_p" in eng.last_kernel, eng.last_kernel
+    coef, pred, _ = _expected(y, cols, offs, w, icpt, policy, **kw)
+    assert np.allclose(out["coef"], coef, rtol=tol, atol=tol), (eng.last_kernel, float(np.nanmax(np.abs(out["coef"] - coef))))
+    assert np.array_equal(np.isnan(out["pred"]), np.isnan(pred))
+    assert np.allclose(out["pred"], pred, rtol=tol, atol=tol, equal_nan=True)
 
 
 def test_validity_bytes_drop_rows(eng):
