@@ -45,6 +45,7 @@ cd $R
 echo "== side benches"
 timeout 200 python scripts/bench_ragged.py 2>/dev/null | tail -1 > $O/${TAG}_bench_ragged.json; cut -c1-1500 $O/${TAG}_bench_ragged.json; echo
 timeout 120 python scripts/bench_nulls.py 2>/dev/null | tail -1 > $O/${TAG}_bench_nulls.json; cat $O/${TAG}_bench_nulls.json; echo
+timeout 200 python scripts/bench_nulls_wide.py 2>/dev/null | tail -1 > $O/${TAG}_bench_nulls_wide.json; cut -c1-800 $O/${TAG}_bench_nulls_wide.json; echo
 timeout 120 python scripts/bench_layout.py 2>/dev/null | tail -1 > $O/${TAG}_bench_layout.json; cut -c1-600 $O/${TAG}_bench_layout.json; echo
 timeout 200 python scripts/bench_k9.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k9.txt; cut -c1-160 $O/${TAG}_bench_k9.txt
 timeout 200 python scripts/bench_k16.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k16.txt; cat $O/${TAG}_bench_k16.txt
