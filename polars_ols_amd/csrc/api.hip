@@ -348,7 +348,9 @@ static bool k1_nulls_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_ro
     if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
     const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
     if (kt <= K1_MAX_KT) return need <= 1024;
-    return kt <= K1W_MAX_KT && need <= (int64_t)256 * 2 * vec;
+    if (kt <= K1W_MAX_KT) return need <= (int64_t)256 * 2 * vec;
+    if (!f32 && (kt < 17 || kt > 24)) return false;                 // 16-31 columns: where the plain kernels run (k1_valu_takes)
+    return kt <= K1X_MAX_KT && need <= (int64_t)256 * 1 * vec;
 }
 
 // handle_nulls (src/expressions.rs:255-296) for the entries that work on FILTERED rows: the batch as the policy leaves it --
@@ -1552,6 +1554,9 @@ template <typename T> int k1m_launch_t(pols_ctx *ctx, int kt, const K1Args &a, i
 #define K1W_DECL(name) int name(pols_ctx *ctx, int kt, const K1Args &a, int64_t max_rows);
 K1W_DECL(k1w_launch_f32_a) K1W_DECL(k1w_launch_f32_b) K1W_DECL(k1w_launch_f32_c) K1W_DECL(k1w_launch_f32_d)
 K1W_DECL(k1w_launch_f64_a) K1W_DECL(k1w_launch_f64_b) K1W_DECL(k1w_launch_f64_c) K1W_DECL(k1w_launch_f64_d)
+// ... and their null-policy family (k1nw_*.hip; f64 up to 27 columns: the plain f64 kernels run at 17-24)
+K1W_DECL(k1nw_launch_f32_a) K1W_DECL(k1nw_launch_f32_b) K1W_DECL(k1nw_launch_f32_c) K1W_DECL(k1nw_launch_f32_d)
+K1W_DECL(k1nw_launch_f64_a) K1W_DECL(k1nw_launch_f64_b) K1W_DECL(k1nw_launch_f64_c)
 #undef K1W_DECL
 
 // Engine choice for the static least-squares path:
@@ -1562,7 +1567,14 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
     const bool f32 = dtype == POLS_F32;
     const int vec = f32 ? 4 : 2;
     if (a.null_policy != POLS_NULL_IGNORE) {
-        if (kt > K1W_MAX_KT) return fail(POLS_ERR_UNSUPPORTED, "k1 null-policy kernels stop at %d columns", K1W_MAX_KT);
+        if (kt > K1X_MAX_KT || (kt > K1W_MAX_KT && !f32 && kt > 27))
+            return fail(POLS_ERR_UNSUPPORTED, "k1 null-policy kernels stop at %d columns", f32 ? K1X_MAX_KT : 27);
+        if (kt > K1W_MAX_KT) {
+            using Fn = int (*)(pols_ctx *, int, const K1Args &, int64_t);
+            static const Fn wide[2][4] = {{k1nw_launch_f32_a, k1nw_launch_f32_b, k1nw_launch_f32_c, k1nw_launch_f32_d},
+                                          {k1nw_launch_f64_a, k1nw_launch_f64_b, k1nw_launch_f64_c, nullptr}};
+            return wide[f32 ? 0 : 1][(kt - 16) / 4](ctx, kt, a, max_group_rows);
+        }
         return f32 ? k1n_launch_t<float>(ctx, kt, a, max_group_rows) : k1n_launch_t<double>(ctx, kt, a, max_group_rows);
     }
     const bool fits = kt <= K1M_MAX_KT && (f32 ? k1m_fits<float>(a.k_user, a.w != nullptr, max_group_rows)

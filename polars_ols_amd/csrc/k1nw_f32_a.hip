@@ -1,0 +1,6 @@
+// K1 null-policy family, resident multi-pass kernels, 16..19 columns, f32 (see k1w_tu.inl)
+#define K1_NULLS_TU 1
+#define K1W_T float
+#define K1W_LO 16
+#define K1W_FN k1nw_launch_f32_a
+#include "k1w_tu.inl"

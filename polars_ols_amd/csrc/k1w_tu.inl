@@ -1,5 +1,6 @@
 // k1w_tu.inl -- one translation unit of the 16..31-column resident multi-pass K1 kernels: four column counts of one dtype per
-// TU (K1W_T, K1W_LO, K1W_FN set by the including .hip), so that the fully unrolled Gram passes compile in parallel.
+// TU (K1W_T, K1W_LO, K1W_FN set by the including .hip; K1_NULLS_TU for the null-policy family, k1nw_*.hip), so that the fully
+// unrolled Gram passes compile in parallel.
 #define K1_WIDE_TU 1
 #include "k1_kernel.inl"
 

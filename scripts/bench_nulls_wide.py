@@ -1,4 +1,4 @@
-"""Null policies at 11-15 columns: the register-resident masked kernels next to the plain kernel and the streamed three-launch path."""
+"""Null policies at 11-31 columns: the register-resident masked kernels next to the plain kernel and the streamed three-launch path."""
 import json
 import os
 import sys
@@ -17,7 +17,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     res = {}
     for dt in (torch.float32, torch.float64):
-        for k in (12, 15):
+        for k in (12, 15, 20):
             cols = [torch.randn(G * n, device="cuda", generator=g, dtype=dt) for _ in range(k)]
             y = sum(cols) + 0.1 * torch.randn(G * n, device="cuda", generator=g, dtype=dt)
             yn = y.clone()

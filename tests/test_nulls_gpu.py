@@ -86,7 +86,10 @@ def test_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt, kw):
     out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "resid", "status"),
                             null_policy=policy, **kw)
     coef, pred, resid = _expected(y, cols, offs, w, icpt, "drop_zero" if policy == "drop_window" else policy, **kw)
-    k1 = k + int(icpt) <= 15 and "l1_ratio" not in kw  # register-resident NULLS family (9-15 columns: masked three- / four-pass Gram) vs the streamed / wide kernels
+    # register-resident NULLS family (9+ columns: masked multi-pass Gram; 16-31 columns f32 up to 1 024 rows, f64 up to 512 -- these
+    # groups reach 899) vs the streamed / wide kernels
+    kt = k + int(icpt)
+    k1 = "l1_ratio" not in kw and (kt <= 15 or (kt <= 31 and dtype == np.float32))
     assert eng.last_kernel.startswith("k1_gram_chol") == k1 and (not k1 or eng.last_kernel.endswith("_nulls")), eng.last_kernel
     assert eng.last_kernel.startswith("k8_wide") == (k + int(icpt) > 31)
     if policy != "zero":
@@ -113,6 +116,29 @@ def test_null_policies_11_to_15_columns_stay_resident(eng, dtype, tol, policy, k
     w = w if weights else None
     out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "status"), null_policy=policy, **kw)
     assert eng.last_kernel.startswith("k1_gram_chol") and eng.last_kernel.endswith("_nulls") and "_p" in eng.last_kernel, eng.last_kernel
+    coef, pred, _ = _expected(y, cols, offs, w, icpt, policy, **kw)
+    assert np.allclose(out["coef"], coef, rtol=tol, atol=tol), (eng.last_kernel, float(np.nanmax(np.abs(out["coef"] - coef))))
+    assert np.array_equal(np.isnan(out["pred"]), np.isnan(pred))
+    assert np.allclose(out["pred"], pred, rtol=tol, atol=tol, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("policy", ["drop", "zero", "drop_y_zero_x"])
+@pytest.mark.parametrize("k,weights,icpt,kw", [
+    (16, False, False, {}),
+    (19, True, True, {"alpha": 0.3}),
+    (24, False, False, {}),
+    (27, True, False, {"alpha": 0.1}),
+    (30, False, True, {}),
+])
+def test_null_policies_16_to_31_columns(eng, dtype, tol, policy, k, weights, icpt, kw):
+    """16-31 columns under a null policy: the register-resident masked kernels wherever the plain ones run (f32; f64 at 17-24)."""
+    y, cols, offs, w = _frame(200 + k, dtype, k, G=17, lo=5 * k, hi=250, null_frac=0.02)
+    w = w if weights else None
+    out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, want=("coef", "pred", "status"), null_policy=policy, **kw)
+    kt = k + int(icpt)
+    resident = dtype == np.float32 or 17 <= kt <= 24
+    assert (eng.last_kernel.startswith("k1_gram_chol") and eng.last_kernel.endswith("_nulls")) == resident, eng.last_kernel
     coef, pred, _ = _expected(y, cols, offs, w, icpt, policy, **kw)
     assert np.allclose(out["coef"], coef, rtol=tol, atol=tol), (eng.last_kernel, float(np.nanmax(np.abs(out["coef"] - coef))))
     assert np.array_equal(np.isnan(out["pred"]), np.isnan(pred))
