@@ -1469,7 +1469,9 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             const int64_t need = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1);
             // (10 columns: the two-wave team's 8 resident rows x 11 columns leave one wave per SIMD -- the 256-thread team with 4 rows
             // per lane and the three-pass Gram keeps its registers under 168)
-            const bool team128 = KT < 10 || need <= 128 * 2 * VEC;
+            // (9 columns WITH weights: 8 rows x 11 values tip the two-wave team into AGPRs -- 274 registers, one wave per SIMD, 258 us
+            // on 10 000 x 1 000 rows where the 256-thread team takes ~185)
+            const bool team128 = (KT < 10 && !(KT == 9 && HAS_W)) || need <= 128 * 2 * VEC;
             if (!ctx->opt.k1_f64_team256 && team128 && need <= 128 * 4 * VEC && !ctx->opt.timeline) {
                 const int pp = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 10 ? 3 : 0);   // 10 columns: 66 f64 accumulators -> three passes
                 if (pp == 3 && al) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
