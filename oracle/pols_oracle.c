@@ -219,8 +219,21 @@ void orc_update_xtx_inv(const double *xtx_inv, const double *x_update, const dou
 /* ------------------------------------------------------------ QR solver */
 
 /* ls.rs:195-205 solve_ols_qr: faer col_piv_qr().solve_lstsq -- Householder QR
- * with column pivoting (largest remaining column norm), NO rank truncation,
- * then R z = (Q^T y)[:k], beta = P z.  Requires n >= k. */
+ * with column pivoting (largest remaining column norm, the FIRST of tied
+ * columns), then R z = (Q^T y)[:k], beta = P z.  Requires n >= k.
+ *
+ * Rank-deficient X: the reference holds one printed vector for it -- the
+ * collinear frame of notebooks/polars_ols_demo.ipynb cell 28 (x3 an exact copy
+ * of x2, y = x1 + x2 + x3) prints {1.0, 2.0, -0.0} for solve_method="qr": the
+ * BASIC solution, the dependent column at exactly zero (cell 32: only "svd"
+ * gives the minimum-norm {1, 1, 1}).  A textbook back substitution through the
+ * rounding-noise pivot R_jj ~ eps |R_00| instead returns noise / noise
+ * ({1, 0.976, 1.024} on that frame).  This restatement is therefore
+ * rank-revealing the way LAPACK dgelsy is: the factorisation stops at the first
+ * pivot with |R_jj| <= eps * max(n, k) * |R_00| (the cut-off the reference
+ * itself uses for singular values, ls.rs:143-145), the columns from there on
+ * get coefficient 0 and the leading block is back-substituted.  Pinned by
+ * tests/golden/notebook_kat.json (cells 28 / 32). */
 void orc_solve_ols_qr(const double *y, const double *x, int64_t n, int k, double *beta) {
     double *a = tls_alloc(0, (size_t)n * k); /* column-major */
     double *b = tls_alloc(1, (size_t)n);
@@ -232,6 +245,9 @@ void orc_solve_ols_qr(const double *y, const double *x, int64_t n, int k, double
     }
     for (int j = 0; j < k; ++j) jpvt[j] = j;
     int steps = (int)((n < k) ? n : k);
+    int rank = steps;
+    double r00 = 0.0;
+    const double rank_tol = 2.220446049250313e-16 * (double)((n > k) ? n : k);
     for (int j = 0; j < steps; ++j) {
         /* pivot selection on the trailing sub-columns */
         int best = j;
@@ -249,7 +265,8 @@ void orc_solve_ols_qr(const double *y, const double *x, int64_t n, int k, double
         }
         double *cj = a + (size_t)j * n;
         double normx = sqrt(bestn);
-        if (normx == 0.0) continue;
+        if (j == 0) r00 = normx;
+        if (normx <= rank_tol * r00) { rank = j; break; } /* numerically dependent from here on (NaN data: never true) */
         double alpha = cj[j];
         double bh = -copysign(normx, alpha);
         double tau = (bh - alpha) / bh;
@@ -267,9 +284,10 @@ void orc_solve_ols_qr(const double *y, const double *x, int64_t n, int k, double
         }
     }
     double *z = tls_alloc(2, (size_t)k);
-    for (int i = k - 1; i >= 0; --i) {
-        double s = (i < n) ? b[i] : 0.0;
-        for (int p = i + 1; p < k; ++p) s -= a[(size_t)p * n + i] * z[p];
+    for (int i = k - 1; i >= rank; --i) z[i] = 0.0;
+    for (int i = rank - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int p = i + 1; p < rank; ++p) s -= a[(size_t)p * n + i] * z[p];
         z[i] = s / a[(size_t)i * n + i];
     }
     for (int i = 0; i < k; ++i) beta[jpvt[i]] = z[i];

@@ -21,6 +21,12 @@ Two kinds of vectors:
    per-window lstsq).  Nothing from oracle/ or polars_ols_amd/ is used to make
    these numbers, so they pin both independently.
 
+3. ``notebook_kat.json`` + ``notebook_frame.npz`` -- the outputs the REFERENCE prints in its demo notebook
+   (reference notebooks/polars_ols_demo.ipynb cells 7, 9, 11, 28, 30, 32, 36, 47, 49, 53, 54) on the seeded frame of
+   its cell 1 / 2 (``_make_data(n_samples=2_000, n_features=3, n_groups=5)``, re-stated as
+   ``refdata.notebook_make_data``).  The printed values are typed in as data; the frame is regenerated from the seed and
+   stored so that a numpy whose Generator stream ever changed would be noticed (the printed input rows of cells 7 / 53 pin it).
+
 The reference itself cannot be imported here (needs polars + its Rust cdylib),
 so no vector is produced by running reference code.
 """
@@ -35,7 +41,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent))
 
-from refdata import make_data, insert_nulls  # noqa: E402
+from refdata import make_data, insert_nulls, notebook_make_data  # noqa: E402
 
 
 def readme_kat() -> dict:
@@ -69,6 +75,66 @@ def readme_kat() -> dict:
         },
         "woodbury": {"a": [[0.5, 0.2], [0.0, 0.5]], "u": [[1.0, 2.0], [3.0, 4.0]],
                      "c": [[1.0, 0.0], [0.0, 1.0]], "v": [[1.0, 0.0], [0.0, 1.0]]},
+    }
+
+
+def notebook_kat() -> dict:
+    """Typed in from the output cells of reference notebooks/polars_ols_demo.ipynb (6 printed digits)."""
+    nan = None
+    return {
+        "source": "reference notebooks/polars_ols_demo.ipynb, output cells 7, 9, 11, 28, 30, 32, 36, 47, 49, 53, 54",
+        "frame": {"n_samples": 2000, "n_features": 3, "n_groups": 5, "file": "notebook_frame.npz"},
+        # cell 53 head(5): the input rows as printed (x1, x2, x3, group, sample_weights); y struct = (x1+x2+x3, x1-x2+x3, -x1+x2-x3)
+        "cell53_head5": {
+            "x1": [0.12573, 0.1049, 1.304, -1.265421, -2.325031],
+            "x2": [-0.132105, -0.535669, 0.947081, -0.623274, -0.218792],
+            "x3": [0.640423, 0.361595, -0.703735, 0.041326, -1.245911],
+            "group": [1, 0, 4, 3, 3],
+            "sample_weights": [0.709215, 0.731333, 0.701351, 0.052596, 0.963254],
+            "y_struct": [[0.634048, 0.898258, -0.898258], [-0.069174, 1.002165, -1.002165], [1.547346, -0.346816, 0.346816],
+                         [-1.84737, -0.600821, 0.600821], [-3.789733, -3.35215, 3.35215]],
+        },
+        # cell 7 tail(10): inputs as printed + ols(svd, null_policy="drop").over("group"), the same over the whole frame,
+        # and wls(sample_weights) * (group == 2)
+        "cell7_tail10": {
+            "x1": [-0.583369, 0.71304, 1.098849, -0.485594, 0.949438, 1.057735, -0.122949, -0.491295, -0.226812, 0.159845],
+            "x2": [0.890726, 1.751887, 0.463944, -0.315542, 1.029228, 0.268385, 2.002523, 0.870951, 0.740164, -0.226334],
+            "x3": [0.497755, -0.223204, -0.451817, 0.096269, 0.318868, 0.350553, 1.63392, 0.24026, 0.180547, -0.093559],
+            "y": [-0.70099, -2.230821, -1.116165, 0.866697, -2.197234, -1.559323, -3.658936, -0.552929, -0.599317, 0.203998],
+            "sample_weights": [0.871927, 0.776195, 0.01473, 0.507687, 0.062403, 0.559756, 0.585527, 0.367483, 0.119438, 0.082505],
+            "predictions_ols_group": [-0.800004, -2.241771, -1.111206, 0.70668, -2.295554, -1.67483, -3.503794, -0.617277, -0.691848, 0.15888],
+            "predictions_ols": [-0.802822, -2.239055, -1.110725, 0.704341, -2.294688, -1.674932, -3.506601, -0.6182, -0.692402, 0.159546],
+            "predictions_wls_masked": [-0.800443, -0.0, -1.11138, 0.0, -0.0, -0.0, -0.0, -0.0, -0.0, 0.158951],
+        },
+        # cell 9: ols(x*, add_intercept=True, mode="coefficients"); the display shows the first two fields
+        "cell9_coefficients_first2": [-0.999496, -0.998398],
+        # cell 11: ols("x1","x2","x3", add_intercept=True, mode="coefficients").over("group"), (x1, x2, x3, const) by group key
+        "cell11_coefficients_group": {"1": [-0.993655, -0.997968, -1.006029, 0.003129], "0": [-1.002313, -1.0001, -0.993786, -0.006384],
+                                      "4": [-1.000859, -0.998017, -0.998356, 0.004797], "3": [-0.999962, -0.999101, -0.995044, 0.004376]},
+        # cells 26-32: x3 := x2 (exact copy), y := x1 + x2 + x3 (sum_horizontal, left to right)
+        "cell28_collinear_qr": [1.0, 2.0, -0.0],
+        "cell28_norm": 2.23606797749979,
+        "cell30_collinear_chol": [nan, nan, nan],
+        "cell32_collinear_svd": [1.0, 1.0, 1.0],
+        # cell 36: elastic_net(alpha=0.0001, l1_ratio=0.5, positive=True) and ridge(alpha=100, sample_weights)
+        "cell36_enet_non_negative": [0.0, 0.0, 0.0],
+        "cell36_ridge_alpha100_weighted": [-0.912021, -0.898583, -0.908957],
+        # cell 47: rolling_ols(window_size=252, min_periods=5, alpha=0.0001).over("group") | rls(half_life=21, initial_state_mean=
+        # [-1,-1,-1], initial_state_covariance=10).over("group") | expanding_ols(...) predictions over the whole frame
+        "cell47_rolling_ridge_head5": [[nan, nan, nan]] * 5,
+        "cell47_rolling_ridge_tail5": [[-0.995486, -1.003153, -0.998155], [-0.995348, -1.004411, -0.99898], [-1.001142, -1.002267, -1.002736],
+                                       [-1.001257, -1.001316, -1.003019], [-1.002536, -0.993688, -0.998938]],
+        "cell47_rls_head5": [[-1.031467, -0.966938, -1.160281], [-1.013228, -0.932454, -1.045596], [-1.003344, -1.002429, -0.998195],
+                             [-1.053291, -1.026248, -0.99826], [-1.059251, -1.017933, -1.014118]],
+        "cell47_rls_tail5": [[-0.987406, -1.004047, -1.004306], [-0.985392, -1.011036, -1.00789], [-1.001857, -0.980484, -1.007321],
+                             [-1.002182, -0.978417, -1.006454], [-0.968934, -1.00696, -1.010813]],
+        "cell47_expanding_pred_head5": [-0.627675, -0.127212, -1.48872, 1.852231, 3.941405],
+        "cell47_expanding_pred_tail5": [-1.674772, -3.506569, -0.618197, -0.692359, 0.159536],
+        # cell 49: ols("x1","x2", mode="coefficients").over("group") by group key
+        "cell49_coefficients_group": {"2": [-0.948578, -0.917406], "1": [-1.094156, -0.946028], "0": [-1.028893, -1.004733],
+                                      "3": [-1.074243, -1.050159], "4": [-1.037308, -0.981468]},
+        # cell 54: multi_target_ols(x1, x2, x3, sample_weights, mode="residuals").over("group"): every printed residual is ~1e-16
+        "cell54_multi_target_residual_bound": 1e-14,
     }
 
 
@@ -187,6 +253,9 @@ def main() -> None:
 
     np.savez_compressed(HERE / "make_data_cases.npz", **out)
     (HERE / "readme_kat.json").write_text(json.dumps(readme_kat(), indent=1))
+    (HERE / "notebook_kat.json").write_text(json.dumps(notebook_kat(), indent=1))
+    nb = notebook_make_data(n_samples=2_000, n_features=3, n_groups=5)
+    np.savez_compressed(HERE / "notebook_frame.npz", x=nb["x"], y=nb["y"], group=nb["group"], sample_weights=nb["sample_weights"])
     print("wrote", HERE / "make_data_cases.npz", "and readme_kat.json;", len(out), "arrays")
 
 

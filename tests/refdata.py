@@ -27,6 +27,21 @@ def make_data(n_samples: int = 5_000, n_features: int = 2, n_groups: Optional[in
     return out
 
 
+def notebook_make_data(n_samples: int = 2_000, n_features: int = 5, n_groups: int = 5, noise: float = 0.1,
+                       sparsity: float = 0.0) -> Dict[str, np.ndarray]:
+    """The seeded frame of the reference's demo notebook (notebooks/polars_ols_demo.ipynb cell 1, `_make_data`): same RNG call
+    order (x, eps, group, sample_weights) -- note the MINUS sign of the target, unlike tests/test_ols.py:22-51."""
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(n_samples, n_features))
+    eps = rng.normal(size=n_samples, scale=noise)
+    out = {"x": x, "y": -1 * x[:, : int(n_features * (1.0 - sparsity))].sum(1) + eps}
+    for i in range(n_features):
+        out[f"x{i + 1}"] = np.ascontiguousarray(x[:, i])
+    out["group"] = rng.integers(0, n_groups, size=n_samples)
+    out["sample_weights"] = rng.uniform(0, 1, size=n_samples)
+    return out
+
+
 def insert_nulls(d: Dict[str, np.ndarray], columns: Sequence[str], frac: float = 0.1, seed: int = 7):
     """10 % missing values per listed column (reference tests/test_ols.py:42-50)."""
     rng = np.random.default_rng(seed)

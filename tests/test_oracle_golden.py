@@ -250,3 +250,100 @@ def test_configs0_oracle_matches_lstsq(method):
     assert np.allclose(got, exp, rtol=1e-12, atol=1e-12), float(np.abs(got - exp).max())
     out = orc.batched_least_squares(d["y"], [d[f"x{i + 1}"] for i in range(4)], [0, 10_000], solve_method=method, want=("coef",))
     assert np.allclose(out["coef"][0], exp, rtol=1e-12, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- demo-notebook KATs (reference-held vectors)
+# notebooks/polars_ols_demo.ipynb: the printed outputs of cells 7 / 9 / 11 / 28 / 30 / 32 / 36 / 47 / 49 / 54 on the seeded frame
+# of cell 1 (tests/golden/notebook_kat.json).  Printed to 6 decimals, so |oracle - printed| <= 0.5e-6 (+ rounding slack).
+
+P6 = 0.6e-6
+
+
+def _nan(a):
+    return np.array([[np.nan if v is None else v for v in row] if isinstance(row, list) else (np.nan if row is None else row)
+                     for row in a], dtype=np.float64)
+
+
+def test_notebook_frame_is_the_printed_one(notebook):
+    kat, d = notebook["kat"], notebook["d"]
+    h, t = kat["cell53_head5"], kat["cell7_tail10"]
+    for c in ("x1", "x2", "x3", "sample_weights"):
+        assert np.allclose(d[c][:5], h[c], atol=P6) and np.allclose(d[c][-10:], t[c], atol=P6), c
+    assert np.array_equal(d["group"][:5], h["group"])
+    assert np.allclose(d["y"][-10:], t["y"], atol=P6)
+    ys = np.column_stack([d["x1"] + d["x2"] + d["x3"], d["x1"] - d["x2"] + d["x3"], -d["x1"] + d["x2"] - d["x3"]])
+    assert np.allclose(ys[:5], h["y_struct"], atol=P6)
+
+
+def test_notebook_static_cells(notebook):
+    kat, d = notebook["kat"], notebook["d"]
+    x, y, w = d["x"], d["y"], d["sample_weights"]
+    cols = [d["x1"], d["x2"], d["x3"]]
+    order, offs, keys = sort_by_group(d["group"])
+    inv = np.empty_like(order); inv[order] = np.arange(len(order))
+    # cell 7
+    t = kat["cell7_tail10"]
+    g = orc.batched_least_squares(y[order], [c[order] for c in cols], offs, solve_method="svd", null_policy="drop")
+    assert np.allclose(g["pred"][inv][-10:], t["predictions_ols_group"], atol=P6)
+    f = orc.batched_least_squares(y, cols, [0, len(y)], solve_method="svd", null_policy="drop")
+    assert np.allclose(f["pred"][-10:], t["predictions_ols"], atol=P6)
+    wl = orc.batched_least_squares(y, cols, [0, len(y)], weights=w)
+    assert np.allclose(wl["pred"][-10:] * (d["group"][-10:] == 2), t["predictions_wls_masked"], atol=P6)
+    # cell 9 / 11 / 49
+    c9 = orc.get_coefficients(y, np.column_stack([x, np.ones(len(y))]))
+    assert np.allclose(c9[:2], kat["cell9_coefficients_first2"], atol=P6)
+    g11 = orc.batched_least_squares(y[order], [c[order] for c in cols], offs, add_intercept=True)
+    for gi, key in enumerate(keys):
+        if str(key) in kat["cell11_coefficients_group"]:
+            assert np.allclose(g11["coef"][gi], kat["cell11_coefficients_group"][str(key)], atol=P6)
+    g49 = orc.batched_least_squares(y[order], [c[order] for c in cols[:2]], offs)
+    for gi, key in enumerate(keys):
+        assert np.allclose(g49["coef"][gi], kat["cell49_coefficients_group"][str(key)], atol=P6)
+    # cell 36
+    assert np.array_equal(orc.get_coefficients(y, x, alpha=0.0001, l1_ratio=0.5, positive=True), kat["cell36_enet_non_negative"])
+    sw = np.sqrt(w)
+    assert np.allclose(orc.get_coefficients(y * sw, x * sw[:, None], alpha=100.0), kat["cell36_ridge_alpha100_weighted"], atol=P6)
+
+
+def test_notebook_collinear_cells(notebook):
+    """Cells 26-34: x3 := x2 exactly, y := x1 + x2 + x3.  "qr" / default: the basic solution {1, 2, -0}; "chol" / "lu": Cholesky
+    fails, LU meets an exactly zero pivot -> nulls; "svd": the minimum-norm {1, 1, 1}."""
+    kat, d = notebook["kat"], notebook["d"]
+    xc = np.column_stack([d["x1"], d["x2"], d["x2"]])
+    yc = (xc[:, 0] + xc[:, 1]) + xc[:, 2]
+    for m in ("qr", None):
+        c = orc.get_coefficients(yc, xc, solve_method=m)
+        assert np.allclose(c, kat["cell28_collinear_qr"], atol=1e-12)
+        assert abs(np.linalg.norm(c) - kat["cell28_norm"]) < 1e-12
+    for m in ("chol", "lu"):
+        assert np.isnan(orc.get_coefficients(yc, xc, solve_method=m)).all()
+    assert np.allclose(orc.get_coefficients(yc, xc, solve_method="svd"), kat["cell32_collinear_svd"], atol=1e-12)
+
+
+def test_notebook_dynamic_cells(notebook):
+    kat, d = notebook["kat"], notebook["d"]
+    y = d["y"]
+    cols = [d["x1"], d["x2"], d["x3"]]
+    order, offs, _ = sort_by_group(d["group"])
+    inv = np.empty_like(order); inv[order] = np.arange(len(order))
+    r = orc.batched_rolling(y[order], [c[order] for c in cols], offs, window_size=252, min_periods=5, alpha=0.0001)["coef"][inv]
+    assert np.isnan(r[:5]).all()
+    assert np.allclose(r[-5:], kat["cell47_rolling_ridge_tail5"], atol=P6)
+    rl = orc.batched_rls(y[order], [c[order] for c in cols], offs, half_life=21.0, initial_state_covariance=10.0,
+                         initial_state_mean=[-1.0, -1.0, -1.0])["coef"][inv]
+    assert np.allclose(rl[:5], kat["cell47_rls_head5"], atol=P6) and np.allclose(rl[-5:], kat["cell47_rls_tail5"], atol=P6)
+    ex = orc.batched_rls(y, cols, [0, len(y)], half_life=None)["pred"]         # expanding_ols == rls(half_life=None), __init__.py:260-261
+    assert np.allclose(ex[:5], kat["cell47_expanding_pred_head5"], atol=P6)
+    assert np.allclose(ex[-5:], kat["cell47_expanding_pred_tail5"], atol=P6)
+
+
+def test_notebook_multi_target_residuals(notebook):
+    kat, d = notebook["kat"], notebook["d"]
+    order, offs, _ = sort_by_group(d["group"])
+    x = d["x"][order]
+    sw = np.sqrt(d["sample_weights"][order])
+    ys = np.column_stack([x[:, 0] + x[:, 1] + x[:, 2], x[:, 0] - x[:, 1] + x[:, 2], -x[:, 0] + x[:, 1] - x[:, 2]])
+    for g in range(len(offs) - 1):
+        s, e = offs[g], offs[g + 1]
+        b = orc.solve_multi_target(ys[s:e] * sw[s:e, None], x[s:e] * sw[s:e, None])
+        assert np.abs(ys[s:e] - x[s:e] @ b).max() < kat["cell54_multi_target_residual_bound"]
