@@ -330,6 +330,46 @@ int pols_least_squares_arrow(pols_ctx *ctx, const pols_arrow_column *target, con
                              const pols_arrow_column *weights, const int64_t *group_offsets, int64_t n_groups, int32_t add_intercept,
                              const pols_ols_params *p, int32_t mode, struct ArrowArray *out, struct ArrowSchema *out_schema);
 
+/* The other seven plugin functions (src/expressions.rs:468-741), same conventions: columns as Polars holds them in, a
+ * released-by-callback ArrowArray / ArrowSchema pair out; group_offsets NULL = the per-group call; all inputs Float32 -> f32.
+ *
+ * least_squares_statistics (ex.rs:448-509): a struct array "statistics" with ONE row per group and the fields of
+ * statistics_struct_dtype (:448-466): r2, mae, mse (Float64), feature_names (list<str>), coefficients, standard_errors,
+ * t_values, p_values (list<Float64>); lists are Arrow large lists ("+L") of large strings ("U") / Float64.  A group whose
+ * degrees of freedom are <= 0 fails the call with POLS_ERR_PANIC like the reference's assert (src/statistics.rs:131-134). */
+int pols_least_squares_statistics_arrow(pols_ctx *ctx, const pols_arrow_column *target, const pols_arrow_column *features,
+                                        int32_t n_features, const pols_arrow_column *weights, const int64_t *group_offsets,
+                                        int64_t n_groups, int32_t add_intercept, const pols_ols_params *p, struct ArrowArray *out,
+                                        struct ArrowSchema *out_schema);
+/* multi_target_least_squares (ex.rs:511-591): `targets` is the STRUCT Series of inputs[0] (format "+s", one numeric field per
+ * target; a null struct row is a null in every field); out: a struct array "predictions" of n_rows rows with the targets' field
+ * names (multi_target_struct_dtype, :511-519), NaN -> null.  Residuals are the caller's `target - predictions`
+ * (polars_ols/least_squares.py:236-239). */
+int pols_multi_target_least_squares_arrow(pols_ctx *ctx, const pols_arrow_column *targets, const pols_arrow_column *features,
+                                          int32_t n_features, const pols_arrow_column *weights, const int64_t *group_offsets,
+                                          int64_t n_groups, int32_t add_intercept, const pols_ols_params *p, struct ArrowArray *out,
+                                          struct ArrowSchema *out_schema);
+/* recursive_least_squares / recursive_least_squares_coefficients (ex.rs:593-646) and rolling_least_squares /
+ * rolling_least_squares_coefficients (:648-701); mode POLS_MODE_PREDICTIONS: a primitive array named after the target, null where
+ * the validity mask of the null policy masks the row (make_predictions with is_valid, :640-645) or no estimate exists yet;
+ * POLS_MODE_COEFFICIENTS: a struct array "coefficients" with ONE ROW PER INPUT ROW, one field per feature (+ "const"), NaN -> null.
+ * Quirk kept: the reference's prediction form of RLS ignores initial_state_mean (ex.rs:636) -- pass NULL for it there. */
+int pols_recursive_least_squares_arrow(pols_ctx *ctx, const pols_arrow_column *target, const pols_arrow_column *features,
+                                       int32_t n_features, const pols_arrow_column *weights, const int64_t *group_offsets,
+                                       int64_t n_groups, int32_t add_intercept, const pols_rls_params *p, int32_t mode,
+                                       struct ArrowArray *out, struct ArrowSchema *out_schema);
+int pols_rolling_least_squares_arrow(pols_ctx *ctx, const pols_arrow_column *target, const pols_arrow_column *features,
+                                     int32_t n_features, const pols_arrow_column *weights, const int64_t *group_offsets,
+                                     int64_t n_groups, int32_t add_intercept, const pols_rolling_params *p, int32_t mode,
+                                     struct ArrowArray *out, struct ArrowSchema *out_schema);
+/* predict (ex.rs:706-741): `coefficients` is the coefficients STRUCT Series of inputs[0] -- one row per input row (what Polars
+ * broadcasts / joins it to), n_features (+ 1 with add_intercept: the pl.lit(1.0) "const" feature of least_squares.py:479-483)
+ * numeric fields; null_policy is one of ignore / zero / drop (least_squares.py:474): features are zero-filled unless "ignore"
+ * (:725), "drop" nulls the rows with a null anywhere (:732-738).  out: a primitive array named `name` (NULL / "" -> "predictions"). */
+int pols_predict_arrow(pols_ctx *ctx, const pols_arrow_column *coefficients, const pols_arrow_column *features, int32_t n_features,
+                       int32_t add_intercept, int32_t null_policy, const char *name, struct ArrowArray *out,
+                       struct ArrowSchema *out_schema);
+
 /* ---- more than one GPU ------------------------------------------------------------------------------------------------
  * Groups are independent in the reference -- every plugin call sees one group's rows, nothing in src/least_squares.rs carries
  * state across groups, and Polars runs the calls concurrently on its rayon pool (README.md:19) -- so the data path has NO

@@ -54,12 +54,21 @@ int orc_max_threads(void) {
 }
 
 /* faer `cholesky(Side::Lower)` (ls.rs:23,289): plain LL^T, Err on a
- * non-positive (or NaN) pivot. */
+ * non-positive (or NaN) pivot.  On an exactly singular matrix the last pivot
+ * is 0 in exact arithmetic and +/- a few ulps of a_jj as computed -- a coin
+ * flip between "failed" and a division by rounding noise.  The reference
+ * holds one vector for that case: the collinear frame of the demo notebook,
+ * cell 30, prints "Cholesky decomposition failed, falling back to LU" and
+ * {null, null, null}.  A pivot within 16 k eps of a_jj therefore counts as
+ * non-positive here (and in the HIP kernels), which pins that outcome instead
+ * of leaving it to the summation order. */
 static int chol_factor(double *l, int k) {
+    const double tol = 16.0 * (double)k * 2.220446049250313e-16;
     for (int j = 0; j < k; ++j) {
         double d = l[j * k + j];
+        const double ajj = d;
         for (int p = 0; p < j; ++p) d -= l[j * k + p] * l[j * k + p];
-        if (!(d > 0.0)) return 1;
+        if (!(d > tol * ajj)) return 1;
         d = sqrt(d);
         l[j * k + j] = d;
         for (int i = j + 1; i < k; ++i) {

@@ -167,7 +167,6 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_SHAPE")) { o.k1_shape_team = on && ieq(v, "team"); o.k1_shape_wave = on && ieq(v, "wave"); }
     else if (ieq(key, "K1_F64_TEAM")) o.k1_f64_team256 = on && std::atoi(v) == 256;
     else if (ieq(key, "KG_NOYV")) o.kg_noyv = on;
-    else if (ieq(key, "FUSED_FIXUP")) o.fused_fixup = on;
     else if (ieq(key, "K2_NOPREFETCH")) o.k2_noprefetch = on;
     else if (ieq(key, "K1_PASSES")) o.k1_passes = on ? std::atoi(v) : d.k1_passes;
     else if (ieq(key, "K1T_RC4")) o.k1t_rc4 = on ? (std::atoi(v) != 0) : d.k1t_rc4;
@@ -185,7 +184,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
-                                       "KG_NOYV", "FUSED_FIXUP", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
+                                       "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE"};
     char name[64];
     for (const char *k : keys) {
@@ -662,7 +661,7 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         POLS_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->fb_flag), 256));
         POLS_HIP(hipMemsetAsync(ctx->fb_flag, 0, 256, ctx->stream));
     }
-    ctx->epoch = (ctx->epoch % 0x0ffffff0) + 1;   // (epoch << 3 | status) must fit an int32 (fused fix-up tags)
+    ctx->epoch = (ctx->epoch % 0x0ffffff0) + 1;
 
     WideArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -784,10 +783,16 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             POLS_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->fb_flag), 256));
             POLS_HIP(hipMemsetAsync(ctx->fb_flag, 0, 256, ctx->stream));
         }
-        ctx->epoch = (ctx->epoch % 0x0ffffff0) + 1;   // (epoch << 3 | status) must fit an int32 (fused fix-up tags)
+        ctx->epoch = (ctx->epoch % 0x0ffffff0) + 1;
     }
     const bool ols_branch = !enet && ridge_alpha == 0.0 && (m == POLS_SOLVE_AUTO || m == POLS_SOLVE_SVD || m == POLS_SOLVE_QR) && alpha == 0.0;
-    const double pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : 0.0;
+    // Ridge branch: the reference solves the same normal equations in f64, so an f64 batch flags only a failed factorisation; an f32
+    // batch also flags pivots that say cond(X'X + alpha I) * eps_f32 would exceed the 1e-4 tolerance -- those groups get the
+    // reference's own chain (Cholesky -> LU) in f64 from the fix-up pass.
+    // A pivot within 16 k eps of its diagonal entry is rounding noise around the exact 0 of a singular matrix: it counts as a failed
+    // factorisation ("Cholesky decomposition failed, falling back to LU", demo notebook cell 30) rather than a coin flip.
+    const double chol_noise = 16.0 * (double)kt * 2.220446049250313e-16;
+    const double pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : (b->dtype == POLS_F32 && m != POLS_SOLVE_SVD ? 1e-3 : chol_noise);
     K6Args ka;
     int fix_workers = 0;
     auto prepare_fix = [&](int max_workers = 64) -> int {       // arguments + work area of the fix-up pass
@@ -813,6 +818,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // noise, far below the 1e-14-relative singular values the reference's test_fit_multi_collinear expects to be resolved.
         const double eps_nk = 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt);
         ka.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
+        // ... and the solver itself is the one the reference runs for this (branch, solve_method): solve_ols None -> pivoted QR when
+        // n > k else SVD (ls.rs:224-231), "qr" -> QR, "svd" -> SVD; solve_ridge None / "chol" -> Cholesky then LU, "lu" -> LU (:352-363)
+        ka.mode = ols_branch ? (m == POLS_SOLVE_AUTO ? K6_OLS_AUTO : m == POLS_SOLVE_QR ? K6_OLS_QR : K6_MINNORM)
+                             : (m == POLS_SOLVE_SVD ? K6_MINNORM : m == POLS_SOLVE_LU ? K6_LU : K6_CHOL_LU);
         ka.k_user = b->n_features; ka.kt = kt;
         ka.valid = st.valid; ka.null_policy = pol;
         fix_workers = w_use;
@@ -956,22 +965,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.k_user = b->n_features;
     a.null_policy = pol;
-    // The wave-per-group kernels can carry the fix-up pass as trailing workgroups of the same launch (no second dispatch in the
-    // common no-flag case); everything is prepared for it here and k1_launch says whether the chosen variant took it.
     if ((rc = prepare_fix())) return rc;
-    // Opt-in (POLS_FUSED_FIXUP=1): measured on cfg2 it saves 1 % end to end (74.3 vs 75.2 us per call -- the no-op fix-up dispatch
-    // mostly overlaps the next call's ramp-up) but the polling tail lengthens the solver kernel itself by ~2 us.
-    if (ctx->opt.fused_fixup) {
-        void *tg = nullptr;                                   // persistent tag words; a fresh (or re-grown) buffer is cleared once
-        const void *before = ctx->scratch[8].ptr;
-        if ((rc = ensure_scratch(ctx, 8, sizeof(int32_t) * (size_t)b->n_groups, &tg))) return rc;
-        if (tg != before) POLS_HIP(hipMemsetAsync(tg, 0, ctx->scratch[8].cap, ctx->stream));
-        a.fix = ka; a.fix.tags = static_cast<const int32_t *>(tg); a.fix.fb_flag = nullptr;
-        a.n_k1_blocks = fix_workers; a.tags = static_cast<int32_t *>(tg);
-    }
-    ctx->last_fused = false;
     if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
-    if (!ctx->last_fused && (rc = k6_launch(ctx, b->dtype, ka, fix_workers))) return rc;
+    if ((rc = k6_launch(ctx, b->dtype, ka, fix_workers))) return rc;
     return finish(nullptr);
 }
 
@@ -1007,12 +1003,15 @@ int pols_multi_target_least_squares(pols_ctx *ctx, const pols_batch *b, const vo
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
     if (kt + n_targets > K8_KMAX) return fail(POLS_ERR_UNSUPPORTED, "%d columns + %d targets > %d", kt, n_targets, K8_KMAX);
     if (b->n_groups == 0) return POLS_OK;
-    if ((p->null_policy != POLS_NULL_IGNORE && !b->null_free) || b->valid) {
+    // "ignore" is NOT the identity here: the multi-target body builds both arrays with construct_features_array(.., true)
+    // (src/expressions.rs:546-547), so nulls the policy leaves in place -- targets included -- are zero-filled: "ignore" == "zero".
+    const int policy = p->null_policy == POLS_NULL_IGNORE ? POLS_NULL_ZERO : p->null_policy;
+    if (!b->null_free || b->valid) {
         // The plugin body under a null policy (src/expressions.rs:521-591): the joint validity mask over every target (and, unless
         // drop_y_zero_x, every feature), the fit on the rows handle_nulls leaves -- compacted on the device --, then predictions for
         // EVERY row from the zero-filled features, masked under "drop".
         Compacted c;
-        if ((rc = compact_nulls(ctx, &bb, p->null_policy, &c, y_cols, n_targets))) return rc;
+        if ((rc = compact_nulls(ctx, &bb, policy, &c, y_cols, n_targets))) return rc;
         const bool host = b->mem == POLS_MEM_HOST;
         const size_t G = (size_t)b->n_groups, N = (size_t)b->n_rows, sz = dtype_size(b->dtype);
         const size_t coefb = round256(sz * G * n_targets * kt), statb = round256(sizeof(int32_t) * G), colb = round256(sz * std::max<size_t>(N, 1));

@@ -50,7 +50,6 @@ struct Options {
     bool k1_shape_wave = false;   // POLS_K1_SHAPE=wave  f32: wave-per-group even where the 256-thread team is the default
     bool k1_f64_team256 = false;  // POLS_K1_F64_TEAM=256
     bool kg_noyv = false;         // POLS_KG_NOYV        streamed Gram: keep the target in a second MFMA tile at 16 columns
-    bool fused_fixup = false;     // POLS_FUSED_FIXUP    K1 wave kernels carry the fix-up pass as trailing workgroups
     int k1_passes = 0;            // POLS_K1_PASSES      0: default
     int k1t_rc4 = -1;             // POLS_K1T_RC4        -1: default rule
     int static_engine = 0;        // POLS_STATIC_ENGINE  0 auto, 1 "stream" (three launches), 2 "k2" (wherever it fits), 3 "nok2"
@@ -78,7 +77,7 @@ struct pols_ctx {
     int num_cus = 0;
     // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] fix-up work area,
     // [4] staged targets / statistics of HOST batches, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean,
-    // [7] status words, [8] fused fix-up tags, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
+    // [7] status words, [8] (free), [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
     pols::Scratch scratch[16];
@@ -110,7 +109,6 @@ struct pols_ctx {
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag
     int32_t epoch = 0;
     bool offs_aligned[2] = {false, false};   // every group start AND size a multiple of 2 / of 4 rows
-    bool last_fused = false;                 // the last K1 launch carried its own fix-up workers
     // cache of the chunk tables of the dynamic kernels (scratch slot 4) for mask-free batches: rebuilt only when the
     // offsets, min_periods or the chunk length change
     struct { uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;

@@ -22,7 +22,6 @@
 #pragma once
 
 #include "common.hpp"
-#include "k6_svd.hpp"
 
 namespace pols {
 
@@ -46,15 +45,6 @@ struct K1Args {
     int32_t k_user;                      // KT - add_intercept
     int64_t skip_group;                  // K1p: the group a single wave handles after the persistent loop (or -1)
     unsigned long long *dbg;             // POLS_TIMELINE=1: 8 s_memtime stamps per group (debug only)
-    // Fused fix-up (wave-per-group FAST kernels): the grid carries `gridDim.x - n_k1_blocks` trailing fix-up workgroups.  They
-    // are dispatched last; each polls the TAGS of its own groups -- one word per group, (epoch << 3 | status), stored
-    // write-through (agent scope) by the group's solver wave -- until they carry this call's epoch, and runs the K6 body on
-    // the flagged ones.  The common no-flag case then costs one extra 4-byte store per group instead of a second dispatch
-    // (3.9 us + two kernel boundaries per call).  A solver wave does not write the outputs of a group it flags, so nothing
-    // but the tag passes between workgroups of the launch.  No counters, no read-modify-write atomics.
-    int32_t n_k1_blocks;                 // 0: not fused; on entry to k1_launch: the number of fix-up workers prepared for
-    int32_t *tags;                       // n_groups words, persistent across calls (a stale epoch never matches)
-    K6Args fix;                          // arguments of the fix-up body (work area sized for gridDim.x - n_k1_blocks workers)
 };
 
 // Launches the (dtype, KT, team, resident-chunks) variant that fits max_group_rows.

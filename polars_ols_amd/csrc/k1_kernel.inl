@@ -1,6 +1,5 @@
 // k1_kernel.inl -- body of K1 (see k1_gram_chol.hpp for the design notes).  Included by k1_{f32,f64}_*.hip and k1n_{f32,f64}_*.hip, a few column counts per unit.
 #include "k1_gram_chol.hpp"
-#include "k6_body.inl"
 
 #ifndef K1_RAGGED_VECTOR_LOADS
 #define K1_RAGGED_VECTOR_LOADS 1
@@ -510,38 +509,14 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 // NPASS > 1 (every row resident -- FAST, or the host checked max_rows against the capacity): the Gram is accumulated in NPASS passes
 // over the resident registers, each keeping 1 / NPASS of the
 // accumulators live -- fewer VGPRs, one more workgroup per CU for the f64 team kernel.
-// Trailing workgroups of a fused launch (see K1Args::n_k1_blocks): worker w owns the groups w, w + n_workers, ...
-template <typename T>
-__device__ __forceinline__ void k1_fixup_worker(const K1Args &a) {
-    __shared__ int any_flagged;
-    const int worker = (int)blockIdx.x - a.n_k1_blocks, n_workers = (int)gridDim.x - a.n_k1_blocks;
-    if (threadIdx.x == 0) any_flagged = 0;
-    __syncthreads();
-    bool mine = false;
-    for (int64_t g = worker + (int64_t)n_workers * threadIdx.x; g < a.n_groups; g += (int64_t)n_workers * 256) {
-        int32_t t;
-        while (((t = __hip_atomic_load(&a.tags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 3) != a.epoch)
-            __builtin_amdgcn_s_sleep(4);                       // the group's solver wave has not finished yet
-        mine = mine || (t & 7) == POLS_GROUP_FALLBACK;
-    }
-    if (mine) any_flagged = 1;
-    __syncthreads();
-    if (!any_flagged) return;                                  // the common case: one round of loads
-    k6_process<T>(a.fix, worker, n_workers);
-}
-
 // EDGE (with FAST): the branch-free form for RAGGED frames whose groups stay resident -- every load of every chunk issued up front
 // like FAST (unconditional, clamped into the columns), then the rows outside [s, e) -- the head / tail chunks' neighbours' rows --
 // zeroed in registers; stores of edge chunks guarded per row.  The general (FAST = false) code loads chunk by chunk inside per-lane
 // branches: with the same group sizes it runs 797 vs 679 us (130..252 rows) and 118 vs 91 us (100..300 rows) behind FAST.
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false,
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool NT = false,
           bool EDGE = false>
 __device__ __forceinline__ void k1_body(const K1Args &a) {
-    static_assert(!EDGE || (FAST && !FUSED), "EDGE refines FAST");
-    static_assert(!FUSED || TEAM == 64, "the fused fix-up counts solver WAVES");
-    if constexpr (FUSED) {
-        if ((int)blockIdx.x >= a.n_k1_blocks) { k1_fixup_worker<T>(a); return; }
-    }
+    static_assert(!EDGE || FAST, "EDGE refines FAST");
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
     constexpr int NACC = NZ * (NZ + 1) / 2;
@@ -653,7 +628,6 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
     // ---- K x K solve on wave-uniform values: ONE wave per team solves (the others would only burn the
     // SIMDs' VALU issue slots that co-resident workgroups need), beta goes back through LDS
     T beta[KT];
-    bool flagged = false;                                    // FUSED: this wave's group goes to the fix-up workers
     if constexpr (NPASS > 1) {
         constexpr int TEAMS = 256 / TEAM;                          // one scratch set per team of the block
         __shared__ T gsum_s[TEAMS][NACC + 3], lfac_s[TEAMS][KT * KT], lrinv_s[TEAMS][KT];
@@ -703,19 +677,15 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
             const bool ok = chol_solve<T, KT>(acc, (T)a.alpha, beta, (T)a.pivot_tol);
             if (!ok) {                                       // K6 re-solves this group
                 st = POLS_GROUP_FALLBACK;
-                flagged = true;
                 if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch;
             }
         }
         if (tid == 0 && a.status) a.status[g] = st;
-        if constexpr (FUSED) {                               // publish this group's verdict to the fix-up workers
-            if (tid == 0) __hip_atomic_store(&a.tags[g], (a.epoch << 3) | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (tid < KT) {
             T bv = T(0);
 #pragma unroll
             for (int j = 0; j < KT; ++j) bv = (tid == j) ? beta[j] : bv;
-            if (a.coef && !(FUSED && flagged)) static_cast<T *>(a.coef)[g * KT + tid] = bv;
+            if (a.coef) static_cast<T *>(a.coef)[g * KT + tid] = bv;
             if constexpr (WAVES > 1) bcast[tid] = bv;
         }
     }
@@ -729,7 +699,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 
     K1_STAMP(4);
     // ---- fused predictions / residuals from the resident rows, then the streamed overflow rows
-    if ((a.pred || a.resid) && !(FUSED && flagged)) {       // a flagged group's outputs belong to the fix-up workers
+    if (a.pred || a.resid) {
 #pragma unroll
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
@@ -748,22 +718,22 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 #undef K1_STAMP
 }
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false, bool NT = false,
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool NT = false,
           bool EDGE = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, NT, EDGE>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, NT, EDGE>(a);
 }
 // The same body held to 128 VGPRs (four waves per SIMD): the ragged one-chunk-per-lane wave kernel needs 130.
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k1_kernel_occ4(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a);
 }
 
 // (the null-policy wave kernel with 16 resident rows sits at exactly 256 VGPRs; one more value and the allocator reaches for an AGPR,
 // which halves the occupancy of the unified register file: 80.7 -> 132 us on 10 000 x 1 000 x 8.  Held to two waves per SIMD.)
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k1_kernel_occ2(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a);
 }
 
 // One chunk of a small ragged group, branch-free: the 16-byte loads of every column issued unconditionally (lanes without a chunk
@@ -923,9 +893,7 @@ static int k1t_launch(pols_ctx *ctx, const K1Args &a) {
     const int64_t blocks = (a.n_groups + per_block - 1) / per_block;
     if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     ctx->last_kernel = name;
-    ctx->last_fused = false;
     K1Args aa = a;
-    aa.n_k1_blocks = 0;
     hipEvent_t ev0, ev1;
     if (timing_pair(ctx, &ev0, &ev1))
         hipExtLaunchKernelGGL((k1t_kernel<T, KT, HAS_W, K1T_SUB, K1T_RC>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, aa);
@@ -1186,9 +1154,7 @@ static int k1p_launch(pols_ctx *ctx, const K1Args &a) {
     const int64_t want = (a.n_groups + 4 * GPW - 1) / (4 * GPW);
     const int64_t blocks = std::min<int64_t>(want, (int64_t)ctx->num_cus * occ);
     ctx->last_kernel = name;
-    ctx->last_fused = false;
     K1Args aa = a;
-    aa.n_k1_blocks = 0;
     aa.skip_group = (a.n_rows % Vec16<T>::N == 0) ? -1 : ctx->offs_tail_group;   // the chunk grid crosses the end of the columns
     if constexpr (KT == 8 && !HAS_W) {
         if (ctx->opt.timeline) {                             // phase cycles summed per persistent wave (debug): 7 "stamps" = 6 phases
@@ -1213,7 +1179,7 @@ static int k1p_launch(pols_ctx *ctx, const K1Args &a) {
 }
 #endif
 
-template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool FUSED = false>
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     char name[96];
     char passes[8] = "";
@@ -1227,11 +1193,6 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     K1Args aa = a;
-    ctx->last_fused = FUSED;
-    if constexpr (FUSED) {
-        aa.n_k1_blocks = (int32_t)blocks;
-        blocks += a.n_k1_blocks;                             // a.n_k1_blocks carries the number of fix-up workers on entry
-    }
     const bool timeline = ctx->opt.timeline;
     if (timeline) {
         void *d = nullptr;
@@ -1240,30 +1201,30 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         aa.dbg = static_cast<unsigned long long *>(d);
     }
     hipEvent_t ev0, ev1;
-    constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !FUSED && !NULLS;
-    void (*kern)(const K1Args) = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
+    constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !NULLS;
+    void (*kern)(const K1Args) = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>;
     // the f32 wave-per-group FAST kernel (BASELINE configs[1]) reads its columns with `nt` (streaming) loads: every line is used
     // once, so it should not compete for L2 with lines that are -- 73.2-73.3 against 74.3-75.0 us per 400 MB launch
     // (POLS_K1_NT_LOADS=0 selects the plain-load build of the same kernel)
     // (the f64 two-wave kernel of cfg3 as well: 169-173 against 173-174 us per call; the f32 256-thread team from 8 columns: 71.9 vs
     // 72.4 us at 8 -- but 57.8 vs 50.4 us at 6 columns, where the plain loads win by far)
     constexpr bool HAS_NT = ((sizeof(T) == 4 && TEAM == 64 && RC == 4 && NPASS == 1) || (sizeof(T) == 4 && TEAM == 256 && RC == 1 && KT >= 8 && KT <= 10) || (sizeof(T) == 8 && TEAM == 128 && RC == 4 && NPASS == 2 && KT <= 8)) &&
-                            FAST && !NULLS && !FUSED;
+                            FAST && !NULLS;
     if constexpr (HAS_NT) {
-        if (ctx->opt.k1_nt_loads != 0) { kern = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED, true>; std::strcat(name, "_nt"); }
+        if (ctx->opt.k1_nt_loads != 0) { kern = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, true>; std::strcat(name, "_nt"); }
     }
     if constexpr (OCC4) {
-        if (!ctx->opt.k1_noocc4) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
+        if (!ctx->opt.k1_noocc4) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>;
     }
-    if constexpr (NULLS && sizeof(T) == 4 && TEAM == 64 && RC == 4 && KT <= 8 && !HAS_W && !FUSED)
-        kern = k1_kernel_occ2<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, FUSED>;
-    if constexpr (!FAST && !FUSED) {
+    if constexpr (NULLS && sizeof(T) == 4 && TEAM == 64 && RC == 4 && KT <= 8 && !HAS_W)
+        kern = k1_kernel_occ2<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>;
+    if constexpr (!FAST) {
         // ragged frames whose groups all stay resident: the branch-free EDGE form of the FAST kernel instead of the general code
         // (POLS_K1_NOEDGE=1 goes back)
         constexpr int VEC = Vec16<T>::N;
         const bool resident = ctx->offs_max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
         if (resident && a.n_rows >= VEC && !ctx->opt.k1_noedge && !ctx->opt.timeline) {
-            kern = k1_kernel<T, KT, HAS_W, TEAM, RC, true, NPASS, NULLS, false, false, true>;
+            kern = k1_kernel<T, KT, HAS_W, TEAM, RC, true, NPASS, NULLS, false, true>;
             std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d_edge%s%s", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", TEAM, RC,
                           passes, NULLS ? "_nulls" : "");
         }
@@ -1350,11 +1311,6 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         const bool resident = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
         if (npass == 3 && resident) return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
         if (npass == 2 && resident) return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
-    }
-    if constexpr (TEAM == 64) {
-        // wave-per-group: the launch can carry its own fix-up workers (a.n_k1_blocks = how many the host prepared for)
-        if (fast && a.n_k1_blocks > 0 && a.tags && !ctx->opt.timeline)
-            return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 1, false, true>(ctx, a);
     }
     return fast ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false>(ctx, a);
 #endif
@@ -1446,12 +1402,12 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         // Interleaved A/B on 10 000 x 1 000 rows (scripts/ab_headline.py, wall clock per call): 2 columns 26.4 vs 29.9 us, 4: 37.7 vs
         // 43.7, 6: 50.4 vs 58.3 (6.35 TB/s), 7: 62.3 vs 65.6, 8: 71.9 vs 73.2, 9: 78.6 vs 81.1, 10: 85.8 vs 89.0.  POLS_K1_SHAPE=wave
         // goes back.  Ragged frames too (their edge chunks take 16-byte loads + rows zeroed in registers): 900..1 020 rows 78.2 -> 71.8 us.
-        if (!ctx->opt.k1_shape_wave && need <= 256 * 1 * VEC && a.n_k1_blocks == 0)
+        if (!ctx->opt.k1_shape_wave && need <= 256 * 1 * VEC)
             return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
         // (the wave kernel with 16 rows per lane -- and its streamed overflow for frames a little beyond 1 024 rows -- is what
-        // POLS_K1_SHAPE=wave and the fused fix-up still use; by default the two-chunk team takes 1 025..2 048 rows: 950..1 100 rows
+        // POLS_K1_SHAPE=wave still uses; by default the two-chunk team takes 1 025..2 048 rows: 950..1 100 rows
         // 88.2 -> 85.6 us)
-        const bool wave_default = ctx->opt.k1_shape_wave || a.n_k1_blocks > 0;
+        const bool wave_default = ctx->opt.k1_shape_wave;
         if (want_wave && wave_default && (need <= wave_cap || (need <= 2 * wave_cap && ctx->offs_wave_overflow * 16 <= a.n_rows)))
             return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);

@@ -121,7 +121,9 @@ class Engine:
         for c in keep[1:]:
             if (c.numel() if dev else c.shape[0]) != n:
                 raise ValueError("all input series passed must be of equal length")  # src/expressions.rs:96-100
-        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        # a private COPY: every Plan promises the library (offsets_generation) that its offsets never change, which must not
+        # depend on what the caller does to the array it passed in afterwards
+        offs = np.array(offsets, dtype=np.int64, copy=True, order="C")
         colp = (C.c_void_p * len(cols))(*[ptr(c) for c in keep[1:]])
         b = L.Batch(dtype=dtype, mem=L.POLS_MEM_DEVICE if dev else L.POLS_MEM_HOST, n_rows=n,
                     n_groups=len(offs) - 1, group_offsets=offs.ctypes.data_as(C.POINTER(C.c_int64)),
@@ -177,13 +179,17 @@ class Engine:
 
     def multi_target_least_squares(self, y_cols: Sequence, x_cols: Sequence, offsets, *, weights=None, add_intercept: bool = False,
                                    alpha: float = 0.0, solve_method: Optional[str] = None, rcond: Optional[float] = None,
-                                   null_policy: str = "ignore", valid=None, want: Sequence[str] = ("pred", "coef")) -> Dict:
+                                   null_policy: str = "ignore", valid=None, null_free: bool = False,
+                                   want: Sequence[str] = ("pred", "coef")) -> Dict:
         """solve_multi_target (src/least_squares.rs:243-260) for every group: ONE Gram pass and ONE factorisation shared by all
         targets.  Returns ``pred`` (list of n_targets columns), ``coef`` [n_groups, n_targets, k], ``status`` [n_groups].
-        Null policies like the plugin body (src/expressions.rs:521-591): joint mask, fit on the rows it leaves, every row predicted."""
+        Null policies like the plugin body (src/expressions.rs:521-591): joint mask, fit on the rows it leaves, every row predicted;
+        "ignore" zero-fills the nulls it leaves in place (construct_features_array(.., true), :546-547).  ``null_free=True`` promises
+        that no target / feature / weight is null and skips the device-side null pass."""
         ys = list(y_cols)
         plan = self.plan_least_squares(ys[0], x_cols, offsets, weights=weights, add_intercept=add_intercept, alpha=alpha,
-                                       solve_method=solve_method, rcond=rcond, null_policy=null_policy, valid=valid, want=())
+                                       solve_method=solve_method, rcond=rcond, null_policy=null_policy, valid=valid, null_free=null_free,
+                                       want=())
         b = plan._b
         dev = b.mem == L.POLS_MEM_DEVICE
         like = plan._keep[0][0]
@@ -441,6 +447,118 @@ def _least_squares_arrow(self, target, features, *, target_name: str = "y", weig
 
 
 Engine.least_squares_arrow = _least_squares_arrow
+
+
+def _ols_params(lib, alpha=0.0, l1_ratio=None, max_iter=1000, tol=1e-5, positive=False, solve_method=None, rcond=None,
+                null_policy="ignore"):
+    p = L.OlsParams()
+    lib.pols_ols_params_default(C.byref(p))
+    p.alpha = float(alpha if alpha is not None else 0.0)
+    p.has_l1_ratio, p.l1_ratio = int(l1_ratio is not None), float(l1_ratio) if l1_ratio is not None else 0.0
+    p.max_iter, p.tol, p.positive = int(max_iter), float(tol), int(bool(positive))
+    p.solve_method = L.SOLVE_METHODS[solve_method]
+    p.has_rcond, p.rcond = int(rcond is not None), float(rcond) if rcond is not None else 0.0
+    p.null_policy = L.NULL_POLICIES[null_policy]
+    return p
+
+
+def _arrow_call(self, fn, first, first_name: str, features, weights, offsets, add_intercept: bool, tail_args):
+    """Shared marshalling of the pols_*_arrow entries: (ctx, first column, features, n, weights, offsets, n_groups, intercept,
+    *tail_args, out array, out schema) -> pyarrow Array."""
+    import pyarrow as pa
+
+    feats = list(features.items()) if isinstance(features, dict) else [("", f) for f in features]
+    ex_t = _ArrowExport(first_name, first)
+    ex_f = [_ArrowExport(n, f) for n, f in feats]
+    ex_w = _ArrowExport("sample_weights", weights) if weights is not None else None
+    try:
+        fcols = (L.ArrowColumn * len(ex_f))(*[e.column for e in ex_f])
+        offs = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int64)
+        out_a, out_s = (C.c_byte * 80)(), (C.c_byte * 72)()
+        rc = fn(self._h, C.byref(ex_t.column), fcols, len(ex_f), C.byref(ex_w.column) if ex_w else None,
+                offs.ctypes.data_as(C.POINTER(C.c_int64)) if offs is not None else None, 0 if offs is None else len(offs) - 1,
+                int(bool(add_intercept)), *tail_args, C.addressof(out_a), C.addressof(out_s))
+        L.check(rc)
+        return pa.Array._import_from_c(C.addressof(out_a), C.addressof(out_s))
+    finally:
+        for e in [ex_t] + ex_f + ([ex_w] if ex_w else []):
+            e.close()
+
+
+def _statistics_arrow(self, target, features, *, target_name: str = "y", weights=None, offsets=None, add_intercept: bool = False, **kw):
+    """``pols_least_squares_statistics_arrow`` (plugin least_squares_statistics, src/expressions.rs:448-509): the ``statistics``
+    struct, one row per group."""
+    p = _ols_params(self._lib, **kw)
+    return _arrow_call(self, self._lib.pols_least_squares_statistics_arrow, target, target_name, features, weights, offsets, add_intercept,
+                       (C.byref(p),))
+
+
+def _multi_target_arrow(self, targets, features, *, weights=None, offsets=None, add_intercept: bool = False, **kw):
+    """``pols_multi_target_least_squares_arrow`` (src/expressions.rs:511-591): ``targets`` is a pyarrow StructArray (or a chunked
+    one); returns the ``predictions`` struct with the same field names."""
+    p = _ols_params(self._lib, **kw)
+    return _arrow_call(self, self._lib.pols_multi_target_least_squares_arrow, targets, "y", features, weights, offsets, add_intercept,
+                       (C.byref(p),))
+
+
+def _rls_arrow(self, target, features, *, target_name: str = "y", weights=None, offsets=None, add_intercept: bool = False,
+               mode: str = "predictions", half_life: Optional[float] = None, initial_state_covariance: Optional[float] = 10.0,
+               initial_state_mean=None, null_policy: str = "drop"):
+    """``pols_recursive_least_squares_arrow`` (src/expressions.rs:593-646)."""
+    p = L.RlsParams()
+    self._lib.pols_rls_params_default(C.byref(p))
+    p.has_half_life, p.half_life = int(half_life is not None), float(half_life) if half_life is not None else 0.0
+    p.initial_state_covariance = float(10.0 if initial_state_covariance is None else initial_state_covariance)
+    mean = None
+    if initial_state_mean is not None and mode == "coefficients":          # ex.rs:636: the prediction form passes None
+        kt = len(features) + int(bool(add_intercept))
+        mean = np.ascontiguousarray(np.broadcast_to(np.asarray(initial_state_mean, dtype=np.float64), (kt,)))
+        p.initial_state_mean = mean.ctypes.data_as(C.POINTER(C.c_double))
+    p.null_policy = L.NULL_POLICIES[null_policy]
+    return _arrow_call(self, self._lib.pols_recursive_least_squares_arrow, target, target_name, features, weights, offsets, add_intercept,
+                       (C.byref(p), {"predictions": 0, "coefficients": 2}[mode]))
+
+
+def _rolling_arrow(self, target, features, *, window_size: int, target_name: str = "y", weights=None, offsets=None,
+                   add_intercept: bool = False, mode: str = "predictions", min_periods: Optional[int] = None,
+                   use_woodbury: Optional[bool] = None, alpha: Optional[float] = None, null_policy: str = "drop_window"):
+    """``pols_rolling_least_squares_arrow`` (src/expressions.rs:648-701)."""
+    p = L.RollingParams()
+    self._lib.pols_rolling_params_default(C.byref(p))
+    p.window_size = int(window_size)
+    p.min_periods = -1 if min_periods is None else int(min_periods)
+    p.use_woodbury = -1 if use_woodbury is None else int(bool(use_woodbury))
+    p.alpha = float(alpha) if alpha is not None else 0.0
+    p.null_policy = L.NULL_POLICIES[null_policy]
+    return _arrow_call(self, self._lib.pols_rolling_least_squares_arrow, target, target_name, features, weights, offsets, add_intercept,
+                       (C.byref(p), {"predictions": 0, "coefficients": 2}[mode]))
+
+
+def _predict_arrow(self, coefficients, features, *, add_intercept: bool = False, null_policy: str = "zero", name: Optional[str] = None):
+    """``pols_predict_arrow`` (src/expressions.rs:706-741): ``coefficients`` is a pyarrow StructArray with one row per input row."""
+    import pyarrow as pa
+
+    feats = list(features.items()) if isinstance(features, dict) else [("", f) for f in features]
+    ex_c = _ArrowExport("coefficients", coefficients)
+    ex_f = [_ArrowExport(n, f) for n, f in feats]
+    try:
+        fcols = (L.ArrowColumn * len(ex_f))(*[e.column for e in ex_f])
+        out_a, out_s = (C.c_byte * 80)(), (C.c_byte * 72)()
+        rc = self._lib.pols_predict_arrow(self._h, C.byref(ex_c.column), fcols, len(ex_f), int(bool(add_intercept)),
+                                          L.NULL_POLICIES[null_policy], name.encode() if name else None, C.addressof(out_a),
+                                          C.addressof(out_s))
+        L.check(rc)
+        return pa.Array._import_from_c(C.addressof(out_a), C.addressof(out_s))
+    finally:
+        for e in [ex_c] + ex_f:
+            e.close()
+
+
+Engine.least_squares_statistics_arrow = _statistics_arrow
+Engine.multi_target_least_squares_arrow = _multi_target_arrow
+Engine.recursive_least_squares_arrow = _rls_arrow
+Engine.rolling_least_squares_arrow = _rolling_arrow
+Engine.predict_arrow = _predict_arrow
 
 
 class Comm:

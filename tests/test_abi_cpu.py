@@ -120,8 +120,7 @@ def test_header_is_plain_c_and_links(tmp_path):
 def test_hot_kernels_keep_their_arrays_in_registers():
     """The code objects' own metadata (no GPU, no recompilation): none of the HBM-bound static kernels may hold an array in scratch
     memory -- private_segment_fixed_size 0.  A lambda around K1's loads once put the ragged kernels' chunks in scratch (736 bytes per
-    lane, 4x slower) without a single compiler warning; this pins it.  Allowed: the fused-fix-up K1 builds (an SGPR spill slot) and
-    the ragged one-chunk kernel that is deliberately held to 128 VGPRs."""
+    lane, 4x slower) without a single compiler warning; this pins it."""
     import sys
 
     sys.path.insert(0, str(ROOT / "scripts"))
@@ -135,8 +134,7 @@ def test_hot_kernels_keep_their_arrays_in_registers():
     assert len(ks) > 500, len(ks)
     hot = ("pols::k1_kernel<", "pols::k1t_kernel<", "pols::k1p_kernel<", "pols::k1m_kernel<", "pols::k2_kernel<", "pols::gram_stream_kernel<",
            "pols::predict_kernel<", "pols::gram_solve_kernel<", "pols::take_kernel<", "pols::arrow_ingest_kernel<")
-    bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0
-           and not k.rstrip().endswith("true, false, false>(pols::K1Args)")}   # FUSED = true, NT = false, EDGE = false: the fused fix-up builds
+    bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0}
     assert not bad, sorted(bad.items())[:5]
 
 
@@ -155,13 +153,13 @@ def test_bench_kernels_keep_two_waves_per_simd():
         _lib.build()
     ks = kernel_scratch(_lib.LIB_PATH)
     want = {
-        "pols::k1_kernel<float, 8, false, 256, 1, true, 2, false, false, true, false>(": 96,       # configs[1]: 256-thread team, two passes, nt loads
-        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, true, false>(": 256,       # ... and the wave-per-group form (ragged frames)
-        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, false, false>(": 256,
-        "pols::k1_kernel_occ2<float, 8, false, 64, 4, true, 1, true, false>(": 256,         # configs[1] under a null policy
-        "pols::k1_kernel<double, 8, true, 128, 4, true, 2, false, false, true, false>(": 256,      # configs[2]
-        "pols::k1_kernel<float, 9, false, 64, 4, true, 3, false, false, false, false>(": 256,
-        "pols::k1_kernel<float, 8, false, 64, 1, true, 1, false, false, false, true>(": 128,    # ragged year-sized groups: the EDGE wave kernel      # smoke(): 8 features + intercept
+        "pols::k1_kernel<float, 8, false, 256, 1, true, 2, false, true, false>(": 96,       # configs[1]: 256-thread team, two passes, nt loads
+        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, true, false>(": 256,       # ... and the wave-per-group form (ragged frames)
+        "pols::k1_kernel<float, 8, false, 64, 4, true, 1, false, false, false>(": 256,
+        "pols::k1_kernel_occ2<float, 8, false, 64, 4, true, 1, true>(": 256,         # configs[1] under a null policy
+        "pols::k1_kernel<double, 8, true, 128, 4, true, 2, false, true, false>(": 256,      # configs[2]
+        "pols::k1_kernel<float, 9, false, 64, 4, true, 3, false, false, false>(": 256,
+        "pols::k1_kernel<float, 8, false, 64, 1, true, 1, false, false, true>(": 128,    # ragged year-sized groups: the EDGE wave kernel      # smoke(): 8 features + intercept
         "pols::k2_kernel<double, 16, 8, 2, true, false>(": 256,                             # configs[4]
     }
     for key, cap in want.items():

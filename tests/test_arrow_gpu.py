@@ -72,7 +72,7 @@ def test_arrow_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt
     else:
         assert got.null_count == 0
     got = eng.least_squares_arrow(_arrow(y, chunks=chunks, slice_pad=pad), feats, mode="residuals", **args)
-    assert np.allclose(_np(got), resid, rtol=tol, atol=10 * tol, equal_nan=True)
+    assert np.allclose(_np(got), resid, rtol=tol, atol=tol, equal_nan=True)
     assert got.type == (pa.float32() if dtype == np.float32 else pa.float64())
 
 

@@ -170,8 +170,9 @@ def test_max_iter_reached_is_reported(eng):
 
 
 def test_empty_tiny_and_flagged_groups(eng):
-    """Empty groups give zeros (ex.rs:357-359); a rank-deficient group on the OLS branch is flagged and re-solved by the Jacobi-SVD
-    pass (minimum norm, like the reference's dgelsd), its neighbours are untouched."""
+    """Empty groups give zeros (ex.rs:357-359); rank-deficient groups on the OLS branch are flagged and re-solved by the fix-up pass
+    with the reference's own solver for them (ls.rs:224-231: pivoted QR -> basic solution when n > k, dgelsd's minimum norm when
+    n <= k), their neighbours are untouched."""
     from oracle import orc
 
     rng = np.random.default_rng(12)
@@ -190,12 +191,12 @@ def test_empty_tiny_and_flagged_groups(eng):
     coef = _np(out["coef"])
     assert np.array_equal(coef[[0, 2, 5]], np.zeros((3, k)))
     ref = orc.batched_least_squares(y, cols, offs)
-    for g in (1, 6):
-        assert np.allclose(coef[g], ref["coef"][g], rtol=1e-6, atol=1e-9)
-    X = np.stack([c[43:700] for c in cols], axis=1)
-    mn = np.linalg.lstsq(X, y[43:700], rcond=None)[0]
-    assert np.allclose(coef[4], mn, rtol=1e-6, atol=1e-8)                        # dgelsd's minimum-norm solution
-    assert np.allclose(_np(out["pred"])[43:700], X @ mn, rtol=1e-6, atol=1e-8)
+    for g in (1, 3, 4, 6):
+        assert np.allclose(coef[g], ref["coef"][g], rtol=1e-6, atol=1e-9), g
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-8)
+    assert (coef[4][2] == 0.0) != (coef[4][7] == 0.0)                           # one of the twins carries both, the other is exactly 0
+    X = np.stack([c[40:43] for c in cols], axis=1)
+    assert np.allclose(coef[3], np.linalg.lstsq(X, y[40:43], rcond=None)[0], rtol=1e-6, atol=1e-8)   # n < k: dgelsd's minimum norm
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

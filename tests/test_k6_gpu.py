@@ -74,20 +74,56 @@ def test_degenerate_groups_do_not_disturb_healthy_ones(eng, dtype):
     assert list(st) == [0, 1, 1, 1, 1, 0]                            # groups 1 and 4 have n < k
     tol = 1e-6 if dtype == np.float64 else 1e-4
     coef, pred = _np(out["coef"]), _np(out["pred"])
-    for g in (0, 5):                                                 # healthy groups: the reference's QR answer
+    # EVERY group against the oracle's dispatch (ls.rs:224-231): more rows than columns -> the pivoted QR, whose answer on a
+    # rank-deficient group is the BASIC solution (dependent / zero columns get coefficient 0: the reference's notebook prints
+    # {1.0, 2.0, -0.0} for it, cell 28); n <= k -> dgelsd's minimum-norm answer
+    for g in range(6):
         sl = slice(offs[g], offs[g + 1])
         ref = orc.batched_least_squares(y[sl], [c[sl] for c in cols], [0, sizes[g]])
-        assert np.allclose(coef[g], ref["coef"][0], rtol=tol, atol=tol)
-        assert np.allclose(pred[sl], ref["pred"], rtol=tol, atol=tol)
-    for g in (1, 2, 3, 4):                                           # degenerate groups: dgelsd's minimum-norm answer
-        sl = slice(offs[g], offs[g + 1])
-        x = np.column_stack([c[sl].astype(np.float64) for c in cols])
-        exp = np.linalg.lstsq(x, y[sl].astype(np.float64), rcond=None)[0]
-        t = 1e-6 if dtype == np.float64 else 5e-3
-        assert np.allclose(x @ coef[g], x @ exp, rtol=t, atol=t)
-        assert np.allclose(pred[sl], x @ coef[g], rtol=t, atol=t)
-        if dtype == np.float64:
-            assert np.allclose(coef[g], exp, rtol=1e-6, atol=1e-8)
+        assert np.allclose(coef[g], ref["coef"][0], rtol=tol, atol=tol), g
+        assert np.allclose(pred[sl], ref["pred"], rtol=tol, atol=tol), g
+    assert coef[2][2] == 0.0 and coef[3][4] == 0.0                   # the all-zero column; the SECOND of the two identical columns
+    x3 = np.column_stack([c[offs[3]:offs[4]].astype(np.float64) for c in cols])
+    mn = np.linalg.lstsq(x3, y[offs[3]:offs[4]].astype(np.float64), rcond=None)[0]
+    assert not np.allclose(coef[3], mn, rtol=1e-3, atol=1e-3)        # ... which is NOT the minimum-norm solution ...
+    svd = eng.least_squares(yd, cd, offs, solve_method="svd", want=("coef",))
+    assert np.allclose(_np(svd["coef"])[3], mn, rtol=tol, atol=tol)  # ... that only solve_method="svd" returns (notebook cell 32)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("engine", [None, "k2", "stream"])
+def test_notebook_collinear_frame_every_method(eng, dtype, engine):
+    """The reference's own rank-deficient vectors (notebooks/polars_ols_demo.ipynb cells 26-34): x3 an exact copy of x2, y = x1 + x2 + x3.
+    "qr" / default -> {1, 2, -0}; "svd" -> {1, 1, 1}; "chol" / "lu" -> Cholesky fails, LU divides by an exactly zero pivot -> nulls.
+    Through every static engine (K1, K2, the streamed three-launch path), several groups at once."""
+    from refdata import notebook_make_data
+
+    d = notebook_make_data(n_samples=2_000, n_features=3, n_groups=5)
+    n = 500
+    cols, ys = [[], [], []], []
+    for g in range(4):                                               # four groups of 500 rows of the frame
+        sl = slice(g * n, (g + 1) * n)
+        x1, x2 = d["x1"][sl].astype(dtype), d["x2"][sl].astype(dtype)
+        for j, c in enumerate((x1, x2, x2)):
+            cols[j].append(c)
+        ys.append(((x1 + x2) + x2).astype(dtype))
+    cols = [np.concatenate(c) for c in cols]
+    y = np.concatenate(ys)
+    offs = np.arange(5, dtype=np.int64) * n
+    tol = 1e-9 if dtype == np.float64 else 1e-4
+    eng.set_option("STATIC_ENGINE", engine)
+    try:
+        for m, exp in (("qr", [1.0, 2.0, 0.0]), (None, [1.0, 2.0, 0.0]), ("svd", [1.0, 1.0, 1.0])):
+            out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, solve_method=m, want=("coef", "pred", "status"))
+            assert np.allclose(_np(out["coef"]), np.tile(exp, (4, 1)), rtol=tol, atol=tol), (m, _np(out["coef"]))
+            assert np.allclose(_np(out["pred"]), y, rtol=tol, atol=tol)
+            assert (_np(out["status"]) == 1).all()
+        for m in ("chol", "lu"):
+            out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, solve_method=m, want=("coef", "pred"))
+            assert np.isnan(_np(out["coef"])).all(), (m, _np(out["coef"]))
+            assert np.isnan(_np(out["pred"])).all()
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
 
 
 def test_nan_group_gives_nan_like_reference(eng):
@@ -134,34 +170,6 @@ def test_ridge_on_collinear_data_needs_no_fallback(eng):
     out = eng.least_squares(y, cols, [0, n], alpha=0.5, l1_ratio=0.0, want=("coef", "status"))
     ref = orc.batched_least_squares(y, cols, [0, n], alpha=0.5, l1_ratio=0.0)
     assert out["status"][0] == 0 and np.allclose(out["coef"], ref["coef"], rtol=1e-6, atol=1e-8)
-
-
-def test_fused_fixup_matches_two_launch_form(eng):
-    """POLS_FUSED_FIXUP=1: the wave-per-group launch carries its own fix-up workgroups (per-group epoch tags); the result must be
-    bit-identical to the default two-dispatch form, flagged groups included."""
-    import torch
-
-    rng = np.random.default_rng(3)
-    G, n, k = 1_000, 1_000, 8
-    cols = [torch.randn(G * n, device="cuda") for _ in range(k)]
-    y = sum(cols) + 0.1 * torch.randn(G * n, device="cuda")
-    flagged = sorted(rng.choice(G, size=17, replace=False).tolist())
-    for g in flagged:
-        cols[6][g * n:(g + 1) * n] = cols[1][g * n:(g + 1) * n]
-    offs = np.arange(G + 1, dtype=np.int64) * n
-    eng.set_option("K1_SHAPE", "wave")                   # the fused form exists for the wave-per-group kernel: same kernel on both sides
-    ref = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
-    torch.cuda.synchronize()
-    eng.set_option("FUSED_FIXUP", "1")
-    try:
-        for _ in range(5):
-            out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
-            torch.cuda.synchronize()
-            assert np.nonzero(out["status"].cpu().numpy() == 1)[0].tolist() == flagged
-            assert torch.equal(out["coef"], ref["coef"]) and torch.equal(out["pred"], ref["pred"])
-    finally:
-        eng.set_option("FUSED_FIXUP", None)
-        eng.set_option("K1_SHAPE", None)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

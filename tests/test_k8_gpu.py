@@ -248,7 +248,7 @@ def test_multi_target_rank_deficient_group_and_panics(eng):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
-@pytest.mark.parametrize("policy", ["drop", "zero", "drop_y_zero_x", "drop_zero"])
+@pytest.mark.parametrize("policy", ["drop", "zero", "drop_y_zero_x", "drop_zero", "ignore"])
 @pytest.mark.parametrize("k,m,weights,icpt,alpha", [(3, 2, False, False, 0.0), (5, 3, True, True, 0.7), (40, 5, False, True, 0.0)])
 def test_multi_target_null_policies_behind_the_cabi(eng, dtype, tol, policy, k, m, weights, icpt, alpha):
     """The plugin body under a null policy (src/expressions.rs:521-591) inside pols_multi_target_least_squares: the joint mask over
@@ -280,8 +280,9 @@ def test_multi_target_null_policies_behind_the_cabi(eng, dtype, tol, policy, k, 
     for g in range(len(offs) - 1):
         s, e = offs[g], offs[g + 1]
         kk = keep[s:e]
-        Xf = (np.nan_to_num(X[s:e]) if policy in ("zero", "drop_y_zero_x") else X[s:e])[kk] * sw[s:e][kk, None]
-        Yf = (np.nan_to_num(Y[s:e]) if policy == "zero" else Y[s:e])[kk] * sw[s:e][kk, None]
+        # "ignore" zero-fills too: both arrays come from construct_features_array(.., true) (ex.rs:546-547)
+        Xf = (np.nan_to_num(X[s:e]) if policy in ("zero", "drop_y_zero_x", "ignore") else X[s:e])[kk] * sw[s:e][kk, None]
+        Yf = (np.nan_to_num(Y[s:e]) if policy in ("zero", "ignore") else Y[s:e])[kk] * sw[s:e][kk, None]
         B = orc.solve_multi_target(Yf, Xf, alpha=alpha)                             # kt x m
         exp[s:e] = Xz[s:e] @ B
     if policy == "drop":
@@ -294,4 +295,4 @@ def test_multi_target_null_policies_behind_the_cabi(eng, dtype, tol, policy, k, 
     for res in (host, {"pred": [p.cpu().numpy() for p in dev["pred"]]}):
         got = np.column_stack([np.asarray(p, dtype=np.float64) for p in res["pred"]])
         assert np.array_equal(np.isnan(got), np.isnan(exp))
-        assert np.allclose(got, exp, rtol=tol, atol=10 * tol, equal_nan=True), float(np.nanmax(np.abs(got - exp)))
+        assert np.allclose(got, exp, rtol=tol, atol=tol, equal_nan=True), float(np.nanmax(np.abs(got - exp)))

@@ -98,7 +98,7 @@ def test_null_policies_vs_oracle(eng, dtype, tol, policy, k, weights, icpt, kw):
     assert np.array_equal(np.isnan(out["pred"]), np.isnan(pred))
     assert np.allclose(out["pred"], pred, rtol=tol, atol=tol, equal_nan=True)
     assert np.array_equal(np.isnan(out["resid"]), np.isnan(resid))
-    assert np.allclose(out["resid"], resid, rtol=tol, atol=10 * tol, equal_nan=True)
+    assert np.allclose(out["resid"], resid, rtol=tol, atol=tol, equal_nan=True)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
