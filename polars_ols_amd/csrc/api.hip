@@ -681,7 +681,9 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     a.positive = p->positive ? 1 : 0; a.active_set = (p->solve_method == POLS_SOLVE_CD_ACTIVE_SET) ? 1 : 0;
     // OLS branch (the reference solves it with a pivoted QR / dgelsd): groups whose pivots say cond(X)^2 would eat the
     // tolerance go to the Jacobi-SVD pass, exactly like the narrow path; ridge: only a failed factorisation is flagged
-    a.pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : 0.0;
+    // (ridge branch: an f32 batch flags what cond * eps_f32 would spoil, an f64 batch only a pivot within rounding noise of 0 -- see ls_core)
+    a.pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10)
+                             : (b->dtype == POLS_F32 && p->solve_method != POLS_SOLVE_SVD ? 1e-3 : 16.0 * (double)kt * 2.220446049250313e-16);
     const double eps_nk = 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt);   // see svd_fixup in ls_core
     a.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (p->solve_method == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
     a.status = st.status; a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
@@ -700,9 +702,14 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
         if ((rc = wide_chol_launch(ctx, b->dtype, a))) return rc;
         int workers = (int)std::min<size_t>(G, 64);
         void *wk = nullptr;
-        const int64_t ncmax = std::min<int64_t>(std::max<int64_t>(1, max_rows), kt);
+        // the solver the fix-up pass runs on a flagged group: the reference's own for this (branch, solve_method), see ls_core
+        const int sm = p->solve_method;
+        a.fix_mode = ols_branch ? (m > 1 ? FIX_MINNORM : sm == POLS_SOLVE_AUTO ? FIX_OLS_AUTO : sm == POLS_SOLVE_QR ? FIX_OLS_QR : FIX_MINNORM)
+                                : ((sm == POLS_SOLVE_SVD || m > 1) ? FIX_MINNORM : sm == POLS_SOLVE_LU ? FIX_LU : FIX_CHOL_LU);
+        const bool lu = fix_uses_lu(a.fix_mode);
+        const int64_t ncmax = lu ? kt : std::min<int64_t>(std::max<int64_t>(1, max_rows), kt);
         a.work_w_elems = (int64_t)(kt + m) * std::max<int64_t>(1, max_rows);
-        a.work_stride = a.work_w_elems + ncmax * ncmax + 2 * ncmax;
+        a.work_stride = a.work_w_elems + ncmax * ncmax + 2 * ncmax + (lu ? (int64_t)kt * m : 0);
         while (workers > 1 && (double)workers * (double)a.work_stride * 8.0 > 1e9) workers /= 2;
         if ((rc = ensure_scratch(ctx, 3, sizeof(double) * (size_t)workers * (size_t)a.work_stride, &wk))) return rc;
         a.work = static_cast<double *>(wk);
@@ -755,7 +762,8 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);
     if (b->n_groups == 0) return POLS_OK;
     if (kt > 31) {
-        const bool ols_b = !enet && ridge_alpha == 0.0 && alpha == 0.0;
+        // (solve_method "chol" / "lu" with alpha == 0 go through solve_ridge(alpha = 0), ex.rs:366-376: the RIDGE branch)
+        const bool ols_b = !enet && ridge_alpha == 0.0 && alpha == 0.0 && (m == POLS_SOLVE_AUTO || m == POLS_SOLVE_SVD || m == POLS_SOLVE_QR);
         if (info) return fail(POLS_ERR_INVALID, "internal: the wide statistics path calls wide_static itself");
         return wide_static(ctx, b, p, o, kt, enet, ridge_alpha, enet_l1, ols_b);
     }
@@ -820,8 +828,8 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         ka.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
         // ... and the solver itself is the one the reference runs for this (branch, solve_method): solve_ols None -> pivoted QR when
         // n > k else SVD (ls.rs:224-231), "qr" -> QR, "svd" -> SVD; solve_ridge None / "chol" -> Cholesky then LU, "lu" -> LU (:352-363)
-        ka.mode = ols_branch ? (m == POLS_SOLVE_AUTO ? K6_OLS_AUTO : m == POLS_SOLVE_QR ? K6_OLS_QR : K6_MINNORM)
-                             : (m == POLS_SOLVE_SVD ? K6_MINNORM : m == POLS_SOLVE_LU ? K6_LU : K6_CHOL_LU);
+        ka.mode = ols_branch ? (m == POLS_SOLVE_AUTO ? FIX_OLS_AUTO : m == POLS_SOLVE_QR ? FIX_OLS_QR : FIX_MINNORM)
+                             : (m == POLS_SOLVE_SVD ? FIX_MINNORM : m == POLS_SOLVE_LU ? FIX_LU : FIX_CHOL_LU);
         ka.k_user = b->n_features; ka.kt = kt;
         ka.valid = st.valid; ka.null_policy = pol;
         fix_workers = w_use;

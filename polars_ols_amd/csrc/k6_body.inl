@@ -15,165 +15,6 @@ __device__ __forceinline__ double k6_block_sum(double v, double *red) {   // red
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__device__ __forceinline__ double k6_wave_sum(double v) { return readlane63(wave_sum_row3(v)); }   // all 64 lanes active
-
-// solve_ols_qr (ls.rs:195-205; faer col_piv_qr().solve_lstsq) on the worker's f64 copy W = [kt columns | y], n rows each:
-// Householder QR with column pivoting (largest remaining column norm, the FIRST of tied columns), rank-revealing like LAPACK
-// dgelsy -- the factorisation stops at the first pivot with |R_jj| <= eps max(n, k) |R_00|, those columns get coefficient 0, the
-// leading block is back-substituted: on the reference's own collinear frame (demo notebook cell 28: x3 an exact copy of x2)
-// that is the printed {1.0, 2.0, -0.0}.
-// One wave per trailing column (dot, update and the column's new norm in one pass, no workgroup barrier inside a step).
-// cidx / cn: kt ints / doubles of LDS; result in beta[] (LDS), every thread returns after a barrier.
-__device__ __forceinline__ void k6_qr_basic(double *W, const int64_t n, const int kt, int *cidx, double *cn, double *beta) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int c = wv; c < kt; c += 4) {
-        const double *col = W + (size_t)c * n;
-        double s = 0.0;
-        for (int64_t r = lane; r < n; r += 64) s += col[r] * col[r];
-        s = k6_wave_sum(s);
-        if (lane == 0) { cn[c] = s; cidx[c] = c; }
-    }
-    __syncthreads();
-    const int steps = (int)(n < (int64_t)kt ? n : (int64_t)kt);
-    int rank = steps;
-    bool bad = false;                                              // NaN data: every coefficient NaN, like the reference's QR
-    double r00 = 0.0;
-    const double rank_tol = 2.220446049250313e-16 * (double)(n > kt ? n : (int64_t)kt);
-    double *yv = W + (size_t)kt * n;
-    for (int j = 0; j < steps; ++j) {
-        int best = j;
-        double bestn = -1.0;
-        for (int c = j; c < kt; ++c) { const double s = cn[c]; bad = bad || (s != s); if (s > bestn) { bestn = s; best = c; } }
-        if (bad) break;                                            // (block-uniform: every thread scanned the same LDS words)
-        __syncthreads();
-        if (tid == 0 && best != j) {
-            const int t = cidx[j]; cidx[j] = cidx[best]; cidx[best] = t;
-            const double u = cn[j]; cn[j] = cn[best]; cn[best] = u;
-        }
-        __syncthreads();
-        const double normx = sqrt(bestn);
-        if (j == 0) r00 = normx;
-        if (normx <= rank_tol * r00) { rank = j; break; }
-        double *pj = W + (size_t)cidx[j] * n;
-        const double alpha = pj[j];
-        const double bh = -copysign(normx, alpha), tau = (bh - alpha) / bh, scale = 1.0 / (alpha - bh);
-        __syncthreads();                                           // everyone holds alpha before it is overwritten
-        for (int64_t r = j + 1 + tid; r < n; r += 256) pj[r] *= scale;
-        if (tid == 0) pj[j] = bh;
-        __syncthreads();
-        for (int c = j + 1 + wv; c <= kt; c += 4) {                // H = I - tau v v' (v_j = 1) on the trailing columns and on y
-            double *col = (c < kt) ? W + (size_t)cidx[c] * n : yv;
-            double d = 0.0;
-            for (int64_t r = j + 1 + lane; r < n; r += 64) d += pj[r] * col[r];
-            const double w = (k6_wave_sum(d) + col[j]) * tau;
-            double nn = 0.0;
-            for (int64_t r = j + 1 + lane; r < n; r += 64) { const double v = col[r] - w * pj[r]; col[r] = v; nn += v * v; }
-            nn = k6_wave_sum(nn);
-            if (lane == 0) { col[j] -= w; if (c < kt) cn[c] = nn; }
-        }
-        __syncthreads();
-    }
-    // R z = (Q'y)[:rank] on wave 0: lane p keeps z_p
-    if (wv == 0) {
-        double zl = 0.0;
-        for (int i = rank - 1; i >= 0; --i) {
-            const double rip = (lane > i && lane < rank) ? W[(size_t)cidx[lane] * n + i] * zl : 0.0;
-            const double zi = (yv[i] - k6_wave_sum(rip)) / W[(size_t)cidx[i] * n + i];
-            if (lane == i) zl = zi;
-        }
-        if (lane < kt) beta[cidx[lane]] = bad ? __longlong_as_double(0x7ff8000000000000LL) : (lane < rank ? zl : 0.0);
-    }
-    __syncthreads();
-}
-
-// solve_ridge None / "chol" / "lu" (ls.rs:342-364 -> solve_normal_equations :277-337) on the worker's f64 copy: G = X'X + alpha I and
-// X'y with one wave per entry (identical columns give bit-identical entries, as in the reference's GEMM), then thread 0 runs the
-// reference's chain in f64: Cholesky (a pivot that is not > 0 fails it, faer) -> LU with row partial pivoting, no cut-off --
-// an exactly singular system divides by its zero pivot and returns NaN, which is what the reference prints (notebook cell 30).
-// G: kt x kt doubles of LDS, bv / beta: kt doubles.
-__device__ __forceinline__ void k6_chol_lu(const double *W, const int64_t n, const int kt, const double alpha, const bool try_chol,
-                                           double *G, double *bv, double *beta) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int npair = kt * (kt + 1) / 2 + kt;
-    for (int q = wv; q < npair; q += 4) {
-        int a, b;
-        if (q < kt) { a = q; b = kt; }                              // X'y
-        else { int t = q - kt; a = 0; while (t >= kt - a) { t -= kt - a; ++a; } b = a + t; }
-        const double *ca = W + (size_t)a * n, *cb = W + (size_t)b * n;
-        double s = 0.0;
-        for (int64_t r = lane; r < n; r += 64) s += ca[r] * cb[r];
-        s = k6_wave_sum(s);
-        if (lane == 0) {
-            if (b == kt) bv[a] = s;
-            else { G[a * kt + b] = s + (a == b ? alpha : 0.0); G[b * kt + a] = s; }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        bool solved = false;
-        if (try_chol) {                                            // in place: L overwrites the strict lower triangle, its diagonal lives
-            // in beta[]; the upper triangle keeps G for the LU fallback
-            bool ok = true;
-            const double noise = 16.0 * (double)kt * 2.220446049250313e-16;   // a pivot within rounding noise of 0 fails (see api.hip)
-            for (int j = 0; j < kt && ok; ++j) {
-                double d = G[j * kt + j];
-                const double gjj = d;
-                for (int p = 0; p < j; ++p) d -= G[j * kt + p] * G[j * kt + p];
-                if (!(d > noise * gjj)) { ok = false; break; }
-                d = sqrt(d);
-                beta[j] = d;
-                for (int i = j + 1; i < kt; ++i) {
-                    double s = G[i * kt + j];
-                    for (int p = 0; p < j; ++p) s -= G[i * kt + p] * G[j * kt + p];
-                    G[i * kt + j] = s / d;
-                }
-            }
-            if (ok) {
-                for (int i = 0; i < kt; ++i) {                     // L z = b, L' x = z
-                    double s = bv[i];
-                    for (int p = 0; p < i; ++p) s -= G[i * kt + p] * bv[p];
-                    bv[i] = s / beta[i];
-                }
-                for (int i = kt - 1; i >= 0; --i) {
-                    double s = bv[i];
-                    for (int p = i + 1; p < kt; ++p) s -= G[p * kt + i] * bv[p];
-                    bv[i] = s / beta[i];
-                }
-                for (int i = 0; i < kt; ++i) beta[i] = bv[i];
-                solved = true;
-            } else {                                               // restore the symmetric matrix from its untouched upper triangle
-                for (int i = 0; i < kt; ++i)
-                    for (int c = 0; c < i; ++c) G[i * kt + c] = G[c * kt + i];
-            }
-        }
-        if (!solved) {                                             // faer partial_piv_lu().solve (ls.rs:264-273)
-            for (int j = 0; j < kt; ++j) {
-                int p = j;
-                double best = fabs(G[j * kt + j]);
-                for (int i = j + 1; i < kt; ++i)
-                    if (fabs(G[i * kt + j]) > best) { best = fabs(G[i * kt + j]); p = i; }
-                if (p != j) {
-                    for (int c = 0; c < kt; ++c) { const double t = G[j * kt + c]; G[j * kt + c] = G[p * kt + c]; G[p * kt + c] = t; }
-                    const double t = bv[j]; bv[j] = bv[p]; bv[p] = t;
-                }
-                const double d = G[j * kt + j];
-                for (int i = j + 1; i < kt; ++i) {
-                    const double f = G[i * kt + j] / d;
-                    for (int c = j + 1; c < kt; ++c) G[i * kt + c] -= f * G[j * kt + c];
-                    bv[i] -= f * bv[j];
-                }
-            }
-            for (int i = kt - 1; i >= 0; --i) {
-                double s = bv[i];
-                for (int p = i + 1; p < kt; ++p) s -= G[i * kt + p] * bv[p];
-                bv[i] = s / G[i * kt + i];
-            }
-            for (int i = 0; i < kt; ++i) beta[i] = bv[i];
-        }
-    }
-    __syncthreads();
-}
-
 // The fix-up pass as a device function: worker `worker` of `n_workers` 256-thread workgroups strides over the groups and
 // re-solves the flagged ones.
 template <typename T>
@@ -207,14 +48,17 @@ __device__ __forceinline__ void k6_process(const K6Args &a, const int worker, co
         }
         const double nfit = k6_block_sum((double)nfit_l, red);
         if (nfit == 0.0 && tid == 0) a.status[g] = POLS_GROUP_EMPTY;   // every row dropped by the null policy: zeros, like an empty group
-        // ---- the solver the reference runs on this group (K6Mode); rows the null policy dropped are zero rows of W, so "more rows
-        //      than columns" (ls.rs:224-229) is about the rows in the fit
-        const bool use_qr = (a.mode == K6_OLS_AUTO && nfit > (double)kt) || (a.mode == K6_OLS_QR && nfit >= (double)kt);
-        const bool use_lu = a.mode == K6_CHOL_LU || a.mode == K6_LU;
+        // ---- the solver the reference runs on this group (FixMode)
+        const bool use_qr = fix_uses_qr(a.mode, nfit, kt), use_lu = fix_uses_lu(a.mode);
         if (use_qr || use_lu) {
             __syncthreads();
-            if (use_qr) k6_qr_basic(W, n, kt, cidx, cj, beta);
-            else k6_chol_lu(W, n, kt, a.alpha, a.mode == K6_CHOL_LU, V, cj, beta);
+            if (use_qr) fix_qr_basic(W, n, kt, 1, cidx, cj, beta);
+            else {                                                 // V: the Gram matrix, cj: X'y -> the solution, sv: factor diagonal / LU multipliers
+                fix_gram(W, n, kt, 1, a.alpha, V, cj);
+                if (!(a.mode == FIX_CHOL_LU && fix_chol_solve(V, cj, kt, 1, sv))) fix_lu_solve(V, cj, kt, 1, sv, &rotated);
+                if (tid < kt) beta[tid] = cj[tid];
+                __syncthreads();
+            }
             if (tid < kt) {
                 if (nfit == 0.0) beta[tid] = 0.0;
                 if (a.coef) static_cast<T *>(a.coef)[g * kt + tid] = (T)beta[tid];

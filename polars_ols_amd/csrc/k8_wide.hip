@@ -18,6 +18,7 @@
 //             the coefficient vector in LDS; same order, alpha * n scaling, soft threshold, active set and stop rule.
 //   predict   X . beta (+ residuals) with the reference's weighted arithmetic.
 #include "k8_wide.hpp"
+#include "fix_solvers.inl"
 #include "k1m_kernel.inl"   // Mfma16
 #include "k7_stats.hpp"     // k7_betai
 
@@ -287,6 +288,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
     __shared__ double red[3 * 4];
     __shared__ int rotated;
+    __shared__ int cidx[K8_KMAX];                                  // pivoted QR: column order; LU: nothing
+    __shared__ double cn[K8_KMAX];                                 // pivoted QR: trailing column norms; LU: multipliers / factor diagonal
     const int tid = threadIdx.x;
     const int kt = a.kt;
     if (a.fb_flag && *a.fb_flag != a.epoch) return;
@@ -296,7 +299,10 @@ __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
         if (a.status[g] != POLS_GROUP_FALLBACK) continue;
         const int64_t s = a.offs[g];
         const int n = (int)(a.offs[g + 1] - s);
-        const bool dual = n < kt;
+        // the solver the reference runs on this group (FixMode): pivoted QR / Cholesky -> LU work on the columns of X (primal copy)
+        const double nfit_g = a.nfit ? a.nfit[g] : (double)n;
+        const bool use_qr = fix_uses_qr(a.fix_mode, nfit_g, kt), use_lu = fix_uses_lu(a.fix_mode);
+        const bool dual = n < kt && !use_qr && !use_lu;
         const int nc = dual ? n : kt, len = dual ? kt : n;
         const int m = wide_m(a);
         double *yv = W + (size_t)nc * len;                         // the scaled targets, m x n values
@@ -310,6 +316,24 @@ __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
                 if (dual) W[(size_t)r * len + j] = z; else W[(size_t)j * len + r] = z;
             }
             if (tid < m) yv[(size_t)tid * n + r] = wide_z<T>(a, nullptr, kt + tid, s + r) * sw;
+        }
+        if (use_qr || use_lu) {
+            __syncthreads();
+            double *cout = a.coef64 + (size_t)g * m * kt;
+            if (use_qr) fix_qr_basic(W, n, kt, m, cidx, cn, cout);
+            else {                                                 // Vm: G (kt x kt) then B (kt x m)
+                double *Bm = Vm + (size_t)kt * kt;
+                fix_gram(W, n, kt, m, a.alpha, Vm, Bm);
+                if (!(a.fix_mode == FIX_CHOL_LU && fix_chol_solve(Vm, Bm, kt, m, cn))) fix_lu_solve(Vm, Bm, kt, m, cn, &rotated);
+                for (int q = tid; q < kt * m; q += 256) cout[(size_t)(q % m) * kt + q / m] = Bm[q];
+                __syncthreads();
+            }
+            for (int q = tid; q < kt * m; q += 256) {
+                if (n == 0) cout[q] = 0.0;
+                if (a.coef) static_cast<T *>(a.coef)[(size_t)g * m * kt + q] = (T)cout[q];
+            }
+            __syncthreads();
+            continue;
         }
         for (int q = tid; q < nc * nc; q += 256) Vm[q] = ((q / nc) == (q % nc)) ? 1.0 : 0.0;
         __syncthreads();

@@ -43,6 +43,7 @@ struct WideArgs {
     uint8_t *rowmask;
     double *nfit;
     int32_t null_policy;
+    int32_t fix_mode;          // FixMode (fix_solvers.inl): the solver the fix-up pass runs on the groups wide_chol flags
 };
 
 __host__ __device__ inline int wide_m(const WideArgs &a) { return a.n_targets > 1 ? a.n_targets : 1; }

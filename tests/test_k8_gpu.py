@@ -96,21 +96,24 @@ def test_fit_wide_reference_case(eng, k):                            # tests/tes
 
 
 def test_wide_rank_deficient_tall_groups(eng):
-    """Collinear columns in tall wide groups: flagged by the pivot test, solved by the primal Jacobi pass; healthy groups untouched."""
+    """Collinear columns in tall wide groups: flagged by the pivot test; default method and n > k -> the reference's pivoted QR, i.e.
+    the basic solution (one twin carries both, the other is 0); solve_method="svd" -> the primal Jacobi pass, minimum norm (the twins
+    share the weight); healthy groups untouched."""
     y, cols, offs, _ = _frame(21, np.float64, 50, [400, 900, 650])
     s, e = offs[1], offs[2]
     cols[7][s:e] = cols[3][s:e]                                      # group 1: two identical columns
     out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
-    assert list(out["status"]) == [0, 1, 0]
+    svd = eng.least_squares(y, cols, offs, solve_method="svd", want=("coef", "pred", "status"))
+    ref = orc.batched_least_squares(y, cols, offs)
+    assert list(out["status"]) == [0, 1, 0] and list(svd["status"]) == [0, 1, 0]
+    assert np.allclose(out["coef"], ref["coef"], rtol=1e-6, atol=1e-6) and np.allclose(out["pred"], ref["pred"], rtol=1e-6, atol=1e-6)
     for g in range(3):
         a, b = offs[g], offs[g + 1]
         X = np.column_stack([c[a:b] for c in cols])
         exp = np.linalg.lstsq(X, y[a:b], rcond=None)[0]
-        assert np.allclose(out["pred"][a:b], X @ exp, rtol=1e-6, atol=1e-6)
-        if g != 1:
-            assert np.allclose(out["coef"][g], exp, rtol=1e-6, atol=1e-6)
-        else:
-            assert np.allclose(out["coef"][g], exp, rtol=1e-5, atol=1e-6)   # minimum norm: the twin columns share the weight
+        assert np.allclose(out["pred"][a:b], X @ exp, rtol=1e-6, atol=1e-6) and np.allclose(svd["pred"][a:b], X @ exp, rtol=1e-6, atol=1e-6)
+        assert np.allclose(svd["coef"][g], exp, rtol=1e-5, atol=1e-6)
+    assert (out["coef"][1][3] == 0.0) != (out["coef"][1][7] == 0.0)
 
 
 def test_wide_device_matches_host_and_is_repeatable(eng):
@@ -296,3 +299,34 @@ def test_multi_target_null_policies_behind_the_cabi(eng, dtype, tol, policy, k, 
         got = np.column_stack([np.asarray(p, dtype=np.float64) for p in res["pred"]])
         assert np.array_equal(np.isnan(got), np.isnan(exp))
         assert np.allclose(got, exp, rtol=tol, atol=tol, equal_nan=True), float(np.nanmax(np.abs(got - exp)))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-7), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k", [40, 150])
+def test_wide_rank_deficient_groups_get_the_reference_solver(eng, dtype, tol, k):
+    """Beyond 31 columns too, a flagged group is re-solved by what the REFERENCE runs for the (branch, method): default / "qr" with
+    n > k -> pivoted QR, basic solution (a duplicated column: ONE twin carries the sum, the other is exactly 0; demo notebook cell 28);
+    "svd" -> dgelsd's minimum norm (cell 32); "chol" / "lu" -> Cholesky fails, LU divides by an exactly zero pivot -> NaN (cell 30)."""
+    y, cols, offs, _ = _frame(7 * k, dtype, k, [3 * k + 17, 2 * k + 5, 4 * k])
+    s, e = offs[1], offs[2]
+    cols[k - 3][s:e] = cols[5][s:e]                                  # group 1: two identical columns
+    for m in (None, "qr"):
+        out = eng.least_squares(y, cols, offs, solve_method=m, want=("coef", "pred", "status"))
+        assert eng.last_kernel.startswith("k8_wide")
+        ref = orc.batched_least_squares(y, cols, offs, solve_method=m)
+        assert list(out["status"]) == [0, 1, 0]
+        assert np.allclose(out["coef"], ref["coef"], rtol=tol, atol=tol), (m, float(np.abs(out["coef"] - ref["coef"]).max()))
+        assert np.allclose(out["pred"], ref["pred"], rtol=tol, atol=tol)
+        assert (out["coef"][1][5] == 0.0) != (out["coef"][1][k - 3] == 0.0)
+    out = eng.least_squares(y, cols, offs, solve_method="svd", want=("coef",))
+    X = np.column_stack([c[s:e].astype(np.float64) for c in cols])
+    mn = np.linalg.lstsq(X, y[s:e].astype(np.float64), rcond=None)[0]
+    assert np.allclose(out["coef"][1], mn, rtol=10 * tol, atol=10 * tol)
+    assert abs(out["coef"][1][5] - out["coef"][1][k - 3]) < 10 * tol  # minimum norm: the twins share the coefficient
+    for m in ("chol", "lu"):
+        out = eng.least_squares(y, cols, offs, solve_method=m, want=("coef", "pred", "status"))
+        ref = orc.batched_least_squares(y, cols, offs, solve_method=m)
+        assert np.isnan(out["coef"][1]).all() and np.isnan(ref["coef"][1]).all(), m
+        assert np.isnan(out["pred"][s:e]).all()
+        for g in (0, 2):
+            assert np.allclose(out["coef"][g], ref["coef"][g], rtol=tol, atol=tol)
