@@ -25,6 +25,13 @@ FAILS -- a multi-GPU line is never printed without its collective.
   ref100 the reference's own benchmark shape: ONE 10 000 x 100 f64 OLS problem (published: 17.6 ms per call, M2 Max)
   cfg5  100 000 groups x 2 000 rows x 16 feats elastic net alpha = 0.001 l1_ratio = 0.5, f64; the groups are SPLIT
         across the ranks (strong scaling: 100 000 / N per GPU)
+--frames F (default: as many as it takes for the inputs to exceed 3 x the 256 MB Infinity Cache, at least 3 for cfg2 / cfg3): the
+  steps rotate over F independent synthetic frames of the same shape, so that no step can find its input in a cache -- the number is
+  an HBM-stream number.  (cfg5's one frame is 27 GB.)
+--gather coef|pred|none (N > 1; default coef): what is re-assembled every step.  coef: the per-group coefficient tables, all-gathered
+  eight steps at a time (above).  pred: the PREDICTIONS column gathered to rank 0 with pols_comm_gather_rows every step (the root
+  pulls 40 MB per peer per step over its xGMI links; double-buffered on a side stream) -- the exchange north_star names; it is
+  bound by the links, which is why the product leaves predictions sharded unless asked.
 --mem host (cfg1 / cfg2 / cfg3): the columns are host numpy arrays handed to the C-ABI as POLS_MEM_HOST -- the PCIe-inclusive
   rate ("data": "synthetic, host-resident"); never the headline value.
 """
@@ -121,8 +128,9 @@ def make_columns(n: int, feats: int, tdt, seed: int, weights: bool = False):
     return y, cols, w
 
 
-def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: str):
-    """Returns dict(plan, units, unit, alg_bytes, text, dtype, coef, scaling, shard)."""
+def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: str, frame: int = 0):
+    """Returns dict(plan, units, unit, alg_bytes, text, dtype, coef, scaling, shard).  `frame`: which of the rotated synthetic frames
+    (another seed, same shape)."""
     from polars_ols_amd.distributed import shard_for_rank
 
     host = mem == "host"
@@ -134,7 +142,7 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
         # the GLOBAL frame's offsets, partitioned by the product's partitioner; this rank generates only its shard
         shard = shard_for_rank(np.arange(G_total + 1, dtype=np.int64) * n, world, rank)
         G = shard.group_hi - shard.group_lo
-        y, cols, w = make_columns(G * n, k, tdt, 1234 + rank, weights=kw.pop("weights", False))
+        y, cols, w = make_columns(G * n, k, tdt, 1234 + rank + 1000 * frame, weights=kw.pop("weights", False))
         want = kw.pop("want", ("pred", "coef"))
         out = None
         if not host:
@@ -205,6 +213,8 @@ def main() -> None:
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4r", "cfg5", "ref100"])
     ap.add_argument("--mem", default="device", choices=["device", "host"])
+    ap.add_argument("--frames", type=int, default=0, help="rotate the steps over this many independent frames (0: automatic)")
+    ap.add_argument("--gather", default="coef", choices=["coef", "pred", "none"], help="N > 1: what is re-assembled every step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,8 +246,24 @@ def main() -> None:
     eng.set_stream(eng_stream.cuda_stream)
     wl = build_workload(args.config, eng, rank, world, args.dtype, args.mem)
     plan, coef, shard = wl["plan"], wl["coef"], wl["shard"]
+    # Frame rotation: a 360 MB frame re-read every step could live in part in the 256 MB Infinity Cache; rotating over frames whose
+    # inputs add up to more than three times that makes every step stream its input from HBM.  Outputs go to the first frame's
+    # buffers (written, never read).
+    in_bytes = wl["alg_bytes"]
+    n_frames = args.frames if args.frames > 0 else (1 if (args.config in ("cfg1", "cfg4", "cfg4r", "ref100") or args.mem == "host")
+                                                    else max(1, min(8, -(-3 * 256 * 2 ** 20 // max(1, in_bytes)))))
+    if args.frames == 0 and args.config in ("cfg2", "cfg3") and args.mem == "device":
+        n_frames = max(3, n_frames)
+    plans = [plan]
+    for f in range(1, n_frames):
+        w2 = build_workload(args.config, eng, rank, world, args.dtype, args.mem, frame=f)
+        for key in ("coef", "pred", "resid"):
+            if key in plan.results and key in w2["plan"].results:
+                w2["plan"].set_output(key, plan.results[key])
+        plans.append(w2["plan"])
     torch.cuda.synchronize()                                                           # inputs are resident
-    gather = dist is not None and coef is not None
+    gather = dist is not None and coef is not None and args.gather == "coef"
+    gather_pred = dist is not None and args.gather == "pred" and "pred" in plan.results and shard is not None
     collective = {"kind": "none", "backend": None, "bytes_per_step_per_rank": 0}
     RING = 8
     ring = None
@@ -269,12 +295,46 @@ def main() -> None:
         collective = {"kind": f"pols_comm_allgather_rows (RCCL behind the C-ABI) of {RING} steps' coefficient tables, side stream",
                       "backend": dist.get_backend(), "bytes_per_step_per_rank": int(coef.numel() * coef.element_size()) * (world - 1)}
 
+    pred_state = None
+    if gather_pred:
+        # predictions to rank 0 every step (pols_comm_gather_rows: grouped ncclSend / ncclRecv, the root pulls from its peers over
+        # distinct xGMI links), on a side stream, double-buffered: step i + 2 rewrites buffer i % 2 only after gather i has read it
+        side = torch.cuda.Stream()
+        eng_comm = Engine(local_rank)
+        eng_comm.set_stream(side.cuda_stream)
+        comm = create_comm(eng_comm)
+        pred0 = plan.results["pred"]
+        bufs = [pred0, torch.empty_like(pred0)]
+        rows = shard.row_counts
+        gathered_pred = torch.empty(sum(rows), device="cuda", dtype=pred0.dtype) if rank == 0 else None
+        produced = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        for ev in consumed:
+            ev.record(side)
+        pred_state = dict(i=0)
+        collective = {"kind": "pols_comm_gather_rows (RCCL behind the C-ABI) of the predictions column to rank 0, every step, side stream",
+                      "backend": dist.get_backend(), "bytes_per_step_per_rank": int(pred0.numel() * pred0.element_size())}
+
+    step_no = [0]
+
     def step():
-        if ring is None:
-            plan.run()
+        pl = plans[step_no[0] % len(plans)]
+        step_no[0] += 1
+        if pred_state is not None:
+            i = pred_state["i"]; pred_state["i"] = i + 1
+            consumed[i & 1].synchronize()
+            pl.set_output("pred", bufs[i & 1])
+            pl.run()
+            produced[i & 1].record(eng_stream)
+            side.wait_event(produced[i & 1])
+            comm.gather_rows(bufs[i & 1], rows, root=0, out=gathered_pred)
+            consumed[i & 1].record(side)
             return
-        plan.set_output("coef", ring.begin_step())
-        plan.run()
+        if ring is None:
+            pl.run()
+            return
+        pl.set_output("coef", ring.begin_step())
+        pl.run()
         ring.end_step()
 
     def flush():
@@ -335,7 +395,7 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": wl["scaling"], "vs_baseline": None, "dtype": wl["dtype"],
             "data": "synthetic" if args.mem == "device" else "synthetic, host-resident (PCIe-inclusive)",
-            "config": {"workload": wl["text"], "units_per_gpu_per_step": wl["units"],
+            "config": {"workload": wl["text"], "units_per_gpu_per_step": wl["units"], "frames_rotated": n_frames,
                        "sharding": "groups (shard_for_rank: contiguous ranges balanced by rows)" if world > 1 else "none",
                        "world_size": world, "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -405,6 +405,19 @@ int pols_comm_allgather_rows(pols_comm *comm, const void *local, const int64_t *
  * the root pulls from its peers over distinct links at once, where a ring all-gather would be bound by one link. */
 int pols_comm_gather_rows(pols_comm *comm, const void *local, const int64_t *counts, int64_t row_bytes, int root, void *out_on_root);
 
+/* One process, several GPUs -- the form a Polars plugin process takes: the frame sits in HOST memory (b->mem must be POLS_MEM_HOST),
+ * ctxs[0 .. n) are contexts on n devices.  The groups are cut into n contiguous ranges balanced by rows (pols_partition_groups),
+ * range r is staged to and solved on ctxs[r]'s device from its own host thread, exactly as pols_least_squares would, and the outputs
+ * named in `o` are re-assembled according to out_mem:
+ *   POLS_MEM_HOST    o's pointers are host arrays for the WHOLE frame; every device copies its slice into them (no collective;
+ *                    comms may be NULL);
+ *   POLS_MEM_DEVICE  o's pointers are buffers on ctxs[0]'s device for the whole frame: the coefficient table is all-gathered
+ *                    (pols_comm_allgather_rows), predictions / residuals / status are gathered to device 0 (pols_comm_gather_rows)
+ *                    over RCCL / xGMI; comms[r] must be rank r of a world of n (pols_comm_create_all).  Returns when device 0 holds them.
+ * Replaces what Polars' rayon pool does for `.over(group)` (README.md:19) when more than one GPU is present. */
+int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, int n, const pols_batch *b, const pols_ols_params *p,
+                               pols_out *o, int32_t out_mem);
+
 #ifdef __cplusplus
 }
 #endif

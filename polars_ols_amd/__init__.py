@@ -6,7 +6,7 @@ Only the hot path lives here: ``csrc/`` (hand-written gfx950 HIP kernels + the C
 (``least_squares.py``).  Importing the package does not need a GPU; computing does, and there is no CPU fallback.
 """
 from ._lib import LIB_PATH, PolsError, PolsPanic, build  # noqa: F401
-from .engine import Engine, default_engine  # noqa: F401
+from .engine import Engine, comm_create_all, default_engine, least_squares_sharded  # noqa: F401
 from .least_squares import (  # noqa: F401
     Coefficients, Statistics, Expr, Frame, LeastSquares, OLSKwargs, RLSKwargs, RollingKwargs, col, struct, compute_least_squares,
     compute_multi_target_least_squares,

@@ -87,7 +87,7 @@ EXPORTS = [
     "pols_comm_world_size", "pols_comm_rank", "pols_comm_group_begin", "pols_comm_group_end", "pols_comm_allgather_rows",
     "pols_comm_gather_rows", "pols_least_squares_arrow", "pols_least_squares_statistics_arrow",
     "pols_multi_target_least_squares_arrow", "pols_recursive_least_squares_arrow", "pols_rolling_least_squares_arrow",
-    "pols_predict_arrow",
+    "pols_predict_arrow", "pols_least_squares_sharded",
 ]
 POLS_COMM_ID_BYTES = 128
 
@@ -157,6 +157,8 @@ def lib() -> C.CDLL:
         L.pols_recursive_least_squares_arrow.argtypes = _common + [C.POINTER(RlsParams), C.c_int32, C.c_void_p, C.c_void_p]
         L.pols_rolling_least_squares_arrow.argtypes = _common + [C.POINTER(RollingParams), C.c_int32, C.c_void_p, C.c_void_p]
         L.pols_predict_arrow.argtypes = [C.c_void_p, _ac, _ac, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_void_p]
+        L.pols_least_squares_sharded.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(Batch), C.POINTER(OlsParams),
+                                                 C.POINTER(Out), C.c_int32]
         L.pols_partition_groups.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.c_int, C.POINTER(C.c_int64)]
         L.pols_comm_unique_id.argtypes = [C.c_void_p]
         L.pols_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

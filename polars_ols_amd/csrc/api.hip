@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <strings.h>
 #include <mutex>
+#include <thread>
 
 #include "common.hpp"
 #include "k1_gram_chol.hpp"
@@ -1537,6 +1538,119 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
     ctx->last_kernel = "predict";
     if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, kt, &o, st);
+}
+
+// ------------------------------------------------------------------ one process, several GPUs
+// What a Polars plugin process is: ONE process holding the frame in host memory, N devices.  The groups are cut into
+// contiguous ranges balanced by rows (pols_partition_groups), range r is solved on ctxs[r]'s device from its own host thread
+// (staging over that device's PCIe link, the same kernels, its own stream), and the outputs are re-assembled:
+//   out_mem == POLS_MEM_HOST    every device copies its slice straight into the caller's host arrays -- no collective at all;
+//   out_mem == POLS_MEM_DEVICE  the outputs are assembled on ctxs[0]'s device over RCCL / xGMI: the per-group coefficient table
+//                               with pols_comm_allgather_rows (every device ends up with it; device 0's copy is the caller's
+//                               buffer), predictions / residuals / status with pols_comm_gather_rows to device 0 (the root pulls
+//                               from its peers over distinct xGMI links).  Each device's collectives are issued by its own thread,
+//                               stream-ordered behind its kernels.
+int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, int n, const pols_batch *b, const pols_ols_params *p,
+                               pols_out *o, int32_t out_mem) {
+    if (!ctxs || n < 1 || n > 64) return fail(POLS_ERR_INVALID, "ctxs / n");
+    if (!b || !p || !o) return fail(POLS_ERR_INVALID, "batch / params / out is NULL");
+    if (b->mem != POLS_MEM_HOST) return fail(POLS_ERR_INVALID, "the sharded entry takes a HOST batch (the plugin process holds the frame in host memory)");
+    if (out_mem != POLS_MEM_HOST && out_mem != POLS_MEM_DEVICE) return fail(POLS_ERR_INVALID, "out_mem must be POLS_MEM_HOST or POLS_MEM_DEVICE");
+    if (out_mem == POLS_MEM_DEVICE && !comms) return fail(POLS_ERR_INVALID, "device-side assembly needs the communicators (pols_comm_create_all)");
+    int rc = check_batch(b, o, K8_KMAX);
+    if (rc) return rc;
+    for (int r = 0; r < n; ++r) {
+        if (!ctxs[r]) return fail(POLS_ERR_INVALID, "ctxs[%d] is NULL", r);
+        if (out_mem == POLS_MEM_DEVICE && (!comms[r] || pols_comm_world_size(comms[r]) != n || pols_comm_rank(comms[r]) != r))
+            return fail(POLS_ERR_INVALID, "comms[%d] is not rank %d of a world of %d", r, r, n);
+    }
+    const int kt = b->n_features + (b->add_intercept ? 1 : 0);
+    const size_t sz = dtype_size(b->dtype);
+    std::vector<int64_t> bounds((size_t)n + 1);
+    if ((rc = pols_partition_groups(b->group_offsets, b->n_groups, n, bounds.data()))) return rc;
+    std::vector<int64_t> gcounts((size_t)n), rcounts((size_t)n);
+    for (int r = 0; r < n; ++r) {
+        gcounts[(size_t)r] = bounds[(size_t)r + 1] - bounds[(size_t)r];
+        rcounts[(size_t)r] = b->group_offsets[bounds[(size_t)r + 1]] - b->group_offsets[bounds[(size_t)r]];
+    }
+    std::vector<int> rcs((size_t)n, POLS_OK);
+    std::vector<std::string> errs((size_t)n);
+    auto work = [&](int r) {
+        auto done = [&](int code) { rcs[(size_t)r] = code; if (code) errs[(size_t)r] = pols_last_error(); };
+        pols_ctx *ctx = ctxs[r];
+        const int64_t g0 = bounds[(size_t)r], g1 = bounds[(size_t)r + 1], row0 = b->group_offsets[g0], nrows = rcounts[(size_t)r];
+        // the shard as a batch of its own: column pointers advanced to its first row, offsets rebased to 0
+        std::vector<int64_t> offs((size_t)(g1 - g0) + 1);
+        for (int64_t g = g0; g <= g1; ++g) offs[(size_t)(g - g0)] = b->group_offsets[g] - row0;
+        std::vector<const void *> xs((size_t)b->n_features);
+        auto at = [&](const void *base, int64_t row, size_t elem) { return base ? static_cast<const void *>(static_cast<const char *>(base) + (size_t)row * elem) : nullptr; };
+        for (int j = 0; j < b->n_features; ++j) xs[(size_t)j] = at(b->x_cols[j], row0, sz);
+        pols_batch sb = *b;
+        sb.n_rows = nrows; sb.n_groups = g1 - g0; sb.group_offsets = offs.data(); sb.offsets_generation = 0;
+        sb.y = at(b->y, row0, sz); sb.x_cols = xs.data(); sb.weights = at(b->weights, row0, sz);
+        sb.valid = static_cast<const uint8_t *>(at(b->valid, row0, 1));
+        auto out_at = [&](void *base, int64_t row, size_t elem) { return base ? static_cast<void *>(static_cast<char *>(base) + (size_t)row * elem) : nullptr; };
+        if (out_mem == POLS_MEM_HOST) {                            // every device writes its own slice of the caller's host arrays
+            pols_out so;
+            so.coef = out_at(o->coef, g0 * kt, sz); so.pred = out_at(o->pred, row0, sz); so.resid = out_at(o->resid, row0, sz);
+            so.status = static_cast<int32_t *>(out_at(o->status, g0, sizeof(int32_t)));
+            if (sb.n_groups == 0) return done(POLS_OK);
+            return done(pols_least_squares(ctx, &sb, p, &so));
+        }
+        // device-side assembly: stage the shard on this device (scratch slot 13), solve it there with the outputs next to it, then
+        // the collectives on this device's stream.  Every rank takes part in every collective, shard or no shard.
+        int rc2 = check_ctx(ctx);
+        if (rc2) return done(rc2);
+        const size_t colb = round256(sz * (size_t)std::max<int64_t>(nrows, 1)), vb = round256((size_t)std::max<int64_t>(nrows, 1));
+        const size_t coefb = round256(sz * (size_t)std::max<int64_t>(sb.n_groups, 1) * kt), allb = round256(sz * (size_t)std::max<int64_t>(b->n_groups, 1) * kt);
+        const size_t statb = round256(sizeof(int32_t) * (size_t)std::max<int64_t>(sb.n_groups, 1));
+        const int n_in = 1 + b->n_features + (b->weights ? 1 : 0);
+        void *base = nullptr;
+        if ((rc2 = ensure_scratch(ctx, 13, colb * (size_t)(n_in + 2) + vb + coefb + allb + statb, &base))) return done(rc2);
+        char *q = static_cast<char *>(base);
+        auto put = [&](const void *src, size_t bytes, size_t slot) -> const void * {
+            char *d = q; q += slot;
+            if (src && bytes && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc2 = POLS_ERR_HIP;
+            return src ? d : nullptr;
+        };
+        pols_batch db = sb;
+        db.mem = POLS_MEM_DEVICE;
+        db.y = put(sb.y, sz * (size_t)nrows, colb);
+        std::vector<const void *> dx((size_t)b->n_features);
+        for (int j = 0; j < b->n_features; ++j) dx[(size_t)j] = put(xs[(size_t)j], sz * (size_t)nrows, colb);
+        db.x_cols = dx.data();
+        if (b->weights) db.weights = put(sb.weights, sz * (size_t)nrows, colb);
+        db.valid = b->valid ? static_cast<const uint8_t *>(put(sb.valid, (size_t)nrows, vb)) : nullptr;
+        if (!b->valid) q += vb;
+        if (rc2) { set_error("staging copy failed on device %d", ctx->device); return done(rc2); }
+        pols_out so;
+        std::memset(&so, 0, sizeof(so));
+        if (o->pred) so.pred = q;
+        q += colb;
+        if (o->resid) so.resid = q;
+        q += colb;
+        if (o->coef) so.coef = q;
+        q += coefb;
+        void *all_coef = q; q += allb;
+        if (o->status) so.status = reinterpret_cast<int32_t *>(q);
+        if (sb.n_groups > 0 && (rc2 = pols_least_squares(ctx, &db, p, &so))) return done(rc2);
+        pols_comm *cm = comms[r];
+        if (o->coef && (rc2 = pols_comm_allgather_rows(cm, so.coef, gcounts.data(), (int64_t)(sz * kt), r == 0 ? o->coef : all_coef))) return done(rc2);
+        if (o->pred && (rc2 = pols_comm_gather_rows(cm, so.pred, rcounts.data(), (int64_t)sz, 0, r == 0 ? o->pred : nullptr))) return done(rc2);
+        if (o->resid && (rc2 = pols_comm_gather_rows(cm, so.resid, rcounts.data(), (int64_t)sz, 0, r == 0 ? o->resid : nullptr))) return done(rc2);
+        if (o->status && (rc2 = pols_comm_gather_rows(cm, so.status, gcounts.data(), (int64_t)sizeof(int32_t), 0, r == 0 ? o->status : nullptr))) return done(rc2);
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("stream synchronisation failed on device %d", ctx->device); return done(POLS_ERR_HIP); }
+        return done(POLS_OK);
+    };
+    if (n == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n; ++r) th.emplace_back(work, r);
+        for (auto &t : th) t.join();
+    }
+    for (int r = 0; r < n; ++r)
+        if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "device %d: %s", r, errs[(size_t)r].c_str());
+    return POLS_OK;
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@ kernels behind the C-ABI.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional, Sequence
+from typing import List, Dict, Optional, Sequence
 
 import numpy as np
 
@@ -616,6 +616,62 @@ class Comm:
         L.check(self._lib.pols_comm_gather_rows(self._h, C.c_void_p(local.data_ptr()), self._counts(counts), C.c_int64(row_bytes),
                                                 C.c_int(root), C.c_void_p(out.data_ptr() if self.rank == root else 0)))
         return out if self.rank == root else None
+
+
+def comm_create_all(engines: Sequence[Engine]) -> List["Comm"]:
+    """``pols_comm_create_all``: one process driving several devices -- rank i of the returned communicators lives on
+    ``engines[i]``'s device (ncclCommInitAll)."""
+    n = len(engines)
+    hs = (C.c_void_p * n)(*[e._h for e in engines])
+    out = (C.c_void_p * n)()
+    L.check(L.lib().pols_comm_create_all(hs, n, out))
+    comms = []
+    for i, e in enumerate(engines):
+        c = Comm.__new__(Comm)
+        c._eng, c._lib, c._h, c.world, c.rank = e, e._lib, C.c_void_p(out[i]), n, i
+        comms.append(c)
+    return comms
+
+
+def least_squares_sharded(engines: Sequence[Engine], y, x_cols: Sequence, offsets, *, comms: Optional[Sequence["Comm"]] = None,
+                          out: str = "host", weights=None, valid=None, add_intercept: bool = False, want: Sequence[str] = ("pred",),
+                          **kwargs) -> Dict:
+    """``pols_least_squares_sharded``: ONE process, ``len(engines)`` devices.  ``y`` / ``x_cols`` / ``weights`` are HOST (numpy) columns
+    of the whole group-sorted frame; the groups are cut into contiguous ranges balanced by rows, range r runs on ``engines[r]``'s
+    device from its own host thread.  ``out="host"``: numpy outputs for the whole frame (each device copies its slice home, no
+    collective).  ``out="device"``: torch tensors on ``engines[0]``'s device, assembled over RCCL (``comms`` from
+    :func:`comm_create_all`): coefficients all-gathered, predictions / residuals / status gathered to device 0."""
+    e0 = engines[0]
+    plan = e0.plan_least_squares(y, x_cols, offsets, weights=weights, valid=valid, add_intercept=add_intercept, want=(), **kwargs)
+    b = plan._b
+    if b.mem != L.POLS_MEM_HOST:
+        raise ValueError("the sharded entry takes host (numpy) columns")
+    dt = plan._keep[0][0].dtype
+    kt = b.n_features + b.add_intercept
+    res: Dict = {}
+    if out == "host":
+        mk = lambda shape, d: np.empty(shape, dtype=d)  # noqa: E731
+    else:
+        tdt = torch.float32 if dt == np.float32 else torch.float64
+        dev = torch.device("cuda", e0.device)
+        mk = lambda shape, d: torch.empty(shape, dtype=(torch.int32 if d == np.int32 else tdt), device=dev)  # noqa: E731
+    if "coef" in want:
+        res["coef"] = mk((b.n_groups, kt), dt)
+    if "pred" in want:
+        res["pred"] = mk((b.n_rows,), dt)
+    if "resid" in want:
+        res["resid"] = mk((b.n_rows,), dt)
+    if "status" in want:
+        res["status"] = mk((b.n_groups,), np.int32)
+    o = L.Out(coef=Engine._ptr(res.get("coef")), pred=Engine._ptr(res.get("pred")), resid=Engine._ptr(res.get("resid")),
+              status=Engine._ptr(res.get("status")))
+    n = len(engines)
+    hs = (C.c_void_p * n)(*[e._h for e in engines])
+    cs = (C.c_void_p * n)(*[c._h for c in comms]) if comms is not None else None
+    b.offsets_generation = 0
+    L.check(L.lib().pols_least_squares_sharded(hs, cs, n, C.byref(b), C.byref(plan._p), C.byref(o),
+                                               L.POLS_MEM_HOST if out == "host" else L.POLS_MEM_DEVICE))
+    return res
 
 
 def partition_groups_native(offsets, world: int):

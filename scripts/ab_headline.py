@@ -21,6 +21,8 @@ y = sum(cols) + 0.1 * torch.randn(N, device="cuda", generator=g)
 plan = eng.plan_least_squares(y, cols, offs, want=("pred", "coef"))
 variants = {"wave_rc4_nt": {"K1_SHAPE": "wave"}, "default": {}, "team256_rc1_nt": {"K1_SHAPE": "team"}, "team256_rc1_p2_nt": {"K1_SHAPE": "team", "K1_PASSES": "2"},
             "team256_rc1_p2": {"K1_SHAPE": "team", "K1_PASSES": "2", "K1_NT_LOADS": "0"}, "team256_rc1_p3_nt": {"K1_SHAPE": "team", "K1_PASSES": "3"}}
+if os.environ.get("ONLY"):
+    variants = {k: v for k, v in variants.items() if k in os.environ["ONLY"].split(",")}
 res = {v: [] for v in variants}
 names = {}
 for rnd in range(12):

@@ -38,6 +38,7 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
     assert r["algorithmic_bytes_per_launch"] == 400_000_000 and (r["traffic"] is None or 0.9 < r["traffic"] / 4e8 < 1.3)
     assert 0.5 < d["value"] * d["ms_per_step"] * 1e-3 / 10_000 < 1.5       # value == groups / step time
+    assert d["config"]["frames_rotated"] >= 3                              # every step streams its input from HBM, not from a cache
 
 
 def test_bench_collective_path_on_one_gpu():
@@ -45,6 +46,14 @@ def test_bench_collective_path_on_one_gpu():
     c = d["config"]["collective"]
     assert c["kind"].startswith("pols_comm_allgather_rows") and c["backend"] == "nccl", d["config"]
     assert d["value"] > 1e7
+
+
+def test_bench_predictions_gather_on_one_gpu():
+    """--gather pred: the predictions column re-assembled on rank 0 every step (pols_comm_gather_rows), here as a world of one."""
+    d = _run({"POLS_BENCH_FORCE_COLLECTIVE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534"}, "--no-cpu-baseline", "--gather", "pred")
+    c = d["config"]["collective"]
+    assert c["kind"].startswith("pols_comm_gather_rows") and c["backend"] == "nccl" and c["bytes_per_step_per_rank"] == 40_000_000, d["config"]
+    assert d["value"] > 1e6
 
 
 @pytest.mark.parametrize("cfg,metric,kernel", [("cfg1", "single_problems_per_sec", "k5_gram_stream"), ("cfg5", "group_regressions_per_sec", "k2_gram_mfma_resident_f64_k16yv_w8_rc2_cd")])
