@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "k1_gram_chol.hpp"
 #include "k2_resident.hpp"
+#include "k2w_resident.hpp"
 #include "k3_rls.hpp"
 #include "k4_rolling.hpp"
 #include "k5_enet.hpp"
@@ -175,7 +176,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_PERSIST")) o.k1_persist = on ? (std::atoi(v) != 0) : d.k1_persist;
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
     else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
-    else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : 0;
+    else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : ieq(v, "k2w") ? 4 : 0;
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
@@ -892,6 +893,36 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             a2.pivot_tol = pivot_tol;
             a2.fb_flag = enet ? nullptr : ctx->fb_flag; a2.epoch = ctx->epoch;
             if ((rc = k2_launch(ctx, b->dtype, a2, max_rows))) return rc;
+            if ((rc = svd_fixup())) return rc;
+            return finish(nullptr);
+        }
+    }
+
+    // K2w (k2w_kernel.inl): OLS / ridge with 17..31 columns, rows resident in registers, Z'Z as three 16 x 16 tiles on the matrix cores,
+    // Cholesky in the same workgroup -- X read ONCE for groups of up to 1 024 f64 / 2 048 f32 rows, which the three-launch streamed
+    // path below reads twice.  Takes what the resident K1 kernels do not (their shapes: k1_valu_takes); POLS_STATIC_ENGINE=k2w takes
+    // every shape it fits (A/B), =stream / =nok2 leave it out.
+    {
+        const bool f32 = b->dtype == POLS_F32;
+        const int vec = f32 ? 4 : 2;
+        const bool fits = !enet && !nulls && m != POLS_SOLVE_LU && k2w_fits(b->dtype, kt, max_rows, ctx->offs_aligned[f32 ? 1 : 0]) && b->n_rows >= vec &&
+                          ctx->opt.static_engine != 1 && ctx->opt.static_engine != 3;
+        const bool k1_resident = k1_valu_takes(ctx, f32, kt, max_rows);
+        // where it measured ahead of the streamed path (scripts/bench_k16.py, 1 000-row groups): f64 from 25 columns (31: 2.45 vs 2.07
+        // TB/s; 20: 1.93 vs 2.10 -- one group per CU, and the serial 32-column solve is 40 % of a group's time whatever kt), f32 always
+        // (2.53 vs 1.75 at 31 columns)
+        const bool ahead = f32 || kt >= 25;
+        if (fits && ((!k1_resident && ahead) || ctx->opt.static_engine == 4)) {
+            K2wArgs aw;
+            std::memset(&aw, 0, sizeof(aw));
+            aw.y = st.y; aw.w = st.w;
+            for (int j = 0; j < 32; ++j) aw.x[j] = j < b->n_features ? st.x[j] : st.y;   // unused slots: any loadable column
+            aw.offs = d_offs; aw.n_groups = b->n_groups; aw.n_rows = b->n_rows;
+            aw.coef = st.coef; aw.pred = st.pred; aw.resid = st.resid; aw.status = st.status;
+            aw.k_user = b->n_features; aw.kt = kt;
+            aw.alpha = ridge_alpha; aw.pivot_tol = pivot_tol;
+            aw.fb_flag = ctx->fb_flag; aw.epoch = ctx->epoch;
+            if ((rc = k2w_launch(ctx, b->dtype, aw, max_rows))) return rc;
             if ((rc = svd_fixup())) return rc;
             return finish(nullptr);
         }

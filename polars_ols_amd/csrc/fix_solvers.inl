@@ -155,7 +155,8 @@ __device__ __forceinline__ void fix_gram(const double *W, const int64_t n, const
         s = fix_wave_sum(s);
         if (lane == 0) {
             if (b >= kt) B[(size_t)a * m + (b - kt)] = s;
-            else { G[(size_t)a * kt + b] = s + (a == b ? alpha : 0.0); G[(size_t)b * kt + a] = s; }
+            else if (a == b) G[(size_t)a * kt + a] = s + alpha;
+            else { G[(size_t)a * kt + b] = s; G[(size_t)b * kt + a] = s; }
         }
     }
     __syncthreads();

@@ -1,0 +1,364 @@
+// k2w_kernel.inl -- K2w "gram_mfma_resident, two tiles": OLS / ridge for 17 .. 31 columns (the intercept counted) with the group's
+// rows held in registers, so that X is read from HBM exactly ONCE whatever the group length up to the resident capacity -- the
+// shapes that used to take the three-launch streamed path (Gram pass, solve, prediction pass: X read twice, ~2 TB/s).
+//
+// Replaces, per group: construct_features_array + solve_ols / solve_ridge (src/least_squares.rs:211-240, 342-364; normal equations,
+// Cholesky) + make_predictions (src/expressions.rs:175-195) + the sqrt(w) / intercept / un-scaling / residual steps of
+// polars_ols/least_squares.py:184-196, 234-239.  A failed or flagged factorisation marks the group POLS_GROUP_FALLBACK for the
+// fix-up pass (K6), exactly like K1 / K2.
+//
+// One PERSISTENT workgroup of WAVES (4 or 8) waves walks the groups blockIdx.x, + gridDim.x, ...  Per group:
+//   load    : every lane keeps ONE 16-byte chunk (2 f64 / 4 f32 consecutive rows) of EVERY column in VGPRs -- 32 column slots, all
+//             loaded unconditionally from clamped positions (K2's scheme: no load inside a divergent branch), 128 VGPRs of data.
+//   gram    : Z = [sqrt(w) X | sqrt(w) 1 | sqrt(w) y] has up to 32 columns = two 16-column halves; Z'Z is THREE 16 x 16 tiles on the
+//             matrix cores (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32): (0,0) = A0'A0, (0,1) = A0'A1, (1,1) = A1'A1 with A_h the
+//             operand stream of half h.  The matrix cores want lane (c, q) to hold Z[row 4t + q][column c]; the registers hold a
+//             row per lane, so each wave transposes through its PRIVATE 8.25 KB LDS tile (K2's, 16 column slots): half 0 is written,
+//             its 16 operands are read into registers, half 1 is written over it, and its operands are consumed one at a time
+//             next to the three MFMAs of the step.  No workgroup barrier in the Gram phase.  f32 tiles are flushed to f64 per stage.
+//   reduce  : per-wave partial tiles -> LDS -> one f64 32 x 32 matrix, fixed order (run-to-run identical).             [2 barriers]
+//   solve   : wave 0, f64: the matrix padded to 32 x 32 with an identity block, lane i keeps row i in registers, right-looking
+//             Cholesky with v_readlane broadcasts (steps beyond kt skipped), forward substitution, one LDS transposition, backward.
+//   predict : X . beta (+ residuals) from the resident rows, 16-byte streaming stores.                                  [1 barrier]
+// Bound: HBM, b n (k + 1) (+ b n weights) bytes in, b n out per group.
+#pragma once
+#include "k2_kernel.inl"
+#include "k2w_resident.hpp"
+
+namespace pols {
+
+constexpr int K2W_KC = 32;                       // column slots (two 16-column MFMA tiles)
+constexpr int K2W_GS = 33;                       // row stride of the f64 matrices in LDS
+constexpr int K2W_TAIL_B = (2 * 32 * K2W_GS + 64 + 64) * 8;   // Z'Z, the solver's matrix, 64 doubles of vectors, the solver's column buffers
+
+// Cholesky of X'X + alpha I (faer cholesky(Side::Lower), ls.rs:288-297) and the two triangular solves on the 32 x 32 padded system;
+// false = failed / flagged pivot.  G: Z'Z with X'y in column kt; Tm: 32 x 33 scratch.  Lane i keeps row i of the factor in registers,
+// v_readlane broadcasts (k2_chol's form at 32 columns).  Measured against publishing the pivot column through LDS once per step
+// (one round trip instead of 2 (kt - j) broadcasts): the LDS form was SLOWER (f64, 31 columns x 1 000 rows: 614 vs 515 us per 5 000 groups).
+__device__ __forceinline__ bool k2w_chol(const double *G, int kt, double alpha, double pivot_tol, double *Tm, int lane, double &bi) {
+    constexpr int KC = K2W_KC;
+    const int i = lane & 31;                             // lanes 32..63 repeat lanes 0..31 (broadcasts read lanes 0..31)
+    // [X'X + alpha I | X'y] padded with an identity block, built in LDS by a rolled loop (written as per-lane selects in the unrolled
+    // code the padding constants would be hoisted out of the persistent group loop into registers)
+#pragma unroll 1
+    for (int q = lane; q < KC * (KC + 1); q += 64) {
+        const int r = q / (KC + 1), c = q - r * (KC + 1);
+        double v;
+        if (c == KC) v = r < kt ? G[r * K2W_GS + kt] : 0.0;
+        else v = (r < kt && c < kt) ? G[r * K2W_GS + c] + (r == c ? alpha : 0.0) : (r == c ? 1.0 : 0.0);
+        Tm[r * K2W_GS + c] = v;
+    }
+    k2_wave_sync();
+    double row[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) row[c] = Tm[i * K2W_GS + c];
+    bi = Tm[i * K2W_GS + KC];
+    const double gd = Tm[i * K2W_GS + i];
+    k2_wave_sync();                                      // Tm is rewritten for the transposition below
+    double rme = 1.0;                                    // 1 / L[i][i], kept on lane i
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        if (j < kt) {                                    // wave-uniform: the identity block needs no elimination
+            const double d = k2_bcast(row[j], j);
+            ok = ok & (d > pivot_tol * k2_bcast(gd, j)); // also false for NaN
+            const double ri = k2_rsqrt(d);
+            if (i == j) rme = ri;
+            row[j] *= ri;                                // L[i][j] on the lanes below the diagonal
+#pragma unroll
+            for (int c = j + 1; c < KC; ++c) row[c] = fma(-row[j], k2_bcast(row[j], c), row[c]);   // - L[i][j] L[c][j]
+            __builtin_amdgcn_sched_barrier(0);           // a column's broadcasts stay in their column
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < KC; ++p) {                       // forward: t = L^-1 b (rows beyond kt: identity, b = 0)
+        if (p < kt) {
+            const double tp = k2_bcast(bi * rme, p);
+            bi = (i == p) ? tp : ((i > p) ? fma(-row[p], tp, bi) : bi);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (lane < 32) {                                     // the backward solve needs column i of L on lane i: one transposition through LDS
+#pragma unroll
+        for (int c = 0; c < KC; ++c) Tm[i * K2W_GS + c] = row[c];
+    }
+    k2_wave_sync();
+#pragma unroll
+    for (int c = 0; c < KC; ++c) row[c] = Tm[c * K2W_GS + i];   // L[c][i]
+#pragma unroll
+    for (int p = KC - 1; p >= 0; --p) {                  // backward: beta = L^-T t
+        if (p < kt) {
+            const double bp = k2_bcast(bi * rme, p);
+            bi = (i == p) ? bp : ((i < p) ? fma(-row[p], bp, bi) : bi);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    k2_wave_sync();
+    return ok;
+}
+
+template <typename T, int WAVES, bool HAS_W>
+__global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
+    using V = typename Vec16<T>::type;
+    using M = Mfma16<T>;
+    using acc_t = typename M::acc_t;
+    using H = decltype(k2_half(V{}, 0));                     // double or float2
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int TPB = 64 * WAVES;
+    constexpr int KC = K2W_KC;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *Gs = reinterpret_cast<double *>(smem + (size_t)WAVES * K2_TILE_B);      // [32][33]
+    double *As = Gs + 32 * K2W_GS;                                                    // solver matrix [32][33]
+    double *vec = As + 32 * K2W_GS;                                                   // [0, 32) beta
+    double *cbuf = vec + 64;                                                          // 2 x 32: the solver's double-buffered column
+
+#pragma unroll 1
+    for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+    // the thread index and the column counts are laundered once per group (see k2_kernel: nothing derived from them may be hoisted
+    // out of the persistent loop into registers that sit on top of the resident rows)
+    int tid = threadIdx.x, kt = a.kt, ku = a.k_user;
+    asm volatile("" : "+v"(tid), "+s"(kt), "+s"(ku) :: "memory");
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool icpt = ku != kt;
+    constexpr bool has_w = HAS_W;
+    unsigned char *mytile = smem + (size_t)wave * K2_TILE_B;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t base = s - (s % VEC);                      // the chunk grid is aligned to 16 bytes in every column
+    const int64_t nch = (e - base + VEC - 1) / VEC;          // <= TPB: the host checked the largest group
+    unsigned long long *dbg = a.dbg ? a.dbg + g * 8 : nullptr;
+#define K2W_STAMP(i) do { if (dbg && tid == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    K2W_STAMP(0);
+
+    // ---- every load of the resident chunk, back to back, no divergent branch around a load (k2_kernel's scheme): lanes whose chunk
+    // crosses the group's edge read their neighbours' rows too, lanes without a chunk read from a clamped position; a wave-uniform
+    // fix-up shifts / zeroes afterwards.  Column slots beyond the user's features are not loaded (wave-uniform).
+    V x[KC], yv, sw;
+    unsigned keep = 0;                                       // bit v: row v of the chunk belongs to the group
+    int shift;                                               // rows the load position was moved back by (end of the frame)
+    const int64_t row0 = base + (int64_t)tid * VEC;
+    {
+        const bool any = tid < nch;
+        int64_t rl = any ? row0 : base;
+        if (rl > a.n_rows - VEC) rl = a.n_rows - VEC;        // n_rows >= VEC: checked by the host
+        shift = any ? (int)(row0 - rl) : 0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) keep |= (any && row0 + v >= s && row0 + v < e) ? (1u << v) : 0u;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)                         // (one chunk per lane: every load is awaited before the first use anyway, so a
+            if (j < ku) x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + rl);   // wave-uniform skip costs nothing)
+        yv = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + rl);
+        sw = *reinterpret_cast<const V *>(static_cast<const T *>(has_w ? a.w : a.y) + rl);
+    }
+
+    // ---- this chunk's registers
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+        if (j >= ku) x[j] = vsplat<T>((icpt && j == kt - 1) ? T(1) : T(0));      // wave-uniform: intercept / unused slot
+    if (!has_w) sw = vsplat<T>(T(1));
+    if (__any(keep != ((1u << VEC) - 1u))) {                 // wave-uniform, no loads inside: a ragged edge somewhere in the wave
+#pragma unroll
+        for (int j = 0; j < KC; ++j) x[j] = k2_fix<T>(x[j], (j < ku) ? shift : 0, keep, T(0));
+        yv = k2_fix<T>(yv, shift, keep, T(0));
+        sw = k2_fix<T>(sw, has_w ? shift : 0, keep, T(1));
+    }
+    if (has_w) {       // sqrt(w) scaling of every feature, intercept included (least_squares.py:190-196); yv keeps the ORIGINAL target
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const T q = sqrt(vget<T>(sw, v));
+            vset<T>(sw, v, q);
+#pragma unroll
+            for (int j = 0; j < KC; ++j) vset<T>(x[j], v, vget<T>(x[j], v) * q);
+        }
+    }
+    V ys;                                                    // sqrt(w) y
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) vset<T>(ys, v, vget<T>(yv, v) * vget<T>(sw, v));
+
+    // ---- Gram: per 8-byte half of the chunk, transpose both 16-column halves of Z through the wave's tile and feed the matrix cores
+    double accd[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accd[t][r] = 0.0;
+    acc_t acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+    const unsigned char *zp = mytile + (size_t)(lane & 15) * K2_SLOT_B + (lane >> 4) * 8;   // operand stream of lane (c, q)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // half 0 of Z: columns 0 .. 15 (always features: kt >= 17)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *reinterpret_cast<H *>(mytile + (size_t)j * K2_SLOT_B + lane * 8) = k2_half(x[j], h);
+        k2_wave_sync();
+        if (h == 0) K2W_STAMP(1);                            // this wave's loads have landed
+        H va[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) va[u] = *reinterpret_cast<const H *>(zp + u * 32);
+        k2_wave_sync();                                      // everyone has its operands: the tile may be overwritten
+        // half 1: columns 16 .. 31 -- features, intercept, zeros (x[j] already holds them) and the target in slot kt - 16
+#pragma unroll
+        for (int j = 16; j < KC; ++j) {
+            const H vj = (j == kt) ? k2_half(ys, h) : k2_half(x[j], h);          // wave-uniform select
+            *reinterpret_cast<H *>(mytile + (size_t)(j - 16) * K2_SLOT_B + lane * 8) = vj;
+        }
+        k2_wave_sync();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const H vb = *reinterpret_cast<const H *>(zp + u * 32);
+            if constexpr (sizeof(T) == 8) {
+                acc00 = M::mma(va[u], va[u], acc00);
+                acc01 = M::mma(va[u], vb, acc01);
+                acc11 = M::mma(vb, vb, acc11);
+            } else {
+                acc00 = M::mma(va[u].x, va[u].x, acc00);
+                acc01 = M::mma(va[u].x, vb.x, acc01);
+                acc11 = M::mma(vb.x, vb.x, acc11);
+                acc00 = M::mma(va[u].y, va[u].y, acc00);
+                acc01 = M::mma(va[u].y, vb.y, acc01);
+                acc11 = M::mma(vb.y, vb.y, acc11);
+            }
+        }
+        if constexpr (sizeof(T) == 4) {                      // 128 rows per flush: an f32 Gram matrix with f64-summation error
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accd[0][r] += (double)acc00[r]; accd[1][r] += (double)acc01[r]; accd[2][r] += (double)acc11[r];
+            }
+            acc00 = acc_t{0, 0, 0, 0}; acc01 = acc_t{0, 0, 0, 0}; acc11 = acc_t{0, 0, 0, 0};
+        }
+        k2_wave_sync();                                      // the next stage overwrites the tile
+    }
+    if constexpr (sizeof(T) == 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accd[0][r] = acc00[r]; accd[1][r] = acc01[r]; accd[2][r] = acc11[r]; }
+    }
+    K2W_STAMP(2);
+    // ---- per-wave partial tiles -> LDS (3 x 256 doubles = 6 KB of the wave's own tile)
+    {
+        double *part = reinterpret_cast<double *>(mytile);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[t * 256 + r * 64 + lane] = accd[t][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 3 * 256; idx += TPB) {
+        const int t = idx >> 8, q = idx & 255, r = q >> 6, l = q & 63;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += reinterpret_cast<const double *>(smem + (size_t)w * K2_TILE_B)[idx];
+        const int drow = (sizeof(T) == 4) ? (l >> 4) * 4 + r : (l >> 4) + 4 * r;   // C/D layouts of the f32 / f64 16x16x4 MFMA
+        const int dcol = l & 15;
+        const int gi = (t == 2 ? 16 : 0) + drow, gj = (t == 0 ? 0 : 16) + dcol;     // tile (0,0), (0,1), (1,1)
+        Gs[gi * K2W_GS + gj] = v;
+        if (t == 1) Gs[gj * K2W_GS + gi] = v;                                       // (1,0) = (0,1)'
+    }
+    __syncthreads();
+    K2W_STAMP(3);
+
+    // ---- solve: wave 0, f64
+    if (wave == 0) {
+        int st = POLS_GROUP_OK;
+        double bi = 0.0;
+        if (e == s) st = POLS_GROUP_EMPTY;                   // features.is_empty() -> zeros (ex.rs:357-359)
+        else if (!k2w_chol(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi)) {
+            st = POLS_GROUP_FALLBACK;
+            if (lane == 0 && a.fb_flag) *a.fb_flag = a.epoch;
+        }
+        if (lane == 0 && a.status) a.status[g] = st;
+        if (lane < 32) {
+            const double out = lane < kt ? bi : 0.0;
+            vec[lane] = out;
+            if (lane < kt && a.coef) static_cast<T *>(a.coef)[g * kt + lane] = (T)out;
+        }
+    }
+    __syncthreads();
+    K2W_STAMP(4);
+
+    // ---- predictions / residuals from the resident rows
+    if (a.pred || a.resid) {
+        T *pred = static_cast<T *>(a.pred);
+        T *resid = static_cast<T *>(a.resid);
+        T p[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) p[v] = T(0);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {                       // make_predictions (ex.rs:398-405); coefficient j straight from LDS (0 beyond kt)
+            const T bj = (T)vec[j];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) p[v] = fma(vget<T>(x[j], v), bj, p[v]);
+        }
+        if (tid < nch) {
+            V pv, rv;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                T acc = p[v];
+                if (has_w) acc *= T(1) / vget<T>(sw, v);                                         // predictions *= 1/sqrt_w (ls.py:234-235)
+                vset<T>(pv, v, acc);
+                vset<T>(rv, v, vget<T>(yv, v) - acc);                                            // ORIGINAL target - predictions (ls.py:239)
+            }
+            if (keep == ((1u << VEC) - 1u)) {
+                if (pred) store_stream(reinterpret_cast<V *>(pred + row0), pv);
+                if (resid) store_stream(reinterpret_cast<V *>(resid + row0), rv);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const int64_t rr = row0 + v;
+                    if (rr >= s && rr < e) {
+                        if (pred) pred[rr] = vget<T>(pv, v);
+                        if (resid) resid[rr] = vget<T>(rv, v);
+                    }
+                }
+            }
+        }
+    }
+    K2W_STAMP(5);
+    if (dbg && tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dbg[6] = xcc;
+    }
+#undef K2W_STAMP
+    __syncthreads();                                         // vec / Gs / the tiles are rewritten by the next group
+    }   // groups of this workgroup
+}
+
+template <typename T, int WAVES, bool HAS_W>
+static int k2w_launch_v(pols_ctx *ctx, const K2wArgs &a) {
+    const size_t lds = (size_t)WAVES * K2_TILE_B + K2W_TAIL_B;
+    // persistent: two waves per SIMD by the register budget -> one 8-wave or two 4-wave workgroups per CU
+    const unsigned grid = (unsigned)std::min<int64_t>(a.n_groups, (int64_t)ctx->num_cus * (8 / WAVES));
+    static OncePerDevice attr_once;
+    if (attr_once.needed(ctx->device)) {
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k2w_kernel<T, WAVES, HAS_W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_once.done(ctx->device);
+    }
+    char name[96];
+    std::snprintf(name, sizeof(name), "k2w_gram_mfma_resident2_%s_k%d_w%d%s_chol", sizeof(T) == 4 ? "f32" : "f64", a.kt, WAVES, a.w ? "_w" : "");
+    ctx->last_kernel = name;
+    if (a.n_groups > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
+    K2wArgs aa = a;
+    if (ctx->opt.timeline) {
+        void *d = nullptr;
+        int rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)a.n_groups, &d);
+        if (rc) return rc;
+        aa.dbg = static_cast<unsigned long long *>(d);
+    }
+    hipEvent_t ev0, ev1;
+    if (timing_pair(ctx, &ev0, &ev1))
+        hipExtLaunchKernelGGL((k2w_kernel<T, WAVES, HAS_W>), dim3(grid), dim3(64 * WAVES), (unsigned)lds, ctx->stream, ev0, ev1, 0, aa);
+    else
+        hipLaunchKernelGGL((k2w_kernel<T, WAVES, HAS_W>), dim3(grid), dim3(64 * WAVES), lds, ctx->stream, aa);
+    POLS_HIP(hipGetLastError());
+    if (ctx->opt.timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
+    return POLS_OK;
+}
+
+template <typename T>
+int k2w_launch_t(pols_ctx *ctx, const K2wArgs &a, int64_t need) {
+    constexpr int VEC = Vec16<T>::N;
+    if (need <= 256 * VEC) return a.w ? k2w_launch_v<T, 4, true>(ctx, a) : k2w_launch_v<T, 4, false>(ctx, a);
+    if (need <= 512 * VEC) return a.w ? k2w_launch_v<T, 8, true>(ctx, a) : k2w_launch_v<T, 8, false>(ctx, a);
+    return fail(POLS_ERR_UNSUPPORTED, "k2w: %lld-row groups exceed the resident capacity", (long long)need);
+}
+
+}  // namespace pols

@@ -9,8 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polars_ols_amd.engine import Engine  # noqa: E402
 
 eng = Engine(0)
+if os.environ.get("ENGINE"):                                  # ENGINE=k2w | stream: force an engine (A/B)
+    eng.set_option("STATIC_ENGINE", os.environ["ENGINE"])
+KS = tuple(int(v) for v in os.environ.get("KS", "15,16,20,24,31").split(","))
 for dt, dname in ((torch.float32, "f32"), (torch.float64, "f64")):
-    for k in (15, 16, 20, 24, 31):
+    for k in KS:
         for G, n in ((10_000, 1000), (50_000, 200)):
             if dt == torch.float64 and k > 20 and n == 1000:
                 G = 5_000

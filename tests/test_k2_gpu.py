@@ -260,3 +260,53 @@ def test_persistent_workgroups_and_prefetch(eng, dtype, kt, weights, icpt, kw):
     finally:
         eng.set_option("K2_NOPREFETCH", None)
     assert np.array_equal(_np(out["coef"]), _np(out2["coef"])) and np.array_equal(_np(out["pred"]), _np(out2["pred"]))
+
+
+# ----------------------------------------------------------------------------------------------------------------- K2w (17..31 columns)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kt,weights,icpt,alpha", [(17, False, False, 0.0), (24, True, True, 0.0), (31, True, False, 0.7), (31, False, True, 0.0),
+                                                    (20, False, True, 2.0)])
+@pytest.mark.parametrize("shape", ["w4", "w8"])
+def test_k2w_two_tile_resident_kernel(eng, dtype, kt, weights, icpt, alpha, shape):
+    """17..31 columns with every row resident in registers and Z'Z as three 16 x 16 tiles on the matrix cores (k2w_kernel.inl): ragged,
+    unaligned groups up to the capacity of the four- / eight-wave workgroup, an empty group, a rank-deficient one (fix-up pass),
+    weights, intercept, ridge -- against the oracle.  POLS_STATIC_ENGINE=k2w takes the shapes the resident K1 kernels would."""
+    from oracle import orc
+
+    vec = 4 if dtype == np.float32 else 2
+    lo, hi = (kt + 9, 256 * vec - vec) if shape == "w4" else (256 * vec + 1, 512 * vec - vec)
+    rng = np.random.default_rng(kt * 10 + (1 if shape == "w8" else 0))
+    sizes = rng.integers(lo, hi + 1, size=260 if shape == "w4" else 300)
+    sizes[3] = 0
+    sizes[-1] = hi                                                   # the capacity itself
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, kt - int(icpt), dtype, weights=weights)
+    s7, e7 = offs[7], offs[8]
+    cols[2][s7:e7] = cols[5][s7:e7]                                  # rank-deficient group: flagged, re-solved by the fix-up pass
+    eng.set_option("STATIC_ENGINE", "k2w")
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                                alpha=alpha, l1_ratio=0.0 if alpha else None, want=("coef", "pred", "resid", "status"))
+        name = eng.last_kernel
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
+    assert name.startswith(f"k2w_gram_mfma_resident2_{'f32' if dtype == np.float32 else 'f64'}_k{kt}_w{4 if shape == 'w4' else 8}"), name
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, alpha=alpha, l1_ratio=0.0 if alpha else None)
+    st = _np(out["status"]).astype(int)
+    # (the twin-column group: rank deficient without a penalty -> flagged and re-solved by the fix-up pass; with one it is positive
+    # definite -- an f32 batch may still flag it when cond * eps_f32 is beyond the tolerance, and gets the f64 answer from the fix-up)
+    assert st[3] == 2 and (st[7] == 1 or alpha > 0) and (np.delete(st, [3, 7]) == 0).all(), st[:10]
+    _check(out, ref, dtype)
+
+
+def test_k2w_is_the_default_beyond_the_resident_k1_shapes(eng):
+    """f64, 31 columns x 1 000 rows (248 KB per group): used to take the three-launch streamed path (X read twice).  (17..24 f64 columns
+    beyond 512 rows stay with it: measured ahead there.)"""
+    from oracle import orc
+
+    rng = np.random.default_rng(5)
+    offs = np.arange(0, 41 * 1000, 1000, dtype=np.int64)
+    y, cols, _ = _frame(rng, offs, 31, np.float64)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "resid", "status"))
+    assert eng.last_kernel.startswith("k2w_gram_mfma_resident2_f64_k31_w8"), eng.last_kernel
+    _check(out, orc.batched_least_squares(y, cols, offs), np.float64)

@@ -159,6 +159,26 @@ def test_ill_conditioned_f32_group_is_rescued_in_f64(eng):
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("k", [3, 12, 20, 40])
+def test_f32_ridge_on_collinear_data_is_rescued_in_f64(eng, k):
+    """Ridge on data with two identical columns, f32: cond(X'X + alpha I) * eps_f32 is beyond the 1e-4 tolerance, the pivot test flags
+    the group and the fix-up pass runs the reference's own chain (Cholesky of X'X + alpha I, then LU) in f64 -- WITH the penalty on
+    the diagonal.  Every engine width: K1, K2, K1w / K2w, K8."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k)
+    n = 900
+    cols = [rng.standard_normal(n).astype(np.float32) for _ in range(k)]
+    cols[1] = cols[0].copy()
+    y = (sum(c.astype(np.float64) for c in cols) + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    offs = np.array([0, n], dtype=np.int64)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, alpha=0.05, l1_ratio=0.0, want=("coef", "pred", "status"))
+    ref = orc.batched_least_squares(y, cols, offs, alpha=0.05, l1_ratio=0.0)
+    assert int(_np(out["status"])[0]) == 1
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-4, atol=1e-4), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-4, atol=1e-4)
+
+
 def test_ridge_on_collinear_data_needs_no_fallback(eng):
     from oracle import orc
 
