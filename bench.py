@@ -349,8 +349,10 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     # per-launch HIP events inside the timed region, stamped by the kernel's own dispatch packet (hipExtLaunchKernelGGL); every
-    # 4th launch is sampled: an event pair costs ~5 us on the stream's timeline, 6 % of the headline kernel
-    eng.timing(4)
+    # 8th launch is sampled (launches 0, 8, 16, ...): an event-bracketed launch cannot overlap its neighbours' ramp-up / tail and costs
+    # ~5 us on the stream's timeline, 6 % of the headline kernel
+    stride = int(os.environ.get("POLS_BENCH_EVENT_STRIDE", "8"))
+    eng.timing(stride)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -69,6 +69,13 @@ int ensure_scratch(pols_ctx *ctx, int slot, size_t bytes, void **out) {
 
 int upload_small(pols_ctx *ctx, void *dst_device, const void *src, size_t bytes) {
     if (bytes == 0) return POLS_OK;
+    if (bytes > ((size_t)1 << 20)) {
+        // not small (per-row tables of a masked frame, offsets of millions of groups): straight from the caller's array, and the
+        // stream is drained before returning because `src` may be freed -- the pinned ring stays at ~1 MB per slot for good
+        POLS_HIP(hipMemcpyAsync(dst_device, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        POLS_HIP(hipStreamSynchronize(ctx->stream));
+        return POLS_OK;
+    }
     auto &slot = ctx->pinned[ctx->pinned_next];
     ctx->pinned_next = (ctx->pinned_next + 1) % 4;
     if (slot.busy) { POLS_HIP(hipEventSynchronize(slot.done)); slot.busy = false; }   // long complete in steady state
@@ -1264,7 +1271,9 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, int null_policy,
     const size_t sz = dtype_size(b->dtype), colb = round256(sz * (size_t)b->n_rows), vb = round256((size_t)b->n_rows);
     char *base = nullptr;
     DynPrepArgs &pa = ds->pa;
-    if (scan || has_w || icpt) {
+    // (a caller's validity bytes without weights / intercept: the columns may still hold NaNs on the masked rows -- they are
+    //  zero-filled like everywhere else, so that no prefix sum ever meets a NaN; null_free says there is nothing to fill)
+    if (scan || has_w || icpt || (st->valid != nullptr && !b->null_free)) {
         // slot 14: [flags][validity bytes][feature pointers in][column pointers out][sqrt(w)][target][k columns]
         void *d = nullptr;
         const size_t tabb = round256(sizeof(void *) * (size_t)std::max(k, 1));

@@ -175,3 +175,25 @@ def test_null_free_hint_skips_the_policy_work(eng):
         b = fn(yy, cc, offs, null_policy="drop", add_intercept=True, null_free=True, **kw)
         eng.synchronize()
         assert torch.equal(a["coef"].nan_to_num(7.0), b["coef"].nan_to_num(7.0)) and torch.equal(a["pred"].nan_to_num(7.0), b["pred"].nan_to_num(7.0))
+
+
+@pytest.mark.parametrize("kind,kw", [("rls", dict(half_life=15.0)), ("rolling", dict(window_size=25, min_periods=6))])
+@pytest.mark.parametrize("device", [False, True])
+def test_callers_validity_bytes_with_nans_left_in_the_columns(eng, kind, kw, device):
+    """The caller passes its own validity bytes, NO weights and NO intercept, and its columns still hold NaNs on the masked rows (what a
+    null looks like after a cast): the entry zero-fills them like everywhere else -- a NaN must never reach the prefix sums."""
+    import torch
+
+    y, cols, offs, _ = _frame(21, np.float64, 3, n_groups=4, lo=80, hi=200, null_weights=False)
+    valid = ~np.isnan(y)
+    for c in cols:
+        valid &= ~np.isnan(c)
+    assert (~valid).sum() > 5
+    coef, pred = _expected(kind, y, cols, offs, None, False, "drop", **kw)
+    t = (lambda a: torch.from_numpy(a).cuda()) if device else (lambda a: a)  # noqa: E731
+    fn = eng.recursive_least_squares if kind == "rls" else eng.rolling_least_squares
+    out = fn(t(y), [t(c) for c in cols], offs, valid=t(valid.astype(np.uint8)), null_policy="drop", **kw)
+    eng.synchronize()
+    get = lambda a: (a.cpu().numpy() if device else np.asarray(a)).astype(np.float64)  # noqa: E731
+    assert _close(get(out["coef"]), coef, 1e-6), float(np.nanmax(np.abs(get(out["coef"]) - coef)))
+    assert _close(get(out["pred"]), pred, 1e-6)
