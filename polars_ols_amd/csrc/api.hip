@@ -854,7 +854,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     // solve_ridge_svd with a caller-supplied rcond (ls.rs:143-148): singular values below rcond * s_max are dropped on EVERY
     // group, full rank or not -- a truncated solve is not the normal-equation solution, so the Jacobi-SVD kernel takes all of
     // them (one workgroup per group from a pool of up to 2 048 workers; an opt-in, rarely used form of the call).
-    if (!enet && !ols_branch && m == POLS_SOLVE_SVD && p->has_rcond) {
+    // A whole frame of fewer rows than one 16-byte vector (1-3 f32 / 1 f64 rows) goes the same way: the vector kernels clamp their
+    // loads into the columns and need that much to clamp into; the fix-up solvers are the reference's own for every (branch, method).
+    const bool tiny_frame = !enet && b->n_rows < (b->dtype == POLS_F32 ? 4 : 2);
+    if (!enet && ((!ols_branch && m == POLS_SOLVE_SVD && p->has_rcond) || tiny_frame)) {
         if ((rc = prepare_fix(2048))) return rc;
         hipLaunchKernelGGL(mark_fallback_kernel, dim3((unsigned)((b->n_groups + 255) / 256)), dim3(256), 0, ctx->stream, d_offs,
                            b->n_groups, st.status, ctx->fb_flag, ctx->epoch, 0);

@@ -1202,7 +1202,15 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     }
     hipEvent_t ev0, ev1;
     constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !NULLS;
-    void (*kern)(const K1Args) = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>;
+    // The GENERAL (chunk-by-chunk, streamed-overflow) form only exists for the single-pass kernels: a multi-pass kernel is launched
+    // only when every row stays resident (its callers check), and a ragged resident frame takes the branch-free EDGE form -- so the
+    // general form of a multi-pass kernel would be code nothing launches (676 instantiations, a quarter of the library).  Frames of
+    // fewer than VEC rows never get here (the dispatcher hands them to the fix-up solvers).
+    constexpr bool GENERAL = FAST || NPASS == 1;
+    void (*kern)(const K1Args) = k1_kernel<T, KT, HAS_W, TEAM, RC, GENERAL ? FAST : true, NPASS, NULLS, false, !GENERAL>;
+    if constexpr (!GENERAL)
+        std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d_edge%s%s", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", TEAM, RC,
+                      passes, NULLS ? "_nulls" : "");
     // the f32 wave-per-group FAST kernel (BASELINE configs[1]) reads its columns with `nt` (streaming) loads: every line is used
     // once, so it should not compete for L2 with lines that are -- 73.2-73.3 against 74.3-75.0 us per 400 MB launch
     // (POLS_K1_NT_LOADS=0 selects the plain-load build of the same kernel)
@@ -1218,7 +1226,7 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     }
     if constexpr (NULLS && sizeof(T) == 4 && TEAM == 64 && RC == 4 && KT <= 8 && !HAS_W)
         kern = k1_kernel_occ2<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>;
-    if constexpr (!FAST) {
+    if constexpr (!FAST && GENERAL) {
         // ragged frames whose groups all stay resident: the branch-free EDGE form of the FAST kernel instead of the general code
         // (POLS_K1_NOEDGE=1 goes back)
         constexpr int VEC = Vec16<T>::N;

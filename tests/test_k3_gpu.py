@@ -33,6 +33,11 @@ def _np(t):
     return t.double().cpu().numpy() if hasattr(t, "cpu") else np.asarray(t, dtype=np.float64)
 
 
+def _masked(pred, valid):
+    """make_predictions with the validity mask (src/expressions.rs:640-645): rows the mask leaves out are nulls (NaN here)"""
+    return np.where(np.asarray(valid).astype(bool), pred, np.nan)
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("k", [1, 2, 6, 8])
 @pytest.mark.parametrize("half_life,p0,mean", [(None, 10.0, None), (21.0, 10.0, None), (252.0, 0.01, 0.25), (None, 1e6, None)])
@@ -55,7 +60,7 @@ def test_rls_many_groups(eng, rls_engine, dtype, tol, k, half_life, p0, mean):
     assert eng.last_kernel.startswith("k3s_" if rls_engine == "scan" else "k3_rls")
     scale = 1.0 if p0 < 1e5 else 50.0               # a diffuse prior makes the first rows ill-conditioned in ANY arithmetic
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol * scale, atol=tol * scale)
-    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol * scale, atol=tol * scale)
+    assert np.allclose(_np(out["pred"]), _masked(ref["pred"], valid), rtol=tol * scale, atol=tol * scale, equal_nan=True)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
@@ -81,7 +86,7 @@ def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
                           is_valid=valid)
     assert eng.last_kernel.startswith("k3sw_")
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
-    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
+    assert np.allclose(_np(out["pred"]), _masked(ref["pred"], valid), rtol=tol, atol=tol, equal_nan=True)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
@@ -105,7 +110,7 @@ def test_rls_inverse_propagation_33_features_and_up(eng, dtype, tol, k, half_lif
     ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0, is_valid=valid)
     assert eng.last_kernel.startswith("k3y_" if k > 128 else "k3x_")
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
-    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
+    assert np.allclose(_np(out["pred"]), _masked(ref["pred"], valid), rtol=tol, atol=tol, equal_nan=True)
 
 
 def test_rls_readme_known_answer(eng, golden):

@@ -74,7 +74,8 @@ def test_rolling_many_groups(eng, policy, k, window, min_periods, alpha, null_fr
     sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
     strict = sane & (nobs >= k + 2)
     assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
-    assert np.allclose(got_p[strict], ref["pred"][strict], rtol=1e-5, atol=1e-6)
+    vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
+    assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
     assert window < k + 2 or strict.sum() > 0.5 * sane.sum()
 
 
@@ -106,7 +107,8 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
     strict = sane & (nobs >= k + 4)
     assert strict.sum() > 0.3 * sane.sum()
     assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
-    assert np.allclose(got_p[strict], ref["pred"][strict], rtol=1e-5, atol=1e-6)
+    vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
+    assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
 
 
 @pytest.mark.parametrize("policy", ["drop", "drop_window"])
@@ -135,7 +137,8 @@ def test_rolling_inverse_propagation_33_features_and_up(eng, policy, k, window, 
     strict = sane & (nobs >= 2 * k)                                  # well-conditioned windows
     assert strict.sum() > 0.2 * sane.sum()
     assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
-    assert np.allclose(got_p[strict], ref["pred"][strict], rtol=1e-5, atol=1e-6)
+    vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
+    assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
 
 
 def test_rolling_non_contiguous_reference_case():               # tests/test_ols.py:969-995 (10 features, weights, drop)
@@ -253,4 +256,5 @@ def test_rolling_min_periods_beyond_the_window(eng, policy, k, window, min_perio
     assert sane.sum() > 0.5 * len(y)
     tol = 1e-6 if k < 32 else 1e-5
     assert np.allclose(got_c[sane], ref["coef"][sane], rtol=tol, atol=tol), float(np.abs(got_c[sane] - ref["coef"][sane]).max())
-    assert np.allclose(got_p[sane], ref["pred"][sane], rtol=tol, atol=tol)
+    vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)
+    assert np.allclose(got_p[sane & vm], ref["pred"][sane & vm], rtol=tol, atol=tol) and np.isnan(got_p[~vm]).all()
