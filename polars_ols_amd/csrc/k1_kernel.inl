@@ -515,16 +515,21 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 // branches: with the same group sizes it runs 797 vs 679 us (130..252 rows) and 118 vs 91 us (100..300 rows) behind FAST.
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool NT = false,
           bool EDGE = false>
-__device__ __forceinline__ void k1_body(const K1Args &a) {
+__device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
     static_assert(!EDGE || FAST, "EDGE refines FAST");
+    // (tried: a PERSISTENT form of the 256-thread team -- one workgroup per resident slot walking the groups b, b + gridDim.x, ... --
+    // 90 registers once the thread index is laundered per group (109 without), and SLOWER: 73.3 us at five workgroups per CU, 75.8 at
+    // four, against 66.9 us for the one-shot grid on the same box.  The hardware's workgroup dispatcher refills a finished slot
+    // faster than a loop iteration that must drain its stores and re-synchronise.)
+    const int tix = threadIdx.x;
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
     constexpr int NACC = NZ * (NZ + 1) / 2;
     constexpr int WAVES = TEAM / 64;
-    const int lane = threadIdx.x & 63;
-    const int wave = (threadIdx.x >> 6) % WAVES;
-    const int tid = threadIdx.x % TEAM;
-    const int64_t g = (int64_t)blockIdx.x * (blockDim.x / TEAM) + threadIdx.x / TEAM;   // blockDim.x: 256, or TEAM (see k1_launch_fast)
+    const int lane = tix & 63;
+    const int wave = (tix >> 6) % WAVES;
+    const int tid = tix % TEAM;
+    const int64_t g = bid * (blockDim.x / TEAM) + tix / TEAM;   // bid: blockIdx.x, or the persistent kernel's walk (blockDim.x: 256)
     if (g >= a.n_groups) return;   // wave-uniform for TEAM=64; never taken for TEAM=256 (grid == n_groups)
 
     const int64_t s = a.offs[g], e = a.offs[g + 1];
@@ -606,7 +611,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
     constexpr int NACC4 = (NACC + 3) / 4;
     constexpr int SLOTS = NACC4 * 4;                         // accumulator slots, padded to a multiple of 4
     __shared__ __attribute__((aligned(16))) T part[(256 / TEAM) * (SLOTS * WAVES + 32)];
-    T *mypart = part + (threadIdx.x / TEAM) * (SLOTS * WAVES + 32);   // one region per team
+    T *mypart = part + (tix / TEAM) * (SLOTS * WAVES + 32);   // one region per team
     T *bcast = mypart + SLOTS * WAVES;                       // beta broadcast, 32 slots
     if constexpr (NPASS == 1) {
         T u[NACC4];
@@ -631,7 +636,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
     if constexpr (NPASS > 1) {
         constexpr int TEAMS = 256 / TEAM;                          // one scratch set per team of the block
         __shared__ T gsum_s[TEAMS][NACC + 3], lfac_s[TEAMS][KT * KT], lrinv_s[TEAMS][KT];
-        T *gsum = gsum_s[threadIdx.x / TEAM], *lfac = lfac_s[threadIdx.x / TEAM], *lrinv = lrinv_s[threadIdx.x / TEAM];
+        T *gsum = gsum_s[tix / TEAM], *lfac = lfac_s[tix / TEAM], *lrinv = lrinv_s[tix / TEAM];
         if (wave == 0) {
             for (int q = lane; q < NACC; q += 64) {     // NACC = 66 at 10 columns
                 T t = mypart[q * WAVES];
@@ -721,19 +726,19 @@ __device__ __forceinline__ void k1_body(const K1Args &a) {
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool NT = false,
           bool EDGE = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, NT, EDGE>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, NT, EDGE>(a, (int64_t)blockIdx.x);
 }
 // The same body held to 128 VGPRs (four waves per SIMD): the ragged one-chunk-per-lane wave kernel needs 130.
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k1_kernel_occ4(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a, (int64_t)blockIdx.x);
 }
 
 // (the null-policy wave kernel with 16 resident rows sits at exactly 256 VGPRs; one more value and the allocator reaches for an AGPR,
 // which halves the occupancy of the unified register file: 80.7 -> 132 us on 10 000 x 1 000 x 8.  Held to two waves per SIMD.)
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k1_kernel_occ2(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a, (int64_t)blockIdx.x);
 }
 
 // One chunk of a small ragged group, branch-free: the 16-byte loads of every column issued unconditionally (lanes without a chunk

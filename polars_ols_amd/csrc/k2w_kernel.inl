@@ -29,7 +29,7 @@ namespace pols {
 
 constexpr int K2W_KC = 32;                       // column slots (two 16-column MFMA tiles)
 constexpr int K2W_GS = 33;                       // row stride of the f64 matrices in LDS
-constexpr int K2W_TAIL_B = (2 * 32 * K2W_GS + 64 + 64) * 8;   // Z'Z, the solver's matrix, 64 doubles of vectors, the solver's column buffers
+constexpr int K2W_TAIL_B = (2 * 32 * K2W_GS + 64) * 8;   // Z'Z, the solver's matrix, 64 doubles of vectors
 
 // Cholesky of X'X + alpha I (faer cholesky(Side::Lower), ls.rs:288-297) and the two triangular solves on the 32 x 32 padded system;
 // false = failed / flagged pivot.  G: Z'Z with X'y in column kt; Tm: 32 x 33 scratch.  Lane i keeps row i of the factor in registers,
@@ -111,7 +111,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
     double *Gs = reinterpret_cast<double *>(smem + (size_t)WAVES * K2_TILE_B);      // [32][33]
     double *As = Gs + 32 * K2W_GS;                                                    // solver matrix [32][33]
     double *vec = As + 32 * K2W_GS;                                                   // [0, 32) beta
-    double *cbuf = vec + 64;                                                          // 2 x 32: the solver's double-buffered column
 
 #pragma unroll 1
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {

@@ -1,0 +1,61 @@
+#!/bin/bash
+# Round-3 profile: bench lines for every BASELINE config, rocprofv3 kernel-trace stats (cfg2, cfg5), PMC traffic counters in
+# their own passes (FETCH_SIZE / WRITE_SIZE; cfg2 and cfg5), MFMA busy counters for the fused cfg5 kernel.  -> gpurun_out/profile_r3/
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; mkdir -p gpurun_out/profile_r3; O=$R/gpurun_out/profile_r3
+TAG=r03
+echo "== bench lines"
+timeout 600 python bench.py 2> $O/bench.err > $O/${TAG}_bench.json; cut -c1-400 $O/${TAG}_bench.json
+for cfg in cfg1 cfg3 cfg4 cfg4r cfg5 ref100; do
+  timeout 600 python bench.py --config $cfg --steps 20 --warmup 5 2>/dev/null > $O/${TAG}_bench_$cfg.json; cut -c1-300 $O/${TAG}_bench_$cfg.json; echo
+done
+timeout 300 python bench.py --dtype f64 --no-cpu-baseline 2>/dev/null > $O/${TAG}_bench_f64.json; cut -c1-300 $O/${TAG}_bench_f64.json; echo
+timeout 300 python bench.py --mem host --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null > $O/${TAG}_bench_host.json; cut -c1-300 $O/${TAG}_bench_host.json; echo
+cd /tmp && export TMPDIR=/tmp
+for cfg in cfg2 cfg3 cfg5; do
+  echo "== rocprofv3 --kernel-trace --stats $cfg"
+  rm -rf $O/kt_$cfg; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$cfg -o k -- python $R/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof_$cfg.json 2> $O/kt_$cfg.err
+  f=$(find $O/kt_$cfg -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_$cfg.csv && head -5 $O/${TAG}_kernel_stats_$cfg.csv | cut -c1-260
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    echo "== rocprofv3 --pmc $ctr $cfg"
+    rm -rf $O/pmc_${ctr}_$cfg; timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_${ctr}_$cfg -o p -- python $R/bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_${ctr}_$cfg.err
+    f=$(find $O/pmc_${ctr}_$cfg -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python3 - "$f" $ctr <<'PY' | tee $O/${TAG}_pmc_${ctr}_$cfg.txt
+import csv,sys,collections
+acc=collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if r.get('Counter_Name')==sys.argv[2] and ('k1_' in r['Kernel_Name'] or 'k2_' in r['Kernel_Name'] or 'k2w_' in r['Kernel_Name']):
+        acc[r['Kernel_Name'][:90]].append(float(r['Counter_Value']))
+for k,v in acc.items(): print(sys.argv[2], 'dispatches', len(v), 'mean', sum(v)/len(v), 'kernel', k)
+PY
+    else tail -3 $O/pmc_${ctr}_$cfg.err; fi
+  done
+done
+echo "== rocprofv3 --pmc MFMA busy, cfg5 fused kernel"
+rm -rf $O/pmc_mfma; timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python $R/bench.py --config cfg5 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_mfma.err
+f=$(find $O/pmc_mfma -name "*counter_collection.csv" | head -1)
+if [ -n "$f" ]; then python3 - "$f" <<'PY' | tee $O/${TAG}_pmc_mfma_cfg5.txt
+import csv,sys,collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'k2_' in r['Kernel_Name']: acc[r['Kernel_Name'][:80]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k,v in acc.items(): print(k, {c: sum(x)/len(x) for c,x in v.items()})
+PY
+else tail -5 $O/pmc_mfma.err; fi
+cd $R
+echo "== side benches"
+timeout 200 python scripts/bench_ragged.py 2>/dev/null | tail -1 > $O/${TAG}_bench_ragged.json; cut -c1-1500 $O/${TAG}_bench_ragged.json; echo
+timeout 120 python scripts/bench_nulls.py 2>/dev/null | tail -1 > $O/${TAG}_bench_nulls.json; cat $O/${TAG}_bench_nulls.json; echo
+timeout 200 python scripts/bench_nulls_wide.py 2>/dev/null | tail -1 > $O/${TAG}_bench_nulls_wide.json; cut -c1-800 $O/${TAG}_bench_nulls_wide.json; echo
+timeout 120 python scripts/bench_layout.py 2>/dev/null | tail -1 > $O/${TAG}_bench_layout.json; cut -c1-600 $O/${TAG}_bench_layout.json; echo
+timeout 200 python scripts/bench_k9.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k9.txt; cut -c1-160 $O/${TAG}_bench_k9.txt
+timeout 200 python scripts/bench_k16.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k16.txt; cat $O/${TAG}_bench_k16.txt
+echo "== rocprofv3 --kernel-trace --stats, ragged / small frames (K1p, K1t)"
+cd /tmp; rm -rf $O/kt_ragged; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ragged -o k -- python $R/scripts/bench_ragged.py > /dev/null 2> $O/kt_ragged.err
+f=$(find $O/kt_ragged -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|pols::" "$f" | cut -c1-200 > $O/${TAG}_kernel_stats_ragged.csv && head -14 $O/${TAG}_kernel_stats_ragged.csv
+cd $R
+echo "== K2w phase timeline, headline A/B (passes = occupancy 6 / 7 waves per SIMD), predictions gather as a world of one"
+timeout 200 python scripts/dbg_timeline_k2w.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_timeline_k2w.txt; cat $O/${TAG}_timeline_k2w.txt | cut -c1-220
+ONLY=default,team256_rc1_p2_nt,team256_rc1_p3_nt,wave_rc4_nt timeout 200 python scripts/ab_headline.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_ab_headline.txt; cat $O/${TAG}_ab_headline.txt
+POLS_BENCH_FORCE_COLLECTIVE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 timeout 200 python bench.py --no-cpu-baseline --gather pred 2>/dev/null > $O/${TAG}_bench_gather_pred_world1.json; cut -c1-400 $O/${TAG}_bench_gather_pred_world1.json; echo
+rm -rf $O/kt_* $O/pmc_FETCH* $O/pmc_WRITE* $O/pmc_mfma
+ls $O
