@@ -404,7 +404,14 @@ static void svd_apply(const double *y, const double *x, int64_t n, int k, int m,
 
 /* ls.rs:183-191 solve_ols_svd on linux-x86_64: LAPACK dgelsd via
  * ndarray-linalg `least_squares` (rcond argument ignored, :181; LAPACK default
- * rcond = machine epsilon).  Minimum-norm solution. */
+ * rcond = machine epsilon).  Minimum-norm solution.
+ * (An EXACTLY dependent column is a knife edge at this cut-off in any SVD: its
+ * singular value comes out as a few eps * s_max, growing with the column count --
+ * {1, 1, 1} on the 3-column frame of the demo notebook, cell 32, rounding noise
+ * divided by rounding noise at 40 columns, in LAPACK as here.  Raising the cut-off
+ * to numpy's eps * max(n, k) would settle that but break a case the reference's
+ * tests DO hold: test_fit_multi_collinear[99-"svd"], n = k = 100 with a 1e-12
+ * shift, resolves a direction at ~5e-14 of s_max.) */
 void orc_solve_ols_svd(const double *y, const double *x, int64_t n, int k, int m, double *beta) {
     svd_apply(y, x, n, k, m, 0, 0.0, DBL_EPSILON, beta);
 }

@@ -693,8 +693,10 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     // (ridge branch: an f32 batch flags what cond * eps_f32 would spoil, an f64 batch only a pivot within rounding noise of 0 -- see ls_core)
     a.pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10)
                              : (b->dtype == POLS_F32 && p->solve_method != POLS_SOLVE_SVD ? 1e-3 : 16.0 * (double)kt * 2.220446049250313e-16);
-    const double eps_nk = 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt);   // see svd_fixup in ls_core
-    a.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (p->solve_method == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
+    // singular-value cut-off of the minimum-norm solver: a caller's rcond (solve_ridge_svd only, ls.rs:143-145), else -1 = "eps * max(fit
+    // rows, columns) of the group" (see prepare_fix in ls_core)
+    a.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16
+                             : (((p->solve_method == POLS_SOLVE_SVD || m > 1) && p->has_rcond) ? p->rcond : -1.0);   // (m > 1: solve_multi_target -> solve_ridge_svd)
     a.status = st.status; a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.coef = st.coef; a.pred = st.pred; a.resid = st.resid;
     a.null_policy = p->null_policy;
@@ -828,13 +830,14 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         ka.coef = st.coef; ka.pred = st.pred; ka.resid = st.resid;
         ka.work = static_cast<double *>(wk); ka.work_stride = stride;
         ka.alpha = ridge_alpha;
-        // dgelsd drops s < eps * s_max (ls.rs:181-191, rcond ignored); solve_ridge_svd: rcond or eps * max(n, k) (ls.rs:143-145);
-        // the Cholesky -> LU fallback of solve_ridge (ls.rs:358-363) has no cut-off at all.
-        // OLS branch: dgelsd drops s < eps * s_max (rcond ignored, ls.rs:181-191).  The rotations themselves leave an exactly
-        // dependent column with a norm of a few ulps of s_max rather than 0, so the cut-off sits 8 ulps up: enough to drop that
-        // noise, far below the 1e-14-relative singular values the reference's test_fit_multi_collinear expects to be resolved.
-        const double eps_nk = 2.220446049250313e-16 * (double)std::max<int64_t>(max_rows, kt);
-        ka.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : (m == POLS_SOLVE_SVD ? (p->has_rcond ? p->rcond : eps_nk) : 0.0);
+        // Singular-value cut-off of the minimum-norm solver, relative to s_max.  OLS branch: dgelsd drops s < eps * s_max (rcond
+        // ignored, ls.rs:181-191); the Jacobi rotations leave an exactly dependent column with a norm of a few ulps of s_max rather
+        // than 0, so the cut-off sits 8 ulps up -- enough for that noise at the widths where it can be told from signal, far below the
+        // ~5e-14-relative direction the reference's test_fit_multi_collinear[99-"svd"] expects to be resolved.  (Exact dependence at
+        // tens of columns is a knife edge at this cut-off in LAPACK too; numpy's eps * max(n, k) would settle it and break that
+        // test.)  Ridge branch "svd": the caller's rcond, else -1 = eps * max(fit rows, columns) OF THE GROUP, computed in the kernel
+        // (solve_ridge_svd, ls.rs:143-145).
+        ka.rc_factor = ols_branch ? 8.0 * 2.220446049250313e-16 : ((m == POLS_SOLVE_SVD && p->has_rcond) ? p->rcond : -1.0);
         // ... and the solver itself is the one the reference runs for this (branch, solve_method): solve_ols None -> pivoted QR when
         // n > k else SVD (ls.rs:224-231), "qr" -> QR, "svd" -> SVD; solve_ridge None / "chol" -> Cholesky then LU, "lu" -> LU (:352-363)
         ka.mode = ols_branch ? (m == POLS_SOLVE_AUTO ? FIX_OLS_AUTO : m == POLS_SOLVE_QR ? FIX_OLS_QR : FIX_MINNORM)
@@ -1688,7 +1691,13 @@ int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, i
     if (n == 1) work(0);
     else {
         std::vector<std::thread> th;
-        for (int r = 0; r < n; ++r) th.emplace_back(work, r);
+        int started = 0;
+        try {                                                      // no C++ exception may cross the C boundary (thread creation can throw)
+            for (; started < n; ++started) th.emplace_back(work, started);
+        } catch (...) {
+            for (auto &t : th) t.join();
+            return fail(POLS_ERR_INVALID, "could not start the host thread of device %d", started);
+        }
         for (auto &t : th) t.join();
     }
     for (int r = 0; r < n; ++r)

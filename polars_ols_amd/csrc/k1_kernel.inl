@@ -1206,7 +1206,7 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         aa.dbg = static_cast<unsigned long long *>(d);
     }
     hipEvent_t ev0, ev1;
-    constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !NULLS;
+    constexpr bool OCC4 = sizeof(T) == 4 && TEAM == 64 && RC == 1 && !FAST && !NULLS && NPASS == 1;   // (the general form: single-pass only, see GENERAL)
     // The GENERAL (chunk-by-chunk, streamed-overflow) form only exists for the single-pass kernels: a multi-pass kernel is launched
     // only when every row stays resident (its callers check), and a ragged resident frame takes the branch-free EDGE form -- so the
     // general form of a multi-pass kernel would be code nothing launches (676 instantiations, a quarter of the library).  Frames of

@@ -111,7 +111,8 @@ __device__ __forceinline__ void k6_process(const K6Args &a, const int worker, co
         }
         __syncthreads();
         if (tid < kt) {
-            const double cutoff = a.rc_factor * smax;
+            const double rcf = a.rc_factor < 0.0 ? 2.220446049250313e-16 * fmax(nfit, (double)kt) : a.rc_factor;   // eps * max(n, k)
+            const double cutoff = rcf * smax;
             double acc = 0.0;
             for (int j = 0; j < kt; ++j) {
                 const double sj = sv[j];

@@ -20,7 +20,7 @@ struct K6Args {
     double *work;            // workers x work_stride doubles
     int64_t work_stride;     // >= (kt + 1) * max_group_rows
     double alpha;            // 0: minimum-norm least squares; > 0: ridge via d = s / (s^2 + alpha)
-    double rc_factor;        // singular values below rc_factor * s_max are dropped
+    double rc_factor;        // singular values below rc_factor * s_max are dropped; < 0: eps * max(fit rows, columns) of the group
     int32_t k_user, kt;
     const uint8_t *valid;    // null policy of the static entry (see common.hpp::null_row_in_fit)
     int32_t null_policy;

@@ -373,7 +373,8 @@ __global__ void __launch_bounds__(256) wide_svd_kernel(const WideArgs a) {
             smax2 = (acc[0] != acc[0]) ? acc[0] : fmax(smax2, acc[0]);
         }
         __syncthreads();
-        const double cutoff = a.rc_factor * sqrt(smax2);
+        const double rcf = a.rc_factor < 0.0 ? 2.220446049250313e-16 * fmax(nfit_g, (double)kt) : a.rc_factor;   // eps * max(n, k)
+        const double cutoff = rcf * sqrt(smax2);
         for (int t = 0; t < m; ++t) {
             const double *yt = yv + (size_t)t * n;
             for (int c = tid; c < nc; c += 256) {                  // g_c = (w_c . y  |  v_c . y) / (s_c^2 + alpha), 0 below the cut-off
