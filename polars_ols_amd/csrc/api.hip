@@ -1621,7 +1621,7 @@ int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, i
     }
     std::vector<int> rcs((size_t)n, POLS_OK);
     std::vector<std::string> errs((size_t)n);
-    auto work = [&](int r) {
+    auto work_impl = [&](int r) {
         auto done = [&](int code) { rcs[(size_t)r] = code; if (code) errs[(size_t)r] = pols_last_error(); };
         pols_ctx *ctx = ctxs[r];
         const int64_t g0 = bounds[(size_t)r], g1 = bounds[(size_t)r + 1], row0 = b->group_offsets[g0], nrows = rcounts[(size_t)r];
@@ -1687,6 +1687,9 @@ int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, i
         if (o->status && (rc2 = pols_comm_gather_rows(cm, so.status, gcounts.data(), (int64_t)sizeof(int32_t), 0, r == 0 ? o->status : nullptr))) return done(rc2);
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("stream synchronisation failed on device %d", ctx->device); return done(POLS_ERR_HIP); }
         return done(POLS_OK);
+    };
+    auto work = [&](int r) {                                       // (an allocation failure inside a device thread must not terminate the process)
+        try { work_impl(r); } catch (...) { rcs[(size_t)r] = POLS_ERR_INVALID; errs[(size_t)r] = "out of host memory"; }
     };
     if (n == 1) work(0);
     else {
