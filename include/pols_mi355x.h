@@ -211,6 +211,11 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
  * coefficient struct to before the plugin sees it; b->add_intercept appends the literal 1.0 feature of
  * polars_ols/least_squares.py:479-483; nulls are the caller's (the Python layer zero-fills or masks, :455-491). */
 int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, void *pred_out);
+/* The same with the plugin's `null_policy` kwarg (PredictKwargs, ex.rs:708): nulls are NaNs here; features are zero-filled unless the
+ * policy is "ignore" (construct_features_array(.., null_policy != Ignore), :725); under "drop" the rows with a null anywhere come
+ * back null (:732-738) -- with NaN as the null that is what the un-filled product already is, so POLS_NULL_DROP computes like
+ * POLS_NULL_IGNORE.  pols_predict == pols_predict_policy(.., POLS_NULL_IGNORE, ..). */
+int pols_predict_policy(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, int32_t null_policy, void *pred_out);
 
 /* mode="statistics": replaces the plugin `least_squares_statistics` (src/expressions.rs:468-509) and
  * src/statistics.rs:15-156 for every group of the batch.  Per group, on the sqrt(w)-scaled rows the reference's

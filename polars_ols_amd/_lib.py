@@ -79,7 +79,7 @@ EXPORTS = [
     "pols_use_private_stream",
     "pols_synchronize", "pols_timing_enable", "pols_timing_collect", "pols_last_kernel_name", "pols_set_option",
     "pols_ols_params_default", "pols_rls_params_default", "pols_rolling_params_default",
-    "pols_least_squares", "pols_recursive_least_squares", "pols_rolling_least_squares", "pols_predict",
+    "pols_least_squares", "pols_recursive_least_squares", "pols_rolling_least_squares", "pols_predict", "pols_predict_policy",
     "pols_least_squares_statistics", "pols_multi_target_least_squares",
     "pols_layout_create", "pols_layout_destroy", "pols_layout_n_rows", "pols_layout_n_groups", "pols_layout_is_identity",
     "pols_layout_group_offsets", "pols_layout_group_keys", "pols_layout_take", "pols_layout_untake", "pols_layout_row_groups",
@@ -133,6 +133,7 @@ def lib() -> C.CDLL:
         L.pols_recursive_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(RlsParams), C.POINTER(Out)]
         L.pols_rolling_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(RollingParams), C.POINTER(Out)]
         L.pols_predict.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int64, C.c_void_p]
+        L.pols_predict_policy.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.pols_multi_target_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_void_p), C.c_int32,
                                                       C.POINTER(OlsParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
         L.pols_least_squares_statistics.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(OlsParams), C.POINTER(Out),

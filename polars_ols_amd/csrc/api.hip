@@ -179,6 +179,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K2_NOPREFETCH")) o.k2_noprefetch = on;
     else if (ieq(key, "K1_PASSES")) o.k1_passes = on ? std::atoi(v) : d.k1_passes;
     else if (ieq(key, "K1T_RC4")) o.k1t_rc4 = on ? (std::atoi(v) != 0) : d.k1t_rc4;
+    else if (ieq(key, "K1T_SUB8")) o.k1t_sub8 = on ? std::atoi(v) : d.k1t_sub8;
     else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
     else if (ieq(key, "K1_PERSIST")) o.k1_persist = on ? (std::atoi(v) != 0) : d.k1_persist;
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
@@ -194,7 +195,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
-                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE"};
+                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);
@@ -1537,6 +1538,10 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
 }
 
 int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, void *pred_out) {
+    return pols_predict_policy(ctx, b, coef, coef_rows, POLS_NULL_IGNORE, pred_out);
+}
+
+int pols_predict_policy(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, int32_t null_policy, void *pred_out) {
     // `predict` plugin body (src/expressions.rs:706-741): sum_j x[t, j] * coef[t, j]; coef in the batch dtype,
     // coef_rows == n_rows (one coefficient row per input row, what Polars broadcasts the struct to).
     int rc = check_ctx(ctx);
@@ -1548,6 +1553,11 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
     if (!coef || !pred_out) return fail(POLS_ERR_INVALID, "coef / pred_out is NULL");
     if (coef_rows != b->n_rows) return fail(POLS_ERR_INVALID, "number of coefficient rows must match the number of rows");
     if (b->weights) return fail(POLS_ERR_INVALID, "predict takes no weights");
+    if (null_policy != POLS_NULL_IGNORE && null_policy != POLS_NULL_ZERO && null_policy != POLS_NULL_DROP)
+        return fail(POLS_ERR_INVALID, "predict: null_policy must be one of ignore / zero / drop (least_squares.py:474)");
+    // "zero": nulls (NaNs) in the features count as 0 (ex.rs:725).  "drop" zero-fills too and then nulls the rows with a null anywhere
+    // (:732-738): with NaN as the null, that is the un-filled product.
+    const int32_t fill_policy = null_policy == POLS_NULL_ZERO ? POLS_NULL_ZERO : POLS_NULL_IGNORE;
     const int kt = b->n_features + (b->add_intercept ? 1 : 0);   // predict adds pl.lit(1.0) for the intercept (ls.py:479-483)
     if (b->n_rows == 0) return POLS_OK;
     const int64_t *d_offs = nullptr;
@@ -1571,6 +1581,7 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
         std::memset(&wa, 0, sizeof(wa));
         wa.cols = static_cast<const void *const *>(tab);
         wa.n_rows = b->n_rows; wa.k_user = b->n_features; wa.kt = kt; wa.pred = st.pred;
+        wa.null_policy = fill_policy;
         ctx->last_kernel = "k8_wide_predict_rows";
         if ((rc = wide_predict_rows_launch(ctx, b->dtype, wa, d_coef))) return rc;
         return unstage_outputs(ctx, b, b->n_rows, kt, &o, st);
@@ -1581,6 +1592,7 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
     pa.offs = d_offs; pa.n_groups = b->n_groups; pa.n_rows = b->n_rows;
     pa.coef_rows = d_coef; pa.pred = st.pred;
     pa.k_user = b->n_features; pa.kt = kt;
+    pa.null_policy = fill_policy;
     ctx->last_kernel = "predict";
     if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, kt, &o, st);

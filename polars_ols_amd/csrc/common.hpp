@@ -52,6 +52,7 @@ struct Options {
     bool kg_noyv = false;         // POLS_KG_NOYV        streamed Gram: keep the target in a second MFMA tile at 16 columns
     int k1_passes = 0;            // POLS_K1_PASSES      0: default
     int k1t_rc4 = -1;             // POLS_K1T_RC4        -1: default rule
+    int k1t_sub8 = -1;            // POLS_K1T_SUB8       eight-lane K1t teams: -1 default rule (frames that fit 16 chunk slots), 0 never, 1 only frames that fit 8
     int static_engine = 0;        // POLS_STATIC_ENGINE  0 auto, 1 "stream" (three launches), 2 "k2" (wherever it fits), 3 "nok2"
     int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq", 2 "scan"
     int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"

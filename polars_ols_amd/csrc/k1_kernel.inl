@@ -7,6 +7,18 @@
 #ifndef K1T_F32_TWO_PASS
 #define K1T_F32_TWO_PASS 1
 #endif
+#ifndef K1_EDGE_SHIFT
+#define K1_EDGE_SHIFT 1        // load_chunk_edge: the chunk crossing the end of the columns is shifted down in registers (0: guarded scalar loads)
+#endif
+#ifndef K1_EDGE_MASK32
+#define K1_EDGE_MASK32 1       // load_chunk_edge: in-group masks from 32-bit distances (0: 64-bit row compares)
+#endif
+#ifndef K1_KU_STATIC
+#define K1_KU_STATIC 1         // K1t: only the last column slot can be the ones column, the k_user test is compile-time for the others
+#endif
+#ifndef K1T_PASS_MIN_KT
+#define K1T_PASS_MIN_KT 5      // K1t: from this many columns the Gram goes through the 16-entry passes + LDS + the row-cooperative Cholesky
+#endif
 #ifndef K1_SOLVE_ROWS
 #define K1_SOLVE_ROWS 1        // multi-pass team kernels: the row-resident right-looking Cholesky at every width (0: LDS left-looking up to 15 columns)
 #endif
@@ -50,17 +62,20 @@ template <> __device__ __forceinline__ void vset<float>(float4 &v, int i, float 
 template <> __device__ __forceinline__ void vset<double>(double2 &v, int i, double x) { if (i == 0) v.x = x; else v.y = x; }
 
 // the 16-byte loads of one chunk, nothing else: the FAST kernels issue these for ALL resident chunks back to back
-template <typename T, int KT, bool HAS_W, bool NT = false>
+// KUS: only the LAST column slot can be the synthesised intercept, so the k_user test is compile-time for the others.  K1t only: there
+// it removes four v_mov of 1.0 + a scalar branch per column; in the wave / team kernels the loads it un-serialises cost 6-10 VGPRs
+// and an occupancy step (team64_rc1_edge_p2 at 8 columns 77 -> 83: 500 000 groups of 130..252 rows 692 -> 735 us).
+template <typename T, int KT, bool HAS_W, bool NT = false, bool KUS = false>
 __device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Chunk<T, KT, HAS_W> &c) {
     using V = typename Vec16<T>::type;
-    const int ku = a.k_user;
+    const int ku = a.k_user;                                 // KT - add_intercept: only the LAST slot can be the ones column
     // NT: streaming (`nt`) loads, a compile-time choice -- a run-time branch around the two forms cost the plain path 8 us of 73.
     // (Written out twice on purpose: routing the loads through a small lambda kept the chunk in scratch memory in the ragged
     // kernels -- 736 bytes per lane, 4x slower.)
     if constexpr (NT) {
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-            if (j < ku) c.x[j] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
+            if ((K1_KU_STATIC && KUS && j < KT - 1) || j < ku) c.x[j] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
             else c.x[j] = vsplat<T>(T(1));
         }
         c.y = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
@@ -68,7 +83,7 @@ __device__ __forceinline__ void load_chunk_raw(const K1Args &a, int64_t row0, Ch
     } else {
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-            if (j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
+            if ((K1_KU_STATIC && KUS && j < KT - 1) || j < ku) c.x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0);
             else c.x[j] = vsplat<T>(T(1));
         }
         c.y = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
@@ -413,7 +428,10 @@ __device__ __forceinline__ T chol_solve_lds(const T *G, T alpha, T pivot_tol, T 
 template <int WIDTH, typename T>
 __device__ __forceinline__ T team_bcast(T v, int j) {
     if constexpr (WIDTH == 64) return k1p_readlane(v, j);
-    else {
+    else if constexpr (WIDTH == 8) {                         // two eight-lane teams per DPP row: lane j of THIS half = row lane j or j + 8
+        const T lo = team_bcast<16>(v, j), hi = team_bcast<16>(v, j + 8);
+        return (threadIdx.x & 8) ? hi : lo;
+    } else {
         switch (j) {
             case 0: return dpp_get<0x150>(v); case 1: return dpp_get<0x151>(v); case 2: return dpp_get<0x152>(v); case 3: return dpp_get<0x153>(v);
             case 4: return dpp_get<0x154>(v); case 5: return dpp_get<0x155>(v); case 6: return dpp_get<0x156>(v); case 7: return dpp_get<0x157>(v);
@@ -425,7 +443,7 @@ __device__ __forceinline__ T team_bcast(T v, int j) {
 
 template <typename T, int KT, int WIDTH = 64>
 __device__ __forceinline__ T chol_solve_rows(const T *G, T alpha, T pivot_tol, T *L, int lane, bool &ok) {
-    static_assert(WIDTH == 64 || (WIDTH == 16 && KT <= 16), "a wave, or one 16-lane DPP row per group (K1t)");
+    static_assert(WIDTH == 64 || (WIDTH == 16 && KT <= 16) || (WIDTH == 8 && KT <= 8), "a wave, one 16-lane DPP row per group (K1t), or half of one");
     constexpr int NZ = KT + 1;
     const int li = lane < KT ? lane : KT - 1;                // lanes beyond the matrix mirror the last row (their results are unused)
     T r[KT];
@@ -451,18 +469,40 @@ __device__ __forceinline__ T chol_solve_rows(const T *G, T alpha, T pivot_tol, T
 #pragma unroll
         for (int p = 0; p < KT; ++p) L[lane * KT + p] = r[p];
     }
+    if constexpr (WIDTH != 64) {
+        // K1t teams: both substitutions as selects -- an exec-mask branch per step cost more than the FMA it guarded.  (Not for the wave
+        // form: there the selects cost 1-4 VGPRs, an occupancy step at 6 f32 columns and an AGPR at 28 f64 ones.)
 #pragma unroll
-    for (int p = 0; p < KT; ++p) {                           // forward: t = L^-1 b
-        if (lane == p) bi *= myrinv;
-        const T tp = team_bcast<WIDTH>(bi, p);
-        if (lane > p && lane < KT) bi = fma(-r[p], tp, bi);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int p = 0; p < KT; ++p) {                       // forward: t = L^-1 b
+            const T sc = bi * myrinv;
+            bi = (lane == p) ? sc : bi;
+            const T tp = team_bcast<WIDTH>(bi, p);
+            const T nb = fma(-r[p], tp, bi);
+            bi = (lane > p && lane < KT) ? nb : bi;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int p = KT - 1; p >= 0; --p) {                      // backward: beta = L^-T t
-        if (lane == p) bi *= myrinv;
-        const T bp = team_bcast<WIDTH>(bi, p);
-        if (lane < p) bi = fma(-L[p * KT + lane], bp, bi);
+        for (int p = KT - 1; p >= 0; --p) {                  // backward: beta = L^-T t (column `li` of the factor, clamped: no guard)
+            const T sc = bi * myrinv;
+            bi = (lane == p) ? sc : bi;
+            const T bp = team_bcast<WIDTH>(bi, p);
+            const T nb = fma(-L[p * KT + li], bp, bi);
+            bi = (lane < p) ? nb : bi;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < KT; ++p) {                       // forward: t = L^-1 b
+            if (lane == p) bi *= myrinv;
+            const T tp = team_bcast<WIDTH>(bi, p);
+            if (lane > p && lane < KT) bi = fma(-r[p], tp, bi);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int p = KT - 1; p >= 0; --p) {                  // backward: beta = L^-T t
+            if (lane == p) bi *= myrinv;
+            const T bp = team_bcast<WIDTH>(bi, p);
+            if (lane < p) bi = fma(-L[p * KT + lane], bp, bi);
+        }
     }
     return bi;
 }
@@ -744,26 +784,111 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // One chunk of a small ragged group, branch-free: the 16-byte loads of every column issued unconditionally (lanes without a chunk
 // re-read the group's first chunk; positions clamped into the columns), then the rows outside [s, e) zeroed in registers.  In
 // these kernels nearly every chunk is a head or a tail, so the guarded per-row path was what every wave executed.
-template <typename T, int KT, bool HAS_W>
+template <typename T, int KT, bool HAS_W, bool KUS = false>
 __device__ __forceinline__ void load_chunk_edge(const K1Args &a, int64_t row0, int64_t base, bool has, int64_t s, int64_t e,
                                                 Chunk<T, KT, HAS_W> &c) {
     constexpr int VEC = Vec16<T>::N;
     int64_t r0 = has ? row0 : base;
     r0 = r0 > a.n_rows - VEC ? a.n_rows - VEC : r0;
-    load_chunk_raw<T, KT, HAS_W>(a, r0, c);
-    if (has && row0 + VEC > a.n_rows) {                      // the chunk that crosses the end of the columns: at most one lane per launch
+    // f32 only, both: in the f64 kernels the older forms allocate 4-9 fewer VGPRs (code-object metadata over 6-10 columns: never a lower
+    // occupancy, 3 instead of 2 waves per SIMD at 8 columns x two chunks per lane), in the f32 ones the new forms save up to 28
+    constexpr bool SHIFT = K1_EDGE_SHIFT && sizeof(T) == 4, MASK32 = K1_EDGE_MASK32 && sizeof(T) == 4;
+    load_chunk_raw<T, KT, HAS_W, false, KUS>(a, r0, c);
+    if (!SHIFT && has && row0 + VEC > a.n_rows) {
         load_chunk<T, KT, HAS_W, false>(a, row0, s, e, c);
         return;
     }
+    if (SHIFT && has && row0 + VEC > a.n_rows) {     // the chunk that crosses the end of the columns: at most one lane per launch
+        // its 16 bytes were read from the last VEC rows: move them down to their slots (the slots past the end are masked below)
+        const int shift = (int)(row0 - r0);                  // 1 .. VEC - 1
+        for (int k = 0; k < shift; ++k) {
+#pragma unroll
+            for (int v = 0; v + 1 < VEC; ++v) {
+#pragma unroll
+                for (int j = 0; j < KT; ++j) vset<T>(c.x[j], v, vget<T>(c.x[j], v + 1));
+                vset<T>(c.y, v, vget<T>(c.y, v + 1));
+                if constexpr (HAS_W) vset<T>(c.sw, v, vget<T>(c.sw, v + 1));
+            }
+        }
+    }
+    // (row0 lies on the chunk grid of a register-resident group: the distances to its ends fit 32 bits, one compare each per row)
+    const int lo = has ? (int)(s - row0) : VEC, hi = (int)(e - row0);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        const bool in = has && (row0 + v >= s) && (row0 + v < e);
+        const bool in = MASK32 ? ((v >= lo) && (v < hi)) : (has && (row0 + v >= s) && (row0 + v < e));
 #pragma unroll
         for (int j = 0; j < KT; ++j) vset<T>(c.x[j], v, in ? vget<T>(c.x[j], v) : T(0));
         vset<T>(c.y, v, in ? vget<T>(c.y, v) : T(0));
         if constexpr (HAS_W) vset<T>(c.sw, v, in ? vget<T>(c.sw, v) : T(1));
     }
     if constexpr (HAS_W) load_chunk<T, KT, HAS_W, true, false, true>(a, row0, s, e, c);   // the sqrt(w) scaling only
+}
+
+// all-reduce inside a K1t team of 16 lanes (one DPP row: four fused DPP adds) or 8 lanes (half a row: three)
+template <int SUB, typename T>
+__device__ __forceinline__ T k1t_team_allreduce(T v) {
+    v += dpp_get<0xB1>(v);                                   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);                                   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(v);                                  // row_half_mirror
+    if constexpr (SUB >= 16) v += dpp_get<0x140>(v);         // row_mirror
+    return v;
+}
+
+// REDUCE-SCATTER inside a K1t team.  The all-reduce above costs every entry 4 dependent DPP adds, and handing entry q to the lane
+// that parks it in LDS cost a compare + exec-mask branch per entry on top: 540 of the ~1 400 issue slots a wave of the 8-column
+// kernel spent (PMC, 500 000 groups of 12..40 rows: 1 084 VALU + 216 SALU per wave, VALU ~65 % busy).  Here each step adds the two
+// lanes of a DPP pair and keeps ONE of two entries per lane -- the entry count halves per step, 3 instructions per surviving entry:
+// 16 entries -> 8 -> 4 -> 2 -> 1 in 45 instructions, and the lane that ends up with an entry is the one that stores it.
+// Step order row_mirror (lanes i, 15 - i), row_half_mirror (i, 7 - i), quad xor 1, quad xor 2: the two lanes of a pair always hold the
+// same entries (they agree in the lane bits of the earlier steps), and the four steps together reach all 16 lanes.
+template <int CTRL, int M, typename T, int N>
+__device__ __forceinline__ void k1t_rs_step(T (&v)[N], bool side) {      // v[j] <- pair total of entry 2j + side, j < (M + 1) / 2
+#pragma unroll
+    for (int j = 0; j < (M + 1) / 2; ++j) {
+        const T lo = v[2 * j] + dpp_get<CTRL>(v[2 * j]);
+        if (2 * j + 1 < M) {
+            const T hi = v[2 * j + 1] + dpp_get<CTRL>(v[2 * j + 1]);
+            v[j] = side ? hi : lo;
+        } else {
+            v[j] = side ? T(0) : lo;
+        }
+    }
+}
+// the entry of slot t a lane holds afterwards is SUB * t + k1t_rs_slot<SUB>(lane)
+template <int SUB>
+__device__ __forceinline__ int k1t_rs_slot(int l) {
+    if constexpr (SUB == 16) return ((l >> 3) & 1) | (((l >> 2) & 1) << 1) | ((l & 1) << 2) | (((l >> 1) & 1) << 3);
+    else return ((l >> 2) & 1) | ((l & 1) << 1) | (((l >> 1) & 1) << 2);
+}
+template <int SUB, typename T, int N>
+__device__ __forceinline__ void k1t_team_reduce_scatter(T (&v)[N], int l) {
+    static_assert(SUB == 8 || SUB == 16, "half a DPP row or one");
+    constexpr int M1 = SUB == 16 ? (N + 1) / 2 : N, M2 = (M1 + 1) / 2, M3 = (M2 + 1) / 2;
+    if constexpr (SUB == 16) k1t_rs_step<0x140, N>(v, (l & 8) != 0);
+    k1t_rs_step<0x141, M1>(v, (l & 4) != 0);
+    k1t_rs_step<0xB1, M2>(v, (l & 1) != 0);
+    k1t_rs_step<0x4E, M3>(v, (l & 2) != 0);
+}
+
+// The K1t Gram, 16 packed entries per pass (a pass keeps 16 accumulators live whatever the column count): accumulate over the lane's
+// resident chunks, reduce-scatter inside the team, park the totals in the team's LDS row.  The y'y entry (the last one) is not needed
+// for the coefficients and is left out.
+template <typename T, int KT, bool HAS_W, int SUB, int RC, int Q0>
+__device__ __forceinline__ void k1t_gram_passes(const Chunk<T, KT, HAS_W> (&res)[RC], int sub, T *grow) {
+    constexpr int NUSE = (KT + 1) * (KT + 2) / 2 - 1;
+    if constexpr (Q0 < NUSE) {
+        constexpr int Q1 = Q0 + 16 < NUSE ? Q0 + 16 : NUSE;
+        T p[Q1 - Q0];
+#pragma unroll
+        for (int q = 0; q < Q1 - Q0; ++q) p[q] = T(0);
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) gram_accumulate_range<T, KT, HAS_W, Q0, Q1>(p, res[rc]);   // (a lane without this chunk holds zeros: no guard, no branch)
+        k1t_team_reduce_scatter<SUB>(p, sub);
+        const int slot = k1t_rs_slot<SUB>(sub);
+#pragma unroll
+        for (int t = 0; t < (Q1 - Q0 + SUB - 1) / SUB; ++t) grow[Q0 + SUB * t + slot] = p[t];
+        k1t_gram_passes<T, KT, HAS_W, SUB, RC, Q1>(res, sub, grow);
+    }
 }
 
 #ifndef K1_NULLS_TU
@@ -774,17 +899,20 @@ __device__ __forceinline__ void load_chunk_edge(const K1Args &a, int64_t row0, i
 // early exit (the DPP steps need all 64 lanes active).
 template <typename T, int KT, bool HAS_W, int K1T_SUB, int K1T_RC>
 __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
-    static_assert(K1T_SUB == 16 || K1T_SUB == 32, "a team is one DPP row or two");
+    // (no occupancy hint: asking four waves per SIMD of the f64 eight-lane team with two chunks per lane -- 129-170 VGPRs -- spilled 12-192 B)
+    static_assert(K1T_SUB == 8 || K1T_SUB == 16 || K1T_SUB == 32, "a team is half a DPP row, one, or two");
+    static_assert(K1T_SUB != 8 || KT <= 8, "eight-lane teams: one coefficient per lane");
     constexpr int VEC = Vec16<T>::N;
     constexpr int NZ = KT + 1;
     constexpr int NACC = NZ * (NZ + 1) / 2;
     const int lane = threadIdx.x & 63, sub = lane & (K1T_SUB - 1);
-    const int64_t g = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / K1T_SUB) + (lane / K1T_SUB);
-    const bool live = g < a.n_groups;
+    const int64_t gi = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / K1T_SUB) + (lane / K1T_SUB);
+    const bool live = gi < a.n_groups;
+    const int64_t g = live ? gi : 0;
     const int64_t s = live ? a.offs[g] : 0, e = live ? a.offs[g + 1] : 0;
-    const int64_t base = s - (s % VEC);                      // chunk grid aligned to 16 bytes in every column
-    const int64_t nch = (e - base + VEC - 1) / VEC;          // <= K1T_SUB * K1T_RC: the host checked the largest group
-    constexpr bool TWO_PASS = (sizeof(T) == 8 || K1T_F32_TWO_PASS) && KT >= 6 && (K1T_SUB == 16 || K1T_SUB == 32);
+    const int64_t base = s & ~(int64_t)(VEC - 1);            // chunk grid aligned to 16 bytes in every column (offsets are >= 0)
+    const int nch = (int)((e - base + VEC - 1) / VEC);       // <= K1T_SUB * K1T_RC: the host checked the largest group
+    constexpr bool TWO_PASS = (sizeof(T) == 8 || K1T_F32_TWO_PASS) && KT >= K1T_PASS_MIN_KT;
     T acc[TWO_PASS ? 1 : NACC];
     Chunk<T, KT, HAS_W> res[K1T_RC];
     T beta[KT];
@@ -794,45 +922,40 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
         // kernel, the Gram is taken in two passes over the resident rows (half the accumulators live at a time), the row totals go to
         // LDS, and the row solves cooperatively there (lane i of the row owns row i of L).
         constexpr int TEAMS = 256 / K1T_SUB;
-        constexpr int Q1 = ((NACC + 1) / 2 + 3) & ~3;        // entries of the first pass
-        __shared__ T gs[TEAMS][NACC + 3], lf[TEAMS][KT * KT], lr[TEAMS][KT], bc[TEAMS][KT];
+        constexpr int Q1 = ((NACC + 1) / 2 + 3) & ~3;        // entries of the first pass (32-lane teams)
+        constexpr int GS = (NACC + 15) & ~15;                // the passes park whole 16-entry slices
+        __shared__ T gs[TEAMS][GS], lf[TEAMS][KT * KT], lr[TEAMS][KT], bc[TEAMS][KT];
         const int team = threadIdx.x / K1T_SUB;
 #pragma unroll
         for (int rc = 0; rc < K1T_RC; ++rc) {
             const int64_t c = (int64_t)rc * K1T_SUB + sub;
-            load_chunk_edge<T, KT, HAS_W>(a, base + c * VEC, base, c < nch, s, e, res[rc]);
+            load_chunk_edge<T, KT, HAS_W, true>(a, base + c * VEC, base, c < nch, s, e, res[rc]);
         }
-        {
-            T p1[Q1];
+        if constexpr (K1T_SUB == 32) {                       // a team is two 16-lane rows: the pairing reduction of K1p, two passes
+            {
+                T p1[Q1];
 #pragma unroll
-            for (int q = 0; q < Q1; ++q) p1[q] = T(0);
+                for (int q = 0; q < Q1; ++q) p1[q] = T(0);
 #pragma unroll
-            for (int rc = 0; rc < K1T_RC; ++rc)
-                if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, 0, Q1>(p1, res[rc]);
-            if constexpr (K1T_SUB == 32) {                       // a team is two 16-lane rows: the pairing reduction of K1p
+                for (int rc = 0; rc < K1T_RC; ++rc)
+                    if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, 0, Q1>(p1, res[rc]);
                 k1p_team_allreduce<T, Q1, 32>(p1);
 #pragma unroll
                 for (int q = 0; q < Q1; ++q) if ((q % K1T_SUB) == sub) gs[team][q] = p1[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < Q1; ++q) { const T t = row_allreduce(p1[q]); if ((q % K1T_SUB) == sub) gs[team][q] = t; }
             }
-        }
-        {
-            T p2[NACC - Q1];
+            {
+                T p2[NACC - Q1];
 #pragma unroll
-            for (int q = 0; q < NACC - Q1; ++q) p2[q] = T(0);
+                for (int q = 0; q < NACC - Q1; ++q) p2[q] = T(0);
 #pragma unroll
-            for (int rc = 0; rc < K1T_RC; ++rc)
-                if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, Q1, NACC>(p2, res[rc]);
-            if constexpr (K1T_SUB == 32) {
+                for (int rc = 0; rc < K1T_RC; ++rc)
+                    if ((int64_t)rc * K1T_SUB + sub < nch) gram_accumulate_range<T, KT, HAS_W, Q1, NACC>(p2, res[rc]);
                 k1p_team_allreduce<T, NACC - Q1, 32>(p2);
 #pragma unroll
                 for (int q = 0; q < NACC - Q1; ++q) if (((q + Q1) % K1T_SUB) == sub) gs[team][q + Q1] = p2[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < NACC - Q1; ++q) { const T t = row_allreduce(p2[q]); if (((q + Q1) % K1T_SUB) == sub) gs[team][q + Q1] = t; }
             }
+        } else {
+            k1t_gram_passes<T, KT, HAS_W, K1T_SUB, K1T_RC, 0>(res, sub, gs[team]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T bv = T(0);
@@ -841,7 +964,8 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
             bool ok;
             // (32-lane teams: the factor lives in the team's FIRST 16-lane row -- KT <= 16 -- whose lanes broadcast among themselves;
             // the second row runs along on copies of the last matrix row and its results are never read)
-            if constexpr (K1_SOLVE_ROWS || K1T_SUB == 32) bv = chol_solve_rows<T, KT, 16>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], sub, ok);
+            if constexpr (K1T_SUB == 8) bv = chol_solve_rows<T, KT, 8>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], sub, ok);
+            else if constexpr (K1_SOLVE_ROWS || K1T_SUB == 32) bv = chol_solve_rows<T, KT, 16>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], sub, ok);
             else bv = chol_solve_lds<T, KT, K1T_SUB>(gs[team], (T)a.alpha, (T)a.pivot_tol, lf[team], lr[team], sub, ok);
             if (!ok) st = POLS_GROUP_FALLBACK;
         }
@@ -855,13 +979,16 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
 #pragma unroll
     for (int rc = 0; rc < K1T_RC; ++rc) {
         const int64_t c = (int64_t)rc * K1T_SUB + sub;
-        load_chunk_edge<T, KT, HAS_W>(a, base + c * VEC, base, c < nch, s, e, res[rc]);
+        load_chunk_edge<T, KT, HAS_W, true>(a, base + c * VEC, base, c < nch, s, e, res[rc]);
         if (c < nch) gram_accumulate<T, KT, HAS_W>(acc, res[rc]);
     }
 #pragma unroll
     for (int q = 0; q < NACC; ++q) {
-        acc[q] = row_allreduce(acc[q]);
-        if constexpr (K1T_SUB == 32) { T t = acc[q]; pair_rows(t, acc[q]); acc[q] = t; }   // rows [r0 + r1, r0 + r1, r2 + r3, r2 + r3]
+        if constexpr (K1T_SUB == 8) acc[q] = k1t_team_allreduce<8>(acc[q]);
+        else {
+            acc[q] = row_allreduce(acc[q]);
+            if constexpr (K1T_SUB == 32) { T t = acc[q]; pair_rows(t, acc[q]); acc[q] = t; }   // rows [r0 + r1, r0 + r1, r2 + r3, r2 + r3]
+        }
     }
     if (e == s) {                                            // features.is_empty() -> zeros (ex.rs:357-359)
 #pragma unroll
@@ -1364,13 +1491,27 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 #ifndef K1_NULLS_TU
     if (!ctx->opt.k1_notiny && !ctx->opt.timeline && a.n_rows >= VEC) {
         const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
+        if constexpr (KT <= 8) {
+            // EIGHT-LANE TEAMS (round 3), eight groups per wave: frames whose every group fits eight chunk slots (32 f32 / 16 f64 rows
+            // on the chunk grid).  (Splitting a MIXED frame into a list of groups that fit and a list of the rest, two launches, measured
+            // no faster -- 198 vs 191 us on 500 000 groups of 12..40 rows: neighbouring groups share cache lines, the two launches
+            // fetched 1.43x the bytes of one, PMC FETCH_SIZE -- profiles/r03_*_bucketed_rejected.*)
+            const int s8 = ctx->opt.k1t_sub8;                // -1 / 2: the rule below, 1: one chunk per lane only, 0: 16-lane teams
+            if (need <= 8 * 1 * VEC && s8 != 0) return k1t_launch<T, KT, HAS_W, 8, 1>(ctx, a);
+            // two chunks per lane (the 16 slots of a 16-lane team, twice the groups per wave): 500 000 groups of 12..40 rows, f32, 8 columns
+            // 140 vs 160 us, 3 columns 48.5 vs 52.2, 6 columns 110 vs 112; f64 10..16 rows x 8 columns 204 vs 293 -- but 5 columns 95 vs
+            // 88.5: the single-pass form (below 6 columns) with 4-5 columns keeps its 16-lane teams
+            if (need <= 8 * 2 * VEC && s8 != 0 && s8 != 1 && (KT >= K1T_PASS_MIN_KT || KT <= 3 || s8 == 2)) return k1t_launch<T, KT, HAS_W, 8, 2>(ctx, a);
+        }
         if (need <= 16 * 1 * VEC) return k1t_launch<T, KT, HAS_W, 16, 1>(ctx, a);      // one chunk per lane: a third fewer registers
         if (need <= 16 * 2 * VEC) return k1t_launch<T, KT, HAS_W, 16, 2>(ctx, a);
         // four chunks per lane (128 f64 / 256 f32 rows): f64 with 6+ columns has the registers for it since the two-pass form;
         // f32 only on request (POLS_K1T_RC4=1: A/B against the one-chunk wave kernel)
         if (need <= 16 * 4 * VEC) {
-            const bool want = ctx->opt.k1t_rc4 >= 0 ? ctx->opt.k1t_rc4 != 0 : (sizeof(T) == 8 && KT >= 6);
-            if (want) return k1t_launch<T, KT, HAS_W, 16, 4>(ctx, a);
+            // (... up to 8 columns, 7 with weights: beyond, the four chunks tip the kernel into AGPRs -- 266-314 registers, one wave per SIMD)
+            constexpr bool fits = KT <= (HAS_W ? 7 : 8);
+            const bool want = ctx->opt.k1t_rc4 >= 0 ? ctx->opt.k1t_rc4 != 0 : (sizeof(T) == 8 && KT >= 6 && fits);
+            if constexpr (fits || sizeof(T) == 4) { if (want) return k1t_launch<T, KT, HAS_W, 16, 4>(ctx, a); }
         }
         if constexpr (sizeof(T) == 4 && KT >= 6 && KT <= 8) {
             // (9-10 columns: one wave per group with the three-pass Gram is faster -- 76.7 vs 89.4 us on 50 000 x 200 x (8 + 1))
@@ -1384,9 +1525,6 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             // (three chunks per lane -- up to 384 rows -- measured no better than one wave per group: 109.7 vs 107.9 us on 50 000 groups
             // of 100..300 rows)
         }
-        // (SUB = 8, eight groups per wave with two chunks per lane, measured no faster on 500 000 groups of 12..40 rows: 218 vs 214 us --
-        // these frames are bound by lane utilisation in the memory pipe: a 26-row group fills 6.5 of its team's 16 chunk slots, and
-        // the pipe spends its cycles per lane address, used or not)
         // (SUB = 32, two groups per wave up to 256 / 128 rows, measured SLOWER than one wave per group: 1 022 vs 910 us on 500 000
         // f32 groups of 130..252 rows, 1 815 vs 1 217 us on f64 groups of 40..120 -- the kernel template keeps the variant, nothing
         // launches it)

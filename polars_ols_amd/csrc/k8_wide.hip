@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) wide_predict_rows_kernel(const WideArgs a
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < a.n_rows; r += (int64_t)gridDim.x * 256) {
         const T *c = coef + r * kt;
         T p = T(0);
-        for (int j = 0; j < ku; ++j) p = fma(static_cast<const T *>(a.cols[j])[r], c[j], p);   // (features * coefficients).sum_axis(1)
+        for (int j = 0; j < ku; ++j) p = fma(null_fill<T>(a.null_policy, static_cast<const T *>(a.cols[j])[r]), c[j], p);   // (features * coefficients).sum_axis(1)
         if (ku != kt) p += c[kt - 1];
         pred[r] = p;
     }

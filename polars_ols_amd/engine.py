@@ -715,9 +715,10 @@ def default_engine(device: int = 0) -> Engine:
     return _default[device]
 
 
-def _engine_predict(self, x_cols: Sequence, coef, offsets=None, *, add_intercept: bool = False):
+def _engine_predict(self, x_cols: Sequence, coef, offsets=None, *, add_intercept: bool = False, null_policy: str = "ignore"):
     """``predict`` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t, j] * coef[t, j];
-    ``coef`` is n_rows x (k + add_intercept) in the columns' dtype (numpy -> host path, torch CUDA -> device path)."""
+    ``coef`` is n_rows x (k + add_intercept) in the columns' dtype (numpy -> host path, torch CUDA -> device path).  ``null_policy``
+    is the plugin's kwarg: "zero" counts null (NaN) features as 0, "drop" / "ignore" leave the rows with a null anywhere null."""
     cols = list(x_cols)
     n = cols[0].numel() if _is_torch(cols[0]) else len(cols[0])
     offs = np.asarray([0, n] if offsets is None else offsets, dtype=np.int64)
@@ -728,8 +729,8 @@ def _engine_predict(self, x_cols: Sequence, coef, offsets=None, *, add_intercept
     else:
         coef_k = np.ascontiguousarray(coef, dtype=dt)
         out = np.empty(n, dtype=dt)
-    rc = self._lib.pols_predict(self._h, C.byref(b), C.c_void_p(self._ptr(coef_k)), C.c_int64(coef_k.shape[0]),
-                                C.c_void_p(self._ptr(out)))
+    rc = self._lib.pols_predict_policy(self._h, C.byref(b), C.c_void_p(self._ptr(coef_k)), C.c_int64(coef_k.shape[0]),
+                                       C.c_int32(L.NULL_POLICIES[null_policy]), C.c_void_p(self._ptr(out)))
     L.check(rc)
     return out
 

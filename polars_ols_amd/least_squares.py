@@ -208,14 +208,6 @@ def _xp(a):
     return torch if _is_torch(a) else np
 
 
-def _isnan(a):
-    return torch.isnan(a) if _is_torch(a) else np.isnan(a)
-
-
-def _nan_to_zero(a):
-    return torch.nan_to_num(a, nan=0.0) if _is_torch(a) else np.where(np.isnan(a), 0.0, a)
-
-
 def _take(a, idx):
     return a[idx]
 
@@ -292,8 +284,11 @@ def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], samp
     w = None
     if sample_weights is not None:
         w = parse_into_expr(sample_weights)._column(frame)
-        # sqrt_w = w.sqrt().fill_null(1e-12)  (:193): a null weight acts as weight 1e-24
-        if fill_null_weights:                                  # (the dynamic entries do this fill on the device: dyn_prep.hip)
+        # sqrt_w = w.sqrt().fill_null(1e-12)  (:193): a null weight acts as weight 1e-24.  The reference's Python layer does this as a
+        # Polars expression over the column; so does this one for the static entries -- folding the select into the kernels' sqrt(w)
+        # was tried and cost the weighted EDGE kernels 25 VGPRs and an occupancy step (157 -> 182 at 8 f32 columns).  The dynamic and
+        # Arrow entries fill on the device (dyn_prep.hip, arrow.hip).
+        if fill_null_weights:
             w = torch.nan_to_num(w, nan=_EPSILON ** 2) if _is_torch(w) else np.where(np.isnan(w), _EPSILON ** 2, w)
     return target._column(frame), [f._column(frame) for f in features], names, icpt, w
 
@@ -591,18 +586,8 @@ def predict(coefficients: Coefficients, *features, frame: Frame, null_policy: st
     rows = coefficients.to_rows()
     assert rows.shape[1] == len(xs) + int(add_intercept), "number of coefficients must match number of features!"  # ex.rs:717-721
     eng = engine or default_engine((xs[0].device.index or 0) if _is_torch(xs[0]) else 0)   # the engine of the columns' device
-    valid = None
-    if null_policy == "drop":
-        valid = ~_isnan(xs[0])
-        for c in xs[1:]:
-            valid = valid & ~_isnan(c)
-    if null_policy != "ignore":
-        xs = [_nan_to_zero(c) for c in xs]
-    out = eng.predict(xs, rows, add_intercept=add_intercept)
-    if valid is not None:
-        nan = float("nan")
-        out = torch.where(valid, out, torch.full_like(out, nan)) if _is_torch(out) else np.where(valid, out, nan)
-    return out
+    # the zero fill of "zero" and the masking of "drop" are the plugin body's (ex.rs:725, :732-738): done by the kernel
+    return eng.predict(xs, rows, add_intercept=add_intercept, null_policy=null_policy)
 
 
 # ---- the `least_squares` namespace (polars_ols/__init__.py:35-295) -----------------------------------------------

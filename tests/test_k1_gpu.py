@@ -338,10 +338,10 @@ def test_contexts_are_independent_across_host_threads():
             assert torch.equal(a[key], sink[0][key]) or torch.allclose(a[key], sink[0][key], rtol=0, atol=0, equal_nan=True), key
 
 
-@pytest.mark.parametrize("dtype,lo,hi,tag", [(np.float32, 12, 40, "sub16_rc1"), (np.float32, 40, 120, "sub16_rc2"), (np.float64, 12, 30, "sub16_rc1"),
-                                             (np.float64, 20, 60, "sub16_rc2")])
+@pytest.mark.parametrize("dtype,lo,hi,tag", [(np.float32, 12, 40, "sub8_rc2"), (np.float32, 14, 28, "sub8_rc1"), (np.float32, 40, 120, "sub16_rc2"),
+                                             (np.float64, 12, 30, "sub8_rc2"), (np.float64, 20, 60, "sub16_rc2")])
 def test_many_tiny_groups_four_per_wave(eng, dtype, lo, hi, tag):
-    """K1t at scale: 300 000 ragged groups, four per wave.  Size-independent checks on every group (X'(y - yhat) = 0 through a
+    """K1t at scale: 300 000 ragged groups, four or eight per wave.  Size-independent checks on every group (X'(y - yhat) = 0 through a
     segmented sum, pred + resid == y, exact scaling in y) and oracle parity on a sample that includes both ends of the frame."""
     import torch
     from oracle import orc
@@ -544,3 +544,44 @@ def test_sixteen_to_thirtyone_columns_resident_multi_pass(eng, dtype, k, icpt, l
     assert np.allclose(got_c, ref["coef"], rtol=tol, atol=tol), float(np.abs(got_c - ref["coef"]).max())
     assert np.allclose(got_p, ref["pred"], rtol=tol, atol=tol), float(np.abs(got_p - ref["pred"]).max())
     assert np.allclose(got_r, ref["resid"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,weights,icpt", [(8, False, False), (5, True, True), (7, False, True), (6, True, False), (4, False, False), (1, False, False)])
+@pytest.mark.parametrize("slots", [8, 16])
+def test_eight_lane_teams(eng, dtype, k, weights, icpt, slots):
+    """K1t with eight groups per wave (eight-lane teams, the team Gram reduce-scattered over DPP pairs): the default for frames whose
+    every group fits 16 chunk slots (two chunks per lane beyond eight); POLS_K1T_SUB8=0 is the 16-lane form.  Ragged,
+    unaligned groups incl. empty ones and a rank-deficient one; against the oracle and against the 16-lane form."""
+    from oracle import orc
+
+    vec = 4 if dtype == np.float32 else 2
+    rng = np.random.default_rng(17 + k)
+    G = 9_000
+    sizes = rng.integers(min(k + 3, slots * vec - vec), slots * vec - vec + 1, size=G)
+    sizes[[7, 4_000, G - 1]] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, dtype, weights=weights)
+    if k > 1:
+        s, e = offs[11], offs[12]
+        cols[1][s:e] = cols[0][s:e]                                  # rank-deficient group: flagged, re-solved by the fix-up pass
+    args = dict(weights=None if w is None else _cuda(w), add_intercept=icpt, want=("coef", "pred", "resid", "status"))
+    kt = k + int(icpt)
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **args)
+        name = eng.last_kernel
+        want = "_sub8_rc1" if slots == 8 else ("_sub8_rc2" if kt >= 6 or kt <= 3 else "_sub16_rc1")   # (4-5 columns keep 16-lane teams beyond 8 slots)
+        assert name.startswith("k1t_gram_chol_") and name.endswith(want), name
+        eng.set_option("K1T_SUB8", "0")
+        one = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **args)
+        assert "_sub16_rc" in eng.last_kernel, eng.last_kernel
+    finally:
+        eng.set_option("K1T_SUB8", None)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
+    tol = TOL[dtype]
+    st = out["status"].cpu().numpy()
+    assert list(st[[7, 4_000, G - 1]]) == [2, 2, 2] and np.array_equal(st, one["status"].cpu().numpy())
+    for q in ("coef", "pred", "resid"):
+        got = out[q].double().cpu().numpy()
+        assert np.allclose(got, ref[q], rtol=tol, atol=tol), (q, float(np.abs(got - ref[q]).max()))
+        assert np.allclose(got, one[q].double().cpu().numpy(), rtol=tol, atol=tol), q
