@@ -364,6 +364,23 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     kernel_ms = eng.timing_collect()
     eng.timing(False)
+    kernel_name = eng.last_kernel
+
+    # the bandwidth ceiling of this workload's traffic mix, measured on the same frames right behind the timed region (outside it):
+    # pols_stream_probe reads every input column and writes the predictions column with the arithmetic removed, sampled by the
+    # same per-launch HIP events.  Static device-resident configs at N = 1 only.
+    probe_ms = None
+    if world == 1 and args.mem == "device" and args.config in ("cfg2", "cfg3", "cfg5") and all("pred" in p.results for p in plans):
+        for p in plans:
+            p.stream_probe()
+        torch.cuda.synchronize()
+        eng.timing(stride)
+        for i in range(max(args.steps, 3 * len(plans))):
+            plans[i % len(plans)].stream_probe()
+        torch.cuda.synchronize()
+        pm = eng.timing_collect()
+        eng.timing(False)
+        probe_ms = float(np.mean(pm)) if len(pm) else None
 
     total_units = float(wl["units"])
     if dist:
@@ -384,7 +401,7 @@ def main() -> None:
         traffic = None
         try:
             pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-            entry = pmc.get(eng.last_kernel, {})
+            entry = pmc.get(kernel_name, {})
             if entry.get("config", "cfg2") == args.config and args.mem == "device" and world == 1:
                 traffic = entry.get("traffic_bytes")
         except Exception:
@@ -401,9 +418,15 @@ def main() -> None:
                        "sharding": "groups (shard_for_rank: contiguous ranges balanced by rows)" if world > 1 else "none",
                        "world_size": world, "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": eng.last_kernel,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": wl["alg_bytes"]},
         }
+        if probe_ms:
+            ceiling = wl["alg_bytes"] / (probe_ms * 1e-3) / 1e9
+            line["roofline"]["stream_ceiling"] = {
+                "GBps": ceiling, "kernel_ms": probe_ms, "frac_of_peak": ceiling / HBM_PEAK_GBS, "achieved_over_ceiling": achieved / ceiling,
+                "what": "pols_stream_probe: the same columns read and the predictions column written with streaming 16-byte accesses, "
+                        "no arithmetic; same frames, same event sampling, measured right behind the timed region"}
         if args.config == "ref100":
             # BASELINE.md section 2 holds a published number for exactly this shape: 17.6 ms per call (OLS QR, 10 000 x 100, M2 Max,
             # through Polars + pyo3) = 56.8 problems/s.  Different hardware and it includes the Polars overhead: context, not a target.

@@ -217,6 +217,13 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
  * POLS_NULL_IGNORE.  pols_predict == pols_predict_policy(.., POLS_NULL_IGNORE, ..). */
 int pols_predict_policy(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, int32_t null_policy, void *pred_out);
 
+/* Measurement aid, NOT part of the reference interface (bench.py's `roofline.stream_ceiling`): one pass over the batch's columns with
+ * the arithmetic removed -- every feature column, the target and the weights read with 16-byte streaming loads down the row axis,
+ * their sum written over `pred_out` (n_rows values, batch dtype) with streaming stores: the rate HBM admits for this traffic mix on
+ * this device, beside which a static kernel's achieved rate on the same buffers is read.  DEVICE batches, up to POLS_MAX_FEATURES
+ * columns; timed like every launch (pols_timing_enable / pols_timing_collect). */
+int pols_stream_probe(pols_ctx *ctx, const pols_batch *b, void *pred_out);
+
 /* mode="statistics": replaces the plugin `least_squares_statistics` (src/expressions.rs:468-509) and
  * src/statistics.rs:15-156 for every group of the batch.  Per group, on the sqrt(w)-scaled rows the reference's
  * Python layer hands the plugin (polars_ols/least_squares.py:190-196):

@@ -87,7 +87,7 @@ EXPORTS = [
     "pols_comm_world_size", "pols_comm_rank", "pols_comm_group_begin", "pols_comm_group_end", "pols_comm_allgather_rows",
     "pols_comm_gather_rows", "pols_least_squares_arrow", "pols_least_squares_statistics_arrow",
     "pols_multi_target_least_squares_arrow", "pols_recursive_least_squares_arrow", "pols_rolling_least_squares_arrow",
-    "pols_predict_arrow", "pols_least_squares_sharded",
+    "pols_predict_arrow", "pols_least_squares_sharded", "pols_stream_probe",
 ]
 POLS_COMM_ID_BYTES = 128
 
@@ -133,6 +133,7 @@ def lib() -> C.CDLL:
         L.pols_recursive_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(RlsParams), C.POINTER(Out)]
         L.pols_rolling_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(RollingParams), C.POINTER(Out)]
         L.pols_predict.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int64, C.c_void_p]
+        L.pols_stream_probe.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         L.pols_predict_policy.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.pols_multi_target_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_void_p), C.c_int32,
                                                       C.POINTER(OlsParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]

@@ -39,6 +39,33 @@ def test_bench_line_contract():
     assert r["algorithmic_bytes_per_launch"] == 400_000_000 and (r["traffic"] is None or 0.9 < r["traffic"] / 4e8 < 1.3)
     assert 0.5 < d["value"] * d["ms_per_step"] * 1e-3 / 10_000 < 1.5       # value == groups / step time
     assert d["config"]["frames_rotated"] >= 3                              # every step streams its input from HBM, not from a cache
+    c = r["stream_ceiling"]                                                # the copy ceiling of the same traffic mix, same frames
+    assert 0.5 < c["frac_of_peak"] < 1.0 and abs(c["achieved_over_ceiling"] - r["achieved"] / c["GBps"]) < 1e-9
+    assert 0.7 < c["achieved_over_ceiling"] < 1.15, c
+
+
+def test_stream_probe_reads_every_column_and_writes_their_sum():
+    import numpy as np
+    import torch
+
+    from polars_ols_amd import Engine
+
+    eng = Engine(0)
+    try:
+        for dt in (torch.float32, torch.float64):
+            n = 100_003
+            g = torch.Generator(device="cuda").manual_seed(1)
+            cols = [torch.randn(n, device="cuda", generator=g, dtype=dt) for _ in range(11)]
+            y = torch.randn(n, device="cuda", generator=g, dtype=dt)
+            w = torch.rand(n, device="cuda", generator=g, dtype=dt) + 0.5
+            plan = eng.plan_least_squares(y, cols, np.array([0, n], dtype=np.int64), weights=w, want=("pred",))
+            plan.stream_probe()
+            eng.synchronize()
+            assert eng.last_kernel.startswith("stream_probe_")
+            exp = sum(c.double() for c in cols) + y.double() + w.double()
+            assert torch.allclose(plan.results["pred"].double(), exp, rtol=1e-5, atol=1e-5)
+    finally:
+        eng.close()
 
 
 def test_bench_collective_path_on_one_gpu():
