@@ -28,6 +28,10 @@ for it in range(N_STATIC):
                                    {"alpha": float(rng.uniform(0.001, 0.2)), "l1_ratio": float(rng.uniform(0.1, 1.0)), "tol": 1e-10, "max_iter": 50_000,
                                     "positive": bool(rng.random() < 0.3)})
     y, cols, offs, w = frame(G, max(lo, 3 * (k + 1)), hi + 3 * (k + 1), k, dtype)
+    if kind != "enet" and k <= 10 and rng.random() < 0.3:              # many tiny groups: K1t's team shapes (eight / four groups per wave)
+        vec = 2 if dtype == np.float64 else 4
+        G = int(rng.integers(4100, 9000)); slots = int(rng.choice([8, 16, 32, 64]))
+        y, cols, offs, w = frame(G, 3 * (k + 1), max(3 * (k + 1) + 1, slots * vec - vec), k, dtype)
     w = w if wts else None
     if k >= 2 and kind != "enet" and rng.random() < 0.25:            # a rank-deficient group: every solve_method has its own answer for it
         gg = int(rng.integers(0, G)); a, b2 = rng.choice(k, size=2, replace=False)
