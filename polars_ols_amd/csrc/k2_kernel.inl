@@ -298,6 +298,8 @@ __global__ void __launch_bounds__(64 * WAVES, k2_occupancy(KC, RC, WAVES, YV)) k
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool icpt = ku != kt;
+    const bool fullw = KC == K2_KMAX && ku == KC;           // wave-uniform: every column slot is a user column (kt == ku == 16; the 8-slot
+                                                             // variants keep one code path: the second one cost them 8 bytes of scratch)
     constexpr bool has_w = HAS_W;                            // a template parameter: the sqrt(w) registers only exist when there are weights
     const int ncols = ku + 1 + (has_w ? 1 : 0);              // columns that are loaded: features, target, weights
     unsigned char *mytile = smem + (size_t)wave * K2_TILE_B;
@@ -359,9 +361,11 @@ __global__ void __launch_bounds__(64 * WAVES, k2_occupancy(KC, RC, WAVES, YV)) k
 #pragma unroll
     for (int rc = 0; rc < RC; ++rc) {
         // -- this chunk's registers, prepared only now (nothing above touched them: the wait is for THIS chunk's loads)
+        if (!fullw) {                                        // (all KC slots are user columns: nothing to synthesise, one branch instead of KC)
 #pragma unroll
-        for (int j = 0; j < KC; ++j)
-            if (j >= ku) x[rc][j] = vsplat<T>((icpt && j == kt - 1) ? T(1) : T(0));      // wave-uniform: intercept / unused slot
+            for (int j = 0; j < KC; ++j)
+                if (j >= ku) x[rc][j] = vsplat<T>((icpt && j == kt - 1) ? T(1) : T(0));      // wave-uniform: intercept / unused slot
+        }
         if (!has_w) sw[rc] = vsplat<T>(T(1));
         if (__any(keep[rc] != ((1u << VEC) - 1u))) {         // wave-uniform, no loads inside: a ragged edge somewhere in the wave
 #pragma unroll
@@ -389,9 +393,14 @@ __global__ void __launch_bounds__(64 * WAVES, k2_occupancy(KC, RC, WAVES, YV)) k
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (fullw) {
 #pragma unroll
-            for (int j = 0; j < KC; ++j)
-                if (j < kt) *reinterpret_cast<H *>(mytile + (size_t)j * K2_SLOT_B + lane * 8) = k2_half(x[rc][j], h);
+                for (int j = 0; j < KC; ++j) *reinterpret_cast<H *>(mytile + (size_t)j * K2_SLOT_B + lane * 8) = k2_half(x[rc][j], h);
+            } else {
+#pragma unroll
+                for (int j = 0; j < KC; ++j)
+                    if (j < kt) *reinterpret_cast<H *>(mytile + (size_t)j * K2_SLOT_B + lane * 8) = k2_half(x[rc][j], h);
+            }
             if constexpr (!YV) *reinterpret_cast<H *>(mytile + (size_t)kt * K2_SLOT_B + lane * 8) = k2_half(ys, h);
             k2_wave_sync();
             if (rc == 0 && h == 0) K2_STAMP(1);              // the first chunk's loads have landed

@@ -146,14 +146,15 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
         for (int v = 0; v < VEC; ++v) keep |= (any && row0 + v >= s && row0 + v < e) ? (1u << v) : 0u;
 #pragma unroll
         for (int j = 0; j < KC; ++j)                         // (one chunk per lane: every load is awaited before the first use anyway, so a
-            if (j < ku) x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + rl);   // wave-uniform skip costs nothing)
+            if (j < 16 || j < ku) x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + rl);   // wave-uniform skip; the first 16
+                                                                                                               // slots are always user columns (kt >= 17))
         yv = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + rl);
         sw = *reinterpret_cast<const V *>(static_cast<const T *>(has_w ? a.w : a.y) + rl);
     }
 
     // ---- this chunk's registers
 #pragma unroll
-    for (int j = 0; j < KC; ++j)
+    for (int j = 16; j < KC; ++j)                            // (a taken wave-uniform branch is ~30 cycles: only the slots that CAN be synthetic)
         if (j >= ku) x[j] = vsplat<T>((icpt && j == kt - 1) ? T(1) : T(0));      // wave-uniform: intercept / unused slot
     if (!has_w) sw = vsplat<T>(T(1));
     if (__any(keep != ((1u << VEC) - 1u))) {                 // wave-uniform, no loads inside: a ragged edge somewhere in the wave
