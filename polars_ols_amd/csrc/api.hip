@@ -890,7 +890,12 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // 16 columns, tiles beyond LDS, and every solver that is not a Cholesky.
         const bool k1m_takes = kt <= K1M_MAX_KT && (f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
                                                         : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows));
-        const bool want = enet || m == POLS_SOLVE_LU || ctx->opt.static_engine == 2 || (!k1_resident && !legacy_forced && !k1m_takes);
+        // Round 3: K2's loop lost its per-column wave-uniform branches and skips the tile stages of chunks a wave has no row of; on the
+        // over-resident shapes (rows beyond K1's registers, tile within LDS) it now beats K1m everywhere measured but f32 with 9-10
+        // columns -- f64 9 / 12 / 15 columns x 1 100 rows: 434 / 447 / 455 us against 468 / 562 / 722; f32 x 2 200 rows: 358 / 364 / 366
+        // against 306 / 371 / 442 (profiles/r03_ab_overresident.txt).
+        const bool k1m_wins = k1m_takes && f32 && kt <= 10;
+        const bool want = enet || m == POLS_SOLVE_LU || ctx->opt.static_engine == 2 || (!k1_resident && !legacy_forced && !k1m_wins);
         if (k2_ok && want) {
             K2Args a2;
             std::memset(&a2, 0, sizeof(a2));

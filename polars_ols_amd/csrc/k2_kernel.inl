@@ -298,8 +298,6 @@ __global__ void __launch_bounds__(64 * WAVES, k2_occupancy(KC, RC, WAVES, YV)) k
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool icpt = ku != kt;
-    const bool fullw = KC == K2_KMAX && ku == KC;           // wave-uniform: every column slot is a user column (kt == ku == 16; the 8-slot
-                                                             // variants keep one code path: the second one cost them 8 bytes of scratch)
     constexpr bool has_w = HAS_W;                            // a template parameter: the sqrt(w) registers only exist when there are weights
     const int ncols = ku + 1 + (has_w ? 1 : 0);              // columns that are loaded: features, target, weights
     unsigned char *mytile = smem + (size_t)wave * K2_TILE_B;
@@ -360,10 +358,17 @@ __global__ void __launch_bounds__(64 * WAVES, k2_occupancy(KC, RC, WAVES, YV)) k
     const unsigned char *zp = mytile + (size_t)(lane & 15) * K2_SLOT_B + (lane >> 4) * 8;   // operand stream of lane (c, q)
 #pragma unroll
     for (int rc = 0; rc < RC; ++rc) {
+        // (a wave none of whose lanes owns a row of this chunk -- the upper waves of a group that fills little more than the first chunk
+        // -- has only zeros to contribute: it skips the two tile stages and their 32 matrix-core instructions)
+        if (rc > 0 && !__any(keep[rc] != 0u)) continue;
         // -- this chunk's registers, prepared only now (nothing above touched them: the wait is for THIS chunk's loads)
-        if (!fullw) {                                        // (all KC slots are user columns: nothing to synthesise, one branch instead of KC)
+        // (a wave-uniform compare + branch is ~10 cycles falling through and ~30 taken: with 16 slots the first 8 are always user
+        // columns -- the 16-slot variants start at 9 columns)
+        // ... and with every slot a user column (cfg5: 16 features) one test instead of eight: 5.77 vs 6.15 ms there.  f64 only: in the
+        // f32 16-slot kernels with weights the extra path cost 48 bytes of scratch at 256 VGPRs.
+        if (sizeof(T) == 4 || ku != KC) {
 #pragma unroll
-            for (int j = 0; j < KC; ++j)
+            for (int j = (KC == K2_KMAX ? KC / 2 : 0); j < KC; ++j)
                 if (j >= ku) x[rc][j] = vsplat<T>((icpt && j == kt - 1) ? T(1) : T(0));      // wave-uniform: intercept / unused slot
         }
         if (!has_w) sw[rc] = vsplat<T>(T(1));
@@ -393,14 +398,10 @@ __global__ void __launch_bounds__(64 * WAVES, k2_occupancy(KC, RC, WAVES, YV)) k
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (fullw) {
+            // every slot is written, unguarded: the slots from k_user on hold the synthesised columns (ones for the intercept, zeros beyond
+            // kt -- what the one-off zero fill of the tiles used to provide), and slot kt is overwritten with the target just below
 #pragma unroll
-                for (int j = 0; j < KC; ++j) *reinterpret_cast<H *>(mytile + (size_t)j * K2_SLOT_B + lane * 8) = k2_half(x[rc][j], h);
-            } else {
-#pragma unroll
-                for (int j = 0; j < KC; ++j)
-                    if (j < kt) *reinterpret_cast<H *>(mytile + (size_t)j * K2_SLOT_B + lane * 8) = k2_half(x[rc][j], h);
-            }
+            for (int j = 0; j < KC; ++j) *reinterpret_cast<H *>(mytile + (size_t)j * K2_SLOT_B + lane * 8) = k2_half(x[rc][j], h);
             if constexpr (!YV) *reinterpret_cast<H *>(mytile + (size_t)kt * K2_SLOT_B + lane * 8) = k2_half(ys, h);
             k2_wave_sync();
             if (rc == 0 && h == 0) K2_STAMP(1);              // the first chunk's loads have landed
