@@ -310,3 +310,20 @@ def test_k2w_is_the_default_beyond_the_resident_k1_shapes(eng):
     out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "resid", "status"))
     assert eng.last_kernel.startswith("k2w_gram_mfma_resident2_f64_k31_w8"), eng.last_kernel
     _check(out, orc.batched_least_squares(y, cols, offs), np.float64)
+
+
+@pytest.mark.parametrize("dtype,k,rows,family", [(np.float64, 12, 1300, "k2_gram_mfma_resident_f64_k16_w8_rc2"), (np.float64, 9, 1100, "k2_gram_mfma_resident_f64_k16_w8_rc2"),
+                                                 (np.float32, 14, 2600, "k2_gram_mfma_resident_f32_k16_w8_rc2"), (np.float32, 9, 2600, "k1m_gram_mfma_f32_k9")])
+def test_over_resident_groups_route_to_k2_where_it_wins(eng, dtype, k, rows, family):
+    """Rows beyond K1's registers, tile within LDS: K2 by default (it beats the LDS-tile engine there since round 3) except f32 with 9-10
+    columns; ragged groups whose upper waves own no row of the second chunk (they skip its tile stages)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(rows + k)
+    offs = _offsets(rng, 40, rows - 200, rows)
+    y, cols, w = _frame(rng, offs, k, dtype, weights=(k % 2 == 0))
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), want=("coef", "pred", "resid", "status"))
+    assert eng.last_kernel.startswith(family), eng.last_kernel
+    ref = orc.batched_least_squares(y, cols, offs, weights=w)
+    assert int(_np(out["status"]).sum()) == 0
+    _check(out, ref, dtype)
