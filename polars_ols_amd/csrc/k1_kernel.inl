@@ -1399,6 +1399,13 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (resident && (HAS_W || !fastn) && ctx->opt.k1_passes != 1)
             return fastn ? k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2, true>(ctx, a) : k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2, true>(ctx, a);
     }
+    if constexpr (sizeof(T) == 4 && KT >= 6 && KT < 9 && TEAM == 256) {
+        // f32 team of 256 (the headline shape under a null policy), RAGGED frames: two masked passes (97 instead of 107 registers) -- 10 000
+        // groups of 900..1 020 rows under "drop": 78.4 against 81.6 us.  Aligned frames keep the single pass: two passes measured slower
+        // there (5 % null targets 87.5 vs 83.8 us, null-free 80.1 vs 78.8, "zero" 75.5 vs 74.6).  POLS_K1_PASSES=1 goes back.
+        const bool resident = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        if (resident && !fastn && ctx->opt.k1_passes != 1) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2, true>(ctx, a);
+    }
     if constexpr (sizeof(T) == 8 && KT >= 6 && KT < 9) {
         // f64, 6+ columns: the single-pass kernel needs 275-400 registers (one wave per SIMD: 300 against 146 us for the plain kernel on
         // 10 000 x 1 000 x 8); two masked passes over the resident rows like the plain f64 kernels.  POLS_K1_PASSES=1 goes back.
