@@ -169,11 +169,11 @@ __device__ __forceinline__ double k2_soft_threshold(double x, double thr) {   //
 // set (:446-489) and ||w - w_old||_2 < tol stop (:436-444).
 // One sweep, coordinate J onwards, unrolled by recursion (a loop with early exits is re-rolled by the compiler, and every taken
 // branch is ~30 cycles on this chain): no branch is taken until the first coordinate beyond kt.
-template <bool POSITIVE, bool ACTIVE, int KC, int J>
+template <bool POSITIVE, bool ACTIVE, bool FULL, int KC, int J>
 __device__ __forceinline__ void k2_cd_steps(const double (&g)[KC], int kt, unsigned sweep, double thr, double ime, double tol, int sub,
                                             double &ume, double &wme, double &d2, unsigned &mask) {
     if constexpr (J < KC) {
-        if (J < kt) {
+        if (FULL || J < kt) {                                // FULL: kt == KC, no test (a wave-uniform compare + branch per coordinate otherwise)
             if (!ACTIVE || ((sweep >> J) & 1u)) {
                 const double dme = fma(k2_soft_threshold<POSITIVE>(ume, thr), ime, -wme);   // new - old weight, meaningful on lane J (:430-431)
                 const double dj = k2_bcast(dme, J);
@@ -184,13 +184,13 @@ __device__ __forceinline__ void k2_cd_steps(const double (&g)[KC], int kt, unsig
                     if (fabs(k2_bcast(wme, J)) < tol) mask &= ~(1u << J);                   // (:472-476)
                 }
             }
-            k2_cd_steps<POSITIVE, ACTIVE, KC, J + 1>(g, kt, sweep, thr, ime, tol, sub, ume, wme, d2, mask);
+            k2_cd_steps<POSITIVE, ACTIVE, FULL, KC, J + 1>(g, kt, sweep, thr, ime, tol, sub, ume, wme, d2, mask);
         }
     }
 }
 
 // This lane's row of X'X (zero diagonal) lives in 2 KC VGPRs: no LDS on the dependency chain.
-template <bool POSITIVE, bool ACTIVE, int KC>
+template <bool POSITIVE, bool ACTIVE, bool FULL, int KC>
 __device__ __forceinline__ int k2_cd_loop(const double *G, int kt, double n, const K2Args &a, double *T, int lane, double &wout) {
     const int sub = lane & 15;
     const bool in = sub < kt;
@@ -215,7 +215,7 @@ __device__ __forceinline__ int k2_cd_loop(const double *G, int kt, double n, con
     for (int64_t it = 0; it < a.max_iter; ++it) {
         double d2 = 0.0;
         const unsigned sweep = mask;                     // `for j in active_indices.clone()` (:459)
-        k2_cd_steps<POSITIVE, ACTIVE, KC, 0>(g, kt, sweep, thr, ime, a.tol, sub, ume, wme, d2, mask);
+        k2_cd_steps<POSITIVE, ACTIVE, FULL, KC, 0>(g, kt, sweep, thr, ime, a.tol, sub, ume, wme, d2, mask);
         if (d2 < tol2) { status = POLS_GROUP_OK; break; }     // (:436-444)
     }
     wout = wme;
@@ -225,8 +225,11 @@ __device__ __forceinline__ int k2_cd_loop(const double *G, int kt, double n, con
 template <int KC>
 __device__ __forceinline__ int k2_cd(const double *G, int kt, double n, const K2Args &a, double *T, int lane, double &wout) {
     const bool act = a.solver == K2_CD_ACTIVE_SET;
-    if (a.positive) return act ? k2_cd_loop<true, true, KC>(G, kt, n, a, T, lane, wout) : k2_cd_loop<true, false, KC>(G, kt, n, a, T, lane, wout);
-    return act ? k2_cd_loop<false, true, KC>(G, kt, n, a, T, lane, wout) : k2_cd_loop<false, false, KC>(G, kt, n, a, T, lane, wout);
+    if (a.positive) return act ? k2_cd_loop<true, true, false, KC>(G, kt, n, a, T, lane, wout) : k2_cd_loop<true, false, false, KC>(G, kt, n, a, T, lane, wout);
+    if (act) return k2_cd_loop<false, true, false, KC>(G, kt, n, a, T, lane, wout);
+    // the plain cyclic form at full width (cfg5: 16 columns) without the per-coordinate `J < kt` test
+    if (kt == KC) return k2_cd_loop<false, false, true, KC>(G, kt, n, a, T, lane, wout);
+    return k2_cd_loop<false, false, false, KC>(G, kt, n, a, T, lane, wout);
 }
 
 // element v of the result = (row v of the chunk belongs to the group) ? loaded[v + shift] : fill  -- the ragged-edge fix-up
