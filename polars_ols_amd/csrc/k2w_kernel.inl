@@ -35,9 +35,12 @@ constexpr int K2W_TAIL_B = (2 * 32 * K2W_GS + 64) * 8;   // Z'Z, the solver's ma
 // false = failed / flagged pivot.  G: Z'Z with X'y in column kt; Tm: 32 x 33 scratch.  Lane i keeps row i of the factor in registers,
 // v_readlane broadcasts (k2_chol's form at 32 columns).  Measured against publishing the pivot column through LDS once per step
 // (one round trip instead of 2 (kt - j) broadcasts): the LDS form was SLOWER (f64, 31 columns x 1 000 rows: 614 vs 515 us per 5 000 groups).
+// KB: the padded size of the system, 24 or 32 (kt <= KB).  The elimination, the substitutions and the transposition are unrolled over KB:
+// at 17-24 columns the 24-wide form does 37 % less of the (instruction-bound) update work than the 32-wide one.
+template <int KB>
 __device__ __forceinline__ bool k2w_chol(const double *G, int kt, double alpha, double pivot_tol, double *Tm, int lane, double &bi) {
-    constexpr int KC = K2W_KC;
-    const int i = lane & 31;                             // lanes 32..63 repeat lanes 0..31 (broadcasts read lanes 0..31)
+    constexpr int KC = KB;
+    const int i = (lane & 31) < KB ? (lane & 31) : KB - 1;   // lanes 32..63 repeat lanes 0..31 (broadcasts read lanes 0..kt-1); rows beyond KB mirror the last
     // [X'X + alpha I | X'y] padded with an identity block, built in LDS by a rolled loop (written as per-lane selects in the unrolled
     // code the padding constants would be hoisted out of the persistent group loop into registers)
 #pragma unroll 1
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
         int st = POLS_GROUP_OK;
         double bi = 0.0;
         if (e == s) st = POLS_GROUP_EMPTY;                   // features.is_empty() -> zeros (ex.rs:357-359)
-        else if (!k2w_chol(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi)) {
+        else if (!(kt <= 24 ? k2w_chol<24>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi) : k2w_chol<32>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi))) {
             st = POLS_GROUP_FALLBACK;
             if (lane == 0 && a.fb_flag) *a.fb_flag = a.epoch;
         }

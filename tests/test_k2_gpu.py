@@ -299,16 +299,18 @@ def test_k2w_two_tile_resident_kernel(eng, dtype, kt, weights, icpt, alpha, shap
     _check(out, ref, dtype)
 
 
-def test_k2w_is_the_default_beyond_the_resident_k1_shapes(eng):
-    """f64, 31 columns x 1 000 rows (248 KB per group): used to take the three-launch streamed path (X read twice).  (17..24 f64 columns
-    beyond 512 rows stay with it: measured ahead there.)"""
+@pytest.mark.parametrize("k,family", [(31, "k2w_gram_mfma_resident2_f64_k31_w8"), (22, "k2w_gram_mfma_resident2_f64_k22_w8"), (20, "k2w_gram_mfma_resident2_f64_k20_w8"),
+                                      (18, "k5_gram_stream_f64")])
+def test_k2w_is_the_default_beyond_the_resident_k1_shapes(eng, k, family):
+    """f64, 20..31 columns x 1 000 rows (up to 248 KB per group): used to take the three-launch streamed path (X read twice); 20..24 columns
+    since the 24-wide solver.  (17..19 f64 columns beyond 512 rows stay with the streamed path: measured ahead there.)"""
     from oracle import orc
 
     rng = np.random.default_rng(5)
     offs = np.arange(0, 41 * 1000, 1000, dtype=np.int64)
-    y, cols, _ = _frame(rng, offs, 31, np.float64)
+    y, cols, _ = _frame(rng, offs, k, np.float64)
     out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "resid", "status"))
-    assert eng.last_kernel.startswith("k2w_gram_mfma_resident2_f64_k31_w8"), eng.last_kernel
+    assert eng.last_kernel.startswith(family), eng.last_kernel
     _check(out, orc.batched_least_squares(y, cols, offs), np.float64)
 
 
