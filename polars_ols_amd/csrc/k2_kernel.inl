@@ -57,7 +57,7 @@ __device__ __forceinline__ double k2_rsqrt(double d) {          // v_rsq_f64 + t
 // Cholesky of X'X + alpha I (faer cholesky(Side::Lower), ls.rs:288-297) and the two triangular solves; false = failed / flagged pivot
 template <int KC>
 __device__ __forceinline__ bool k2_chol(const double *G, int kt, double alpha, double pivot_tol, double *T, int lane, double &bi) {
-    const int i = lane & 15;                             // lanes 16..63 repeat lanes 0..15 (broadcasts read lanes 0..15)
+    const int i = (lane & 15) < KC ? (lane & 15) : KC - 1;   // lanes 16..63 repeat lanes 0..15 (broadcasts read lanes 0..KC-1); rows beyond KC mirror the last
     // [X'X + alpha I | X'y] padded to KC x KC with an identity block, built in LDS by a rolled loop: written as per-lane selects
     // in the unrolled code below, the padding constants are loop-invariant and get hoisted out of the persistent group loop
     // into ~64 VGPRs
@@ -502,7 +502,12 @@ __global__ void __launch_bounds__(64 * WAVES, k2_occupancy(KC, RC, WAVES, YV)) k
             bool ok;
             if (a.solver == K2_LU) ok = k2_lu(Gs, kt, a.alpha, As, lane, bi);
             else {
-                ok = k2_chol<KC>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi);
+                // (the solve is a chain of ~1 300 dependent-ish instructions whatever kt: 10.9 k cycles of a 27 k-cycle group at 9-15 columns.
+                // Padded to 10 / 12 / 14 instead of 16 it does up to half less: 8.3 k cycles at 12.)
+                if (KC == K2_KMAX && kt <= 10) ok = k2_chol<10>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi);
+                else if (KC == K2_KMAX && kt <= 12) ok = k2_chol<12>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi);
+                else if (KC == K2_KMAX && kt <= 14) ok = k2_chol<14>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi);
+                else ok = k2_chol<KC>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi);
                 if (!ok && a.lu_fallback) ok = k2_lu(Gs, kt, a.alpha, As, lane, bi);   // solve_ridge: Cholesky -> LU (ls.rs:358-363)
             }
             if (!ok) { st = POLS_GROUP_FALLBACK; if (lane == 0 && a.fb_flag) *a.fb_flag = a.epoch; }

@@ -35,7 +35,7 @@ constexpr int K2W_TAIL_B = (2 * 32 * K2W_GS + 64) * 8;   // Z'Z, the solver's ma
 // false = failed / flagged pivot.  G: Z'Z with X'y in column kt; Tm: 32 x 33 scratch.  Lane i keeps row i of the factor in registers,
 // v_readlane broadcasts (k2_chol's form at 32 columns).  Measured against publishing the pivot column through LDS once per step
 // (one round trip instead of 2 (kt - j) broadcasts): the LDS form was SLOWER (f64, 31 columns x 1 000 rows: 614 vs 515 us per 5 000 groups).
-// KB: the padded size of the system, 24 or 32 (kt <= KB).  The elimination, the substitutions and the transposition are unrolled over KB:
+// KB: the padded size of the system, 20 / 24 / 28 / 32 (kt <= KB).  The elimination, the substitutions and the transposition are unrolled over KB:
 // at 17-24 columns the 24-wide form does 37 % less of the (instruction-bound) update work than the 32-wide one.
 template <int KB>
 __device__ __forceinline__ bool k2w_chol(const double *G, int kt, double alpha, double pivot_tol, double *Tm, int lane, double &bi) {
@@ -263,7 +263,10 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
         int st = POLS_GROUP_OK;
         double bi = 0.0;
         if (e == s) st = POLS_GROUP_EMPTY;                   // features.is_empty() -> zeros (ex.rs:357-359)
-        else if (!(kt <= 24 ? k2w_chol<24>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi) : k2w_chol<32>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi))) {
+        else if (!(kt <= 20 ? k2w_chol<20>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi)
+                   : kt <= 24 ? k2w_chol<24>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi)
+                   : kt <= 28 ? k2w_chol<28>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi)
+                              : k2w_chol<32>(Gs, kt, a.alpha, a.pivot_tol, As, lane, bi))) {
             st = POLS_GROUP_FALLBACK;
             if (lane == 0 && a.fb_flag) *a.fb_flag = a.epoch;
         }
