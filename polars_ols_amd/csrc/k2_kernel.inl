@@ -58,24 +58,20 @@ __device__ __forceinline__ double k2_rsqrt(double d) {          // v_rsq_f64 + t
 template <int KC>
 __device__ __forceinline__ bool k2_chol(const double *G, int kt, double alpha, double pivot_tol, double *T, int lane, double &bi) {
     const int i = (lane & 15) < KC ? (lane & 15) : KC - 1;   // lanes 16..63 repeat lanes 0..15 (broadcasts read lanes 0..KC-1); rows beyond KC mirror the last
-    // [X'X + alpha I | X'y] padded to KC x KC with an identity block, built in LDS by a rolled loop: written as per-lane selects
-    // in the unrolled code below, the padding constants are loop-invariant and get hoisted out of the persistent group loop
-    // into ~64 VGPRs
-#pragma unroll 1
-    for (int q = lane; q < KC * (KC + 1); q += 64) {
-        const int r = q / (KC + 1), c = q - r * (KC + 1);
-        double v;
-        if (c == KC) v = r < kt ? G[r * K2_GS + kt] : 0.0;
-        else v = (r < kt && c < kt) ? G[r * K2_GS + c] + (r == c ? alpha : 0.0) : (r == c ? 1.0 : 0.0);
-        T[r * K2_GS + c] = v;
-    }
-    k2_wave_sync();
+    // [X'X + alpha I | X'y] padded to KC x KC with an identity block: lane i builds row i in registers straight from the Gram matrix
+    // (KC independent LDS loads).  (Until round 3 the padded system went through a rolled loop over T: per-lane selects like these used
+    // to be hoisted out of the persistent group loop into ~64 VGPRs; the caller launders the lane id per group now, and the rolled
+    // loop was 4-16 dependent load -> store round trips of ~300 cycles.)
     double row[KC];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) row[c] = T[i * K2_GS + c];
-    bi = T[i * K2_GS + KC];
-    const double gd = T[i * K2_GS + i];
-    k2_wave_sync();                                      // T is rewritten for the transposition below
+    for (int c = 0; c < KC; ++c) {
+        const double gv = (i < kt && c < kt) ? G[i * K2_GS + c] : 0.0;
+        row[c] = (i == c) ? ((i < kt) ? gv + alpha : 1.0) : gv;
+    }
+    bi = (i < kt) ? G[i * K2_GS + kt] : 0.0;
+    double gd = 1.0;                                     // this lane's original diagonal entry
+#pragma unroll
+    for (int c = 0; c < KC; ++c) gd = (i == c) ? row[c] : gd;
     double rme = 1.0;                                    // 1 / L[i][i], kept on lane i (a uniform array would live in 2 KC SGPRs)
     bool ok = true;
 #pragma unroll
@@ -201,16 +197,11 @@ __device__ __forceinline__ int k2_cd_loop(const double *G, int kt, double n, con
     double wme = 0.0;
     unsigned mask = (1u << kt) - 1u;
     int status = POLS_GROUP_NOT_CONVERGED;
-    // X'X with a zero diagonal, padded with zeros, through LDS by a rolled loop (see k2_chol for why)
-#pragma unroll 1
-    for (int q = lane; q < KC * KC; q += 64) {
-        const int r = q / KC, c = q - r * KC;
-        T[r * K2_GS + c] = (r < kt && c < kt && r != c) ? G[r * K2_GS + c] : 0.0;
-    }
-    k2_wave_sync();
+    // this lane's row of X'X with a zero diagonal, padded with zeros: KC independent loads (see k2_chol)
     double g[KC];
 #pragma unroll
-    for (int j = 0; j < KC; ++j) g[j] = T[sub * K2_GS + j];   // G[sub][j], 0 on the diagonal
+    for (int j = 0; j < KC; ++j) g[j] = (in && j < kt && j != sub) ? G[sub * K2_GS + j] : 0.0;
+    (void)T;
     const double tol2 = a.tol > 0.0 ? a.tol * a.tol : -1.0;   // ||dw||_2 < tol  <=>  ||dw||^2 < tol^2 (a sqrt is ~100 cycles per sweep)
     for (int64_t it = 0; it < a.max_iter; ++it) {
         double d2 = 0.0;

@@ -43,13 +43,25 @@ __device__ __forceinline__ bool k2w_chol(const double *G, int kt, double alpha, 
     const int i = (lane & 31) < KB ? (lane & 31) : KB - 1;   // lanes 32..63 repeat lanes 0..31 (broadcasts read lanes 0..kt-1); rows beyond KB mirror the last
     // [X'X + alpha I | X'y] padded with an identity block, built in LDS by a rolled loop (written as per-lane selects in the unrolled
     // code the padding constants would be hoisted out of the persistent group loop into registers)
-#pragma unroll 1
-    for (int q = lane; q < KC * (KC + 1); q += 64) {
-        const int r = q / (KC + 1), c = q - r * (KC + 1);
-        double v;
-        if (c == KC) v = r < kt ? G[r * K2W_GS + kt] : 0.0;
-        else v = (r < kt && c < kt) ? G[r * K2W_GS + c] + (r == c ? alpha : 0.0) : (r == c ? 1.0 : 0.0);
-        Tm[r * K2W_GS + c] = v;
+    // (round 3: lane (row, half) writes half a row with independent loads, unrolled -- the rolled q / (KC + 1) loop was 16 dependent
+    // load -> store round trips of ~300 cycles each; the lane id is laundered per group in the caller, so nothing here is hoisted)
+    {
+        constexpr int HW = (KC + 2) / 2;                 // columns per half row, the right-hand side included
+        const int r = lane & 31, c0 = (lane >> 5) * HW;
+        double v[HW];
+#pragma unroll
+        for (int cc = 0; cc < HW; ++cc) {
+            const int c = c0 + cc;
+            const int src = (c == KC) ? kt : c;          // column kt of G holds X'y
+            v[cc] = (r < kt && (c < kt || c == KC)) ? G[r * K2W_GS + src] : 0.0;
+        }
+#pragma unroll
+        for (int cc = 0; cc < HW; ++cc) {
+            const int c = c0 + cc;
+            double w = v[cc];
+            if (c < KC && r == c) w = (r < kt) ? w + alpha : 1.0;
+            if (r < KC && c <= KC) Tm[r * K2W_GS + c] = w;
+        }
     }
     k2_wave_sync();
     double row[KC];
