@@ -930,9 +930,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // where it measured ahead of the streamed path (scripts/bench_k16.py, 1 000-row groups): f64 from 25 columns (31: 2.45 vs 2.07
         // TB/s; 20: 1.93 vs 2.10 -- one group per CU, and the serial 32-column solve is 40 % of a group's time whatever kt), f32 always
         // (2.53 vs 1.75 at 31 columns)
-        // (round 3, 24-wide solver for 17..24 columns: f64 20 / 24 columns x 1 000 rows 795 / 436 us against 837 / 492 streamed; at 17 the
-        // streamed path still leads, 728 against 758)
-        const bool ahead = f32 || kt >= 20;
+        // (round 3, solvers padded to 20 / 24 / 28 / 32 and built by independent loads: f64 17 / 20 / 24 columns x 1 000 rows 689 / 722 /
+        // 409 us against 729 / 837 / 492 streamed -- ahead at every width it covers now)
+        const bool ahead = true;
+        (void)f32;
         if (fits && ((!k1_resident && ahead) || ctx->opt.static_engine == 4)) {
             K2wArgs aw;
             std::memset(&aw, 0, sizeof(aw));

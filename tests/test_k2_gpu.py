@@ -300,10 +300,10 @@ def test_k2w_two_tile_resident_kernel(eng, dtype, kt, weights, icpt, alpha, shap
 
 
 @pytest.mark.parametrize("k,family", [(31, "k2w_gram_mfma_resident2_f64_k31_w8"), (22, "k2w_gram_mfma_resident2_f64_k22_w8"), (20, "k2w_gram_mfma_resident2_f64_k20_w8"),
-                                      (18, "k5_gram_stream_f64")])
+                                      (18, "k2w_gram_mfma_resident2_f64_k18_w8")])
 def test_k2w_is_the_default_beyond_the_resident_k1_shapes(eng, k, family):
     """f64, 20..31 columns x 1 000 rows (up to 248 KB per group): used to take the three-launch streamed path (X read twice); 20..24 columns
-    since the 24-wide solver.  (17..19 f64 columns beyond 512 rows stay with the streamed path: measured ahead there.)"""
+    since the solvers padded to the next of 20 / 24 / 28 / 32 columns, 17..19 since their padded system is built by independent loads."""
     from oracle import orc
 
     rng = np.random.default_rng(5)
