@@ -329,3 +329,27 @@ def test_over_resident_groups_route_to_k2_where_it_wins(eng, dtype, k, rows, fam
     ref = orc.batched_least_squares(y, cols, offs, weights=w)
     assert int(_np(out["status"]).sum()) == 0
     _check(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kt", list(range(9, 32)))
+def test_every_padded_solver_width(eng, dtype, kt):
+    """The K2 / K2w Cholesky runs on a system padded to the next of 10 / 12 / 14 / 16 and 20 / 24 / 28 / 32 columns: every column count from
+    9 to 31 (the intercept counted, weights on the odd ones, ridge on every third), ragged groups, against the oracle."""
+    from oracle import orc
+
+    rng = np.random.default_rng(100 + kt)
+    icpt = kt % 2 == 0
+    offs = _offsets(rng, 9, 3 * kt, 900)
+    y, cols, w = _frame(rng, offs, kt - int(icpt), dtype, weights=(kt % 2 == 1))
+    kw = dict(alpha=0.4, l1_ratio=0.0) if kt % 3 == 0 else {}
+    eng.set_option("STATIC_ENGINE", "k2" if kt <= 16 else "k2w")
+    try:
+        out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                                want=("coef", "pred", "resid", "status"), **kw)
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
+    assert eng.last_kernel.startswith("k2_gram_mfma_resident_" if kt <= 16 else "k2w_gram_mfma_resident2_"), eng.last_kernel
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert int(_np(out["status"]).sum()) == 0
+    _check(out, ref, dtype)
