@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg4r|cfg5|ref100] [--mem device|host]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg4r|rlsg|rlsgr|cfg5|ref100] [--mem device|host]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -22,6 +22,9 @@ FAILS -- a multi-GPU line is never printed without its collective.
   cfg3  10 000 x 1 000 x 8, f64, ridge alpha = 1 + sample_weights, predictions
   cfg4  1 000 000-row RLS, 6 features, half_life = 21, f64 (ONE sequence: a dependency chain, replicas only)
   cfg4r the other reading of configs[3]: 1 000 000-row rolling OLS, window = 252, 6 features, f64
+  rlsg  the dynamic models the way the reference is used (README.md:119-137, `.rls(...).over("group")`): 10 000 sequences x
+        1 000 rows x 6 features, f64, RLS half_life = 21, coefficients + predictions; sequences shard across ranks
+  rlsgr the same frame through rolling OLS, window = 252
   ref100 the reference's own benchmark shape: ONE 10 000 x 100 f64 OLS problem (published: 17.6 ms per call, M2 Max)
   cfg5  100 000 groups x 2 000 rows x 16 feats elastic net alpha = 0.001 l1_ratio = 0.5, f64; the groups are SPLIT
         across the ranks (strong scaling: 100 000 / N per GPU)
@@ -83,6 +86,35 @@ def cpu_baseline(cfg: str, target_seconds: float = 10.0) -> dict:
                 "sample": f"3 passes over ONE {n}-row sequence x {k} feats f64, "
                           f"{'solve_recursive_least_squares half_life=21' if kind == 'rls' else 'solve_rolling_ols window=252'} + "
                           f"dynamic predictions, timed inside liborc; a sequence is a dependency chain: one core"}
+    if cfg in ("rlsg", "rlsgr"):
+        G, n, k = max(512, 8 * cores), 1_000, 6
+        rng = np.random.default_rng(1)
+        cols = [rng.standard_normal(G * n) for _ in range(k)]
+        y = np.sum(cols, axis=0) + 0.1 * rng.standard_normal(G * n)
+        offs = np.arange(G + 1, dtype=np.int64) * n
+
+        def run(threads):
+            if cfg == "rlsg":
+                orc.batched_rls(y, cols, offs, half_life=21.0, n_threads=threads)
+            else:
+                orc.batched_rolling(y, cols, offs, window_size=252, min_periods=6, null_policy="drop", n_threads=threads)
+
+        rates = {}
+        for t in _thread_ladder(cores):
+            run(t)
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < target_seconds / 5:
+                run(t)
+                reps += 1
+            rates[t] = reps * G * n / (time.perf_counter() - t0)
+        best = max(rates, key=lambda t: rates[t])
+        scal = ", ".join(f"{t} thr {rates[t]:.3g} rows/s" for t in sorted(rates))
+        return {"value": rates[best], "unit": "rows/s", "cores": best, "kind": "port",
+                "sample": f"{G} sequences x {n} rows x {k} feats f64, "
+                          f"{'solve_recursive_least_squares half_life=21' if cfg == 'rlsg' else 'solve_rolling_ols window=252 (drop)'} + "
+                          f"dynamic predictions (marshal ex.rs:22-63 included), one sequence per OpenMP task, wall clock around "
+                          f"orc.batched_* (output arrays allocated inside); best of the thread ladder: {scal}"}
     shapes = {"cfg1": (1, 10_000, 4, {}, False), "cfg2": (max(2_048, 32 * cores), 1_000, 8, {}, False),
               "cfg3": (max(2_048, 32 * cores), 1_000, 8, dict(alpha=1.0, l1_ratio=0.0), True),
               "cfg5": (max(1_024, 8 * cores), 2_000, 16, dict(alpha=0.001, l1_ratio=0.5), False),
@@ -186,6 +218,23 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
             text = f"BASELINE configs[3], second reading: ONE {n}-row sequence, {k} feats f64 rolling OLS window=252 (coefficients + predictions); replicas only"
         return dict(plan=plan, units=n, unit="rows/s", alg_bytes=8 * n * (k + 1) + 8 * n * (k + 1), text=text, dtype="f64", coef=None,
                     scaling="weak", shard=None)
+    if cfg in ("rlsg", "rlsgr"):
+        G_per, n, k = 10_000, 1_000, 6
+        shard = shard_for_rank(np.arange(G_per * world + 1, dtype=np.int64) * n, world, rank)
+        G = shard.group_hi - shard.group_lo
+        y, cols, _ = make_columns(G * n, k, torch.float64, 1234 + rank + 1000 * frame)
+        out = {"pred": torch.empty(G * n, device="cuda", dtype=torch.float64), "coef": torch.empty(G * n, k, device="cuda", dtype=torch.float64)}
+        if cfg == "rlsg":
+            plan = eng.plan_recursive_least_squares(y, cols, shard.offsets, half_life=21.0, out=out, null_free=True)
+            what = "RLS half_life=21"
+        else:
+            plan = eng.plan_rolling_least_squares(y, cols, shard.offsets, window_size=252, min_periods=6, null_policy="drop", out=out,
+                                                  null_free=True)
+            what = "rolling OLS window=252"
+        text = (f"the dynamic models over groups (README.md:119-137): {G} sequences x {n} rows x {k} feats f64 {what} "
+                f"(coefficients + predictions), per GPU")
+        return dict(plan=plan, units=G * n, unit="rows/s", alg_bytes=16 * G * n * (k + 1), text=text, dtype="f64", coef=None,
+                    scaling="weak", shard=None)
     if cfg == "ref100":
         n, k = 10_000, 100
         y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
@@ -211,7 +260,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4r", "cfg5", "ref100"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4r", "rlsg", "rlsgr", "cfg5", "ref100"])
     ap.add_argument("--mem", default="device", choices=["device", "host"])
     ap.add_argument("--frames", type=int, default=0, help="rotate the steps over this many independent frames (0: automatic)")
     ap.add_argument("--gather", default="coef", choices=["coef", "pred", "none"], help="N > 1: what is re-assembled every step")
@@ -250,7 +299,7 @@ def main() -> None:
     # inputs add up to more than three times that makes every step stream its input from HBM.  Outputs go to the first frame's
     # buffers (written, never read).
     in_bytes = wl["alg_bytes"]
-    n_frames = args.frames if args.frames > 0 else (1 if (args.config in ("cfg1", "cfg4", "cfg4r", "ref100") or args.mem == "host")
+    n_frames = args.frames if args.frames > 0 else (1 if (args.config in ("cfg1", "cfg4", "cfg4r", "rlsg", "rlsgr", "ref100") or args.mem == "host")
                                                     else max(1, min(8, -(-3 * 256 * 2 ** 20 // max(1, in_bytes)))))
     if args.frames == 0 and args.config in ("cfg2", "cfg3") and args.mem == "device":
         n_frames = max(3, n_frames)
@@ -362,25 +411,41 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = eng.timing_collect()
+    kernel_ms = list(eng.timing_collect())
     eng.timing(False)
     kernel_name = eng.last_kernel
+    # at least 16 kernel-duration samples whatever --steps is: a sampled pass over the same frames right behind the timed region
+    # (outside it), every second launch stamped so that an event-bracketed launch still has an un-bracketed neighbour on either side
+    MIN_SAMPLES = 16
+    samples_in_region = len(kernel_ms)
+    if len(kernel_ms) < MIN_SAMPLES and pred_state is None and ring is None:
+        eng.timing(2)
+        for _ in range(2 * (MIN_SAMPLES - len(kernel_ms)) + 2):
+            step()
+        torch.cuda.synchronize()
+        kernel_ms += list(eng.timing_collect())
+        eng.timing(False)
 
     # the bandwidth ceiling of this workload's traffic mix, measured on the same frames right behind the timed region (outside it):
     # pols_stream_probe reads every input column and writes the predictions column with the arithmetic removed, sampled by the
     # same per-launch HIP events.  Static device-resident configs at N = 1 only.
     probe_ms = None
+    probe_persistent_ms = None
     if world == 1 and args.mem == "device" and args.config in ("cfg2", "cfg3", "cfg5") and all("pred" in p.results for p in plans):
-        for p in plans:
-            p.stream_probe()
-        torch.cuda.synchronize()
-        eng.timing(stride)
-        for i in range(max(args.steps, 3 * len(plans))):
-            plans[i % len(plans)].stream_probe()
-        torch.cuda.synchronize()
-        pm = eng.timing_collect()
-        eng.timing(False)
-        probe_ms = float(np.mean(pm)) if len(pm) else None
+        def probe(mode):
+            for p in plans:
+                p.stream_probe(mode)
+            torch.cuda.synchronize()
+            eng.timing(2)
+            for i in range(max(args.steps, 2 * MIN_SAMPLES, 3 * len(plans))):
+                plans[i % len(plans)].stream_probe(mode)
+            torch.cuda.synchronize()
+            pm = eng.timing_collect()
+            eng.timing(False)
+            return float(np.mean(pm)) if len(pm) else None
+
+        probe_ms = probe(0)
+        probe_persistent_ms = probe(1)
 
     total_units = float(wl["units"])
     if dist:
@@ -399,17 +464,23 @@ def main() -> None:
         # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 correction
         # applied) for this exact kernel + workload; committed under profiles/ (pmc_traffic.json).  null if absent.
         traffic = None
+        traffic_source = None
         try:
             pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
             entry = pmc.get(kernel_name, {})
             if entry.get("config", "cfg2") == args.config and args.mem == "device" and world == 1:
                 traffic = entry.get("traffic_bytes")
+                traffic_source = {"file": "profiles/pmc_traffic.json", "kernel": kernel_name, "round": entry.get("round"),
+                                  "from": entry.get("source")}
         except Exception:
             traffic = None
+        if traffic is None and args.mem == "device" and world == 1:
+            print(f"bench.py: no PMC traffic entry for kernel {kernel_name!r} / {args.config} in profiles/pmc_traffic.json -- "
+                  f"roofline.traffic is null", file=sys.stderr)
         unit_name = wl["unit"]
         line = {
             "metric": {"regressions/s": "group_regressions_per_sec", "problems/s": "single_problems_per_sec"}.get(
-                unit_name, "rolling_rows_per_sec" if args.config == "cfg4r" else "rls_rows_per_sec"),
+                unit_name, "rolling_rows_per_sec" if args.config in ("cfg4r", "rlsgr") else "rls_rows_per_sec"),
             "value": value, "unit": unit_name, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": wl["scaling"], "vs_baseline": None, "dtype": wl["dtype"],
@@ -418,22 +489,31 @@ def main() -> None:
                        "sharding": "groups (shard_for_rank: contiguous ranges balanced by rows)" if world > 1 else "none",
                        "world_size": world, "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": wl["alg_bytes"]},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name,
+                         "kernel_ms": k_ms, "kernel_samples": len(kernel_ms), "kernel_samples_in_timed_region": samples_in_region,
+                         "algorithmic_bytes_per_launch": wl["alg_bytes"]},
         }
         if probe_ms:
             ceiling = wl["alg_bytes"] / (probe_ms * 1e-3) / 1e9
             line["roofline"]["stream_ceiling"] = {
                 "GBps": ceiling, "kernel_ms": probe_ms, "frac_of_peak": ceiling / HBM_PEAK_GBS, "achieved_over_ceiling": achieved / ceiling,
-                "what": "pols_stream_probe: the same columns read and the predictions column written with streaming 16-byte accesses, "
-                        "no arithmetic; same frames, same event sampling, measured right behind the timed region"}
+                "what": "pols_stream_probe_ex mode 0: the same columns read and the predictions column written with streaming 16-byte "
+                        "accesses, no arithmetic, in the launch shape of the resident kernels (one piece per lane, exits); same frames, "
+                        "event-sampled, measured right behind the timed region"}
+            if probe_persistent_ms:
+                pc = wl["alg_bytes"] / (probe_persistent_ms * 1e-3) / 1e9
+                line["roofline"]["stream_ceiling"]["persistent"] = {
+                    "GBps": pc, "kernel_ms": probe_persistent_ms, "frac_of_peak": pc / HBM_PEAK_GBS, "achieved_over_ceiling": achieved / pc,
+                    "what": "mode 1: the same traffic as a persistent grid-stride stream (4 workgroups per CU, the next piece's loads "
+                            "issued before the current piece is stored): no dispatch ramp, no tail"}
         if args.config == "ref100":
             # BASELINE.md section 2 holds a published number for exactly this shape: 17.6 ms per call (OLS QR, 10 000 x 100, M2 Max,
             # through Polars + pyo3) = 56.8 problems/s.  Different hardware and it includes the Polars overhead: context, not a target.
             line["vs_baseline"] = value / (1.0 / 17.6e-3)
-        if args.config in ("cfg4", "cfg4r"):
-            line["roofline"]["note"] = ("single sequence: bound by the serial rank-1 update chain, not by HBM; "
-                                        "achieved/peak only shows how far from memory-bound it is")
+        if args.config in ("cfg4", "cfg4r", "rlsg", "rlsgr"):
+            line["roofline"]["note"] = ("dynamic models: algorithmic bytes = every input column read once + coefficients and predictions "
+                                        "written once (16 (k + 1) bytes per row, f64); the sequence is a scan, not a chain -- rows are "
+                                        "processed in parallel and the bound is HBM")
         if args.config in ("cfg1", "ref100") or args.mem == "host":
             line["roofline"]["note"] = ("one small problem / host-resident data: launch- or PCIe-bound; achieved/peak only shows how far "
                                         "from HBM-bound it is")

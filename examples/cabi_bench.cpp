@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../include/pols_mi355x.h"
+#include "../include/pols_mi355x_debug.h"   // pols_timing_*, pols_last_kernel_name: measurement aids
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 #define POLS_OK_(x) do { int r_ = (x); if (r_ != POLS_OK) { std::fprintf(stderr, "%s: %d %s\n", #x, r_, pols_last_error()); return 3; } } while (0)

@@ -102,14 +102,6 @@ void pols_destroy(pols_ctx *ctx);
 int pols_set_stream(pols_ctx *ctx, void *hip_stream);
 int pols_use_private_stream(pols_ctx *ctx);
 int pols_synchronize(pols_ctx *ctx);
-/* Kernel timing with HIP events on the context's stream (used by bench.py's roofline leg).
- * While enabled every compute entry brackets its dominant kernel with an event pair; enable = n > 1 times every n-th
- * call only (an event pair costs ~5 us on the stream's timeline, which matters next to a 75 us kernel). */
-int pols_timing_enable(pols_ctx *ctx, int enable);
-/* Synchronises, copies up to `max` per-launch durations (ms) recorded since the last call, returns the count. */
-int pols_timing_collect(pols_ctx *ctx, float *ms_out, int max);
-/* Name of the kernel variant the last compute entry launched (for profiles / DESIGN.md). */
-const char *pols_last_kernel_name(pols_ctx *ctx);
 /* Tuning / diagnostic knobs (engine choices for A/B measurements, debug stamps).  `key` is the name of the matching POLS_*
  * environment variable, with or without the prefix; value NULL restores the default.  The environment is read ONCE, in
  * pols_create(); no compute entry calls getenv. */
@@ -216,13 +208,6 @@ int pols_predict(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t c
  * back null (:732-738) -- with NaN as the null that is what the un-filled product already is, so POLS_NULL_DROP computes like
  * POLS_NULL_IGNORE.  pols_predict == pols_predict_policy(.., POLS_NULL_IGNORE, ..). */
 int pols_predict_policy(pols_ctx *ctx, const pols_batch *b, const void *coef, int64_t coef_rows, int32_t null_policy, void *pred_out);
-
-/* Measurement aid, NOT part of the reference interface (bench.py's `roofline.stream_ceiling`): one pass over the batch's columns with
- * the arithmetic removed -- every feature column, the target and the weights read with 16-byte streaming loads down the row axis,
- * their sum written over `pred_out` (n_rows values, batch dtype) with streaming stores: the rate HBM admits for this traffic mix on
- * this device, beside which a static kernel's achieved rate on the same buffers is read.  DEVICE batches, up to POLS_MAX_FEATURES
- * columns; timed like every launch (pols_timing_enable / pols_timing_collect). */
-int pols_stream_probe(pols_ctx *ctx, const pols_batch *b, void *pred_out);
 
 /* mode="statistics": replaces the plugin `least_squares_statistics` (src/expressions.rs:468-509) and
  * src/statistics.rs:15-156 for every group of the batch.  Per group, on the sqrt(w)-scaled rows the reference's

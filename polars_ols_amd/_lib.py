@@ -77,7 +77,7 @@ class StatsOut(C.Structure):
 EXPORTS = [
     "pols_device_count", "pols_version", "pols_last_error", "pols_create", "pols_destroy", "pols_set_stream",
     "pols_use_private_stream",
-    "pols_synchronize", "pols_timing_enable", "pols_timing_collect", "pols_last_kernel_name", "pols_set_option",
+    "pols_synchronize", "pols_set_option",
     "pols_ols_params_default", "pols_rls_params_default", "pols_rolling_params_default",
     "pols_least_squares", "pols_recursive_least_squares", "pols_rolling_least_squares", "pols_predict", "pols_predict_policy",
     "pols_least_squares_statistics", "pols_multi_target_least_squares",
@@ -87,8 +87,10 @@ EXPORTS = [
     "pols_comm_world_size", "pols_comm_rank", "pols_comm_group_begin", "pols_comm_group_end", "pols_comm_allgather_rows",
     "pols_comm_gather_rows", "pols_least_squares_arrow", "pols_least_squares_statistics_arrow",
     "pols_multi_target_least_squares_arrow", "pols_recursive_least_squares_arrow", "pols_rolling_least_squares_arrow",
-    "pols_predict_arrow", "pols_least_squares_sharded", "pols_stream_probe",
+    "pols_predict_arrow", "pols_least_squares_sharded",
 ]
+# measurement aids (include/pols_mi355x_debug.h): not part of the reference interface
+DEBUG_EXPORTS = ["pols_timing_enable", "pols_timing_collect", "pols_last_kernel_name", "pols_stream_probe", "pols_stream_probe_ex"]
 POLS_COMM_ID_BYTES = 128
 
 
@@ -134,6 +136,7 @@ def lib() -> C.CDLL:
         L.pols_rolling_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(RollingParams), C.POINTER(Out)]
         L.pols_predict.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int64, C.c_void_p]
         L.pols_stream_probe.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
+        L.pols_stream_probe_ex.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int]
         L.pols_predict_policy.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.pols_multi_target_least_squares.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(C.c_void_p), C.c_int32,
                                                       C.POINTER(OlsParams), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]

@@ -185,7 +185,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
     else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
     else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : ieq(v, "k2w") ? 4 : 0;
-    else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : 0;
+    else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
     else return false;
@@ -1390,8 +1390,44 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     const bool wide = kf > K4_KMAX, xwide = kf > POLS_MAX_FEATURES;
     bool scan = max_rows > 4096 || wide;
     if (ctx->opt.rls_engine == 1 && !wide) scan = false;
-    if (ctx->opt.rls_engine == 2) scan = true;
-    if (scan) {
+    if (ctx->opt.rls_engine >= 2) scan = true;
+    // Up to 8 features: the row-parallel, read-once kernel (K3c, k3c_scan.hip) whatever the sequence lengths -- every access a
+    // 16-byte one down the row axis, so it needs 16-byte aligned columns / outputs (anything else: the chunk kernels below).
+    // POLS_RLS_ENGINE=seq|chunk go back to K3 / the lane-per-chunk K3s.
+    bool rowpar = !wide && ctx->opt.rls_engine != 1 && ctx->opt.rls_engine != 3 && aligned16(st.y) && (!st.coef || aligned16(st.coef)) &&
+                  (!st.pred || aligned16(st.pred)) && (!st.valid || (reinterpret_cast<uintptr_t>(st.valid) & 3) == 0);
+    for (int j = 0; j < kf && rowpar; ++j) rowpar = aligned16(st.x[j]);
+    if (rowpar) {
+        const int64_t N = b->n_rows, tile_rows = k3c_tile_rows(kf), n_tiles = (N + tile_rows - 1) / tile_rows;
+        const size_t b_status = round256(sizeof(unsigned long long) * (size_t)n_tiles), b_flags = round256((size_t)N + 4),
+                     b_rec = round256(sizeof(double) * K3C_NCP * (size_t)n_tiles), total = 256 + b_status + b_flags + 2 * b_rec;
+        void *d = nullptr;
+        if ((rc = ensure_scratch(ctx, 8, total, &d))) return rc;
+        char *base = static_cast<char *>(d);
+        auto &kc = ctx->k3c;
+        if (kc.ptr != d || kc.n_rows != N || kc.n_tiles != n_tiles) {     // new layout: nothing stale may look like a status word
+            POLS_HIP(hipMemsetAsync(base, 0, 256 + b_status, ctx->stream));
+            kc.ptr = d; kc.n_rows = N; kc.n_tiles = n_tiles; kc.ticket_base = 0; kc.flags_offs_id = 0; kc.flags_groups = -1;
+        }
+        uint8_t *flags = reinterpret_cast<uint8_t *>(base + 256 + b_status);
+        if (kc.flags_offs_id != ctx->offs_id || kc.flags_groups != b->n_groups) {
+            if ((rc = k3c_start_flags(ctx, d_offs, b->n_groups, N, flags))) return rc;
+            kc.flags_offs_id = ctx->offs_id; kc.flags_groups = b->n_groups;
+        }
+        K3cArgs c;
+        std::memset(&c, 0, sizeof(c));
+        c.y = st.y; c.valid = st.valid; c.start = flags;
+        for (int j = 0; j < kf; ++j) c.x[j] = st.x[j];
+        c.n_rows = N; c.coef = st.coef; c.pred = st.pred; c.mean0 = a.mean0;
+        c.ff = a.forgetting_factor; c.p0 = a.initial_state_covariance;
+        c.ticket = reinterpret_cast<unsigned long long *>(base);
+        c.status = reinterpret_cast<unsigned long long *>(base + 256);
+        c.agg = reinterpret_cast<double *>(base + 256 + b_status + b_flags);
+        c.pre = reinterpret_cast<double *>(base + 256 + b_status + b_flags + b_rec);
+        c.ticket_base = kc.ticket_base; c.epoch = ++kc.epoch; c.n_tiles = n_tiles; c.k = kf;
+        kc.ticket_base += (unsigned long long)n_tiles;
+        if ((rc = k3c_launch(ctx, b->dtype, c))) { kc.ptr = nullptr; return rc; }
+    } else if (scan) {
         const int k = kf;
         K4Args s4;
         std::memset(&s4, 0, sizeof(s4));

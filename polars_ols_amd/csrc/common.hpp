@@ -54,7 +54,7 @@ struct Options {
     int k1t_rc4 = -1;             // POLS_K1T_RC4        -1: default rule
     int k1t_sub8 = -1;            // POLS_K1T_SUB8       eight-lane K1t teams: -1 default rule (frames that fit 16 chunk slots), 0 never, 1 only frames that fit 8
     int static_engine = 0;        // POLS_STATIC_ENGINE  0 auto, 1 "stream" (three launches), 2 "k2" (wherever it fits), 3 "nok2"
-    int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq", 2 "scan"
+    int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq" (K3), 2 "scan" (K3c up to 8 features, else the chunk kernels), 3 "chunk" (lane-per-chunk K3s)
     int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
     int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1
@@ -78,7 +78,7 @@ struct pols_ctx {
     int num_cus = 0;
     // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] fix-up work area,
     // [4] staged targets / statistics of HOST batches, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean,
-    // [7] status words, [8] (free), [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
+    // [7] status words, [8] K3c look-back records + sequence-start bytes, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
     pols::Scratch scratch[16];
@@ -114,6 +114,11 @@ struct pols_ctx {
     // offsets, min_periods or the chunk length change
     struct { uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;
              const void *tab = nullptr; size_t b_groups = 0; } chunk_cache;
+    // K3c (k3c_scan.hip), scratch slot 8: [ticket][status words][sequence-start bytes][aggregate records][prefix records].  The ticket
+    // keeps counting across launches (tile = ticket - ticket_base) and a status word only counts with the launch's epoch, so nothing is
+    // cleared between launches on the same layout; the start bytes are rebuilt when other offsets arrive.
+    struct { const void *ptr = nullptr; int64_t n_rows = -1, n_tiles = -1, flags_groups = -1; unsigned long long ticket_base = 0, epoch = 0;
+             uint64_t flags_offs_id = 0; } k3c;
 };
 
 namespace pols {

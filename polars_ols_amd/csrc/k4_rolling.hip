@@ -18,11 +18,9 @@
 // variant (:737-787) propagates (X'X)^-1 instead of X'X: same mathematics, different rounding; it is not
 // reproduced -- `use_woodbury` is accepted and ignored.  All arithmetic is f64.
 #include "k4_rolling.hpp"
-#include "k1_kernel.inl"   // tri_index, chol_solve
+#include "k4_small.inl"   // K4N, solve_state (tri_index, chol_solve from k1_kernel.inl)
 
 namespace pols {
-
-template <int K> struct K4N { static constexpr int NX = K * (K + 1) / 2; static constexpr int N = NX + K; };
 
 template <typename T, int K>
 struct K4Ctx {
@@ -77,51 +75,6 @@ struct K4Ctx {
             if (valid(j)) add_row(P, j, sign);
     }
 };
-
-// Cholesky -> LU with partial pivoting (solve_normal_equations(.., None, Some(LU)), :732-734 / :277-337)
-template <int K>
-__device__ __noinline__ void lu_solve_small(const double *A, const double *b, double *x) {
-    double m[K][K], r[K];
-    for (int i = 0; i < K; ++i) { r[i] = b[i]; for (int j = 0; j < K; ++j) m[i][j] = A[i * K + j]; }
-    for (int j = 0; j < K; ++j) {
-        int p = j; double best = fabs(m[j][j]);
-        for (int i = j + 1; i < K; ++i) if (fabs(m[i][j]) > best) { best = fabs(m[i][j]); p = i; }
-        if (p != j) { for (int c = 0; c < K; ++c) { const double t = m[j][c]; m[j][c] = m[p][c]; m[p][c] = t; } const double t = r[j]; r[j] = r[p]; r[p] = t; }
-        const double d = m[j][j];
-        for (int i = j + 1; i < K; ++i) {
-            const double f = m[i][j] / d;
-            for (int c = j + 1; c < K; ++c) m[i][c] -= f * m[j][c];
-            r[i] -= f * r[j];
-        }
-    }
-    for (int i = K - 1; i >= 0; --i) {
-        double s = r[i];
-        for (int c = i + 1; c < K; ++c) s -= m[i][c] * x[c];
-        x[i] = s / m[i][i];
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void solve_state(const double (&S)[K4N<K>::N], double alpha, double (&beta)[K]) {
-    constexpr int NZ = K + 1;
-    double acc[(K + 1) * (K + 2) / 2];
-#pragma unroll
-    for (int p = 0; p < K; ++p) {
-#pragma unroll
-        for (int q = p; q < K; ++q) acc[tri_index<NZ>(p, q)] = S[tri_index<K>(p, q)];
-        acc[tri_index<NZ>(p, K)] = S[K4N<K>::NX + p];
-    }
-    acc[tri_index<NZ>(K, K)] = 0.0;
-    if (!chol_solve<double, K>(acc, alpha, beta)) {
-        double A[K * K], b[K], x[K];
-        for (int p = 0; p < K; ++p) {
-            for (int q = 0; q < K; ++q) A[p * K + q] = S[p <= q ? tri_index<K>(p, q) : tri_index<K>(q, p)] + (p == q ? alpha : 0.0);
-            b[p] = S[K4N<K>::NX + p];
-        }
-        lu_solve_small<K>(A, b, x);
-        for (int p = 0; p < K; ++p) beta[p] = x[p];
-    }
-}
 
 // P = A^-1 (packed upper, like S) from the packed SPD matrix in S[0 .. NX): Cholesky A = L L', M = L^-1 by forward substitution,
 // P = M' M.  false on a non-positive pivot.  Used once per chunk by the RLS walk, which then propagates P with the reference's

@@ -71,4 +71,30 @@ constexpr int K4Y_KMAX = 1024;
 // mode 0 plain (rolling), 1 / 2 decayed with the RLS prior as carry-in (packed / full K x K state), see k4_rolling.hip
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);
 
+// ---- K3c: row-parallel, read-once RLS for up to K4_KMAX features (k3c_scan.hip) ------------------------------------------------
+constexpr int K3C_NCP = 48;      // doubles per published tile record: k (k + 1) / 2 + k + 1 <= 45
+constexpr int K3C_R = 4;         // consecutive rows per lane
+constexpr int k3c_waves(int k) { return k <= 6 ? 4 : 2; }    // waves per tile (each parks R (k + 1) row values per lane in LDS)
+constexpr int64_t k3c_tile_rows(int k) { return (int64_t)K3C_R * 64 * k3c_waves(k); }
+struct K3cArgs {
+    const void *y;
+    const void *x[K4_KMAX];
+    const uint8_t *valid;              // validity bytes or nullptr = every row valid
+    const uint8_t *start;              // 1 on the first row of every sequence (k3c_start_flags)
+    int64_t n_rows;
+    void *coef, *pred;                 // n_rows x k / n_rows, batch dtype, 16-byte aligned; either may be nullptr
+    const double *mean0;               // device, k values, or nullptr
+    double ff, p0;
+    // decoupled look-back: one status word + two records (aggregate, inclusive prefix) per tile; nothing is ever cleared -- a
+    // status word counts only when it carries this launch's epoch, and tiles take their index from a ticket that keeps counting
+    unsigned long long *status;
+    double *agg, *pre;
+    unsigned long long *ticket;
+    unsigned long long ticket_base, epoch;
+    int64_t n_tiles;
+    int32_t k;
+};
+int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a);
+int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int64_t n_rows, uint8_t *start);
+
 }  // namespace pols

@@ -8,6 +8,7 @@
 // sum over the predictions column with streaming stores.  Same buffers, same frames, same launch timing as the kernel it is read beside.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstring>
 
 namespace pols {
@@ -54,9 +55,57 @@ __global__ void __launch_bounds__(256) stream_probe_kernel(const ProbeArgs a) {
     }
 }
 
+// mode 1: the same traffic as a PERSISTENT grid-stride stream -- no per-workgroup launch ramp or tail, the next piece's loads issued
+// before the current piece is stored (18 x 16-byte loads in flight per lane): what the memory system admits for this mix when nothing
+// else (dispatch, ramp, per-group arithmetic) is in the way.  Pieces of 256 x VEC rows, like K1's chunks.
+template <typename T>
+__global__ void __launch_bounds__(256) stream_probe_persistent_kernel(const ProbeArgs a, const int64_t n_pieces) {
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NL = 9;
+    T *out = static_cast<T *>(a.out);
+    const int nc = a.n_cols < NL ? a.n_cols : NL;            // (the probe's configs have at most 9 + 1 streams; extra columns: second pass)
+    int64_t piece = blockIdx.x;
+    V cur[NL], nxt[NL];
+    auto issue = [&](int64_t pc, V (&t)[NL]) {
+        const int64_t row0 = (pc * 256 + threadIdx.x) * VEC;
+#pragma unroll
+        for (int u = 0; u < NL; ++u)
+            if (u < nc) t[u] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.cols[u]) + row0));
+    };
+    if (piece < n_pieces) issue(piece, cur);
+    for (; piece < n_pieces; piece += gridDim.x) {
+        const int64_t np = piece + gridDim.x;
+        if (np < n_pieces) issue(np, nxt);
+        T s[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s[v] = T(0);
+#pragma unroll
+        for (int u = 0; u < NL; ++u)
+            if (u < nc) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s[v] += vget<T>(cur[u], v);
+            }
+        const int64_t row0 = (piece * 256 + threadIdx.x) * VEC;
+        for (int j = NL; j < a.n_cols; ++j) {                // streams beyond nine (weights at 8 features + target)
+            const V t = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.cols[j]) + row0));
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[v] += vget<T>(t, v);
+        }
+        V o;
+        if constexpr (VEC == 4) o = V{s[0], s[1], s[2], s[3]}; else o = V{s[0], s[1]};
+        store_stream(reinterpret_cast<V *>(out + row0), o);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) cur[u] = nxt[u];
+    }
+}
+
 }  // namespace pols
 
-extern "C" int pols_stream_probe(pols_ctx *ctx, const pols_batch *b, void *pred_out) {
+extern "C" int pols_stream_probe_ex(pols_ctx *ctx, const pols_batch *b, void *pred_out, int mode);
+extern "C" int pols_stream_probe(pols_ctx *ctx, const pols_batch *b, void *pred_out) { return pols_stream_probe_ex(ctx, b, pred_out, 0); }
+
+extern "C" int pols_stream_probe_ex(pols_ctx *ctx, const pols_batch *b, void *pred_out, int mode) {
     using namespace pols;
     if (!ctx) return fail(POLS_ERR_INVALID, "ctx is NULL");
     if (!b || !pred_out) return fail(POLS_ERR_INVALID, "batch / pred_out is NULL");
@@ -82,6 +131,19 @@ extern "C" int pols_stream_probe(pols_ctx *ctx, const pols_batch *b, void *pred_
     ctx->last_kernel = b->dtype == POLS_F32 ? "stream_probe_f32" : "stream_probe_f64";
     hipEvent_t ev0, ev1;
     const bool timed = timing_pair(ctx, &ev0, &ev1);
+    const int64_t full_pieces = b->n_rows / (256 * (int64_t)vec);
+    if (mode == 1 && full_pieces > 0 && full_pieces * 256 * vec == b->n_rows) {
+        ctx->last_kernel = b->dtype == POLS_F32 ? "stream_probe_persistent_f32" : "stream_probe_persistent_f64";
+        const unsigned grid = (unsigned)std::min<int64_t>(full_pieces, (int64_t)std::max(1, ctx->num_cus) * 4);
+        if (b->dtype == POLS_F32)
+            hipExtLaunchKernelGGL(stream_probe_persistent_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, timed ? ev0 : nullptr,
+                                  timed ? ev1 : nullptr, 0, a, full_pieces);
+        else
+            hipExtLaunchKernelGGL(stream_probe_persistent_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, timed ? ev0 : nullptr,
+                                  timed ? ev1 : nullptr, 0, a, full_pieces);
+        POLS_HIP(hipGetLastError());
+        return POLS_OK;
+    }
     if (b->dtype == POLS_F32) {
         if (timed) hipExtLaunchKernelGGL(stream_probe_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ev0, ev1, 0, a);
         else hipLaunchKernelGGL(stream_probe_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);

@@ -705,10 +705,11 @@ class Plan:
             L.check(rc)
         return self.results
 
-    def stream_probe(self) -> None:
-        """``pols_stream_probe`` on this plan's batch: every input column read, their sum written over the ``pred`` output -- the
-        bandwidth ceiling of the plan's traffic mix (a measurement aid; the predictions are garbage afterwards)."""
-        L.check(self._eng._lib.pols_stream_probe(self._eng._h, C.byref(self._b), C.c_void_p(Engine._ptr(self.results["pred"]))))
+    def stream_probe(self, mode: int = 0) -> None:
+        """``pols_stream_probe_ex`` on this plan's batch: every input column read, their sum written over the ``pred`` output -- the
+        bandwidth ceiling of the plan's traffic mix (a measurement aid; the predictions are garbage afterwards).  mode 0: the launch
+        shape of the resident static kernels; mode 1: a persistent grid-stride stream (include/pols_mi355x_debug.h)."""
+        L.check(self._eng._lib.pols_stream_probe_ex(self._eng._h, C.byref(self._b), C.c_void_p(Engine._ptr(self.results["pred"])), int(mode)))
 
 
 _default: Dict[int, Engine] = {}

@@ -26,6 +26,12 @@ def test_exports_every_declared_symbol(L):
     missing = sorted(s for s in declared if not hasattr(L, s))
     assert not missing, missing
     assert declared == set(_lib.EXPORTS)
+    # the measurement aids live in their own header: nothing of them is declared by the reference interface
+    dbg = (ROOT / "include" / "pols_mi355x_debug.h").read_text()
+    dbg_declared = set(re.findall(r"\b(pols_[a-z_0-9]+)\s*\(", dbg))
+    assert dbg_declared == set(_lib.DEBUG_EXPORTS)
+    assert not (dbg_declared & declared)
+    assert not [s for s in dbg_declared if not hasattr(L, s)]
 
 
 def test_header_cites_reference_interfaces():
