@@ -186,6 +186,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
     else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : ieq(v, "k2w") ? 4 : 0;
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : 0;
+    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
     else return false;
@@ -195,7 +196,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
-                                       "RLS_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8"};
+                                       "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);
@@ -1356,6 +1357,21 @@ static int upload_column_table(pols_ctx *ctx, const Staged &st, int k, K4Args *a
     return POLS_OK;
 }
 
+// Sequence-start bytes of the row-parallel dynamic kernels (scratch slot 16), cached per uploaded offsets.
+static int ensure_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int64_t n_rows, const uint8_t **flags) {
+    void *d = nullptr;
+    int rc = ensure_scratch(ctx, 16, round256((size_t)n_rows + 4), &d);
+    if (rc) return rc;
+    auto &fc = ctx->start_flags;
+    if (fc.ptr != d || fc.offs_id != ctx->offs_id || fc.n_groups != n_groups || fc.n_rows != n_rows) {
+        fc.ptr = nullptr;
+        if ((rc = k3c_start_flags(ctx, d_offs, n_groups, n_rows, static_cast<uint8_t *>(d)))) return rc;
+        fc.ptr = d; fc.offs_id = ctx->offs_id; fc.n_groups = n_groups; fc.n_rows = n_rows;
+    }
+    *flags = static_cast<const uint8_t *>(d);
+    return POLS_OK;
+}
+
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o) {
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
     const int64_t *d_offs = nullptr;
@@ -1399,21 +1415,22 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     for (int j = 0; j < kf && rowpar; ++j) rowpar = aligned16(st.x[j]);
     if (rowpar) {
         const int64_t N = b->n_rows, tile_rows = k3c_tile_rows(kf), n_tiles = (N + tile_rows - 1) / tile_rows;
-        const size_t b_status = round256(sizeof(unsigned long long) * (size_t)n_tiles), b_flags = round256((size_t)N + 4),
-                     b_rec = round256(sizeof(double) * K3C_NCP * (size_t)n_tiles), total = 256 + b_status + b_flags + 2 * b_rec;
+        const int64_t tstride = (n_tiles + 63) / 64 * 64, n_lgroups = (n_tiles + K3C_GT - 1) / K3C_GT, gstride = (n_lgroups + 63) / 64 * 64;
+        const int nc = kf * (kf + 1) / 2 + kf + 1;                          // granules per record
+        const size_t b_trec = round256((size_t)16 * (size_t)nc * (size_t)tstride), b_grec = round256((size_t)16 * (size_t)nc * (size_t)gstride),
+                     b_rec = b_trec + b_grec, b_arrive = round256(sizeof(unsigned long long) * (size_t)n_lgroups),
+                     total = 256 + b_arrive + b_rec;
+        if (b_rec >= ((size_t)1 << 31)) return fail(POLS_ERR_UNSUPPORTED, "rls: too many rows for one launch of the row-parallel kernel");
         void *d = nullptr;
         if ((rc = ensure_scratch(ctx, 8, total, &d))) return rc;
         char *base = static_cast<char *>(d);
         auto &kc = ctx->k3c;
-        if (kc.ptr != d || kc.n_rows != N || kc.n_tiles != n_tiles) {     // new layout: nothing stale may look like a status word
-            POLS_HIP(hipMemsetAsync(base, 0, 256 + b_status, ctx->stream));
-            kc.ptr = d; kc.n_rows = N; kc.n_tiles = n_tiles; kc.ticket_base = 0; kc.flags_offs_id = 0; kc.flags_groups = -1;
+        if (kc.ptr != d || kc.n_rows != N || kc.n_tiles != n_tiles || kc.kf != kf) {   // new layout: nothing stale may look like a valid granule
+            POLS_HIP(hipMemsetAsync(base, 0, 256 + b_arrive + b_rec, ctx->stream));
+            kc.ptr = d; kc.n_rows = N; kc.n_tiles = n_tiles; kc.kf = kf; kc.ticket_base = 0; kc.launches = 0;
         }
-        uint8_t *flags = reinterpret_cast<uint8_t *>(base + 256 + b_status);
-        if (kc.flags_offs_id != ctx->offs_id || kc.flags_groups != b->n_groups) {
-            if ((rc = k3c_start_flags(ctx, d_offs, b->n_groups, N, flags))) return rc;
-            kc.flags_offs_id = ctx->offs_id; kc.flags_groups = b->n_groups;
-        }
+        const uint8_t *flags = nullptr;
+        if ((rc = ensure_start_flags(ctx, d_offs, b->n_groups, N, &flags))) return rc;
         K3cArgs c;
         std::memset(&c, 0, sizeof(c));
         c.y = st.y; c.valid = st.valid; c.start = flags;
@@ -1421,12 +1438,17 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         c.n_rows = N; c.coef = st.coef; c.pred = st.pred; c.mean0 = a.mean0;
         c.ff = a.forgetting_factor; c.p0 = a.initial_state_covariance;
         c.ticket = reinterpret_cast<unsigned long long *>(base);
-        c.status = reinterpret_cast<unsigned long long *>(base + 256);
-        c.agg = reinterpret_cast<double *>(base + 256 + b_status + b_flags);
-        c.pre = reinterpret_cast<double *>(base + 256 + b_status + b_flags + b_rec);
+        c.arrive = reinterpret_cast<unsigned long long *>(base + 256); c.launch_no = kc.launches++;
+        c.rec = base + 256 + b_arrive; c.rec_bytes = (int64_t)b_rec; c.tstride = tstride; c.grec = (int64_t)b_trec; c.gstride = gstride;
         c.ticket_base = kc.ticket_base; c.epoch = ++kc.epoch; c.n_tiles = n_tiles; c.k = kf;
         kc.ticket_base += (unsigned long long)n_tiles;
+        if (ctx->opt.timeline) {
+            void *dbg = nullptr;
+            if ((rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)n_tiles, &dbg))) return rc;
+            c.dbg = static_cast<unsigned long long *>(dbg);
+        }
         if ((rc = k3c_launch(ctx, b->dtype, c))) { kc.ptr = nullptr; return rc; }
+        if (c.dbg && (rc = report_timeline(ctx, c.dbg, n_tiles, 6, "k3c_rls_lookback"))) return rc;
     } else if (scan) {
         const int k = kf;
         K4Args s4;
@@ -1565,6 +1587,24 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     const bool drop = p->null_policy == POLS_NULL_DROP || p->null_policy == POLS_NULL_DROP_ZERO ||
                       p->null_policy == POLS_NULL_DROP_Y_ZERO_X;                                // ls.rs:947-950
 
+    // Null-free frames, up to 8 features, min_periods <= window <= 512: the row-parallel tile kernel (K4c, k4c_rolling.hip) -- with
+    // every row valid the "drop" deque and the fixed window are the same sums.  POLS_ROLLING_ENGINE=chunk goes back to the
+    // lane-per-chunk kernel.
+    bool tiles = !wide && st.valid == nullptr && mp <= w && w <= K4C_MAX_WINDOW && ctx->opt.rolling_engine != 1 && aligned16(st.y) &&
+                 (!st.coef || aligned16(st.coef)) && (!st.pred || aligned16(st.pred));
+    for (int j = 0; j < k && tiles; ++j) tiles = aligned16(st.x[j]);
+    if (tiles) {
+        K4cArgs c;
+        std::memset(&c, 0, sizeof(c));
+        if ((rc = ensure_start_flags(ctx, d_offs, b->n_groups, b->n_rows, &c.start))) return rc;
+        c.y = st.y;
+        for (int j = 0; j < k; ++j) c.x[j] = st.x[j];
+        c.n_rows = b->n_rows; c.coef = st.coef; c.pred = st.pred;
+        c.window = w; c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
+        if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
+        if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+        return unstage_outputs(ctx, b, b->n_rows, k, o, st);
+    }
     K4Args a;
     std::memset(&a, 0, sizeof(a));
     const int64_t minc = k > 128 ? hbm_state_chunk(b->n_rows) : 64;

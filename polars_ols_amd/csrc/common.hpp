@@ -55,6 +55,7 @@ struct Options {
     int k1t_sub8 = -1;            // POLS_K1T_SUB8       eight-lane K1t teams: -1 default rule (frames that fit 16 chunk slots), 0 never, 1 only frames that fit 8
     int static_engine = 0;        // POLS_STATIC_ENGINE  0 auto, 1 "stream" (three launches), 2 "k2" (wherever it fits), 3 "nok2"
     int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq" (K3), 2 "scan" (K3c up to 8 features, else the chunk kernels), 3 "chunk" (lane-per-chunk K3s)
+    int rolling_engine = 0;       // POLS_ROLLING_ENGINE 0 auto (K4c tiles where they apply), 1 "chunk" (lane-per-chunk K4)
     int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
     int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1
@@ -81,7 +82,8 @@ struct pols_ctx {
     // [7] status words, [8] K3c look-back records + sequence-start bytes, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
-    pols::Scratch scratch[16];
+    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17..23] free
+    pols::Scratch scratch[24];
     pols::Options opt;
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
@@ -114,11 +116,13 @@ struct pols_ctx {
     // offsets, min_periods or the chunk length change
     struct { uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;
              const void *tab = nullptr; size_t b_groups = 0; } chunk_cache;
-    // K3c (k3c_scan.hip), scratch slot 8: [ticket][status words][sequence-start bytes][aggregate records][prefix records].  The ticket
+    // K3c (k3c_scan.hip), scratch slot 8: [ticket][group arrival counters][tile records | group records: tagged granules].  The ticket
     // keeps counting across launches (tile = ticket - ticket_base) and a status word only counts with the launch's epoch, so nothing is
     // cleared between launches on the same layout; the start bytes are rebuilt when other offsets arrive.
     struct { const void *ptr = nullptr; int64_t n_rows = -1, n_tiles = -1, flags_groups = -1; unsigned long long ticket_base = 0, epoch = 0;
-             uint64_t flags_offs_id = 0; } k3c;
+             int kf = 0; unsigned long long launches = 0; } k3c;
+    // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };
 
 namespace pols {

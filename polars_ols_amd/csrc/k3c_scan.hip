@@ -57,8 +57,6 @@ __device__ __forceinline__ void k3c_seg_scan(double &D, double (&Tv)[NT], const 
 #undef K3C_STEP
 }
 
-__device__ __forceinline__ double k3c_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void k3c_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <typename T, int R>
 __device__ __forceinline__ void k3c_load_run(const void *col, int64_t row0, double (&out)[R]) {
@@ -81,20 +79,22 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     static_assert(R == 4, "validity / start bytes travel as one 32-bit word per run");
     __shared__ double s_agg[WAVES][NT + 1];      // wave aggregates (slot NT: the decay)
     __shared__ int s_closed[WAVES];              // the aggregate starts at a sequence start inside the wave
-    __shared__ double s_carry[NT + 1];           // the tile's carry-in (look-back result)
     __shared__ double s_wfull[WAVES][NT + 1];    // carry-in of every wave
-    __shared__ double s_w[NT + 1];
+    __shared__ double s_win[NT + 1];             // look-back (last wave): a window's composite on its way to one component per lane
+    __shared__ double s_carry[NT + 1];           // the tile's carry-in
     __shared__ long long s_tile;
     // every lane parks its run here between A and D (its own words only: no synchronisation) -- the scan and the look-back then
     // run without R x (K + 1) row values in registers
     __shared__ T s_x[WAVES][R * (K + 1)][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#define K3C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     if (threadIdx.x == 0) s_tile = (long long)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
     __syncthreads();
     const int64_t t = s_tile;
     const int64_t N = a.n_rows;
     const int64_t row0 = ((t * WAVES + wv) * 64 + lane) * (int64_t)R;
     const double ff = a.ff, ip0 = 1.0 / a.p0;
+    K3C_STAMP(0);
 
     // ---- loads: R consecutive rows of every column, the validity and sequence-start bytes of the run
     double x[R][K], y[R];
@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     }
 
     __builtin_amdgcn_sched_barrier(0);
+    K3C_STAMP(1);
     // ---- B: segmented inclusive scan over the lanes
     const unsigned long long hmask = __ballot(head);
     const unsigned long long upto = hmask & (~0ull >> (63 - lane));          // heads at lanes <= lane
@@ -214,79 +215,141 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
         if (s_closed[w2]) { run = eq; wopen = false; }
         else run = (lane == NT) ? run * eD : fma(eD, run, eq);
     }
-    if (wv == WAVES - 1) {
-        // the tile's aggregate, published at once; then the look-back
-        double agg = run;
-        bool tclosed = !wopen;
-        {
-            const double eD = s_agg[wv][NT], eq = s_agg[wv][ql];
-            if (s_closed[wv]) { agg = eq; tclosed = true; }
-            else agg = (lane == NT) ? agg * eD : fma(eD, agg, eq);
+    K3C_STAMP(2);
+    // the tile's aggregate (every wave computes it: one component per lane, a handful of FMAs)
+    double agg = run;
+    bool tclosed = !wopen;
+    for (int w2 = wv; w2 < WAVES; ++w2) {
+        const double eD = s_agg[w2][NT], eq = s_agg[w2][ql];
+        if (s_closed[w2]) { agg = eq; tclosed = true; }
+        else agg = (lane == NT) ? agg * eD : fma(eD, agg, eq);
+    }
+    const bool is_prefix = tclosed || t == 0;       // the aggregate IS the inclusive prefix
+    // ---- the tile's carry-in: decoupled look-back over published records, two levels (tiles, groups of K3C_GT tiles).
+    // Records: one 16-byte granule {value, tag} per component, component-major (granule (q, i) at q * stride + i: a wave that reads 64
+    // consecutive records' component q moves 1 KiB), written by ONE write-through (sc1) store each and validated by its own
+    // tag = epoch << 3 | kind -- no flag, no ordering between the stores (MI355X_MICROARCH.md, hand-off granules; a reader that meets a
+    // mixture of kinds or an old epoch reads again).  kind 1: an aggregate; kind 2: an inclusive prefix (a look-back stops there).
+    //   tile record t    its aggregate -- kind 2 when a sequence starts inside the tile (nothing before it matters), else kind 1
+    //   group record g   written by the LAST tile of group g to publish (an arrival counter finds it): first the composite of the
+    //                    group's tile records (kind 1; kind 2 if one of them stops), then -- after its own look-back over the
+    //                    group records below -- the inclusive prefix through the group (kind 2)
+    // A tile's carry-in = [prefix through the group below] . [its own group's tiles below it]: at most K3C_GT - 1 + 1 records read
+    // (a single look-back over tile records reads up to every resident tile's record when all tiles of one long sequence publish
+    // at once: measured 114 KB of write-through traffic and 51 k cycles per tile).  Every wait is for a record whose writer holds a
+    // lower ticket, i.e. is already running.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rec, 0, (int)a.rec_bytes, 0x00020000);
+    using U4 = __attribute__((ext_vector_type(4))) unsigned;
+    auto publish = [&](double val, unsigned long long kind, int64_t area, int64_t stride, int64_t idx) {
+        if (lane <= NT) {
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(val), tg = (a.epoch << 3) | kind;
+            const U4 g = {(unsigned)vb, (unsigned)(vb >> 32), (unsigned)tg, (unsigned)(tg >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (int)(area + (lane * stride + idx) * 16), 0, /*sc1*/ 16);
         }
-        const bool is_prefix = tclosed || t == 0;   // the aggregate IS the inclusive prefix
-        if (lane <= NT) k3c_st(a.agg + t * NCP + lane, agg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-            __hip_atomic_store(a.status + t, (a.epoch << 3) | (is_prefix ? 4ull : 0ull) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double acc = (lane == NT) ? 1.0 : 0.0;    // composite of the tiles (base, t - 1], one component per lane
-        int64_t base = t - 1;
-        bool done = t == 0;
-#ifdef K3C_NO_LOOKBACK
-        done = true;
-#endif
-        while (!done) {
-            const int64_t p = base - 63 + lane;   // ascending with the lane
-            unsigned long long sw = 0;
-            if (p >= 0) {
-                sw = __hip_atomic_load(a.status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while ((sw >> 3) != a.epoch) {
-                    __builtin_amdgcn_s_sleep(2);
-                    sw = __hip_atomic_load(a.status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // window of up to 64 records first .. last (ascending with the lane, `last` on lane 63): afterwards lane 63 holds their composite
+    // from the nearest stop on (or of all of them); records below `first` count as the identity -- and as a stop when below_stops
+    auto window = [&](int64_t area, int64_t stride, int64_t first, int64_t last, bool below_stops, double &Dp, double (&Tp)[NT]) -> bool {
+        const int64_t p = last - 63 + lane;
+        Dp = 1.0;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) Tp[q] = 0.0;
+        bool stop = below_stops && p < first;
+        if (p >= first) {
+            const int voff = (int)(area + p * 16);
+            const int qstride = (int)(stride * 16);
+            for (;;) {
+                unsigned long long tag0 = 0;
+                bool same = true;
+#pragma unroll
+                for (int q = 0; q <= NT; ++q) {
+                    const U4 g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + q * qstride, 0, /*sc1*/ 16);
+                    const double val = __longlong_as_double((long long)(((unsigned long long)g[1] << 32) | g[0]));
+                    const unsigned long long tg = ((unsigned long long)g[3] << 32) | g[2];
+                    if (q == 0) tag0 = tg; else same = same && tg == tag0;
+                    if (q < NT) Tp[q] = val; else Dp = val;
                 }
+                if (same && (tag0 >> 3) == a.epoch) { stop = (tag0 & 7ull) == 2ull; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
-            // bit 0: the aggregate record is there; bit 2: it is the inclusive prefix too; bit 1: the prefix record is there
-            const bool stop = p < 0 || (sw & 6ull) != 0;
-            const unsigned long long m = __ballot(stop);
-            const int hd = m ? 63 - __clzll(m) : -1;
-            done = hd >= 0;
-            double Dp = 1.0, Tp[NT];
+        }
+        const unsigned long long m = __ballot(stop);
+        const int hd = m ? 63 - __clzll(m) : -1;
+        k3c_seg_scan<NT>(Dp, Tp, hd, lane);
+        return hd >= 0;
+    };
+    // lane 63's composite -> one component per lane (through this wave's LDS words)
+    auto spread = [&](double Dp, const double (&Tp)[NT]) -> double {
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 63) {
 #pragma unroll
-            for (int q = 0; q < NT; ++q) Tp[q] = 0.0;
-            if (p >= 0 && lane >= hd) {
-                const double *src = (((sw & 6ull) == 2ull) ? a.pre : a.agg) + p * NCP;
-#pragma unroll
-                for (int q = 0; q < NT; ++q) Tp[q] = k3c_ld(src + q);
-                Dp = k3c_ld(src + NT);
+            for (int q = 0; q < NT; ++q) s_win[q] = Tp[q];
+            s_win[NT] = Dp;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const double v = s_win[ql];
+        __builtin_amdgcn_wave_barrier();
+        return v;
+    };
+    auto compose = [&](double first, double second) -> double {   // first . second (first is the EARLIER rows), one component per lane
+        const double sD = k1p_readlane(second, NT);
+        return (lane == NT) ? first * second : fma(sD, first, second);
+    };
+    if (wv == WAVES - 1) {
+        constexpr int GT = K3C_GT;
+        publish(agg, is_prefix ? 2ull : 1ull, 0, a.tstride, t);
+        const int64_t g = t / GT, g0 = g * GT;
+        const int64_t size_g = (a.n_tiles - g0 < GT) ? a.n_tiles - g0 : GT;
+        unsigned arrived = 0;
+        if (lane == 0) arrived = (unsigned)(atomicAdd(a.arrive + g, 1ull) - a.launch_no * (unsigned long long)size_g);
+        arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+        double acc = (lane == NT) ? 1.0 : 0.0;     // the carry-in, one component per lane
+        bool stopped = false;
+        double Dp, Tp[NT];
+        if (t > g0) {                               // this group's tiles below this one
+            stopped = window(0, a.tstride, g0, t - 1, false, Dp, Tp);
+            acc = spread(Dp, Tp);
+        }
+        K3C_STAMP(3);
+        if (arrived == (unsigned)(size_g - 1)) {    // the group's last tile to publish: the group record
+            const bool gstop = window(0, a.tstride, g0, g0 + size_g - 1, false, Dp, Tp);
+            const double gq = spread(Dp, Tp);
+            const bool gprefix = gstop || g == 0;
+            publish(gq, gprefix ? 2ull : 1ull, a.grec, a.gstride, g);
+            if (!gprefix) {
+                double gacc = (lane == NT) ? 1.0 : 0.0;
+                int64_t gb = g - 1;
+                for (bool gdone = false; !gdone; gb -= 64) {
+                    gdone = window(a.grec, a.gstride, 0, gb, true, Dp, Tp);
+                    gacc = compose(spread(Dp, Tp), gacc);
+                }
+                publish(compose(gacc, gq), 2ull, a.grec, a.gstride, g);
             }
-            k3c_seg_scan<NT>(Dp, Tp, hd, lane);
-            if (lane == 63) {
-#pragma unroll
-                for (int q = 0; q < NT; ++q) s_w[q] = Tp[q];
-                s_w[NT] = Dp;
+        }
+        K3C_STAMP(4);
+        if (!stopped && g > 0) {                    // the prefix through the group below: one granule per lane
+            double gp = 0.0;
+            for (;;) {
+                unsigned long long tg = (a.epoch << 3) | 2ull;
+                if (lane <= NT) {
+                    const U4 gr = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(a.grec + (lane * a.gstride + (g - 1)) * 16), 0, /*sc1*/ 16);
+                    gp = __longlong_as_double((long long)(((unsigned long long)gr[1] << 32) | gr[0]));
+                    tg = ((unsigned long long)gr[3] << 32) | gr[2];
+                }
+                if (__all(tg == ((a.epoch << 3) | 2ull))) break;
+                __builtin_amdgcn_s_sleep(2);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const double wq = s_w[ql], wD = s_w[NT];
-            const double accD = k1p_readlane(acc, NT);
-            acc = (lane == NT) ? wD * acc : fma(accD, wq, acc);          // window . acc
-            __builtin_amdgcn_wave_barrier();
-            base -= 64;
+            acc = compose(gp, acc);
         }
         if (lane <= NT) s_carry[lane] = acc;
-        if (!is_prefix) {
-            const double aggD = k1p_readlane(agg, NT);
-            const double pre = (lane == NT) ? acc * agg : fma(aggD, acc, agg);  // carry-in . aggregate
-            if (lane <= NT) k3c_st(a.pre + t * NCP + lane, pre);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store(a.status + t, (a.epoch << 3) | 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        K3C_STAMP(5);
     }
     __syncthreads();
     {
-        const double runD = k1p_readlane(run, NT);
         const double cq = s_carry[ql];
+        const double runD = k1p_readlane(run, NT);
         const double full = wopen ? ((lane == NT) ? cq * run : fma(runD, cq, run)) : run;
         if (lane <= NT) s_wfull[wv][lane] = full;
     }
@@ -349,6 +412,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
                 }
         }
     }
+    K3C_STAMP(7);
+    if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.dbg[t * 8 + 6] = xcc;
+    }
+#undef K3C_STAMP
 }
 
 // sequence-start bytes from the group offsets: start[offs[g]] = 1 for every non-empty group (the caller zero-fills first)

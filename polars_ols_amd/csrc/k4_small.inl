@@ -65,8 +65,9 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // chol_solve's instructions at K = 6 -- keeping only L and 1 / d in registers.  (S + alpha I) beta = b with S packed upper, b = S[NX ..].
 // CLAMP: a non-positive pivot is replaced by eps x its diagonal entry (no LU, no call, no scratch) -- for callers whose matrix is
 // positive definite in exact arithmetic, where such a pivot is rounding noise.  Otherwise `ok` comes back false and beta is unusable.
-template <int K, bool CLAMP>
-__device__ __forceinline__ bool ldl_solve_small(const double (&S)[K4N<K>::N], double alpha, double (&beta)[K]) {
+template <int K, bool CLAMP, int LEN>
+__device__ __forceinline__ bool ldl_solve_small(const double (&S)[LEN], double alpha, double (&beta)[K]) {
+    static_assert(LEN >= K4N<K>::N, "packed upper triangle + right-hand side");
     double L[K][K], dinv[K], dd[K];
     bool ok = true;
 #pragma unroll

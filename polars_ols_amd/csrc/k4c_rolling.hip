@@ -1,0 +1,344 @@
+// k4c_rolling.hip -- K4c "rolling_window_tiles": rolling-window OLS for up to 8 features on null-free frames, ROW-PARALLEL, every
+// access a 16-byte one down the row axis, no cross-workgroup dependency.
+//
+// Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + the dynamic make_predictions (src/expressions.rs:184, 695-700) for
+// the frames where every row is valid (then the "drop" deque of :947-986 and the fixed window of :987-1029 are the same thing:
+// S_i = alpha I + sum of the last min(i + 1, window) rows' outer products, solved from row min_periods - 1 on) and
+// min_periods <= window <= 508.  Everything else -- validity masks, windows beyond the halo, the min_periods > window quirk --
+// stays with the lane-per-chunk kernels of k4_rolling.hip.
+//
+// Layout like K3c: the frame's rows [0, N), all sequences back to back, are cut into tiles of BW x 256 rows (BW body waves, a
+// lane owns 4 CONSECUTIVE rows); a sequence start resets the sums.  A window reaches at most `window` rows back, so a tile needs
+// nothing from its predecessors but their last HW x 256 > window rows: HW halo waves per workgroup re-read them (an L2 hit when
+// the neighbouring tile runs on the same XCD -- the tile -> workgroup map keeps consecutive tiles on one XCD), run the same
+// local sums and scan, and retire.  No look-back, no tickets, no inter-workgroup traffic.
+//   A  every lane sums its run: [x x' | x y] packed (NT values) + the row count since the last sequence start
+//   B  segmented inclusive scan (plain sums) over the lanes, wave totals through LDS: every run's EXCLUSIVE prefix -- the sums from
+//      the last sequence start (or the halo's first row) up to the run's first row -- goes to an LDS table, component-major
+//   D  body lanes: S before the run = E(own run) - E'(row i0 - window) when no sequence started within the last `window` rows, where
+//      E' is the table entry of the run holding that row plus the o = (-window) mod 4 rows in front of it; then per row
+//      S += entering row, S -= leaving row (the same add / subtract NonWoodburyState::update performs, :707-725), one K x K solve
+//      (L D L'; LU on a non-positive pivot, :732-734), coefficients and predictions stored 16 bytes at a time.
+// Bound: HBM, 8 (k + 1) bytes in + 8 (k + 1) bytes out per row (f64), plus the halo re-reads (1 / BW of the input).
+#include "k4_rolling.hpp"
+#include "k4_small.inl"
+
+namespace pols {
+
+template <int NC>
+__device__ __forceinline__ void k4c_seg_scan_add(double (&Tv)[NC], const int h, const int lane) {
+    // inclusive segmented prefix SUM over the lanes: a partner p < lane is added iff no segment starts in (p, lane], i.e. h <= p
+    const int li = lane & 15;
+    constexpr int CH = NC < 12 ? NC : 12;
+#define K4C_STEP(CTRL, RM, OK)                                                                                  \
+    {                                                                                                           \
+        const bool ok_ = (OK);                                                                                  \
+        _Pragma("unroll") for (int q0 = 0; q0 < NC; q0 += CH) {                                                 \
+            double tp[CH];                                                                                      \
+            _Pragma("unroll") for (int q = 0; q < CH; ++q) tp[q] = dpp_get<CTRL, RM>(Tv[q0 + q < NC ? q0 + q : NC - 1]); \
+            if (ok_) {                                                                                          \
+                _Pragma("unroll") for (int q = 0; q < CH; ++q)                                                  \
+                    if (q0 + q < NC) Tv[q0 + q] += tp[q];                                                       \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    K4C_STEP(0x111, 0xf, li >= 1 && h <= lane - 1)
+    K4C_STEP(0x112, 0xf, li >= 2 && h <= lane - 2)
+    K4C_STEP(0x114, 0xf, li >= 4 && h <= lane - 4)
+    K4C_STEP(0x118, 0xf, li >= 8 && h <= lane - 8)
+    K4C_STEP(0x142, 0xa, (lane & 16) && h <= (lane & ~15) - 1)
+    K4C_STEP(0x143, 0xc, lane >= 32 && h <= 31)
+#undef K4C_STEP
+}
+
+template <typename T, int K, int HW, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
+    constexpr int BW = WAVES - HW, R = 4, RUNS = WAVES * 64;
+    constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NC = NT + 1;   // slot NT: rows since the last sequence start (or the halo's first row)
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_E = reinterpret_cast<double *>(smem);              // [NC][RUNS]: exclusive prefix of every run
+    double *s_agg = s_E + (size_t)NC * RUNS;                     // [WAVES][NC]: wave totals (from the wave's last sequence start on)
+    int *s_closed = reinterpret_cast<int *>(s_agg + WAVES * NC); // [WAVES]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#define K4C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // consecutive tiles on one XCD (workgroup b runs on XCD b % 8): a tile's halo is its neighbour's body
+    const int64_t per_xcd = (a.n_tiles + 7) / 8;
+    const int64_t t = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= a.n_tiles) return;
+    const int64_t N = a.n_rows, w = a.window;
+    const int64_t hs = t * (BW * 256) - HW * 256;                // the halo's first row (may be negative)
+    const int u = wv * 64 + lane;                                // this lane's run
+    const int64_t i0 = hs + (int64_t)u * R;
+    const bool inside = i0 >= 0 && i0 + R <= N;
+    K4C_STAMP(0);
+
+    // ---- A: the run's rows (rows outside the frame: zeros, no sequence start)
+    double x[R][K], y[R];
+    unsigned sbits = 0;
+    if (__all(inside)) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + i0);
+#pragma unroll
+            for (int i = 0; i < R / VN; ++i) {
+                const V v = p[i];                        // (not a streaming load: the rows come back as LEAVING rows, from L2)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) x[i * VN + e][j] = (double)vget<T>(v, e);
+            }
+        }
+        const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.y) + i0);
+#pragma unroll
+        for (int i = 0; i < R / VN; ++i) {
+            const V v = p[i];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) y[i * VN + e] = (double)vget<T>(v, e);
+        }
+        sbits = *reinterpret_cast<const unsigned *>(a.start + i0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = i0 + r;
+            const bool in = i >= 0 && i < N;
+            const int64_t ic = in ? i : 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) x[r][j] = in ? (double)static_cast<const T *>(a.x[j])[ic] : 0.0;
+            y[r] = in ? (double)static_cast<const T *>(a.y)[ic] : 0.0;
+            if (in && a.start[ic]) sbits |= 1u << (8 * r);
+        }
+    }
+    bool st[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) st[r] = ((sbits >> (8 * r)) & 0xffu) != 0;
+    auto add_row = [&](double (&S)[NC], const double (&xr)[K], double yr, double sign) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+#pragma unroll
+            for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = fma(sign * xr[p], xr[q], S[tri_index<K>(p, q)]);
+            S[NX + p] = fma(sign * xr[p], yr, S[NX + p]);
+        }
+    };
+    auto reset_if = [&](double (&S)[NC], bool cond, bool any) {   // the sums start over at a sequence start
+        if (any) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) S[q] = cond ? 0.0 : S[q];
+        }
+    };
+    double Tl[NC];
+    bool head = false;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) Tl[q] = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        reset_if(Tl, st[r], __any(st[r]));
+        head = head || st[r];
+        add_row(Tl, x[r], y[r], 1.0);
+        Tl[NT] += 1.0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    K4C_STAMP(1);
+
+    // ---- B: segmented inclusive prefix over the lanes, then over the waves; the exclusive prefixes go to the LDS table
+    const unsigned long long hmask = __ballot(head);
+    const unsigned long long upto = hmask & (~0ull >> (63 - lane));
+    const int h = upto ? 63 - __clzll(upto) : -1;
+    k4c_seg_scan_add<NC>(Tl, h, lane);
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) s_agg[wv * NC + q] = Tl[q];
+        s_closed[wv] = hmask != 0;
+    }
+    double ET[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) ET[q] = dpp_get<0x138>(Tl[q]);                // wave_shr:1 -- the lane below's inclusive value
+    const bool eopen = (hmask & ((1ull << lane) - 1ull)) == 0;                // no sequence start in the lanes below
+    __syncthreads();
+    if (eopen) {                                                               // prepend the waves below, from their last sequence start
+#pragma unroll 1
+        for (int w2 = wv - 1; w2 >= 0; --w2) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) ET[q] += s_agg[w2 * NC + q];
+            if (s_closed[w2]) break;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) s_E[q * RUNS + u] = ET[q];
+    __syncthreads();
+    if (wv < HW) return;                                                       // halo waves are done
+    K4C_STAMP(2);
+
+    // ---- D: body lanes.  S before the run, then one add / subtract / solve per row.
+    const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
+    const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window: (-window) mod 4
+    const int up = u - sh;                                                     // >= 0: the halo covers `window` rows
+    const int64_t rho_run = hs + (int64_t)up * R;                              // first row of the run holding row i0 - window
+    // the LEAVING rows of this run (rows i0 - window .. + 3) and the o rows in front of them: every load issued here, before the
+    // table is read -- one L2 round trip per run instead of one per row on the walk's dependency chain
+    auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
+        const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
+#pragma unroll
+        for (int j = 0; j < K; ++j) xr[j] = (double)static_cast<const T *>(a.x[j])[ic];
+        yr = (double)static_cast<const T *>(a.y)[ic];
+    };
+    double xo[R][K], yo[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) load_row(rho_run + o + r, xo[r], yo[r]);
+    double S[NC];
+    const double cnt_excl = ET[NT];                                            // rows since the last sequence start, before this run
+    // (exact when a sequence starts inside the tile or its halo; otherwise the rows since the halo's first row: >= 256 HW >= window + o + 1)
+    // The part of the prefix E(own run) that lies before row i0 - window goes: the table entry of the run holding that row when the
+    // sequence started before that run, and the rows of that run in front of row i0 - window that the sequence reaches back to.
+    const bool use_ep = cnt_excl >= (double)(w + o + 1);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) S[q] = ET[q] - (use_ep ? s_E[q * RUNS + up] : 0.0);
+    double cnt = cnt_excl;
+    T *coef = static_cast<T *>(a.coef);
+    T *pred = static_cast<T *>(a.pred);
+    const T qnan = nan_if<T>(1u, T(0));
+#pragma unroll 1
+    for (int r = 0; r < o; ++r) {                                             // (window not a multiple of 4: up to 3 rows, one L2 round trip each)
+        const bool gone = cnt_excl >= (double)(w + o - r);                     // the sequence reaches back to row rho_run + r
+        if (__any(gone)) {
+            double xf[K], yf;
+            load_row(rho_run + r, xf, yf);
+            if (gone) add_row(S, xf, yf, -1.0);
+        }
+    }
+    K4C_STAMP(3);
+    const bool full = i0 + R <= N;
+    double beta[K];
+    // outputs leave FL rows at a time: the fewest rows whose K coefficients are a whole number of 16-byte vectors (f64, even K: every row)
+    constexpr int FL = (K * (int)sizeof(T)) % 16 == 0 ? 1 : ((2 * K * (int)sizeof(T)) % 16 == 0 ? 2 : 4);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += FL) {
+        T cbuf[FL * K], pbuf[FL];
+#pragma unroll
+        for (int rr = 0; rr < FL; ++rr) {
+            const int r = r0 + rr;
+            __builtin_amdgcn_sched_barrier(0);
+            if (__any(st[r])) {
+#pragma unroll
+                for (int q = 0; q < NC; ++q) S[q] = st[r] ? 0.0 : S[q];
+                cnt = st[r] ? 0.0 : cnt;
+            }
+            add_row(S, x[r], y[r], 1.0);
+            cnt += 1.0;
+            const bool sub = cnt >= (double)(w + 1);                           // the window is full: row i - window leaves
+            if (__any(sub)) {
+                if (sub) add_row(S, xo[r], yo[r], -1.0);
+                cnt = sub ? (double)w : cnt;                                   // (rows in the window)
+            }
+#ifdef K4C_NOLU
+            bool ok = ldl_solve_small<K, true>(S, a.alpha, beta);
+#else
+            bool ok = ldl_solve_small<K, false>(S, a.alpha, beta);
+#endif
+            if (!ok) {                                                         // Cholesky failed: LU like the reference (:732-734)
+                double A[K * K], b[K], xs[K];
+                for (int p = 0; p < K; ++p) {
+                    for (int q = 0; q < K; ++q) A[p * K + q] = S[p <= q ? tri_index<K>(p, q) : tri_index<K>(q, p)] + (p == q ? a.alpha : 0.0);
+                    b[p] = S[NX + p];
+                }
+                lu_solve_small<K>(A, b, xs);
+                for (int p = 0; p < K; ++p) beta[p] = xs[p];
+            }
+            const bool warm = cnt >= (double)a.min_periods || sub;             // row min_periods - 1 of the sequence and later
+            double pr = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                cbuf[rr * K + j] = warm ? (T)beta[j] : qnan;
+                pr = fma(x[r][j], beta[j], pr);
+            }
+            pbuf[rr] = warm ? (T)pr : qnan;
+        }
+        // (no load may follow these stores inside the walk: on gfx9 a load's s_waitcnt vmcnt also waits for every store before it)
+        if (full) {
+            if (coef) {
+                V *dst = reinterpret_cast<V *>(coef + (i0 + r0) * K);
+#pragma unroll
+                for (int i = 0; i < FL * K / VN; ++i) {
+                    V ov;
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) vset<T>(ov, e, cbuf[i * VN + e]);
+                    store_stream(dst + i, ov);
+                }
+            }
+            if (pred) {
+#pragma unroll
+                for (int rr = 0; rr < FL; ++rr) __builtin_nontemporal_store(pbuf[rr], pred + i0 + r0 + rr);
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < FL; ++rr)
+                if (i0 + r0 + rr < N) {
+                    if (coef)
+#pragma unroll
+                        for (int j = 0; j < K; ++j) coef[(i0 + r0 + rr) * K + j] = cbuf[rr * K + j];
+                    if (pred) pred[i0 + r0 + rr] = pbuf[rr];
+                }
+        }
+    }
+    K4C_STAMP(4);
+    K4C_STAMP(5);
+    if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + 6] = 0;
+#undef K4C_STAMP
+}
+
+template <typename T, int K, int HW>
+static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
+    constexpr int NC = K4N<K>::N + 1;
+    constexpr int WAVES = K <= 7 ? 8 : 6;                        // the prefix table is NC x 64 WAVES doubles of LDS (K = 8: 135 KiB at 6 waves)
+    K4cArgs a = a0;
+    const int64_t tile_rows = (int64_t)(WAVES - HW) * 256;
+    a.n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
+    const int64_t per_xcd = (a.n_tiles + 7) / 8;
+    const size_t lds = sizeof(double) * ((size_t)NC * 64 * WAVES + WAVES * NC) + 64;
+    static OncePerDevice attr_once;
+    if (attr_once.needed(ctx->device)) {
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k4c_kernel<T, K, HW, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_once.done(ctx->device);
+    }
+    if (ctx->opt.timeline) {
+        void *dbg = nullptr;
+        int rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)a.n_tiles, &dbg);
+        if (rc) return rc;
+        a.dbg = static_cast<unsigned long long *>(dbg);
+    }
+    hipEvent_t e0, e1;
+    const bool timed = timing_pair(ctx, &e0, &e1);
+    hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
+                          timed ? e1 : nullptr, 0, a);
+    POLS_HIP(hipGetLastError());
+    if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k4c_rolling_tiles");
+    return POLS_OK;
+}
+
+template <typename T, int K>
+static int k4c_launch_k(pols_ctx *ctx, const K4cArgs &a) {
+    return a.window <= 252 ? k4c_launch_h<T, K, 1>(ctx, a) : k4c_launch_h<T, K, 2>(ctx, a);   // 256 HW >= 4 ceil(window / 4) + 1
+}
+
+template <typename T>
+static int k4c_launch_t(pols_ctx *ctx, const K4cArgs &a) {
+    switch (a.k) {
+        case 1: return k4c_launch_k<T, 1>(ctx, a);
+        case 2: return k4c_launch_k<T, 2>(ctx, a);
+        case 3: return k4c_launch_k<T, 3>(ctx, a);
+        case 4: return k4c_launch_k<T, 4>(ctx, a);
+        case 5: return k4c_launch_k<T, 5>(ctx, a);
+        case 6: return k4c_launch_k<T, 6>(ctx, a);
+        case 7: return k4c_launch_k<T, 7>(ctx, a);
+        case 8: return k4c_launch_k<T, 8>(ctx, a);
+        default: return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): %d features > %d", a.k, K4_KMAX);
+    }
+}
+
+int k4c_launch(pols_ctx *ctx, int dtype, const K4cArgs &a) {
+    if (a.window < 1 || a.window > K4C_MAX_WINDOW || a.min_periods < 1 || a.min_periods > a.window)
+        return fail(POLS_ERR_INVALID, "k4c: window %lld / min_periods %lld outside the row-parallel kernel's range", (long long)a.window, (long long)a.min_periods);
+    ctx->last_kernel = dtype == POLS_F32 ? "k4_rolling_tiles_f32" : "k4_rolling_tiles_f64";
+    return dtype == POLS_F32 ? k4c_launch_t<float>(ctx, a) : k4c_launch_t<double>(ctx, a);
+}
+
+}  // namespace pols

@@ -104,7 +104,7 @@ def test_statistics_struct(eng, dtype, tol, k, weights, icpt, alpha, policy):
             assert np.isclose(row[key], ref[key], rtol=tol, atol=tol), (g, key)
         assert np.allclose(row["coefficients"], ref["coefficients"], rtol=tol, atol=tol)
         for key in ("standard_errors", "t_values", "p_values"):
-            assert np.allclose(row[key], ref[key], rtol=10 * tol, atol=tol), (g, key)
+            assert np.allclose(row[key], ref[key], rtol=tol, atol=tol), (g, key)
 
 
 def test_statistics_bad_dof_panics(eng):

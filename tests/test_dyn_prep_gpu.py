@@ -97,7 +97,7 @@ def test_rls_raw_columns_vs_oracle(eng, dtype, tol, policy, weights, icpt):
         c, p = _run(eng, "rls", y, cols, offs, w, icpt, policy, device, **kw)
         assert c.shape == coef.shape
         assert _close(c, coef, tol), float(np.nanmax(np.abs(c - coef)))
-        assert _close(p, pred, tol * 10 if weights else tol), float(np.nanmax(np.abs(p - pred)))
+        assert _close(p, pred, tol), float(np.nanmax(np.abs(p - pred)))
         assert np.array_equal(np.isnan(p), np.isnan(pred))
 
 
@@ -114,7 +114,7 @@ def test_rolling_raw_columns_vs_oracle(eng, dtype, tol, policy, weights, icpt):
         assert c.shape == coef.shape
         assert np.array_equal(np.isnan(c), np.isnan(coef))
         assert _close(c, coef, tol), float(np.nanmax(np.abs(c - coef)))
-        assert _close(p, pred, tol * 10), float(np.nanmax(np.abs(p - pred)))
+        assert _close(p, pred, tol), float(np.nanmax(np.abs(p - pred)))
 
 
 @pytest.mark.parametrize("kind,kw", [("rls", dict(half_life=None, initial_state_covariance=100.0)),

@@ -77,6 +77,9 @@ def test_rolling_many_groups(eng, policy, k, window, min_periods, alpha, null_fr
     vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
     assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
     assert window < k + 2 or strict.sum() > 0.5 * sane.sum()
+    well = sane & (nobs >= 2 * k)                                    # north_star's 1e-6 wherever the window holds 2k observations
+    assert np.allclose(got_c[well], ref["coef"][well], rtol=1e-6, atol=1e-6), float(np.abs(got_c[well] - ref["coef"][well]).max())
+    assert np.allclose(got_p[well & vm], ref["pred"][well & vm], rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("policy", ["drop", "drop_window"])
@@ -107,6 +110,8 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
     strict = sane & (nobs >= k + 4)
     assert strict.sum() > 0.3 * sane.sum()
     assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
+    well = sane & (nobs >= 2 * k)
+    assert np.allclose(got_c[well], ref["coef"][well], rtol=1e-6, atol=1e-6), float(np.abs(got_c[well] - ref["coef"][well]).max())
     vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
     assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
 
@@ -136,7 +141,7 @@ def test_rolling_inverse_propagation_33_features_and_up(eng, policy, k, window, 
     sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
     strict = sane & (nobs >= 2 * k)                                  # well-conditioned windows
     assert strict.sum() > 0.2 * sane.sum()
-    assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
+    assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-6, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
     vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
     assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
 
@@ -258,3 +263,59 @@ def test_rolling_min_periods_beyond_the_window(eng, policy, k, window, min_perio
     assert np.allclose(got_c[sane], ref["coef"][sane], rtol=tol, atol=tol), float(np.abs(got_c[sane] - ref["coef"][sane]).max())
     vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)
     assert np.allclose(got_p[sane & vm], ref["pred"][sane & vm], rtol=tol, atol=tol) and np.isnan(got_p[~vm]).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,window,min_periods,alpha", [
+    (1, 1, 1, None), (2, 2, None, None), (3, 3, 3, 0.1), (6, 7, 6, None), (4, 63, 4, None), (6, 64, 10, None), (5, 250, None, None),
+    (6, 251, 6, None), (6, 252, 6, None), (6, 253, 6, None), (3, 255, 3, 1.0), (6, 256, 6, None), (8, 300, 8, None), (7, 507, 20, None),
+    (2, 508, 2, None),
+])
+def test_rolling_tiles_null_free(eng, dtype, tol, k, window, min_periods, alpha):
+    """K4c (k4c_rolling.hip): null-free frames, every window offset modulo the 4-row runs, the one- / two-halo-wave boundary (252 / 253),
+    sequences shorter than min_periods, sequences that start on run / wave / tile boundaries, empty groups."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 7919 + window)
+    sizes = np.concatenate([[5000, 0, 1, 2, 3, 1792 - 6, 4, 256, 1536, 7, 0, 2600], rng.integers(1, 900, size=15), [3584, 5, 1]])
+    y, cols, offs, _ = _frame(rng, sizes, k, dtype=dtype)
+    for policy in ("drop", "drop_window"):
+        out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, window_size=window, min_periods=min_periods, alpha=alpha,
+                                        null_policy=policy, null_free=True)
+        assert eng.last_kernel.startswith("k4_rolling_tiles")
+        ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy)
+        got_c, got_p = _np(out["coef"]), _np(out["pred"])
+        assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
+        assert np.array_equal(np.isnan(got_p), np.isnan(ref["pred"]))
+        nobs = _window_obs(offs, None, window, policy)
+        sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+        well = sane & ((nobs >= 2 * k) | (alpha is not None))
+        assert well.sum() > 0.5 * sane.sum() or window < 2 * k
+        assert np.allclose(got_c[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(got_c[well] - ref["coef"][well]).max())
+        assert np.allclose(got_p[well], ref["pred"][well], rtol=tol, atol=tol)
+
+
+def test_rolling_many_sequences_full_size(eng):
+    """bench.py --config rlsgr: 10 000 sequences x 1 000 rows x 6 features, window 252, f64 -- sampled sequences against the oracle."""
+    from oracle import orc
+    import torch
+
+    G, n, k = 10_000, 1_000, 6
+    gen = torch.Generator(device="cuda").manual_seed(78)
+    cols = [torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64) for _ in range(k)]
+    y = sum(cols) + 0.1 * torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64)
+    offs = np.arange(G + 1, dtype=np.int64) * n
+    out = eng.rolling_least_squares(y, cols, offs, window_size=252, min_periods=6, null_policy="drop", null_free=True)
+    assert eng.last_kernel.startswith("k4_rolling_tiles")
+    coef, pred = out["coef"], out["pred"]
+    rng = np.random.default_rng(6)
+    pick = np.unique(np.concatenate([[0, 1, 2, G - 1], rng.integers(0, G, size=40)]))
+    for g in pick:
+        s, e = int(offs[g]), int(offs[g + 1])
+        ref = orc.batched_rolling(_np(y[s:e]), [_np(c[s:e]) for c in cols], [0, n], 252, min_periods=6, null_policy="drop")
+        c, p = _np(coef[s:e]), _np(pred[s:e])
+        assert np.array_equal(np.isnan(c), np.isnan(ref["coef"]))
+        sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+        sane[:2 * k] = False
+        assert np.allclose(c[sane], ref["coef"][sane], rtol=1e-6, atol=1e-6), g
+        assert np.allclose(p[sane], ref["pred"][sane], rtol=1e-6, atol=1e-6), g
