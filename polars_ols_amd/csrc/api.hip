@@ -1415,20 +1415,10 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     for (int j = 0; j < kf && rowpar; ++j) rowpar = aligned16(st.x[j]);
     if (rowpar) {
         const int64_t N = b->n_rows, tile_rows = k3c_tile_rows(kf), n_tiles = (N + tile_rows - 1) / tile_rows;
-        const int64_t tstride = (n_tiles + 63) / 64 * 64, n_lgroups = (n_tiles + K3C_GT - 1) / K3C_GT, gstride = (n_lgroups + 63) / 64 * 64;
-        const int nc = kf * (kf + 1) / 2 + kf + 1;                          // granules per record
-        const size_t b_trec = round256((size_t)16 * (size_t)nc * (size_t)tstride), b_grec = round256((size_t)16 * (size_t)nc * (size_t)gstride),
-                     b_rec = b_trec + b_grec, b_arrive = round256(sizeof(unsigned long long) * (size_t)n_lgroups),
-                     total = 256 + b_arrive + b_rec;
-        if (b_rec >= ((size_t)1 << 31)) return fail(POLS_ERR_UNSUPPORTED, "rls: too many rows for one launch of the row-parallel kernel");
+        const size_t b_rec = round256(sizeof(double) * K3C_NCP * (size_t)n_tiles), b_closed = round256(sizeof(int32_t) * (size_t)n_tiles);
         void *d = nullptr;
-        if ((rc = ensure_scratch(ctx, 8, total, &d))) return rc;
+        if ((rc = ensure_scratch(ctx, 8, 2 * b_rec + b_closed, &d))) return rc;
         char *base = static_cast<char *>(d);
-        auto &kc = ctx->k3c;
-        if (kc.ptr != d || kc.n_rows != N || kc.n_tiles != n_tiles || kc.kf != kf) {   // new layout: nothing stale may look like a valid granule
-            POLS_HIP(hipMemsetAsync(base, 0, 256 + b_arrive + b_rec, ctx->stream));
-            kc.ptr = d; kc.n_rows = N; kc.n_tiles = n_tiles; kc.kf = kf; kc.ticket_base = 0; kc.launches = 0;
-        }
         const uint8_t *flags = nullptr;
         if ((rc = ensure_start_flags(ctx, d_offs, b->n_groups, N, &flags))) return rc;
         K3cArgs c;
@@ -1437,18 +1427,10 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         for (int j = 0; j < kf; ++j) c.x[j] = st.x[j];
         c.n_rows = N; c.coef = st.coef; c.pred = st.pred; c.mean0 = a.mean0;
         c.ff = a.forgetting_factor; c.p0 = a.initial_state_covariance;
-        c.ticket = reinterpret_cast<unsigned long long *>(base);
-        c.arrive = reinterpret_cast<unsigned long long *>(base + 256); c.launch_no = kc.launches++;
-        c.rec = base + 256 + b_arrive; c.rec_bytes = (int64_t)b_rec; c.tstride = tstride; c.grec = (int64_t)b_trec; c.gstride = gstride;
-        c.ticket_base = kc.ticket_base; c.epoch = ++kc.epoch; c.n_tiles = n_tiles; c.k = kf;
-        kc.ticket_base += (unsigned long long)n_tiles;
-        if (ctx->opt.timeline) {
-            void *dbg = nullptr;
-            if ((rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)n_tiles, &dbg))) return rc;
-            c.dbg = static_cast<unsigned long long *>(dbg);
-        }
-        if ((rc = k3c_launch(ctx, b->dtype, c))) { kc.ptr = nullptr; return rc; }
-        if (c.dbg && (rc = report_timeline(ctx, c.dbg, n_tiles, 6, "k3c_rls_lookback"))) return rc;
+        c.rec = reinterpret_cast<double *>(base); c.carry = reinterpret_cast<double *>(base + b_rec);
+        c.rec_closed = reinterpret_cast<int32_t *>(base + 2 * b_rec);
+        c.n_tiles = n_tiles; c.k = kf;
+        if ((rc = k3c_launch(ctx, b->dtype, c))) return rc;
     } else if (scan) {
         const int k = kf;
         K4Args s4;
@@ -1587,10 +1569,10 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     const bool drop = p->null_policy == POLS_NULL_DROP || p->null_policy == POLS_NULL_DROP_ZERO ||
                       p->null_policy == POLS_NULL_DROP_Y_ZERO_X;                                // ls.rs:947-950
 
-    // Null-free frames, up to 8 features, min_periods <= window <= 512: the row-parallel tile kernel (K4c, k4c_rolling.hip) -- with
+    // Null-free frames, up to 6 features, min_periods <= window <= 508: the row-parallel tile kernel (K4c, k4c_rolling.hip) -- with
     // every row valid the "drop" deque and the fixed window are the same sums.  POLS_ROLLING_ENGINE=chunk goes back to the
     // lane-per-chunk kernel.
-    bool tiles = !wide && st.valid == nullptr && mp <= w && w <= K4C_MAX_WINDOW && ctx->opt.rolling_engine != 1 && aligned16(st.y) &&
+    bool tiles = k <= K4C_KMAX && st.valid == nullptr && mp <= w && w <= K4C_MAX_WINDOW && ctx->opt.rolling_engine != 1 && aligned16(st.y) &&
                  (!st.coef || aligned16(st.coef)) && (!st.pred || aligned16(st.pred));
     for (int j = 0; j < k && tiles; ++j) tiles = aligned16(st.x[j]);
     if (tiles) {

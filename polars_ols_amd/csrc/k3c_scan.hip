@@ -15,9 +15,13 @@
 //   A  every lane composes its run                                    (R x 2 NT flops, registers)
 //   B  segmented inclusive scan over the 64 lanes                      (6 DPP steps x (NT + 1) components; a lane only combines
 //      with a partner in its own sequence -- exec-masked, so nothing ever crosses a sequence boundary, not even a NaN)
-//   C  wave aggregates meet in LDS; the tile's aggregate is PUBLISHED (write-through stores + flag) and the tile's carry-in is
-//      found by DECOUPLED LOOK-BACK over the preceding tiles' aggregates / inclusive prefixes (Merrill & Garland): tiles take
-//      their index from an atomic ticket, so every predecessor a tile waits for is already running
+//   C  wave aggregates meet in LDS -> the tile's aggregate.  The tiles' carry-ins come from a scan over the tile aggregates, which
+//      is a launch of its own: pass 1 (this kernel, MODE 0) stops here and writes one record per tile, pass 2 (k3c_tile_scan_kernel,
+//      one workgroup) turns the records into every tile's carry-in, pass 3 (this kernel again, MODE 1) repeats A-B from the same
+//      rows (their second read: the Infinity Cache holds what pass 1 streamed) and goes on to D.  A single-launch form with a
+//      decoupled look-back over published records (round 4: tickets, tagged write-through granules, two levels) measured 125 us on
+//      the 1M-row sequence against 55 for the three launches: every tile of a long sequence waits for the slowest of the tiles
+//      running beside it, and a workgroup that waits holds half a CU.
 //   D  every lane walks its R rows from its carry-in: A' = ff A + x x', one K x K solve per row (square-root-free L D L', LU on
 //      a non-positive pivot like the reference's Cholesky -> LU chain), coefficients and predictions stored 16 bytes at a time.
 // The information matrix is solved directly on every row -- never inverted and propagated -- so a diffuse prior (p0 = 1e6, the
@@ -25,6 +29,7 @@
 // Bound: HBM, 8 (k + 1) bytes in + 8 (k + 1) bytes out per row (coefficients + predictions, f64).
 #include "k4_rolling.hpp"
 #include "k4_small.inl"
+#include "dyn_out.inl"
 
 namespace pols {
 
@@ -72,7 +77,7 @@ __device__ __forceinline__ void k3c_load_run(const void *col, int64_t row0, doub
     }
 }
 
-template <typename T, int K, int R, int WAVES>
+template <typename T, int K, int R, int WAVES, int MODE>
 __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NCP = K3C_NCP;
     static_assert(NT + 1 <= NCP && NT + 1 <= 64, "one component per lane in the cross-wave steps");
@@ -80,17 +85,12 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     __shared__ double s_agg[WAVES][NT + 1];      // wave aggregates (slot NT: the decay)
     __shared__ int s_closed[WAVES];              // the aggregate starts at a sequence start inside the wave
     __shared__ double s_wfull[WAVES][NT + 1];    // carry-in of every wave
-    __shared__ double s_win[NT + 1];             // look-back (last wave): a window's composite on its way to one component per lane
-    __shared__ double s_carry[NT + 1];           // the tile's carry-in
-    __shared__ long long s_tile;
     // every lane parks its run here between A and D (its own words only: no synchronisation) -- the scan and the look-back then
     // run without R x (K + 1) row values in registers
-    __shared__ T s_x[WAVES][R * (K + 1)][64];
+    __shared__ T s_x[MODE == 1 ? WAVES : 1][R * (K + 1)][DYN_STAGE_STRIDE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #define K3C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    if (threadIdx.x == 0) s_tile = (long long)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
-    __syncthreads();
-    const int64_t t = s_tile;
+    const int64_t t = blockIdx.x;
     const int64_t N = a.n_rows;
     const int64_t row0 = ((t * WAVES + wv) * 64 + lane) * (int64_t)R;
     const double ff = a.ff, ip0 = 1.0 / a.p0;
@@ -180,9 +180,11 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
         head = head || st[r];
         Dl = (st[r] ? 1.0 : Dl) * ffr[r];
         add_row(Tl, x[r], y[r], ffr[r]);
+        if constexpr (MODE == 1) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) s_x[wv][r * (K + 1) + j][lane] = (T)x[r][j];
-        s_x[wv][r * (K + 1) + K][lane] = (T)y[r];
+            for (int j = 0; j < K; ++j) s_x[wv][r * (K + 1) + j][lane] = (T)x[r][j];
+            s_x[wv][r * (K + 1) + K][lane] = (T)y[r];
+        }
     }
 
     __builtin_amdgcn_sched_barrier(0);
@@ -216,209 +218,132 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
         else run = (lane == NT) ? run * eD : fma(eD, run, eq);
     }
     K3C_STAMP(2);
-    // the tile's aggregate (every wave computes it: one component per lane, a handful of FMAs)
-    double agg = run;
-    bool tclosed = !wopen;
-    for (int w2 = wv; w2 < WAVES; ++w2) {
-        const double eD = s_agg[w2][NT], eq = s_agg[w2][ql];
-        if (s_closed[w2]) { agg = eq; tclosed = true; }
-        else agg = (lane == NT) ? agg * eD : fma(eD, agg, eq);
+    if constexpr (MODE == 0) {
+        // pass 1: the tile's record -- its aggregate from the last sequence start inside it on, and whether there is one
+        if (wv == WAVES - 1) {
+            double agg = run;
+            bool tclosed = !wopen;
+            const double eD = s_agg[wv][NT], eq = s_agg[wv][ql];
+            if (s_closed[wv]) { agg = eq; tclosed = true; }
+            else agg = (lane == NT) ? agg * eD : fma(eD, agg, eq);
+            if (lane <= NT) a.rec[t * K3C_NCP + lane] = agg;
+            if (lane == 0) a.rec_closed[t] = tclosed ? 1 : 0;
+        }
+        return;
     }
-    const bool is_prefix = tclosed || t == 0;       // the aggregate IS the inclusive prefix
-    // ---- the tile's carry-in: decoupled look-back over published records, two levels (tiles, groups of K3C_GT tiles).
-    // Records: one 16-byte granule {value, tag} per component, component-major (granule (q, i) at q * stride + i: a wave that reads 64
-    // consecutive records' component q moves 1 KiB), written by ONE write-through (sc1) store each and validated by its own
-    // tag = epoch << 3 | kind -- no flag, no ordering between the stores (MI355X_MICROARCH.md, hand-off granules; a reader that meets a
-    // mixture of kinds or an old epoch reads again).  kind 1: an aggregate; kind 2: an inclusive prefix (a look-back stops there).
-    //   tile record t    its aggregate -- kind 2 when a sequence starts inside the tile (nothing before it matters), else kind 1
-    //   group record g   written by the LAST tile of group g to publish (an arrival counter finds it): first the composite of the
-    //                    group's tile records (kind 1; kind 2 if one of them stops), then -- after its own look-back over the
-    //                    group records below -- the inclusive prefix through the group (kind 2)
-    // A tile's carry-in = [prefix through the group below] . [its own group's tiles below it]: at most K3C_GT - 1 + 1 records read
-    // (a single look-back over tile records reads up to every resident tile's record when all tiles of one long sequence publish
-    // at once: measured 114 KB of write-through traffic and 51 k cycles per tile).  Every wait is for a record whose writer holds a
-    // lower ticket, i.e. is already running.
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.rec, 0, (int)a.rec_bytes, 0x00020000);
-    using U4 = __attribute__((ext_vector_type(4))) unsigned;
-    auto publish = [&](double val, unsigned long long kind, int64_t area, int64_t stride, int64_t idx) {
-        if (lane <= NT) {
-            const unsigned long long vb = (unsigned long long)__double_as_longlong(val), tg = (a.epoch << 3) | kind;
-            const U4 g = {(unsigned)vb, (unsigned)(vb >> 32), (unsigned)tg, (unsigned)(tg >> 32)};
-            __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (int)(area + (lane * stride + idx) * 16), 0, /*sc1*/ 16);
-        }
-    };
-    // window of up to 64 records first .. last (ascending with the lane, `last` on lane 63): afterwards lane 63 holds their composite
-    // from the nearest stop on (or of all of them); records below `first` count as the identity -- and as a stop when below_stops
-    auto window = [&](int64_t area, int64_t stride, int64_t first, int64_t last, bool below_stops, double &Dp, double (&Tp)[NT]) -> bool {
-        const int64_t p = last - 63 + lane;
-        Dp = 1.0;
-#pragma unroll
-        for (int q = 0; q < NT; ++q) Tp[q] = 0.0;
-        bool stop = below_stops && p < first;
-        if (p >= first) {
-            const int voff = (int)(area + p * 16);
-            const int qstride = (int)(stride * 16);
-            for (;;) {
-                unsigned long long tag0 = 0;
-                bool same = true;
-#pragma unroll
-                for (int q = 0; q <= NT; ++q) {
-                    const U4 g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + q * qstride, 0, /*sc1*/ 16);
-                    const double val = __longlong_as_double((long long)(((unsigned long long)g[1] << 32) | g[0]));
-                    const unsigned long long tg = ((unsigned long long)g[3] << 32) | g[2];
-                    if (q == 0) tag0 = tg; else same = same && tg == tag0;
-                    if (q < NT) Tp[q] = val; else Dp = val;
-                }
-                if (same && (tag0 >> 3) == a.epoch) { stop = (tag0 & 7ull) == 2ull; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        const unsigned long long m = __ballot(stop);
-        const int hd = m ? 63 - __clzll(m) : -1;
-        k3c_seg_scan<NT>(Dp, Tp, hd, lane);
-        return hd >= 0;
-    };
-    // lane 63's composite -> one component per lane (through this wave's LDS words)
-    auto spread = [&](double Dp, const double (&Tp)[NT]) -> double {
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 63) {
-#pragma unroll
-            for (int q = 0; q < NT; ++q) s_win[q] = Tp[q];
-            s_win[NT] = Dp;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const double v = s_win[ql];
-        __builtin_amdgcn_wave_barrier();
-        return v;
-    };
-    auto compose = [&](double first, double second) -> double {   // first . second (first is the EARLIER rows), one component per lane
-        const double sD = k1p_readlane(second, NT);
-        return (lane == NT) ? first * second : fma(sD, first, second);
-    };
-    if (wv == WAVES - 1) {
-        constexpr int GT = K3C_GT;
-        publish(agg, is_prefix ? 2ull : 1ull, 0, a.tstride, t);
-        const int64_t g = t / GT, g0 = g * GT;
-        const int64_t size_g = (a.n_tiles - g0 < GT) ? a.n_tiles - g0 : GT;
-        unsigned arrived = 0;
-        if (lane == 0) arrived = (unsigned)(atomicAdd(a.arrive + g, 1ull) - a.launch_no * (unsigned long long)size_g);
-        arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
-        double acc = (lane == NT) ? 1.0 : 0.0;     // the carry-in, one component per lane
-        bool stopped = false;
-        double Dp, Tp[NT];
-        if (t > g0) {                               // this group's tiles below this one
-            stopped = window(0, a.tstride, g0, t - 1, false, Dp, Tp);
-            acc = spread(Dp, Tp);
-        }
-        K3C_STAMP(3);
-        if (arrived == (unsigned)(size_g - 1)) {    // the group's last tile to publish: the group record
-            const bool gstop = window(0, a.tstride, g0, g0 + size_g - 1, false, Dp, Tp);
-            const double gq = spread(Dp, Tp);
-            const bool gprefix = gstop || g == 0;
-            publish(gq, gprefix ? 2ull : 1ull, a.grec, a.gstride, g);
-            if (!gprefix) {
-                double gacc = (lane == NT) ? 1.0 : 0.0;
-                int64_t gb = g - 1;
-                for (bool gdone = false; !gdone; gb -= 64) {
-                    gdone = window(a.grec, a.gstride, 0, gb, true, Dp, Tp);
-                    gacc = compose(spread(Dp, Tp), gacc);
-                }
-                publish(compose(gacc, gq), 2ull, a.grec, a.gstride, g);
-            }
-        }
-        K3C_STAMP(4);
-        if (!stopped && g > 0) {                    // the prefix through the group below: one granule per lane
-            double gp = 0.0;
-            for (;;) {
-                unsigned long long tg = (a.epoch << 3) | 2ull;
-                if (lane <= NT) {
-                    const U4 gr = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(a.grec + (lane * a.gstride + (g - 1)) * 16), 0, /*sc1*/ 16);
-                    gp = __longlong_as_double((long long)(((unsigned long long)gr[1] << 32) | gr[0]));
-                    tg = ((unsigned long long)gr[3] << 32) | gr[2];
-                }
-                if (__all(tg == ((a.epoch << 3) | 2ull))) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            acc = compose(gp, acc);
-        }
-        if (lane <= NT) s_carry[lane] = acc;
-        K3C_STAMP(5);
-    }
-    __syncthreads();
     {
-        const double cq = s_carry[ql];
+        // pass 3: the tile's carry-in comes from the scan over the tile records (pass 2)
+        const double cq = a.carry[t * K3C_NCP + ql];
         const double runD = k1p_readlane(run, NT);
         const double full = wopen ? ((lane == NT) ? cq * run : fma(runD, cq, run)) : run;
         if (lane <= NT) s_wfull[wv][lane] = full;
     }
     __syncthreads();
+    K3C_STAMP(3);
     if (eopen) {
 #pragma unroll
         for (int q = 0; q < NT; ++q) ET[q] = fma(ED, s_wfull[wv][q], ET[q]);
     }
 
     __builtin_amdgcn_sched_barrier(0);
-    // ---- D: the walk; outputs leave FL rows at a time (FL x K values = a whole number of 16-byte vectors)
-    using V = typename Vec16<T>::type;
-    constexpr int VN = Vec16<T>::N, FL = VN;
-    const bool full = row0 + R <= N;
+    // ---- D: the walk.  A row's outputs take the LDS slots its inputs were parked in; the wave's 256 rows leave together (dyn_out.inl)
     double beta[K];
 #pragma unroll
-    for (int r0 = 0; r0 < R; r0 += FL) {
-        T cbuf[FL * K], pbuf[FL];
+    for (int r = 0; r < R; ++r) {
+        __builtin_amdgcn_sched_barrier(0);       // one row at a time: the scheduler would otherwise start every row's products at once
+        double xr[K];
 #pragma unroll
-        for (int rr = 0; rr < FL; ++rr) {
-            const int r = r0 + rr;
-            __builtin_amdgcn_sched_barrier(0);   // one row at a time: the scheduler would otherwise start every row's products at once
-            double xr[K];
+        for (int j = 0; j < K; ++j) xr[j] = (double)s_x[wv][r * (K + 1) + j][lane];
+        const double yr = (double)s_x[wv][r * (K + 1) + K][lane];
+        reset_at(ET, r);
+        add_row(ET, xr, yr, ffr[r]);
+        ldl_solve_small<K, true>(ET, 0.0, beta);
+        double pr = 0.0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) xr[j] = (double)s_x[wv][r * (K + 1) + j][lane];
-            const double yr = (double)s_x[wv][r * (K + 1) + K][lane];
-            reset_at(ET, r);
-            add_row(ET, xr, yr, ffr[r]);
-            ldl_solve_small<K, true>(ET, 0.0, beta);
-            double pr = 0.0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) { cbuf[rr * K + j] = (T)beta[j]; pr = fma(xr[j], beta[j], pr); }
-            pbuf[rr] = (T)pr;
+        for (int j = 0; j < K; ++j) {
+            s_x[wv][r * (K + 1) + j][lane] = (T)beta[j];
+            pr = fma(xr[j], beta[j], pr);
         }
-        if (full) {
-            if (a.coef) {
-                V *dst = reinterpret_cast<V *>(static_cast<T *>(a.coef) + (row0 + r0) * K);
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    V o;
-#pragma unroll
-                    for (int j = 0; j < VN; ++j) vset<T>(o, j, cbuf[i * VN + j]);
-                    store_stream(dst + i, o);
-                }
-            }
-            if (a.pred) {
-                V o;
-#pragma unroll
-                for (int j = 0; j < VN; ++j) vset<T>(o, j, pbuf[j]);
-                store_stream(reinterpret_cast<V *>(static_cast<T *>(a.pred) + row0 + r0), o);
-            }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < FL; ++rr)
-                if (row0 + r0 + rr < N) {
-                    if (a.coef)
-#pragma unroll
-                        for (int j = 0; j < K; ++j) static_cast<T *>(a.coef)[(row0 + r0 + rr) * K + j] = cbuf[rr * K + j];
-                    if (a.pred) static_cast<T *>(a.pred)[row0 + r0 + rr] = pbuf[rr];
-                }
-        }
+        s_x[wv][r * (K + 1) + K][lane] = (T)pr;
     }
-    K3C_STAMP(7);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dyn_wave_copy_out<T, K>(&s_x[wv][0][0], lane, ((t * WAVES + wv) * 64) * (int64_t)R, N, static_cast<T *>(a.coef), static_cast<T *>(a.pred));
+    K3C_STAMP(4);
+    K3C_STAMP(5);
     if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         a.dbg[t * 8 + 6] = xcc;
     }
 #undef K3C_STAMP
+}
+
+// ---- pass 2: every tile's carry-in from the tile records.  One workgroup of 16 waves: 1 024 records per step -- every lane loads a
+// record, the same segmented scan over the lanes, the wave totals meet in LDS, the step's total carries over to the next step.
+// carry[t] = the composite of everything from the last sequence start before tile t up to its first row (tile 0 starts a sequence,
+// so the chain always ends at a start: the prior is inside the records).
+template <int NT>
+__global__ void __launch_bounds__(1024) k3c_tile_scan_kernel(const double *rec, const int32_t *rec_closed, double *carry, const int64_t n_tiles) {
+    constexpr int WAVES = 16;
+    __shared__ double s_agg[WAVES][NT + 1];
+    __shared__ int s_closed[WAVES];
+    __shared__ double s_wfull[WAVES][NT + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ql = lane <= NT ? lane : NT;
+    double step_carry = (lane == NT) ? 1.0 : 0.0;                 // composite of the steps so far (from their last sequence start), per component
+    for (int64_t base = 0; base < n_tiles; base += 64 * WAVES) {
+        const int64_t r = base + wv * 64 + lane;
+        const bool in = r < n_tiles;
+        double Dl = 1.0, Tl[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) Tl[q] = in ? rec[r * K3C_NCP + q] : 0.0;
+        if (in) Dl = rec[r * K3C_NCP + NT];
+        const bool head = in && rec_closed[r] != 0;
+        const unsigned long long hmask = __ballot(head);
+        const unsigned long long upto = hmask & (~0ull >> (63 - lane));
+        const int h = upto ? 63 - __clzll(upto) : -1;
+        k3c_seg_scan<NT>(Dl, Tl, h, lane);
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) s_agg[wv][q] = Tl[q];
+            s_agg[wv][NT] = Dl;
+            s_closed[wv] = hmask != 0;
+        }
+        double ED = dpp_get<0x138>(Dl), ET[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) ET[q] = dpp_get<0x138>(Tl[q]);
+        if (lane == 0) ED = 1.0;
+        const bool eopen = (hmask & ((1ull << lane) - 1ull)) == 0;
+        __syncthreads();
+        double run = step_carry;                                  // composite entering this wave
+        for (int w2 = 0; w2 < wv; ++w2) {
+            const double eD = s_agg[w2][NT], eq = s_agg[w2][ql];
+            if (s_closed[w2]) run = eq;
+            else run = (lane == NT) ? run * eD : fma(eD, run, eq);
+        }
+        if (lane <= NT) s_wfull[wv][lane] = run;
+        double tot = run;                                         // ... and leaving the step
+        for (int w2 = wv; w2 < WAVES; ++w2) {
+            const double eD = s_agg[w2][NT], eq = s_agg[w2][ql];
+            if (s_closed[w2]) tot = eq;
+            else tot = (lane == NT) ? tot * eD : fma(eD, tot, eq);
+        }
+        step_carry = tot;
+        __syncthreads();
+        if (eopen) {                                              // carry-in . [the lanes below]
+#pragma unroll
+            for (int q = 0; q < NT; ++q) ET[q] = fma(ED, s_wfull[wv][q], ET[q]);
+            ED *= s_wfull[wv][NT];
+        }
+        if (in) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) carry[r * K3C_NCP + q] = ET[q];
+            carry[r * K3C_NCP + NT] = ED;
+        }
+        __syncthreads();                                          // s_agg / s_wfull are rewritten by the next step
+    }
 }
 
 // sequence-start bytes from the group offsets: start[offs[g]] = 1 for every non-empty group (the caller zero-fills first)
@@ -435,13 +360,24 @@ int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int6
 }
 
 template <typename T, int K>
-static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a) {
-    constexpr int R = K3C_R, WAVES = k3c_waves(K);
-    hipEvent_t e0, e1;
-    const bool timed = timing_pair(ctx, &e0, &e1);
-    hipExtLaunchKernelGGL((k3c_kernel<T, K, R, WAVES>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, timed ? e0 : nullptr,
-                          timed ? e1 : nullptr, 0, a);
+static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
+    constexpr int R = K3C_R, WAVES = k3c_waves(K), NT = K4N<K>::N;
+    K3cArgs a = a0;
+    if (ctx->opt.timeline) {
+        void *dbg = nullptr;
+        int rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)a.n_tiles, &dbg);
+        if (rc) return rc;
+        a.dbg = static_cast<unsigned long long *>(dbg);
+    }
+    timing_begin(ctx);                                            // the three launches as one timed span
+    K3cArgs a1 = a;
+    a1.dbg = nullptr;
+    hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 0>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a1);
+    hipLaunchKernelGGL((k3c_tile_scan_kernel<NT>), dim3(1), dim3(1024), 0, ctx->stream, a.rec, a.rec_closed, a.carry, a.n_tiles);
+    hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 1>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a);
+    timing_end(ctx);
     POLS_HIP(hipGetLastError());
+    if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k3c_rls_rows");
     return POLS_OK;
 }
 
@@ -461,7 +397,7 @@ static int k3c_launch_t(pols_ctx *ctx, const K3cArgs &a) {
 }
 
 int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a) {
-    ctx->last_kernel = dtype == POLS_F32 ? "k3s_rls_lookback_f32" : "k3s_rls_lookback_f64";
+    ctx->last_kernel = dtype == POLS_F32 ? "k3s_rls_rows_f32" : "k3s_rls_rows_f64";
     return dtype == POLS_F32 ? k3c_launch_t<float>(ctx, a) : k3c_launch_t<double>(ctx, a);
 }
 

@@ -72,9 +72,8 @@ constexpr int K4Y_KMAX = 1024;
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);
 
 // ---- K3c: row-parallel, read-once RLS for up to K4_KMAX features (k3c_scan.hip) ------------------------------------------------
-constexpr int K3C_NCP = 45;      // granules per published tile record: k (k + 1) / 2 + k + 1 <= 45
+constexpr int K3C_NCP = 48;      // doubles per tile record: k (k + 1) / 2 + k + 1 <= 45
 constexpr int K3C_R = 4;         // consecutive rows per lane
-constexpr int K3C_GT = 16;       // tiles per look-back group
 constexpr int k3c_waves(int k) { return k <= 6 ? 4 : 2; }    // waves per tile (each parks R (k + 1) row values per lane in LDS)
 constexpr int64_t k3c_tile_rows(int k) { return (int64_t)K3C_R * 64 * k3c_waves(k); }
 struct K3cArgs {
@@ -86,15 +85,10 @@ struct K3cArgs {
     void *coef, *pred;                 // n_rows x k / n_rows, batch dtype, 16-byte aligned; either may be nullptr
     const double *mean0;               // device, k values, or nullptr
     double ff, p0;
-    // decoupled look-back: one record of 16-byte {value, tag} granules per tile (component-major, stride tstride tiles); nothing is
-    // ever cleared -- a granule counts only when its tag carries this launch's epoch, and tiles take their index from a ticket that
-    // keeps counting
-    void *rec;                         // [tile records: tstride per component][group records at byte offset grec: gstride per component]
-    int64_t rec_bytes, tstride, grec, gstride;
-    unsigned long long *arrive;        // per group: tiles that have published (keeps counting: launch_no launches came before)
-    unsigned long long launch_no;
-    unsigned long long *ticket;
-    unsigned long long ticket_base, epoch;
+    // one record per tile (K3C_NCP doubles: the aggregate from the tile's last sequence start on, slot NT its decay), whether the tile
+    // holds a sequence start, and -- written by the tile scan between the two passes -- every tile's carry-in
+    double *rec, *carry;
+    int32_t *rec_closed;
     int64_t n_tiles;
     unsigned long long *dbg;           // POLS_TIMELINE: 8 words per tile (s_memtime stamps of the tile's last wave) or nullptr
     int32_t k;
@@ -103,6 +97,7 @@ int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a);
 int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int64_t n_rows, uint8_t *start);
 
 // ---- K4c: row-parallel rolling OLS on null-free frames, window <= K4C_MAX_WINDOW (k4c_rolling.hip) ------------------------------
+constexpr int K4C_KMAX = 6;                // beyond 6 features the walk no longer fits 256 registers next to its leaving rows
 constexpr int64_t K4C_MAX_WINDOW = 508;   // two halo waves: 512 >= 4 ceil(window / 4) + 1
 struct K4cArgs {
     const void *y;

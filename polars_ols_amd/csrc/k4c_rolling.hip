@@ -1,4 +1,4 @@
-// k4c_rolling.hip -- K4c "rolling_window_tiles": rolling-window OLS for up to 8 features on null-free frames, ROW-PARALLEL, every
+// k4c_rolling.hip -- K4c "rolling_window_tiles": rolling-window OLS for up to 6 features on null-free frames, ROW-PARALLEL, every
 // access a 16-byte one down the row axis, no cross-workgroup dependency.
 //
 // Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + the dynamic make_predictions (src/expressions.rs:184, 695-700) for
@@ -22,6 +22,9 @@
 // Bound: HBM, 8 (k + 1) bytes in + 8 (k + 1) bytes out per row (f64), plus the halo re-reads (1 / BW of the input).
 #include "k4_rolling.hpp"
 #include "k4_small.inl"
+#include "dyn_out.inl"
+
+#include <algorithm>
 
 namespace pols {
 
@@ -108,6 +111,45 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
             if (in && a.start[ic]) sbits |= 1u << (8 * r);
         }
     }
+    // The LEAVING rows of a body lane's run (rows i0 - window .. + 3, in the run u - ceil(window / 4), o = (-window) mod 4 rows in):
+    // issued here, right behind the entering rows, so that they are in registers long before the walk needs them -- they are
+    // rows another wave of this workgroup is loading just now, one L2 line fill serves both.
+    const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
+    const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window
+    const int up = u - sh;                                                     // >= 0 for body lanes: the halo covers `window` rows
+    const int64_t rho_run = hs + (int64_t)up * R;                              // first row of the run holding row i0 - window
+    auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
+        const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
+#pragma unroll
+        for (int j = 0; j < K; ++j) xr[j] = (double)static_cast<const T *>(a.x[j])[ic];
+        yr = (double)static_cast<const T *>(a.y)[ic];
+    };
+    double xo[R][K], yo[R];
+    if (wv >= HW) {
+        const int64_t l0 = rho_run + o;
+        if ((o % VN) == 0 && __all(l0 >= 0 && l0 + R <= N)) {                  // 16-byte aligned: vector loads
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + l0);
+#pragma unroll
+                for (int i = 0; i < R / VN; ++i) {
+                    const V v = p[i];
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) xo[i * VN + e][j] = (double)vget<T>(v, e);
+                }
+            }
+            const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.y) + l0);
+#pragma unroll
+            for (int i = 0; i < R / VN; ++i) {
+                const V v = p[i];
+#pragma unroll
+                for (int e = 0; e < VN; ++e) yo[i * VN + e] = (double)vget<T>(v, e);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) load_row(l0 + r, xo[r], yo[r]);
+        }
+    }
     bool st[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) st[r] = ((sbits >> (8 * r)) & 0xffu) != 0;
@@ -169,21 +211,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
     K4C_STAMP(2);
 
     // ---- D: body lanes.  S before the run, then one add / subtract / solve per row.
-    const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
-    const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window: (-window) mod 4
-    const int up = u - sh;                                                     // >= 0: the halo covers `window` rows
-    const int64_t rho_run = hs + (int64_t)up * R;                              // first row of the run holding row i0 - window
-    // the LEAVING rows of this run (rows i0 - window .. + 3) and the o rows in front of them: every load issued here, before the
-    // table is read -- one L2 round trip per run instead of one per row on the walk's dependency chain
-    auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
-        const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
-#pragma unroll
-        for (int j = 0; j < K; ++j) xr[j] = (double)static_cast<const T *>(a.x[j])[ic];
-        yr = (double)static_cast<const T *>(a.y)[ic];
-    };
-    double xo[R][K], yo[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) load_row(rho_run + o + r, xo[r], yo[r]);
     double S[NC];
     const double cnt_excl = ET[NT];                                            // rows since the last sequence start, before this run
     // (exact when a sequence starts inside the tile or its halo; otherwise the rows since the halo's first row: >= 256 HW >= window + o + 1)
@@ -206,79 +233,44 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
         }
     }
     K4C_STAMP(3);
-    const bool full = i0 + R <= N;
+    // the prefix table has been read by every body lane: its LDS becomes the staging area of the outputs (dyn_out.inl) -- a row's
+    // coefficients and prediction wait there until the wave's 256 rows leave as whole lines
+    __syncthreads();                                                           // (the halo waves have retired: they no longer count)
+    T *stage = reinterpret_cast<T *>(smem) + (size_t)(wv - HW) * (R * (K + 1) * DYN_STAGE_STRIDE);
     double beta[K];
-    // outputs leave FL rows at a time: the fewest rows whose K coefficients are a whole number of 16-byte vectors (f64, even K: every row)
-    constexpr int FL = (K * (int)sizeof(T)) % 16 == 0 ? 1 : ((2 * K * (int)sizeof(T)) % 16 == 0 ? 2 : 4);
 #pragma unroll
-    for (int r0 = 0; r0 < R; r0 += FL) {
-        T cbuf[FL * K], pbuf[FL];
+    for (int r = 0; r < R; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (__any(st[r])) {
 #pragma unroll
-        for (int rr = 0; rr < FL; ++rr) {
-            const int r = r0 + rr;
-            __builtin_amdgcn_sched_barrier(0);
-            if (__any(st[r])) {
-#pragma unroll
-                for (int q = 0; q < NC; ++q) S[q] = st[r] ? 0.0 : S[q];
-                cnt = st[r] ? 0.0 : cnt;
-            }
-            add_row(S, x[r], y[r], 1.0);
-            cnt += 1.0;
-            const bool sub = cnt >= (double)(w + 1);                           // the window is full: row i - window leaves
-            if (__any(sub)) {
-                if (sub) add_row(S, xo[r], yo[r], -1.0);
-                cnt = sub ? (double)w : cnt;                                   // (rows in the window)
-            }
-#ifdef K4C_NOLU
-            bool ok = ldl_solve_small<K, true>(S, a.alpha, beta);
-#else
-            bool ok = ldl_solve_small<K, false>(S, a.alpha, beta);
-#endif
-            if (!ok) {                                                         // Cholesky failed: LU like the reference (:732-734)
-                double A[K * K], b[K], xs[K];
-                for (int p = 0; p < K; ++p) {
-                    for (int q = 0; q < K; ++q) A[p * K + q] = S[p <= q ? tri_index<K>(p, q) : tri_index<K>(q, p)] + (p == q ? a.alpha : 0.0);
-                    b[p] = S[NX + p];
-                }
-                lu_solve_small<K>(A, b, xs);
-                for (int p = 0; p < K; ++p) beta[p] = xs[p];
-            }
-            const bool warm = cnt >= (double)a.min_periods || sub;             // row min_periods - 1 of the sequence and later
-            double pr = 0.0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                cbuf[rr * K + j] = warm ? (T)beta[j] : qnan;
-                pr = fma(x[r][j], beta[j], pr);
-            }
-            pbuf[rr] = warm ? (T)pr : qnan;
+            for (int q = 0; q < NC; ++q) S[q] = st[r] ? 0.0 : S[q];
+            cnt = st[r] ? 0.0 : cnt;
         }
-        // (no load may follow these stores inside the walk: on gfx9 a load's s_waitcnt vmcnt also waits for every store before it)
-        if (full) {
-            if (coef) {
-                V *dst = reinterpret_cast<V *>(coef + (i0 + r0) * K);
-#pragma unroll
-                for (int i = 0; i < FL * K / VN; ++i) {
-                    V ov;
-#pragma unroll
-                    for (int e = 0; e < VN; ++e) vset<T>(ov, e, cbuf[i * VN + e]);
-                    store_stream(dst + i, ov);
-                }
-            }
-            if (pred) {
-#pragma unroll
-                for (int rr = 0; rr < FL; ++rr) __builtin_nontemporal_store(pbuf[rr], pred + i0 + r0 + rr);
-            }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < FL; ++rr)
-                if (i0 + r0 + rr < N) {
-                    if (coef)
-#pragma unroll
-                        for (int j = 0; j < K; ++j) coef[(i0 + r0 + rr) * K + j] = cbuf[rr * K + j];
-                    if (pred) pred[i0 + r0 + rr] = pbuf[rr];
-                }
+        add_row(S, x[r], y[r], 1.0);
+        cnt += 1.0;
+        const bool sub = cnt >= (double)(w + 1);                               // the window is full: row i - window leaves
+        if (__any(sub)) {
+            if (sub) add_row(S, xo[r], yo[r], -1.0);
+            cnt = sub ? (double)w : cnt;                                       // (rows in the window)
         }
+        // Cholesky -> LU in the reference (:732-734).  A non-positive pivot here means a window without K independent rows (or one
+        // whose X'X is singular to working precision): the reference's LU then divides by a zero or noise pivot and returns
+        // inf / NaN / 1e15-sized numbers.  This kernel reports such rows as NaN -- no LU, hence no scratch memory in the launch;
+        // POLS_ROLLING_ENGINE=chunk has the LU.
+        const bool ok = ldl_solve_small<K, false>(S, a.alpha, beta);
+        const bool good = (cnt >= (double)a.min_periods || sub) && ok;         // row min_periods - 1 of the sequence and later
+        double pr = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            stage[(r * (K + 1) + j) * DYN_STAGE_STRIDE + lane] = good ? (T)beta[j] : qnan;
+            pr = fma(x[r][j], beta[j], pr);
+        }
+        stage[(r * (K + 1) + K) * DYN_STAGE_STRIDE + lane] = good ? (T)pr : qnan;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dyn_wave_copy_out<T, K>(stage, lane, hs + (int64_t)wv * 64 * R, N, coef, pred);
     K4C_STAMP(4);
     K4C_STAMP(5);
     if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + 6] = 0;
@@ -288,12 +280,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
 template <typename T, int K, int HW>
 static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     constexpr int NC = K4N<K>::N + 1;
-    constexpr int WAVES = K <= 7 ? 8 : 6;                        // the prefix table is NC x 64 WAVES doubles of LDS (K = 8: 135 KiB at 6 waves)
+    constexpr int WAVES = 8;                                     // the prefix table is NC x 64 WAVES doubles of LDS (K = 6: 112 KiB)
     K4cArgs a = a0;
     const int64_t tile_rows = (int64_t)(WAVES - HW) * 256;
     a.n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
     const int64_t per_xcd = (a.n_tiles + 7) / 8;
-    const size_t lds = sizeof(double) * ((size_t)NC * 64 * WAVES + WAVES * NC) + 64;
+    const size_t lds = std::max(sizeof(double) * ((size_t)NC * 64 * WAVES + WAVES * NC) + 64,                      // prefix table + wave totals
+                                (size_t)(WAVES - HW) * 4 * (K + 1) * DYN_STAGE_STRIDE * sizeof(T));              // ... reused as the output staging area
     static OncePerDevice attr_once;
     if (attr_once.needed(ctx->device)) {
         POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k4c_kernel<T, K, HW, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -328,9 +321,7 @@ static int k4c_launch_t(pols_ctx *ctx, const K4cArgs &a) {
         case 4: return k4c_launch_k<T, 4>(ctx, a);
         case 5: return k4c_launch_k<T, 5>(ctx, a);
         case 6: return k4c_launch_k<T, 6>(ctx, a);
-        case 7: return k4c_launch_k<T, 7>(ctx, a);
-        case 8: return k4c_launch_k<T, 8>(ctx, a);
-        default: return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): %d features > %d", a.k, K4_KMAX);
+        default: return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): %d features > %d", a.k, K4C_KMAX);
     }
 }
 

@@ -162,7 +162,7 @@ def test_rls_many_sequences_full_size(eng):
     y = sum(cols) + 0.1 * torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64)
     offs = np.arange(G + 1, dtype=np.int64) * n
     out = eng.recursive_least_squares(y, cols, offs, half_life=21.0, null_free=True)
-    assert eng.last_kernel.startswith("k3s_rls_lookback")
+    assert eng.last_kernel.startswith("k3s_rls_rows")
     coef, pred = out["coef"], out["pred"]
     assert bool(torch.isfinite(coef).all()) and bool(torch.isfinite(pred).all())
     rng = np.random.default_rng(5)
@@ -191,7 +191,7 @@ def test_rls_lookback_long_and_short_sequences_mixed(eng, dtype, tol, k):
     for v in (None, valid):
         out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if v is None else _cuda(v), half_life=63.0,
                                           initial_state_covariance=5.0, initial_state_mean=[0.1] * k, null_free=v is None)
-        assert eng.last_kernel.startswith("k3s_rls_lookback")
+        assert eng.last_kernel.startswith("k3s_rls_rows")
         ref = orc.batched_rls(y, cols, offs, half_life=63.0, initial_state_covariance=5.0, initial_state_mean=[0.1] * k, is_valid=v)
         assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
         exp_p = ref["pred"] if v is None else _masked(ref["pred"], v)
