@@ -15,13 +15,14 @@
 //   A  every lane composes its run                                    (R x 2 NT flops, registers)
 //   B  segmented inclusive scan over the 64 lanes                      (6 DPP steps x (NT + 1) components; a lane only combines
 //      with a partner in its own sequence -- exec-masked, so nothing ever crosses a sequence boundary, not even a NaN)
-//   C  wave aggregates meet in LDS -> the tile's aggregate.  The tiles' carry-ins come from a scan over the tile aggregates, which
-//      is a launch of its own: pass 1 (this kernel, MODE 0) stops here and writes one record per tile, pass 2 (k3c_tile_scan_kernel,
-//      one workgroup) turns the records into every tile's carry-in, pass 3 (this kernel again, MODE 1) repeats A-B from the same
-//      rows (their second read: the Infinity Cache holds what pass 1 streamed) and goes on to D.  A single-launch form with a
-//      decoupled look-back over published records (round 4: tickets, tagged write-through granules, two levels) measured 125 us on
-//      the 1M-row sequence against 55 for the three launches: every tile of a long sequence waits for the slowest of the tiles
-//      running beside it, and a workgroup that waits holds half a CU.
+//   C  wave aggregates meet in LDS -> the tile's aggregate.  The tiles' carry-ins come from a scan over the tile aggregates, and that
+//      needs every aggregate first: TWO launches.  Pass 1 (this kernel, MODE 0) stops after C and publishes the tile's record; the
+//      LAST tile of each block of 64 tiles to arrive (an arrival counter -- nobody ever waits) scans its block's 64 records, and the
+//      last BLOCK to arrive scans the block totals: when pass 1 ends every tile's carry-in is in memory as [its block's carry-in] .
+//      [the tiles of its block below it].  Pass 2 (MODE 1) repeats A-B from the same rows (their second read: the Infinity Cache
+//      holds what pass 1 streamed) and goes on to D.  A single-launch form with a decoupled look-back over published records
+//      (round 4: tickets, tagged write-through granules, two levels of records) measured 96 us on the 1M-row sequence and 488 us on
+//      10 000 x 1 000 rows against 5x / 4xx for the two launches: every tile waits 27-60 k cycles for the tiles running beside it.
 //   D  every lane walks its R rows from its carry-in: A' = ff A + x x', one K x K solve per row (square-root-free L D L', LU on
 //      a non-positive pivot like the reference's Cholesky -> LU chain), coefficients and predictions stored 16 bytes at a time.
 // The information matrix is solved directly on every row -- never inverted and propagated -- so a diffuse prior (p0 = 1e6, the
@@ -62,6 +63,9 @@ __device__ __forceinline__ void k3c_seg_scan(double &D, double (&Tv)[NT], const 
 #undef K3C_STEP
 }
 
+
+__device__ __forceinline__ double k3c_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void k3c_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <typename T, int R>
 __device__ __forceinline__ void k3c_load_run(const void *col, int64_t row0, double (&out)[R]) {
@@ -219,21 +223,105 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     }
     K3C_STAMP(2);
     if constexpr (MODE == 0) {
-        // pass 1: the tile's record -- its aggregate from the last sequence start inside it on, and whether there is one
-        if (wv == WAVES - 1) {
-            double agg = run;
-            bool tclosed = !wopen;
+        // pass 1: the tile's record -- its aggregate from the last sequence start inside it on, and whether there is one.  Records
+        // that another workgroup reads inside this launch travel write-through (sc1 stores, sc1 loads: no fences), counted in by a
+        // relaxed atomic behind a drained store queue (MI355X_MICROARCH.md, hand-off forms).
+        if (wv != WAVES - 1) return;
+        double agg = run;
+        bool tclosed = !wopen;
+        {
             const double eD = s_agg[wv][NT], eq = s_agg[wv][ql];
             if (s_closed[wv]) { agg = eq; tclosed = true; }
             else agg = (lane == NT) ? agg * eD : fma(eD, agg, eq);
-            if (lane <= NT) a.rec[t * K3C_NCP + lane] = agg;
-            if (lane == 0) a.rec_closed[t] = tclosed ? 1 : 0;
+        }
+        if (lane <= NT) k3c_st(a.rec + t * K3C_NCP + lane, agg);
+        if (lane == 0) __hip_atomic_store(a.rec_closed + t, tclosed ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int64_t blk = t >> 6, n_blocks = (a.n_tiles + 63) >> 6;
+        const int64_t blk_size = (a.n_tiles - (blk << 6) < 64) ? a.n_tiles - (blk << 6) : 64;
+        int arrived = 0;
+        if (lane == 0) arrived = (int)__hip_atomic_fetch_add(a.blk_arrive + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived != (int)blk_size - 1) return;
+        // ---- the last tile of its block: the block's 64 records -> every tile's carry-in relative to the block's start
+        if (lane == 0) __hip_atomic_store(a.blk_arrive + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next launch)
+        auto scan_records = [&](const double *rec, const int32_t *closed, int64_t first, int64_t count, double *excl, int32_t *open_out,
+                                double &Dl, double (&Tl)[NT], bool carry_in_valid, double carry_in_q) -> bool {
+            // lane l <-> record first + l (l < count); writes the exclusive composite of every record (from the last closed one below
+            // it in this window, or -- nothing closed below -- with carry_in prepended when there is one) and whether it is still
+            // open; returns "some record is closed", leaves the inclusive composite of the window in lane 63's (Dl, Tl)
+            const bool in = lane < count;
+            const int64_t r = first + (in ? lane : 0);
+            Dl = 1.0;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) Tl[q] = in ? k3c_ld(rec + r * K3C_NCP + q) : 0.0;
+            if (in) Dl = k3c_ld(rec + r * K3C_NCP + NT);
+            const bool head = in && __hip_atomic_load(closed + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            const unsigned long long hm = __ballot(head);
+            const unsigned long long up2 = hm & (~0ull >> (63 - lane));
+            k3c_seg_scan<NT>(Dl, Tl, up2 ? 63 - __clzll(up2) : -1, lane);
+            double ED2 = dpp_get<0x138>(Dl), ET2[NT];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) ET2[q] = dpp_get<0x138>(Tl[q]);
+            if (lane == 0) {
+                ED2 = 1.0;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) ET2[q] = 0.0;
+            }
+            const bool open = (hm & ((1ull << lane) - 1ull)) == 0;
+            if (open && carry_in_valid) {                    // carry_in . [the records below]: the carry-in arrives one component per lane
+#pragma unroll
+                for (int q = 0; q < NT; ++q) ET2[q] = fma(ED2, k1p_readlane(carry_in_q, q), ET2[q]);
+                ED2 *= k1p_readlane(carry_in_q, NT);
+            }
+            if (in) {
+#pragma unroll
+                for (int q = 0; q < NT; ++q) excl[r * K3C_NCP + q] = ET2[q];
+                excl[r * K3C_NCP + NT] = ED2;
+                if (open_out) open_out[r] = open ? 1 : 0;
+            }
+            return hm != 0;
+        };
+        double Dl2, Tl2[NT];
+        const bool bclosed = scan_records(a.rec, a.rec_closed, blk << 6, blk_size, a.carry, a.carry_open, Dl2, Tl2, false, 0.0);
+        // lane 63 holds the block's inclusive composite: the block record
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) k3c_st(a.brec + blk * K3C_NCP + q, Tl2[q]);
+            k3c_st(a.brec + blk * K3C_NCP + NT, Dl2);
+            __hip_atomic_store(a.brec_closed + blk, bclosed ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int barrived = 0;
+        if (lane == 63) barrived = (int)__hip_atomic_fetch_add(a.all_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        barrived = __builtin_amdgcn_readlane(barrived, 63);
+        if (barrived != (int)n_blocks - 1) return;
+        // ---- the last block: the block records -> every block's carry-in, 64 blocks per step, the steps chained
+        if (lane == 0) __hip_atomic_store(a.all_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double chain = (lane == NT) ? 1.0 : 0.0;             // composite of the steps so far (from their last closed block), per component
+        bool chain_valid = false;
+        for (int64_t b0 = 0; b0 < n_blocks; b0 += 64) {
+            const int64_t cnt = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
+            const bool anyc = scan_records(a.brec, a.brec_closed, b0, cnt, a.bcarry, nullptr, Dl2, Tl2, chain_valid, chain);
+            // chain = anyc ? window : chain . window   (the window's composite sits in lane 63: spread it one component per lane)
+            double wq = 0.0;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) { const double v = k1p_readlane(Tl2[q], 63); wq = (lane == q) ? v : wq; }
+            { const double v = k1p_readlane(Dl2, 63); wq = (lane == NT) ? v : wq; }
+            if (anyc || !chain_valid) chain = wq;
+            else { const double wD = k1p_readlane(wq, NT); chain = (lane == NT) ? chain * wq : fma(wD, chain, wq); }
+            chain_valid = true;
         }
         return;
     }
     {
-        // pass 3: the tile's carry-in comes from the scan over the tile records (pass 2)
-        const double cq = a.carry[t * K3C_NCP + ql];
+        // pass 2: the tile's carry-in = [its block's carry-in] . [the tiles of its block below it], both written by pass 1
+        double cq = a.carry[t * K3C_NCP + ql];
+        if (a.carry_open[t] && t >= 64) {
+            const double bq = a.bcarry[(t >> 6) * K3C_NCP + ql];
+            const double cD = k1p_readlane(cq, NT);
+            cq = (lane == NT) ? bq * cq : fma(cD, bq, cq);
+        }
         const double runD = k1p_readlane(run, NT);
         const double full = wopen ? ((lane == NT) ? cq * run : fma(runD, cq, run)) : run;
         if (lane <= NT) s_wfull[wv][lane] = full;
@@ -280,72 +368,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
 #undef K3C_STAMP
 }
 
-// ---- pass 2: every tile's carry-in from the tile records.  One workgroup of 16 waves: 1 024 records per step -- every lane loads a
-// record, the same segmented scan over the lanes, the wave totals meet in LDS, the step's total carries over to the next step.
-// carry[t] = the composite of everything from the last sequence start before tile t up to its first row (tile 0 starts a sequence,
-// so the chain always ends at a start: the prior is inside the records).
-template <int NT>
-__global__ void __launch_bounds__(1024) k3c_tile_scan_kernel(const double *rec, const int32_t *rec_closed, double *carry, const int64_t n_tiles) {
-    constexpr int WAVES = 16;
-    __shared__ double s_agg[WAVES][NT + 1];
-    __shared__ int s_closed[WAVES];
-    __shared__ double s_wfull[WAVES][NT + 1];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ql = lane <= NT ? lane : NT;
-    double step_carry = (lane == NT) ? 1.0 : 0.0;                 // composite of the steps so far (from their last sequence start), per component
-    for (int64_t base = 0; base < n_tiles; base += 64 * WAVES) {
-        const int64_t r = base + wv * 64 + lane;
-        const bool in = r < n_tiles;
-        double Dl = 1.0, Tl[NT];
-#pragma unroll
-        for (int q = 0; q < NT; ++q) Tl[q] = in ? rec[r * K3C_NCP + q] : 0.0;
-        if (in) Dl = rec[r * K3C_NCP + NT];
-        const bool head = in && rec_closed[r] != 0;
-        const unsigned long long hmask = __ballot(head);
-        const unsigned long long upto = hmask & (~0ull >> (63 - lane));
-        const int h = upto ? 63 - __clzll(upto) : -1;
-        k3c_seg_scan<NT>(Dl, Tl, h, lane);
-        if (lane == 63) {
-#pragma unroll
-            for (int q = 0; q < NT; ++q) s_agg[wv][q] = Tl[q];
-            s_agg[wv][NT] = Dl;
-            s_closed[wv] = hmask != 0;
-        }
-        double ED = dpp_get<0x138>(Dl), ET[NT];
-#pragma unroll
-        for (int q = 0; q < NT; ++q) ET[q] = dpp_get<0x138>(Tl[q]);
-        if (lane == 0) ED = 1.0;
-        const bool eopen = (hmask & ((1ull << lane) - 1ull)) == 0;
-        __syncthreads();
-        double run = step_carry;                                  // composite entering this wave
-        for (int w2 = 0; w2 < wv; ++w2) {
-            const double eD = s_agg[w2][NT], eq = s_agg[w2][ql];
-            if (s_closed[w2]) run = eq;
-            else run = (lane == NT) ? run * eD : fma(eD, run, eq);
-        }
-        if (lane <= NT) s_wfull[wv][lane] = run;
-        double tot = run;                                         // ... and leaving the step
-        for (int w2 = wv; w2 < WAVES; ++w2) {
-            const double eD = s_agg[w2][NT], eq = s_agg[w2][ql];
-            if (s_closed[w2]) tot = eq;
-            else tot = (lane == NT) ? tot * eD : fma(eD, tot, eq);
-        }
-        step_carry = tot;
-        __syncthreads();
-        if (eopen) {                                              // carry-in . [the lanes below]
-#pragma unroll
-            for (int q = 0; q < NT; ++q) ET[q] = fma(ED, s_wfull[wv][q], ET[q]);
-            ED *= s_wfull[wv][NT];
-        }
-        if (in) {
-#pragma unroll
-            for (int q = 0; q < NT; ++q) carry[r * K3C_NCP + q] = ET[q];
-            carry[r * K3C_NCP + NT] = ED;
-        }
-        __syncthreads();                                          // s_agg / s_wfull are rewritten by the next step
-    }
-}
-
 // sequence-start bytes from the group offsets: start[offs[g]] = 1 for every non-empty group (the caller zero-fills first)
 __global__ void k3c_start_kernel(const int64_t *offs, int64_t n_groups, uint8_t *start) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,7 +383,7 @@ int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int6
 
 template <typename T, int K>
 static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
-    constexpr int R = K3C_R, WAVES = k3c_waves(K), NT = K4N<K>::N;
+    constexpr int R = K3C_R, WAVES = k3c_waves(K);
     K3cArgs a = a0;
     if (ctx->opt.timeline) {
         void *dbg = nullptr;
@@ -369,11 +391,10 @@ static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
         if (rc) return rc;
         a.dbg = static_cast<unsigned long long *>(dbg);
     }
-    timing_begin(ctx);                                            // the three launches as one timed span
+    timing_begin(ctx);                                            // the two launches as one timed span
     K3cArgs a1 = a;
     a1.dbg = nullptr;
     hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 0>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a1);
-    hipLaunchKernelGGL((k3c_tile_scan_kernel<NT>), dim3(1), dim3(1024), 0, ctx->stream, a.rec, a.rec_closed, a.carry, a.n_tiles);
     hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 1>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());

@@ -85,10 +85,13 @@ struct K3cArgs {
     void *coef, *pred;                 // n_rows x k / n_rows, batch dtype, 16-byte aligned; either may be nullptr
     const double *mean0;               // device, k values, or nullptr
     double ff, p0;
-    // one record per tile (K3C_NCP doubles: the aggregate from the tile's last sequence start on, slot NT its decay), whether the tile
-    // holds a sequence start, and -- written by the tile scan between the two passes -- every tile's carry-in
-    double *rec, *carry;
-    int32_t *rec_closed;
+    // pass 1 -> pass 2: one record per tile (K3C_NCP doubles: the aggregate from the tile's last sequence start on, slot NT its
+    // decay) and whether the tile holds a sequence start; per tile the composite of the tiles of its 64-tile block below it and
+    // whether it is still open (no sequence start among them); the same per block: records, carry-ins.  The arrival counters are
+    // zero between launches (the last arriver resets them).
+    double *rec, *carry, *brec, *bcarry;
+    int32_t *rec_closed, *carry_open, *brec_closed;
+    unsigned *blk_arrive, *all_arrive;
     int64_t n_tiles;
     unsigned long long *dbg;           // POLS_TIMELINE: 8 words per tile (s_memtime stamps of the tile's last wave) or nullptr
     int32_t k;
