@@ -181,8 +181,10 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
             out = {"coef": torch.empty(G, k, device="cuda", dtype=tdt)}
             if "pred" in want:
                 out["pred"] = torch.empty(G * n, device="cuda", dtype=tdt)
+        # null_free: the synthetic columns hold no nulls, which a Polars caller reads off null_count (with sample weights the entry
+        # would otherwise spend a pass over the weights column on the null-weight fill of least_squares.py:193)
         plan = eng.plan_least_squares(to_mem(y), [to_mem(c) for c in cols], shard.offsets, weights=None if w is None else to_mem(w),
-                                      want=want, out=out, **kw)
+                                      want=want, out=out, null_free=True, **kw)
         nbytes = b * n * (k + 1 + (1 if w is not None else 0)) * G + (b * n * G if "pred" in want else 0)
         return plan, G, nbytes, (out or plan.results).get("coef"), shard
 

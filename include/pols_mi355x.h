@@ -139,7 +139,10 @@ void pols_rls_params_default(pols_rls_params *p);
 typedef struct {
     int64_t window_size;
     int64_t min_periods;  /* < 0 <=> None -> min(k, window) (ls.rs:860) */
-    int32_t use_woodbury; /* < 0 <=> None -> k > 60 (ls.rs:863) */
+    int32_t use_woodbury; /* < 0 <=> None -> k > 60 (ls.rs:863).  DIVERGENCE: only the default is reproduced -- up to 32 features the
+                             window state is X'X (NonWoodburyState, ls.rs:669-735) whatever this field says; from 33 features the
+                             inverse is propagated (WoodburyState, :737-787).  use_woodbury = 1 below 33 features (tested by the reference
+                             at tests/test_ols.py:718-772) is accepted and ignored: same mathematics, different rounding */
     double alpha;         /* 0 <=> None */
     int32_t null_policy;  /* dataclass default "drop_window"; the namespace method passes "drop" */
 } pols_rolling_params;
@@ -154,7 +157,9 @@ typedef struct {
     int32_t n_features;           /* user features, excluding the intercept */
     const void *y;                /* target column, n_rows */
     const void *const *x_cols;    /* HOST array of n_features column pointers, each n_rows */
-    const void *weights;          /* sample_weights column or NULL (polars_ols/least_squares.py:190-196) */
+    const void *weights;          /* sample_weights column or NULL (polars_ols/least_squares.py:190-196).  A null (NaN) weight acts as
+                                     the weight 1e-24 -- sqrt_w = w.sqrt().fill_null(1e-12), least_squares.py:193 -- in every entry:
+                                     the fill is a device pass behind this boundary (skipped when null_free is set) */
     const uint8_t *valid;         /* optional row validity, 1 byte per row (1 = valid), or NULL = all valid */
     int32_t add_intercept;        /* append a ones column LAST, named "const" (least_squares.py:184-188) */
     uint64_t offsets_generation;  /* 0: group_offsets is content-checked on every call (hash, then memcmp against the copy the
@@ -162,7 +167,7 @@ typedef struct {
                                      (group_offsets pointer, n_groups, offsets_generation) always names the same content and bumps
                                      the value whenever it rewrites the array -- repeated calls on one frame then cost O(1) on
                                      the host instead of a pass over the offsets */
-    int32_t null_free;            /* non-zero: the caller KNOWS that no target / feature value is null (= NaN here) -- what a Polars
+    int32_t null_free;            /* non-zero: the caller KNOWS that no target / feature / weight value is null (= NaN here) -- what a Polars
                                      / Arrow caller reads off null_count == 0 for free.  The null policy then has nothing to do:
                                      the static entry takes its policy-free kernels and the dynamic entries skip their validity
                                      scan (one pass over the columns + one stream synchronisation per call).  0 = unknown */
@@ -195,7 +200,11 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
  * kt = n_features + add_intercept columns; p->initial_state_mean has kt values. */
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o);
 
-/* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions. */
+/* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions.
+ * DIVERGENCE (null-free frames, up to 6 features, min_periods <= window <= 508: the row-parallel kernel): a window whose X'X has
+ * no Cholesky factorisation -- fewer than k independent rows -- yields NaN coefficients; the reference falls back to LU there
+ * (ls.rs:732-734) and returns whatever a zero or noise pivot produces (inf / NaN / 1e15-sized numbers).
+ * pols_set_option("ROLLING_ENGINE", "chunk") selects the kernels that run the LU. */
 int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o);
 
 /* Replaces the `predict` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t,j] * coef[t,j].  `coef` holds one

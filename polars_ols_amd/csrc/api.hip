@@ -4,6 +4,7 @@
 #include <cctype>
 #include <cstdlib>
 #include <strings.h>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -258,6 +259,42 @@ struct Staged {
     int32_t *status = nullptr;
 };
 
+
+// Null sample weights of the static entries: sqrt_w = w.sqrt().fill_null(1e-12) in the reference's Python layer
+// (polars_ols/least_squares.py:193) -- a null (NaN) weight acts as the weight 1e-24.  One read + write pass of the weights column,
+// 16 bytes per lane; skipped when the batch promises null_free.
+template <typename T>
+__global__ void __launch_bounds__(256) null_weights_kernel(const T *w, T *out, int64_t n) {
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VN;
+    if (i0 + VN <= n) {
+        const V v = *reinterpret_cast<const V *>(w + i0);
+        T f[4];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { const T x = vget<T>(v, e); f[e] = x != x ? (T)1e-24 : x; }
+        if constexpr (VN == 4) *reinterpret_cast<V *>(out + i0) = V{f[0], f[1], f[2], f[3]};
+        else *reinterpret_cast<V *>(out + i0) = V{f[0], f[1]};
+    } else {
+        for (int64_t i = i0; i < n; ++i) { const T x = w[i]; out[i] = x != x ? (T)1e-24 : x; }
+    }
+}
+
+static int fill_null_weights(pols_ctx *ctx, const pols_batch *b, Staged *st) {
+    if (!st->w || b->null_free || b->n_rows <= 0) return POLS_OK;
+    void *dst = const_cast<void *>(st->w);                     // HOST batch: the staged copy is ours -- in place
+    if (b->mem == POLS_MEM_DEVICE) {                           // DEVICE batch: the caller's column stays untouched
+        int rc = ensure_scratch(ctx, 17, round256(dtype_size(b->dtype) * (size_t)b->n_rows), &dst);
+        if (rc) return rc;
+    }
+    const int vn = b->dtype == POLS_F32 ? 4 : 2;
+    const unsigned blocks = (unsigned)((b->n_rows + 256 * (int64_t)vn - 1) / (256 * (int64_t)vn));
+    if (b->dtype == POLS_F32) hipLaunchKernelGGL(null_weights_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const float *>(st->w), static_cast<float *>(dst), b->n_rows);
+    else hipLaunchKernelGGL(null_weights_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const double *>(st->w), static_cast<double *>(dst), b->n_rows);
+    POLS_HIP(hipGetLastError());
+    st->w = dst;
+    return POLS_OK;
+}
 
 static int stage_inputs(pols_ctx *ctx, const pols_batch *b, int64_t coef_rows, int kt, const pols_out *o, Staged *st) {
     const size_t sz = dtype_size(b->dtype);
@@ -623,6 +660,7 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows, b->offsets_generation))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups * m, kt, o, &st))) return rc;
+    if ((rc = fill_null_weights(ctx, b, &st))) return rc;
     const size_t G = (size_t)b->n_groups;
     const int NZ = kt + m, nt = (NZ + 63) / 64, npairs = nt * (nt + 1) / 2;
     // multi-target: device pointers of the m target and m prediction columns (host batches are staged in slot 4)
@@ -785,6 +823,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     if ((rc = upload_offsets(ctx, b->group_offsets, b->n_groups, &d_offs, &max_rows, b->offsets_generation))) return rc;
     Staged st;
     if ((rc = stage_inputs(ctx, b, b->n_groups, kt, o, &st))) return rc;
+    if ((rc = fill_null_weights(ctx, b, &st))) return rc;
     auto finish = [&](double *gram) -> int {
         if (!info) return unstage_outputs(ctx, b, b->n_groups, kt, o, st);
         info->st = st; info->d_offs = d_offs; info->max_rows = max_rows; info->gram = gram; info->kt = kt;
@@ -851,6 +890,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     };
     auto svd_fixup = [&]() -> int {
         if (enet) return POLS_OK;
+        // (measurement aid, read once: what the fix-up dispatch of a call that flags nothing costs on the stream -- DESIGN.md section 4)
+        static const bool skip_for_measurement = std::getenv("POLS_DEBUG_SKIP_FIXUP") != nullptr;
+        if (skip_for_measurement) return POLS_OK;
         int r2 = prepare_fix();
         if (r2) return r2;
         return k6_launch(ctx, b->dtype, ka, fix_workers);
@@ -1711,8 +1753,26 @@ int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, i
     }
     std::vector<int> rcs((size_t)n, POLS_OK);
     std::vector<std::string> errs((size_t)n);
+    // Device-side assembly runs in two phases with a host-side rendezvous between them: a rank that fails BEFORE its collectives
+    // (context, scratch, staging copy, solve) must not leave its peers waiting inside RCCL for a send / receive that never comes.
+    // Every rank reports after its solve; the collectives are issued only when every rank succeeded.
+    std::mutex gate_m;
+    std::condition_variable gate_cv;
+    int gate_arrived = 0, gate_decision = 0;                       // decision: 0 pending, 1 go, 2 abort
+    auto rendezvous = [&]() -> bool {
+        std::unique_lock<std::mutex> lk(gate_m);
+        ++gate_arrived;
+        gate_cv.notify_all();
+        gate_cv.wait(lk, [&] { return gate_decision != 0; });
+        return gate_decision == 1;
+    };
+    std::vector<char> met((size_t)n, 0);                           // rank r has been through the rendezvous
     auto work_impl = [&](int r) {
-        auto done = [&](int code) { rcs[(size_t)r] = code; if (code) errs[(size_t)r] = pols_last_error(); };
+        auto done = [&](int code) {
+            rcs[(size_t)r] = code;
+            if (code) errs[(size_t)r] = pols_last_error();
+            if (out_mem == POLS_MEM_DEVICE && !met[(size_t)r]) { met[(size_t)r] = 1; rendezvous(); }   // a failed rank still reports, so that the others are released
+        };
         pols_ctx *ctx = ctxs[r];
         const int64_t g0 = bounds[(size_t)r], g1 = bounds[(size_t)r + 1], row0 = b->group_offsets[g0], nrows = rcounts[(size_t)r];
         // the shard as a batch of its own: column pointers advanced to its first row, offsets rebased to 0
@@ -1770,6 +1830,8 @@ int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, i
         void *all_coef = q; q += allb;
         if (o->status) so.status = reinterpret_cast<int32_t *>(q);
         if (sb.n_groups > 0 && (rc2 = pols_least_squares(ctx, &db, p, &so))) return done(rc2);
+        met[(size_t)r] = 1;
+        if (!rendezvous()) { rcs[(size_t)r] = POLS_OK; return; }    // another rank failed: nobody enters the collectives (its error is reported)
         pols_comm *cm = comms[r];
         if (o->coef && (rc2 = pols_comm_allgather_rows(cm, so.coef, gcounts.data(), (int64_t)(sz * kt), r == 0 ? o->coef : all_coef))) return done(rc2);
         if (o->pred && (rc2 = pols_comm_gather_rows(cm, so.pred, rcounts.data(), (int64_t)sz, 0, r == 0 ? o->pred : nullptr))) return done(rc2);
@@ -1779,19 +1841,30 @@ int pols_least_squares_sharded(pols_ctx *const *ctxs, pols_comm *const *comms, i
         return done(POLS_OK);
     };
     auto work = [&](int r) {                                       // (an allocation failure inside a device thread must not terminate the process)
-        try { work_impl(r); } catch (...) { rcs[(size_t)r] = POLS_ERR_INVALID; errs[(size_t)r] = "out of host memory"; }
+        try { work_impl(r); } catch (...) {
+            rcs[(size_t)r] = POLS_ERR_INVALID; errs[(size_t)r] = "out of host memory";
+            if (out_mem == POLS_MEM_DEVICE && !met[(size_t)r]) { met[(size_t)r] = 1; rendezvous(); }
+        }
     };
-    if (n == 1) work(0);
-    else {
+    {
         std::vector<std::thread> th;
         int started = 0;
+        bool all_started = true;
         try {                                                      // no C++ exception may cross the C boundary (thread creation can throw)
             for (; started < n; ++started) th.emplace_back(work, started);
         } catch (...) {
-            for (auto &t : th) t.join();
-            return fail(POLS_ERR_INVALID, "could not start the host thread of device %d", started);
+            all_started = false;
+        }
+        if (out_mem == POLS_MEM_DEVICE) {                          // release the ranks once every started one has reported
+            std::unique_lock<std::mutex> lk(gate_m);
+            gate_cv.wait(lk, [&] { return gate_arrived == started; });
+            bool ok = all_started;
+            for (int r = 0; r < started; ++r) ok = ok && rcs[(size_t)r] == POLS_OK;
+            gate_decision = ok ? 1 : 2;
+            gate_cv.notify_all();
         }
         for (auto &t : th) t.join();
+        if (!all_started) return fail(POLS_ERR_INVALID, "could not start the host thread of device %d", started);
     }
     for (int r = 0; r < n; ++r)
         if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "device %d: %s", r, errs[(size_t)r].c_str());

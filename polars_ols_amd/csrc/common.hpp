@@ -79,10 +79,10 @@ struct pols_ctx {
     int num_cus = 0;
     // device scratch (grow-only): [0] group offsets, [1] inputs for HOST batches, [2] outputs, [3] fix-up work area,
     // [4] staged targets / statistics of HOST batches, [5] Gram matrices / chunk totals / staged coefficients, [6] RLS prior mean,
-    // [7] status words, [8] K3c look-back records + sequence-start bytes, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
+    // [7] status words, [8] K3c tile / block records, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
-    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17..23] free
+    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18..23] free
     pols::Scratch scratch[24];
     pols::Options opt;
     bool timing = false;
@@ -116,11 +116,9 @@ struct pols_ctx {
     // offsets, min_periods or the chunk length change
     struct { uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;
              const void *tab = nullptr; size_t b_groups = 0; } chunk_cache;
-    // K3c (k3c_scan.hip), scratch slot 8: [ticket][group arrival counters][tile records | group records: tagged granules].  The ticket
-    // keeps counting across launches (tile = ticket - ticket_base) and a status word only counts with the launch's epoch, so nothing is
-    // cleared between launches on the same layout; the start bytes are rebuilt when other offsets arrive.
-    struct { const void *ptr = nullptr; int64_t n_rows = -1, n_tiles = -1, flags_groups = -1; unsigned long long ticket_base = 0, epoch = 0;
-             int kf = 0; unsigned long long launches = 0; } k3c;
+    // K3c (k3c_scan.hip), scratch slot 8: tile / block records, carry-ins, arrival counters (zeroed when the layout changes: every
+    // launch leaves them at zero)
+    struct { const void *ptr = nullptr; int64_t n_tiles = -1; } k3c;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };

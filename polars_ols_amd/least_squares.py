@@ -269,8 +269,7 @@ class _Groups:
         return _to_index(np.repeat(np.arange(len(self.offsets) - 1, dtype=np.int64), np.diff(self.offsets)), like)
 
 
-def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], sample_weights, add_intercept: bool,
-                      fill_null_weights: bool = True):
+def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], sample_weights, add_intercept: bool):
     """least_squares.py:163-196 up to (not including) the sqrt_w multiplications, which the kernels fuse:
     returns (y, x columns, feature names, add_intercept flag for the engine, weights or None)."""
     names = [f.output_name for f in features]
@@ -284,12 +283,9 @@ def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], samp
     w = None
     if sample_weights is not None:
         w = parse_into_expr(sample_weights)._column(frame)
-        # sqrt_w = w.sqrt().fill_null(1e-12)  (:193): a null weight acts as weight 1e-24.  The reference's Python layer does this as a
-        # Polars expression over the column; so does this one for the static entries -- folding the select into the kernels' sqrt(w)
-        # was tried and cost the weighted EDGE kernels 25 VGPRs and an occupancy step (157 -> 182 at 8 f32 columns).  The dynamic and
-        # Arrow entries fill on the device (dyn_prep.hip, arrow.hip).
-        if fill_null_weights:
-            w = torch.nan_to_num(w, nan=_EPSILON ** 2) if _is_torch(w) else np.where(np.isnan(w), _EPSILON ** 2, w)
+        # sqrt_w = w.sqrt().fill_null(1e-12)  (:193): a null weight acts as weight 1e-24.  That fill happens BEHIND the C-ABI, on the
+        # device (pols_least_squares: one pass over the weights column unless the batch promises null_free; the dynamic and Arrow
+        # entries in dyn_prep.hip / arrow.hip) -- nothing to do here.
     return target._column(frame), [f._column(frame) for f in features], names, icpt, w
 
 
@@ -360,7 +356,7 @@ def _apply_dynamic(frame: Frame, over, eng: Optional[Engine], target: Expr, feat
     src/expressions.rs:593-701): the plugin gets sqrt_w-scaled, intercept-extended columns, a validity mask from the
     null policy, and zero-filled data (NullPolicy::Zero conversion, ex.rs:603,629,656,683).  All of that is done by the
     C-ABI entries themselves (csrc/dyn_prep.hip); this function only lays the groups out and hands the raw columns over."""
-    y, xs, names, icpt, w = _pre_process_data(frame, target, features, sample_weights, add_intercept, fill_null_weights=False)
+    y, xs, names, icpt, w = _pre_process_data(frame, target, features, sample_weights, add_intercept)
     n = y.shape[0]
     eng = eng or default_engine(y.device.index or 0 if _is_torch(y) else 0)
     policy = kw.null_policy

@@ -186,3 +186,38 @@ def test_rank_deficient_group_under_drop_takes_svd(eng):
     assert int(out["status"][0]) == 1
     assert np.allclose(out["coef"][0], beta, rtol=1e-6, atol=1e-8)
     assert np.allclose(out["pred"], X @ beta, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,n_lo,n_hi", [(3, 30, 900), (8, 900, 1100), (20, 300, 600)])
+def test_null_weights_act_as_1e_24_behind_the_c_abi(eng, dtype, tol, k, n_lo, n_hi):
+    """polars_ols/least_squares.py:193: sqrt_w = w.sqrt().fill_null(1e-12).  pols_least_squares itself does the fill (a device pass
+    over the weights column; nothing in the Python front end): NaN weights straight into the C-ABI, device and host batches, must
+    equal the oracle on the column with 1e-24 in their place -- and the caller's column must come back untouched."""
+    import torch
+
+    rng = np.random.default_rng(31 + k)
+    sizes = rng.integers(n_lo, n_hi, size=9)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    cols = [rng.normal(size=n).astype(dtype) for _ in range(k)]
+    y = (sum(cols) + 0.2 * rng.normal(size=n)).astype(dtype)
+    w = rng.uniform(0.2, 2.0, size=n).astype(dtype)
+    w[rng.random(n) < 0.1] = np.nan
+    w_filled = np.where(np.isnan(w), dtype(1e-24), w).astype(dtype)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w_filled, add_intercept=True, alpha=0.1, l1_ratio=0.0)
+    # (predictions on a null-weight row: (x sqrt_w) . beta / sqrt_w is evaluated with sqrt_w = 1e-12 in both -- compare where the weight is real)
+    real = ~np.isnan(w)
+    for device in (True, False):
+        if device:
+            wt = torch.from_numpy(w).cuda()
+            out = eng.least_squares(torch.from_numpy(y).cuda(), [torch.from_numpy(c).cuda() for c in cols], offs, weights=wt,
+                                    add_intercept=True, alpha=0.1, l1_ratio=0.0, want=("coef", "pred"))
+            got_c, got_p = out["coef"].double().cpu().numpy(), out["pred"].double().cpu().numpy()
+            back = wt.cpu().numpy()
+            assert np.array_equal(np.isnan(back), np.isnan(w)) and np.array_equal(back[real], w[real])
+        else:
+            out = eng.least_squares(y, cols, offs, weights=w, add_intercept=True, alpha=0.1, l1_ratio=0.0, want=("coef", "pred"))
+            got_c, got_p = np.asarray(out["coef"], dtype=np.float64), np.asarray(out["pred"], dtype=np.float64)
+        assert np.allclose(got_c, ref["coef"], rtol=tol, atol=tol), (device, float(np.abs(got_c - ref["coef"]).max()))
+        assert np.allclose(got_p[real], ref["pred"][real], rtol=tol, atol=tol), device

@@ -96,3 +96,25 @@ def test_sharded_argument_errors():
             least_squares_sharded([eng], y, cols, offs, out="device")
     finally:
         eng.close()
+
+
+def test_device_side_assembly_returns_a_rank_failure_instead_of_waiting():
+    """A rank that fails before its collectives (here: the reference's panic for solve_method="qr" with alpha > 0, src/least_squares.rs:366)
+    reports through the host-side rendezvous and the call returns its error -- no rank enters RCCL (with N > 1 the peers would wait for
+    a send / receive that never comes); the contexts and communicators stay usable."""
+    from polars_ols_amd import Engine, PolsError, comm_create_all, least_squares_sharded
+
+    y, cols, offs, _ = _frame(5, np.float64, 3, [200, 150, 90], weights=False)
+    eng = Engine(0)
+    comms = comm_create_all([eng])
+    try:
+        with pytest.raises(PolsError):
+            least_squares_sharded([eng], y, cols, offs, comms=comms, out="device", alpha=0.5, l1_ratio=0.0, solve_method="qr", want=("coef", "pred"))
+        out = least_squares_sharded([eng], y, cols, offs, comms=comms, out="device", want=("coef", "pred"))
+        got = out["coef"].cpu().numpy()
+    finally:
+        for c in comms:
+            c.close()
+        eng.close()
+    ref = orc.batched_least_squares(y, cols, offs)
+    assert np.allclose(got, ref["coef"], rtol=1e-9, atol=1e-9)
