@@ -1460,16 +1460,10 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         const int64_t n_blocks = (n_tiles + 63) / 64;
         const size_t b_rec = round256(sizeof(double) * K3C_NCP * (size_t)n_tiles), b_int = round256(sizeof(int32_t) * (size_t)n_tiles),
                      b_brec = round256(sizeof(double) * K3C_NCP * (size_t)n_blocks), b_bint = round256(sizeof(int32_t) * (size_t)n_blocks),
-                     b_cnt = round256(sizeof(unsigned) * (size_t)(n_blocks + 1)), total = 2 * b_rec + 2 * b_int + 2 * b_brec + b_bint + b_cnt;
+                     total = 2 * b_rec + 2 * b_int + 2 * b_brec + b_bint;
         void *d = nullptr;
         if ((rc = ensure_scratch(ctx, 8, total, &d))) return rc;
         char *base = static_cast<char *>(d);
-        char *cnt = base + 2 * b_rec + 2 * b_int + 2 * b_brec + b_bint;
-        auto &kc = ctx->k3c;
-        if (kc.ptr != d || kc.n_tiles != n_tiles) {               // the arrival counters of a new layout start at zero (every launch leaves them there)
-            POLS_HIP(hipMemsetAsync(cnt, 0, b_cnt, ctx->stream));
-            kc.ptr = d; kc.n_tiles = n_tiles;
-        }
         const uint8_t *flags = nullptr;
         if ((rc = ensure_start_flags(ctx, d_offs, b->n_groups, N, &flags))) return rc;
         K3cArgs c;
@@ -1482,9 +1476,9 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         c.rec_closed = reinterpret_cast<int32_t *>(base + 2 * b_rec); c.carry_open = reinterpret_cast<int32_t *>(base + 2 * b_rec + b_int);
         c.brec = reinterpret_cast<double *>(base + 2 * b_rec + 2 * b_int); c.bcarry = reinterpret_cast<double *>(base + 2 * b_rec + 2 * b_int + b_brec);
         c.brec_closed = reinterpret_cast<int32_t *>(base + 2 * b_rec + 2 * b_int + 2 * b_brec);
-        c.blk_arrive = reinterpret_cast<unsigned *>(cnt); c.all_arrive = reinterpret_cast<unsigned *>(cnt) + n_blocks;
         c.n_tiles = n_tiles; c.k = kf;
-        if ((rc = k3c_launch(ctx, b->dtype, c))) { ctx->k3c.ptr = nullptr; return rc; }
+        c.all_closed = max_rows <= tile_rows ? 1 : 0;            // (any tile_rows consecutive rows then hold a sequence start)
+        if ((rc = k3c_launch(ctx, b->dtype, c))) return rc;
     } else if (scan) {
         const int k = kf;
         K4Args s4;

@@ -16,13 +16,14 @@
 //   B  segmented inclusive scan over the 64 lanes                      (6 DPP steps x (NT + 1) components; a lane only combines
 //      with a partner in its own sequence -- exec-masked, so nothing ever crosses a sequence boundary, not even a NaN)
 //   C  wave aggregates meet in LDS -> the tile's aggregate.  The tiles' carry-ins come from a scan over the tile aggregates, and that
-//      needs every aggregate first: TWO launches.  Pass 1 (this kernel, MODE 0) stops after C and publishes the tile's record; the
-//      LAST tile of each block of 64 tiles to arrive (an arrival counter -- nobody ever waits) scans its block's 64 records, and the
-//      last BLOCK to arrive scans the block totals: when pass 1 ends every tile's carry-in is in memory as [its block's carry-in] .
-//      [the tiles of its block below it].  Pass 2 (MODE 1) repeats A-B from the same rows (their second read: the Infinity Cache
-//      holds what pass 1 streamed) and goes on to D.  A single-launch form with a decoupled look-back over published records
-//      (round 4: tickets, tagged write-through granules, two levels of records) measured 96 us on the 1M-row sequence and 488 us on
-//      10 000 x 1 000 rows against 5x / 4xx for the two launches: every tile waits 27-60 k cycles for the tiles running beside it.
+//      needs every aggregate first: pass 1 (this kernel, MODE 0) stops after C and writes the tile's record; the records are scanned
+//      (k3c_block_scan_kernel: one wave per 64 tiles, k3c_top_scan_kernel: one wave over the block totals) -- or not at all when no
+//      sequence is longer than a tile, because then every tile holds a sequence start and tile t's carry-in is tile t - 1's record;
+//      pass 2 (MODE 1) repeats A-B from the same rows (their second read: the Infinity Cache holds what pass 1 streamed) and goes
+//      on to D.  Measured and not adopted (round 4): a single launch with a decoupled look-back over published records (tickets,
+//      tagged write-through granules, two levels of records) -- 96 us on the 1M-row sequence and 488 us on 10 000 x 1 000 rows,
+//      every tile waits 27-60 k cycles for the tiles running beside it; the scans done inside pass 1 by the last tile / block to
+//      arrive -- pass 1 14 -> 34 us (write-through stores, drained store queues, a two-level serial tail).
 //   D  every lane walks its R rows from its carry-in: A' = ff A + x x', one K x K solve per row (square-root-free L D L', LU on
 //      a non-positive pivot like the reference's Cholesky -> LU chain), coefficients and predictions stored 16 bytes at a time.
 // The information matrix is solved directly on every row -- never inverted and propagated -- so a diffuse prior (p0 = 1e6, the
@@ -64,9 +65,6 @@ __device__ __forceinline__ void k3c_seg_scan(double &D, double (&Tv)[NT], const 
 }
 
 
-__device__ __forceinline__ double k3c_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void k3c_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 template <typename T, int R>
 __device__ __forceinline__ void k3c_load_run(const void *col, int64_t row0, double (&out)[R]) {
     using V = typename Vec16<T>::type;
@@ -78,6 +76,84 @@ __device__ __forceinline__ void k3c_load_run(const void *col, int64_t row0, doub
         const V v = load_stream(p + i);
 #pragma unroll
         for (int j = 0; j < VN; ++j) out[i * VN + j] = (double)vget<T>(v, j);
+    }
+}
+
+// One wave scans a window of up to 64 records (lane l <-> record first + l, l < count): writes every record's exclusive composite --
+// from the last closed record below it in the window, or, nothing closed below, with carry_in (one component per lane, slot NT the
+// decay) prepended when there is one -- and whether it is still open; returns "some record of the window is closed" and leaves the
+// window's inclusive composite in lane 63's (Dl, Tl).
+template <int NT>
+__device__ __forceinline__ bool k3c_scan_window(const double *rec, const int32_t *closed, int64_t first, int64_t count, double *excl,
+                                                int32_t *open_out, double &Dl, double (&Tl)[NT], bool carry_in_valid, double carry_in_q,
+                                                const int lane) {
+    const bool in = lane < count;
+    const int64_t r = first + (in ? lane : 0);
+    Dl = 1.0;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) Tl[q] = in ? rec[r * K3C_NCP + q] : 0.0;
+    if (in) Dl = rec[r * K3C_NCP + NT];
+    const bool head = in && closed[r] != 0;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long up2 = hm & (~0ull >> (63 - lane));
+    k3c_seg_scan<NT>(Dl, Tl, up2 ? 63 - __clzll(up2) : -1, lane);
+    double ED2 = dpp_get<0x138>(Dl), ET2[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) ET2[q] = dpp_get<0x138>(Tl[q]);
+    if (lane == 0) {
+        ED2 = 1.0;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) ET2[q] = 0.0;
+    }
+    const bool open = (hm & ((1ull << lane) - 1ull)) == 0;
+    if (open && carry_in_valid) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) ET2[q] = fma(ED2, k1p_readlane(carry_in_q, q), ET2[q]);
+        ED2 *= k1p_readlane(carry_in_q, NT);
+    }
+    if (in) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) excl[r * K3C_NCP + q] = ET2[q];
+        excl[r * K3C_NCP + NT] = ED2;
+        if (open_out) open_out[r] = open ? 1 : 0;
+    }
+    return hm != 0;
+}
+
+// Between the passes, launch 1 (one wave per block of 64 tiles): every tile's carry-in relative to its block's start, the block's record.
+template <int NT>
+__global__ void __launch_bounds__(64) k3c_block_scan_kernel(const K3cArgs a) {
+    const int lane = threadIdx.x;
+    const int64_t blk = blockIdx.x;
+    const int64_t left = a.n_tiles - (blk << 6), cnt = left < 64 ? left : 64;
+    double Dl, Tl[NT];
+    const bool bclosed = k3c_scan_window<NT>(a.rec, a.rec_closed, blk << 6, cnt, a.carry, a.carry_open, Dl, Tl, false, 0.0, lane);
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) a.brec[blk * K3C_NCP + q] = Tl[q];
+        a.brec[blk * K3C_NCP + NT] = Dl;
+        a.brec_closed[blk] = bclosed ? 1 : 0;
+    }
+}
+
+// Between the passes, launch 2 (one wave): every block's carry-in, 64 blocks per step, the steps chained.
+template <int NT>
+__global__ void __launch_bounds__(64) k3c_top_scan_kernel(const K3cArgs a) {
+    const int lane = threadIdx.x;
+    const int64_t n_blocks = (a.n_tiles + 63) >> 6;
+    double chain = (lane == NT) ? 1.0 : 0.0;                     // composite of the steps so far (from their last closed block), per component
+    bool chain_valid = false;
+    double Dl, Tl[NT];
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += 64) {
+        const int64_t cnt = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
+        const bool anyc = k3c_scan_window<NT>(a.brec, a.brec_closed, b0, cnt, a.bcarry, nullptr, Dl, Tl, chain_valid, chain, lane);
+        double wq = 0.0;                                         // the window's composite (lane 63) spread one component per lane
+#pragma unroll
+        for (int q = 0; q < NT; ++q) { const double v = k1p_readlane(Tl[q], 63); wq = (lane == q) ? v : wq; }
+        { const double v = k1p_readlane(Dl, 63); wq = (lane == NT) ? v : wq; }
+        if (anyc || !chain_valid) chain = wq;
+        else { const double wD = k1p_readlane(wq, NT); chain = (lane == NT) ? chain * wq : fma(wD, chain, wq); }
+        chain_valid = true;
     }
 }
 
@@ -223,9 +299,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     }
     K3C_STAMP(2);
     if constexpr (MODE == 0) {
-        // pass 1: the tile's record -- its aggregate from the last sequence start inside it on, and whether there is one.  Records
-        // that another workgroup reads inside this launch travel write-through (sc1 stores, sc1 loads: no fences), counted in by a
-        // relaxed atomic behind a drained store queue (MI355X_MICROARCH.md, hand-off forms).
+        // pass 1: the tile's record -- its aggregate from the last sequence start inside it on, and whether there is one
         if (wv != WAVES - 1) return;
         double agg = run;
         bool tclosed = !wopen;
@@ -234,90 +308,18 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
             if (s_closed[wv]) { agg = eq; tclosed = true; }
             else agg = (lane == NT) ? agg * eD : fma(eD, agg, eq);
         }
-        if (lane <= NT) k3c_st(a.rec + t * K3C_NCP + lane, agg);
-        if (lane == 0) __hip_atomic_store(a.rec_closed + t, tclosed ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int64_t blk = t >> 6, n_blocks = (a.n_tiles + 63) >> 6;
-        const int64_t blk_size = (a.n_tiles - (blk << 6) < 64) ? a.n_tiles - (blk << 6) : 64;
-        int arrived = 0;
-        if (lane == 0) arrived = (int)__hip_atomic_fetch_add(a.blk_arrive + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived != (int)blk_size - 1) return;
-        // ---- the last tile of its block: the block's 64 records -> every tile's carry-in relative to the block's start
-        if (lane == 0) __hip_atomic_store(a.blk_arrive + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next launch)
-        auto scan_records = [&](const double *rec, const int32_t *closed, int64_t first, int64_t count, double *excl, int32_t *open_out,
-                                double &Dl, double (&Tl)[NT], bool carry_in_valid, double carry_in_q) -> bool {
-            // lane l <-> record first + l (l < count); writes the exclusive composite of every record (from the last closed one below
-            // it in this window, or -- nothing closed below -- with carry_in prepended when there is one) and whether it is still
-            // open; returns "some record is closed", leaves the inclusive composite of the window in lane 63's (Dl, Tl)
-            const bool in = lane < count;
-            const int64_t r = first + (in ? lane : 0);
-            Dl = 1.0;
-#pragma unroll
-            for (int q = 0; q < NT; ++q) Tl[q] = in ? k3c_ld(rec + r * K3C_NCP + q) : 0.0;
-            if (in) Dl = k3c_ld(rec + r * K3C_NCP + NT);
-            const bool head = in && __hip_atomic_load(closed + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            const unsigned long long hm = __ballot(head);
-            const unsigned long long up2 = hm & (~0ull >> (63 - lane));
-            k3c_seg_scan<NT>(Dl, Tl, up2 ? 63 - __clzll(up2) : -1, lane);
-            double ED2 = dpp_get<0x138>(Dl), ET2[NT];
-#pragma unroll
-            for (int q = 0; q < NT; ++q) ET2[q] = dpp_get<0x138>(Tl[q]);
-            if (lane == 0) {
-                ED2 = 1.0;
-#pragma unroll
-                for (int q = 0; q < NT; ++q) ET2[q] = 0.0;
-            }
-            const bool open = (hm & ((1ull << lane) - 1ull)) == 0;
-            if (open && carry_in_valid) {                    // carry_in . [the records below]: the carry-in arrives one component per lane
-#pragma unroll
-                for (int q = 0; q < NT; ++q) ET2[q] = fma(ED2, k1p_readlane(carry_in_q, q), ET2[q]);
-                ED2 *= k1p_readlane(carry_in_q, NT);
-            }
-            if (in) {
-#pragma unroll
-                for (int q = 0; q < NT; ++q) excl[r * K3C_NCP + q] = ET2[q];
-                excl[r * K3C_NCP + NT] = ED2;
-                if (open_out) open_out[r] = open ? 1 : 0;
-            }
-            return hm != 0;
-        };
-        double Dl2, Tl2[NT];
-        const bool bclosed = scan_records(a.rec, a.rec_closed, blk << 6, blk_size, a.carry, a.carry_open, Dl2, Tl2, false, 0.0);
-        // lane 63 holds the block's inclusive composite: the block record
-        if (lane == 63) {
-#pragma unroll
-            for (int q = 0; q < NT; ++q) k3c_st(a.brec + blk * K3C_NCP + q, Tl2[q]);
-            k3c_st(a.brec + blk * K3C_NCP + NT, Dl2);
-            __hip_atomic_store(a.brec_closed + blk, bclosed ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int barrived = 0;
-        if (lane == 63) barrived = (int)__hip_atomic_fetch_add(a.all_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        barrived = __builtin_amdgcn_readlane(barrived, 63);
-        if (barrived != (int)n_blocks - 1) return;
-        // ---- the last block: the block records -> every block's carry-in, 64 blocks per step, the steps chained
-        if (lane == 0) __hip_atomic_store(a.all_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double chain = (lane == NT) ? 1.0 : 0.0;             // composite of the steps so far (from their last closed block), per component
-        bool chain_valid = false;
-        for (int64_t b0 = 0; b0 < n_blocks; b0 += 64) {
-            const int64_t cnt = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
-            const bool anyc = scan_records(a.brec, a.brec_closed, b0, cnt, a.bcarry, nullptr, Dl2, Tl2, chain_valid, chain);
-            // chain = anyc ? window : chain . window   (the window's composite sits in lane 63: spread it one component per lane)
-            double wq = 0.0;
-#pragma unroll
-            for (int q = 0; q < NT; ++q) { const double v = k1p_readlane(Tl2[q], 63); wq = (lane == q) ? v : wq; }
-            { const double v = k1p_readlane(Dl2, 63); wq = (lane == NT) ? v : wq; }
-            if (anyc || !chain_valid) chain = wq;
-            else { const double wD = k1p_readlane(wq, NT); chain = (lane == NT) ? chain * wq : fma(wD, chain, wq); }
-            chain_valid = true;
-        }
+        // (all_closed -- no sequence longer than a tile, the host knows: every tile holds a sequence start, tile t + 1's carry-in IS
+        // this record and nothing scans them.  Otherwise two small launches between the passes do.)
+        if (lane <= NT) a.rec[t * K3C_NCP + lane] = agg;
+        if (lane == 0 && !a.all_closed) a.rec_closed[t] = tclosed ? 1 : 0;
         return;
     }
     {
         // pass 2: the tile's carry-in = [its block's carry-in] . [the tiles of its block below it], both written by pass 1
-        double cq = a.carry[t * K3C_NCP + ql];
-        if (a.carry_open[t] && t >= 64) {
+        double cq;
+        if (a.all_closed) cq = a.rec[(t > 0 ? t - 1 : 0) * K3C_NCP + ql];     // (tile 0 starts with a sequence start: its carry-in is never used)
+        else cq = a.carry[t * K3C_NCP + ql];
+        if (!a.all_closed && a.carry_open[t] && t >= 64) {
             const double bq = a.bcarry[(t >> 6) * K3C_NCP + ql];
             const double cD = k1p_readlane(cq, NT);
             cq = (lane == NT) ? bq * cq : fma(cD, bq, cq);
@@ -391,10 +393,14 @@ static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
         if (rc) return rc;
         a.dbg = static_cast<unsigned long long *>(dbg);
     }
-    timing_begin(ctx);                                            // the two launches as one timed span
+    timing_begin(ctx);                                            // all launches of the call as one timed span
     K3cArgs a1 = a;
     a1.dbg = nullptr;
     hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 0>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a1);
+    if (!a.all_closed) {                                          // sequences longer than a tile: the records are scanned (two small launches)
+        hipLaunchKernelGGL((k3c_block_scan_kernel<K4N<K>::N>), dim3((unsigned)((a.n_tiles + 63) / 64)), dim3(64), 0, ctx->stream, a1);
+        hipLaunchKernelGGL((k3c_top_scan_kernel<K4N<K>::N>), dim3(1), dim3(64), 0, ctx->stream, a1);
+    }
     hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 1>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a);
     timing_end(ctx);
     POLS_HIP(hipGetLastError());

@@ -87,12 +87,11 @@ struct K3cArgs {
     double ff, p0;
     // pass 1 -> pass 2: one record per tile (K3C_NCP doubles: the aggregate from the tile's last sequence start on, slot NT its
     // decay) and whether the tile holds a sequence start; per tile the composite of the tiles of its 64-tile block below it and
-    // whether it is still open (no sequence start among them); the same per block: records, carry-ins.  The arrival counters are
-    // zero between launches (the last arriver resets them).
+    // whether it is still open (no sequence start among them); the same per block: records, carry-ins
     double *rec, *carry, *brec, *bcarry;
     int32_t *rec_closed, *carry_open, *brec_closed;
-    unsigned *blk_arrive, *all_arrive;
     int64_t n_tiles;
+    int32_t all_closed;                // no sequence is longer than a tile: every tile holds a sequence start, tile t's carry-in is tile t - 1's record
     unsigned long long *dbg;           // POLS_TIMELINE: 8 words per tile (s_memtime stamps of the tile's last wave) or nullptr
     int32_t k;
 };
