@@ -160,7 +160,7 @@ def make_columns(n: int, feats: int, tdt, seed: int, weights: bool = False):
     return y, cols, w
 
 
-def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: str, frame: int = 0):
+def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: str, frame: int = 0, groups: int = 0):
     """Returns dict(plan, units, unit, alg_bytes, text, dtype, coef, scaling, shard).  `frame`: which of the rotated synthetic frames
     (another seed, same shape)."""
     from polars_ols_amd.distributed import shard_for_rank
@@ -193,7 +193,7 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
         text = "BASELINE configs[0]: ONE group, 10000 rows x 4 feats f64 OLS mode=coefficients (the per-plugin-call shape)"
         return dict(plan=plan, units=1, unit="problems/s", alg_bytes=nbytes, text=text, dtype="f64", coef=None, scaling="weak", shard=shard)
     if cfg == "cfg2":
-        G_per, n, k = 10_000, 1_000, 8
+        G_per, n, k = (groups or 10_000), 1_000, 8
         tdt = torch.float32 if dtype_flag == "f32" else torch.float64
         b = 4 if dtype_flag == "f32" else 8
         plan, G, nbytes, coef, shard = grouped(G_per * world, n, k, tdt, b)
@@ -201,7 +201,7 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
                 f"(+coefficients), inputs resident in {'host memory (POLS_MEM_HOST)' if host else 'HBM'}, per GPU")
         return dict(plan=plan, units=G, unit="regressions/s", alg_bytes=nbytes, text=text, dtype=dtype_flag, coef=coef, scaling="weak", shard=shard)
     if cfg == "cfg3":
-        G_per, n, k = 10_000, 1_000, 8
+        G_per, n, k = (groups or 10_000), 1_000, 8
         plan, G, nbytes, coef, shard = grouped(G_per * world, n, k, torch.float64, 8, weights=True, alpha=1.0, l1_ratio=0.0)
         text = f"BASELINE configs[2]: {G} groups x {n} rows x {k} feats f64 ridge alpha=1.0 + sample_weights, predictions, per GPU"
         return dict(plan=plan, units=G, unit="regressions/s", alg_bytes=nbytes, text=text, dtype="f64", coef=coef, scaling="weak", shard=shard)
@@ -246,7 +246,7 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
                 f"predictions; published 17.6 ms per call on an M2 Max incl. Polars overhead")
         return dict(plan=plan, units=1, unit="problems/s", alg_bytes=8 * n * (k + 1) + 8 * n, text=text, dtype="f64", coef=None, scaling="weak", shard=None)
     if cfg == "cfg5":
-        Gtot, n, k = 100_000, 2_000, 16
+        Gtot, n, k = (groups or 100_000), 2_000, 16
         plan, G, nbytes, coef, shard = grouped(Gtot, n, k, torch.float64, 8, alpha=0.001, l1_ratio=0.5, want=("coef", "pred"))
         text = (f"BASELINE configs[4]: {Gtot} groups x {n} rows x {k} feats f64 elastic net alpha=0.001 l1_ratio=0.5, "
                 f"predictions (+coefficients), groups split over {world} GPU(s): {G} on this one")
@@ -265,6 +265,8 @@ def main() -> None:
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4r", "rlsg", "rlsgr", "cfg5", "ref100"])
     ap.add_argument("--mem", default="device", choices=["device", "host"])
     ap.add_argument("--frames", type=int, default=0, help="rotate the steps over this many independent frames (0: automatic)")
+    ap.add_argument("--groups", type=int, default=0, help="cfg2 / cfg3 / cfg5: this many groups (per GPU for cfg2 / cfg3, in total for cfg5) "
+                                                         "instead of the config's own count -- e.g. 12500 = the 8-GPU shard of cfg5 on one GPU")
     ap.add_argument("--gather", default="coef", choices=["coef", "pred", "none"], help="N > 1: what is re-assembled every step")
     args = ap.parse_args()
 
@@ -295,7 +297,7 @@ def main() -> None:
     # run the engine on a torch-visible stream so torch events can order the collective's stream against it
     eng_stream = torch.cuda.Stream()
     eng.set_stream(eng_stream.cuda_stream)
-    wl = build_workload(args.config, eng, rank, world, args.dtype, args.mem)
+    wl = build_workload(args.config, eng, rank, world, args.dtype, args.mem, groups=args.groups)
     plan, coef, shard = wl["plan"], wl["coef"], wl["shard"]
     # Frame rotation: a 360 MB frame re-read every step could live in part in the 256 MB Infinity Cache; rotating over frames whose
     # inputs add up to more than three times that makes every step stream its input from HBM.  Outputs go to the first frame's
@@ -307,7 +309,7 @@ def main() -> None:
         n_frames = max(3, n_frames)
     plans = [plan]
     for f in range(1, n_frames):
-        w2 = build_workload(args.config, eng, rank, world, args.dtype, args.mem, frame=f)
+        w2 = build_workload(args.config, eng, rank, world, args.dtype, args.mem, frame=f, groups=args.groups)
         for key in ("coef", "pred", "resid"):
             if key in plan.results and key in w2["plan"].results:
                 w2["plan"].set_output(key, plan.results[key])
@@ -469,7 +471,7 @@ def main() -> None:
         traffic_source = None
         try:
             pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-            entry = pmc.get(kernel_name, {})
+            entry = pmc.get(f"{kernel_name}|{args.config}") or pmc.get(kernel_name, {})
             if entry.get("config", "cfg2") == args.config and args.mem == "device" and world == 1:
                 traffic = entry.get("traffic_bytes")
                 traffic_source = {"file": "profiles/pmc_traffic.json", "kernel": kernel_name, "round": entry.get("round"),
