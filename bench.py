@@ -419,12 +419,14 @@ def main() -> None:
     eng.timing(False)
     kernel_name = eng.last_kernel
     # at least 16 kernel-duration samples whatever --steps is: a sampled pass over the same frames right behind the timed region
-    # (outside it), every second launch stamped so that an event-bracketed launch still has an un-bracketed neighbour on either side
+    # (outside it) with the SAME stride -- an event-bracketed launch cannot overlap its neighbours' ramp-up / tail, and the fewer
+    # un-bracketed launches sit between two bracketed ones the longer a bracketed one measures (stride 2: 76.4 us, stride 8: 74 us,
+    # rocprofv3 on every launch: 72.2 us for the headline kernel)
     MIN_SAMPLES = 16
     samples_in_region = len(kernel_ms)
     if len(kernel_ms) < MIN_SAMPLES and pred_state is None and ring is None:
-        eng.timing(2)
-        for _ in range(2 * (MIN_SAMPLES - len(kernel_ms)) + 2):
+        eng.timing(stride)
+        for _ in range(stride * (MIN_SAMPLES - len(kernel_ms)) + 1):
             step()
         torch.cuda.synchronize()
         kernel_ms += list(eng.timing_collect())
@@ -440,8 +442,8 @@ def main() -> None:
             for p in plans:
                 p.stream_probe(mode)
             torch.cuda.synchronize()
-            eng.timing(2)
-            for i in range(max(args.steps, 2 * MIN_SAMPLES, 3 * len(plans))):
+            eng.timing(stride)
+            for i in range(max(args.steps, stride * MIN_SAMPLES, 3 * len(plans))):
                 plans[i % len(plans)].stream_probe(mode)
             torch.cuda.synchronize()
             pm = eng.timing_collect()
@@ -472,7 +474,7 @@ def main() -> None:
         try:
             pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
             entry = pmc.get(f"{kernel_name}|{args.config}") or pmc.get(kernel_name, {})
-            if entry.get("config", "cfg2") == args.config and args.mem == "device" and world == 1:
+            if entry.get("config", "cfg2") == args.config and args.mem == "device" and world == 1 and not args.groups:
                 traffic = entry.get("traffic_bytes")
                 traffic_source = {"file": "profiles/pmc_traffic.json", "kernel": kernel_name, "round": entry.get("round"),
                                   "from": entry.get("source")}
