@@ -23,7 +23,8 @@
 //      on to D.  Measured and not adopted (round 4): a single launch with a decoupled look-back over published records (tickets,
 //      tagged write-through granules, two levels of records) -- 96 us on the 1M-row sequence and 488 us on 10 000 x 1 000 rows,
 //      every tile waits 27-60 k cycles for the tiles running beside it; the scans done inside pass 1 by the last tile / block to
-//      arrive -- pass 1 14 -> 34 us (write-through stores, drained store queues, a two-level serial tail).
+//      arrive -- pass 1 14 -> 34 us (write-through stores, drained store queues, a two-level serial tail); both record scans in one
+//      16-wave workgroup -- 58 -> 79 us on the 1M-row sequence (458 KB through ONE CU's memory pipe instead of 16).
 //   D  every lane walks its R rows from its carry-in: A' = ff A + x x', one K x K solve per row (square-root-free L D L', LU on
 //      a non-positive pivot like the reference's Cholesky -> LU chain), coefficients and predictions stored 16 bytes at a time.
 // The information matrix is solved directly on every row -- never inverted and propagated -- so a diffuse prior (p0 = 1e6, the
