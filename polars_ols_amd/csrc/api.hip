@@ -952,7 +952,11 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             a2.lu_fallback = (!enet && !ols_branch && m != POLS_SOLVE_SVD) ? 1 : 0;
             a2.alpha = enet ? alpha : ridge_alpha;
             a2.l1_ratio = enet_l1; a2.tol = p->tol; a2.max_iter = p->max_iter; a2.positive = positive ? 1 : 0;
-            a2.pivot_tol = pivot_tol;
+            // (an engine that re-solves a flagged group IN the kernel with LU does so on the same Gram matrix: only a genuinely failed
+            // factorisation -- a non-positive or noise pivot -- may take that route.  The f32 ridge branch's conditioning tolerance
+            // (1e-3: those groups get the reference's chain in f64 from the fix-up pass on the K1 / K2w routes) is not applied here,
+            // so that one ill-conditioned group does not get different numerics by the route its shape takes.)
+            a2.pivot_tol = a2.lu_fallback ? chol_noise : pivot_tol;
             a2.fb_flag = enet ? nullptr : ctx->fb_flag; a2.epoch = ctx->epoch;
             if ((rc = k2_launch(ctx, b->dtype, a2, max_rows))) return rc;
             if ((rc = svd_fixup())) return rc;
@@ -1036,9 +1040,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             if ((rc = gram_cd_launch(ctx, b->dtype, ca))) return rc;
         } else {
             ca.alpha = ridge_alpha;
-            ca.pivot_tol = pivot_tol;
             ca.solver = (m == POLS_SOLVE_LU) ? 1 : 0;
             ca.lu_fallback = (!ols_branch && m != POLS_SOLVE_SVD) ? 1 : 0;
+            ca.pivot_tol = ca.lu_fallback ? chol_noise : pivot_tol;   // (see K2 above)
             ca.fb_flag = ctx->fb_flag; ca.epoch = ctx->epoch;
             if ((rc = gram_solve_launch(ctx, b->dtype, ca))) return rc;
         }

@@ -285,30 +285,37 @@ static void make_array(ArrowArray *a, int64_t length, int64_t n_buffers, int64_t
 template <typename T>
 static int export_column(pols_ctx *ctx, const T *dvals, int64_t n, bool nan_is_null, char *dscratch, ArrowArray *out, int64_t stride = 1) {
     make_array(out, n, 2, 0);
+    // Both host buffers exist BEFORE the first copy is queued, and no early return leaves a copy in flight behind it: the caller
+    // answers an error with release_array(out), which frees these buffers -- a DMA still landing in them would write freed memory.
+    const int64_t nbytes = (n + 7) / 8;
     void *hv = std::malloc(std::max<size_t>(1, (size_t)n * sizeof(T)));
-    if (!hv) return fail(POLS_ERR_INVALID, "out of host memory");
+    void *hb = (nan_is_null && n) ? std::malloc((size_t)nbytes + sizeof(unsigned long long)) : nullptr;   // bitmap, then the null count behind it
     out->buffers[1] = hv;                                     // owned by `out` from here on: an early return leaks nothing
-    unsigned long long *hn = nullptr;                         // pinned? no: a malloc'd word the copy lands in before the sync below
+    out->buffers[0] = hb;
+    if (!hv || (nan_is_null && n && !hb)) return fail(POLS_ERR_INVALID, "out of host memory");
+    unsigned long long *hn = nullptr;
+    auto queued = [&](hipError_t e, const char *what) -> int {   // a failed call behind queued copies: drain the stream, then report
+        if (e == hipSuccess) return POLS_OK;
+        (void)hipStreamSynchronize(ctx->stream);
+        return fail(POLS_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    int rc;
     if (n && stride != 1) {                                   // column j of a row-major table -> contiguous
         T *dcol = reinterpret_cast<T *>(dscratch);
-        POLS_HIP(hipMemcpy2DAsync(dcol, sizeof(T), dvals, sizeof(T) * (size_t)stride, sizeof(T), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        if ((rc = queued(hipMemcpy2DAsync(dcol, sizeof(T), dvals, sizeof(T) * (size_t)stride, sizeof(T), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpy2DAsync"))) return rc;
         dvals = dcol;
         dscratch += round256((size_t)n * sizeof(T));
     }
-    if (n) POLS_HIP(hipMemcpyAsync(hv, dvals, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    if (n && (rc = queued(hipMemcpyAsync(hv, dvals, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync"))) return rc;
     if (nan_is_null && n) {
-        const int64_t nbytes = (n + 7) / 8;
         uint8_t *dbits = reinterpret_cast<uint8_t *>(dscratch);
         unsigned long long *dcnt = reinterpret_cast<unsigned long long *>(dscratch + round256((size_t)nbytes));
-        POLS_HIP(hipMemsetAsync(dcnt, 0, sizeof(*dcnt), ctx->stream));
+        if ((rc = queued(hipMemsetAsync(dcnt, 0, sizeof(*dcnt), ctx->stream), "hipMemsetAsync"))) return rc;
         hipLaunchKernelGGL((arrow_validity_kernel<T>), dim3((unsigned)((nbytes + 255) / 256)), dim3(256), 0, ctx->stream, dvals, n, dbits, dcnt);
-        POLS_HIP(hipGetLastError());
-        void *hb = std::malloc((size_t)nbytes + sizeof(unsigned long long));   // bitmap, then the null count behind it
-        if (!hb) return fail(POLS_ERR_INVALID, "out of host memory");
-        out->buffers[0] = hb;
+        if ((rc = queued(hipGetLastError(), "arrow_validity_kernel"))) return rc;
         hn = reinterpret_cast<unsigned long long *>(static_cast<char *>(hb) + nbytes);
-        POLS_HIP(hipMemcpyAsync(hb, dbits, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
-        POLS_HIP(hipMemcpyAsync(hn, dcnt, sizeof(*hn), hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = queued(hipMemcpyAsync(hb, dbits, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync"))) return rc;
+        if ((rc = queued(hipMemcpyAsync(hn, dcnt, sizeof(*hn), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync"))) return rc;
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(POLS_ERR_HIP, "stream synchronisation failed");   // (nothing of ours is queued any more)
     if (hn) {

@@ -289,6 +289,10 @@ def _pre_process_data(frame: Frame, target: Expr, features: Sequence[Expr], samp
     return target._column(frame), [f._column(frame) for f in features], names, icpt, w
 
 
+def _has_nan(a) -> bool:
+    return bool(torch.isnan(a).any()) if _is_torch(a) else bool(np.isnan(a).any())
+
+
 def _ones_like(a):
     return torch.ones_like(a) if _is_torch(a) else np.ones_like(a)
 
@@ -421,9 +425,13 @@ def compute_multi_target_least_squares(targets, *features, sample_weights=None, 
         moved = grp.take([w] + list(ys) + list(xs))
         w_s, ys_s, xs_s = moved[0], moved[1:1 + len(ys)], moved[1 + len(ys):]
         # joint validity mask, fit on the rows it leaves, every row predicted from zero-filled features, "drop" masked
-        # (ex.rs:539-585): all of it inside the entry (csrc/dyn_prep.hip)
+        # (ex.rs:539-585): all of it inside the entry (csrc/dyn_prep.hip).  A Polars caller reads null_count off its Series; here the
+        # columns are arrays, so the null count is one reduction per column -- cheap next to the compaction pass (every column read
+        # AND rewritten) that the entry runs whenever it cannot be promised a null-free frame.
+        null_free = not any(_has_nan(c) for c in list(ys_s) + list(xs_s) + ([w_s] if w_s is not None else []))
         preds = eng.multi_target_least_squares(ys_s, xs_s, offs, weights=w_s, add_intercept=icpt, want=("pred",), alpha=kw.alpha,
-                                               solve_method=kw.solve_method, rcond=kw.rcond, null_policy=kw.null_policy)["pred"]
+                                               solve_method=kw.solve_method, rcond=kw.rcond, null_policy=kw.null_policy,
+                                               null_free=null_free)["pred"]
         out = {}
         for t, y_s, pr in zip(ts, ys_s, preds):
             val = pr if mode == "predictions" else y_s - pr
