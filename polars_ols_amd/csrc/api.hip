@@ -1472,6 +1472,32 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         if ((rc = ensure_start_flags(ctx, d_offs, b->n_groups, N, &flags))) return rc;
         K3cArgs c;
         std::memset(&c, 0, sizeof(c));
+        // No sequence longer than a tile (less the three rows a tile may start before its first sequence): tiles are cut at sequence
+        // starts -- whole sequences, first fit in frame order -- and need no carry-in, so ONE launch reads and writes the frame once.
+        // Taken when the packed tiles are at least 70 % full (the two-pass form costs about 1.5 launches of full tiles).
+        int64_t n_packed = 0;
+        if (max_rows <= tile_rows - 3 && ctx->opt.rls_engine != 2) {
+            auto &tc = ctx->k3c;
+            void *dmap = nullptr;
+            if ((rc = ensure_scratch(ctx, 18, round256(sizeof(int64_t) * (size_t)(b->n_groups + 2)), &dmap))) return rc;
+            if (tc.ptr != dmap || tc.offs_id != ctx->offs_id || tc.n_groups != b->n_groups || tc.n_rows != N || tc.tile_rows != tile_rows) {
+                tc.ptr = nullptr;
+                std::vector<int64_t> first;
+                const int64_t *offs = b->group_offsets;
+                int64_t base = -1;
+                for (int64_t g = 0; g < b->n_groups; ++g) {
+                    if (offs[g + 1] == offs[g]) continue;
+                    if (base < 0 || offs[g + 1] - base > tile_rows) { first.push_back(offs[g]); base = offs[g] & ~(int64_t)3; }
+                }
+                const int64_t nt = (int64_t)first.size();
+                first.push_back(N);
+                tc.n_tiles = nt * tile_rows * 7 <= N * 10 ? nt : 0;
+                if (tc.n_tiles && (rc = upload_small(ctx, dmap, first.data(), sizeof(int64_t) * first.size()))) return rc;
+                tc.ptr = dmap; tc.offs_id = ctx->offs_id; tc.n_groups = b->n_groups; tc.n_rows = N; tc.tile_rows = tile_rows;
+            }
+            n_packed = tc.n_tiles;
+            if (n_packed) c.tile_row0 = static_cast<const int64_t *>(dmap);
+        }
         c.y = st.y; c.valid = st.valid; c.start = flags;
         for (int j = 0; j < kf; ++j) c.x[j] = st.x[j];
         c.n_rows = N; c.coef = st.coef; c.pred = st.pred; c.mean0 = a.mean0;
@@ -1480,8 +1506,8 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         c.rec_closed = reinterpret_cast<int32_t *>(base + 2 * b_rec); c.carry_open = reinterpret_cast<int32_t *>(base + 2 * b_rec + b_int);
         c.brec = reinterpret_cast<double *>(base + 2 * b_rec + 2 * b_int); c.bcarry = reinterpret_cast<double *>(base + 2 * b_rec + 2 * b_int + b_brec);
         c.brec_closed = reinterpret_cast<int32_t *>(base + 2 * b_rec + 2 * b_int + 2 * b_brec);
-        c.n_tiles = n_tiles; c.k = kf;
-        c.all_closed = max_rows <= tile_rows ? 1 : 0;            // (any tile_rows consecutive rows then hold a sequence start)
+        c.n_tiles = n_packed ? n_packed : n_tiles; c.k = kf;
+        c.all_closed = n_packed || max_rows <= tile_rows ? 1 : 0;   // (any tile_rows consecutive rows then hold a sequence start)
         if ((rc = k3c_launch(ctx, b->dtype, c))) return rc;
     } else if (scan) {
         const int k = kf;

@@ -82,7 +82,7 @@ struct pols_ctx {
     // [7] status words, [8] K3c tile / block records, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
-    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18..23] free
+    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..23] free
     pols::Scratch scratch[24];
     pols::Options opt;
     bool timing = false;
@@ -116,9 +116,9 @@ struct pols_ctx {
     // offsets, min_periods or the chunk length change
     struct { uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, mp = -1, n_chunks = 0; int32_t chunk_len = 0;
              const void *tab = nullptr; size_t b_groups = 0; } chunk_cache;
-    // K3c (k3c_scan.hip), scratch slot 8: tile / block records, carry-ins, arrival counters (zeroed when the layout changes: every
-    // launch leaves them at zero)
-    struct { const void *ptr = nullptr; int64_t n_tiles = -1; } k3c;
+    // K3c (k3c_scan.hip), scratch slot 18: first row of every PACKED tile (tiles cut at sequence starts, single-pass mode); n_tiles 0 =
+    // this frame does not pack (a sequence longer than a tile, or tiles too empty)
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, tile_rows = 0, n_tiles = 0; } k3c;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };

@@ -14,12 +14,16 @@ namespace pols {
 
 constexpr int DYN_STAGE_STRIDE = 65;
 
-template <typename T, int K>
-__device__ __forceinline__ void dyn_wave_copy_out(const T *stage, const int lane, const int64_t wrow0, const int64_t N, T *coef, T *pred) {
+// SLOTS = K + 1: slot K of a row holds its prediction; SLOTS = K: the predictions arrive in registers (pr[r]: row 4 l + r) and take the
+// first four slots once the coefficients have left.
+template <typename T, int K, int SLOTS = K + 1>
+__device__ __forceinline__ void dyn_wave_copy_out(T *stage, const int lane, const int64_t wrow0, const int64_t N, T *coef, T *pred,
+                                                  const int64_t lo, const T (&pr)[4]) {
+    // rows [lo, N) of the wave's 256 are stored (N: the end of the frame or of a packed tile, lo: the first row of a packed tile)
     using V = typename Vec16<T>::type;
     constexpr int VN = Vec16<T>::N;
-    auto at = [&](int row_local, int j) -> T { return stage[((row_local & 3) * (K + 1) + j) * DYN_STAGE_STRIDE + (row_local >> 2)]; };
-    const bool whole = wrow0 + 256 <= N;                             // wave-uniform
+    auto at = [&](int row_local, int j) -> T { return stage[((row_local & 3) * SLOTS + j) * DYN_STAGE_STRIDE + (row_local >> 2)]; };
+    const bool whole = wrow0 + 256 <= N && wrow0 >= lo;              // wave-uniform
     if (coef) {
         T *dst = coef + wrow0 * K;
 #pragma unroll
@@ -31,30 +35,48 @@ __device__ __forceinline__ void dyn_wave_copy_out(const T *stage, const int lane
                 const int m = m0 + e, rl = m / K, j = m - rl * K;
                 vset<T>(o, e, at(rl, j));
             }
-            if (whole) store_stream(reinterpret_cast<V *>(dst + m0), o);
+            const int64_t ra = wrow0 + m0 / K, rb = wrow0 + (m0 + VN - 1) / K;   // rows of the first / last value
+            if (whole || (ra >= lo && rb < N)) store_stream(reinterpret_cast<V *>(dst + m0), o);
             else {
 #pragma unroll
-                for (int e = 0; e < VN; ++e)
-                    if (wrow0 + (m0 + e) / K < N) dst[m0 + e] = vget<T>(o, e);
+                for (int e = 0; e < VN; ++e) {
+                    const int64_t re = wrow0 + (m0 + e) / K;
+                    if (re >= lo && re < N) dst[m0 + e] = vget<T>(o, e);
+                }
             }
         }
     }
     if (pred) {
         T *dst = pred + wrow0;
+        if constexpr (SLOTS == K) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(r * SLOTS + K - 1) * DYN_STAGE_STRIDE + lane] = pr[r];   // (slot K - 1 of row r: read as at(row, K - 1))
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
 #pragma unroll
         for (int i = 0; i < 4 / VN; ++i) {
             const int m0 = (i * 64 + lane) * VN;
             V o;
 #pragma unroll
-            for (int e = 0; e < VN; ++e) vset<T>(o, e, at(m0 + e, K));
-            if (whole) store_stream(reinterpret_cast<V *>(dst + m0), o);
+            for (int e = 0; e < VN; ++e) vset<T>(o, e, at(m0 + e, SLOTS == K ? K - 1 : K));
+            if (whole || (wrow0 + m0 >= lo && wrow0 + m0 + VN - 1 < N)) store_stream(reinterpret_cast<V *>(dst + m0), o);
             else {
 #pragma unroll
                 for (int e = 0; e < VN; ++e)
-                    if (wrow0 + m0 + e < N) dst[m0 + e] = vget<T>(o, e);
+                    if (wrow0 + m0 + e >= lo && wrow0 + m0 + e < N) dst[m0 + e] = vget<T>(o, e);
             }
         }
     }
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void dyn_wave_copy_out(T *stage, const int lane, const int64_t wrow0, const int64_t N, T *coef, T *pred) {
+    const T none[4] = {};
+    dyn_wave_copy_out<T, K, K + 1>(stage, lane, wrow0, N, coef, pred, 0, none);
 }
 
 }  // namespace pols

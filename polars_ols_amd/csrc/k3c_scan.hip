@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k3c_top_scan_kernel(const K3cArgs a) {
 }
 
 template <typename T, int K, int R, int WAVES, int MODE>
-__global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) k3c_kernel(const K3cArgs a) {
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NCP = K3C_NCP;
     static_assert(NT + 1 <= NCP && NT + 1 <= 64, "one component per lane in the cross-wave steps");
     static_assert(R == 4, "validity / start bytes travel as one 32-bit word per run");
@@ -168,12 +168,16 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     __shared__ double s_wfull[WAVES][NT + 1];    // carry-in of every wave
     // every lane parks its run here between A and D (its own words only: no synchronisation) -- the scan and the look-back then
     // run without R x (K + 1) row values in registers
-    __shared__ T s_x[MODE == 1 ? WAVES : 1][R * (K + 1)][DYN_STAGE_STRIDE];
+    __shared__ T s_x[MODE == 1 ? WAVES : 1][R * K][DYN_STAGE_STRIDE];   // (targets and predictions stay in registers)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #define K3C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     const int64_t t = blockIdx.x;
     const int64_t N = a.n_rows;
-    const int64_t row0 = ((t * WAVES + wv) * 64 + lane) * (int64_t)R;
+    // packed tiles (single-pass mode): the tile owns the whole sequences of rows [lo, hi) and its lanes start at lo rounded down to
+    // a run -- up to three rows of the sequence before, walked from nothing and never stored
+    int64_t lo = 0, hi = N, tbase = t * (int64_t)(WAVES * 64 * R);
+    if (a.tile_row0) { lo = a.tile_row0[t]; hi = a.tile_row0[t + 1]; tbase = lo & ~(int64_t)3; }
+    const int64_t row0 = tbase + (int64_t)((wv * 64 + lane) * R);
     const double ff = a.ff, ip0 = 1.0 / a.p0;
     K3C_STAMP(0);
 
@@ -208,28 +212,28 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     // zeros and its decay 1, so that every lane runs the same instruction stream (their predictions are masked by the caller's
     // post pass, ex.rs:640-645).
     bool st[R];
-    double ffr[R];
+    unsigned fit = 0;                             // bit r: row r is a valid row inside the frame (its decay is ff, else 1)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         st[r] = ((sbits >> (8 * r)) & 0xffu) != 0;
-        ffr[r] = ff;
+        fit |= 1u << r;
     }
     if (a.valid) {
+        fit = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool vr = ((vbits >> (8 * r)) & 0xffu) != 0;
-            ffr[r] = vr ? ff : 1.0;
+            fit |= vr ? (1u << r) : 0u;
             y[r] = vr ? y[r] : 0.0;
 #pragma unroll
             for (int j = 0; j < K; ++j) x[r][j] = vr ? x[r][j] : 0.0;
         }
     } else if (!__all(row0 + R <= N)) {
+        fit = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) ffr[r] = (row0 + r < N) ? ff : 1.0;
+        for (int r = 0; r < R; ++r) fit |= (row0 + r < N) ? (1u << r) : 0u;
     }
-    double b0[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) b0[j] = a.mean0 ? a.mean0[j] * ip0 : 0.0;
+    auto ffr = [&](int r) -> double { return ((fit >> r) & 1u) ? ff : 1.0; };
     auto add_row = [&](double (&S)[NT], const double (&xr)[K], double yr, double f) { // S = f S + [x x' | x y]
 #pragma unroll
         for (int p = 0; p < K; ++p) {
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
             for (int p = 0; p < K; ++p) {
 #pragma unroll
                 for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = st[r] ? ((p == q) ? ip0 : 0.0) : S[tri_index<K>(p, q)];
-                S[NX + p] = st[r] ? b0[p] : S[NX + p];
+                S[NX + p] = st[r] ? (a.mean0 ? a.mean0[p] * ip0 : 0.0) : S[NX + p];   // (b_0 = A_0 mean0, re-read here: the path is rare)
             }
         }
     };
@@ -259,12 +263,11 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     for (int r = 0; r < R; ++r) {
         reset_at(Tl, r);
         head = head || st[r];
-        Dl = (st[r] ? 1.0 : Dl) * ffr[r];
-        add_row(Tl, x[r], y[r], ffr[r]);
+        Dl = (st[r] ? 1.0 : Dl) * ffr(r);
+        add_row(Tl, x[r], y[r], ffr(r));
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) s_x[wv][r * (K + 1) + j][lane] = (T)x[r][j];
-            s_x[wv][r * (K + 1) + K][lane] = (T)y[r];
+            for (int j = 0; j < K; ++j) s_x[wv][r * K + j][lane] = (T)x[r][j];
         }
     }
 
@@ -318,7 +321,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     {
         // pass 2: the tile's carry-in = [its block's carry-in] . [the tiles of its block below it], both written by pass 1
         double cq;
-        if (a.all_closed) cq = a.rec[(t > 0 ? t - 1 : 0) * K3C_NCP + ql];     // (tile 0 starts with a sequence start: its carry-in is never used)
+        if (a.tile_row0) cq = (lane == NT) ? 1.0 : 0.0;                        // packed: the tile starts (within a run) at a sequence start
+        else if (a.all_closed) cq = a.rec[(t > 0 ? t - 1 : 0) * K3C_NCP + ql];     // (tile 0 starts with a sequence start: its carry-in is never used)
         else cq = a.carry[t * K3C_NCP + ql];
         if (!a.all_closed && a.carry_open[t] && t >= 64) {
             const double bq = a.bcarry[(t >> 6) * K3C_NCP + ql];
@@ -339,28 +343,30 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k3c_kernel(const K3cArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- D: the walk.  A row's outputs take the LDS slots its inputs were parked in; the wave's 256 rows leave together (dyn_out.inl)
     double beta[K];
+    T prd[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         __builtin_amdgcn_sched_barrier(0);       // one row at a time: the scheduler would otherwise start every row's products at once
         double xr[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) xr[j] = (double)s_x[wv][r * (K + 1) + j][lane];
-        const double yr = (double)s_x[wv][r * (K + 1) + K][lane];
+        for (int j = 0; j < K; ++j) xr[j] = (double)s_x[wv][r * K + j][lane];
+        const double yr = y[r];
         reset_at(ET, r);
-        add_row(ET, xr, yr, ffr[r]);
+        add_row(ET, xr, yr, ffr(r));
         ldl_solve_small<K, true>(ET, 0.0, beta);
         double pr = 0.0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            s_x[wv][r * (K + 1) + j][lane] = (T)beta[j];
+            s_x[wv][r * K + j][lane] = (T)beta[j];
             pr = fma(xr[j], beta[j], pr);
         }
-        s_x[wv][r * (K + 1) + K][lane] = (T)pr;
+        prd[r] = (T)pr;
+        asm volatile("" : "+v"(prd[r]));           // computed HERE: left alone the compiler keeps x and beta of every row alive for it (190 VGPRs, not 150)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    dyn_wave_copy_out<T, K>(&s_x[wv][0][0], lane, ((t * WAVES + wv) * 64) * (int64_t)R, N, static_cast<T *>(a.coef), static_cast<T *>(a.pred));
+    dyn_wave_copy_out<T, K, K>(&s_x[wv][0][0], lane, tbase + (int64_t)(wv * 64 * R), hi, static_cast<T *>(a.coef), static_cast<T *>(a.pred), lo, prd);
     K3C_STAMP(4);
     K3C_STAMP(5);
     if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) {
@@ -397,8 +403,8 @@ static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
     timing_begin(ctx);                                            // all launches of the call as one timed span
     K3cArgs a1 = a;
     a1.dbg = nullptr;
-    hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 0>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a1);
-    if (!a.all_closed) {                                          // sequences longer than a tile: the records are scanned (two small launches)
+    if (!a.tile_row0) hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 0>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a1);
+    if (!a.tile_row0 && !a.all_closed) {                                          // sequences longer than a tile: the records are scanned (two small launches)
         hipLaunchKernelGGL((k3c_block_scan_kernel<K4N<K>::N>), dim3((unsigned)((a.n_tiles + 63) / 64)), dim3(64), 0, ctx->stream, a1);
         hipLaunchKernelGGL((k3c_top_scan_kernel<K4N<K>::N>), dim3(1), dim3(64), 0, ctx->stream, a1);
     }

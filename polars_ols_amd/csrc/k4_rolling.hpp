@@ -74,7 +74,10 @@ void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);
 // ---- K3c: row-parallel, read-once RLS for up to K4_KMAX features (k3c_scan.hip) ------------------------------------------------
 constexpr int K3C_NCP = 48;      // doubles per tile record: k (k + 1) / 2 + k + 1 <= 45
 constexpr int K3C_R = 4;         // consecutive rows per lane
-constexpr int k3c_waves(int k) { return k <= 6 ? 4 : 2; }    // waves per tile (each parks R (k + 1) row values per lane in LDS)
+#ifndef K3C_WAVES_SMALL
+#define K3C_WAVES_SMALL 4
+#endif
+constexpr int k3c_waves(int k) { return k <= 6 ? K3C_WAVES_SMALL : 2; }    // waves per tile (each parks R (k + 1) row values per lane in LDS)
 constexpr int64_t k3c_tile_rows(int k) { return (int64_t)K3C_R * 64 * k3c_waves(k); }
 struct K3cArgs {
     const void *y;
@@ -92,6 +95,8 @@ struct K3cArgs {
     int32_t *rec_closed, *carry_open, *brec_closed;
     int64_t n_tiles;
     int32_t all_closed;                // no sequence is longer than a tile: every tile holds a sequence start, tile t's carry-in is tile t - 1's record
+    const int64_t *tile_row0;          // PACKED tiles (or nullptr): tile t owns rows [tile_row0[t], tile_row0[t + 1]), whole sequences only, and
+                                       // loads from tile_row0[t] & ~3 on -- no carry-in, so one launch (pass 2 alone) does the frame
     unsigned long long *dbg;           // POLS_TIMELINE: 8 words per tile (s_memtime stamps of the tile's last wave) or nullptr
     int32_t k;
 };

@@ -196,3 +196,38 @@ def test_rls_lookback_long_and_short_sequences_mixed(eng, dtype, tol, k):
         assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
         exp_p = ref["pred"] if v is None else _masked(ref["pred"], v)
         assert np.allclose(_np(out["pred"]), exp_p, rtol=tol, atol=tol, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k", [2, 6, 8])
+def test_rls_packed_tiles_ragged_sequences(eng, dtype, tol, k):
+    """K3c's single-pass form: no sequence longer than a tile, so tiles are cut at sequence starts (whole sequences, starts at any
+    row -- a tile's lanes begin up to three rows before its first sequence) and nothing is carried between them.  Ragged lengths up
+    to the largest a tile holds, with and without validity bytes; the same frame through the two-pass form (RLS_ENGINE=scan) must
+    give the same numbers."""
+    from oracle import orc
+
+    rng = np.random.default_rng(4100 + k)
+    top = (1024 if k <= 6 else 512) - 3
+    sizes = np.concatenate([[top, 1, top - 1, 2, 3, 5, top, top], rng.integers(1, top + 1, size=120), rng.integers(300, top + 1, size=200), [1, 1, 7]])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(cols).astype(np.float64) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    valid = (rng.random(N) > 0.05).astype(np.uint8)
+    for v in (None, valid):
+        kw = dict(valid=None if v is None else _cuda(v), half_life=40.0, initial_state_covariance=3.0, initial_state_mean=[0.05] * k,
+                  null_free=v is None)
+        out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+        assert eng.last_kernel.startswith("k3s_rls_rows")
+        ref = orc.batched_rls(y, cols, offs, half_life=40.0, initial_state_covariance=3.0, initial_state_mean=[0.05] * k, is_valid=v)
+        assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+        exp_p = ref["pred"] if v is None else _masked(ref["pred"], v)
+        assert np.allclose(_np(out["pred"]), exp_p, rtol=tol, atol=tol, equal_nan=True)
+        eng.set_option("RLS_ENGINE", "scan")
+        try:
+            two = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+        finally:
+            eng.set_option("RLS_ENGINE", None)
+        assert np.allclose(_np(two["coef"]), _np(out["coef"]), rtol=tol, atol=tol)
+        assert np.allclose(_np(two["pred"]), _np(out["pred"]), rtol=tol, atol=tol, equal_nan=True)
