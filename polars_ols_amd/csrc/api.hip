@@ -187,7 +187,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
     else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : ieq(v, "k2w") ? 4 : 0;
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : 0;
-    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : 0;
+    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
     else return false;
@@ -1418,6 +1418,37 @@ static int ensure_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_gr
     return POLS_OK;
 }
 
+// Packed tiles of the row-parallel dynamic kernels (K3c / K4c): no sequence longer than a tile (less the three rows a tile may start
+// before its first sequence) -> tiles are cut at sequence starts, whole sequences, first fit in frame order; tile t owns rows
+// [map[t], map[t + 1]).  Taken when the tiles come out at least 70 % full; *n_tiles = 0 otherwise.  Scratch slot 18, cached per frame.
+static int ensure_packed_tiles(pols_ctx *ctx, const pols_batch *b, int64_t tile_rows, int64_t max_rows, const int64_t **map, int64_t *n_tiles) {
+    *map = nullptr; *n_tiles = 0;
+    if (max_rows > tile_rows - 3) return POLS_OK;
+    const int64_t N = b->n_rows;
+    auto &tc = ctx->k3c;
+    void *dmap = nullptr;
+    int rc = ensure_scratch(ctx, 18, round256(sizeof(int64_t) * (size_t)(b->n_groups + 2)), &dmap);
+    if (rc) return rc;
+    if (tc.ptr != dmap || tc.offs_id != ctx->offs_id || tc.n_groups != b->n_groups || tc.n_rows != N || tc.tile_rows != tile_rows) {
+        tc.ptr = nullptr;
+        std::vector<int64_t> first;
+        const int64_t *offs = b->group_offsets;
+        int64_t base = -1;
+        for (int64_t g = 0; g < b->n_groups; ++g) {
+            if (offs[g + 1] == offs[g]) continue;
+            if (base < 0 || offs[g + 1] - base > tile_rows) { first.push_back(offs[g]); base = offs[g] & ~(int64_t)3; }
+        }
+        const int64_t nt = (int64_t)first.size();
+        first.push_back(N);
+        tc.n_tiles = nt * tile_rows * 7 <= N * 10 ? nt : 0;
+        if (tc.n_tiles && (rc = upload_small(ctx, dmap, first.data(), sizeof(int64_t) * first.size()))) return rc;
+        tc.ptr = dmap; tc.offs_id = ctx->offs_id; tc.n_groups = b->n_groups; tc.n_rows = N; tc.tile_rows = tile_rows;
+    }
+    *n_tiles = tc.n_tiles;
+    if (tc.n_tiles) *map = static_cast<const int64_t *>(dmap);
+    return POLS_OK;
+}
+
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o) {
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
     const int64_t *d_offs = nullptr;
@@ -1476,28 +1507,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         // starts -- whole sequences, first fit in frame order -- and need no carry-in, so ONE launch reads and writes the frame once.
         // Taken when the packed tiles are at least 70 % full (the two-pass form costs about 1.5 launches of full tiles).
         int64_t n_packed = 0;
-        if (max_rows <= tile_rows - 3 && ctx->opt.rls_engine != 2) {
-            auto &tc = ctx->k3c;
-            void *dmap = nullptr;
-            if ((rc = ensure_scratch(ctx, 18, round256(sizeof(int64_t) * (size_t)(b->n_groups + 2)), &dmap))) return rc;
-            if (tc.ptr != dmap || tc.offs_id != ctx->offs_id || tc.n_groups != b->n_groups || tc.n_rows != N || tc.tile_rows != tile_rows) {
-                tc.ptr = nullptr;
-                std::vector<int64_t> first;
-                const int64_t *offs = b->group_offsets;
-                int64_t base = -1;
-                for (int64_t g = 0; g < b->n_groups; ++g) {
-                    if (offs[g + 1] == offs[g]) continue;
-                    if (base < 0 || offs[g + 1] - base > tile_rows) { first.push_back(offs[g]); base = offs[g] & ~(int64_t)3; }
-                }
-                const int64_t nt = (int64_t)first.size();
-                first.push_back(N);
-                tc.n_tiles = nt * tile_rows * 7 <= N * 10 ? nt : 0;
-                if (tc.n_tiles && (rc = upload_small(ctx, dmap, first.data(), sizeof(int64_t) * first.size()))) return rc;
-                tc.ptr = dmap; tc.offs_id = ctx->offs_id; tc.n_groups = b->n_groups; tc.n_rows = N; tc.tile_rows = tile_rows;
-            }
-            n_packed = tc.n_tiles;
-            if (n_packed) c.tile_row0 = static_cast<const int64_t *>(dmap);
-        }
+        if (ctx->opt.rls_engine != 2 && (rc = ensure_packed_tiles(ctx, b, tile_rows, max_rows, &c.tile_row0, &n_packed))) return rc;
         c.y = st.y; c.valid = st.valid; c.start = flags;
         for (int j = 0; j < kf; ++j) c.x[j] = st.x[j];
         c.n_rows = N; c.coef = st.coef; c.pred = st.pred; c.mean0 = a.mean0;
@@ -1661,6 +1671,8 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         for (int j = 0; j < k; ++j) c.x[j] = st.x[j];
         c.n_rows = b->n_rows; c.coef = st.coef; c.pred = st.pred;
         c.window = w; c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
+        // whole sequences per tile when none is longer than one: no window reaches outside its tile, no halo (POLS_ROLLING_ENGINE=halo: off)
+        if (ctx->opt.rolling_engine != 2 && (rc = ensure_packed_tiles(ctx, b, K4C_PACKED_ROWS, max_rows, &c.tile_row0, &c.n_packed))) return rc;
         if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
         if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
         return unstage_outputs(ctx, b, b->n_rows, k, o, st);

@@ -116,7 +116,10 @@ struct K4cArgs {
     double alpha;
     unsigned long long *dbg;           // POLS_TIMELINE: 8 words per tile or nullptr (set by the launcher)
     int32_t k;
+    const int64_t *tile_row0;          // PACKED tiles (or nullptr), K3cArgs::tile_row0's table for 1 024-row tiles: whole sequences per tile, so no
+    int64_t n_packed;                  // window reaches outside it and the halo waves go (n_packed tiles)
 };
+constexpr int64_t K4C_PACKED_ROWS = 1024;    // rows of a packed tile (four body waves)
 int k4c_launch(pols_ctx *ctx, int dtype, const K4cArgs &a);
 
 }  // namespace pols

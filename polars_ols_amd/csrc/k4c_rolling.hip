@@ -19,7 +19,7 @@
 //      E' is the table entry of the run holding that row plus the o = (-window) mod 4 rows in front of it; then per row
 //      S += entering row, S -= leaving row (the same add / subtract NonWoodburyState::update performs, :707-725), one K x K solve
 //      (L D L'; LU on a non-positive pivot, :732-734), coefficients and predictions stored 16 bytes at a time.
-// Bound: HBM, 8 (k + 1) bytes in + 8 (k + 1) bytes out per row (f64), plus the halo re-reads (1 / BW of the input).
+// Bound: HBM, 8 (k + 1) bytes in + 8 (k + 1) bytes out per row (f64), plus the halo re-reads (HW / BW of the input, L2 hits mostly).
 #include "k4_rolling.hpp"
 #include "k4_small.inl"
 #include "dyn_out.inl"
@@ -71,7 +71,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
     const int64_t t = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= a.n_tiles) return;
     const int64_t N = a.n_rows, w = a.window;
-    const int64_t hs = t * (BW * 256) - HW * 256;                // the halo's first row (may be negative)
+    // HW == 0: packed tiles -- the tile owns the whole sequences of rows [lo, hi) and starts at lo rounded down to a run
+    int64_t lo = 0, hi = N, hs = t * (BW * 256) - HW * 256;      // hs: the halo's first row (may be negative)
+    if constexpr (HW == 0) { lo = a.tile_row0[t]; hi = a.tile_row0[t + 1]; hs = lo & ~(int64_t)3; }
     const int u = wv * 64 + lane;                                // this lane's run
     const int64_t i0 = hs + (int64_t)u * R;
     const bool inside = i0 >= 0 && i0 + R <= N;
@@ -116,8 +118,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
     // rows another wave of this workgroup is loading just now, one L2 line fill serves both.
     const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
     const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window
-    const int up = u - sh;                                                     // >= 0 for body lanes: the halo covers `window` rows
-    const int64_t rho_run = hs + (int64_t)up * R;                              // first row of the run holding row i0 - window
+    const int up = u - sh < 0 ? 0 : u - sh;                                    // table index: u - sh >= 0 for body lanes behind a halo (it covers `window`
+                                                                               // rows); packed tiles: a negative one is never looked up (use_ep below is false)
+    const int64_t rho_run = hs + (int64_t)(u - sh) * R;                        // first row of the run holding row i0 - window
     auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
         const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
 #pragma unroll
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
         yr = (double)static_cast<const T *>(a.y)[ic];
     };
     double xo[R][K], yo[R];
-    if (wv >= HW) {
+    auto load_leaving = [&]() {
         const int64_t l0 = rho_run + o;
         if ((o % VN) == 0 && __all(l0 >= 0 && l0 + R <= N)) {                  // 16-byte aligned: vector loads
 #pragma unroll
@@ -149,7 +152,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) load_row(l0 + r, xo[r], yo[r]);
         }
-    }
+    };
+    if (wv >= HW) load_leaving();
     bool st[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) st[r] = ((sbits >> (8 * r)) & 0xffu) != 0;
@@ -270,7 +274,10 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    dyn_wave_copy_out<T, K>(stage, lane, hs + (int64_t)wv * 64 * R, N, coef, pred);
+    {
+        const T none[4] = {};
+        dyn_wave_copy_out<T, K, K + 1>(stage, lane, hs + (int64_t)wv * 64 * R, hi, coef, pred, lo, none);
+    }
     K4C_STAMP(4);
     K4C_STAMP(5);
     if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + 6] = 0;
@@ -280,10 +287,15 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
 template <typename T, int K, int HW>
 static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     constexpr int NC = K4N<K>::N + 1;
-    constexpr int WAVES = 8;                                     // the prefix table is NC x 64 WAVES doubles of LDS (K = 6: 112 KiB)
+    // Waves per workgroup.  The prefix table is NC x 64 WAVES doubles of LDS (K = 6: 14 KiB per wave) and a lane holds its entering
+    // and leaving rows through the scan (229 VGPRs: two waves per SIMD).  One halo wave: FOUR waves, two workgroups per CU whose
+    // phases interleave (one streams rows in while the other walks) -- measured against one 8-wave workgroup, which repeats
+    // 1 / 7 instead of 1 / 3 of the rows: 1M rows 54.5 -> 43.5 us, 10 000 x 1 000 rows 390 -> 326 us.  Two halo waves: eight.
+    constexpr int WAVES = HW <= 1 ? 4 : 8;
     K4cArgs a = a0;
     const int64_t tile_rows = (int64_t)(WAVES - HW) * 256;
-    a.n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
+    static_assert(HW != 0 || (WAVES - HW) * 256 == K4C_PACKED_ROWS, "the packed tile map is built for this tile");
+    a.n_tiles = HW == 0 ? a.n_packed : (a.n_rows + tile_rows - 1) / tile_rows;
     const int64_t per_xcd = (a.n_tiles + 7) / 8;
     const size_t lds = std::max(sizeof(double) * ((size_t)NC * 64 * WAVES + WAVES * NC) + 64,                      // prefix table + wave totals
                                 (size_t)(WAVES - HW) * 4 * (K + 1) * DYN_STAGE_STRIDE * sizeof(T));              // ... reused as the output staging area
@@ -309,6 +321,7 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
 
 template <typename T, int K>
 static int k4c_launch_k(pols_ctx *ctx, const K4cArgs &a) {
+    if (a.tile_row0) return k4c_launch_h<T, K, 0>(ctx, a);                                      // packed tiles: no halo
     return a.window <= 252 ? k4c_launch_h<T, K, 1>(ctx, a) : k4c_launch_h<T, K, 2>(ctx, a);   // 256 HW >= 4 ceil(window / 4) + 1
 }
 

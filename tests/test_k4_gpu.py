@@ -319,3 +319,41 @@ def test_rolling_many_sequences_full_size(eng):
         sane[:2 * k] = False
         assert np.allclose(c[sane], ref["coef"][sane], rtol=1e-6, atol=1e-6), g
         assert np.allclose(p[sane], ref["pred"][sane], rtol=1e-6, atol=1e-6), g
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,window,min_periods,alpha", [
+    (1, 1, 1, None), (3, 3, 3, 0.1), (6, 7, 6, None), (4, 63, 4, None), (6, 250, 10, None), (6, 251, 6, None), (6, 252, 6, None),
+    (6, 253, 6, None), (5, 254, None, None), (3, 255, 3, 1.0), (6, 256, 6, None), (6, 507, 20, None), (2, 508, 2, None),
+])
+def test_rolling_packed_tiles_ragged_sequences(eng, dtype, tol, k, window, min_periods, alpha):
+    """K4c's halo-free form: no sequence longer than a tile, so tiles hold whole sequences (cut at sequence starts, any row) and no
+    window reaches outside its tile.  Ragged lengths up to the largest a tile holds, every window offset modulo the 4-row runs,
+    windows longer than some sequences; the same frame through the halo form (ROLLING_ENGINE=halo) must give the same numbers."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 104729 + window)
+    top = 1024 - 3
+    sizes = np.concatenate([[top, 1, top - 1, 2, 3, 5, top, top, 0, 600], rng.integers(1, top + 1, size=60), rng.integers(400, top + 1, size=100), [1, 0, 7]])
+    y, cols, offs, _ = _frame(rng, sizes, k, dtype=dtype)
+    kw = dict(window_size=window, min_periods=min_periods, alpha=alpha, null_policy="drop", null_free=True)
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    assert eng.last_kernel.startswith("k4_rolling_tiles")
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy="drop")
+    got_c, got_p = _np(out["coef"]), _np(out["pred"])
+    assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
+    assert np.array_equal(np.isnan(got_p), np.isnan(ref["pred"]))
+    nobs = _window_obs(offs, None, window, "drop")
+    sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+    well = sane & ((nobs >= 2 * k) | (alpha is not None))
+    assert well.sum() > 0.5 * sane.sum() or window < 2 * k
+    assert np.allclose(got_c[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(got_c[well] - ref["coef"][well]).max())
+    assert np.allclose(got_p[well], ref["pred"][well], rtol=tol, atol=tol)
+    eng.set_option("ROLLING_ENGINE", "halo")
+    try:
+        two = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    finally:
+        eng.set_option("ROLLING_ENGINE", None)
+    two_c, two_p = _np(two["coef"]), _np(two["pred"])
+    assert np.array_equal(np.isnan(two_c), np.isnan(got_c))
+    assert np.allclose(two_c[well], got_c[well], rtol=tol, atol=tol) and np.allclose(two_p[well], got_p[well], rtol=tol, atol=tol)
