@@ -979,9 +979,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // (2.53 vs 1.75 at 31 columns)
         // (round 3, solvers padded to 20 / 24 / 28 / 32 and built by independent loads: f64 17 / 20 / 24 columns x 1 000 rows 689 / 722 /
         // 409 us against 729 / 837 / 492 streamed -- ahead at every width it covers now)
-        const bool ahead = true;
-        (void)f32;
-        if (fits && ((!k1_resident && ahead) || ctx->opt.static_engine == 4)) {
+        // (round 4, two-wave workgroups -- four per CU, four solves in flight: f64 groups of up to 256 rows 24 / 31 columns x 200 rows
+        // 2.03 / 2.10 TB/s against 1.83 (K1) / 1.25 (four waves); at 20 columns K1 stays ahead, 2.02 against 1.87)
+        const bool short_wide = !f32 && kt >= 23 && max_rows <= 254;
+        if (fits && (!k1_resident || short_wide || ctx->opt.static_engine == 4)) {
             K2wArgs aw;
             std::memset(&aw, 0, sizeof(aw));
             aw.y = st.y; aw.w = st.w;

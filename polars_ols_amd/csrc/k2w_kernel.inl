@@ -7,7 +7,7 @@
 // polars_ols/least_squares.py:184-196, 234-239.  A failed or flagged factorisation marks the group POLS_GROUP_FALLBACK for the
 // fix-up pass (K6), exactly like K1 / K2.
 //
-// One PERSISTENT workgroup of WAVES (4 or 8) waves walks the groups blockIdx.x, + gridDim.x, ...  Per group:
+// One PERSISTENT workgroup of WAVES (2, 4 or 8) waves walks the groups blockIdx.x, + gridDim.x, ...  Per group:
 //   load    : every lane keeps ONE 16-byte chunk (2 f64 / 4 f32 consecutive rows) of EVERY column in VGPRs -- 32 column slots, all
 //             loaded unconditionally from clamped positions (K2's scheme: no load inside a divergent branch), 128 VGPRs of data.
 //   gram    : Z = [sqrt(w) X | sqrt(w) 1 | sqrt(w) y] has up to 32 columns = two 16-column halves; Z'Z is THREE 16 x 16 tiles on the
@@ -17,8 +17,8 @@
 //             its 16 operands are read into registers, half 1 is written over it, and its operands are consumed one at a time
 //             next to the three MFMAs of the step.  No workgroup barrier in the Gram phase.  f32 tiles are flushed to f64 per stage.
 //   reduce  : per-wave partial tiles -> LDS -> one f64 32 x 32 matrix, fixed order (run-to-run identical).             [2 barriers]
-//   solve   : wave 0, f64: the matrix padded to 32 x 32 with an identity block, lane i keeps row i in registers, right-looking
-//             Cholesky with v_readlane broadcasts (steps beyond kt skipped), forward substitution, one LDS transposition, backward.
+//   solve   : one wave, f64: [A | b] padded with an identity block, lane i keeps row i in registers, Gauss-Jordan elimination without
+//             pivoting with v_readlane broadcasts (steps beyond kt skipped): no substitution passes (k2w_chol below).
 //   predict : X . beta (+ residuals) from the resident rows, 16-byte streaming stores.                                  [1 barrier]
 // Bound: HBM, b n (k + 1) (+ b n weights) bytes in, b n out per group.
 #pragma once
@@ -31,20 +31,30 @@ constexpr int K2W_KC = 32;                       // column slots (two 16-column 
 constexpr int K2W_GS = 33;                       // row stride of the f64 matrices in LDS
 constexpr int K2W_TAIL_B = (2 * 32 * K2W_GS + 64) * 8;   // Z'Z, the solver's matrix, 64 doubles of vectors
 
-// Cholesky of X'X + alpha I (faer cholesky(Side::Lower), ls.rs:288-297) and the two triangular solves on the 32 x 32 padded system;
-// false = failed / flagged pivot.  G: Z'Z with X'y in column kt; Tm: 32 x 33 scratch.  Lane i keeps row i of the factor in registers,
-// v_readlane broadcasts (k2_chol's form at 32 columns).  Measured against publishing the pivot column through LDS once per step
-// (one round trip instead of 2 (kt - j) broadcasts): the LDS form was SLOWER (f64, 31 columns x 1 000 rows: 614 vs 515 us per 5 000 groups).
-// KB: the padded size of the system, 20 / 24 / 28 / 32 (kt <= KB).  The elimination, the substitutions and the transposition are unrolled over KB:
-// at 17-24 columns the 24-wide form does 37 % less of the (instruction-bound) update work than the 32-wide one.
+// (X'X + alpha I) beta = X'y on the padded system (the reference: faer cholesky(Side::Lower) + two triangular solves, ls.rs:288-297);
+// false = failed / flagged pivot.  G: Z'Z with X'y in column kt; Tm: 32 x 33 scratch.  Lane i keeps row i of [A | b] in registers and the
+// wave runs Gauss-Jordan elimination WITHOUT pivoting: at step j every row but row j subtracts its multiple of row j (v_readlane
+// broadcasts of row j's entries), so the matrix ends up diagonal and beta_i = b_i / a_ii in every lane at once.  The pivots are the
+// squares of Cholesky's diagonal (the same Schur complements), so the positive-definiteness / conditioning test is the same test;
+// what goes is the two substitution passes -- 2 kt dependent broadcast -> multiply -> subtract steps of ~80 cycles each -- and the
+// transposition between them: in this layout a row update costs the same instructions whether 31 - j rows take part (Cholesky) or
+// 31 (here).  Measured (f64, 1 000-row groups, per group): 31 columns 20.7 k -> see DESIGN cycles, 20 columns 13.7 k -> see DESIGN.
+// Round 3, measured against publishing the pivot column through LDS once per step instead of the broadcasts: the LDS form was SLOWER
+// (31 columns x 1 000 rows: 614 vs 515 us per 5 000 groups).
+// KB: the padded size of the system, 20 / 24 / 28 / 32 (kt <= KB); the elimination is unrolled over KB.
+__device__ __forceinline__ double k2w_rcp(double d) {           // v_rcp_f64 + two Newton steps
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+}
+
 template <int KB>
 __device__ __forceinline__ bool k2w_chol(const double *G, int kt, double alpha, double pivot_tol, double *Tm, int lane, double &bi) {
     constexpr int KC = KB;
     const int i = (lane & 31) < KB ? (lane & 31) : KB - 1;   // lanes 32..63 repeat lanes 0..31 (broadcasts read lanes 0..kt-1); rows beyond KB mirror the last
-    // [X'X + alpha I | X'y] padded with an identity block, built in LDS by a rolled loop (written as per-lane selects in the unrolled
-    // code the padding constants would be hoisted out of the persistent group loop into registers)
-    // (round 3: lane (row, half) writes half a row with independent loads, unrolled -- the rolled q / (KC + 1) loop was 16 dependent
-    // load -> store round trips of ~300 cycles each; the lane id is laundered per group in the caller, so nothing here is hoisted)
+    // [X'X + alpha I | X'y] padded with an identity block, built in LDS: lane (row, half) writes half a row with independent loads,
+    // unrolled (the lane id is laundered per group in the caller, so nothing here is hoisted out of the persistent loop)
     {
         constexpr int HW = (KC + 2) / 2;                 // columns per half row, the right-hand side included
         const int r = lane & 31, c0 = (lane >> 5) * HW;
@@ -69,51 +79,36 @@ __device__ __forceinline__ bool k2w_chol(const double *G, int kt, double alpha, 
     for (int c = 0; c < KC; ++c) row[c] = Tm[i * K2W_GS + c];
     bi = Tm[i * K2W_GS + KC];
     const double gd = Tm[i * K2W_GS + i];
-    k2_wave_sync();                                      // Tm is rewritten for the transposition below
-    double rme = 1.0;                                    // 1 / L[i][i], kept on lane i
+    k2_wave_sync();                                      // (Tm belongs to the next group's build)
+    double rme = 1.0;                                    // 1 / pivot i, kept on lane i
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
         if (j < kt) {                                    // wave-uniform: the identity block needs no elimination
             const double d = k2_bcast(row[j], j);
             ok = ok & (d > pivot_tol * k2_bcast(gd, j)); // also false for NaN
-            const double ri = k2_rsqrt(d);
+            const double ri = k2w_rcp(d);
             if (i == j) rme = ri;
-            row[j] *= ri;                                // L[i][j] on the lanes below the diagonal
+            const double f = (i == j) ? 0.0 : row[j] * ri;                       // this row's multiple of row j (row j itself stays)
 #pragma unroll
-            for (int c = j + 1; c < KC; ++c) row[c] = fma(-row[j], k2_bcast(row[j], c), row[c]);   // - L[i][j] L[c][j]
-            __builtin_amdgcn_sched_barrier(0);           // a column's broadcasts stay in their column
+            for (int c = j + 1; c < KC; ++c) row[c] = fma(-f, k2_bcast(row[c], j), row[c]);
+            bi = fma(-f, k2_bcast(bi, j), bi);
+            __builtin_amdgcn_sched_barrier(0);           // a step's broadcasts stay in their step
         }
     }
-#pragma unroll
-    for (int p = 0; p < KC; ++p) {                       // forward: t = L^-1 b (rows beyond kt: identity, b = 0)
-        if (p < kt) {
-            const double tp = k2_bcast(bi * rme, p);
-            bi = (i == p) ? tp : ((i > p) ? fma(-row[p], tp, bi) : bi);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (lane < 32) {                                     // the backward solve needs column i of L on lane i: one transposition through LDS
-#pragma unroll
-        for (int c = 0; c < KC; ++c) Tm[i * K2W_GS + c] = row[c];
-    }
-    k2_wave_sync();
-#pragma unroll
-    for (int c = 0; c < KC; ++c) row[c] = Tm[c * K2W_GS + i];   // L[c][i]
-#pragma unroll
-    for (int p = KC - 1; p >= 0; --p) {                  // backward: beta = L^-T t
-        if (p < kt) {
-            const double bp = k2_bcast(bi * rme, p);
-            bi = (i == p) ? bp : ((i < p) ? fma(-row[p], bp, bi) : bi);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    k2_wave_sync();
+    bi *= rme;                                           // beta_i (rows beyond kt: 0 x 1)
     return ok;
 }
 
+// npf (eight-wave form: ONE persistent workgroup per CU, nothing else on the CU while wave 0 solves): the first npf of a wave's
+// loaded columns (features, then the target, then the weights) of the NEXT group are DMA'd into LDS by waves 1..7 during the solve
+// (`global_load_lds`, 1 KiB per wave-instruction) -- a CU's memory pipe delivers ~10 bytes per clock however idle HBM is, and a
+// 31-column x 1 000-row f64 group is 264 KB of it.  Pieces 0..7 of a wave sit in that wave's own Gram tile (idle between the
+// reduce and the next group's transposes; read back by the same wave before it writes the tile: no barrier), the rest in the LDS
+// beyond the solver's matrices, K2W_PF_DED pieces per wave.
+constexpr int K2W_PF_TILE = 8;                   // 1 KiB pieces inside a wave's 8.25 KiB tile
 template <typename T, int WAVES, bool HAS_W>
-__global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
+__global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a, const int npf, const int pf_ded) {
     using V = typename Vec16<T>::type;
     using M = Mfma16<T>;
     using acc_t = typename M::acc_t;
@@ -126,6 +121,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
     double *Gs = reinterpret_cast<double *>(smem + (size_t)WAVES * K2_TILE_B);      // [32][33]
     double *As = Gs + 32 * K2W_GS;                                                    // solver matrix [32][33]
     double *vec = As + 32 * K2W_GS;                                                   // [0, 32) beta
+    unsigned char *pfd = smem + (size_t)WAVES * K2_TILE_B + K2W_TAIL_B;               // [wave][pf_ded][1 KiB]
+    // piece (consumer wave wt, loaded column col < npf) lives at:
+    auto pf_at = [&](int wt, int col) -> unsigned char * {
+        return col < K2W_PF_TILE ? smem + (size_t)wt * K2_TILE_B + (size_t)col * 1024
+                                 : pfd + ((size_t)wt * pf_ded + (col - K2W_PF_TILE)) * 1024;
+    };
+    bool pf_ready = false;                                   // the pieces hold columns of the group being worked on
 
 #pragma unroll 1
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
@@ -159,12 +161,18 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
         shift = any ? (int)(row0 - rl) : 0;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) keep |= (any && row0 + v >= s && row0 + v < e) ? (1u << v) : 0u;
+        const int np = pf_ready ? npf : 0;                   // block-uniform: columns < np wait in LDS (same clamped positions)
 #pragma unroll
-        for (int j = 0; j < KC; ++j)                         // (one chunk per lane: every load is awaited before the first use anyway, so a
-            if (j < 16 || j < ku) x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + rl);   // wave-uniform skip; the first 16
-                                                                                                               // slots are always user columns (kt >= 17))
-        yv = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + rl);
-        sw = *reinterpret_cast<const V *>(static_cast<const T *>(has_w ? a.w : a.y) + rl);
+        for (int j = 0; j < KC; ++j) {                       // (one chunk per lane: every load is awaited before the first use anyway, so a
+            if (j < 16 || j < ku) {                          // wave-uniform skip; the first 16 slots are always user columns (kt >= 17))
+                if (j < np) x[j] = *reinterpret_cast<const V *>(pf_at(wave, j) + lane * 16);
+                else x[j] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + rl);
+            }
+        }
+        if (ku < np) yv = *reinterpret_cast<const V *>(pf_at(wave, ku) + lane * 16);
+        else yv = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + rl);
+        if (has_w && ku + 1 < np) sw = *reinterpret_cast<const V *>(pf_at(wave, ku + 1) + lane * 16);
+        else sw = *reinterpret_cast<const V *>(static_cast<const T *>(has_w ? a.w : a.y) + rl);
     }
 
     // ---- this chunk's registers
@@ -269,9 +277,33 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
     }
     __syncthreads();
     K2W_STAMP(3);
+    bool pf_next = false;
+    if constexpr (WAVES == 8) {
+        const int64_t gn = g + gridDim.x;
+        pf_next = npf > 0 && gn < a.n_groups;                // block-uniform
+        if (pf_next && wave != 0) {                          // (the tiles' partial sums were consumed before the barrier above)
+            const int64_t sn = a.offs[gn], en = a.offs[gn + 1];
+            const int64_t basen = sn - (sn % VEC);
+            const int64_t nchn = (en - basen + VEC - 1) / VEC;
+            const int npieces = WAVES * npf;
+            for (int p = wave - 1; p < npieces; p += WAVES - 1) {
+                const int col = p / WAVES, wt = p - col * WAVES;                // column-major: every wave's first columns first
+                const T *src = static_cast<const T *>(col < ku ? a.x[col] : (col == ku ? a.y : a.w));
+                const int64_t c = (int64_t)wt * 64 + lane;
+                int64_t rl = c < nchn ? basen + c * VEC : basen;               // the clamped position the consumer expects
+                if (rl > a.n_rows - VEC) rl = a.n_rows - VEC;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + rl),
+                                                 (__attribute__((address_space(3))) void *)pf_at(wt, col), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed before the barrier below lets anyone read them
+        }
+    }
 
-    // ---- solve: wave 0, f64
-    if (wave == 0) {
+    // ---- solve: one wave, f64.  Which one: workgroups that share a CU put their solver on different SIMDs (a workgroup's wave w runs
+    // on SIMD (w mod 4) when the CU fills in order; with every workgroup solving on its wave 0 the co-resident solves all queue on one
+    // SIMD while three idle)
+    const int solver = WAVES == 8 ? 0 : (int)((blockIdx.x / (gridDim.x / (8 / WAVES))) % WAVES);
+    if (wave == solver) {
         int st = POLS_GROUP_OK;
         double bi = 0.0;
         if (e == s) st = POLS_GROUP_EMPTY;                   // features.is_empty() -> zeros (ex.rs:357-359)
@@ -337,12 +369,23 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a) {
     }
 #undef K2W_STAMP
     __syncthreads();                                         // vec / Gs / the tiles are rewritten by the next group
+    pf_ready = pf_next;
     }   // groups of this workgroup
 }
 
 template <typename T, int WAVES, bool HAS_W>
 static int k2w_launch_v(pols_ctx *ctx, const K2wArgs &a) {
-    const size_t lds = (size_t)WAVES * K2_TILE_B + K2W_TAIL_B;
+    size_t lds = (size_t)WAVES * K2_TILE_B + K2W_TAIL_B;
+    // eight waves = one persistent workgroup per CU: the rest of the CU's 160 KiB LDS (and the idle Gram tiles) take the next group's
+    // first columns while wave 0 solves (POLS_K2_NOPREFETCH=1: off)
+    int npf = 0, pf_ded = 0;
+    if (WAVES == 8 && !ctx->opt.k2_noprefetch) {
+        const int ncols = a.k_user + 1 + (a.w ? 1 : 0);
+        pf_ded = (int)((160 * 1024 - lds) / 1024 / WAVES);
+        npf = std::min(ncols, K2W_PF_TILE + pf_ded);
+        pf_ded = std::max(0, npf - K2W_PF_TILE);
+        lds += (size_t)WAVES * pf_ded * 1024;
+    }
     // persistent: two waves per SIMD by the register budget -> one 8-wave or two 4-wave workgroups per CU
     const unsigned grid = (unsigned)std::min<int64_t>(a.n_groups, (int64_t)ctx->num_cus * (8 / WAVES));
     static OncePerDevice attr_once;
@@ -363,9 +406,9 @@ static int k2w_launch_v(pols_ctx *ctx, const K2wArgs &a) {
     }
     hipEvent_t ev0, ev1;
     if (timing_pair(ctx, &ev0, &ev1))
-        hipExtLaunchKernelGGL((k2w_kernel<T, WAVES, HAS_W>), dim3(grid), dim3(64 * WAVES), (unsigned)lds, ctx->stream, ev0, ev1, 0, aa);
+        hipExtLaunchKernelGGL((k2w_kernel<T, WAVES, HAS_W>), dim3(grid), dim3(64 * WAVES), (unsigned)lds, ctx->stream, ev0, ev1, 0, aa, npf, pf_ded);
     else
-        hipLaunchKernelGGL((k2w_kernel<T, WAVES, HAS_W>), dim3(grid), dim3(64 * WAVES), lds, ctx->stream, aa);
+        hipLaunchKernelGGL((k2w_kernel<T, WAVES, HAS_W>), dim3(grid), dim3(64 * WAVES), lds, ctx->stream, aa, npf, pf_ded);
     POLS_HIP(hipGetLastError());
     if (ctx->opt.timeline) return report_timeline(ctx, aa.dbg, a.n_groups, 6, name);
     return POLS_OK;
@@ -374,6 +417,8 @@ static int k2w_launch_v(pols_ctx *ctx, const K2wArgs &a) {
 template <typename T>
 int k2w_launch_t(pols_ctx *ctx, const K2wArgs &a, int64_t need) {
     constexpr int VEC = Vec16<T>::N;
+    // (two waves per SIMD by the register budget: 8 / WAVES workgroups per CU -- the short groups' serial solves overlap four deep)
+    if (need <= 128 * VEC) return a.w ? k2w_launch_v<T, 2, true>(ctx, a) : k2w_launch_v<T, 2, false>(ctx, a);
     if (need <= 256 * VEC) return a.w ? k2w_launch_v<T, 4, true>(ctx, a) : k2w_launch_v<T, 4, false>(ctx, a);
     if (need <= 512 * VEC) return a.w ? k2w_launch_v<T, 8, true>(ctx, a) : k2w_launch_v<T, 8, false>(ctx, a);
     return fail(POLS_ERR_UNSUPPORTED, "k2w: %lld-row groups exceed the resident capacity", (long long)need);
