@@ -13,6 +13,8 @@ if os.environ.get("ENGINE"):                                  # ENGINE=k2w | str
     eng.set_option("STATIC_ENGINE", os.environ["ENGINE"])
 KS = tuple(int(v) for v in os.environ.get("KS", "15,16,20,24,31").split(","))
 for dt, dname in ((torch.float32, "f32"), (torch.float64, "f64")):
+    if os.environ.get("ONLY_F64") and dt != torch.float64:
+        continue
     for k in KS:
         for G, n in ((10_000, 1000), (50_000, 200)):
             if dt == torch.float64 and k > 20 and n == 1000:

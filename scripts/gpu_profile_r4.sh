@@ -60,11 +60,24 @@ for r in csv.DictReader(open(sys.argv[1])):
 for k,v in acc.items(): print(k, ' '.join('%s=%.4g'%(c, sum(x)/len(x)) for c,x in v.items()))
 PY
 done; done 2>&1 | tee $O/${TAG}_pmc_sq_dynamic.txt
+echo "== K2w (f64, 31 columns x 1 000 rows): HBM traffic and matrix-core / wait counters"
+for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+  rm -rf /tmp/pmc; KS=31 ONLY_F64=1 timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc -o p -- python $R/scripts/bench_k16.py > /dev/null 2> /tmp/pmc.err
+  f=$(find /tmp/pmc -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 - "$f" <<'PY'
+import csv,sys,collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k=r['Kernel_Name']
+    if 'k2w_kernel<double, 8' in k: acc[k[:70]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k,v in acc.items(): print(k, ' '.join('%s=%.6g (n=%d)'%(c, sum(x)/len(x), len(x)) for c,x in v.items()))
+PY
+done 2>&1 | tee $O/${TAG}_pmc_k2w.txt
 cd $R
 echo "== side benches"
 timeout 200 python scripts/bench_ragged.py 2>/dev/null | tail -1 > $O/${TAG}_bench_ragged.json; cut -c1-1200 $O/${TAG}_bench_ragged.json; echo
 timeout 120 python scripts/bench_nulls.py 2>/dev/null | tail -1 > $O/${TAG}_bench_nulls.json; cat $O/${TAG}_bench_nulls.json; echo
 timeout 200 python scripts/bench_k9.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k9.txt; cut -c1-160 $O/${TAG}_bench_k9.txt
-timeout 200 python scripts/bench_k16.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k16.txt; cat $O/${TAG}_bench_k16.txt
+KS=15,16,17,20,24,28,31 timeout 300 python scripts/bench_k16.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_k16.txt; cat $O/${TAG}_bench_k16.txt
 rm -rf $O/kt_* $O/pmc_FETCH* $O/pmc_WRITE* $O/pmc_mfma
 ls $O
