@@ -22,6 +22,7 @@
 //   predict : X . beta (+ residuals) from the resident rows, 16-byte streaming stores.                                  [1 barrier]
 // Bound: HBM, b n (k + 1) (+ b n weights) bytes in, b n out per group.
 #pragma once
+#include <cstddef>
 #include "k2_kernel.inl"
 #include "k2w_resident.hpp"
 
@@ -120,7 +121,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a, con
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *Gs = reinterpret_cast<double *>(smem + (size_t)WAVES * K2_TILE_B);      // [32][33]
     double *As = Gs + 32 * K2W_GS;                                                    // solver matrix [32][33]
-    double *vec = As + 32 * K2W_GS;                                                   // [0, 32) beta
+    double *vec = As + 32 * K2W_GS;                                                   // [0, 32) beta, [32, 64) the column pointers (prefetch)
+    unsigned long long *s_xptr = reinterpret_cast<unsigned long long *>(vec + 32);
     unsigned char *pfd = smem + (size_t)WAVES * K2_TILE_B + K2W_TAIL_B;               // [wave][pf_ded][1 KiB]
     // piece (consumer wave wt, loaded column col < npf) lives at:
     auto pf_at = [&](int wt, int col) -> unsigned char * {
@@ -128,6 +130,11 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a, con
                                  : pfd + ((size_t)wt * pf_ded + (col - K2W_PF_TILE)) * 1024;
     };
     bool pf_ready = false;                                   // the pieces hold columns of the group being worked on
+    if (WAVES == 8 && npf > 0) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (threadIdx.x == j) s_xptr[j] = reinterpret_cast<unsigned long long>(a.x[j]);
+    }                                                        // (read after several barriers)
 
 #pragma unroll 1
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
@@ -288,7 +295,10 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a, con
             const int npieces = WAVES * npf;
             for (int p = wave - 1; p < npieces; p += WAVES - 1) {
                 const int col = p / WAVES, wt = p - col * WAVES;                // column-major: every wave's first columns first
-                const T *src = static_cast<const T *>(col < ku ? a.x[col] : (col == ku ? a.y : a.w));
+                // (a.x[col] with a run-time col: from the LDS copy of the pointer table made at kernel start -- indexing the kernel
+                // arguments at run time left the f64 build with a 36-byte private segment)
+                const T *xcol = reinterpret_cast<const T *>(s_xptr[col < ku ? col : 0]);
+                const T *src = col < ku ? xcol : static_cast<const T *>(col == ku ? a.y : a.w);
                 const int64_t c = (int64_t)wt * 64 + lane;
                 int64_t rl = c < nchn ? basen + c * VEC : basen;               // the clamped position the consumer expects
                 if (rl > a.n_rows - VEC) rl = a.n_rows - VEC;
