@@ -101,8 +101,8 @@ __device__ __forceinline__ bool k2w_chol(const double *G, int kt, double alpha, 
     return ok;
 }
 
-// npf (eight-wave form: ONE persistent workgroup per CU, nothing else on the CU while wave 0 solves): the first npf of a wave's
-// loaded columns (features, then the target, then the weights) of the NEXT group are DMA'd into LDS by waves 1..7 during the solve
+// npf: the first npf of a wave's loaded columns (features, then the target, then the weights) of the workgroup's NEXT group are DMA'd
+// into LDS by the waves that are not solving, during the solve
 // (`global_load_lds`, 1 KiB per wave-instruction) -- a CU's memory pipe delivers ~10 bytes per clock however idle HBM is, and a
 // 31-column x 1 000-row f64 group is 264 KB of it.  Pieces 0..7 of a wave sit in that wave's own Gram tile (idle between the
 // reduce and the next group's transposes; read back by the same wave before it writes the tile: no barrier), the rest in the LDS
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a, con
                                  : pfd + ((size_t)wt * pf_ded + (col - K2W_PF_TILE)) * 1024;
     };
     bool pf_ready = false;                                   // the pieces hold columns of the group being worked on
-    if (WAVES == 8 && npf > 0) {
+    if (npf > 0) {
 #pragma unroll
         for (int j = 0; j < 32; ++j)
             if (threadIdx.x == j) s_xptr[j] = reinterpret_cast<unsigned long long>(a.x[j]);
@@ -284,16 +284,21 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a, con
     }
     __syncthreads();
     K2W_STAMP(3);
+    // which wave solves: workgroups that share a CU put their solver on different SIMDs (a workgroup's wave w runs on SIMD (w mod 4)
+    // when the CU fills in order; with every workgroup solving on its wave 0 the co-resident solves all queue on one SIMD while three idle)
+    const unsigned per_cu_round = gridDim.x >= 8 / WAVES ? gridDim.x / (8 / WAVES) : 1u;   // (workgroup b and b + per_cu_round tend to share a CU)
+    const int solver = WAVES == 8 ? 0 : (int)((blockIdx.x / per_cu_round) % WAVES);
     bool pf_next = false;
-    if constexpr (WAVES == 8) {
+    {
         const int64_t gn = g + gridDim.x;
         pf_next = npf > 0 && gn < a.n_groups;                // block-uniform
-        if (pf_next && wave != 0) {                          // (the tiles' partial sums were consumed before the barrier above)
+        if (pf_next && wave != solver) {                     // (the tiles' partial sums were consumed before the barrier above)
+            const int producer = wave < solver ? wave : wave - 1;             // 0 .. WAVES - 2
             const int64_t sn = a.offs[gn], en = a.offs[gn + 1];
             const int64_t basen = sn - (sn % VEC);
             const int64_t nchn = (en - basen + VEC - 1) / VEC;
             const int npieces = WAVES * npf;
-            for (int p = wave - 1; p < npieces; p += WAVES - 1) {
+            for (int p = producer; p < npieces; p += WAVES - 1) {
                 const int col = p / WAVES, wt = p - col * WAVES;                // column-major: every wave's first columns first
                 // (a.x[col] with a run-time col: from the LDS copy of the pointer table made at kernel start -- indexing the kernel
                 // arguments at run time left the f64 build with a 36-byte private segment)
@@ -309,10 +314,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k2w_kernel(const K2wArgs a, con
         }
     }
 
-    // ---- solve: one wave, f64.  Which one: workgroups that share a CU put their solver on different SIMDs (a workgroup's wave w runs
-    // on SIMD (w mod 4) when the CU fills in order; with every workgroup solving on its wave 0 the co-resident solves all queue on one
-    // SIMD while three idle)
-    const int solver = WAVES == 8 ? 0 : (int)((blockIdx.x / (gridDim.x / (8 / WAVES))) % WAVES);
+    // ---- solve: one wave, f64
     if (wave == solver) {
         int st = POLS_GROUP_OK;
         double bi = 0.0;
@@ -389,9 +391,11 @@ static int k2w_launch_v(pols_ctx *ctx, const K2wArgs &a) {
     // eight waves = one persistent workgroup per CU: the rest of the CU's 160 KiB LDS (and the idle Gram tiles) take the next group's
     // first columns while wave 0 solves (POLS_K2_NOPREFETCH=1: off)
     int npf = 0, pf_ded = 0;
-    if (WAVES == 8 && !ctx->opt.k2_noprefetch) {
+    // (two-wave workgroups: measured slower with it, f64 31 / 24 columns x 200 rows 2.29 / 2.16 against 2.36 / 2.24 TB/s -- four workgroups
+    // per CU already keep the memory pipe busy and the DMA competes with their loads; four waves: f32 31 columns x 1 000 rows 2.76 -> 2.87)
+    if (WAVES >= 4 && !ctx->opt.k2_noprefetch) {
         const int ncols = a.k_user + 1 + (a.w ? 1 : 0);
-        pf_ded = (int)((160 * 1024 - lds) / 1024 / WAVES);
+        pf_ded = (int)(((size_t)160 * 1024 * WAVES / 8 - lds) / 1024 / WAVES);   // (8 / WAVES workgroups share the CU's LDS)
         npf = std::min(ncols, K2W_PF_TILE + pf_ded);
         pf_ded = std::max(0, npf - K2W_PF_TILE);
         lds += (size_t)WAVES * pf_ded * 1024;
