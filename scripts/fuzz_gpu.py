@@ -87,6 +87,52 @@ for it in range(N_DYN):
     except Exception as exc:
         bad += 1
         print("DYNAMIC ERROR", it, k, G, repr(exc)[:200])
+# ---- the row-parallel dynamic kernels (K3c / K4c): many sequences around the tile sizes (packed tiles, halo tiles, two-pass RLS), f32 and f64
+N_DYN2 = int(os.environ.get("FUZZ_DYN2", "120")); seen2 = {}
+for it in range(N_DYN2):
+    dtype = np.float64 if rng.random() < 0.6 else np.float32
+    k = int(rng.integers(1, 9)); G = int(rng.integers(1, 400))
+    top = int(rng.choice([3, 40, 300, 509, 1021, 1024, 1100, 2600]))
+    y, cols, offs, _ = frame(G, int(rng.choice([0, 1, top // 2])), top, k, dtype)
+    if len(y) < 8:
+        continue
+    valid = None if rng.random() < 0.6 else (rng.random(len(y)) > 0.08).astype(np.uint8)
+    tol = 2e-6 if dtype == np.float64 else 2e-3
+    try:
+        if rng.random() < 0.5:
+            hl = None if rng.random() < 0.3 else float(rng.uniform(5, 300))
+            p0 = float(rng.choice([1.0, 10.0, 1e4]))
+            out = eng.recursive_least_squares(y, cols, offs, valid=valid, half_life=hl, initial_state_covariance=p0, null_free=valid is None)
+            ref = orc.batched_rls(y, cols, offs, half_life=hl, initial_state_covariance=p0, is_valid=valid)
+            vm = np.ones(len(y), dtype=bool) if valid is None else valid.astype(bool)
+            ok = (np.allclose(out["coef"], ref["coef"], rtol=tol, atol=tol) and np.allclose(out["pred"][vm], ref["pred"][vm], rtol=tol, atol=tol)
+                  and np.isnan(out["pred"][~vm]).all())
+            what = ("rls", hl, p0)
+        else:
+            win = int(rng.integers(max(2, k), 509)); pol = str(rng.choice(["drop", "drop_window"]))
+            mp = int(rng.integers(1, win + 1)) if rng.random() < 0.5 else None
+            out = eng.rolling_least_squares(y, cols, offs, valid=valid, window_size=win, min_periods=mp, null_policy=pol, null_free=valid is None)
+            ref = orc.batched_rolling(y, cols, offs, win, min_periods=mp, null_policy=pol, is_valid=valid)
+            sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e2)
+            v = np.ones(len(y), dtype=np.int64) if valid is None else valid.astype(np.int64); nobs = np.zeros(len(y), dtype=np.int64)
+            for g in range(G):
+                s_, e_ = offs[g], offs[g + 1]; c = np.cumsum(v[s_:e_])
+                if pol == "drop": nobs[s_:e_] = np.minimum(c, win)
+                else: nobs[s_:e_] = c - np.concatenate([np.zeros(min(win, e_ - s_), dtype=np.int64), c[: max(0, e_ - s_ - win)]])
+            m = sane & (nobs >= 2 * k + 4)
+            vm = v.astype(bool)
+            rt = 10 * tol
+            ok = (np.allclose(out["coef"][m], ref["coef"][m], rtol=rt, atol=rt) and np.allclose(out["pred"][m & vm], ref["pred"][m & vm], rtol=rt, atol=rt)
+                  and np.isnan(out["pred"][~vm]).all())
+            what = ("rolling", win, mp, pol)
+        seen2[eng.last_kernel] = seen2.get(eng.last_kernel, 0) + 1
+        if not ok:
+            bad += 1
+            print("DYN2 MISMATCH", it, dtype.__name__, "k", k, "G", G, "top", top, "valid", valid is not None, what, eng.last_kernel)
+    except Exception as exc:
+        bad += 1
+        print("DYN2 ERROR", it, dtype.__name__, k, G, top, repr(exc)[:200])
+print("row-parallel dynamic cases ran:", dict(sorted(seen2.items())))
 # ---- null policies (static models; expected values composed like the reference composes them: tests/test_nulls_gpu.py::_expected)
 from test_nulls_gpu import _expected
 for it in range(80):
