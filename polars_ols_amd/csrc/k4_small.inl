@@ -63,31 +63,28 @@ __device__ __forceinline__ double fast_rcp(double d) {
 
 // The same solve as a square-root-free L D L' factorisation: K reciprocals instead of K (sqrt + division) pairs -- about a third of
 // chol_solve's instructions at K = 6 -- keeping only L and 1 / d in registers.  (S + alpha I) beta = b with S packed upper, b = S[NX ..].
-// CLAMP: a non-positive pivot is replaced by eps x its diagonal entry (no LU, no call, no scratch) -- for callers whose matrix is
+// CLAMP: a pivot below eps x its diagonal entry (non-positive ones included) is replaced by that (no LU, no call, no scratch) -- for callers whose matrix is
 // positive definite in exact arithmetic, where such a pivot is rounding noise.  Otherwise `ok` comes back false and beta is unusable.
 template <int K, bool CLAMP, int LEN>
 __device__ __forceinline__ bool ldl_solve_small(const double (&S)[LEN], double alpha, double (&beta)[K]) {
     static_assert(LEN >= K4N<K>::N, "packed upper triangle + right-hand side");
-    double L[K][K], dinv[K], dd[K];
-    bool ok = true;
+    double L[K][K], W[K][K], dinv[K];                         // W[i][j] = L[i][j] d_j: the unscaled column entries, kept so that row j's
+    bool ok = true;                                           // u[p] = L[j][p] d_p below costs nothing
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        double u[K];
-#pragma unroll
-        for (int p = 0; p < j; ++p) u[p] = L[j][p] * dd[p];
         const double ajj = S[tri_index<K>(j, j)] + alpha;
         double d = ajj;
 #pragma unroll
-        for (int p = 0; p < j; ++p) d = fma(-u[p], L[j][p], d);
-        if constexpr (CLAMP) d = d > 0.0 ? d : 0x1p-52 * ajj;
+        for (int p = 0; p < j; ++p) d = fma(-W[j][p], L[j][p], d);
+        if constexpr (CLAMP) d = fmax(d, 0x1p-52 * ajj);      // (one v_max_f64; a pivot below eps x its diagonal entry is noise either way)
         else ok = ok && (d > 0.0);
-        dd[j] = d;
         dinv[j] = fast_rcp(d);
 #pragma unroll
         for (int i = j + 1; i < K; ++i) {
             double s = S[tri_index<K>(j, i)];
 #pragma unroll
-            for (int p = 0; p < j; ++p) s = fma(-u[p], L[i][p], s);
+            for (int p = 0; p < j; ++p) s = fma(-W[j][p], L[i][p], s);
+            W[i][j] = s;
             L[i][j] = s * dinv[j];
         }
     }
