@@ -45,10 +45,10 @@ __device__ __forceinline__ void k3c_seg_scan(double &D, double (&Tv)[NT], const 
 #define K3C_STEP(CTRL, RM, OK)                                                                  \
     {                                                                                           \
         const bool ok_ = (OK);                                                                  \
-        const double dp = dpp_get<CTRL, RM>(D);                                                 \
+        const double dp = dpp_get0<CTRL>(D);                                                 \
         _Pragma("unroll") for (int q0 = 0; q0 < NT; q0 += CH) {   /* CH partner values in flight at a time */ \
             double tp[CH];                                                                      \
-            _Pragma("unroll") for (int q = 0; q < CH; ++q) tp[q] = dpp_get<CTRL, RM>(Tv[q0 + q < NT ? q0 + q : NT - 1]); \
+            _Pragma("unroll") for (int q = 0; q < CH; ++q) tp[q] = dpp_get0<CTRL>(Tv[q0 + q < NT ? q0 + q : NT - 1]); \
             if (ok_) {                                                                          \
                 _Pragma("unroll") for (int q = 0; q < CH; ++q)                                  \
                     if (q0 + q < NT) Tv[q0 + q] = fma(D, tp[q], Tv[q0 + q]);                    \
@@ -98,9 +98,9 @@ __device__ __forceinline__ bool k3c_scan_window(const double *rec, const int32_t
     const unsigned long long hm = __ballot(head);
     const unsigned long long up2 = hm & (~0ull >> (63 - lane));
     k3c_seg_scan<NT>(Dl, Tl, up2 ? 63 - __clzll(up2) : -1, lane);
-    double ED2 = dpp_get<0x138>(Dl), ET2[NT];
+    double ED2 = dpp_get0<0x138>(Dl), ET2[NT];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) ET2[q] = dpp_get<0x138>(Tl[q]);
+    for (int q = 0; q < NT; ++q) ET2[q] = dpp_get0<0x138>(Tl[q]);
     if (lane == 0) {
         ED2 = 1.0;
 #pragma unroll
@@ -285,9 +285,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) k3c_kernel(con
         s_closed[wv] = hmask != 0;
     }
     // exclusive value: the inclusive value of the lane below (wave_shr:1); lane 0: the identity
-    double ED = dpp_get<0x138>(Dl), ET[NT];
+    double ED = dpp_get0<0x138>(Dl), ET[NT];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) ET[q] = dpp_get<0x138>(Tl[q]);
+    for (int q = 0; q < NT; ++q) ET[q] = dpp_get0<0x138>(Tl[q]);
     if (lane == 0) ED = 1.0;
     const bool eopen = (hmask & ((1ull << lane) - 1ull)) == 0;                // no sequence start in the lanes below
     __syncthreads();

@@ -53,6 +53,17 @@ __device__ __forceinline__ void solve_state(const double (&S)[K4N<K>::N], double
     }
 }
 
+// DPP move with bound_ctrl (lanes whose source lies outside the row / wave read 0) and every row enabled: unlike common.hpp's dpp_get
+// the destination needs no `v_mov_b32 v, 0` in front of every v_mov_b32_dpp -- 2 of the 5 instructions per f64 component and scan step.
+// For scans whose combine step is predicated per lane anyway (the segmented scans of k3c_scan.hip / k4c_rolling.hip).
+template <int CTRL>
+__device__ __forceinline__ double dpp_get0(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // 1 / d to f64 accuracy without the IEEE division sequence: v_rcp_f64 + two Newton steps (the solves below run once per ROW)
 __device__ __forceinline__ double fast_rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);

@@ -38,7 +38,7 @@ __device__ __forceinline__ void k4c_seg_scan_add(double (&Tv)[NC], const int h, 
         const bool ok_ = (OK);                                                                                  \
         _Pragma("unroll") for (int q0 = 0; q0 < NC; q0 += CH) {                                                 \
             double tp[CH];                                                                                      \
-            _Pragma("unroll") for (int q = 0; q < CH; ++q) tp[q] = dpp_get<CTRL, RM>(Tv[q0 + q < NC ? q0 + q : NC - 1]); \
+            _Pragma("unroll") for (int q = 0; q < CH; ++q) tp[q] = dpp_get0<CTRL>(Tv[q0 + q < NC ? q0 + q : NC - 1]); \
             if (ok_) {                                                                                          \
                 _Pragma("unroll") for (int q = 0; q < CH; ++q)                                                  \
                     if (q0 + q < NC) Tv[q0 + q] += tp[q];                                                       \
@@ -62,7 +62,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
     constexpr int VN = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *s_E = reinterpret_cast<double *>(smem);              // [NC][RUNS]: exclusive prefix of every run
-    double *s_agg = s_E + (size_t)NC * RUNS;                     // [WAVES][NC]: wave totals (from the wave's last sequence start on)
+    // (the same region first holds the tile's rows -- 4 (K + 1) x RUNS values of the batch dtype -- for the hand-over of the leaving rows)
+    constexpr size_t TAB_B = sizeof(double) * NC * RUNS > sizeof(T) * 4 * (K + 1) * RUNS ? sizeof(double) * NC * RUNS : sizeof(T) * 4 * (K + 1) * RUNS;
+    double *s_agg = reinterpret_cast<double *>(smem + TAB_B);    // [WAVES][NC]: wave totals (from the wave's last sequence start on)
     int *s_closed = reinterpret_cast<int *>(s_agg + WAVES * NC); // [WAVES]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #define K4C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -113,9 +115,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
             if (in && a.start[ic]) sbits |= 1u << (8 * r);
         }
     }
-    // The LEAVING rows of a body lane's run (rows i0 - window .. + 3, in the run u - ceil(window / 4), o = (-window) mod 4 rows in):
-    // issued here, right behind the entering rows, so that they are in registers long before the walk needs them -- they are
-    // rows another wave of this workgroup is loading just now, one L2 line fill serves both.
     const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
     const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window
     const int up = u - sh < 0 ? 0 : u - sh;                                    // table index: u - sh >= 0 for body lanes behind a halo (it covers `window`
@@ -127,33 +126,33 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
         for (int j = 0; j < K; ++j) xr[j] = (double)static_cast<const T *>(a.x[j])[ic];
         yr = (double)static_cast<const T *>(a.y)[ic];
     };
+    // The LEAVING rows of a body lane's run -- rows i0 - window .. + 3: rows (o + r) of the runs u - sh and u - sh + 1 -- are rows other
+    // lanes of this workgroup have just loaded: they change hands through LDS (the region the prefix table takes over after the next
+    // barrier: [row of the run][column][run], batch dtype).  Loaded from global memory instead (round 4 until then: 16-byte loads, L2
+    // hits) they went through the CU's memory pipe a second time -- a third of the tile's traffic on the resource this kernel is bound
+    // by (10.5 bytes per clock per CU with them).
     double xo[R][K], yo[R];
-    auto load_leaving = [&]() {
-        const int64_t l0 = rho_run + o;
-        if ((o % VN) == 0 && __all(l0 >= 0 && l0 + R <= N)) {                  // 16-byte aligned: vector loads
+    {
+        T *s_X = reinterpret_cast<T *>(smem);
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + l0);
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int i = 0; i < R / VN; ++i) {
-                    const V v = p[i];
-#pragma unroll
-                    for (int e = 0; e < VN; ++e) xo[i * VN + e][j] = (double)vget<T>(v, e);
-                }
-            }
-            const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.y) + l0);
-#pragma unroll
-            for (int i = 0; i < R / VN; ++i) {
-                const V v = p[i];
-#pragma unroll
-                for (int e = 0; e < VN; ++e) yo[i * VN + e] = (double)vget<T>(v, e);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) load_row(l0 + r, xo[r], yo[r]);
+            for (int j = 0; j < K; ++j) s_X[(size_t)(r * (K + 1) + j) * RUNS + u] = (T)x[r][j];
+            s_X[(size_t)(r * (K + 1) + K) * RUNS + u] = (T)y[r];
         }
-    };
-    if (wv >= HW) load_leaving();
+        __syncthreads();
+        if (wv >= HW) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int g = (u - sh) * R + o + r;                                  // row index inside [halo | body]; negative: never used (the
+                g = g < 0 ? 0 : g;                                             // sequence then starts inside the tile, `sub` below stays false)
+                const int run = g >> 2, rr = g & 3;
+#pragma unroll
+                for (int j = 0; j < K; ++j) xo[r][j] = (double)s_X[(size_t)(rr * (K + 1) + j) * RUNS + run];
+                yo[r] = (double)s_X[(size_t)(rr * (K + 1) + K) * RUNS + run];
+            }
+        }
+    }
     bool st[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) st[r] = ((sbits >> (8 * r)) & 0xffu) != 0;
@@ -197,7 +196,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
     }
     double ET[NC];
 #pragma unroll
-    for (int q = 0; q < NC; ++q) ET[q] = dpp_get<0x138>(Tl[q]);                // wave_shr:1 -- the lane below's inclusive value
+    for (int q = 0; q < NC; ++q) ET[q] = dpp_get0<0x138>(Tl[q]);                // wave_shr:1 -- the lane below's inclusive value
     const bool eopen = (hmask & ((1ull << lane) - 1ull)) == 0;                // no sequence start in the lanes below
     __syncthreads();
     if (eopen) {                                                               // prepend the waves below, from their last sequence start
@@ -297,7 +296,8 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     static_assert(HW != 0 || (WAVES - HW) * 256 == K4C_PACKED_ROWS, "the packed tile map is built for this tile");
     a.n_tiles = HW == 0 ? a.n_packed : (a.n_rows + tile_rows - 1) / tile_rows;
     const int64_t per_xcd = (a.n_tiles + 7) / 8;
-    const size_t lds = std::max(sizeof(double) * ((size_t)NC * 64 * WAVES + WAVES * NC) + 64,                      // prefix table + wave totals
+    const size_t tab = std::max(sizeof(double) * (size_t)NC * 64 * WAVES, sizeof(T) * (size_t)4 * (K + 1) * 64 * WAVES);   // the tile's rows, then the prefix table
+    const size_t lds = std::max(tab + sizeof(double) * WAVES * NC + 64,                                             // ... + wave totals
                                 (size_t)(WAVES - HW) * 4 * (K + 1) * DYN_STAGE_STRIDE * sizeof(T));              // ... reused as the output staging area
     static OncePerDevice attr_once;
     if (attr_once.needed(ctx->device)) {
