@@ -139,7 +139,8 @@ def test_hot_kernels_keep_their_arrays_in_registers():
     ks = kernel_scratch(_lib.LIB_PATH)
     assert len(ks) > 500, len(ks)
     hot = ("pols::k1_kernel<", "pols::k1t_kernel<", "pols::k1p_kernel<", "pols::k1m_kernel<", "pols::k2_kernel<", "pols::gram_stream_kernel<",
-           "pols::predict_kernel<", "pols::gram_solve_kernel<", "pols::take_kernel<", "pols::arrow_ingest_kernel<")
+           "pols::predict_kernel<", "pols::gram_solve_kernel<", "pols::take_kernel<", "pols::arrow_ingest_kernel<",
+           "pols::k2w_kernel<", "pols::k3c_kernel<", "pols::k4c_kernel<")      # round 4: the 17..31-column and the row-parallel dynamic kernels
     bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0}
     assert not bad, sorted(bad.items())[:5]
 
@@ -167,6 +168,10 @@ def test_bench_kernels_keep_two_waves_per_simd():
         "pols::k1_kernel<float, 9, false, 64, 4, true, 3, false, false, false>(": 256,
         "pols::k1_kernel<float, 8, false, 64, 1, true, 1, false, false, true>(": 128,    # ragged year-sized groups: the EDGE wave kernel      # smoke(): 8 features + intercept
         "pols::k2_kernel<double, 16, 8, 2, true, false>(": 256,                             # configs[4]
+        "pols::k3c_kernel<double, 6, 4, 4, 1>(": 168,                                       # configs[3] as RLS: three tiles (12 waves) per CU
+        "pols::k3c_kernel<double, 6, 4, 4, 0>(": 128,                                       # ... its first pass: four waves per SIMD
+        "pols::k4c_kernel<double, 6, 1, 4>(": 256,                                          # configs[3] as rolling OLS: two four-wave workgroups per CU
+        "pols::k4c_kernel<double, 6, 0, 4>(": 256,                                          # ... on packed tiles (many sequences)
     }
     for key, cap in want.items():
         hits = [(k, v) for k, v in ks.items() if key in k]
