@@ -24,7 +24,9 @@
 //      tagged write-through granules, two levels of records) -- 96 us on the 1M-row sequence and 488 us on 10 000 x 1 000 rows,
 //      every tile waits 27-60 k cycles for the tiles running beside it; the scans done inside pass 1 by the last tile / block to
 //      arrive -- pass 1 14 -> 34 us (write-through stores, drained store queues, a two-level serial tail); both record scans in one
-//      16-wave workgroup -- 58 -> 79 us on the 1M-row sequence (458 KB through ONE CU's memory pipe instead of 16).
+//      16-wave workgroup -- 58 -> 79 us on the 1M-row sequence (458 KB through ONE CU's memory pipe instead of 16); the top scan folded
+//      into pass 2 (every tile composes the <= 64 block records below its block itself, no third launch): 50 -> 52-56 us, the chain sits
+//      in front of every tile's row loads.
 //   D  every lane walks its R rows from its carry-in: A' = ff A + x x', one K x K solve per row (square-root-free L D L', LU on
 //      a non-positive pivot like the reference's Cholesky -> LU chain), coefficients and predictions stored 16 bytes at a time.
 // The information matrix is solved directly on every row -- never inverted and propagated -- so a diffuse prior (p0 = 1e6, the

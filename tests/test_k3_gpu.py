@@ -231,3 +231,22 @@ def test_rls_packed_tiles_ragged_sequences(eng, dtype, tol, k):
             eng.set_option("RLS_ENGINE", None)
         assert np.allclose(_np(two["coef"]), _np(out["coef"]), rtol=tol, atol=tol)
         assert np.allclose(_np(two["pred"]), _np(out["pred"]), rtol=tol, atol=tol, equal_nan=True)
+
+
+def test_rls_more_than_64_blocks_of_tiles(eng):
+    """One 4.4M-row sequence = 67 blocks of 64 tiles: the one-wave top scan between the passes chains two 64-block windows (a 1M-row
+    sequence is 16 blocks: one window); a 1M-row neighbour in the same frame.  Every row against the oracle."""
+    from oracle import orc
+
+    rng = np.random.default_rng(6464)
+    k = 3
+    sizes = np.array([4_400_000, 700, 1_000_003], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N) for _ in range(k)]
+    y = sum(cols) + 0.1 * rng.standard_normal(N)
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, half_life=2000.0, null_free=True)
+    assert eng.last_kernel.startswith("k3s_rls_rows")
+    ref = orc.batched_rls(y, cols, offs, half_life=2000.0)
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
