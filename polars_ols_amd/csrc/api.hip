@@ -187,7 +187,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
     else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : ieq(v, "k2w") ? 4 : 0;
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : 0;
-    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : 0;
+    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : ieq(v, "nocompact") ? 3 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
     else return false;
@@ -1419,6 +1419,17 @@ static int ensure_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_gr
     return POLS_OK;
 }
 
+// first rows of the packed tiles of a frame (whole sequences per tile, first fit in frame order; N appended) -- see ensure_packed_tiles
+static void packed_tile_starts(const int64_t *offs, int64_t n_groups, int64_t N, int64_t tile_rows, std::vector<int64_t> *first) {
+    first->clear();
+    int64_t base = -1;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        if (offs[g + 1] == offs[g]) continue;
+        if (base < 0 || offs[g + 1] - base > tile_rows) { first->push_back(offs[g]); base = offs[g] & ~(int64_t)3; }
+    }
+    first->push_back(N);
+}
+
 // Packed tiles of the row-parallel dynamic kernels (K3c / K4c): no sequence longer than a tile (less the three rows a tile may start
 // before its first sequence) -> tiles are cut at sequence starts, whole sequences, first fit in frame order; tile t owns rows
 // [map[t], map[t + 1]).  Taken when the tiles come out at least 70 % full; *n_tiles = 0 otherwise.  Scratch slot 18, cached per frame.
@@ -1433,14 +1444,8 @@ static int ensure_packed_tiles(pols_ctx *ctx, const pols_batch *b, int64_t tile_
     if (tc.ptr != dmap || tc.offs_id != ctx->offs_id || tc.n_groups != b->n_groups || tc.n_rows != N || tc.tile_rows != tile_rows) {
         tc.ptr = nullptr;
         std::vector<int64_t> first;
-        const int64_t *offs = b->group_offsets;
-        int64_t base = -1;
-        for (int64_t g = 0; g < b->n_groups; ++g) {
-            if (offs[g + 1] == offs[g]) continue;
-            if (base < 0 || offs[g + 1] - base > tile_rows) { first.push_back(offs[g]); base = offs[g] & ~(int64_t)3; }
-        }
-        const int64_t nt = (int64_t)first.size();
-        first.push_back(N);
+        packed_tile_starts(b->group_offsets, b->n_groups, N, tile_rows, &first);
+        const int64_t nt = (int64_t)first.size() - 1;
         tc.n_tiles = nt * tile_rows * 7 <= N * 10 ? nt : 0;
         if (tc.n_tiles && (rc = upload_small(ctx, dmap, first.data(), sizeof(int64_t) * first.size()))) return rc;
         tc.ptr = dmap; tc.offs_id = ctx->offs_id; tc.n_groups = b->n_groups; tc.n_rows = N; tc.tile_rows = tile_rows;
@@ -1664,6 +1669,85 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     bool tiles = k <= K4C_KMAX && st.valid == nullptr && mp <= w && w <= K4C_MAX_WINDOW && ctx->opt.rolling_engine != 1 && aligned16(st.y) &&
                  (!st.coef || aligned16(st.coef)) && (!st.pred || aligned16(st.pred));
     for (int j = 0; j < k && tiles; ++j) tiles = aligned16(st.x[j]);
+    // The drop family on a frame WITH nulls (the reference's default policy for rolling_ols, ls.rs:947-986): its deque of valid rows is
+    // the null-free window over the VALID rows, and a row left out repeats the last coefficients -- so the valid rows are compacted
+    // (dyn_prep.hip: slab counts, scan, scatter), the tile kernel runs on them, and an expansion pass forward-fills the coefficients
+    // onto the original rows and predicts them.  Not taken when a non-empty group holds fewer valid rows than min_periods (the
+    // reference then solves a window it never filled, :881-900 -- the lane-per-chunk kernels below reproduce that).
+    bool tiles_c = !tiles && drop && st.valid != nullptr && k <= K4C_KMAX && mp <= w && w <= K4C_MAX_WINDOW && ctx->opt.rolling_engine != 1 &&
+                   ctx->opt.rolling_engine != 3 && b->n_rows >= 8;
+    if (tiles_c) {
+        const int64_t N = b->n_rows, G = b->n_groups, n_slabs = (N + 255) / 256;
+        const size_t sz = dtype_size(b->dtype), colb = round256(sz * (size_t)N);
+        const size_t b_cnt = round256(sizeof(uint32_t) * (size_t)n_slabs), b_base = round256(sizeof(int64_t) * (size_t)(n_slabs + 1)),
+                     b_offs = round256(sizeof(int64_t) * (size_t)(G + 1)), b_gf = round256(sizeof(int64_t) * (size_t)n_slabs),
+                     b_tab = round256(sizeof(void *) * (size_t)(k + 1));
+        void *d = nullptr;
+        if ((rc = ensure_scratch(ctx, 19, b_cnt + b_base + b_offs + b_gf + 2 * b_tab + colb * (size_t)(k + 1), &d))) return rc;
+        char *base = static_cast<char *>(d);
+        char *cols = base + b_cnt + b_base + b_offs + b_gf + 2 * b_tab;
+        std::vector<const void *> inp((size_t)k + 1);
+        std::vector<void *> outp((size_t)k + 1);
+        inp[0] = st.y;
+        for (int j = 0; j < k; ++j) inp[(size_t)j + 1] = st.x[(size_t)j];
+        for (int j = 0; j <= k; ++j) outp[(size_t)j] = cols + colb * (size_t)j;
+        if ((rc = upload_small(ctx, base + b_cnt + b_base + b_offs + b_gf, inp.data(), sizeof(void *) * (size_t)(k + 1)))) return rc;
+        if ((rc = upload_small(ctx, base + b_cnt + b_base + b_offs + b_gf + b_tab, outp.data(), sizeof(void *) * (size_t)(k + 1)))) return rc;
+        RowCompactArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.valid = st.valid;
+        if ((rc = ensure_start_flags(ctx, d_offs, G, N, &ra.start))) return rc;
+        ra.offs = d_offs; ra.n_rows = N; ra.n_groups = G; ra.n_slabs = n_slabs;
+        ra.slab_cnt = reinterpret_cast<uint32_t *>(base);
+        ra.slab_base = reinterpret_cast<int64_t *>(base + b_cnt);
+        ra.c_offs = reinterpret_cast<int64_t *>(base + b_cnt + b_base);
+        ra.slab_gfirst = reinterpret_cast<int64_t *>(base + b_cnt + b_base + b_offs);
+        ra.in = reinterpret_cast<const void *const *>(base + b_cnt + b_base + b_offs + b_gf);
+        ra.out = reinterpret_cast<void *const *>(base + b_cnt + b_base + b_offs + b_gf + b_tab);
+        ra.n_cols = k + 1; ra.k = k;
+        if ((rc = row_compact_offsets_launch(ctx, ra))) return rc;
+        std::vector<int64_t> c_offs((size_t)G + 1);
+        POLS_HIP(hipMemcpyAsync(c_offs.data(), ra.c_offs, sizeof(int64_t) * (size_t)(G + 1), hipMemcpyDeviceToHost, ctx->stream));
+        POLS_HIP(hipStreamSynchronize(ctx->stream));       // the host cuts the compacted frame into tiles and checks the warm-up quirk
+        const int64_t Nc = c_offs[(size_t)G];
+        int64_t max_c = 0;
+        for (int64_t g = 0; g < G && tiles_c; ++g) {
+            const int64_t nc = c_offs[(size_t)g + 1] - c_offs[(size_t)g];
+            if (b->group_offsets[g + 1] > b->group_offsets[g] && nc < mp) tiles_c = false;
+            max_c = std::max(max_c, nc);
+        }
+        if (Nc < 8) tiles_c = false;
+        if (tiles_c) {
+            if ((rc = row_compact_scatter_launch(ctx, b->dtype, ra))) return rc;
+            void *dc = nullptr, *df = nullptr, *dm = nullptr;
+            if ((rc = ensure_scratch(ctx, 20, round256(sz * (size_t)Nc * (size_t)k), &dc))) return rc;
+            if ((rc = ensure_scratch(ctx, 21, round256((size_t)Nc + 4), &df))) return rc;
+            if ((rc = k3c_start_flags(ctx, ra.c_offs, G, Nc, static_cast<uint8_t *>(df)))) return rc;
+            K4cArgs c;
+            std::memset(&c, 0, sizeof(c));
+            c.start = static_cast<const uint8_t *>(df);
+            c.y = outp[0];
+            for (int j = 0; j < k; ++j) c.x[j] = outp[(size_t)j + 1];
+            c.n_rows = Nc; c.coef = dc; c.pred = nullptr;
+            c.window = w; c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
+            if (max_c <= K4C_PACKED_ROWS - 3 && ctx->opt.rolling_engine != 2) {
+                std::vector<int64_t> first;
+                packed_tile_starts(c_offs.data(), G, Nc, K4C_PACKED_ROWS, &first);
+                const int64_t nt = (int64_t)first.size() - 1;
+                if (nt * K4C_PACKED_ROWS * 7 <= Nc * 10) {
+                    if ((rc = ensure_scratch(ctx, 22, round256(sizeof(int64_t) * first.size()), &dm))) return rc;
+                    if ((rc = upload_small(ctx, dm, first.data(), sizeof(int64_t) * first.size()))) return rc;
+                    c.tile_row0 = static_cast<const int64_t *>(dm); c.n_packed = nt;
+                }
+            }
+            if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
+            ra.coef_c = dc; ra.coef = st.coef; ra.pred = st.pred;
+            if ((rc = row_compact_expand_launch(ctx, b->dtype, ra))) return rc;
+            ctx->last_kernel += "_compacted";
+            if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+            return unstage_outputs(ctx, b, b->n_rows, k, o, st);
+        }
+    }
     if (tiles) {
         K4cArgs c;
         std::memset(&c, 0, sizeof(c));

@@ -155,6 +155,158 @@ int mt_predict_launch(pols_ctx *ctx, int dtype, const MtPredictArgs &a) {
     return POLS_OK;
 }
 
+// ---------------------------------------------------------------- row compaction (rolling OLS, drop family, frames with nulls)
+constexpr int RC_SLAB = 256;
+
+// valid rows of this workgroup's slab at or below each thread's row (inclusive), and the slab's total
+__device__ __forceinline__ unsigned rc_slab_prefix(bool ok, unsigned *wave_cnt, unsigned *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned before = 0, tot = 0;
+    for (int w = 0; w < RC_SLAB / 64; ++w) { before += w < wave ? wave_cnt[w] : 0u; tot += wave_cnt[w]; }
+    *total = tot;
+    return before + (unsigned)__popcll(bal & ((2ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(RC_SLAB) rc_count_kernel(const RowCompactArgs a) {
+    __shared__ unsigned wave_cnt[RC_SLAB / 64];
+    const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
+    unsigned total;
+    rc_slab_prefix(r < a.n_rows && a.valid[r], wave_cnt, &total);
+    if (threadIdx.x == 0) a.slab_cnt[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) rc_scan_kernel(const RowCompactArgs a) {          // one workgroup: exclusive prefix over the slabs
+    __shared__ long long part[1024 / 64];
+    __shared__ long long carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t s0 = 0; s0 < a.n_slabs; s0 += 1024) {
+        const int64_t s = s0 + threadIdx.x;
+        const long long v = s < a.n_slabs ? (long long)a.slab_cnt[s] : 0;
+        long long incl = v;                                   // inclusive scan inside the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        long long before = carry;
+        for (int w = 0; w < wave; ++w) before += part[w];
+        if (s < a.n_slabs) a.slab_base[s] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.slab_base[a.n_slabs] = carry;
+}
+
+__global__ void __launch_bounds__(256) rc_groups_kernel(const RowCompactArgs a) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g > a.n_groups) return;
+    const int64_t r0 = a.offs[g], s = r0 / RC_SLAB;
+    int64_t c = a.slab_base[s < a.n_slabs ? s : a.n_slabs];
+    if (s < a.n_slabs)
+        for (int64_t i = s * RC_SLAB; i < r0; ++i) c += a.valid[i] ? 1 : 0;
+    a.c_offs[g] = c;
+    if (g < a.n_groups) {
+        const int64_t r1 = a.offs[g + 1];
+        if (r1 > r0)
+            for (int64_t ss = s + 1; ss <= (r1 - 1) / RC_SLAB; ++ss) a.slab_gfirst[ss] = c;      // slabs that start inside this group
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(RC_SLAB) rc_scatter_kernel(const RowCompactArgs a) {
+    __shared__ unsigned wave_cnt[RC_SLAB / 64];
+    const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
+    const bool ok = r < a.n_rows && a.valid[r];
+    unsigned total;
+    const unsigned incl = rc_slab_prefix(ok, wave_cnt, &total);
+    if (ok) {
+        const int64_t pos = a.slab_base[blockIdx.x] + incl - 1;                          // stable: the rows keep their order
+        for (int c = 0; c < a.n_cols; ++c) static_cast<T *>(a.out[c])[pos] = static_cast<const T *>(a.in[c])[r];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(RC_SLAB) rc_expand_kernel(const RowCompactArgs a) {
+    __shared__ unsigned wave_cnt[RC_SLAB / 64];
+    __shared__ int wave_flag[RC_SLAB / 64];                   // the wave's last sequence start (thread index) or -1
+    __shared__ unsigned s_incl[RC_SLAB];
+    __shared__ long long s_src[RC_SLAB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * RC_SLAB, r = r0 + threadIdx.x;
+    const bool in = r < a.n_rows;
+    const bool ok = in && a.valid[r];
+    const bool st = in && a.start[r];
+    unsigned total;
+    const unsigned incl = rc_slab_prefix(ok, wave_cnt, &total);
+    s_incl[threadIdx.x] = incl;
+    const unsigned long long fw = __ballot(st);
+    const unsigned long long fb = fw & ((2ull << lane) - 1ull);                          // sequence starts at or below this lane
+    int last = fb ? wave * 64 + (63 - __clzll(fb)) : -1;
+    if (lane == 0) wave_flag[wave] = fw ? wave * 64 + (63 - __clzll(fw)) : -1;
+    __syncthreads();
+    for (int w = wave - 1; w >= 0 && last < 0; --w) last = wave_flag[w];
+    // compacted index of the first valid row of this row's sequence (= valid rows of the frame before the sequence's first row)
+    const long long base = a.slab_base[blockIdx.x];
+    long long gfirst;
+    if (last >= 0) gfirst = base + (long long)s_incl[last] - (a.valid[r0 + last] ? 1 : 0);
+    else gfirst = a.slab_gfirst[blockIdx.x];
+    const long long cidx = base + (long long)incl - 1;       // the last valid row at or before this one
+    const long long src = (in && cidx >= gfirst) ? cidx : -1; // none yet in this sequence: NaN (ls.rs:864)
+    s_src[threadIdx.x] = src;
+    __syncthreads();
+    const T qnan = nan_if<T>(1u, T(0));
+    const int k = a.k;
+    const int64_t rows = a.n_rows - r0 < RC_SLAB ? a.n_rows - r0 : RC_SLAB;
+    if (a.coef) {                                             // whole lines: consecutive threads write consecutive values
+        T *dst = static_cast<T *>(a.coef) + r0 * k;
+        const T *cc = static_cast<const T *>(a.coef_c);
+        for (int64_t e = threadIdx.x; e < rows * k; e += RC_SLAB) {
+            const int rr = (int)(e / k), j = (int)(e - (int64_t)rr * k);
+            const long long sidx = s_src[rr];
+            dst[e] = sidx >= 0 ? cc[sidx * k + j] : qnan;
+        }
+    }
+    if (a.pred && in) {
+        T p = qnan;
+        if (src >= 0) {
+            const T *cc = static_cast<const T *>(a.coef_c) + src * k;
+            p = T(0);
+            for (int j = 0; j < k; ++j) p = fma(static_cast<const T *>(a.in[1 + j])[r], cc[j], p);    // (in[0] is the target)
+        }
+        static_cast<T *>(a.pred)[r] = p;
+    }
+}
+
+int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a) {
+    if (a.n_rows == 0) return POLS_OK;
+    hipLaunchKernelGGL(rc_count_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rc_groups_kernel, dim3((unsigned)((a.n_groups + 1 + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+int row_compact_scatter_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a) {
+    if (a.n_rows == 0) return POLS_OK;
+    if (dtype == POLS_F32) hipLaunchKernelGGL(rc_scatter_kernel<float>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(rc_scatter_kernel<double>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+int row_compact_expand_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a) {
+    if (a.n_rows == 0) return POLS_OK;
+    if (dtype == POLS_F32) hipLaunchKernelGGL(rc_expand_kernel<float>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(rc_expand_kernel<double>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
 #define DYN_LAUNCH(kernel)                                                                                              \
     if (a.n_rows == 0) return POLS_OK;                                                                                  \
     const unsigned blocks = (unsigned)((a.n_rows + 255) / 256);                                                         \

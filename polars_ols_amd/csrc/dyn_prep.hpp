@@ -59,6 +59,32 @@ struct MtPredictArgs {
 };
 int mt_predict_launch(pols_ctx *ctx, int dtype, const MtPredictArgs &a);
 
+// Rolling OLS under the drop family on a frame WITH nulls (src/least_squares.rs:947-986: the window is a deque of the last `window`
+// VALID rows, a row left out repeats the last coefficients) = the null-free problem on the valid rows, then every original row takes
+// the coefficients of the last valid row at or before it in its sequence.  Slab-parallel (256 rows per workgroup, any group sizes):
+//   count   valid rows per slab                              scan    exclusive prefix over the slabs (one workgroup)
+//   groups  compacted offset of every group + what a slab that starts inside a group needs to know about it
+//   scatter the valid rows of every column, order kept       [the row-parallel rolling kernel runs on the compacted frame]
+//   expand  coefficients forward-filled onto the original rows (whole lines), predictions from the original rows
+struct RowCompactArgs {
+    const uint8_t *valid;        // n_rows validity bytes (device)
+    const uint8_t *start;        // n_rows sequence-start bytes of the ORIGINAL frame (k3c_start_flags)
+    const int64_t *offs;         // DEVICE group offsets of the original frame, n_groups + 1
+    int64_t n_rows, n_groups, n_slabs;
+    uint32_t *slab_cnt;          // n_slabs
+    int64_t *slab_base;          // n_slabs + 1: valid rows before the slab; [n_slabs] = all of them
+    int64_t *c_offs;             // n_groups + 1: group offsets of the compacted frame
+    int64_t *slab_gfirst;        // n_slabs: compacted offset of the group that holds the slab's first row when it started before the slab
+    const void *const *in;       // DEVICE table of n_cols column pointers (target first, then the features)
+    void *const *out;            // DEVICE table of n_cols compacted column pointers
+    int32_t n_cols, k;
+    const void *coef_c;          // expand: compacted n_valid x k coefficients
+    void *coef, *pred;           // expand: n_rows x k / n_rows (either may be nullptr)
+};
+int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a);            // count + scan + groups
+int row_compact_scatter_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
+int row_compact_expand_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
+
 int dyn_scan_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_rewrite_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_post_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);

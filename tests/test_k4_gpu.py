@@ -357,3 +357,91 @@ def test_rolling_packed_tiles_ragged_sequences(eng, dtype, tol, k, window, min_p
     two_c, two_p = _np(two["coef"]), _np(two["pred"])
     assert np.array_equal(np.isnan(two_c), np.isnan(got_c))
     assert np.allclose(two_c[well], got_c[well], rtol=tol, atol=tol) and np.allclose(two_p[well], got_p[well], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,window,min_periods,shape", [
+    (6, 252, 6, "many"), (6, 250, 20, "many"), (3, 21, None, "many"), (6, 253, 6, "long"), (5, 64, 5, "long"), (2, 7, 2, "tiny"),
+    (4, 100, 8, "holes"), (6, 508, 30, "many"),
+])
+def test_rolling_drop_with_nulls_compacted(eng, dtype, tol, k, window, min_periods, shape):
+    """The drop family on frames WITH nulls up to 6 features: the valid rows are compacted, the tile kernel runs on them, the
+    coefficients are forward-filled onto the original rows (ls.rs:947-986).  Many ragged sequences, one long sequence, tiny groups
+    with empty ones between them, long runs of nulls (first rows of a sequence, whole slabs); validity bytes and NaN targets.  Against
+    the oracle and against the lane-per-chunk kernels (ROLLING_ENGINE=nocompact) on the same frame, NaN pattern included."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 31 + window)
+    mp = min_periods if min_periods is not None else min(k, window)
+    if shape == "many":
+        sizes = np.concatenate([rng.integers(2 * mp + 5, 1400, size=60), [2600, 0, 3000]])
+    elif shape == "long":
+        sizes = np.array([60_000, 0, 5_000])
+    elif shape == "tiny":
+        sizes = np.concatenate([rng.integers(2 * mp + 3, 40, size=300), [0, 0, 35]])
+    else:
+        sizes = rng.integers(1500, 4000, size=12)
+    y, cols, offs, _ = _frame(rng, sizes, k, dtype=dtype)
+    N = len(y)
+    valid = (rng.random(N) > 0.06).astype(np.uint8)
+    if shape == "holes":
+        for g in range(len(sizes)):
+            s = int(offs[g])
+            valid[s:s + int(rng.integers(0, 700))] = 0                  # the sequence starts with a run of nulls (whole slabs of them)
+            h = s + int(rng.integers(800, 1200))
+            valid[h:h + 300] = 0
+    for g in range(len(sizes)):                                          # every non-empty sequence keeps min_periods valid rows (else: old path)
+        s, e = int(offs[g]), int(offs[g + 1])
+        if e > s and valid[s:e].sum() < mp:
+            valid[s:e] = 1
+    for mode in ("bytes", "nan"):
+        if mode == "bytes":
+            kw = dict(valid=_cuda(valid))
+            yy = y
+        else:
+            kw = {}
+            yy = y.copy()
+            yy[valid == 0] = np.nan
+        args = dict(window_size=window, min_periods=min_periods, null_policy="drop")
+        out = eng.rolling_least_squares(_cuda(yy), [_cuda(c) for c in cols], offs, **args, **kw)
+        assert eng.last_kernel.endswith("_compacted"), eng.last_kernel
+        ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, null_policy="drop", is_valid=valid)
+        got_c, got_p = _np(out["coef"]), _np(out["pred"])
+        assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
+        vm = valid.astype(bool)
+        assert np.isnan(got_p[~vm]).all()
+        nobs = _window_obs(offs, valid, window, "drop")
+        sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+        well = sane & (nobs >= 2 * k)
+        assert well.sum() > 0.5 * sane.sum()
+        assert np.allclose(got_c[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(got_c[well] - ref["coef"][well]).max())
+        assert np.allclose(got_p[well & vm], ref["pred"][well & vm], rtol=tol, atol=tol)
+        eng.set_option("ROLLING_ENGINE", "nocompact")
+        try:
+            old = eng.rolling_least_squares(_cuda(yy), [_cuda(c) for c in cols], offs, **args, **kw)
+            assert not eng.last_kernel.endswith("_compacted")
+        finally:
+            eng.set_option("ROLLING_ENGINE", None)
+        old_c = _np(old["coef"])
+        assert np.array_equal(np.isnan(old_c), np.isnan(got_c))
+        assert np.allclose(old_c[well], got_c[well], rtol=tol, atol=tol)
+
+
+def test_rolling_drop_with_nulls_short_of_min_periods_keeps_the_old_path(eng):
+    """A non-empty sequence with fewer valid rows than min_periods: the reference solves a window it never filled (ls.rs:881-900) --
+    the compacted path leaves such frames to the kernels that reproduce that."""
+    from oracle import orc
+
+    rng = np.random.default_rng(5)
+    sizes = np.array([400, 30, 500])
+    y, cols, offs, _ = _frame(rng, sizes, 3)
+    valid = np.ones(len(y), dtype=np.uint8)
+    valid[int(offs[1]):int(offs[2])] = 0
+    valid[int(offs[1]) + 3] = 1                                          # one valid row in the middle sequence, min_periods = 8
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), window_size=50, min_periods=8, null_policy="drop")
+    assert not eng.last_kernel.endswith("_compacted")
+    ref = orc.batched_rolling(y, cols, offs, 50, min_periods=8, null_policy="drop", is_valid=valid)
+    healthy = np.ones(len(y), dtype=bool)
+    healthy[int(offs[1]):int(offs[2])] = False                           # (the starved sequence is a singular system: whatever LU makes of it)
+    healthy &= np.isfinite(ref["coef"]).all(axis=1) & (_window_obs(offs, valid, 50, "drop") >= 8)
+    assert np.allclose(_np(out["coef"])[healthy], ref["coef"][healthy], rtol=1e-6, atol=1e-6)
