@@ -21,10 +21,12 @@ __global__ void __launch_bounds__(256) dyn_scan_kernel(const DynPrepArgs a) {
         invalid = ok ? 0 : 1;
         nulls = (ok && (ynull || xnull)) ? 1 : 0;
     }
+    // the host only asks "any?": plain stores of the same value.  (Counting them with one atomicAdd per wave serialised ~150 000 waves
+    // on two addresses: 1.53 ms of a 10M-row frame with 3 % nulls, against the 0.1 ms the pass takes to read the frame.)
     const unsigned long long bi = __ballot(invalid), bn = __ballot(nulls);
     if ((threadIdx.x & 63) == 0) {
-        if (bi) atomicAdd(&a.flags[0], __popcll(bi));
-        if (bn) atomicAdd(&a.flags[1], __popcll(bn));
+        if (bi) a.flags[0] = 1;
+        if (bn) a.flags[1] = 1;
     }
 }
 
