@@ -1666,16 +1666,22 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     // Null-free frames, up to 6 features, min_periods <= window <= 508: the row-parallel tile kernel (K4c, k4c_rolling.hip) -- with
     // every row valid the "drop" deque and the fixed window are the same sums.  POLS_ROLLING_ENGINE=chunk goes back to the
     // lane-per-chunk kernel.
-    bool tiles = k <= K4C_KMAX && st.valid == nullptr && mp <= w && w <= K4C_MAX_WINDOW && ctx->opt.rolling_engine != 1 && aligned16(st.y) &&
+    bool tiles = k <= K4C_KMAX && st.valid == nullptr && mp <= w && ctx->opt.rolling_engine != 1 && aligned16(st.y) &&
                  (!st.coef || aligned16(st.coef)) && (!st.pred || aligned16(st.pred));
     for (int j = 0; j < k && tiles; ++j) tiles = aligned16(st.x[j]);
+    // whole sequences per tile when none is longer than one: no window reaches outside its tile, no halo, any window
+    // (POLS_ROLLING_ENGINE=halo: off); otherwise the halo waves cover windows up to 508 rows (252 at 7 / 8 features)
+    const int64_t *packed_map = nullptr;
+    int64_t n_packed = 0;
+    if (tiles && ctx->opt.rolling_engine != 2 && (rc = ensure_packed_tiles(ctx, b, K4C_PACKED_ROWS, max_rows, &packed_map, &n_packed))) return rc;
+    if (tiles && !packed_map && w > k4c_max_window(k)) tiles = false;
     // The drop family on a frame WITH nulls (the reference's default policy for rolling_ols, ls.rs:947-986): its deque of valid rows is
     // the null-free window over the VALID rows, and a row left out repeats the last coefficients -- so the valid rows are compacted
     // (dyn_prep.hip: slab counts, scan, scatter), the tile kernel runs on them, and an expansion pass forward-fills the coefficients
     // onto the original rows and predicts them.  Not taken when a non-empty group holds fewer valid rows than min_periods (the
     // reference then solves a window it never filled, :881-900 -- the lane-per-chunk kernels below reproduce that).
-    bool tiles_c = !tiles && drop && st.valid != nullptr && k <= K4C_KMAX && mp <= w && w <= K4C_MAX_WINDOW && ctx->opt.rolling_engine != 1 &&
-                   ctx->opt.rolling_engine != 3 && b->n_rows >= 8;
+    bool tiles_c = !tiles && drop && st.valid != nullptr && k <= K4C_KMAX && mp <= w && (w <= k4c_max_window(k) || max_rows <= K4C_PACKED_ROWS - 3) &&
+                   ctx->opt.rolling_engine != 1 && ctx->opt.rolling_engine != 3 && b->n_rows >= 8;
     if (tiles_c) {
         const int64_t N = b->n_rows, G = b->n_groups, n_slabs = (N + 255) / 256;
         const size_t sz = dtype_size(b->dtype), colb = round256(sz * (size_t)N);
@@ -1730,11 +1736,12 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
             for (int j = 0; j < k; ++j) c.x[j] = outp[(size_t)j + 1];
             c.n_rows = Nc; c.coef = dc; c.pred = nullptr;
             c.window = w; c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
-            if (max_c <= K4C_PACKED_ROWS - 3 && ctx->opt.rolling_engine != 2) {
+            if (max_c <= K4C_PACKED_ROWS - 3 && (ctx->opt.rolling_engine != 2 || w > k4c_max_window(k))) {
                 std::vector<int64_t> first;
                 packed_tile_starts(c_offs.data(), G, Nc, K4C_PACKED_ROWS, &first);
                 const int64_t nt = (int64_t)first.size() - 1;
-                if (nt * K4C_PACKED_ROWS * 7 <= Nc * 10) {
+                if (nt * K4C_PACKED_ROWS * 7 <= Nc * 10 || w > k4c_max_window(k)) {    // (a window beyond the halo forms: packed whatever the fill)
+                    c.window = std::min<int64_t>(w, 2 * K4C_PACKED_ROWS);
                     if ((rc = ensure_scratch(ctx, 22, round256(sizeof(int64_t) * first.size()), &dm))) return rc;
                     if ((rc = upload_small(ctx, dm, first.data(), sizeof(int64_t) * first.size()))) return rc;
                     c.tile_row0 = static_cast<const int64_t *>(dm); c.n_packed = nt;
@@ -1755,9 +1762,9 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         c.y = st.y;
         for (int j = 0; j < k; ++j) c.x[j] = st.x[j];
         c.n_rows = b->n_rows; c.coef = st.coef; c.pred = st.pred;
-        c.window = w; c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
-        // whole sequences per tile when none is longer than one: no window reaches outside its tile, no halo (POLS_ROLLING_ENGINE=halo: off)
-        if (ctx->opt.rolling_engine != 2 && (rc = ensure_packed_tiles(ctx, b, K4C_PACKED_ROWS, max_rows, &c.tile_row0, &c.n_packed))) return rc;
+        c.window = packed_map ? std::min<int64_t>(w, 2 * K4C_PACKED_ROWS) : w;   // (a window longer than a tile never fills: any such is the same)
+        c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
+        c.tile_row0 = packed_map; c.n_packed = n_packed;
         if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
         if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
         return unstage_outputs(ctx, b, b->n_rows, k, o, st);

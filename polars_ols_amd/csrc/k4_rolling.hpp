@@ -104,7 +104,7 @@ int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a);
 int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int64_t n_rows, uint8_t *start);
 
 // ---- K4c: row-parallel rolling OLS on null-free frames, window <= K4C_MAX_WINDOW (k4c_rolling.hip) ------------------------------
-constexpr int K4C_KMAX = 6;                // beyond 6 features the walk no longer fits 256 registers next to its leaving rows
+constexpr int K4C_KMAX = 8;                // 7 / 8 features: more than 256 registers (256 + 24 / 88 AGPRs), one four-wave workgroup per CU instead of two
 constexpr int64_t K4C_MAX_WINDOW = 508;   // two halo waves: 512 >= 4 ceil(window / 4) + 1
 struct K4cArgs {
     const void *y;
@@ -119,6 +119,8 @@ struct K4cArgs {
     const int64_t *tile_row0;          // PACKED tiles (or nullptr), K3cArgs::tile_row0's table for 1 024-row tiles: whole sequences per tile, so no
     int64_t n_packed;                  // window reaches outside it and the halo waves go (n_packed tiles)
 };
+// widest window of the halo forms (packed tiles take any window: nothing reaches outside a tile)
+constexpr int64_t k4c_max_window(int k) { return k <= 6 ? K4C_MAX_WINDOW : 252; }
 constexpr int64_t K4C_PACKED_ROWS = 1024;    // rows of a packed tile (four body waves)
 int k4c_launch(pols_ctx *ctx, int dtype, const K4cArgs &a);
 

@@ -55,7 +55,7 @@ __device__ __forceinline__ void k4c_seg_scan_add(double (&Tv)[NC], const int h, 
 }
 
 template <typename T, int K, int HW, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 2) k4c_kernel(const K4cArgs a) {
+__global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K4cArgs a) {
     constexpr int BW = WAVES - HW, R = 4, RUNS = WAVES * 64;
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NC = NT + 1;   // slot NT: rows since the last sequence start (or the halo's first row)
     using V = typename Vec16<T>::type;
@@ -322,7 +322,10 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
 template <typename T, int K>
 static int k4c_launch_k(pols_ctx *ctx, const K4cArgs &a) {
     if (a.tile_row0) return k4c_launch_h<T, K, 0>(ctx, a);                                      // packed tiles: no halo
-    return a.window <= 252 ? k4c_launch_h<T, K, 1>(ctx, a) : k4c_launch_h<T, K, 2>(ctx, a);   // 256 HW >= 4 ceil(window / 4) + 1
+    if (a.window <= 252) return k4c_launch_h<T, K, 1>(ctx, a);                                  // 256 HW >= 4 ceil(window / 4) + 1
+    if constexpr (K <= 6) return k4c_launch_h<T, K, 2>(ctx, a);
+    // (7 / 8 features need more than 256 registers: one four-wave workgroup per CU; the eight-wave two-halo form would spill)
+    return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): window %lld with %d features needs packed tiles", (long long)a.window, K);
 }
 
 template <typename T>
@@ -334,12 +337,14 @@ static int k4c_launch_t(pols_ctx *ctx, const K4cArgs &a) {
         case 4: return k4c_launch_k<T, 4>(ctx, a);
         case 5: return k4c_launch_k<T, 5>(ctx, a);
         case 6: return k4c_launch_k<T, 6>(ctx, a);
+        case 7: return k4c_launch_k<T, 7>(ctx, a);
+        case 8: return k4c_launch_k<T, 8>(ctx, a);
         default: return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): %d features > %d", a.k, K4C_KMAX);
     }
 }
 
 int k4c_launch(pols_ctx *ctx, int dtype, const K4cArgs &a) {
-    if (a.window < 1 || a.window > K4C_MAX_WINDOW || a.min_periods < 1 || a.min_periods > a.window)
+    if (a.window < 1 || (a.window > k4c_max_window(a.k) && !a.tile_row0) || a.min_periods < 1 || a.min_periods > a.window)
         return fail(POLS_ERR_INVALID, "k4c: window %lld / min_periods %lld outside the row-parallel kernel's range", (long long)a.window, (long long)a.min_periods);
     ctx->last_kernel = dtype == POLS_F32 ? "k4_rolling_tiles_f32" : "k4_rolling_tiles_f64";
     return dtype == POLS_F32 ? k4c_launch_t<float>(ctx, a) : k4c_launch_t<double>(ctx, a);

@@ -269,7 +269,7 @@ def test_rolling_min_periods_beyond_the_window(eng, policy, k, window, min_perio
 @pytest.mark.parametrize("k,window,min_periods,alpha", [
     (1, 1, 1, None), (2, 2, None, None), (3, 3, 3, 0.1), (6, 7, 6, None), (4, 63, 4, None), (6, 64, 10, None), (5, 250, None, None),
     (6, 251, 6, None), (6, 252, 6, None), (6, 253, 6, None), (3, 255, 3, 1.0), (6, 256, 6, None), (8, 300, 8, None), (7, 507, 20, None),
-    (2, 508, 2, None),
+    (2, 508, 2, None), (7, 64, 7, None), (8, 252, 8, None), (7, 21, None, 0.5), (8, 9, 8, None),
 ])
 def test_rolling_tiles_null_free(eng, dtype, tol, k, window, min_periods, alpha):
     """K4c (k4c_rolling.hip): null-free frames, every window offset modulo the 4-row runs, the one- / two-halo-wave boundary (252 / 253),
@@ -282,7 +282,8 @@ def test_rolling_tiles_null_free(eng, dtype, tol, k, window, min_periods, alpha)
     for policy in ("drop", "drop_window"):
         out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, window_size=window, min_periods=min_periods, alpha=alpha,
                                         null_policy=policy, null_free=True)
-        assert eng.last_kernel.startswith("k4_rolling_tiles" if k <= 6 else "k4_rolling_walk")
+        # (7 / 8 features: more than 256 registers, one halo wave only -- windows up to 252 unless the tiles pack)
+        assert eng.last_kernel.startswith("k4_rolling_tiles" if (k <= 6 or window <= 252) else "k4_rolling_walk")
         ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy)
         got_c, got_p = _np(out["coef"]), _np(out["pred"])
         assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
@@ -325,6 +326,7 @@ def test_rolling_many_sequences_full_size(eng):
 @pytest.mark.parametrize("k,window,min_periods,alpha", [
     (1, 1, 1, None), (3, 3, 3, 0.1), (6, 7, 6, None), (4, 63, 4, None), (6, 250, 10, None), (6, 251, 6, None), (6, 252, 6, None),
     (6, 253, 6, None), (5, 254, None, None), (3, 255, 3, 1.0), (6, 256, 6, None), (6, 507, 20, None), (2, 508, 2, None),
+    (7, 100, 7, None), (8, 252, 8, None), (8, 600, 10, None), (6, 700, 6, None), (3, 5000, 3, None),
 ])
 def test_rolling_packed_tiles_ragged_sequences(eng, dtype, tol, k, window, min_periods, alpha):
     """K4c's halo-free form: no sequence longer than a tile, so tiles hold whole sequences (cut at sequence starts, any row) and no
@@ -349,7 +351,7 @@ def test_rolling_packed_tiles_ragged_sequences(eng, dtype, tol, k, window, min_p
     assert well.sum() > 0.5 * sane.sum() or window < 2 * k
     assert np.allclose(got_c[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(got_c[well] - ref["coef"][well]).max())
     assert np.allclose(got_p[well], ref["pred"][well], rtol=tol, atol=tol)
-    eng.set_option("ROLLING_ENGINE", "halo")
+    eng.set_option("ROLLING_ENGINE", "halo" if window <= (508 if k <= 6 else 252) else "chunk")   # (no halo form for that window: the chunk kernels)
     try:
         two = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
     finally:
@@ -362,7 +364,7 @@ def test_rolling_packed_tiles_ragged_sequences(eng, dtype, tol, k, window, min_p
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("k,window,min_periods,shape", [
     (6, 252, 6, "many"), (6, 250, 20, "many"), (3, 21, None, "many"), (6, 253, 6, "long"), (5, 64, 5, "long"), (2, 7, 2, "tiny"),
-    (4, 100, 8, "holes"), (6, 508, 30, "many"),
+    (4, 100, 8, "holes"), (6, 508, 30, "many"), (7, 60, 7, "many"), (8, 252, 8, "long"), (8, 900, 10, "tiny"),
 ])
 def test_rolling_drop_with_nulls_compacted(eng, dtype, tol, k, window, min_periods, shape):
     """The drop family on frames WITH nulls up to 6 features: the valid rows are compacted, the tile kernel runs on them, the
