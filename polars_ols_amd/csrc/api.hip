@@ -178,6 +178,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_F64_TEAM")) o.k1_f64_team256 = on && std::atoi(v) == 256;
     else if (ieq(key, "KG_NOYV")) o.kg_noyv = on;
     else if (ieq(key, "K2_NOPREFETCH")) o.k2_noprefetch = on;
+    else if (ieq(key, "NO_SPLIT")) o.no_split = on;
     else if (ieq(key, "K1_PASSES")) o.k1_passes = on ? std::atoi(v) : d.k1_passes;
     else if (ieq(key, "K1T_RC4")) o.k1t_rc4 = on ? (std::atoi(v) != 0) : d.k1t_rc4;
     else if (ieq(key, "K1T_SUB8")) o.k1t_sub8 = on ? std::atoi(v) : d.k1t_sub8;
@@ -1020,15 +1021,82 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const size_t nv_bytes = nulls ? round256(sizeof(double) * (size_t)b->n_groups) : 0;
         if ((rc = ensure_scratch(ctx, 5, gram_bytes + c64_bytes + nv_bytes, &scr))) return rc;
         double *nvalid = nulls ? reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes + c64_bytes) : nullptr;
+        // Few long groups (ONE regression over a whole frame is the reference's first README example): a group is one workgroup in
+        // the Gram and the prediction pass, so a 10M-row group used to be one CU's work -- 94 ms.  Long groups are cut into segments
+        // (segment offsets, one workgroup each; the segments' Gram matrices are summed per group in segment order), sized so that the
+        // launch fills the chip about eight deep.
+        const int64_t seg_target = std::max<int64_t>(4096, ((b->n_rows / std::max<int64_t>(1, 8 * (int64_t)ctx->num_cus) + 1023) / 1024) * 1024);
+        const bool split = max_rows > 2 * seg_target && !ctx->opt.no_split;    // (only the long groups are cut; the others are one segment each)
+        const int64_t *seg_offs = d_offs;
+        const int32_t *seg_map = nullptr;
+        int64_t n_seg = b->n_groups;
+        double *gram_part = nullptr, *nv_part = nullptr;
+        const int32_t *seg_first = nullptr;
+        auto &sc = ctx->seg_cache;
+        const bool seg_hit = split && sc.ptr && sc.ptr == ctx->scratch[23].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups &&
+                             sc.n_rows == b->n_rows && sc.seg_target == seg_target && sc.nz2 == nz * nz && sc.nulls == nulls;
+        if (seg_hit) {                                        // same frame as the last call: the tables are still in scratch slot 23
+            n_seg = sc.n_seg;
+            const size_t b_so = round256(sizeof(int64_t) * (size_t)(n_seg + 1)), b_sm = round256(sizeof(int32_t) * (size_t)n_seg),
+                         b_sf = round256(sizeof(int32_t) * (size_t)(b->n_groups + 1)), b_gp = round256(sizeof(double) * nz * nz * (size_t)n_seg);
+            char *sb = static_cast<char *>(ctx->scratch[23].ptr);
+            seg_offs = reinterpret_cast<const int64_t *>(sb);
+            seg_map = reinterpret_cast<const int32_t *>(sb + b_so);
+            seg_first = reinterpret_cast<const int32_t *>(sb + b_so + b_sm);
+            gram_part = reinterpret_cast<double *>(sb + b_so + b_sm + b_sf);
+            nv_part = nulls ? reinterpret_cast<double *>(sb + b_so + b_sm + b_sf + b_gp) : nullptr;
+        } else if (split) {
+            sc.ptr = nullptr;
+            std::vector<int64_t> so;
+            std::vector<int32_t> sm, sf((size_t)b->n_groups + 1);
+            so.push_back(0);
+            for (int64_t g = 0; g < b->n_groups; ++g) {
+                sf[(size_t)g] = (int32_t)sm.size();
+                const int64_t s0 = b->group_offsets[g], e0 = b->group_offsets[g + 1];
+                const int64_t pieces = std::max<int64_t>(1, (e0 - s0 + seg_target - 1) / seg_target);
+                const int64_t len = ((e0 - s0 + pieces - 1) / pieces + 255) / 256 * 256;   // (256-row multiples: whole staging chunks)
+                for (int64_t t = s0; t < e0 || t == s0; t += std::max<int64_t>(len, 1)) {
+                    so.push_back(std::min(e0, t + std::max<int64_t>(len, 1)));
+                    sm.push_back((int32_t)g);
+                    if (e0 == s0) break;
+                }
+            }
+            sf[(size_t)b->n_groups] = (int32_t)sm.size();
+            n_seg = (int64_t)sm.size();
+            const size_t b_so = round256(sizeof(int64_t) * so.size()), b_sm = round256(sizeof(int32_t) * sm.size()), b_sf = round256(sizeof(int32_t) * sf.size());
+            const size_t b_gp = round256(sizeof(double) * nz * nz * (size_t)n_seg), b_nv = nulls ? round256(sizeof(double) * (size_t)n_seg) : 0;
+            void *ds = nullptr;
+            if ((rc = ensure_scratch(ctx, 23, b_so + b_sm + b_sf + b_gp + b_nv, &ds))) return rc;
+            char *sb = static_cast<char *>(ds);
+            if ((rc = upload_small(ctx, sb, so.data(), sizeof(int64_t) * so.size()))) return rc;
+            if ((rc = upload_small(ctx, sb + b_so, sm.data(), sizeof(int32_t) * sm.size()))) return rc;
+            if ((rc = upload_small(ctx, sb + b_so + b_sm, sf.data(), sizeof(int32_t) * sf.size()))) return rc;
+            seg_offs = reinterpret_cast<const int64_t *>(sb);
+            seg_map = reinterpret_cast<const int32_t *>(sb + b_so);
+            seg_first = reinterpret_cast<const int32_t *>(sb + b_so + b_sm);
+            gram_part = reinterpret_cast<double *>(sb + b_so + b_sm + b_sf);
+            nv_part = nulls ? reinterpret_cast<double *>(sb + b_so + b_sm + b_sf + b_gp) : nullptr;
+            sc.ptr = ds; sc.offs_id = ctx->offs_id; sc.n_groups = b->n_groups; sc.n_rows = b->n_rows; sc.seg_target = seg_target;
+            sc.n_seg = n_seg; sc.nz2 = nz * nz; sc.nulls = nulls;
+        }
         GramArgs ga;
         std::memset(&ga, 0, sizeof(ga));
         ga.y = st.y; ga.w = st.w;
         for (int j = 0; j < b->n_features; ++j) ga.x[j] = st.x[j];
-        ga.offs = d_offs; ga.n_groups = b->n_groups; ga.n_rows = b->n_rows;
-        ga.gram = static_cast<double *>(scr);
+        ga.offs = seg_offs; ga.n_groups = n_seg; ga.n_rows = b->n_rows;
+        ga.gram = split ? gram_part : static_cast<double *>(scr);
         ga.k_user = b->n_features; ga.kt = kt;
-        ga.valid = st.valid; ga.null_policy = pol; ga.nvalid = nvalid;
+        ga.valid = st.valid; ga.null_policy = pol; ga.nvalid = split ? nv_part : nvalid;
         if ((rc = gram_stream_launch(ctx, b->dtype, ga))) return rc;
+        if (split) {
+            GramReduceArgs ra;
+            std::memset(&ra, 0, sizeof(ra));
+            ra.part = gram_part; ra.nv_part = nv_part; ra.first = seg_first;
+            ra.gram = static_cast<double *>(scr); ra.nvalid = nvalid; ra.n_groups = b->n_groups; ra.nz2 = (int32_t)(nz * nz);
+            if ((rc = gram_reduce_launch(ctx, ra))) return rc;
+            ga.gram = static_cast<double *>(scr);
+            ctx->last_kernel += "_split";
+        }
         CdArgs ca;
         std::memset(&ca, 0, sizeof(ca));
         ca.gram = ga.gram; ca.offs = d_offs; ca.n_groups = b->n_groups;
@@ -1052,7 +1120,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             std::memset(&pa, 0, sizeof(pa));
             pa.y = st.y; pa.w = st.w;
             for (int j = 0; j < b->n_features; ++j) pa.x[j] = st.x[j];
-            pa.offs = d_offs; pa.n_groups = b->n_groups; pa.n_rows = b->n_rows;
+            pa.offs = seg_offs; pa.n_groups = n_seg; pa.n_rows = b->n_rows; pa.gmap = seg_map;
             pa.coef64 = ca.coef64; pa.pred = st.pred; pa.resid = st.resid;
             pa.k_user = b->n_features; pa.kt = kt;
             pa.valid = st.valid; pa.null_policy = pol;

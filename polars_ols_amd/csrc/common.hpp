@@ -59,6 +59,7 @@ struct Options {
     int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
     int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1
+    bool no_split = false;        // POLS_NO_SPLIT       streamed static path: long groups stay one workgroup each (A/B of the segment split)
     bool k2_noprefetch = false;   // POLS_K2_NOPREFETCH  eight-wave K2: one workgroup per group, no next-group prefetch into LDS
     bool k1_noedge = false;       // POLS_K1_NOEDGE      ragged resident frames: the general chunk-by-chunk code instead of the branch-free EDGE kernels
     int k1t_sub32 = -1;           // POLS_K1T_SUB32      -1: default (on), 0: never two groups per wave in the one-shot kernel
@@ -82,7 +83,7 @@ struct pols_ctx {
     // [7] status words, [8] K3c tile / block records, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
-    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..23] free
+    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..22] row compaction of the rolling entry (columns, coefficients, start bytes, tile map), [23] segment tables + partial Gram matrices of the streamed static path
     pols::Scratch scratch[24];
     pols::Options opt;
     bool timing = false;
@@ -119,6 +120,8 @@ struct pols_ctx {
     // K3c (k3c_scan.hip), scratch slot 18: first row of every PACKED tile (tiles cut at sequence starts, single-pass mode); n_tiles 0 =
     // this frame does not pack (a sequence longer than a tile, or tiles too empty)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, tile_rows = 0, n_tiles = 0; } k3c;
+    // segment tables of the streamed static path (scratch slot 23: long groups cut into segments): rebuilt when other offsets arrive
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0; size_t nz2 = 0; bool nulls = false; } seg_cache;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };

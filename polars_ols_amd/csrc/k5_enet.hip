@@ -269,6 +269,38 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     return POLS_OK;
 }
 
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const GramReduceArgs a) {
+    // one workgroup per group; 64 matrix entries at a time (a lane each: coalesced), the four waves take a quarter of the segments each
+    // and their sums meet in LDS in wave order -- the order of the additions does not depend on anything but the segment list
+    __shared__ double part[4][64];
+    const int64_t g = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v0 = a.first[g], v1 = a.first[g + 1];
+    const int per = (v1 - v0 + 3) / 4, va = v0 + wave * per < v1 ? v0 + wave * per : v1, vb = va + per < v1 ? va + per : v1;
+    for (int e0 = 0; e0 < a.nz2; e0 += 64) {
+        const int e = e0 + lane;
+        double acc = 0.0;
+        if (e < a.nz2)
+            for (int v = va; v < vb; ++v) acc += a.part[(size_t)v * a.nz2 + e];
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && e < a.nz2) a.gram[(size_t)g * a.nz2 + e] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        __syncthreads();
+    }
+    if (a.nvalid && threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int v = v0; v < v1; ++v) acc += a.nv_part[v];
+        a.nvalid[g] = acc;
+    }
+}
+
+int gram_reduce_launch(pols_ctx *ctx, const GramReduceArgs &a) {
+    if (a.n_groups == 0) return POLS_OK;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
     if (a.kt + 1 > 32) return fail(POLS_ERR_UNSUPPORTED, "gram_stream: %d features (incl. intercept) > 31", a.kt);
     const bool two = a.kt + 1 > 16, w = a.w != nullptr || a.null_policy != POLS_NULL_IGNORE;   // null policies ride on the sqrt(w) prep pass
@@ -496,7 +528,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
     const int64_t base = s - (s % VEC);
     const int ku = a.k_user, kt = a.kt;
     const bool icpt = ku != kt;
-    const double *cg = a.coef64 ? a.coef64 + (size_t)g * kt : nullptr;
+    const double *cg = a.coef64 ? a.coef64 + (size_t)(a.gmap ? a.gmap[g] : g) * kt : nullptr;
     const T *crow = static_cast<const T *>(a.coef_rows);
     T *pred = static_cast<T *>(a.pred);
     T *resid = static_cast<T *>(a.resid);

@@ -67,7 +67,21 @@ struct PredictArgs {
     // ex.rs:408); "drop" masks the rows that were not part of the fit with NaN (ex.rs:409-417).  `y` must then be set.
     const uint8_t *valid;
     int32_t null_policy;
+    const int32_t *gmap;    // SPLIT groups (or nullptr): `offs` cuts long groups into segments, segment g uses the coefficients of group gmap[g]
 };
+
+// Long groups cut into segments (one workgroup each in gram_stream / predict): partial Gram matrices (and fit-row counts) of the
+// segments [first[g], first[g + 1]) summed into group g's, in segment order.
+struct GramReduceArgs {
+    const double *part;     // n_segments x NZ x NZ
+    const double *nv_part;  // n_segments or nullptr
+    const int32_t *first;   // n_groups + 1
+    double *gram;           // n_groups x NZ x NZ
+    double *nvalid;         // n_groups or nullptr
+    int64_t n_groups;
+    int32_t nz2;
+};
+int gram_reduce_launch(pols_ctx *ctx, const GramReduceArgs &a);
 
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a);
 int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a);

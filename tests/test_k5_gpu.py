@@ -233,3 +233,45 @@ def test_static_huge_groups_streamed(eng):
     assert eng.last_kernel.startswith("k5_gram_stream")
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6)
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("sizes,k,kind", [
+    ([500_003], 8, "ols"), ([200_000, 0, 5, 100_001, 17_000, 3], 4, "ridge_w_icpt"), ([300_000, 150_000], 12, "enet"),
+    ([120_001, 90_000, 64], 6, "drop_nulls"), ([1_000_000], 20, "ols"),
+])
+def test_static_few_long_groups_are_split_into_segments(eng, dtype, tol, sizes, k, kind):
+    """ONE regression over a whole frame (the reference's first README example) or a few long groups: the streamed path cuts them
+    into segments (one workgroup each in the Gram and the prediction pass; the segments' Gram matrices are summed per group in
+    segment order).  Against the oracle and against the unsplit launch (NO_SPLIT) on the same frame."""
+    from oracle import orc
+
+    rng = np.random.default_rng(len(sizes) * 1000 + k)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, dtype, sparsity=0.0, weights=(kind == "ridge_w_icpt"))
+    kw, okw = {}, {}
+    if kind == "ridge_w_icpt":
+        kw = dict(weights=_cuda(w), alpha=0.5, l1_ratio=0.0, add_intercept=True)
+        okw = dict(weights=w, alpha=0.5, l1_ratio=0.0, add_intercept=True)
+    elif kind == "enet":
+        kw = okw = dict(alpha=0.01, l1_ratio=0.5, tol=1e-10, max_iter=20_000)
+    elif kind == "drop_nulls":
+        y = y.copy()
+        y[rng.random(len(y)) < 0.02] = np.nan
+        cols[1] = cols[1].copy()
+        cols[1][rng.random(len(y)) < 0.01] = np.nan
+        kw = dict(null_policy="drop")
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred"), **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream") and eng.last_kernel.endswith("_split"), eng.last_kernel
+    eng.set_option("NO_SPLIT", "1")
+    try:
+        one = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred"), **kw)
+        assert not eng.last_kernel.endswith("_split")
+    finally:
+        eng.set_option("NO_SPLIT", None)
+    assert np.allclose(_np(out["coef"]), _np(one["coef"]), rtol=tol, atol=tol, equal_nan=True)
+    assert np.allclose(_np(out["pred"]), _np(one["pred"]), rtol=tol, atol=tol, equal_nan=True)
+    if kind != "drop_nulls":
+        ref = orc.batched_least_squares(y, cols, offs, **okw)
+        assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+        assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
