@@ -427,13 +427,16 @@ static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compact
     const int k = b->n_features, ncols = m + k + (st.w ? 1 : 0);
     const size_t G = (size_t)b->n_groups, N = (size_t)b->n_rows;
     const size_t sz = dtype_size(b->dtype), colb = round256(sz * std::max<size_t>(N, 1));
-    const size_t cntb = round256(sizeof(unsigned long long) * G), vb = round256(std::max<size_t>(N, 1));
-    const size_t tabb = round256(sizeof(void *) * (size_t)ncols), offb = round256(sizeof(int64_t) * (G + 1));
+    const size_t n_slabs = (N + 255) / 256;
+    const size_t vb = round256(std::max<size_t>(N, 1)), tabb = round256(sizeof(void *) * (size_t)ncols), offb = round256(sizeof(int64_t) * (G + 1));
+    const size_t cntb = round256(sizeof(uint32_t) * std::max<size_t>(n_slabs, 1)), baseb = round256(sizeof(int64_t) * (n_slabs + 1)),
+                 gfb = round256(sizeof(int64_t) * std::max<size_t>(n_slabs, 1));
     void *d = nullptr;
     const bool stage_targets = n_targets > 0 && b->mem == POLS_MEM_HOST;      // host targets: uploaded behind the compacted columns
-    if ((rc = ensure_scratch(ctx, 14, cntb + vb + 2 * tabb + offb + colb * (size_t)(ncols + (stage_targets ? m : 0)), &d))) return rc;
+    if ((rc = ensure_scratch(ctx, 14, cntb + baseb + gfb + vb + 2 * tabb + offb + colb * (size_t)(ncols + (stage_targets ? m : 0)), &d))) return rc;
     char *base = static_cast<char *>(d);
-    char *cols = base + cntb + vb + 2 * tabb + offb;
+    char *q_valid = base + cntb + baseb + gfb, *q_tab = q_valid + vb, *q_offs = q_tab + 2 * tabb;
+    char *cols = q_offs + offb;
     std::vector<const void *> inp((size_t)ncols);
     std::vector<void *> outp((size_t)ncols);
     for (int t = 0; t < m; ++t) {
@@ -448,31 +451,36 @@ static int compact_nulls(pols_ctx *ctx, const pols_batch *b, int policy, Compact
     for (int j = 0; j < k; ++j) inp[(size_t)(m + j)] = st.x[(size_t)j];
     if (st.w) inp[(size_t)(m + k)] = st.w;
     for (int j = 0; j < ncols; ++j) outp[(size_t)j] = cols + colb * (size_t)j;
-    if ((rc = upload_small(ctx, base + cntb + vb, inp.data(), sizeof(void *) * (size_t)ncols))) return rc;
-    if ((rc = upload_small(ctx, base + cntb + vb + tabb, outp.data(), sizeof(void *) * (size_t)ncols))) return rc;
-    CompactArgs ca;
-    std::memset(&ca, 0, sizeof(ca));
-    ca.in = reinterpret_cast<const void *const *>(base + cntb + vb);
-    ca.out = reinterpret_cast<void *const *>(base + cntb + vb + tabb);
-    ca.n_cols = ncols;
-    ca.w_col = st.w ? m + k : -1;
-    ca.drop = (policy == POLS_NULL_DROP || policy == POLS_NULL_DROP_ZERO || policy == POLS_NULL_DROP_WINDOW || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;
-    ca.n_mask = policy == POLS_NULL_DROP_Y_ZERO_X ? m : m + k;                                 // ex.rs:209-220
-    ca.zero_fill = (policy == POLS_NULL_ZERO || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;   // ex.rs:264-283
-    ca.valid_in = st.valid;
-    ca.offs = d_offs;
-    ca.offs_out = reinterpret_cast<const int64_t *>(base + cntb + vb + 2 * tabb);
-    ca.counts = reinterpret_cast<unsigned long long *>(base);
-    ca.vbytes = reinterpret_cast<uint8_t *>(base + cntb);
-    ca.n_groups = b->n_groups;
-    if ((rc = compact_count_launch(ctx, b->dtype, ca))) return rc;
-    std::vector<unsigned long long> counts(G);
-    POLS_HIP(hipMemcpyAsync(counts.data(), ca.counts, sizeof(unsigned long long) * G, hipMemcpyDeviceToHost, ctx->stream));
-    POLS_HIP(hipStreamSynchronize(ctx->stream));       // the compacted offsets are a HOST array of the batch: the host needs the counts
+    if ((rc = upload_small(ctx, q_tab, inp.data(), sizeof(void *) * (size_t)ncols))) return rc;
+    if ((rc = upload_small(ctx, q_tab + tabb, outp.data(), sizeof(void *) * (size_t)ncols))) return rc;
+    // slab-parallel (dyn_prep.hip, 256 rows per workgroup whatever the group sizes -- one long group used to be ONE workgroup's
+    // count and scatter): validity bytes, valid rows per slab + scan, the compacted offset of every group, a stable scatter
+    RowCompactArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.in = reinterpret_cast<const void *const *>(q_tab);
+    ra.out = reinterpret_cast<void *const *>(q_tab + tabb);
+    ra.n_cols = ncols;
+    ra.w_col = st.w ? m + k : -1;
+    ra.drop = (policy == POLS_NULL_DROP || policy == POLS_NULL_DROP_ZERO || policy == POLS_NULL_DROP_WINDOW || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;
+    ra.n_mask = policy == POLS_NULL_DROP_Y_ZERO_X ? m : m + k;                                 // ex.rs:209-220
+    ra.zero_fill = (policy == POLS_NULL_ZERO || policy == POLS_NULL_DROP_Y_ZERO_X) ? 1 : 0;   // ex.rs:264-283
+    ra.valid_in = st.valid;
+    ra.valid_out = reinterpret_cast<uint8_t *>(q_valid);
+    ra.valid = ra.valid_out;
+    ra.offs = d_offs; ra.n_rows = (int64_t)N; ra.n_groups = b->n_groups; ra.n_slabs = (int64_t)n_slabs;
+    ra.slab_cnt = reinterpret_cast<uint32_t *>(base);
+    ra.slab_base = reinterpret_cast<int64_t *>(base + cntb);
+    ra.slab_gfirst = reinterpret_cast<int64_t *>(base + cntb + baseb);
+    ra.c_offs = reinterpret_cast<int64_t *>(q_offs);
     c->offs.assign(G + 1, 0);
-    for (size_t g = 0; g < G; ++g) c->offs[g + 1] = c->offs[g] + (int64_t)counts[g];
-    if ((rc = upload_small(ctx, base + cntb + vb + 2 * tabb, c->offs.data(), sizeof(int64_t) * (G + 1)))) return rc;
-    if ((rc = compact_scatter_launch(ctx, b->dtype, ca))) return rc;
+    if (N > 0) {
+        if ((rc = row_compact_mask_launch(ctx, b->dtype, ra))) return rc;
+        if ((rc = row_compact_offsets_launch(ctx, ra))) return rc;
+        POLS_HIP(hipMemcpyAsync(c->offs.data(), ra.c_offs, sizeof(int64_t) * (G + 1), hipMemcpyDeviceToHost, ctx->stream));
+        POLS_HIP(hipStreamSynchronize(ctx->stream));       // the compacted offsets are a HOST array of the batch
+        if ((rc = row_compact_scatter_launch(ctx, b->dtype, ra))) return rc;
+    }
+    struct { uint8_t *vbytes; } ca{ra.valid_out};
     c->xcols.assign(outp.begin() + m, outp.begin() + m + k);
     c->ycols.assign(outp.begin(), outp.begin() + m);
     c->d_offs = d_offs;
@@ -1219,6 +1227,7 @@ int pols_multi_target_least_squares(pols_ctx *ctx, const pols_batch *b, const vo
             ma.w = c.st.w; ma.coef = dcoef; ma.vbytes = c.vbytes; ma.offs = d_offs; ma.n_groups = b->n_groups;
             ma.k_user = b->n_features; ma.kt = kt; ma.m = n_targets;
             ma.mask_drop = p->null_policy == POLS_NULL_DROP ? 1 : 0;                   // ex.rs:575-583
+            ma.row_blocks = (int32_t)std::min<int64_t>(1024, std::max<int64_t>(1, (int64_t)(N / std::max<size_t>(G, 1)) / 4096));
             if ((rc = mt_predict_launch(ctx, b->dtype, ma))) return rc;
             if (host)
                 for (int t = 0; t < n_targets; ++t)

@@ -2,6 +2,8 @@
 // consecutive rows of every column: coalesced), nothing to tile.
 #include "dyn_prep.hpp"
 
+#include <algorithm>
+
 namespace pols {
 
 template <typename T>
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(256) mt_predict_kernel(const MtPredictArgs a) 
     const int64_t s = a.offs[g], e = a.offs[g + 1];
     const T *cg = static_cast<const T *>(a.coef) + (size_t)g * a.m * a.kt;
     const bool icpt = a.kt != a.k_user;
-    for (int64_t r = s + threadIdx.x; r < e; r += 256) {
+    for (int64_t r = s + (int64_t)blockIdx.y * 256 + threadIdx.x; r < e; r += (int64_t)gridDim.y * 256) {   // (long groups: several workgroups)
         T sw = T(1);
         if (a.w) { T wv = static_cast<const T *>(a.w)[r]; if (wv != wv) wv = (T)1e-24; sw = sqrt(wv); }
         for (int t0 = 0; t0 < a.m; t0 += 4) {                 // four targets per sweep over the features
@@ -151,8 +153,9 @@ __global__ void __launch_bounds__(256) mt_predict_kernel(const MtPredictArgs a) 
 
 int mt_predict_launch(pols_ctx *ctx, int dtype, const MtPredictArgs &a) {
     if (a.n_groups == 0) return POLS_OK;
-    if (dtype == POLS_F32) hipLaunchKernelGGL(mt_predict_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(mt_predict_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    const unsigned ny = (unsigned)std::max(1, std::min(1024, a.row_blocks));
+    if (dtype == POLS_F32) hipLaunchKernelGGL(mt_predict_kernel<float>, dim3((unsigned)a.n_groups, ny), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(mt_predict_kernel<double>, dim3((unsigned)a.n_groups, ny), dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
@@ -222,6 +225,16 @@ __global__ void __launch_bounds__(256) rc_groups_kernel(const RowCompactArgs a) 
 }
 
 template <typename T>
+__global__ void __launch_bounds__(RC_SLAB) rc_mask_kernel(const RowCompactArgs a) {       // one thread per row: coalesced down every column
+    const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
+    if (r >= a.n_rows) return;
+    bool ok = !a.valid_in || a.valid_in[r];
+    if (a.drop)
+        for (int c = 0; c < a.n_mask; ++c) { const T v = static_cast<const T *>(a.in[c])[r]; ok = ok && (v == v); }
+    a.valid_out[r] = ok ? 1 : 0;
+}
+
+template <typename T>
 __global__ void __launch_bounds__(RC_SLAB) rc_scatter_kernel(const RowCompactArgs a) {
     __shared__ unsigned wave_cnt[RC_SLAB / 64];
     const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
@@ -230,7 +243,11 @@ __global__ void __launch_bounds__(RC_SLAB) rc_scatter_kernel(const RowCompactArg
     const unsigned incl = rc_slab_prefix(ok, wave_cnt, &total);
     if (ok) {
         const int64_t pos = a.slab_base[blockIdx.x] + incl - 1;                          // stable: the rows keep their order
-        for (int c = 0; c < a.n_cols; ++c) static_cast<T *>(a.out[c])[pos] = static_cast<const T *>(a.in[c])[r];
+        for (int c = 0; c < a.n_cols; ++c) {
+            T v = static_cast<const T *>(a.in[c])[r];
+            if (v != v) v = (c == a.w_col) ? (T)1e-24 : (a.zero_fill ? T(0) : v);
+            static_cast<T *>(a.out[c])[pos] = v;
+        }
     }
 }
 
@@ -286,6 +303,13 @@ __global__ void __launch_bounds__(RC_SLAB) rc_expand_kernel(const RowCompactArgs
     }
 }
 
+int row_compact_mask_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a) {
+    if (a.n_rows == 0) return POLS_OK;
+    if (dtype == POLS_F32) hipLaunchKernelGGL(rc_mask_kernel<float>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(rc_mask_kernel<double>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
 int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a) {
     if (a.n_rows == 0) return POLS_OK;
     hipLaunchKernelGGL(rc_count_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);

@@ -56,6 +56,7 @@ struct MtPredictArgs {
     const int64_t *offs;         // DEVICE group offsets (original rows)
     int64_t n_groups;
     int32_t k_user, kt, m, mask_drop;
+    int32_t row_blocks;          // workgroups per group (long groups), 1 .. 1024
 };
 int mt_predict_launch(pols_ctx *ctx, int dtype, const MtPredictArgs &a);
 
@@ -80,7 +81,14 @@ struct RowCompactArgs {
     int32_t n_cols, k;
     const void *coef_c;          // expand: compacted n_valid x k coefficients
     void *coef, *pred;           // expand: n_rows x k / n_rows (either may be nullptr)
+    // mask pass (handle_nulls for the static entries that work on filtered rows): valid[r] = valid_in[r] && no NaN in columns [0, n_mask)
+    uint8_t *valid_out;          // written by row_compact_mask_launch (then `valid` points at it)
+    const uint8_t *valid_in;     // caller's validity bytes or nullptr
+    int32_t n_mask, drop;        // drop == 0: only valid_in decides
+    // scatter: what a surviving null becomes -- the weights column -> 1e-24 (least_squares.py:193), others -> 0 when zero_fill
+    int32_t w_col, zero_fill;
 };
+int row_compact_mask_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
 int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a);            // count + scan + groups
 int row_compact_scatter_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
 int row_compact_expand_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
