@@ -784,6 +784,66 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     return unstage_outputs(ctx, b, b->n_groups * m, kt, o, st);
 }
 
+// Long groups cut into segments (the streamed static path, the statistics of long groups): a group is one workgroup in those
+// kernels, so ONE regression over a 10M-row frame used to be one CU's work.  Groups longer than two segments are cut into pieces
+// of about N / (8 x CUs) rows (256-row multiples), the others are one segment each; tables in scratch slot 23 -- segment offsets,
+// segment -> group, group -> first segment -- followed by `extra_per_seg` bytes per segment for the caller's partial results.
+// n_seg = 0: nothing is longer than two segments (or POLS_NO_SPLIT).  Cached per frame.
+struct SegTables {
+    const int64_t *offs = nullptr;
+    const int32_t *map = nullptr, *first = nullptr;
+    int64_t n_seg = 0;
+    char *extra = nullptr;
+};
+static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows, size_t extra_per_seg, SegTables *t) {
+    *t = SegTables();
+    const int64_t seg_target = std::max<int64_t>(4096, ((b->n_rows / std::max<int64_t>(1, 8 * (int64_t)ctx->num_cus) + 1023) / 1024) * 1024);
+    if (!(max_rows > 2 * seg_target) || ctx->opt.no_split) return POLS_OK;
+    auto &sc = ctx->seg_cache;
+    int rc;
+    const bool hit = sc.ptr && sc.ptr == ctx->scratch[23].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups && sc.n_rows == b->n_rows &&
+                     sc.seg_target == seg_target && sc.nz2 == extra_per_seg;
+    auto lay = [&](char *sb, int64_t n_seg) {
+        const size_t b_so = round256(sizeof(int64_t) * (size_t)(n_seg + 1)), b_sm = round256(sizeof(int32_t) * (size_t)n_seg),
+                     b_sf = round256(sizeof(int32_t) * (size_t)(b->n_groups + 1));
+        t->offs = reinterpret_cast<const int64_t *>(sb);
+        t->map = reinterpret_cast<const int32_t *>(sb + b_so);
+        t->first = reinterpret_cast<const int32_t *>(sb + b_so + b_sm);
+        t->extra = sb + b_so + b_sm + b_sf;
+        t->n_seg = n_seg;
+        return b_so + b_sm + b_sf;
+    };
+    if (hit) { lay(static_cast<char *>(ctx->scratch[23].ptr), sc.n_seg); return POLS_OK; }
+    sc.ptr = nullptr;
+    std::vector<int64_t> so;
+    std::vector<int32_t> sm, sf((size_t)b->n_groups + 1);
+    so.push_back(0);
+    for (int64_t g = 0; g < b->n_groups; ++g) {
+        sf[(size_t)g] = (int32_t)sm.size();
+        const int64_t s0 = b->group_offsets[g], e0 = b->group_offsets[g + 1];
+        const int64_t pieces = std::max<int64_t>(1, (e0 - s0 + seg_target - 1) / seg_target);
+        const int64_t len = std::max<int64_t>(1, ((e0 - s0 + pieces - 1) / pieces + 255) / 256 * 256);   // (256-row multiples: whole staging chunks)
+        for (int64_t r = s0; r < e0 || r == s0; r += len) {
+            so.push_back(std::min(e0, r + len));
+            sm.push_back((int32_t)g);
+            if (e0 == s0) break;
+        }
+    }
+    sf[(size_t)b->n_groups] = (int32_t)sm.size();
+    const int64_t n_seg = (int64_t)sm.size();
+    const size_t tabs = round256(sizeof(int64_t) * so.size()) + round256(sizeof(int32_t) * sm.size()) + round256(sizeof(int32_t) * sf.size());
+    void *ds = nullptr;
+    if ((rc = ensure_scratch(ctx, 23, tabs + round256(extra_per_seg * (size_t)n_seg), &ds))) return rc;
+    char *sb = static_cast<char *>(ds);
+    lay(sb, n_seg);
+    if ((rc = upload_small(ctx, const_cast<int64_t *>(t->offs), so.data(), sizeof(int64_t) * so.size()))) return rc;
+    if ((rc = upload_small(ctx, const_cast<int32_t *>(t->map), sm.data(), sizeof(int32_t) * sm.size()))) return rc;
+    if ((rc = upload_small(ctx, const_cast<int32_t *>(t->first), sf.data(), sizeof(int32_t) * sf.size()))) return rc;
+    sc.ptr = ds; sc.offs_id = ctx->offs_id; sc.n_groups = b->n_groups; sc.n_rows = b->n_rows; sc.seg_target = seg_target;
+    sc.n_seg = n_seg; sc.nz2 = extra_per_seg; sc.nulls = false;
+    return POLS_OK;
+}
+
 static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, LsInfo *info) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
@@ -1033,60 +1093,14 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // the Gram and the prediction pass, so a 10M-row group used to be one CU's work -- 94 ms.  Long groups are cut into segments
         // (segment offsets, one workgroup each; the segments' Gram matrices are summed per group in segment order), sized so that the
         // launch fills the chip about eight deep.
-        const int64_t seg_target = std::max<int64_t>(4096, ((b->n_rows / std::max<int64_t>(1, 8 * (int64_t)ctx->num_cus) + 1023) / 1024) * 1024);
-        const bool split = max_rows > 2 * seg_target && !ctx->opt.no_split;    // (only the long groups are cut; the others are one segment each)
-        const int64_t *seg_offs = d_offs;
-        const int32_t *seg_map = nullptr;
-        int64_t n_seg = b->n_groups;
-        double *gram_part = nullptr, *nv_part = nullptr;
-        const int32_t *seg_first = nullptr;
-        auto &sc = ctx->seg_cache;
-        const bool seg_hit = split && sc.ptr && sc.ptr == ctx->scratch[23].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups &&
-                             sc.n_rows == b->n_rows && sc.seg_target == seg_target && sc.nz2 == nz * nz && sc.nulls == nulls;
-        if (seg_hit) {                                        // same frame as the last call: the tables are still in scratch slot 23
-            n_seg = sc.n_seg;
-            const size_t b_so = round256(sizeof(int64_t) * (size_t)(n_seg + 1)), b_sm = round256(sizeof(int32_t) * (size_t)n_seg),
-                         b_sf = round256(sizeof(int32_t) * (size_t)(b->n_groups + 1)), b_gp = round256(sizeof(double) * nz * nz * (size_t)n_seg);
-            char *sb = static_cast<char *>(ctx->scratch[23].ptr);
-            seg_offs = reinterpret_cast<const int64_t *>(sb);
-            seg_map = reinterpret_cast<const int32_t *>(sb + b_so);
-            seg_first = reinterpret_cast<const int32_t *>(sb + b_so + b_sm);
-            gram_part = reinterpret_cast<double *>(sb + b_so + b_sm + b_sf);
-            nv_part = nulls ? reinterpret_cast<double *>(sb + b_so + b_sm + b_sf + b_gp) : nullptr;
-        } else if (split) {
-            sc.ptr = nullptr;
-            std::vector<int64_t> so;
-            std::vector<int32_t> sm, sf((size_t)b->n_groups + 1);
-            so.push_back(0);
-            for (int64_t g = 0; g < b->n_groups; ++g) {
-                sf[(size_t)g] = (int32_t)sm.size();
-                const int64_t s0 = b->group_offsets[g], e0 = b->group_offsets[g + 1];
-                const int64_t pieces = std::max<int64_t>(1, (e0 - s0 + seg_target - 1) / seg_target);
-                const int64_t len = ((e0 - s0 + pieces - 1) / pieces + 255) / 256 * 256;   // (256-row multiples: whole staging chunks)
-                for (int64_t t = s0; t < e0 || t == s0; t += std::max<int64_t>(len, 1)) {
-                    so.push_back(std::min(e0, t + std::max<int64_t>(len, 1)));
-                    sm.push_back((int32_t)g);
-                    if (e0 == s0) break;
-                }
-            }
-            sf[(size_t)b->n_groups] = (int32_t)sm.size();
-            n_seg = (int64_t)sm.size();
-            const size_t b_so = round256(sizeof(int64_t) * so.size()), b_sm = round256(sizeof(int32_t) * sm.size()), b_sf = round256(sizeof(int32_t) * sf.size());
-            const size_t b_gp = round256(sizeof(double) * nz * nz * (size_t)n_seg), b_nv = nulls ? round256(sizeof(double) * (size_t)n_seg) : 0;
-            void *ds = nullptr;
-            if ((rc = ensure_scratch(ctx, 23, b_so + b_sm + b_sf + b_gp + b_nv, &ds))) return rc;
-            char *sb = static_cast<char *>(ds);
-            if ((rc = upload_small(ctx, sb, so.data(), sizeof(int64_t) * so.size()))) return rc;
-            if ((rc = upload_small(ctx, sb + b_so, sm.data(), sizeof(int32_t) * sm.size()))) return rc;
-            if ((rc = upload_small(ctx, sb + b_so + b_sm, sf.data(), sizeof(int32_t) * sf.size()))) return rc;
-            seg_offs = reinterpret_cast<const int64_t *>(sb);
-            seg_map = reinterpret_cast<const int32_t *>(sb + b_so);
-            seg_first = reinterpret_cast<const int32_t *>(sb + b_so + b_sm);
-            gram_part = reinterpret_cast<double *>(sb + b_so + b_sm + b_sf);
-            nv_part = nulls ? reinterpret_cast<double *>(sb + b_so + b_sm + b_sf + b_gp) : nullptr;
-            sc.ptr = ds; sc.offs_id = ctx->offs_id; sc.n_groups = b->n_groups; sc.n_rows = b->n_rows; sc.seg_target = seg_target;
-            sc.n_seg = n_seg; sc.nz2 = nz * nz; sc.nulls = nulls;
-        }
+        SegTables sg;
+        if ((rc = ensure_segments(ctx, b, max_rows, sizeof(double) * (nz * nz + 1), &sg))) return rc;
+        const bool split = sg.n_seg > 0;
+        const int64_t *seg_offs = split ? sg.offs : d_offs;
+        const int32_t *seg_map = sg.map, *seg_first = sg.first;
+        const int64_t n_seg = split ? sg.n_seg : b->n_groups;
+        double *gram_part = reinterpret_cast<double *>(sg.extra);
+        double *nv_part = (split && nulls) ? gram_part + nz * nz * (size_t)n_seg : nullptr;
         GramArgs ga;
         std::memset(&ga, 0, sizeof(ga));
         ga.y = st.y; ga.w = st.w;
@@ -1366,6 +1380,20 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
     sa.offs = info.d_offs; sa.n_groups = b->n_groups; sa.gram = gram;
     sa.coef = info.st.coef; sa.lambda = p->alpha; sa.status = info.st.status;
     sa.k_user = b->n_features; sa.kt = kt;
+    {   // long groups (ONE model summary over a whole frame): the row passes run per segment
+        int64_t mr = 0;
+        for (int64_t g = 0; g < b->n_groups; ++g) mr = std::max(mr, b->group_offsets[g + 1] - b->group_offsets[g]);
+        SegTables sg;
+        const size_t per_seg = sizeof(double) * 5;
+        if ((rc = ensure_segments(ctx, b, mr, per_seg, &sg))) return rc;
+        if (sg.n_seg > 0) {
+            void *pp = nullptr;
+            if ((rc = ensure_scratch(ctx, 19, round256(sizeof(double) * G * (3 * (size_t)kt + 1)), &pp))) return rc;   // (slot 19: the rolling entry's, never live here)
+            sa.seg_offs = sg.offs; sa.seg_map = sg.map; sa.seg_first = sg.first; sa.n_seg = sg.n_seg;
+            sa.seg_part = reinterpret_cast<double *>(sg.extra);
+            sa.prep = static_cast<double *>(pp);
+        }
+    }
     double *dev[6];
     double *const user[6] = {s->r2, s->mae, s->mse, s->std_err, s->t_values, s->p_values};
     for (int i = 0; i < 6; ++i) {

@@ -16,6 +16,14 @@ struct StatsArgs {
     double *r2, *mae, *mse, *se, *tv, *pv;
     int32_t *status;
     int32_t k_user, kt;
+    // LONG groups cut into segments (api.hip: ensure_segments) or nullptr: the row passes run one workgroup per SEGMENT, their sums
+    // meet per group in segment order (k7_stats_launch then runs prepare / segment sums / finish instead of the one kernel)
+    const int64_t *seg_offs;   // n_seg + 1
+    const int32_t *seg_map;    // segment -> group
+    const int32_t *seg_first;  // group -> first segment, n_groups + 1
+    int64_t n_seg;
+    double *seg_part;          // n_seg x 5 partial sums
+    double *prep;              // n_groups x (3 kt + 1): dispatcher coefficients, A^-1 X'y, diag(A^-1), factorisation ok
 };
 
 int k7_stats_launch(pols_ctx *ctx, int dtype, const StatsArgs &a);

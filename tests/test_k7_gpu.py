@@ -285,3 +285,37 @@ def test_statistics_null_policies_behind_the_cabi(engine, dtype, rtol, policy, w
                                           add_intercept=add_intercept, null_policy=policy)
     torch.cuda.synchronize()
     _check({k_: v.cpu().numpy() for k_, v in dev.items()}, exp, rtol, rtol)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("sizes,k,weights,icpt,alpha", [([600_000], 6, False, True, 0.0), ([250_000, 40, 0, 180_001], 4, True, False, 0.5)])
+def test_statistics_of_long_groups_run_per_segment(engine, dtype, sizes, k, weights, icpt, alpha):
+    """ONE model summary over a whole frame: the row passes of the statistics run one workgroup per segment (shifted one-pass sums,
+    added per group in segment order).  Against the unsplit kernel (NO_SPLIT) on the same frame and against the oracle."""
+    import torch
+
+    eng = engine
+
+    def _cuda(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+    rng = np.random.default_rng(len(sizes) + k)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(c.astype(np.float64) for c in cols) + 3.0 + 0.5 * rng.standard_normal(N)).astype(dtype)
+    w = rng.uniform(0.3, 2.0, N).astype(dtype) if weights else None
+    kw = dict(weights=None if w is None else _cuda(w), add_intercept=icpt, alpha=alpha, l1_ratio=0.0 if alpha else None)
+    kw = {a: b for a, b in kw.items() if b is not None}
+    out = eng.least_squares_statistics(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    eng.set_option("NO_SPLIT", "1")
+    try:
+        one = eng.least_squares_statistics(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    finally:
+        eng.set_option("NO_SPLIT", None)
+    tol = 1e-6 if dtype == np.float64 else 2e-4
+    live = np.asarray(sizes) > k + 2
+    for key in ("r2", "mae", "mse", "std_err", "t_values", "p_values"):
+        f = lambda v: v.double().cpu().numpy() if hasattr(v, "cpu") else np.asarray(v, dtype=np.float64)  # noqa: E731
+        a, b2 = f(out[key])[live], f(one[key])[live]
+        assert np.allclose(a, b2, rtol=tol, atol=tol, equal_nan=True), (key, a, b2)
