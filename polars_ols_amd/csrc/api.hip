@@ -1947,6 +1947,11 @@ int pols_predict_policy(pols_ctx *ctx, const pols_batch *b, const void *coef, in
     pa.k_user = b->n_features; pa.kt = kt;
     pa.null_policy = fill_policy;
     ctx->last_kernel = "predict";
+    {   // (a group is one workgroup in this kernel: long groups -- the dynamic models' one long sequence -- go segment by segment)
+        SegTables sg;
+        if ((rc = ensure_segments(ctx, b, max_rows, 0, &sg))) return rc;
+        if (sg.n_seg > 0) { pa.offs = sg.offs; pa.n_groups = sg.n_seg; }
+    }
     if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, kt, &o, st);
 }
