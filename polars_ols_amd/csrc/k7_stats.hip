@@ -207,8 +207,10 @@ __global__ void __launch_bounds__(64) k7_finish_kernel(const StatsArgs a) {
     const int tid = threadIdx.x, kt = a.kt;
     const int64_t n = a.offs[g + 1] - a.offs[g];
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int v = a.seg_first[g]; v < a.seg_first[g + 1]; ++v)       // segment order: the same sums whatever ran first
-        for (int i = 0; i < 5; ++i) acc[i] += a.seg_part[(size_t)v * 5 + i];
+    for (int v = a.seg_first[g] + tid; v < a.seg_first[g + 1]; v += 64)   // lane l: segments l, l + 64, ...; then a fixed tree over the lanes:
+        for (int i = 0; i < 5; ++i) acc[i] += a.seg_part[(size_t)v * 5 + i];   // the same sums whatever ran first
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] = __shfl(wave_sum_row3(acc[i]), 63);
     const double nn = (double)n;
     const double sst = n ? acc[1] - acc[0] * acc[0] / nn : 0.0;    // sum (y - mean)^2 from the shifted sums
     const double *P = a.prep + (size_t)g * (3 * kt + 1);
