@@ -924,7 +924,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     const double pivot_tol = ols_branch ? (b->dtype == POLS_F32 ? 1e-3 : 1e-10) : (b->dtype == POLS_F32 && m != POLS_SOLVE_SVD ? 1e-3 : chol_noise);
     K6Args ka;
     int fix_workers = 0;
-    auto prepare_fix = [&](int max_workers = 64) -> int {       // arguments + work area of the fix-up pass
+    // (the pool of fix-up workgroups: 64 for the frames the benchmarks visit -- an empty dispatch -- growing with the number of groups up to
+    //  2 048: a frame of a million 10-row f32 groups has most of them re-solved in f64 here, 64 workgroups were a quarter of the chip)
+    auto prepare_fix = [&](int max_workers = 0) -> int {        // arguments + work area of the fix-up pass
+        if (max_workers <= 0) max_workers = (int)std::max<int64_t>(64, std::min<int64_t>(2048, b->n_groups / 128));
         const int workers = (int)std::min<int64_t>(b->n_groups, max_workers);
         const int64_t stride = std::max<int64_t>(1, max_rows) * (kt + 1);
         void *wk = nullptr;
