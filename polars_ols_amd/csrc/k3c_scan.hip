@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) k3c_top_scan_kernel(const K3cArgs a) {
 }
 
 template <typename T, int K, int R, int WAVES, int MODE>
-__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) k3c_kernel(const K3cArgs a) {
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1)) k3c_kernel(const K3cArgs a) {
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NCP = K3C_NCP;
     static_assert(NT + 1 <= NCP && NT + 1 <= 64, "one component per lane in the cross-wave steps");
     static_assert(R == 4, "validity / start bytes travel as one 32-bit word per run");
@@ -428,6 +428,7 @@ static int k3c_launch_t(pols_ctx *ctx, const K3cArgs &a) {
         case 6: return k3c_launch_k<T, 6>(ctx, a);
         case 7: return k3c_launch_k<T, 7>(ctx, a);
         case 8: return k3c_launch_k<T, 8>(ctx, a);
+        case 9: return k3c_launch_k<T, 9>(ctx, a);
         default: return fail(POLS_ERR_UNSUPPORTED, "rls (row-parallel): %d features > %d", a.k, K4_KMAX);
     }
 }

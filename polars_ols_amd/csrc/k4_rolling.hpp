@@ -71,8 +71,9 @@ constexpr int K4Y_KMAX = 1024;
 // mode 0 plain (rolling), 1 / 2 decayed with the RLS prior as carry-in (packed / full K x K state), see k4_rolling.hip
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);
 
-// ---- K3c: row-parallel, read-once RLS for up to K4_KMAX features (k3c_scan.hip) ------------------------------------------------
-constexpr int K3C_NCP = 48;      // doubles per tile record: k (k + 1) / 2 + k + 1 <= 45
+constexpr int KC_KMAX = 9;       // the row-parallel dynamic kernels (K3c / K4c): 8 features + intercept still fit a lane's registers (512 at one wave per SIMD)
+// ---- K3c: row-parallel, read-once RLS for up to KC_KMAX features (k3c_scan.hip) ------------------------------------------------
+constexpr int K3C_NCP = 56;      // doubles per tile record: k (k + 1) / 2 + k + 1 <= 55
 constexpr int K3C_R = 4;         // consecutive rows per lane
 #ifndef K3C_WAVES_SMALL
 #define K3C_WAVES_SMALL 4
@@ -81,7 +82,7 @@ constexpr int k3c_waves(int k) { return k <= 6 ? K3C_WAVES_SMALL : 2; }    // wa
 constexpr int64_t k3c_tile_rows(int k) { return (int64_t)K3C_R * 64 * k3c_waves(k); }
 struct K3cArgs {
     const void *y;
-    const void *x[K4_KMAX];
+    const void *x[KC_KMAX];
     const uint8_t *valid;              // validity bytes or nullptr = every row valid
     const uint8_t *start;              // 1 on the first row of every sequence (k3c_start_flags)
     int64_t n_rows;
@@ -104,11 +105,11 @@ int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a);
 int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int64_t n_rows, uint8_t *start);
 
 // ---- K4c: row-parallel rolling OLS on null-free frames, window <= K4C_MAX_WINDOW (k4c_rolling.hip) ------------------------------
-constexpr int K4C_KMAX = 8;                // 7 / 8 features: more than 256 registers (256 + 24 / 88 AGPRs), one four-wave workgroup per CU instead of two
+constexpr int K4C_KMAX = 9;                // 7 / 8 features: more than 256 registers (256 + 24 / 88 AGPRs), one four-wave workgroup per CU instead of two
 constexpr int64_t K4C_MAX_WINDOW = 508;   // two halo waves: 512 >= 4 ceil(window / 4) + 1
 struct K4cArgs {
     const void *y;
-    const void *x[K4_KMAX];
+    const void *x[KC_KMAX];
     const uint8_t *start;              // 1 on the first row of every sequence (k3c_start_flags)
     int64_t n_rows, n_tiles;           // n_tiles is set by the launcher
     void *coef, *pred;                 // n_rows x k / n_rows, batch dtype, 16-byte aligned; either may be nullptr
