@@ -201,7 +201,7 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o);
 
 /* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions.
- * DIVERGENCE (the row-parallel kernel: up to 9 features, min_periods <= window, windows up to 508 rows -- 252 at 7 to 9 features -- or
+ * DIVERGENCE (the row-parallel kernel: up to 10 features, min_periods <= window, windows up to 508 rows -- 252 at 7 to 10 features -- or
  * any window when no sequence is longer than 1 021 rows; null-free frames, and frames with nulls under the drop family): a window whose X'X has
  * no Cholesky factorisation -- fewer than k independent rows -- yields NaN coefficients; the reference falls back to LU there
  * (ls.rs:732-734) and returns whatever a zero or noise pivot produces (inf / NaN / 1e15-sized numbers).

@@ -1601,7 +1601,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     // Up to 9 features (8 + intercept): the row-parallel, read-once kernel (K3c, k3c_scan.hip) whatever the sequence lengths -- every access a
     // 16-byte one down the row axis, so it needs 16-byte aligned columns / outputs (anything else: the chunk kernels below).
     // POLS_RLS_ENGINE=seq|chunk go back to K3 / the lane-per-chunk K3s.
-    bool rowpar = kf <= KC_KMAX && ctx->opt.rls_engine != 1 && ctx->opt.rls_engine != 3 && aligned16(st.y) && (!st.coef || aligned16(st.coef)) &&
+    bool rowpar = kf <= K3C_KMAX && ctx->opt.rls_engine != 1 && ctx->opt.rls_engine != 3 && aligned16(st.y) && (!st.coef || aligned16(st.coef)) &&
                   (!st.pred || aligned16(st.pred)) && (!st.valid || (reinterpret_cast<uintptr_t>(st.valid) & 3) == 0);
     for (int j = 0; j < kf && rowpar; ++j) rowpar = aligned16(st.x[j]);
     if (rowpar) {

@@ -71,8 +71,9 @@ constexpr int K4Y_KMAX = 1024;
 // mode 0 plain (rolling), 1 / 2 decayed with the RLS prior as carry-in (packed / full K x K state), see k4_rolling.hip
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);
 
-constexpr int KC_KMAX = 9;       // the row-parallel dynamic kernels (K3c / K4c): 8 features + intercept still fit a lane's registers (512 at one wave per SIMD)
+constexpr int KC_KMAX = 10;      // the row-parallel dynamic kernels: K3c up to 9 features, K4c up to 10 (512 registers at one wave per SIMD, a 137 KB table)
 // ---- K3c: row-parallel, read-once RLS for up to KC_KMAX features (k3c_scan.hip) ------------------------------------------------
+constexpr int K3C_KMAX = 9;       // (its cross-wave steps give every state component a lane: k (k + 3) / 2 + 1 <= 64)
 constexpr int K3C_NCP = 56;      // doubles per tile record: k (k + 1) / 2 + k + 1 <= 55
 constexpr int K3C_R = 4;         // consecutive rows per lane
 #ifndef K3C_WAVES_SMALL
@@ -105,7 +106,7 @@ int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a);
 int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int64_t n_rows, uint8_t *start);
 
 // ---- K4c: row-parallel rolling OLS on null-free frames, window <= K4C_MAX_WINDOW (k4c_rolling.hip) ------------------------------
-constexpr int K4C_KMAX = 9;                // 7 / 8 features: more than 256 registers (256 + 24 / 88 AGPRs), one four-wave workgroup per CU instead of two
+constexpr int K4C_KMAX = 10;                // 7 .. 10 features: more than 256 registers (256 + 24 .. 190 AGPRs), one four-wave workgroup per CU instead of two
 constexpr int64_t K4C_MAX_WINDOW = 508;   // two halo waves: 512 >= 4 ceil(window / 4) + 1
 struct K4cArgs {
     const void *y;

@@ -340,6 +340,7 @@ static int k4c_launch_t(pols_ctx *ctx, const K4cArgs &a) {
         case 7: return k4c_launch_k<T, 7>(ctx, a);
         case 8: return k4c_launch_k<T, 8>(ctx, a);
         case 9: return k4c_launch_k<T, 9>(ctx, a);
+        case 10: return k4c_launch_k<T, 10>(ctx, a);
         default: return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): %d features > %d", a.k, K4C_KMAX);
     }
 }

@@ -97,7 +97,13 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
     y, cols, offs, valid = _frame(rng, sizes, k, null_frac=null_frac)
     out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid),
                                     window_size=window, min_periods=min_periods, alpha=alpha, null_policy=policy)
-    assert eng.last_kernel.startswith("k4_rolling_tiles" if k <= 9 and valid is None else "k4w_")   # (8 features + intercept: the row-parallel kernel)
+    # (up to 10 features: the row-parallel kernel -- on frames with nulls under "drop" when every sequence keeps min_periods valid rows)
+    if k <= 10 and valid is None:
+        assert eng.last_kernel.startswith("k4_rolling_tiles")
+    elif k <= 10 and policy == "drop":
+        assert eng.last_kernel.startswith(("k4_rolling_tiles", "k4w_"))
+    else:
+        assert eng.last_kernel.startswith("k4w_")
     ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy, is_valid=valid)
     got_c, got_p = _np(out["coef"]), _np(out["pred"])
     nobs = _window_obs(offs, valid, window, policy)
@@ -269,7 +275,7 @@ def test_rolling_min_periods_beyond_the_window(eng, policy, k, window, min_perio
 @pytest.mark.parametrize("k,window,min_periods,alpha", [
     (1, 1, 1, None), (2, 2, None, None), (3, 3, 3, 0.1), (6, 7, 6, None), (4, 63, 4, None), (6, 64, 10, None), (5, 250, None, None),
     (6, 251, 6, None), (6, 252, 6, None), (6, 253, 6, None), (3, 255, 3, 1.0), (6, 256, 6, None), (8, 300, 8, None), (7, 507, 20, None),
-    (2, 508, 2, None), (7, 64, 7, None), (8, 252, 8, None), (7, 21, None, 0.5), (8, 9, 8, None), (9, 100, 9, None), (9, 252, 12, 0.1),
+    (2, 508, 2, None), (7, 64, 7, None), (8, 252, 8, None), (7, 21, None, 0.5), (8, 9, 8, None), (9, 100, 9, None), (9, 252, 12, 0.1), (10, 120, 10, None),
 ])
 def test_rolling_tiles_null_free(eng, dtype, tol, k, window, min_periods, alpha):
     """K4c (k4c_rolling.hip): null-free frames, every window offset modulo the 4-row runs, the one- / two-halo-wave boundary (252 / 253),
@@ -283,7 +289,7 @@ def test_rolling_tiles_null_free(eng, dtype, tol, k, window, min_periods, alpha)
         out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, window_size=window, min_periods=min_periods, alpha=alpha,
                                         null_policy=policy, null_free=True)
         # (7 / 8 features: more than 256 registers, one halo wave only -- windows up to 252 unless the tiles pack)
-        assert eng.last_kernel.startswith("k4_rolling_tiles" if (k <= 6 or window <= 252) else ("k4_rolling_walk" if k <= 8 else "k4w_rolling_walk"))
+        assert eng.last_kernel.startswith("k4_rolling_tiles" if (k <= 6 or window <= 252) else ("k4_rolling_walk" if k <= 8 else "k4w_rolling_walk"))   # (k <= 10 here)
         ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy)
         got_c, got_p = _np(out["coef"]), _np(out["pred"])
         assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
@@ -326,7 +332,7 @@ def test_rolling_many_sequences_full_size(eng):
 @pytest.mark.parametrize("k,window,min_periods,alpha", [
     (1, 1, 1, None), (3, 3, 3, 0.1), (6, 7, 6, None), (4, 63, 4, None), (6, 250, 10, None), (6, 251, 6, None), (6, 252, 6, None),
     (6, 253, 6, None), (5, 254, None, None), (3, 255, 3, 1.0), (6, 256, 6, None), (6, 507, 20, None), (2, 508, 2, None),
-    (7, 100, 7, None), (8, 252, 8, None), (8, 600, 10, None), (6, 700, 6, None), (3, 5000, 3, None), (9, 252, 9, None), (9, 800, 12, None),
+    (7, 100, 7, None), (8, 252, 8, None), (8, 600, 10, None), (6, 700, 6, None), (3, 5000, 3, None), (9, 252, 9, None), (9, 800, 12, None), (10, 252, 10, None),
 ])
 def test_rolling_packed_tiles_ragged_sequences(eng, dtype, tol, k, window, min_periods, alpha):
     """K4c's halo-free form: no sequence longer than a tile, so tiles hold whole sequences (cut at sequence starts, any row) and no
@@ -364,7 +370,7 @@ def test_rolling_packed_tiles_ragged_sequences(eng, dtype, tol, k, window, min_p
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("k,window,min_periods,shape", [
     (6, 252, 6, "many"), (6, 250, 20, "many"), (3, 21, None, "many"), (6, 253, 6, "long"), (5, 64, 5, "long"), (2, 7, 2, "tiny"),
-    (4, 100, 8, "holes"), (6, 508, 30, "many"), (7, 60, 7, "many"), (8, 252, 8, "long"), (8, 900, 10, "tiny"), (9, 120, 9, "many"),
+    (4, 100, 8, "holes"), (6, 508, 30, "many"), (7, 60, 7, "many"), (8, 252, 8, "long"), (8, 900, 10, "tiny"), (9, 120, 9, "many"), (10, 60, 10, "many"),
 ])
 def test_rolling_drop_with_nulls_compacted(eng, dtype, tol, k, window, min_periods, shape):
     """The drop family on frames WITH nulls up to 6 features: the valid rows are compacted, the tile kernel runs on them, the
