@@ -82,14 +82,51 @@ __device__ __forceinline__ void k3c_load_run(const void *col, int64_t row0, doub
     }
 }
 
+// A composite (d, t) of the scan spread over the lanes of a wave: component q of t (q < NT) and the decay d (component NT) sit at lane
+// q % 64, slot q / 64 -- one slot up to 63 components (9 features), two beyond (10 features: 65 + 1).
+template <int NT>
+struct K3cLaneVec {
+    static constexpr int NS = (NT + 1 + 63) / 64;
+    double v[NS];
+    __device__ __forceinline__ void identity(int lane) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = (lane + 64 * s == NT) ? 1.0 : 0.0;
+    }
+    __device__ __forceinline__ void load(const double *p, int lane) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = (lane + 64 * s <= NT) ? p[lane + 64 * s] : 0.0;
+    }
+    __device__ __forceinline__ void store(double *p, int lane) const {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (lane + 64 * s <= NT) p[lane + 64 * s] = v[s];
+    }
+    template <int Q> __device__ __forceinline__ double get() const { return k1p_readlane(v[Q / 64], Q % 64); }
+    __device__ __forceinline__ double get_d() const { return get<NT>(); }
+    __device__ __forceinline__ void set(int q, double val, int lane) {     // q: wave-uniform
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = (lane + 64 * s == q) ? val : v[s];
+    }
+    // *this <- (*this) . b   under (d1, t1) . (d2, t2) = (d1 d2, d2 t1 + t2); bd = b's decay
+    __device__ __forceinline__ void then(const K3cLaneVec &b, double bd, int lane) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = (lane + 64 * s == NT) ? v[s] * b.v[s] : fma(bd, v[s], b.v[s]);
+    }
+};
+
+template <int NT, int Q>
+__device__ __forceinline__ void k3c_unpack(const K3cLaneVec<NT> &c, double (&out)[NT]) {
+    if constexpr (Q < NT) { out[Q] = c.template get<Q>(); k3c_unpack<NT, Q + 1>(c, out); }
+}
+
 // One wave scans a window of up to 64 records (lane l <-> record first + l, l < count): writes every record's exclusive composite --
 // from the last closed record below it in the window, or, nothing closed below, with carry_in (one component per lane, slot NT the
 // decay) prepended when there is one -- and whether it is still open; returns "some record of the window is closed" and leaves the
 // window's inclusive composite in lane 63's (Dl, Tl).
 template <int NT>
 __device__ __forceinline__ bool k3c_scan_window(const double *rec, const int32_t *closed, int64_t first, int64_t count, double *excl,
-                                                int32_t *open_out, double &Dl, double (&Tl)[NT], bool carry_in_valid, double carry_in_q,
-                                                const int lane) {
+                                                int32_t *open_out, double &Dl, double (&Tl)[NT], bool carry_in_valid,
+                                                const K3cLaneVec<NT> &carry_in, const int lane) {
     const bool in = lane < count;
     const int64_t r = first + (in ? lane : 0);
     Dl = 1.0;
@@ -109,10 +146,15 @@ __device__ __forceinline__ bool k3c_scan_window(const double *rec, const int32_t
         for (int q = 0; q < NT; ++q) ET2[q] = 0.0;
     }
     const bool open = (hm & ((1ull << lane) - 1ull)) == 0;
-    if (open && carry_in_valid) {
+    if (carry_in_valid) {                                    // (wave-uniform; the broadcasts run with every lane enabled)
+        double cv[NT];
+        k3c_unpack<NT, 0>(carry_in, cv);
+        const double cd = carry_in.get_d();
+        if (open) {
 #pragma unroll
-        for (int q = 0; q < NT; ++q) ET2[q] = fma(ED2, k1p_readlane(carry_in_q, q), ET2[q]);
-        ED2 *= k1p_readlane(carry_in_q, NT);
+            for (int q = 0; q < NT; ++q) ET2[q] = fma(ED2, cv[q], ET2[q]);
+            ED2 *= cd;
+        }
     }
     if (in) {
 #pragma unroll
@@ -130,7 +172,9 @@ __global__ void __launch_bounds__(64) k3c_block_scan_kernel(const K3cArgs a) {
     const int64_t blk = blockIdx.x;
     const int64_t left = a.n_tiles - (blk << 6), cnt = left < 64 ? left : 64;
     double Dl, Tl[NT];
-    const bool bclosed = k3c_scan_window<NT>(a.rec, a.rec_closed, blk << 6, cnt, a.carry, a.carry_open, Dl, Tl, false, 0.0, lane);
+    K3cLaneVec<NT> none;
+    none.identity(lane);
+    const bool bclosed = k3c_scan_window<NT>(a.rec, a.rec_closed, blk << 6, cnt, a.carry, a.carry_open, Dl, Tl, false, none, lane);
     if (lane == 63) {
 #pragma unroll
         for (int q = 0; q < NT; ++q) a.brec[blk * K3C_NCP + q] = Tl[q];
@@ -144,18 +188,20 @@ template <int NT>
 __global__ void __launch_bounds__(64) k3c_top_scan_kernel(const K3cArgs a) {
     const int lane = threadIdx.x;
     const int64_t n_blocks = (a.n_tiles + 63) >> 6;
-    double chain = (lane == NT) ? 1.0 : 0.0;                     // composite of the steps so far (from their last closed block), per component
+    K3cLaneVec<NT> chain;                                        // composite of the steps so far (from their last closed block), per component
+    chain.identity(lane);
     bool chain_valid = false;
     double Dl, Tl[NT];
     for (int64_t b0 = 0; b0 < n_blocks; b0 += 64) {
         const int64_t cnt = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
         const bool anyc = k3c_scan_window<NT>(a.brec, a.brec_closed, b0, cnt, a.bcarry, nullptr, Dl, Tl, chain_valid, chain, lane);
-        double wq = 0.0;                                         // the window's composite (lane 63) spread one component per lane
+        K3cLaneVec<NT> wq;                                       // the window's composite (lane 63) spread over the lanes
+        wq.identity(lane);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) { const double v = k1p_readlane(Tl[q], 63); wq = (lane == q) ? v : wq; }
-        { const double v = k1p_readlane(Dl, 63); wq = (lane == NT) ? v : wq; }
+        for (int q = 0; q < NT; ++q) wq.set(q, k1p_readlane(Tl[q], 63), lane);
+        wq.set(NT, k1p_readlane(Dl, 63), lane);
         if (anyc || !chain_valid) chain = wq;
-        else { const double wD = k1p_readlane(wq, NT); chain = (lane == NT) ? chain * wq : fma(wD, chain, wq); }
+        else chain.then(wq, wq.get_d(), lane);
         chain_valid = true;
     }
 }
@@ -163,7 +209,7 @@ __global__ void __launch_bounds__(64) k3c_top_scan_kernel(const K3cArgs a) {
 template <typename T, int K, int R, int WAVES, int MODE>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1)) k3c_kernel(const K3cArgs a) {
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NCP = K3C_NCP;
-    static_assert(NT + 1 <= NCP && NT + 1 <= 64, "one component per lane in the cross-wave steps");
+    static_assert(NT + 1 <= NCP && NT + 1 <= 128, "at most two components per lane in the cross-wave steps");
     static_assert(R == 4, "validity / start bytes travel as one 32-bit word per run");
     __shared__ double s_agg[WAVES][NT + 1];      // wave aggregates (slot NT: the decay)
     __shared__ int s_closed[WAVES];              // the aggregate starts at a sequence start inside the wave
@@ -295,45 +341,46 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
     __syncthreads();
 
     // ---- C: across the waves of the tile, one component per lane (lane NT: the decay)
-    const int ql = lane <= NT ? lane : NT;
-    double run = (lane == NT) ? 1.0 : 0.0;       // composite of the waves below, from the last sequence start among them
+    K3cLaneVec<NT> run;                          // composite of the waves below, from the last sequence start among them
+    run.identity(lane);
     bool wopen = true;                           // ... none among them: the tile's carry-in still has to be prepended
     for (int w2 = 0; w2 < wv; ++w2) {
-        const double eD = s_agg[w2][NT], eq = s_agg[w2][ql];
+        K3cLaneVec<NT> eq;
+        eq.load(&s_agg[w2][0], lane);
         if (s_closed[w2]) { run = eq; wopen = false; }
-        else run = (lane == NT) ? run * eD : fma(eD, run, eq);
+        else run.then(eq, s_agg[w2][NT], lane);
     }
     K3C_STAMP(2);
     if constexpr (MODE == 0) {
         // pass 1: the tile's record -- its aggregate from the last sequence start inside it on, and whether there is one
         if (wv != WAVES - 1) return;
-        double agg = run;
         bool tclosed = !wopen;
         {
-            const double eD = s_agg[wv][NT], eq = s_agg[wv][ql];
-            if (s_closed[wv]) { agg = eq; tclosed = true; }
-            else agg = (lane == NT) ? agg * eD : fma(eD, agg, eq);
+            K3cLaneVec<NT> eq;
+            eq.load(&s_agg[wv][0], lane);
+            if (s_closed[wv]) { run = eq; tclosed = true; }
+            else run.then(eq, s_agg[wv][NT], lane);
         }
         // (all_closed -- no sequence longer than a tile, the host knows: every tile holds a sequence start, tile t + 1's carry-in IS
         // this record and nothing scans them.  Otherwise two small launches between the passes do.)
-        if (lane <= NT) a.rec[t * K3C_NCP + lane] = agg;
+        run.store(a.rec + t * K3C_NCP, lane);
         if (lane == 0 && !a.all_closed) a.rec_closed[t] = tclosed ? 1 : 0;
         return;
     }
     {
         // pass 2: the tile's carry-in = [its block's carry-in] . [the tiles of its block below it], both written by pass 1
-        double cq;
-        if (a.tile_row0) cq = (lane == NT) ? 1.0 : 0.0;                        // packed: the tile starts (within a run) at a sequence start
-        else if (a.all_closed) cq = a.rec[(t > 0 ? t - 1 : 0) * K3C_NCP + ql];     // (tile 0 starts with a sequence start: its carry-in is never used)
-        else cq = a.carry[t * K3C_NCP + ql];
+        K3cLaneVec<NT> cq;
+        if (a.tile_row0) cq.identity(lane);                                     // packed: the tile starts (within a run) at a sequence start
+        else if (a.all_closed) cq.load(a.rec + (t > 0 ? t - 1 : 0) * K3C_NCP, lane);   // (tile 0 starts with a sequence start: its carry-in is never used)
+        else cq.load(a.carry + t * K3C_NCP, lane);
         if (!a.all_closed && a.carry_open[t] && t >= 64) {
-            const double bq = a.bcarry[(t >> 6) * K3C_NCP + ql];
-            const double cD = k1p_readlane(cq, NT);
-            cq = (lane == NT) ? bq * cq : fma(cD, bq, cq);
+            K3cLaneVec<NT> bq;
+            bq.load(a.bcarry + (t >> 6) * K3C_NCP, lane);
+            bq.then(cq, cq.get_d(), lane);
+            cq = bq;
         }
-        const double runD = k1p_readlane(run, NT);
-        const double full = wopen ? ((lane == NT) ? cq * run : fma(runD, cq, run)) : run;
-        if (lane <= NT) s_wfull[wv][lane] = full;
+        if (wopen) { cq.then(run, run.get_d(), lane); run = cq; }
+        run.store(&s_wfull[wv][0], lane);
     }
     __syncthreads();
     K3C_STAMP(3);
@@ -429,6 +476,7 @@ static int k3c_launch_t(pols_ctx *ctx, const K3cArgs &a) {
         case 7: return k3c_launch_k<T, 7>(ctx, a);
         case 8: return k3c_launch_k<T, 8>(ctx, a);
         case 9: return k3c_launch_k<T, 9>(ctx, a);
+        case 10: return k3c_launch_k<T, 10>(ctx, a);
         default: return fail(POLS_ERR_UNSUPPORTED, "rls (row-parallel): %d features > %d", a.k, K4_KMAX);
     }
 }

@@ -73,8 +73,8 @@ void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode);
 
 constexpr int KC_KMAX = 10;      // the row-parallel dynamic kernels: K3c up to 9 features, K4c up to 10 (512 registers at one wave per SIMD, a 137 KB table)
 // ---- K3c: row-parallel, read-once RLS for up to KC_KMAX features (k3c_scan.hip) ------------------------------------------------
-constexpr int K3C_KMAX = 9;       // (its cross-wave steps give every state component a lane: k (k + 3) / 2 + 1 <= 64)
-constexpr int K3C_NCP = 56;      // doubles per tile record: k (k + 1) / 2 + k + 1 <= 55
+constexpr int K3C_KMAX = 10;      // (its cross-wave steps spread the state components over the lanes: one per lane up to 9 features, two at 10)
+constexpr int K3C_NCP = 72;      // doubles per tile record: k (k + 1) / 2 + k + 1 <= 66
 constexpr int K3C_R = 4;         // consecutive rows per lane
 #ifndef K3C_WAVES_SMALL
 #define K3C_WAVES_SMALL 4

@@ -65,10 +65,10 @@ def test_rls_many_groups(eng, rls_engine, dtype, tol, k, half_life, p0, mean):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
-@pytest.mark.parametrize("k", [9, 16, 32])
+@pytest.mark.parametrize("k", [9, 10, 16, 32])
 @pytest.mark.parametrize("half_life,p0,mean", [(None, 10.0, None), (252.0, 1.0, 0.25)])
 def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
-    """9..32 features: 9 on the row-parallel kernel, 10+ on the wave-per-chunk scan (k4w_wide.hip), several chunks per sequence, invalid rows."""
+    """9..32 features: 9 and 10 on the row-parallel kernel, 11+ on the wave-per-chunk scan (k4w_wide.hip), several chunks per sequence, invalid rows."""
     from oracle import orc
 
     rng = np.random.default_rng(100 + k)
@@ -85,7 +85,7 @@ def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
                                       initial_state_covariance=p0, initial_state_mean=mean0)
     ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0,
                           is_valid=valid)
-    assert eng.last_kernel.startswith("k3s_rls_rows" if k <= 9 else "k3sw_")     # (8 features + intercept still fit the row-parallel kernel)
+    assert eng.last_kernel.startswith("k3s_rls_rows" if k <= 10 else "k3sw_")    # (up to 10 features fit the row-parallel kernel)
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
     assert np.allclose(_np(out["pred"]), _masked(ref["pred"], valid), rtol=tol, atol=tol, equal_nan=True)
 
@@ -175,7 +175,7 @@ def test_rls_many_sequences_full_size(eng):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
-@pytest.mark.parametrize("k", [3, 6, 7, 9])
+@pytest.mark.parametrize("k", [3, 6, 7, 9, 10])
 def test_rls_lookback_long_and_short_sequences_mixed(eng, dtype, tol, k):
     """K3c's look-back across tiles and groups of tiles: a frame of one 40 000-row sequence (several look-back groups), thousands
     of rows of tiny sequences (every tile closed), and sequences that start exactly on tile / run boundaries; with validity bytes."""
@@ -199,7 +199,7 @@ def test_rls_lookback_long_and_short_sequences_mixed(eng, dtype, tol, k):
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
-@pytest.mark.parametrize("k", [2, 6, 8, 9])
+@pytest.mark.parametrize("k", [2, 6, 8, 9, 10])
 def test_rls_packed_tiles_ragged_sequences(eng, dtype, tol, k):
     """K3c's single-pass form: no sequence longer than a tile, so tiles are cut at sequence starts (whole sequences, starts at any
     row -- a tile's lanes begin up to three rows before its first sequence) and nothing is carried between them.  Ragged lengths up
