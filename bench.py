@@ -255,6 +255,21 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
     raise SystemExit(f"unknown --config {cfg}")
 
 
+def self_launch_command(n_gpus: int, argv: list) -> list:
+    """argv of the launcher `bench.py --gpus N` turns itself into when nothing has launched it (no WORLD_SIZE): the driver's own
+    command form, on 127.0.0.1 (the container's hostname may not resolve)."""
+    port = os.environ.get("MASTER_PORT", "29531")
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
+def self_launch_env() -> dict:
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return env
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,8 +288,13 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  One rank per GPU under torch.distributed.run with the
+        # same arguments; rank 0 still prints the ONE JSON line (the children inherit stdout).  A box with fewer than N GPUs fails
+        # INSIDE the ranks (torch.cuda.set_device: invalid device ordinal), never here.
+        os.execvpe(sys.executable, self_launch_command(args.gpus, sys.argv[1:]), self_launch_env())
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if args.mem == "host" and (world > 1 or args.config not in ("cfg1", "cfg2", "cfg3")):
         raise SystemExit("--mem host: cfg1 / cfg2 / cfg3 on one GPU")
     torch.cuda.set_device(local_rank)

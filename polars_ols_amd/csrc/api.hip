@@ -117,12 +117,13 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
         h0 = (h0 ^ u[g]) * P; h1 = (h1 ^ u[g + 1]) * P; h2 = (h2 ^ u[g + 2]) * P; h3 = (h3 ^ u[g + 3]) * P;
     }
     for (; g < cnt; ++g) h0 = (h0 ^ u[g]) * P;
-    int64_t mx = 0, ored = 0, mn = 0;
+    int64_t mx = 0, ored = 0, mn = 0, mn_pos = INT64_MAX;
     for (int64_t i = 0; i < cnt; ++i) ored |= offs[i];
     int64_t over = 0;                                  // rows beyond the 1 021 (+ 3 of chunk-grid slack) a wave-per-group f32 kernel keeps resident
     for (int64_t i = 1; i < cnt; ++i) {
         const int64_t d = offs[i] - offs[i - 1];
         mn = d < mn ? d : mn; mx = d > mx ? d : mx;
+        mn_pos = (d > 0 && d < mn_pos) ? d : mn_pos;
         over += d > 1021 ? d - 1021 : 0;
     }
     if (mn < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending");
@@ -142,6 +143,7 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
     ctx->offs_host = offs;
     ctx->offs_generation = generation;
     ctx->offs_max_rows = mx;
+    ctx->offs_min_rows = mn_pos == INT64_MAX ? 0 : mn_pos;
     ctx->offs_wave_overflow = over;
     {
         int64_t tail = -1;                             // the last group that has rows: its chunk grid may cross the end of the columns
@@ -183,6 +185,8 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1T_RC4")) o.k1t_rc4 = on ? (std::atoi(v) != 0) : d.k1t_rc4;
     else if (ieq(key, "K1T_SUB8")) o.k1t_sub8 = on ? std::atoi(v) : d.k1t_sub8;
     else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
+    else if (ieq(key, "K1_XCD")) o.k1_xcd = on ? std::atoi(v) : d.k1_xcd;
+    else if (ieq(key, "DEBUG_SKIP_FIXUP")) o.debug_skip_fixup = on && std::atoi(v) != 0;
     else if (ieq(key, "K1_PERSIST")) o.k1_persist = on ? (std::atoi(v) != 0) : d.k1_persist;
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
     else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
@@ -198,7 +202,8 @@ bool options_set(Options &o, const char *key, const char *v) {
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
-                                       "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8"};
+                                       "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
+                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);
@@ -962,9 +967,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     };
     auto svd_fixup = [&]() -> int {
         if (enet) return POLS_OK;
-        // (measurement aid, read once: what the fix-up dispatch of a call that flags nothing costs on the stream -- DESIGN.md section 4)
-        static const bool skip_for_measurement = std::getenv("POLS_DEBUG_SKIP_FIXUP") != nullptr;
-        if (skip_for_measurement) return POLS_OK;
+        // (measurement aid, an Options switch like the others -- no compute entry reads the environment: what the fix-up dispatch of a
+        // call that flags nothing costs on the stream)
+        if (ctx->opt.debug_skip_fixup) return POLS_OK;
         int r2 = prepare_fix();
         if (r2) return r2;
         return k6_launch(ctx, b->dtype, ka, fix_workers);
@@ -1850,6 +1855,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
                 const int64_t nt = (int64_t)first.size() - 1;
                 if (nt * K4C_PACKED_ROWS * 7 <= Nc * 10 || w > k4c_max_window(k)) {    // (a window beyond the halo forms: packed whatever the fill)
                     c.window = std::min<int64_t>(w, 2 * K4C_PACKED_ROWS);
+                    c.min_periods = std::min<int64_t>(mp, c.window);     // (see the null-free route below)
                     if ((rc = ensure_scratch(ctx, 22, round256(sizeof(int64_t) * first.size()), &dm))) return rc;
                     if ((rc = upload_small(ctx, dm, first.data(), sizeof(int64_t) * first.size()))) return rc;
                     c.tile_row0 = static_cast<const int64_t *>(dm); c.n_packed = nt;
@@ -1871,7 +1877,10 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         for (int j = 0; j < k; ++j) c.x[j] = st.x[j];
         c.n_rows = b->n_rows; c.coef = st.coef; c.pred = st.pred;
         c.window = packed_map ? std::min<int64_t>(w, 2 * K4C_PACKED_ROWS) : w;   // (a window longer than a tile never fills: any such is the same)
-        c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
+        // min_periods follows the clamp: on packed tiles no sequence has more than 1 021 rows, so a min_periods beyond the clamped
+        // window (2 048 < min_periods <= window_size) is "never enough rows" either way -- all NaN, what the reference returns for a
+        // sequence shorter than min_periods (ls.rs:893-900) -- and the launch check (min_periods <= window) must not reject it
+        c.min_periods = std::min<int64_t>(mp, c.window); c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
         c.tile_row0 = packed_map; c.n_packed = n_packed;
         if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
         if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;

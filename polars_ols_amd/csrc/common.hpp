@@ -65,6 +65,8 @@ struct Options {
     int k1t_sub32 = -1;           // POLS_K1T_SUB32      -1: default (on), 0: never two groups per wave in the one-shot kernel
     int k1_persist_sub = 0;       // POLS_K1_PERSIST_SUB 0: default rule, 64 / 32 / 16 lanes per group
     int k1_persist = -1;          // POLS_K1_PERSIST     -1: default rule (enough groups), 0 never, 1 whenever the groups fit K1p
+    bool debug_skip_fixup = false; // POLS_DEBUG_SKIP_FIXUP  measurement switch: the fix-up dispatch behind a static solve is skipped (flagged groups keep their unusable coefficients)
+    int k1_xcd = 0;               // POLS_K1_XCD         resident K1 kernels: 1 = XCD-contiguous workgroup -> group map (each XCD walks one eighth of the frame)
 };
 void options_from_env(Options &o);
 // key: the variable's name with or without the POLS_ prefix (case-insensitive); value NULL = back to the default.  False = unknown key.
@@ -108,6 +110,7 @@ struct pols_ctx {
     PinnedSlot pinned[4];
     int pinned_next = 0;
     int64_t offs_max_rows = 0;
+    int64_t offs_min_rows = 0;               // fewest rows of a NON-EMPTY group (0: no group has rows)
     int64_t offs_tail_group = -1;            // last group with rows (K1p hands it to one wave when n_rows is not a multiple of the vector width)
     int64_t offs_wave_overflow = 0;          // sum over groups of the rows beyond 1 021 (see k1_launch_kw)
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag

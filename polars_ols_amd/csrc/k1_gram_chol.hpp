@@ -45,6 +45,8 @@ struct K1Args {
     int32_t k_user;                      // KT - add_intercept
     int64_t skip_group;                  // K1p: the group a single wave handles after the persistent loop (or -1)
     unsigned long long *dbg;             // POLS_TIMELINE=1: 8 s_memtime stamps per group (debug only)
+    int64_t xcd_chunk;                   // 0: workgroup b takes block b of the groups; else b -> (b % 8) * xcd_chunk + b / 8, so that each XCD
+                                         // (workgroups are dealt round-robin over the eight) walks one contiguous eighth of every column
 };
 
 // Launches the (dtype, KT, team, resident-chunks) variant that fits max_group_rows.

@@ -763,22 +763,30 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
 #undef K1_STAMP
 }
 
+// workgroup -> block of groups.  The hardware deals workgroups round-robin over the eight XCDs, so the identity map sends neighbouring
+// groups -- whose slices share the 128-byte lines at their ends -- to eight different L2s; with xcd_chunk set, XCD x walks the blocks
+// [x * xcd_chunk, (x + 1) * xcd_chunk) in order (grid padded to 8 * xcd_chunk; the body returns for blocks past the last group).
+__device__ __forceinline__ int64_t k1_block_id(const K1Args &a) {
+    const int64_t b = blockIdx.x;
+    return a.xcd_chunk ? (b & 7) * a.xcd_chunk + (b >> 3) : b;
+}
+
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool NT = false,
           bool EDGE = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, NT, EDGE>(a, (int64_t)blockIdx.x);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, NT, EDGE>(a, k1_block_id(a));
 }
 // The same body held to 128 VGPRs (four waves per SIMD): the ragged one-chunk-per-lane wave kernel needs 130.
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k1_kernel_occ4(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a, (int64_t)blockIdx.x);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a, k1_block_id(a));
 }
 
 // (the null-policy wave kernel with 16 resident rows sits at exactly 256 VGPRs; one more value and the allocator reaches for an AGPR,
 // which halves the occupancy of the unified register file: 80.7 -> 132 us on 10 000 x 1 000 x 8.  Held to two waves per SIMD.)
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k1_kernel_occ2(const K1Args a) {
-    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a, (int64_t)blockIdx.x);
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>(a, k1_block_id(a));
 }
 
 // One chunk of a small ragged group, branch-free: the 16-byte loads of every column issued unconditionally (lanes without a chunk
@@ -1325,6 +1333,8 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     K1Args aa = a;
+    aa.xcd_chunk = 0;
+    if (ctx->opt.k1_xcd > 0 && blocks >= 64) { aa.xcd_chunk = (blocks + 7) / 8; blocks = aa.xcd_chunk * 8; }
     const bool timeline = ctx->opt.timeline;
     if (timeline) {
         void *d = nullptr;

@@ -33,6 +33,7 @@ __device__ __forceinline__ void k6_process(const K6Args &a, const int worker, co
         if (a.status[g] != POLS_GROUP_FALLBACK) continue;         // block-uniform
         const int64_t s = a.offs[g], e = a.offs[g + 1];
         const int64_t n = e - s;
+        if (k6s_takes(a.mode, n, kt, a.small_rows)) continue;     // K6s's (block-uniform)
         // ---- copy the group as f64, sqrt(w)-scaled, intercept appended last (least_squares.py:184-196)
         const int pol = a.null_policy;
         int nfit_l = 0;

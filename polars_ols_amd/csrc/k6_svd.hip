@@ -14,13 +14,25 @@
 // eigen-decomposition of X'X could not.  Not bandwidth-critical: it runs on the rare groups only.
 #include "k6_body.inl"
 
+#include <algorithm>
+
 namespace pols {
 
 int k6_launch(pols_ctx *ctx, int dtype, const K6Args &a, int workers) {
     if (a.kt > K6_KMAX) return fail(POLS_ERR_UNSUPPORTED, "svd fallback: %d features > %d", a.kt, K6_KMAX);
-    if (dtype == POLS_F32) hipLaunchKernelGGL(k6_svd_kernel<float>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k6_svd_kernel<double>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, a);
+    // Short groups whose reference solver is the SVD (n <= k under solve_method = None, anything under "svd") go to K6s, a sub-wave team
+    // per group; the host knows from the offsets whether the frame holds any (no extra dispatch on the frames the benchmarks visit).
+    K6Args aa = a;
+    aa.small_rows = 0;
+    const int64_t short_rows = ctx->offs_min_rows;                // fewest rows of a non-empty group
+    if (short_rows > 0 && short_rows <= 32 && (a.mode == FIX_MINNORM || (a.mode == FIX_OLS_AUTO && short_rows <= a.kt))) {
+        const int64_t top = std::min<int64_t>(32, ctx->offs_max_rows);
+        aa.small_rows = top <= 4 ? 4 : top <= 8 ? 8 : top <= 16 ? 16 : 32;
+    }
+    if (dtype == POLS_F32) hipLaunchKernelGGL(k6_svd_kernel<float>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, aa);
+    else hipLaunchKernelGGL(k6_svd_kernel<double>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, aa);
     POLS_HIP(hipGetLastError());
+    if (aa.small_rows > 0) return k6s_launch(ctx, dtype, aa);
     return POLS_OK;
 }
 

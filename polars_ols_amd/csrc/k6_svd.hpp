@@ -25,8 +25,18 @@ struct K6Args {
     const uint8_t *valid;    // null policy of the static entry (see common.hpp::null_row_in_fit)
     int32_t null_policy;
     int32_t mode;            // FixMode (fix_solvers.inl)
+    int32_t small_rows;      // > 0: flagged groups of at most this many rows whose solver is the SVD belong to K6s (k6s_small.hip); K6 skips them
 };
 
+// Does K6s (a sub-wave team per group, dual Jacobi) take this flagged group?  Decided from (mode, rows, columns) alone so that K6 and K6s
+// agree without a hand-over: the SVD is the reference's solver for "svd" on any group and for solve_method = None on a group with no
+// more rows than columns (ls.rs:224-231; rows the null policy drops only lower the fit's row count further).
+__host__ __device__ inline bool k6s_takes(int mode, int64_t n, int kt, int small_rows) {
+    return small_rows > 0 && n <= (int64_t)small_rows && (mode == FIX_MINNORM || (mode == FIX_OLS_AUTO && n <= (int64_t)kt));
+}
+
+// launches the K6 pool and, when the frame holds groups short enough for it, K6s
 int k6_launch(pols_ctx *ctx, int dtype, const K6Args &a, int workers);
+int k6s_launch(pols_ctx *ctx, int dtype, const K6Args &a);
 
 }  // namespace pols

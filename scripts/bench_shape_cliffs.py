@@ -16,6 +16,8 @@ SHAPES = [("1 x 10M", [N]), ("10 x 1M", [N // 10] * 10), ("100 x 100k", [100_000
           ("mixed 1 x 5M + 5k x 1k", [5_000_000] + [1_000] * 5_000)]
 # (2 500 000 groups of 4 rows x 8 features -- fewer rows than columns: EVERY group goes through the minimum-norm fix-up pass, 65 s per
 #  call; not part of the default sweep.  ONLY=<substring> picks shapes.)
+if os.environ.get("SHORT"):                                   # round 5: those groups take K6s (a sub-wave team per group), milliseconds
+    SHAPES += [("2.5M x 4 (n < k)", [4] * 2_500_000), ("1.25M x 8 (n = k)", [8] * 1_250_000), ("mixed 5k x 1k + 100k x 6", [1_000] * 5_000 + [6] * 100_000)]
 if os.environ.get("ONLY"):
     SHAPES = [sh for sh in SHAPES if os.environ["ONLY"] in sh[0]]
 for dt, dname in ((torch.float32, "f32"), (torch.float64, "f64")):

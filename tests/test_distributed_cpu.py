@@ -188,3 +188,44 @@ def test_comm_entries_fail_cleanly_without_a_gpu():
     assert L.pols_comm_create(None, None, 2, 0, C.byref(h)) == -1 and not h.value    # POLS_ERR_INVALID: no context without a GPU
     assert L.pols_comm_world_size(None) == -1 and L.pols_comm_rank(None) == -1
     L.pols_comm_destroy(None)
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` with no launcher around it re-executes itself under torch.distributed.run in the driver's own command
+    form (VERDICT r04 #14: it used to exit at argument handling)."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_for_test", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.self_launch_command(8, ["--gpus", "8", "--steps", "5", "--warmup", "2"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(str(root / "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    env = bench.self_launch_env()
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_gpus2_fails_inside_the_ranks_not_at_argument_handling():
+    """No GPU here: `python bench.py --gpus 2` must get as far as the ranks (torch.distributed.run starts two of them, each dies
+    selecting its device) instead of refusing the command line."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(root))
+    assert r.returncode != 0
+    err = r.stderr + r.stdout
+    assert "launch with torch.distributed.run" not in err
+    # the launcher ran and its children failed: torch.distributed.run reports the failed ranks
+    assert "ChildFailedError" in err or "local_rank" in err or "exitcode" in err, err[-2000:]

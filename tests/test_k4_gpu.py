@@ -453,3 +453,81 @@ def test_rolling_drop_with_nulls_short_of_min_periods_keeps_the_old_path(eng):
     healthy[int(offs[1]):int(offs[2])] = False                           # (the starved sequence is a singular system: whatever LU makes of it)
     healthy &= np.isfinite(ref["coef"]).all(axis=1) & (_window_obs(offs, valid, 50, "drop") >= 8)
     assert np.allclose(_np(out["coef"])[healthy], ref["coef"][healthy], rtol=1e-6, atol=1e-6)
+
+
+def test_rolling_min_periods_beyond_the_clamped_window_on_packed_tiles(eng):
+    """on packed tiles the window is clamped to 2 048 rows (no sequence is longer than a tile, so any longer window is the
+    same window); a min_periods in (2 048, window_size] must follow the clamp instead of failing the launch check -- every sequence is
+    shorter than min_periods, so the answer is the reference's all-NaN (ls.rs:893-900)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(3000)
+    sizes = np.concatenate([[1000, 1000, 1, 0, 1021], rng.integers(300, 1000, size=40)])
+    y, cols, offs, _ = _frame(rng, sizes, 6)
+    for window, mp in ((3000, 3000), (5000, 2500), (2049, 2049)):
+        for policy in ("drop", "drop_window"):
+            out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, window_size=window, min_periods=mp, null_policy=policy,
+                                            null_free=True)
+            assert eng.last_kernel.startswith("k4_rolling_tiles"), eng.last_kernel
+            ref = orc.batched_rolling(y, cols, offs, window, min_periods=mp, null_policy=policy)
+            assert np.isnan(ref["coef"]).all()
+            assert np.isnan(_np(out["coef"])).all() and np.isnan(_np(out["pred"])).all()
+
+
+def _window_rows(offs, i, window):
+    g = int(np.searchsorted(offs, i, side="right") - 1)
+    return max(int(offs[g]), i - window + 1), i + 1
+
+
+@pytest.mark.parametrize("k,window,min_periods", [(3, 3, 3), (4, 5, 4), (6, 7, 6), (6, 6, 2), (5, 12, 1), (8, 9, 3)])
+def test_rolling_divergence_band_is_pinned(eng, k, window, min_periods):
+    """VERDICT r04 #8 / ADVICE: where the default row-parallel route (K4c: L D L', NaN on a failed factorisation) and the reference
+    (Cholesky -> LU, `NonWoodburyState::solve`, ls.rs:732-734) can return different KINDS of answer.
+    (i)  POLS_ROLLING_ENGINE=chunk (the lane-per-chunk kernels, which have the LU) on windows holding k ... k + 1 observations:
+         value-compared with the oracle wherever the oracle is finite and < 1e3, at 1e-6 or -- recorded per row -- at the bound the
+         window's own conditioning allows (cond(X'X) eps: a k-row window is a square system);
+    (ii) the default route's NaN rows are a SUBSET of the rows where the oracle has no usable answer either (non-finite or > 1e3:
+         a window with fewer than k independent rows, where the reference's LU divides by zero or by rounding noise), and everywhere
+         else the two routes agree with the oracle to the same bound."""
+    from oracle import orc
+
+    rng = np.random.default_rng(1000 * k + window)
+    sizes = np.concatenate([[400, 1, 2, k - 1, k, k + 1, 0, 37], rng.integers(1, 120, size=12)])
+    y, cols, offs, _ = _frame(rng, sizes, k)
+    X = np.stack(cols, axis=1)
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, null_policy="drop")
+    nobs = _window_obs(offs, None, window, "drop")
+    usable = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+    kw = dict(window_size=window, min_periods=min_periods, null_policy="drop", null_free=True)
+
+    def bound(i):                                                   # what the window's conditioning allows, never below 1e-6
+        lo, hi = _window_rows(offs, i, window)
+        return max(1e-6, 1e3 * np.linalg.cond(X[lo:hi].T @ X[lo:hi]) * np.finfo(np.float64).eps)
+
+    dflt = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    assert eng.last_kernel.startswith("k4_rolling_tiles")
+    eng.set_option("ROLLING_ENGINE", "chunk")
+    try:
+        chunk = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+        assert not eng.last_kernel.startswith("k4_rolling_tiles")
+    finally:
+        eng.set_option("ROLLING_ENGINE", None)
+    d_c, c_c = _np(dflt["coef"]), _np(chunk["coef"])
+    # (i) the band k ... k + 1 through the engine that has the reference's LU
+    band = usable & (nobs >= k) & (nobs <= k + 1)
+    assert band.sum() >= 20
+    loosened = 0
+    for i in np.flatnonzero(band):
+        tol = bound(i)
+        loosened += tol > 1e-6
+        assert np.allclose(c_c[i], ref["coef"][i], rtol=tol, atol=tol), (i, int(nobs[i]), tol, c_c[i], ref["coef"][i])
+    assert loosened <= 0.2 * band.sum()                              # most k-row windows of a random frame are well enough conditioned for 1e-6
+    # the chunk engine reproduces the NaN pattern exactly (it has the LU, so a NaN is a row before min_periods)
+    assert np.array_equal(np.isnan(c_c), np.isnan(ref["coef"]))
+    # (ii) the default route
+    d_nan = np.isnan(d_c).any(axis=1)
+    assert not (d_nan & usable).any(), np.flatnonzero(d_nan & usable)[:10]
+    assert np.array_equal(d_nan[nobs >= k] | ~usable[nobs >= k], ~usable[nobs >= k])
+    for i in np.flatnonzero(usable & (nobs >= k)):
+        tol = bound(i)
+        assert np.allclose(d_c[i], ref["coef"][i], rtol=tol, atol=tol), (i, int(nobs[i]), tol)

@@ -218,3 +218,81 @@ def test_ridge_svd_honours_rcond_on_every_group(eng, dtype, rcond):
     assert list(st) == [1, 2, 1, 1, 1]                               # every non-empty group took the SVD pass
     for key in ("coef", "pred", "resid"):
         assert np.allclose(_np(out[key]), ref[key], rtol=tol, atol=tol), (key, float(np.abs(_np(out[key]) - ref[key]).max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,rows,add_intercept,weights,method", [
+    (8, (4, 4), False, False, None), (8, (1, 8), False, False, None), (8, (1, 9), True, True, None), (3, (1, 3), False, False, "svd"),
+    (8, (2, 30), False, True, "svd"), (12, (1, 12), True, False, None), (16, (5, 16), False, False, None), (20, (1, 20), False, True, None),
+    (31, (1, 31), False, False, None), (31, (20, 32), False, False, "svd"), (5, (1, 5), False, False, None),
+])
+def test_short_groups_take_the_team_min_norm_solver(eng, dtype, tol, k, rows, add_intercept, weights, method):
+    """K6s (k6s_small.hip): groups with no more rows than columns -- `solve_ols`'s own n <= k -> SVD branch (ls.rs:211-240,
+    tests/test_ols.py:272-312) -- and short groups under "svd", a sub-wave team per group instead of K6's pool.  Every group against the
+    oracle's dgelsd restatement; duplicated rows (rank below n) and an all-zero group included."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 131 + rows[1])
+    G = 3000
+    sizes = rng.integers(rows[0], rows[1] + 1, size=G)
+    sizes[5] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(c.astype(np.float64) for c in cols) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    big = np.flatnonzero(sizes >= 2)
+    g_dup, g_zero = int(big[0]), int(big[1])
+    for c in cols:                                                    # a duplicated row: rank n - 1; an all-zero group: beta = 0
+        c[offs[g_dup] + 1] = c[offs[g_dup]]
+        c[offs[g_zero]:offs[g_zero + 1]] = 0
+    y[offs[g_dup] + 1] = y[offs[g_dup]]
+    w = (0.5 + rng.random(N)).astype(dtype) if weights else None
+    kw = dict(add_intercept=add_intercept, solve_method=method)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
+                            want=("coef", "pred", "resid", "status"), **kw)
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, **kw)
+    kt = k + int(add_intercept)
+    st = _np(out["status"]).astype(int)
+    short = (sizes > 0) & (sizes < kt)
+    assert (st[short] == 1).all() and st[5] == 2                      # X'X singular -> fallback taken; the empty group
+    coef = _np(out["coef"])
+    # the comparison scale: a minimum-norm solution of a 4 x 8 system is O(1); near-singular square groups (n == kt) are compared
+    # through what they predict (the reference's own convention for ill-posed fits, tests/test_ols.py:355-360)
+    loose = sizes >= kt
+    assert np.allclose(coef[~loose], ref["coef"][~loose], rtol=tol, atol=tol), float(np.abs(coef[~loose] - ref["coef"][~loose]).max())
+    pred, resid = _np(out["pred"]), _np(out["resid"])
+    rowmask = np.repeat(~loose, sizes)
+    assert np.allclose(pred[rowmask], ref["pred"][rowmask], rtol=tol, atol=tol)
+    assert np.allclose(resid[rowmask], ref["resid"][rowmask], rtol=tol, atol=10 * tol if dtype == np.float32 else tol)
+    wellposed = loose & (st == 0)
+    if wellposed.any():
+        rm = np.repeat(wellposed, sizes)
+        assert np.allclose(pred[rm], ref["pred"][rm], rtol=1e-3, atol=1e-3)
+
+
+def test_short_groups_full_size_min_norm(eng):
+    """200 000 groups of 4 rows x 8 features (every one a minimum-norm problem) in one call, f32 and f64, every group
+    against numpy's batched pinv (dgelsd's answer for full-row-rank groups); must take milliseconds, not the fix-up pool's minutes."""
+    import time
+
+    import torch
+
+    G, n, k = 200_000, 4, 8
+    for dt, tol in ((torch.float64, 1e-6), (torch.float32, 1e-4)):
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        cols = [torch.randn(G * n, generator=gen, device="cuda", dtype=dt) for _ in range(k)]
+        y = sum(cols) + 0.1 * torch.randn(G * n, generator=gen, device="cuda", dtype=dt)
+        offs = np.arange(G + 1, dtype=np.int64) * n
+        out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
+        eng.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = eng.least_squares(y, cols, offs, want=("coef", "pred", "status"))
+        eng.synchronize(); torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.5
+        X = torch.stack(cols, dim=1).double().reshape(G, n, k).cpu().numpy()
+        Y = y.double().reshape(G, n).cpu().numpy()
+        exp = np.einsum("gkn,gn->gk", np.linalg.pinv(X), Y)
+        got = _np(out["coef"])
+        assert (_np(out["status"]) == 1).all()
+        assert np.allclose(got, exp, rtol=tol, atol=tol), float(np.abs(got - exp).max())
+        assert np.allclose(_np(out["pred"]).reshape(G, n), Y, rtol=10 * tol, atol=10 * tol)     # n < k: the fit interpolates
