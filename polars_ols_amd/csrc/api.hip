@@ -1642,8 +1642,12 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         const int k = kf;
         K4Args s4;
         std::memset(&s4, 0, sizeof(s4));
-        const int64_t minc = k > 128 ? hbm_state_chunk(b->n_rows) : 64;
-        if ((rc = build_chunk_tables(ctx, &ds.tables, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, minc, std::max<int64_t>(512, minc)))) return rc;
+        // 9..32 features: one wave per chunk with the covariance distributed over its registers (K3p, k4p_wide.hip).  A sequence of up to
+        // 1 024 rows is one chunk (the recursion starts from the prior: no totals, no scan); POLS_RLS_ENGINE=chunk keeps k4w_wide.hip.
+        const bool wave_p = wide && !xwide && ctx->opt.rls_engine != 3;
+        const int64_t pchunk = max_rows <= 1024 ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
+        const int64_t minc = wave_p ? pchunk : (k > 128 ? hbm_state_chunk(b->n_rows) : 64);
+        if ((rc = build_chunk_tables(ctx, &ds.tables, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, minc, wave_p ? pchunk : std::max<int64_t>(512, minc)))) return rc;
         s4.y = st.y; s4.valid = st.valid;
         if ((rc = upload_column_table(ctx, st, k, &s4))) return rc;
         s4.coef = st.coef; s4.pred = st.pred;
@@ -1651,7 +1655,9 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         s4.ff = a.forgetting_factor; s4.p0 = a.initial_state_covariance; s4.mean0 = a.mean0;
         if (wide) { s4.tot_cs = k * k + k + 1; s4.tot_qs = 1; }            // chunk-major for the wave / workgroup-per-chunk kernels
         else { s4.tot_cs = 1; s4.tot_qs = s4.n_chunks; }                   // component-major for the lane-per-chunk kernels
-        if ((rc = k > K4X_KMAX ? k3y_launch(ctx, b->dtype, s4) : xwide ? k3x_launch(ctx, b->dtype, s4) : (wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4)))) return rc;
+        if (wave_p) rc = k4p_launch(ctx, b->dtype, s4, true, max_rows <= pchunk);
+        else rc = k > K4X_KMAX ? k3y_launch(ctx, b->dtype, s4) : xwide ? k3x_launch(ctx, b->dtype, s4) : (wide ? k3sw_launch(ctx, b->dtype, s4) : k3s_launch(ctx, b->dtype, s4));
+        if (rc) return rc;
     } else {
         if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
     }
@@ -1888,8 +1894,13 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     }
     K4Args a;
     std::memset(&a, 0, sizeof(a));
-    const int64_t minc = k > 128 ? hbm_state_chunk(b->n_rows) : 64;
-    if ((rc = build_chunk_tables(ctx, &ds.tables, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, minc, std::max<int64_t>(512, minc)))) return rc;
+    // 9..32 features on a null-free frame, min_periods <= window: one wave per chunk, the inverse distributed over its registers and the
+    // sums kept beside it (K4p, k4p_wide.hip).  A sequence of up to 1 024 rows is one chunk; a chunk of a longer one re-sums the rows of the
+    // window in front of it, so cut sequences need a window of at most 1 024 rows.  POLS_ROLLING_ENGINE=chunk keeps k4w_wide.hip.
+    const int64_t pchunk = max_rows <= 1024 ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
+    const bool wave_p = wide && !xwide && st.valid == nullptr && mp <= w && (max_rows <= pchunk || w <= 1024) && ctx->opt.rolling_engine != 1;
+    const int64_t minc = wave_p ? pchunk : (k > 128 ? hbm_state_chunk(b->n_rows) : 64);
+    if ((rc = build_chunk_tables(ctx, &ds.tables, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, minc, wave_p ? pchunk : std::max<int64_t>(512, minc)))) return rc;
     a.y = st.y; a.valid = st.valid;
     if ((rc = upload_column_table(ctx, st, k, &a))) return rc;
     a.coef = st.coef; a.pred = st.pred;
@@ -1897,7 +1908,9 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     a.k = k; a.drop_mode = drop ? 1 : 0;
     if (wide) { a.tot_cs = k * k + k; a.tot_qs = 1; }
     else { a.tot_cs = 1; a.tot_qs = a.n_chunks; }
-    if ((rc = k > K4X_KMAX ? k4y_launch(ctx, b->dtype, a) : xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a)))) return rc;
+    if (wave_p) rc = k4p_launch(ctx, b->dtype, a, false, max_rows <= pchunk);
+    else rc = k > K4X_KMAX ? k4y_launch(ctx, b->dtype, a) : xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a));
+    if (rc) return rc;
     if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, k, o, st);
 }

@@ -59,6 +59,9 @@ int k3s_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 // 9..32 features: one wave per chunk, state in LDS (k4w_wide.hip).  Totals rows are k*k + k (+ 1 for the RLS decay) doubles.
 int k4w_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3sw_launch(pols_ctx *ctx, int dtype, const K4Args &a);
+// 9..32 features, one wave per chunk, the inverse / covariance distributed over the wave's registers (k4p_wide.hip): RLS (any validity
+// mask) and rolling OLS on null-free frames with min_periods <= window.  single_chunk: no sequence was cut into several chunks.
+int k4p_launch(pols_ctx *ctx, int dtype, const K4Args &a, bool rls, bool single_chunk);
 // 33..128 features: one workgroup per chunk, the inverse propagated in LDS (k4x_inverse.hip).  Totals rows as for k4w.
 int k4x_launch(pols_ctx *ctx, int dtype, const K4Args &a);
 int k3x_launch(pols_ctx *ctx, int dtype, const K4Args &a);

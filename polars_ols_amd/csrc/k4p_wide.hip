@@ -1,0 +1,455 @@
+// k4p_wide.hip -- K4p / K3p: rolling OLS and RLS for 11..32 features, ONE WAVE PER CHUNK, the INVERSE distributed over the wave's registers.
+//
+// Replaces solve_rolling_ols (src/least_squares.rs:848-1032) on null-free frames and solve_recursive_least_squares (:568-598, validity
+// mask included) + the dynamic make_predictions (src/expressions.rs:184) at the widths where a lane can no longer hold a state of its own
+// (K3c / K4c stop at 10 features).  The wave-per-chunk kernels of k4w_wide.hip that used to take these widths handle ONE row at a time
+// through dependent global loads, an LDS Cholesky with a wave barrier per elimination step and a second load for the prediction --
+// 15-30 k cycles per row, 39-44 ms per 10 M rows at 12 features (profiles/r04_bench_dyn_edges.txt).  Here:
+//   * rows arrive 32 at a time: lane l loads row i0 + l of every column (coalesced down the row axis; lanes 32-63 load the rows that
+//     LEAVE the window), converted to f64 and parked row-major in LDS, from where every row is read back with broadcast 16-byte reads;
+//   * the state is P = (X'X)^-1 (rolling) or the RLS covariance, KP x KP padded (KP = 16 or 32), lane (r, seg) holding the CPL = KP^2 / 64
+//     entries P[r][seg CPL ..] in registers.  A row costs O(K^2): z = P x is CPL multiply-adds per lane and a 1-2 step cross-segment
+//     sum (`v_permlane16/32_swap`), x'z and x'beta one DPP row all-reduce each, z changes hands through a KP-double LDS slot, and
+//     P -= g z z' is CPL more.  RLS is the reference's update literally (:531-540); rolling applies Sherman-Morrison for the row that
+//     enters and the row that leaves -- what the reference's own WoodburyState does beyond 60 features (:737-787) -- with beta updated
+//     incrementally (beta += g z (y - x'beta));
+//   * the information form (X'X, X'y) is kept NEXT to the inverse (rolling: the same lanes, CPL registers), exactly as
+//     NonWoodburyState::update accumulates it (:707-725).  While a window is young (the first solves of a sequence, where X'X is
+//     nearly singular) every row INVERTS it afresh (symmetric sweep operator, one pivot row broadcast through LDS per step: K steps);
+//     the inverse is only propagated once a factorisation's smallest pivot ratio says the window is well conditioned, is rebuilt from
+//     the sums every 128 rows and at every chunk start, and is dropped again whenever a downdate's denominator collapses -- so rounding
+//     never accumulates beyond 128 rows and an ill-conditioned window is always solved from the sums, like the reference does;
+//   * a non-positive pivot (fewer than K independent rows in the window) yields NaN where the reference's LU fallback returns
+//     inf / NaN / 1e15-sized numbers (the K4c divergence, include/pols_mi355x.h);
+//   * coefficients leave one row per store instruction (K consecutive values), predictions 32 rows at a time.
+// Chunks: a sequence of up to 1 024 rows is ONE chunk (no totals, no scan: the state at a sequence start is the prior / empty);
+// longer sequences are cut, an RLS chunk starts from the scanned decayed sums (kp_totals + chunk_scan_launch mode 2, inverted once),
+// a rolling chunk re-sums the min(window, rel0) rows in front of it (windows up to 1 024 rows; beyond that only single-chunk
+// sequences come here).  Everything else (validity masks under rolling, min_periods > window) stays with k4w_wide.hip.
+#include "k4_rolling.hpp"
+
+// No implicit contraction in this file: `v += dpp(v)` behind `v = x * z` was fused into fl(partner's product) + (own product, unrounded),
+// which gives the two lanes of a pair sums that differ in the last bit -- x'Px then differs from lane to lane, the rank-1 term loses its
+// exact symmetry, and the antisymmetric residue of P grows by 1 / ff per row (half_life 21: 2e14 over 1 000 rows).  Every multiply-add
+// that should be fused is an explicit fma().
+#pragma clang fp contract(off)
+
+namespace pols {
+
+constexpr int KP_RB = 32;              // rows staged per block
+constexpr int KP_REFRESH = 128;        // rolling: rows between two rebuilds of the inverse from the sums
+constexpr double KP_SWITCH_RATIO = 1e-4;   // propagate the inverse only from a factorisation whose smallest pivot / diagonal exceeds this
+
+__device__ __forceinline__ double kp_xor32_add(double v) {     // v(l) + v(l ^ 32)
+    const unsigned long long b = __double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ double kp_xor16_add(double v) {     // v(l) + v(l ^ 16)
+    const unsigned long long b = __double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+// sum over the segments (lanes with the same row index r = lane % KP)
+template <int KP> __device__ __forceinline__ double kp_segsum(double v) {
+    asm volatile("" : "+v"(v));
+    if constexpr (KP == 16) v = kp_xor16_add(v);
+    return kp_xor32_add(v);
+}
+// sum over the KP row indices of a segment (every lane gets the total)
+template <int KP> __device__ __forceinline__ double kp_rowsum(double v) {
+    asm volatile("" : "+v"(v));                    // (the product is rounded before it is shared: every lane ends with the same bits)
+    v = row_allreduce(v);
+    if constexpr (KP == 32) v = kp_xor16_add(v);
+    return v;
+}
+__device__ __forceinline__ void kp_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int KP>
+struct KpGeo {
+    static constexpr int CPL = KP * KP / 64;       // matrix entries per lane: 4 (KP = 16) or 16 (KP = 32)
+    static constexpr int XS = KP + 2;              // staged row: KP features (zero padded), the target, one pad (16-byte rows)
+};
+
+// One row of the staging area in registers: the lane's CPL features of its segment, feature r, the target.
+template <int KP>
+struct KpRow {
+    double xc[KpGeo<KP>::CPL], xr, y;
+    __device__ __forceinline__ void load(const double *row, int r, int c0) {
+        constexpr int CPL = KpGeo<KP>::CPL;
+#pragma unroll
+        for (int cc = 0; cc < CPL; cc += 2) {
+            const double2 t = *reinterpret_cast<const double2 *>(row + c0 + cc);
+            xc[cc] = t.x; xc[cc + 1] = t.y;
+        }
+        xr = row[r];
+        y = row[KP];
+    }
+};
+
+template <typename T, int KP>
+struct KpCtx {
+    static constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
+    const K4Args &a;
+    const int K, lane, r, seg, c0;
+    double *xin, *xout, *zb, *rowbuf, *diag;
+    __device__ KpCtx(const K4Args &a_, double *lds)
+        : a(a_), K(a_.k), lane(threadIdx.x), r(threadIdx.x % KP), seg(threadIdx.x / KP), c0((threadIdx.x / KP) * CPL) {
+        xin = lds; xout = xin + KP_RB * XS; zb = xout + KP_RB * XS; rowbuf = zb + KP; diag = rowbuf + KP;
+    }
+    static constexpr size_t lds_doubles() { return 2 * (size_t)KP_RB * XS + 3 * KP; }
+
+    // rows [i_in, i_in + KP_RB) of the sequence starting at absolute row s -> xin (lanes 0..31), rows [i_out, ...) -> xout (lanes 32..63);
+    // rows outside [lo, hi) are staged as zero rows.  Returns the ballot of the validity bytes of the entering rows.
+    __device__ __forceinline__ unsigned long long stage(int64_t s, int64_t i_in, int64_t i_out, int64_t lo, int64_t hi, bool with_out) const {
+        const int t = lane & 31;
+        const bool outl = lane >= 32;
+        const int64_t i = (outl ? i_out : i_in) + t;
+        const bool on = (!outl || with_out) && i >= lo && i < hi;
+        double *dst = (outl ? xout : xin) + t * XS;
+        bool v = false;
+        if (on) {
+#pragma unroll 4
+            for (int j = 0; j < K; ++j) dst[j] = (double)static_cast<const T *>(a.x[j])[s + i];
+            dst[KP] = (double)static_cast<const T *>(a.y)[s + i];
+            v = outl ? false : (a.valid ? a.valid[s + i] != 0 : true);
+        } else if (!outl || with_out) {
+            for (int j = 0; j < K; ++j) dst[j] = 0.0;
+            dst[KP] = 0.0;
+        }
+        const unsigned long long m = __ballot(v);
+        kp_sync();
+        return m;
+    }
+    __device__ __forceinline__ void zero_pads() const {             // features K .. KP - 1 of every staged row are zero, once
+        for (int q = lane; q < 2 * KP_RB * XS; q += 64) xin[q] = 0.0;
+        kp_sync();
+    }
+    // every lane gets the CPL entries v[c0 ..] of a vector held one entry per row index (lanes of segment 0 publish)
+    __device__ __forceinline__ void bcast(double vr, double (&vc)[CPL]) const {
+        if (seg == 0) zb[r] = vr;
+        kp_sync();
+#pragma unroll
+        for (int cc = 0; cc < CPL; cc += 2) {
+            const double2 t = *reinterpret_cast<const double2 *>(zb + c0 + cc);
+            vc[cc] = t.x; vc[cc + 1] = t.y;
+        }
+        kp_sync();
+    }
+    // M (symmetric, this lane's CPL entries of row r) -> its inverse, by K steps of the symmetric sweep operator; the pivot row travels
+    // through LDS.  ok: every pivot positive; ratio: the smallest pivot / its diagonal entry (how much of the diagonal survives).
+    __device__ __forceinline__ void invert(double (&M)[CPL], bool &ok, double &ratio) const {
+        double dg = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) dg = (c0 + cc == r) ? M[cc] : dg;
+        if (r >= c0 && r < c0 + CPL) diag[r] = dg;
+        ok = true; ratio = 1.0;
+        for (int j = 0; j < K; ++j) {
+            if (r == j) {
+#pragma unroll
+                for (int cc = 0; cc < CPL; cc += 2) *reinterpret_cast<double2 *>(rowbuf + c0 + cc) = double2{M[cc], M[cc + 1]};
+            }
+            kp_sync();
+            double vc[CPL];
+#pragma unroll
+            for (int cc = 0; cc < CPL; cc += 2) {
+                const double2 t = *reinterpret_cast<const double2 *>(rowbuf + c0 + cc);
+                vc[cc] = t.x; vc[cc + 1] = t.y;
+            }
+            const double vr = rowbuf[r], pj = rowbuf[j], dj = diag[j];
+            kp_sync();
+            ok = ok && (pj > 0.0);
+            ratio = fmin(ratio, pj / dj);
+            const double p = 1.0 / pj, vrp = vr * p;
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+                double val = fma(-(vr * vc[cc]), p, M[cc]);                // (v_r v_c first: the result is exactly symmetric)
+                val = (r == j) ? vc[cc] * p : val;
+                val = (c0 + cc == j) ? ((r == j) ? -p : vrp) : val;
+                M[cc] = val;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) M[cc] = -M[cc];
+        ok = ok && (ratio == ratio);
+    }
+    // (P b)_r for a vector b held one entry per row index
+    __device__ __forceinline__ double matvec(const double (&P)[CPL], double br) const {
+        double bc[CPL];
+        bcast(br, bc);
+        double acc = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) acc = fma(P[cc], bc[cc], acc);
+        return kp_segsum<KP>(acc);
+    }
+    // coefficient row / prediction of relative row i (beta one entry per row index; `good` false -> NaN)
+    __device__ __forceinline__ void store_coef(int64_t row, double beta, bool good) const {
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        if (a.coef && seg == 0 && r < K) static_cast<T *>(a.coef)[row * K + r] = (T)(good ? beta : qnan);
+    }
+};
+
+// ------------------------------------------------------------------ RLS: per-chunk decayed sums (only for sequences cut into chunks)
+template <typename T, int KP>
+__global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
+    constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
+    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP>::lds_doubles()];
+    const int64_t c = blockIdx.x;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    KpCtx<T, KP> cx(a, lds);
+    const int K = cx.K;
+    cx.zero_pads();
+    double S[CPL], b = 0.0, decay = 1.0;
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) S[cc] = 0.0;
+    const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
+    for (int64_t i0 = rel0; i0 < rel1; i0 += KP_RB) {
+        const unsigned long long vm = cx.stage(G.start, i0, 0, rel0, rel1, false);
+        const int nb = (int)min((int64_t)KP_RB, rel1 - i0);
+        for (int t = 0; t < nb; ++t) {
+            if (!((vm >> t) & 1)) continue;
+            KpRow<KP> x;
+            x.load(cx.xin + t * XS, cx.r, cx.c0);
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], a.ff * S[cc]);
+            b = fma(x.xr, x.y, a.ff * b);
+            decay *= a.ff;
+        }
+        kp_sync();
+    }
+    double *out = a.totals + (size_t)c * a.tot_cs;
+    if (cx.r < K) {
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc)
+            if (cx.c0 + cc < K) out[cx.r * K + cx.c0 + cc] = S[cc];
+        if (cx.seg == 0) out[K * K + cx.r] = b;
+    }
+    if (cx.lane == 0) out[K * K + K] = decay;
+}
+
+// ------------------------------------------------------------------ RLS walk (RecursiveLeastSquares::update, literally)
+template <typename T, int KP>
+__global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
+    constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
+    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP>::lds_doubles()];
+    const int64_t c = blockIdx.x;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    KpCtx<T, KP> cx(a, lds);
+    const int K = cx.K, r = cx.r, c0 = cx.c0;
+    const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
+    cx.zero_pads();
+    double P[CPL], beta;
+    if (rel0 == 0) {                                               // :505-529: P = p0 I, beta = initial_state_mean
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) P[cc] = (c0 + cc == r && r < K) ? a.p0 : 0.0;
+        beta = (r < K && a.mean0) ? a.mean0[r] : 0.0;
+    } else {                                                       // the scanned information state entering this chunk (prior included)
+        const double *tot = a.totals + (size_t)c * a.tot_cs;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) P[cc] = (r < K && c0 + cc < K) ? tot[r * K + c0 + cc] : 0.0;
+        const double br = r < K ? tot[K * K + r] : 0.0;
+        bool ok; double ratio;
+        cx.invert(P, ok, ratio);
+        beta = cx.matvec(P, br);
+    }
+    const double ff = a.ff, iff = 1.0 / a.ff;
+    for (int64_t i0 = rel0; i0 < rel1; i0 += KP_RB) {
+        const unsigned long long vm = cx.stage(G.start, i0, 0, rel0, rel1, false);
+        const int nb = (int)min((int64_t)KP_RB, rel1 - i0);
+        double predv = 0.0;
+        for (int t = 0; t < nb; ++t) {
+            KpRow<KP> x;
+            x.load(cx.xin + t * XS, r, c0);
+            if ((vm >> t) & 1) {
+                double zp = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
+                const double z = kp_segsum<KP>(zp);                        // (P x)_r
+                const double d = kp_rowsum<KP>(x.xr * z), xb = kp_rowsum<KP>(x.xr * beta);
+                const double rr = 1.0 + d / ff;                            // :533
+                const double g = 1.0 / (rr * ff);
+                const double kk = z * g;                                   // gain_r (:534)
+                beta = fma(kk, x.y - xb, beta);                            // :536-537
+                // P / ff - k k' r (:538-539).  The product k_r k_c is formed FIRST: it is bitwise the same for (r, c) and (c, r), so P stays
+                // exactly symmetric like the reference's (an antisymmetric rounding residue grows by 1 / ff per row: 2e14 over 1 000 rows
+                // at half_life 21)
+                double kc[CPL];
+                cx.bcast(kk, kc);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) P[cc] = fma(-(kk * kc[cc]), rr, P[cc] * iff);
+            }
+            cx.store_coef(G.start + i0 + t, beta, true);
+            const double p = kp_rowsum<KP>(x.xr * beta);
+            predv = (cx.lane == t) ? p : predv;
+        }
+        if (a.pred && cx.lane < nb) static_cast<T *>(a.pred)[G.start + i0 + cx.lane] = (T)predv;
+        kp_sync();
+    }
+}
+
+// ------------------------------------------------------------------ rolling walk (null-free frames, min_periods <= window)
+template <typename T, int KP>
+__global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
+    constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
+    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP>::lds_doubles()];
+    const int64_t c = blockIdx.x;
+    const K4Chunk ch = a.chunks[c];
+    const K4Group G = a.groups[ch.group];
+    KpCtx<T, KP> cx(a, lds);
+    const int K = cx.K, r = cx.r, c0 = cx.c0;
+    const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start, n = G.end - G.start;
+    const int64_t w = a.window, mpv = G.mpv;
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    if (G.all_nan) {                                               // :893-900
+        for (int64_t i = rel0; i < rel1; ++i) {
+            cx.store_coef(G.start + i, 0.0, false);
+            if (a.pred && cx.lane == 0) static_cast<T *>(a.pred)[G.start + i] = (T)qnan;
+        }
+        return;
+    }
+    cx.zero_pads();
+    double S[CPL], P[CPL], bsum = 0.0, beta = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CPL; ++cc) { S[cc] = 0.0; P[cc] = 0.0; }
+    // the sums after row rel0 - 1: the last min(window, rel0) rows in front of the chunk (+ alpha I once the warm-up row has passed, :924-926)
+    for (int64_t j0 = max((int64_t)0, rel0 - w); j0 < rel0; j0 += KP_RB) {
+        cx.stage(G.start, j0, 0, 0, rel0, false);
+        const int nb = (int)min((int64_t)KP_RB, rel0 - j0);
+        for (int t = 0; t < nb; ++t) {
+            KpRow<KP> x;
+            x.load(cx.xin + t * XS, r, c0);
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
+            bsum = fma(x.xr, x.y, bsum);
+        }
+        kp_sync();
+    }
+    if (rel0 - 1 >= mpv - 1 && a.alpha != 0.0) {
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) S[cc] += (c0 + cc == r && r < K) ? a.alpha : 0.0;
+    }
+    bool inverted = false;
+    int since = 0;
+    // A window that can never hold 2 K rows is re-inverted on every row (it is never far from singular)
+    const bool may_propagate = w >= 2 * (int64_t)K;
+    for (int64_t i0 = rel0; i0 < rel1; i0 += KP_RB) {
+        cx.stage(G.start, i0, i0 - w, 0, n, i0 + KP_RB > w);
+        const int nb = (int)min((int64_t)KP_RB, rel1 - i0);
+        double predv = 0.0;
+        for (int t = 0; t < nb; ++t) {
+            const int64_t i = i0 + t;
+            KpRow<KP> x;
+            x.load(cx.xin + t * XS, r, c0);
+            // ---- the row enters (NonWoodburyState::update, :707-725)
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
+            bsum = fma(x.xr, x.y, bsum);
+            if (inverted) {
+                double zp = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
+                const double z = kp_segsum<KP>(zp);
+                const double d = kp_rowsum<KP>(x.xr * z), xb = kp_rowsum<KP>(x.xr * beta);
+                const double g = 1.0 / (1.0 + d);
+                beta = fma(g * z, x.y - xb, beta);
+                double zc[CPL];
+                cx.bcast(z, zc);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) P[cc] = fma(-(z * zc[cc]), g, P[cc]);   // (z_r z_c first: P stays exactly symmetric)
+            }
+            // ---- row i - window leaves
+            if (i >= w) {
+                KpRow<KP> o;
+                o.load(cx.xout + t * XS, r, c0);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(-o.xr, o.xc[cc], S[cc]);
+                bsum = fma(-o.xr, o.y, bsum);
+                if (inverted) {
+                    double zp = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], o.xc[cc], zp);
+                    const double z = kp_segsum<KP>(zp);
+                    const double d = kp_rowsum<KP>(o.xr * z), xb = kp_rowsum<KP>(o.xr * beta);
+                    const double den = 1.0 - d;
+                    if (!(den > 1e-6)) inverted = false;                   // the downdate collapses: back to the sums (wave-uniform)
+                    else {
+                        const double g = 1.0 / den;
+                        beta = fma(-g * z, o.y - xb, beta);
+                        double zc[CPL];
+                        cx.bcast(z, zc);
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) P[cc] = fma(z * zc[cc], g, P[cc]);
+                    }
+                }
+            }
+            if (i == mpv - 1 && a.alpha != 0.0) {                          // alpha enters once, at the warm-up (:924-926)
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) S[cc] += (c0 + cc == r && r < K) ? a.alpha : 0.0;
+                inverted = false;
+            }
+            bool good = false;
+            double bout = 0.0;
+            if (i >= mpv - 1) {
+                ++since;
+                if (!inverted || since >= KP_REFRESH) {
+                    double M[CPL];
+#pragma unroll
+                    for (int cc = 0; cc < CPL; ++cc) M[cc] = S[cc];
+                    bool ok; double ratio;
+                    cx.invert(M, ok, ratio);
+                    const double bnew = cx.matvec(M, bsum);
+                    good = ok; bout = bnew;
+                    inverted = ok && may_propagate && ratio > KP_SWITCH_RATIO;
+                    if (inverted) {
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) P[cc] = M[cc];
+                        beta = bnew;
+                        since = 0;
+                    }
+                } else {
+                    good = true; bout = beta;
+                }
+            }
+            cx.store_coef(G.start + i, bout, good);
+            const double p = kp_rowsum<KP>(x.xr * bout);
+            predv = (cx.lane == t) ? (good ? p : qnan) : predv;
+        }
+        if (a.pred && cx.lane < nb) static_cast<T *>(a.pred)[G.start + i0 + cx.lane] = (T)predv;
+        kp_sync();
+    }
+}
+
+template <typename T, int KP>
+static int kp_launch_kp(pols_ctx *ctx, const K4Args &a, bool rls, bool single_chunk) {
+    timing_begin(ctx);
+    if (rls) {
+        if (!single_chunk) {
+            hipLaunchKernelGGL((kp_totals_kernel<T, KP>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+            chunk_scan_launch(ctx, a, a.k * a.k + a.k, 2);
+        }
+        hipLaunchKernelGGL((kp_rls_walk_kernel<T, KP>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+    }
+    timing_end(ctx);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+// single_chunk: no sequence was cut (every chunk starts its sequence).  Rolling: the frame is null-free, min_periods <= window, and
+// window <= KP_MAX_DIRECT_WINDOW unless single_chunk (the caller checks).
+int k4p_launch(pols_ctx *ctx, int dtype, const K4Args &a, bool rls, bool single_chunk) {
+    if (a.k > 32 || a.k < 1) return fail(POLS_ERR_UNSUPPORTED, "k4p: %d features", a.k);
+    if (a.n_chunks <= 0) return POLS_OK;
+    ctx->last_kernel = std::string(rls ? "k3p_rls_inverse_wave" : "k4p_rolling_inverse_wave") + (dtype == POLS_F32 ? "_f32" : "_f64");
+    if (a.k <= 16) return dtype == POLS_F32 ? kp_launch_kp<float, 16>(ctx, a, rls, single_chunk) : kp_launch_kp<double, 16>(ctx, a, rls, single_chunk);
+    return dtype == POLS_F32 ? kp_launch_kp<float, 32>(ctx, a, rls, single_chunk) : kp_launch_kp<double, 32>(ctx, a, rls, single_chunk);
+}
+
+}  // namespace pols

@@ -34,15 +34,21 @@ __device__ __forceinline__ double k6s_team_max(double v) {
 
 template <typename T, int TEAM, int KTB>
 __global__ void __launch_bounds__(256) k6s_kernel(const K6Args a) {
-    if (a.fb_flag && *a.fb_flag != a.epoch) return;               // nothing was flagged in this call
+    // solve_method = None picks the SVD BY SHAPE (ls.rs:224-231: "n > k ? QR : SVD"), so a group with fewer rows than columns comes here
+    // whether or not its Cholesky noticed: in f32 the last pivot of a rank-deficient Gram matrix can come out as positive noise above the
+    // flagging threshold (one group in 2 600 in tests/test_k6_gpu.py) -- the reference never factors such a group at all.
+    const bool by_shape = a.mode == FIX_OLS_AUTO || a.mode == FIX_MINNORM;   // ("svd": the SVD on every group -- K1's Cholesky answer stands in for it only at full column rank)
+    if (!by_shape && a.fb_flag && *a.fb_flag != a.epoch) return;  // nothing was flagged in this call
     const int tix = threadIdx.x, lane = tix & 63, sub = lane % TEAM, team0 = lane - sub;
     const int kt = a.kt, ku = a.k_user, pol = a.null_policy;
     const int64_t g = (int64_t)blockIdx.x * (256 / TEAM) + tix / TEAM;
     int64_t s = 0, e = 0;
     bool live = g < a.n_groups;
-    if (live) { s = a.offs[g]; e = a.offs[g + 1]; live = a.status[g] == POLS_GROUP_FALLBACK; }
+    bool flagged = false;
+    if (live) { s = a.offs[g]; e = a.offs[g + 1]; flagged = a.status[g] == POLS_GROUP_FALLBACK; }
     const int64_t n = e - s;
-    live = live && k6s_takes(a.mode, n, kt, a.small_rows);
+    const bool shaped = by_shape && n > 0 && n <= (int64_t)kt;    // n < kt: singular by construction; n == kt: the reference still takes the SVD
+    live = live && (flagged || shaped) && k6s_takes(a.mode, n, kt, a.small_rows);
     if (!__any(live)) return;                                      // (wave-uniform; from here on every lane stays active: the shuffles need them)
 
     // ---- lane `sub` = data row s + sub: kt features and the target, sqrt(w)-scaled; dropped rows and lanes beyond the group: zero rows
@@ -118,7 +124,9 @@ __global__ void __launch_bounds__(256) k6s_kernel(const K6Args a) {
         beta[j] = nfit == 0.0 ? 0.0 : bj;
     }
     if (live) {
-        if (nfit == 0.0 && sub == 0) a.status[g] = POLS_GROUP_EMPTY;   // every row dropped by the null policy: zeros, like an empty group
+        // (a square group that factored keeps its status: nothing failed, it only gets the solver the reference runs on it)
+        if (sub == 0 && (nfit == 0.0 || (!flagged && n < (int64_t)kt)))   // every row dropped by the null policy: zeros, like an empty group
+            a.status[g] = nfit == 0.0 ? POLS_GROUP_EMPTY : POLS_GROUP_FALLBACK;
         if (a.coef) {
 #pragma unroll
             for (int j = 0; j < KTB; ++j)

@@ -24,7 +24,7 @@ def timed(fn, reps=5):
     return 1e3 * (time.perf_counter() - t0) / reps
 
 
-for k in (6, 7, 8, 12):
+for k in [int(v) for v in os.environ.get('KS', '6,7,8,12').split(',')]:
     gen = torch.Generator(device="cuda").manual_seed(3)
     cols = [torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64) for _ in range(k)]
     y = sum(cols) + 0.1 * torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64)

@@ -68,7 +68,8 @@ def test_rls_many_groups(eng, rls_engine, dtype, tol, k, half_life, p0, mean):
 @pytest.mark.parametrize("k", [9, 10, 16, 32])
 @pytest.mark.parametrize("half_life,p0,mean", [(None, 10.0, None), (252.0, 1.0, 0.25)])
 def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
-    """9..32 features: 9 and 10 on the row-parallel kernel, 11+ on the wave-per-chunk scan (k4w_wide.hip), several chunks per sequence, invalid rows."""
+    """9..32 features: 9 and 10 on the row-parallel kernel, 11+ on the wave-per-chunk P-form kernel (k4p_wide.hip), several chunks per sequence
+    (decayed totals + scan + one inversion per chunk start), invalid rows."""
     from oracle import orc
 
     rng = np.random.default_rng(100 + k)
@@ -85,7 +86,7 @@ def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
                                       initial_state_covariance=p0, initial_state_mean=mean0)
     ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0,
                           is_valid=valid)
-    assert eng.last_kernel.startswith("k3s_rls_rows" if k <= 10 else "k3sw_")    # (up to 10 features fit the row-parallel kernel)
+    assert eng.last_kernel.startswith("k3s_rls_rows" if k <= 10 else "k3p_")     # (up to 10 features fit the row-parallel kernel; beyond: k4p_wide.hip)
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
     assert np.allclose(_np(out["pred"]), _masked(ref["pred"], valid), rtol=tol, atol=tol, equal_nan=True)
 
@@ -250,3 +251,37 @@ def test_rls_more_than_64_blocks_of_tiles(eng):
     ref = orc.batched_rls(y, cols, offs, half_life=2000.0)
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,half_life,p0,mean,null_frac", [(11, 21.0, 10.0, None, 0.0), (12, None, 1e6, None, 0.0), (16, 63.0, 10.0, 0.5, 0.05),
+                                                           (17, 21.0, 10.0, None, 0.2), (24, None, 10.0, None, 0.0), (32, 100.0, 1.0, 0.1, 0.1)])
+def test_rls_wave_per_chunk_single_chunk_sequences(eng, dtype, tol, k, half_life, p0, mean, null_frac):
+    """K3p (k4p_wide.hip) on the `.rls().over(group)` shape: no sequence longer than 1 024 rows, so every sequence is ONE chunk that runs
+    the reference's recursion from the prior (no totals, no scan) -- both padded widths (16, 32), a diffuse prior (p0 = 1e6, the reference's
+    own test setting tests/test_ols.py:633-681), validity masks, empty and one-row sequences, every row against the oracle; the same frame
+    through the old wave-per-chunk kernels (POLS_RLS_ENGINE=chunk) must agree."""
+    from oracle import orc
+
+    rng = np.random.default_rng(500 + k)
+    sizes = np.concatenate([[1024, 0, 1, 2, k - 1, k, k + 1, 33, 64, 1000], rng.integers(1, 700, size=30)])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(cols).astype(np.float64) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    valid = (rng.random(N) >= null_frac).astype(np.uint8) if null_frac > 0 else None
+    mean0 = None if mean is None else [mean] * k
+    kw = dict(half_life=half_life, initial_state_covariance=p0, initial_state_mean=mean0)
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid), **kw)
+    assert eng.last_kernel.startswith("k3p_")
+    ref = orc.batched_rls(y, cols, offs, is_valid=valid, **kw)
+    got_c, got_p = _np(out["coef"]), _np(out["pred"])
+    assert np.allclose(got_c, ref["coef"], rtol=tol, atol=tol), float(np.abs(got_c - ref["coef"]).max())
+    assert np.allclose(got_p, _masked(ref["pred"], valid) if valid is not None else ref["pred"], rtol=tol, atol=tol, equal_nan=True)
+    eng.set_option("RLS_ENGINE", "chunk")
+    try:
+        old = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid), **kw)
+        assert eng.last_kernel.startswith("k3sw_")
+    finally:
+        eng.set_option("RLS_ENGINE", None)
+    assert np.allclose(_np(old["coef"]), got_c, rtol=tol, atol=tol)
