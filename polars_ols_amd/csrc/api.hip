@@ -1799,7 +1799,11 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     // (dyn_prep.hip: slab counts, scan, scatter), the tile kernel runs on them, and an expansion pass forward-fills the coefficients
     // onto the original rows and predicts them.  Not taken when a non-empty group holds fewer valid rows than min_periods (the
     // reference then solves a window it never filled, :881-900 -- the lane-per-chunk kernels below reproduce that).
-    bool tiles_c = !tiles && drop && st.valid != nullptr && k <= K4C_KMAX && mp <= w && (w <= k4c_max_window(k) || max_rows <= K4C_PACKED_ROWS - 3) &&
+    // (11..32 features, and 9 / 10 where the tile kernel's window / alignment conditions fail: the same compaction in front of the
+    // wave-per-chunk kernel K4p, k4p_wide.hip)
+    const bool c_tiles_ok = k <= K4C_KMAX && (w <= k4c_max_window(k) || max_rows <= K4C_PACKED_ROWS - 3);
+    const bool c_wave_ok = k > K4_KMAX && k <= POLS_MAX_FEATURES && (w <= 1024 || max_rows <= 1024);
+    bool tiles_c = !tiles && drop && st.valid != nullptr && mp <= w && (c_tiles_ok || c_wave_ok) &&
                    ctx->opt.rolling_engine != 1 && ctx->opt.rolling_engine != 3 && b->n_rows >= 8;
     if (tiles_c) {
         const int64_t N = b->n_rows, G = b->n_groups, n_slabs = (N + 255) / 256;
@@ -1846,6 +1850,29 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
             if ((rc = row_compact_scatter_launch(ctx, b->dtype, ra))) return rc;
             void *dc = nullptr, *df = nullptr, *dm = nullptr;
             if ((rc = ensure_scratch(ctx, 20, round256(sz * (size_t)Nc * (size_t)k), &dc))) return rc;
+            if (!c_tiles_ok) {
+                // the compacted frame through K4p: chunk tables of the COMPACTED offsets (never cached: two null patterns of one frame can
+                // share every key the cache compares)
+                pols_batch cb = *b;
+                cb.group_offsets = c_offs.data(); cb.n_rows = Nc; cb.valid = nullptr;
+                const int64_t pchunk = max_c <= 1024 ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, Nc / 16384));
+                K4Args a;
+                std::memset(&a, 0, sizeof(a));
+                ctx->chunk_cache.tab = nullptr;
+                if ((rc = build_chunk_tables(ctx, &cb, mp, k * k + k, &a, pchunk, pchunk))) return rc;
+                ctx->chunk_cache.tab = nullptr;
+                a.y = outp[0];
+                for (int j = 0; j < k; ++j) a.x[j] = outp[(size_t)j + 1];
+                a.coef = dc; a.pred = nullptr;
+                a.window = w; a.alpha = p->alpha > 0.0 ? p->alpha : 0.0; a.k = k; a.drop_mode = 1;
+                a.tot_cs = k * k + k; a.tot_qs = 1;
+                if ((rc = k4p_launch(ctx, b->dtype, a, false, max_c <= pchunk))) return rc;
+                ra.coef_c = dc; ra.coef = st.coef; ra.pred = st.pred;
+                if ((rc = row_compact_expand_launch(ctx, b->dtype, ra))) return rc;
+                ctx->last_kernel += "_compacted";
+                if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+                return unstage_outputs(ctx, b, b->n_rows, k, o, st);
+            }
             if ((rc = ensure_scratch(ctx, 21, round256((size_t)Nc + 4), &df))) return rc;
             if ((rc = k3c_start_flags(ctx, ra.c_offs, G, Nc, static_cast<uint8_t *>(df)))) return rc;
             K4cArgs c;

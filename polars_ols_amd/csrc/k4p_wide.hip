@@ -58,12 +58,31 @@ template <int KP> __device__ __forceinline__ double kp_segsum(double v) {
     if constexpr (KP == 16) v = kp_xor16_add(v);
     return kp_xor32_add(v);
 }
-// sum over the KP row indices of a segment (every lane gets the total)
+// DPP move with bound_ctrl (every pattern below is a permutation of the row: no lane reads out of range, and no `v_mov_b32 v, 0` is
+// needed in front of the move)
+template <int CTRL> __device__ __forceinline__ double kp_dpp(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the KP row indices of a segment (every lane gets the total, bit for bit the same)
 template <int KP> __device__ __forceinline__ double kp_rowsum(double v) {
     asm volatile("" : "+v"(v));                    // (the product is rounded before it is shared: every lane ends with the same bits)
-    v = row_allreduce(v);
+    v += kp_dpp<0xB1>(v);                          // quad_perm [1,0,3,2]
+    v += kp_dpp<0x4E>(v);                          // quad_perm [2,3,0,1]
+    v += kp_dpp<0x141>(v);                         // row_half_mirror
+    v += kp_dpp<0x140>(v);                         // row_mirror
     if constexpr (KP == 32) v = kp_xor16_add(v);
     return v;
+}
+// 1 / x: v_rcp_f64 and two Newton steps (the division sequence is ~15 instructions; the inputs here are sums of squares, far from the
+// denormal / overflow cases its scaling exists for)
+__device__ __forceinline__ double kp_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
 }
 __device__ __forceinline__ void kp_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -163,8 +182,8 @@ struct KpCtx {
             const double vr = rowbuf[r], pj = rowbuf[j], dj = diag[j];
             kp_sync();
             ok = ok && (pj > 0.0);
-            ratio = fmin(ratio, pj / dj);
-            const double p = 1.0 / pj, vrp = vr * p;
+            const double p = kp_rcp(pj), vrp = vr * p;
+            ratio = fmin(ratio, pj * kp_rcp(dj));
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
                 double val = fma(-(vr * vc[cc]), p, M[cc]);                // (v_r v_c first: the result is exactly symmetric)
@@ -266,16 +285,19 @@ __global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
         for (int t = 0; t < nb; ++t) {
             KpRow<KP> x;
             x.load(cx.xin + t * XS, r, c0);
+            double xb = kp_rowsum<KP>(x.xr * beta);                        // x'beta: the prediction of a row that does not update
             if ((vm >> t) & 1) {
                 double zp = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
                 const double z = kp_segsum<KP>(zp);                        // (P x)_r
-                const double d = kp_rowsum<KP>(x.xr * z), xb = kp_rowsum<KP>(x.xr * beta);
-                const double rr = 1.0 + d / ff;                            // :533
-                const double g = 1.0 / (rr * ff);
+                const double d = kp_rowsum<KP>(x.xr * z);
+                const double rr = fma(d, iff, 1.0);                        // :533
+                const double g = kp_rcp(rr * ff);
                 const double kk = z * g;                                   // gain_r (:534)
-                beta = fma(kk, x.y - xb, beta);                            // :536-537
+                const double err = x.y - xb;
+                beta = fma(kk, err, beta);                                 // :536-537
+                xb = fma(d * g, err, xb);                                  // x'beta after the update: x'k = x'P x / (r ff)
                 // P / ff - k k' r (:538-539).  The product k_r k_c is formed FIRST: it is bitwise the same for (r, c) and (c, r), so P stays
                 // exactly symmetric like the reference's (an antisymmetric rounding residue grows by 1 / ff per row: 2e14 over 1 000 rows
                 // at half_life 21)
@@ -285,8 +307,7 @@ __global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
                 for (int cc = 0; cc < CPL; ++cc) P[cc] = fma(-(kk * kc[cc]), rr, P[cc] * iff);
             }
             cx.store_coef(G.start + i0 + t, beta, true);
-            const double p = kp_rowsum<KP>(x.xr * beta);
-            predv = (cx.lane == t) ? p : predv;
+            predv = (cx.lane == t) ? xb : predv;
         }
         if (a.pred && cx.lane < nb) static_cast<T *>(a.pred)[G.start + i0 + cx.lane] = (T)predv;
         kp_sync();
@@ -356,7 +377,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                 for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
                 const double z = kp_segsum<KP>(zp);
                 const double d = kp_rowsum<KP>(x.xr * z), xb = kp_rowsum<KP>(x.xr * beta);
-                const double g = 1.0 / (1.0 + d);
+                const double g = kp_rcp(1.0 + d);
                 beta = fma(g * z, x.y - xb, beta);
                 double zc[CPL];
                 cx.bcast(z, zc);
@@ -379,7 +400,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                     const double den = 1.0 - d;
                     if (!(den > 1e-6)) inverted = false;                   // the downdate collapses: back to the sums (wave-uniform)
                     else {
-                        const double g = 1.0 / den;
+                        const double g = kp_rcp(den);
                         beta = fma(-g * z, o.y - xb, beta);
                         double zc[CPL];
                         cx.bcast(z, zc);

@@ -101,7 +101,9 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
     if k <= 10 and valid is None:
         assert eng.last_kernel.startswith("k4_rolling_tiles")
     elif k <= 10 and policy == "drop":
-        assert eng.last_kernel.startswith(("k4_rolling_tiles", "k4w_"))
+        assert eng.last_kernel.startswith(("k4_rolling_tiles", "k4w_", "k4p_"))
+    elif policy == "drop":                         # 11+ features with nulls: the valid rows compacted in front of K4p (k4p_wide.hip)
+        assert eng.last_kernel.startswith(("k4p_", "k4w_"))
     else:
         assert eng.last_kernel.startswith("k4w_")
     ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy, is_valid=valid)
