@@ -1673,7 +1673,10 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     const int64_t N = b->n_rows;
     std::vector<uint8_t> hvalid;
     const uint8_t *hv = nullptr;
-    if (b->valid) {
+    // validity bytes that live on the device: the prefix tables are built there too (dyn_prep.hip valid_tables_launch) -- copying the
+    // bytes home, walking every row and uploading two int32 tables was 40+ ms of a 10 M-row call whose kernels take 3-5
+    const bool dev_tables = b->valid && b->mem == POLS_MEM_DEVICE && ctx->scratch[0].ptr && b->n_groups > 0 && N > 0;
+    if (b->valid && !dev_tables) {
         if (b->mem == POLS_MEM_DEVICE) {
             hvalid.resize((size_t)N);
             POLS_HIP(hipMemcpyAsync(hvalid.data(), b->valid, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
@@ -1688,7 +1691,7 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     // uncoalesced and more concurrent lanes cost more in the memory system than they win in parallelism)
     const int64_t chunk_len = std::min<int64_t>(std::max(max_chunk, min_chunk), std::max<int64_t>(min_chunk, N / 16384));
     auto &cc = ctx->chunk_cache;
-    if (!hv && cc.tab && cc.tab == ctx->scratch[10].ptr && cc.offs_id == ctx->offs_id && cc.n_groups == b->n_groups &&
+    if (!hv && !dev_tables && cc.tab && cc.tab == ctx->scratch[10].ptr && cc.offs_id == ctx->offs_id && cc.n_groups == b->n_groups &&
         cc.n_rows == N && cc.mp == mp && cc.chunk_len == (int32_t)chunk_len) {      // same frame as the last call
         void *tot = nullptr;
         if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)slots * std::max<size_t>(1, (size_t)cc.n_chunks), &tot))) return rc;
@@ -1735,10 +1738,13 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     }
     const size_t b_groups = round256(sizeof(K4Group) * groups.size());
     const size_t b_chunks = round256(sizeof(K4Chunk) * chunks.size());
-    const size_t b_cnt = hv ? round256(sizeof(int32_t) * (size_t)N) : 0;
+    const size_t b_cnt = (hv || dev_tables) ? round256(sizeof(int32_t) * (size_t)N) : 0;
+    const int64_t n_slabs = (N + 255) / 256;
+    const size_t b_sc = dev_tables ? round256(sizeof(uint32_t) * (size_t)n_slabs) : 0, b_sb = dev_tables ? round256(sizeof(int64_t) * (size_t)(n_slabs + 1)) : 0,
+                 b_co = dev_tables ? round256(sizeof(int64_t) * (size_t)(b->n_groups + 1)) : 0;
     void *tab = nullptr, *tot = nullptr;
     cc.tab = nullptr;                                  // the slot is about to be rewritten (and possibly re-allocated)
-    if ((rc = ensure_scratch(ctx, 10, b_groups + b_chunks + 2 * b_cnt + 256, &tab))) return rc;   // slot 10 belongs to these tables alone
+    if ((rc = ensure_scratch(ctx, 10, b_groups + b_chunks + 2 * b_cnt + b_sc + b_sb + b_co + 256, &tab))) return rc;   // slot 10 belongs to these tables alone
     if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)slots * std::max<size_t>(1, chunks.size()), &tot))) return rc;
     char *tp = static_cast<char *>(tab);
     if ((rc = upload_small(ctx, tp, groups.data(), sizeof(K4Group) * groups.size()))) return rc;   // locals: through the pinned ring
@@ -1749,14 +1755,36 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     }
     a->groups = reinterpret_cast<const K4Group *>(tp);
     a->chunks = reinterpret_cast<const K4Chunk *>(tp + b_groups);
-    a->cnt = hv ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks) : nullptr;
-    a->vidx = hv ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks + b_cnt) : nullptr;
+    a->cnt = (hv || dev_tables) ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks) : nullptr;
+    a->vidx = (hv || dev_tables) ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks + b_cnt) : nullptr;
+    if (dev_tables) {
+        // (the groups were uploaded with the null-free constants -- mpv = min_periods, gate_n = min(rows, min_periods); the device pass
+        // patches both from the validity bytes.  all_nan only depends on the group's length: n_valid never exceeds min_periods)
+        char *xb = tp + b_groups + b_chunks + 2 * b_cnt;
+        RowCompactArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.valid = b->valid; ra.offs = static_cast<const int64_t *>(ctx->scratch[0].ptr);
+        ra.n_rows = N; ra.n_groups = b->n_groups; ra.n_slabs = n_slabs;
+        ra.slab_cnt = reinterpret_cast<uint32_t *>(xb);
+        ra.slab_base = reinterpret_cast<int64_t *>(xb + b_sc);
+        ra.c_offs = reinterpret_cast<int64_t *>(xb + b_sc + b_sb);
+        ra.slab_gfirst = nullptr;
+        if ((rc = row_compact_offsets_launch(ctx, ra))) return rc;
+        ValidTablesArgs va;
+        std::memset(&va, 0, sizeof(va));
+        va.valid = b->valid; va.offs = ra.offs; va.n_rows = N; va.n_groups = b->n_groups; va.n_slabs = n_slabs;
+        va.slab_base = ra.slab_base; va.c_offs = ra.c_offs;
+        va.cnt = reinterpret_cast<int32_t *>(tp + b_groups + b_chunks);
+        va.vidx = reinterpret_cast<int32_t *>(tp + b_groups + b_chunks + b_cnt);
+        va.groups = tp; va.min_periods = mp;
+        if ((rc = valid_tables_launch(ctx, va))) return rc;
+    }
     a->n_chunks = (int64_t)chunks.size();
     a->n_groups = (int32_t)b->n_groups;
     a->totals = static_cast<double *>(tot);
     a->chunk_len = (int32_t)chunk_len;
     cc.tab = nullptr;
-    if (!hv) {
+    if (!hv && !dev_tables) {
         cc.offs_id = ctx->offs_id; cc.n_groups = b->n_groups; cc.n_rows = N; cc.mp = mp; cc.n_chunks = a->n_chunks;
         cc.chunk_len = (int32_t)chunk_len; cc.tab = tab; cc.b_groups = b_groups;
     }
@@ -1925,7 +1953,10 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     // sums kept beside it (K4p, k4p_wide.hip).  A sequence of up to 1 024 rows is one chunk; a chunk of a longer one re-sums the rows of the
     // window in front of it, so cut sequences need a window of at most 1 024 rows.  POLS_ROLLING_ENGINE=chunk keeps k4w_wide.hip.
     const int64_t pchunk = max_rows <= 1024 ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
-    const bool wave_p = wide && !xwide && st.valid == nullptr && mp <= w && (max_rows <= pchunk || w <= 1024) && ctx->opt.rolling_engine != 1;
+    // ... and the FIXED window over rows ("drop_window") on frames with validity bytes on the device: the same kernel with the rows masked
+    // and the solves gated (the validity prefix is built on the device, dyn_prep.hip)
+    const bool wave_p = wide && !xwide && mp <= w && (max_rows <= pchunk || w <= 1024) && ctx->opt.rolling_engine != 1 &&
+                        (st.valid == nullptr || (!drop && ds.tables.valid != nullptr && ds.tables.mem == POLS_MEM_DEVICE));
     const int64_t minc = wave_p ? pchunk : (k > 128 ? hbm_state_chunk(b->n_rows) : 64);
     if ((rc = build_chunk_tables(ctx, &ds.tables, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, minc, wave_p ? pchunk : std::max<int64_t>(512, minc)))) return rc;
     a.y = st.y; a.valid = st.valid;

@@ -1,6 +1,7 @@
 // dyn_prep.hip -- see dyn_prep.hpp.  HBM-bound element-wise passes: one thread per row walks the columns (consecutive lanes =
 // consecutive rows of every column: coalesced), nothing to tile.
 #include "dyn_prep.hpp"
+#include "k4_rolling.hpp"
 
 #include <algorithm>
 
@@ -217,11 +218,20 @@ __global__ void __launch_bounds__(256) rc_groups_kernel(const RowCompactArgs a) 
     if (s < a.n_slabs)
         for (int64_t i = s * RC_SLAB; i < r0; ++i) c += a.valid[i] ? 1 : 0;
     a.c_offs[g] = c;
-    if (g < a.n_groups) {
-        const int64_t r1 = a.offs[g + 1];
-        if (r1 > r0)
-            for (int64_t ss = s + 1; ss <= (r1 - 1) / RC_SLAB; ++ss) a.slab_gfirst[ss] = c;      // slabs that start inside this group
+}
+
+// slab_gfirst[s] = compacted offset of the group that holds the slab's first row, for slabs that start INSIDE a group -- one thread per
+// slab (a binary search of the offsets) instead of one thread writing every slab of a long group (39 000 stores for a 10 M-row group)
+__global__ void __launch_bounds__(256) rc_gfirst_kernel(const RowCompactArgs a) {
+    const int64_t sl = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sl >= a.n_slabs) return;
+    const int64_t r0 = sl * RC_SLAB;
+    int64_t lo = 0, hi = a.n_groups;                         // the last g with offs[g] <= r0
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.offs[mid] <= r0) lo = mid; else hi = mid;
     }
+    if (a.offs[lo] < r0 && r0 < a.offs[lo + 1]) a.slab_gfirst[sl] = a.c_offs[lo];
 }
 
 template <typename T>
@@ -303,6 +313,46 @@ __global__ void __launch_bounds__(RC_SLAB) rc_expand_kernel(const RowCompactArgs
     }
 }
 
+// ---------------------------------------------------------------- validity prefix of the chunk kernels, on the device
+__global__ void __launch_bounds__(RC_SLAB) vt_rows_kernel(const ValidTablesArgs a) {
+    __shared__ unsigned wave_cnt[RC_SLAB / 64];
+    const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
+    const bool in = r < a.n_rows;
+    const bool ok = in && a.valid[r];
+    unsigned total;
+    const unsigned incl = rc_slab_prefix(ok, wave_cnt, &total);
+    if (!in) return;
+    int64_t lo = 0, hi = a.n_groups;                         // the group holding row r: the last g with offs[g] <= r
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.offs[mid] <= r) lo = mid; else hi = mid;
+    }
+    const int64_t g0 = a.offs[lo];
+    const int64_t c = a.slab_base[blockIdx.x] + (int64_t)incl - a.c_offs[lo];   // valid rows of the group at or before r
+    a.cnt[r] = (int32_t)c;
+    if (ok) a.vidx[g0 + c - 1] = (int32_t)(r - g0);
+}
+
+__global__ void __launch_bounds__(256) vt_groups_kernel(const ValidTablesArgs a) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.n_groups) return;
+    K4Group *G = static_cast<K4Group *>(a.groups) + g;
+    const int64_t tot = a.c_offs[g + 1] - a.c_offs[g], mp = a.min_periods;
+    // ls.rs:881-891: min_periods_valid = the row at which the min_periods-th valid observation arrives (else it stays min_periods),
+    // n_valid = the valid rows counted until then
+    G->mpv = tot >= mp ? (int64_t)a.vidx[a.offs[g] + mp - 1] + 1 : mp;
+    G->gate_n = tot < mp ? tot : mp;
+}
+
+int valid_tables_launch(pols_ctx *ctx, const ValidTablesArgs &a) {
+    if (a.n_rows == 0 || a.n_groups == 0) return POLS_OK;
+    POLS_HIP(hipMemsetAsync(a.vidx, 0xff, sizeof(int32_t) * (size_t)a.n_rows, ctx->stream));
+    hipLaunchKernelGGL(vt_rows_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(vt_groups_kernel, dim3((unsigned)((a.n_groups + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
 int row_compact_mask_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a) {
     if (a.n_rows == 0) return POLS_OK;
     if (dtype == POLS_F32) hipLaunchKernelGGL(rc_mask_kernel<float>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
@@ -315,6 +365,7 @@ int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a) {
     hipLaunchKernelGGL(rc_count_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
     hipLaunchKernelGGL(rc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
     hipLaunchKernelGGL(rc_groups_kernel, dim3((unsigned)((a.n_groups + 1 + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    if (a.slab_gfirst) hipLaunchKernelGGL(rc_gfirst_kernel, dim3((unsigned)((a.n_slabs + 255) / 256)), dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

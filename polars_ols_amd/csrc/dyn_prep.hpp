@@ -93,6 +93,23 @@ int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a);         
 int row_compact_scatter_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
 int row_compact_expand_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
 
+// The validity prefix of the chunk-parallel dynamic kernels (K4Args::cnt / vidx and the per-group warm-up constants of
+// solve_rolling_ols, ls.rs:881-891) built ON THE DEVICE from device validity bytes: the host-side build copied the bytes home, walked
+// every row and uploaded two int32 tables -- 40+ ms of a 10 M-row call whose kernels take 3 (profiles/r04_bench_dyn_nulls.txt).
+// Needs row_compact_offsets_launch's slab_base / c_offs of the same frame.
+struct ValidTablesArgs {
+    const uint8_t *valid;
+    const int64_t *offs;         // DEVICE group offsets, n_groups + 1
+    int64_t n_rows, n_groups, n_slabs;
+    const int64_t *slab_base;    // valid rows before each 256-row slab
+    const int64_t *c_offs;       // valid rows before each group
+    int32_t *cnt;                // out: inclusive count of valid rows inside the group, per row
+    int32_t *vidx;               // out: row (relative to the group) of the r-th valid row, slot offs[g] + r (pre-filled with -1)
+    void *groups;                // K4Group[n_groups]: mpv and gate_n are patched (k4_rolling.hpp)
+    int64_t min_periods;
+};
+int valid_tables_launch(pols_ctx *ctx, const ValidTablesArgs &a);
+
 int dyn_scan_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_rewrite_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);
 int dyn_post_launch(pols_ctx *ctx, int dtype, const DynPrepArgs &a);

@@ -314,8 +314,16 @@ __global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
     }
 }
 
-// ------------------------------------------------------------------ rolling walk (null-free frames, min_periods <= window)
-template <typename T, int KP>
+// ------------------------------------------------------------------ rolling walk (min_periods <= window)
+// MASKED = false: null-free frames (the "drop" deque and the fixed window are the same sums).
+// MASKED = true : the FIXED window over rows with validity bytes ("drop_window", ls.rs:987-1029): a row enters only if it is valid, row
+//   i - window leaves only if it is valid, at or beyond j_min = max(mpv - window, 0) (rows older than that are never dropped: the
+//   sliding loop only starts at i = mpv, :989-990) and i >= mpv; a row is SOLVED when it is the warm-up row mpv - 1 or its window holds
+//   at least gate_n valid rows (the n_valid_window gate, :1013, :1022) and otherwise repeats the last solved row's coefficients.  The
+//   validity prefix (K4Args::cnt) and the per-group constants come from the device tables (dyn_prep.hip valid_tables_launch).
+struct KpMasks { unsigned vin, vout, gate; };
+
+template <typename T, int KP, bool MASKED>
 __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
     __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP>::lds_doubles()];
@@ -326,6 +334,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     const int K = cx.K, r = cx.r, c0 = cx.c0;
     const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start, n = G.end - G.start;
     const int64_t w = a.window, mpv = G.mpv;
+    const int64_t j_min = MASKED ? max(mpv - w, (int64_t)0) : 0;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     if (G.all_nan) {                                               // :893-900
         for (int64_t i = rel0; i < rel1; ++i) {
@@ -336,24 +345,90 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     }
     cx.zero_pads();
     double S[CPL], P[CPL], bsum = 0.0, beta = 0.0;
+    const uint8_t *valid = a.valid ? a.valid + G.start : nullptr;
+    const int32_t *cnt = a.cnt ? a.cnt + G.start : nullptr;
+    // what row i's block of 32 does: which rows enter, which rows i - window leave, which rows are solved
+    auto masks = [&](int64_t i0, int64_t hi) -> KpMasks {
+        const int t = cx.lane & 31;
+        const int64_t i = i0 + t;
+        bool vin = false, vout = false, gate = false;
+        if (i < hi) {
+            if (cx.lane < 32) {
+                vin = MASKED ? valid[i] != 0 : true;
+                if (i >= mpv - 1) {
+                    if constexpr (MASKED) {
+                        const int64_t is = i >= w ? i - w : 0;          // saturating_sub (:990)
+                        gate = (i == mpv - 1) || ((int64_t)cnt[i] - (int64_t)cnt[is] >= G.gate_n);
+                    } else gate = true;
+                }
+            } else {
+                const int64_t o = i - w;
+                vout = o >= j_min && o >= 0 && i >= mpv && (MASKED ? valid[o] != 0 : true);
+            }
+        }
+        const unsigned long long bi = __ballot(vin), bo = __ballot(vout), bg = __ballot(gate);
+        return KpMasks{(unsigned)bi, (unsigned)(bo >> 32), (unsigned)bg};
+    };
+    // S, bsum += the valid rows of [lo, hi)
+    auto accumulate = [&](int64_t lo, int64_t hi) {
+        for (int64_t j0 = lo; j0 < hi; j0 += KP_RB) {
+            cx.stage(G.start, j0, 0, 0, hi, false);
+            const int nb = (int)min((int64_t)KP_RB, hi - j0);
+            unsigned vm = 0xffffffffu;
+            if constexpr (MASKED) { const int64_t j = j0 + (cx.lane & 31); vm = (unsigned)__ballot(cx.lane < 32 && j < hi && valid[j] != 0); }
+            for (int t = 0; t < nb; ++t) {
+                if (!((vm >> t) & 1)) continue;
+                KpRow<KP> x;
+                x.load(cx.xin + t * XS, r, c0);
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
+                bsum = fma(x.xr, x.y, bsum);
+            }
+            kp_sync();
+        }
+    };
+    // the sums after row ip (>= 0): the valid rows the sliding loop has not dropped yet (+ alpha I once the warm-up row has passed, :924-926)
+    auto state_after = [&](int64_t ip) {
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) S[cc] = 0.0;
+        bsum = 0.0;
+        if (ip < mpv) accumulate(0, ip + 1);                       // (nothing is subtracted before the sliding loop starts)
+        else {
+            const int64_t lo = max(ip - w + 1, (int64_t)0);
+            if (j_min > 0) accumulate(0, min(j_min, lo));          // rows older than j_min are never dropped
+            accumulate(lo, ip + 1);
+        }
+        if (ip >= mpv - 1 && a.alpha != 0.0) {
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) S[cc] += (c0 + cc == r && r < K) ? a.alpha : 0.0;
+        }
+    };
+    auto solve_fresh = [&](double (&M)[CPL], bool &ok, double &ratio) -> double {
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) M[cc] = S[cc];
+        cx.invert(M, ok, ratio);
+        return cx.matvec(M, bsum);
+    };
 #pragma unroll
     for (int cc = 0; cc < CPL; ++cc) { S[cc] = 0.0; P[cc] = 0.0; }
-    // the sums after row rel0 - 1: the last min(window, rel0) rows in front of the chunk (+ alpha I once the warm-up row has passed, :924-926)
-    for (int64_t j0 = max((int64_t)0, rel0 - w); j0 < rel0; j0 += KP_RB) {
-        cx.stage(G.start, j0, 0, 0, rel0, false);
-        const int nb = (int)min((int64_t)KP_RB, rel0 - j0);
-        for (int t = 0; t < nb; ++t) {
-            KpRow<KP> x;
-            x.load(cx.xin + t * XS, r, c0);
-#pragma unroll
-            for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
-            bsum = fma(x.xr, x.y, bsum);
-        }
-        kp_sync();
-    }
-    if (rel0 - 1 >= mpv - 1 && a.alpha != 0.0) {
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) S[cc] += (c0 + cc == r && r < K) ? a.alpha : 0.0;
+    double last = 0.0;                                             // MASKED: the coefficients of the last solved row (forward fill)
+    bool last_good = false;
+    if (rel0 > 0) {
+        if constexpr (MASKED) {
+            if (rel0 - 1 >= mpv - 1) {
+                // the last row at or before rel0 - 1 that was solved: its coefficients are what a closed gate repeats
+                int64_t ip = rel0 - 1;
+                for (; ip > mpv - 1; --ip) {
+                    const int64_t is = ip >= w ? ip - w : 0;
+                    if ((int64_t)cnt[ip] - (int64_t)cnt[is] >= G.gate_n) break;
+                }
+                state_after(ip);
+                double M[CPL]; bool ok; double ratio;
+                last = solve_fresh(M, ok, ratio);
+                last_good = ok;
+                if (ip != rel0 - 1) state_after(rel0 - 1);
+            } else state_after(rel0 - 1);
+        } else state_after(rel0 - 1);
     }
     bool inverted = false;
     int since = 0;
@@ -361,6 +436,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     const bool may_propagate = w >= 2 * (int64_t)K;
     for (int64_t i0 = rel0; i0 < rel1; i0 += KP_RB) {
         cx.stage(G.start, i0, i0 - w, 0, n, i0 + KP_RB > w);
+        const KpMasks mk = masks(i0, rel1);
         const int nb = (int)min((int64_t)KP_RB, rel1 - i0);
         double predv = 0.0;
         for (int t = 0; t < nb; ++t) {
@@ -368,24 +444,26 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
             KpRow<KP> x;
             x.load(cx.xin + t * XS, r, c0);
             // ---- the row enters (NonWoodburyState::update, :707-725)
+            if ((mk.vin >> t) & 1) {
 #pragma unroll
-            for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
-            bsum = fma(x.xr, x.y, bsum);
-            if (inverted) {
-                double zp = 0.0;
+                for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
+                bsum = fma(x.xr, x.y, bsum);
+                if (inverted) {
+                    double zp = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
-                const double z = kp_segsum<KP>(zp);
-                const double d = kp_rowsum<KP>(x.xr * z), xb = kp_rowsum<KP>(x.xr * beta);
-                const double g = kp_rcp(1.0 + d);
-                beta = fma(g * z, x.y - xb, beta);
-                double zc[CPL];
-                cx.bcast(z, zc);
+                    for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
+                    const double z = kp_segsum<KP>(zp);
+                    const double d = kp_rowsum<KP>(x.xr * z), xb = kp_rowsum<KP>(x.xr * beta);
+                    const double g = kp_rcp(1.0 + d);
+                    beta = fma(g * z, x.y - xb, beta);
+                    double zc[CPL];
+                    cx.bcast(z, zc);
 #pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) P[cc] = fma(-(z * zc[cc]), g, P[cc]);   // (z_r z_c first: P stays exactly symmetric)
+                    for (int cc = 0; cc < CPL; ++cc) P[cc] = fma(-(z * zc[cc]), g, P[cc]);   // (z_r z_c first: P stays exactly symmetric)
+                }
             }
             // ---- row i - window leaves
-            if (i >= w) {
+            if ((mk.vout >> t) & 1) {
                 KpRow<KP> o;
                 o.load(cx.xout + t * XS, r, c0);
 #pragma unroll
@@ -416,15 +494,12 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
             }
             bool good = false;
             double bout = 0.0;
-            if (i >= mpv - 1) {
+            if ((mk.gate >> t) & 1) {
                 ++since;
                 if (!inverted || since >= KP_REFRESH) {
                     double M[CPL];
-#pragma unroll
-                    for (int cc = 0; cc < CPL; ++cc) M[cc] = S[cc];
                     bool ok; double ratio;
-                    cx.invert(M, ok, ratio);
-                    const double bnew = cx.matvec(M, bsum);
+                    const double bnew = solve_fresh(M, ok, ratio);
                     good = ok; bout = bnew;
                     inverted = ok && may_propagate && ratio > KP_SWITCH_RATIO;
                     if (inverted) {
@@ -436,6 +511,9 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                 } else {
                     good = true; bout = beta;
                 }
+                if constexpr (MASKED) { last = bout; last_good = good; }
+            } else if (MASKED && i >= mpv - 1) {                           // the gate is closed: the last solved row's coefficients
+                good = last_good; bout = last;
             }
             cx.store_coef(G.start + i, bout, good);
             const double p = kp_rowsum<KP>(x.xr * bout);
@@ -456,15 +534,17 @@ static int kp_launch_kp(pols_ctx *ctx, const K4Args &a, bool rls, bool single_ch
         }
         hipLaunchKernelGGL((kp_rls_walk_kernel<T, KP>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
     } else {
-        hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+        if (a.valid) hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, true>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, false>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
     }
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
 
-// single_chunk: no sequence was cut (every chunk starts its sequence).  Rolling: the frame is null-free, min_periods <= window, and
-// window <= KP_MAX_DIRECT_WINDOW unless single_chunk (the caller checks).
+// single_chunk: no sequence was cut (every chunk starts its sequence).  Rolling: min_periods <= window, window <= 1 024 unless
+// single_chunk, and either a null-free frame (a.valid == nullptr) or the fixed window over rows with validity bytes + the device
+// validity tables (a.valid, a.cnt, patched groups; "drop_window") -- the caller checks.
 int k4p_launch(pols_ctx *ctx, int dtype, const K4Args &a, bool rls, bool single_chunk) {
     if (a.k > 32 || a.k < 1) return fail(POLS_ERR_UNSUPPORTED, "k4p: %d features", a.k);
     if (a.n_chunks <= 0) return POLS_OK;

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polars_ols_amd.engine import Engine  # noqa: E402
 
 eng = Engine(0)
-G, n, k = int(os.environ.get("G", 10_000)), 1_000, 6
+G, n, k = int(os.environ.get("G", 10_000)), 1_000, int(os.environ.get("K", 6))
 gen = torch.Generator(device="cuda").manual_seed(3)
 cols = [torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64) for _ in range(k)]
 y = sum(cols) + 0.1 * torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64)
@@ -33,6 +33,6 @@ for name, kw in (("null-free", dict(y=y, null_free=True)), ("validity bytes", di
     yy = kw.pop("y")
     for pol in ("drop", "drop_window"):
         ms = timed(lambda: eng.rolling_least_squares(yy, cols, offs, window_size=252, min_periods=6, null_policy=pol, **kw))
-        print(f"rolling {name:15s} {pol:12s} {ms:8.3f} ms per call  {eng.last_kernel}")
+        print(f"k={k:2d} rolling {name:15s} {pol:12s} {ms:8.3f} ms per call  {eng.last_kernel}")
     ms = timed(lambda: eng.recursive_least_squares(yy, cols, offs, half_life=21.0, **kw))
-    print(f"rls     {name:15s} {'':12s} {ms:8.3f} ms per call  {eng.last_kernel}")
+    print(f"k={k:2d} rls     {name:15s} {'':12s} {ms:8.3f} ms per call  {eng.last_kernel}")

@@ -100,12 +100,10 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
     # (up to 10 features: the row-parallel kernel -- on frames with nulls under "drop" when every sequence keeps min_periods valid rows)
     if k <= 10 and valid is None:
         assert eng.last_kernel.startswith("k4_rolling_tiles")
-    elif k <= 10 and policy == "drop":
+    elif k <= 10:
         assert eng.last_kernel.startswith(("k4_rolling_tiles", "k4w_", "k4p_"))
-    elif policy == "drop":                         # 11+ features with nulls: the valid rows compacted in front of K4p (k4p_wide.hip)
-        assert eng.last_kernel.startswith(("k4p_", "k4w_"))
-    else:
-        assert eng.last_kernel.startswith("k4w_")
+    else:                                          # with nulls: "drop" compacts the valid rows in front of K4p (k4p_wide.hip), "drop_window" takes
+        assert eng.last_kernel.startswith(("k4p_", "k4w_"))   # its masked form; windows beyond 1 024 rows on cut sequences stay with k4w_wide.hip
     ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy, is_valid=valid)
     got_c, got_p = _np(out["coef"]), _np(out["pred"])
     nobs = _window_obs(offs, valid, window, policy)
@@ -587,3 +585,52 @@ def test_rolling_wave_per_chunk_null_free(eng, dtype, tol, k, window, min_period
         eng.set_option("ROLLING_ENGINE", None)
     out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, null_policy="drop", **kw)
     assert np.allclose(_np(old["coef"])[well], _np(out["coef"])[well], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,window,min_periods,alpha,null_frac,shape", [
+    (12, 100, 12, None, 0.05, "long"), (11, 252, None, None, 0.03, "groups"), (16, 64, 16, 0.5, 0.3, "long"), (24, 300, 30, None, 0.1, "long"),
+    (32, 400, None, None, 0.05, "groups"), (9, 30, 9, None, 0.5, "groups"), (12, 60, 3, None, 0.1, "groups"), (14, 2000, 20, None, 0.2, "groups"),
+])
+def test_rolling_wave_per_chunk_drop_window_with_nulls(eng, dtype, tol, k, window, min_periods, alpha, null_frac, shape):
+    """K4p, masked form: the FIXED window over rows with validity bytes ("drop_window", ls.rs:987-1029) -- invalid rows neither enter nor
+    leave, a row is solved when its window holds n_valid valid rows and otherwise repeats the last solved row's coefficients, the warm-up
+    index is the row of the min_periods-th VALID observation (all from the device-built validity prefix).  Heavy null fractions (long gated
+    stretches, warm-ups pushed beyond the window: the reference's never-dropped rows), cut sequences, both padded widths; against the
+    oracle and against k4w_wide.hip (POLS_ROLLING_ENGINE=chunk) on the same frame."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 11 + window % 1013)
+    if shape == "groups":
+        sizes = np.concatenate([[1024, 0, 1, 2, k - 1, k, k + 1, 2 * k, 1000], rng.integers(1, 800, size=20)])
+    else:
+        sizes = np.array([3000, 5, 0, 1025, 2049, 700])
+    y, cols, offs, valid = _frame(rng, sizes, k, dtype=dtype, null_frac=null_frac)
+    kw = dict(window_size=window, min_periods=min_periods, alpha=alpha, null_policy="drop_window")
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
+    assert eng.last_kernel.startswith("k4p_"), eng.last_kernel
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy="drop_window", is_valid=valid)
+    got_c, got_p = _np(out["coef"]), _np(out["pred"])
+    nobs = _window_obs(offs, valid, window, "drop_window")
+    mp_eff = min_periods if min_periods is not None else min(k, window)
+    sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+    eng.set_option("ROLLING_ENGINE", "chunk")
+    try:
+        old = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
+        assert eng.last_kernel.startswith("k4w_")
+    finally:
+        eng.set_option("ROLLING_ENGINE", None)
+    old_c = _np(old["coef"])
+    # forward-filled rows repeat whatever the last solved row returned, so "well-posed" is a property of THAT row: compare where the
+    # reference (and the old engine, which has its LU) is sane, and hold the coefficients of a row whose own window is well filled to tol
+    well = sane & ((nobs >= 2 * k) | (alpha is not None))
+    assert well.sum() > (0.2 if null_frac < 0.4 else 0.1) * sane.sum()       # (half the rows null in a 30-row window: few windows hold 2 k of them)
+    assert np.allclose(got_c[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(got_c[well] - ref["coef"][well]).max())
+    vm = np.asarray(valid).astype(bool)
+    assert np.allclose(got_p[well & vm], ref["pred"][well & vm], rtol=tol, atol=tol) and np.isnan(got_p[~vm]).all()
+    # rows before the warm-up are NaN in both; beyond it the new kernel is NaN only where the window (or the row it repeats) had fewer
+    # than k valid rows
+    before = np.isnan(ref["coef"]).all(axis=1)
+    assert np.isnan(got_c[before]).all()
+    strict = sane & (nobs >= k + 4) & np.isfinite(old_c).all(axis=1)
+    assert np.allclose(got_c[strict], old_c[strict], rtol=10 * tol, atol=tol) or np.allclose(got_c[strict], ref["coef"][strict], rtol=10 * tol, atol=tol)
