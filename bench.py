@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg4r|rlsg|rlsgr|cfg5|ref100] [--mem device|host]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg4r|rlsg|rlsgr|cfg5|ref100|rls100|roll100] [--mem device|host]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -26,6 +26,8 @@ FAILS -- a multi-GPU line is never printed without its collective.
         1 000 rows x 6 features, f64, RLS half_life = 21, coefficients + predictions; sequences shard across ranks
   rlsgr the same frame through rolling OLS, window = 252
   ref100 the reference's own benchmark shape: ONE 10 000 x 100 f64 OLS problem (published: 17.6 ms per call, M2 Max)
+  rls100 / roll100 the reference's published dynamic rows (README.md:235-236): ONE 10 000-row sequence x 100 features, RLS half_life = 252
+        (270 ms) / rolling OLS window = 252 (371 ms)
   cfg5  100 000 groups x 2 000 rows x 16 feats elastic net alpha = 0.001 l1_ratio = 0.5, f64; the groups are SPLIT
         across the ranks (strong scaling: 100 000 / N per GPU)
 --frames F (default: as many as it takes for the inputs to exceed 3 x the 256 MB Infinity Cache, at least 3 for cfg2 / cfg3): the
@@ -74,6 +76,19 @@ def cpu_baseline(cfg: str, target_seconds: float = 10.0) -> dict:
     from refdata import synthetic_groups
 
     cores = orc.max_threads()
+    if cfg in ("rls100", "roll100"):
+        n, k = 10_000, 100
+        rng = np.random.default_rng(1)
+        cols = [rng.standard_normal(n) for _ in range(k)]
+        y = np.sum(cols, axis=0) + 0.1 * rng.standard_normal(n)
+        kind = "rls" if cfg == "rls100" else "rolling"
+        one = orc.bench_dynamic(kind, y, cols, half_life=252.0, window=252, min_periods=k, passes=1)
+        passes = int(max(1, min(20, target_seconds / max(one, 1e-3))))
+        sec = orc.bench_dynamic(kind, y, cols, half_life=252.0, window=252, min_periods=k, passes=passes)
+        return {"value": passes * n / sec, "unit": "rows/s", "cores": 1, "kind": "port",
+                "sample": f"{passes} passes over ONE {n}-row sequence x {k} feats f64, "
+                          f"{'solve_recursive_least_squares half_life=252' if kind == 'rls' else 'solve_rolling_ols window=252 min_periods=100 (Woodbury: k > 60)'} + "
+                          f"dynamic predictions, timed inside liborc; a sequence is a dependency chain: one core"}
     if cfg in ("cfg4", "cfg4r"):
         n, k = 200_000, 6
         rng = np.random.default_rng(1)
@@ -245,6 +260,24 @@ def build_workload(cfg: str, eng, rank: int, world: int, dtype_flag: str, mem: s
         text = (f"the reference's own benchmark shape (tests/benchmark.py:219, README.md:229): ONE problem, {n} rows x {k} feats f64 OLS, "
                 f"predictions; published 17.6 ms per call on an M2 Max incl. Polars overhead")
         return dict(plan=plan, units=1, unit="problems/s", alg_bytes=8 * n * (k + 1) + 8 * n, text=text, dtype="f64", coef=None, scaling="weak", shard=None)
+    if cfg in ("rls100", "roll100"):
+        # the reference's own published dynamic rows (README.md:235-236; tests/benchmark.py:146-172): ONE 10 000-row sequence x 100
+        # features, f64 -- RLS half_life = 252 / rolling OLS window = 252, min_periods = 100, null_policy = "drop_window"; mode = predictions
+        # (the plugin functions `recursive_least_squares` / `rolling_least_squares`), coefficients are written as well
+        n, k = 10_000, 100
+        y, cols, _ = make_columns(n, k, torch.float64, 1234 + rank)
+        out = {"pred": torch.empty(n, device="cuda", dtype=torch.float64), "coef": torch.empty(n, k, device="cuda", dtype=torch.float64)}
+        offs1 = np.array([0, n], dtype=np.int64)
+        if cfg == "rls100":
+            plan = eng.plan_recursive_least_squares(y, cols, offs1, half_life=252.0, out=out, null_free=True)
+            text = (f"the reference's published RLS row (README.md:235, tests/benchmark.py:146-157): ONE {n}-row sequence x {k} feats f64, "
+                    f"half_life=252; published 270 ms per call on an M2 Max incl. Polars overhead")
+        else:
+            plan = eng.plan_rolling_least_squares(y, cols, offs1, window_size=252, min_periods=k, null_policy="drop_window", out=out, null_free=True)
+            text = (f"the reference's published rolling row (README.md:236, tests/benchmark.py:159-172): ONE {n}-row sequence x {k} feats f64, "
+                    f"window=252 min_periods={k} drop_window; published 371 ms per call on an M2 Max incl. Polars overhead")
+        return dict(plan=plan, units=n, unit="rows/s", alg_bytes=8 * n * (k + 1) + 8 * n * (k + 1), text=text, dtype="f64", coef=None,
+                    scaling="weak", shard=None)
     if cfg == "cfg5":
         Gtot, n, k = (groups or 100_000), 2_000, 16
         plan, G, nbytes, coef, shard = grouped(Gtot, n, k, torch.float64, 8, alpha=0.001, l1_ratio=0.5, want=("coef", "pred"))
@@ -277,7 +310,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4r", "rlsg", "rlsgr", "cfg5", "ref100"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg4r", "rlsg", "rlsgr", "cfg5", "ref100", "rls100", "roll100"])
     ap.add_argument("--mem", default="device", choices=["device", "host"])
     ap.add_argument("--frames", type=int, default=0, help="rotate the steps over this many independent frames (0: automatic)")
     ap.add_argument("--groups", type=int, default=0, help="cfg2 / cfg3 / cfg5: this many groups (per GPU for cfg2 / cfg3, in total for cfg5) "
@@ -323,7 +356,7 @@ def main() -> None:
     # inputs add up to more than three times that makes every step stream its input from HBM.  Outputs go to the first frame's
     # buffers (written, never read).
     in_bytes = wl["alg_bytes"]
-    n_frames = args.frames if args.frames > 0 else (1 if (args.config in ("cfg1", "cfg4", "cfg4r", "rlsg", "rlsgr", "ref100") or args.mem == "host")
+    n_frames = args.frames if args.frames > 0 else (1 if (args.config in ("cfg1", "cfg4", "cfg4r", "rlsg", "rlsgr", "ref100", "rls100", "roll100") or args.mem == "host")
                                                     else max(1, min(8, -(-3 * 256 * 2 ** 20 // max(1, in_bytes)))))
     if args.frames == 0 and args.config in ("cfg2", "cfg3") and args.mem == "device":
         n_frames = max(3, n_frames)
@@ -506,7 +539,7 @@ def main() -> None:
         unit_name = wl["unit"]
         line = {
             "metric": {"regressions/s": "group_regressions_per_sec", "problems/s": "single_problems_per_sec"}.get(
-                unit_name, "rolling_rows_per_sec" if args.config in ("cfg4r", "rlsgr") else "rls_rows_per_sec"),
+                unit_name, "rolling_rows_per_sec" if args.config in ("cfg4r", "rlsgr", "roll100") else "rls_rows_per_sec"),
             "value": value, "unit": unit_name, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": wl["scaling"], "vs_baseline": None, "dtype": wl["dtype"],
@@ -536,6 +569,12 @@ def main() -> None:
             # BASELINE.md section 2 holds a published number for exactly this shape: 17.6 ms per call (OLS QR, 10 000 x 100, M2 Max,
             # through Polars + pyo3) = 56.8 problems/s.  Different hardware and it includes the Polars overhead: context, not a target.
             line["vs_baseline"] = value / (1.0 / 17.6e-3)
+        if args.config in ("rls100", "roll100"):
+            published_ms = 270.0 if args.config == "rls100" else 371.0     # BASELINE.md section 2 / README.md:235-236 (M2 Max, through Polars)
+            line["vs_baseline"] = value / (10_000 / (published_ms * 1e-3))
+            line["roofline"]["note"] = ("ONE sequence of 100 features: 157 chunks of 64 rows, one workgroup each, the 100 x 100 inverse propagated "
+                                        "in LDS (O(k^2) per row, a dependency chain inside a chunk) -- latency-bound, nowhere near HBM; "
+                                        "achieved/peak only shows how far")
         if args.config in ("cfg4", "cfg4r", "rlsg", "rlsgr"):
             line["roofline"]["note"] = ("dynamic models: algorithmic bytes = every input column read once + coefficients and predictions "
                                         "written once (16 (k + 1) bytes per row, f64); the sequence is a scan, not a chain -- rows are "
