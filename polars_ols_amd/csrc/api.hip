@@ -186,6 +186,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1T_SUB8")) o.k1t_sub8 = on ? std::atoi(v) : d.k1t_sub8;
     else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
     else if (ieq(key, "K1_XCD")) o.k1_xcd = on ? std::atoi(v) : d.k1_xcd;
+    else if (ieq(key, "K4P_LPS")) o.k4p_lps = on ? std::atoi(v) : d.k4p_lps;
     else if (ieq(key, "DEBUG_SKIP_FIXUP")) o.debug_skip_fixup = on && std::atoi(v) != 0;
     else if (ieq(key, "K1_PERSIST")) o.k1_persist = on ? (std::atoi(v) != 0) : d.k1_persist;
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
@@ -203,7 +204,7 @@ void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
-                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP"};
+                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);

@@ -22,6 +22,11 @@
 //   * a non-positive pivot (fewer than K independent rows in the window) yields NaN where the reference's LU fallback returns
 //     inf / NaN / 1e15-sized numbers (the K4c divergence, include/pols_mi355x.h);
 //   * coefficients leave one row per store instruction (K consecutive values), predictions 32 rows at a time.
+//   * LPS lanes per sequence.  With LPS = 64 a wave walks one chunk; with many chunks in the frame a wave takes SEVERAL -- KP = 16: four
+//     chunks, each on one 16-lane DPP row holding a whole 16-column row of P per lane (LPS = 16: the cross-segment sums go, the row sums
+//     and the LDS hand-over serve four sequences per instruction: ~30 instead of ~110 instructions per row); KP = 32 (RLS): two chunks on
+//     32 lanes each.  The sub-waves run the same code on their own chunk, staging area and LDS slots; where their control flow differs
+//     (lengths, validity, a fresh inversion) the others are masked -- every cross-lane operation stays inside a sub-wave.
 // Chunks: a sequence of up to 1 024 rows is ONE chunk (no totals, no scan: the state at a sequence start is the prior / empty);
 // longer sequences are cut, an RLS chunk starts from the scanned decayed sums (kp_totals + chunk_scan_launch mode 2, inverted once),
 // a rolling chunk re-sums the min(window, rel0) rows in front of it (windows up to 1 024 rows; beyond that only single-chunk
@@ -36,7 +41,6 @@
 
 namespace pols {
 
-constexpr int KP_RB = 32;              // rows staged per block
 constexpr int KP_REFRESH = 128;        // rolling: rows between two rebuilds of the inverse from the sums
 constexpr double KP_SWITCH_RATIO = 1e-4;   // propagate the inverse only from a factorisation whose smallest pivot / diagonal exceeds this
 
@@ -52,11 +56,31 @@ __device__ __forceinline__ double kp_xor16_add(double v) {     // v(l) + v(l ^ 1
     const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
     return __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
 }
-// sum over the segments (lanes with the same row index r = lane % KP)
-template <int KP> __device__ __forceinline__ double kp_segsum(double v) {
-    asm volatile("" : "+v"(v));
-    if constexpr (KP == 16) v = kp_xor16_add(v);
-    return kp_xor32_add(v);
+
+// KP: padded width (16 or 32).  LPS: lanes per sequence (a multiple of KP): lane l of a sub-wave holds the CPL = KP KP / LPS entries
+// P[r][seg CPL ..] with r = l % KP, seg = l / KP; SEQ = 64 / LPS chunks per wave; RB = LPS / 2 rows staged per block (the lower half of
+// the sub-wave loads the rows that enter, the upper half the rows that leave).
+template <int KP, int LPS>
+struct KpGeo {
+    static_assert(LPS % KP == 0 && 64 % LPS == 0, "whole segments, whole sub-waves");
+    static constexpr int NSEG = LPS / KP;
+    static constexpr int CPL = KP / NSEG;          // matrix entries per lane
+    static constexpr int SEQ = 64 / LPS;
+    static constexpr int RB = LPS / 2;
+    static constexpr int XS = KP + 2;              // staged row: KP features (zero padded), the target, one pad (16-byte rows)
+    static constexpr int PER_SUB = 2 * RB * XS + 3 * KP;     // doubles of LDS per sub-wave: two staging areas, z, pivot row, diagonal
+};
+
+// sum over the segments (lanes of the sub-wave with the same row index r)
+template <int KP, int LPS> __device__ __forceinline__ double kp_segsum(double v) {
+    constexpr int NSEG = LPS / KP;
+    static_assert(NSEG == 1 || (KP == 16 && NSEG == 4) || (KP == 32 && NSEG == 2), "one segment per lane row, or the whole wave");
+    if constexpr (NSEG == 1) return v;
+    else {
+        asm volatile("" : "+v"(v));
+        if constexpr (KP == 16) v = kp_xor16_add(v);
+        return kp_xor32_add(v);
+    }
 }
 // DPP move with bound_ctrl (every pattern below is a permutation of the row: no lane reads out of range, and no `v_mov_b32 v, 0` is
 // needed in front of the move)
@@ -88,18 +112,26 @@ __device__ __forceinline__ void kp_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int KP>
-struct KpGeo {
-    static constexpr int CPL = KP * KP / 64;       // matrix entries per lane: 4 (KP = 16) or 16 (KP = 32)
-    static constexpr int XS = KP + 2;              // staged row: KP features (zero padded), the target, one pad (16-byte rows)
-};
+// sum_cc P[cc] x[cc] with up to four independent chains (a 16- or 32-long dependent fma chain is 130-260 cycles of latency per row)
+template <int CPL>
+__device__ __forceinline__ double kp_dot(const double (&P)[CPL], const double (&x)[CPL]) {
+    constexpr int NC = CPL >= 16 ? 4 : (CPL >= 8 ? 2 : 1);
+    double acc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = P[q] * x[q];
+#pragma unroll
+    for (int cc = NC; cc < CPL; ++cc) acc[cc % NC] = fma(P[cc], x[cc], acc[cc % NC]);
+    if constexpr (NC == 4) return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    else if constexpr (NC == 2) return acc[0] + acc[1];
+    else return acc[0];
+}
 
 // One row of the staging area in registers: the lane's CPL features of its segment, feature r, the target.
-template <int KP>
+template <int KP, int LPS>
 struct KpRow {
-    double xc[KpGeo<KP>::CPL], xr, y;
+    double xc[KpGeo<KP, LPS>::CPL], xr, y;
     __device__ __forceinline__ void load(const double *row, int r, int c0) {
-        constexpr int CPL = KpGeo<KP>::CPL;
+        constexpr int CPL = KpGeo<KP, LPS>::CPL;
 #pragma unroll
         for (int cc = 0; cc < CPL; cc += 2) {
             const double2 t = *reinterpret_cast<const double2 *>(row + c0 + cc);
@@ -110,23 +142,25 @@ struct KpRow {
     }
 };
 
-template <typename T, int KP>
+template <typename T, int KP, int LPS>
 struct KpCtx {
-    static constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
+    using Geo = KpGeo<KP, LPS>;
+    static constexpr int CPL = Geo::CPL, XS = Geo::XS, RB = Geo::RB, SEQ = Geo::SEQ;
     const K4Args &a;
-    const int K, lane, r, seg, c0;
+    const int K, lane, sub, r, seg, c0;          // lane: inside the sub-wave
     double *xin, *xout, *zb, *rowbuf, *diag;
     __device__ KpCtx(const K4Args &a_, double *lds)
-        : a(a_), K(a_.k), lane(threadIdx.x), r(threadIdx.x % KP), seg(threadIdx.x / KP), c0((threadIdx.x / KP) * CPL) {
-        xin = lds; xout = xin + KP_RB * XS; zb = xout + KP_RB * XS; rowbuf = zb + KP; diag = rowbuf + KP;
+        : a(a_), K(a_.k), lane(threadIdx.x % LPS), sub(threadIdx.x / LPS), r((threadIdx.x % LPS) % KP), seg((threadIdx.x % LPS) / KP),
+          c0(((threadIdx.x % LPS) / KP) * CPL) {
+        xin = lds + (size_t)sub * Geo::PER_SUB; xout = xin + RB * XS; zb = xout + RB * XS; rowbuf = zb + KP; diag = rowbuf + KP;
     }
-    static constexpr size_t lds_doubles() { return 2 * (size_t)KP_RB * XS + 3 * KP; }
+    static constexpr size_t lds_doubles() { return (size_t)SEQ * Geo::PER_SUB; }
 
-    // rows [i_in, i_in + KP_RB) of the sequence starting at absolute row s -> xin (lanes 0..31), rows [i_out, ...) -> xout (lanes 32..63);
-    // rows outside [lo, hi) are staged as zero rows.  Returns the ballot of the validity bytes of the entering rows.
-    __device__ __forceinline__ unsigned long long stage(int64_t s, int64_t i_in, int64_t i_out, int64_t lo, int64_t hi, bool with_out) const {
-        const int t = lane & 31;
-        const bool outl = lane >= 32;
+    // rows [i_in, i_in + RB) of the sequence starting at absolute row s -> xin (lower half of the sub-wave), rows [i_out, ...) -> xout
+    // (upper half); rows outside [lo, hi) are staged as zero rows.  Returns the validity bits of the entering rows.
+    __device__ __forceinline__ unsigned stage(int64_t s, int64_t i_in, int64_t i_out, int64_t lo, int64_t hi, bool with_out) const {
+        const int t = lane % RB;
+        const bool outl = lane >= RB;
         const int64_t i = (outl ? i_out : i_in) + t;
         const bool on = (!outl || with_out) && i >= lo && i < hi;
         double *dst = (outl ? xout : xin) + t * XS;
@@ -142,10 +176,10 @@ struct KpCtx {
         }
         const unsigned long long m = __ballot(v);
         kp_sync();
-        return m;
+        return (unsigned)((m >> (sub * LPS)) & ((1ull << RB) - 1ull));
     }
     __device__ __forceinline__ void zero_pads() const {             // features K .. KP - 1 of every staged row are zero, once
-        for (int q = lane; q < 2 * KP_RB * XS; q += 64) xin[q] = 0.0;
+        for (int q = lane; q < 2 * RB * XS; q += LPS) xin[q] = 0.0;
         kp_sync();
     }
     // every lane gets the CPL entries v[c0 ..] of a vector held one entry per row index (lanes of segment 0 publish)
@@ -200,10 +234,7 @@ struct KpCtx {
     __device__ __forceinline__ double matvec(const double (&P)[CPL], double br) const {
         double bc[CPL];
         bcast(br, bc);
-        double acc = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) acc = fma(P[cc], bc[cc], acc);
-        return kp_segsum<KP>(acc);
+        return kp_segsum<KP, LPS>(kp_dot<CPL>(P, bc));
     }
     // coefficient row / prediction of relative row i (beta one entry per row index; `good` false -> NaN)
     __device__ __forceinline__ void store_coef(int64_t row, double beta, bool good) const {
@@ -213,14 +244,15 @@ struct KpCtx {
 };
 
 // ------------------------------------------------------------------ RLS: per-chunk decayed sums (only for sequences cut into chunks)
-template <typename T, int KP>
+template <typename T, int KP, int LPS>
 __global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
-    constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
-    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP>::lds_doubles()];
-    const int64_t c = blockIdx.x;
+    constexpr int CPL = KpGeo<KP, LPS>::CPL, XS = KpGeo<KP, LPS>::XS, KP_RB = KpGeo<KP, LPS>::RB;
+    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP, LPS>::lds_doubles()];
+    KpCtx<T, KP, LPS> cx(a, lds);
+    const int64_t c = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
+    if (c >= a.n_chunks) return;                                   // (a whole sub-wave: the others' cross-lane traffic stays inside them)
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
-    KpCtx<T, KP> cx(a, lds);
     const int K = cx.K;
     cx.zero_pads();
     double S[CPL], b = 0.0, decay = 1.0;
@@ -228,11 +260,11 @@ __global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
     for (int cc = 0; cc < CPL; ++cc) S[cc] = 0.0;
     const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
     for (int64_t i0 = rel0; i0 < rel1; i0 += KP_RB) {
-        const unsigned long long vm = cx.stage(G.start, i0, 0, rel0, rel1, false);
+        const unsigned vm = cx.stage(G.start, i0, 0, rel0, rel1, false);
         const int nb = (int)min((int64_t)KP_RB, rel1 - i0);
         for (int t = 0; t < nb; ++t) {
             if (!((vm >> t) & 1)) continue;
-            KpRow<KP> x;
+            KpRow<KP, LPS> x;
             x.load(cx.xin + t * XS, cx.r, cx.c0);
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], a.ff * S[cc]);
@@ -252,14 +284,15 @@ __global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
 }
 
 // ------------------------------------------------------------------ RLS walk (RecursiveLeastSquares::update, literally)
-template <typename T, int KP>
+template <typename T, int KP, int LPS>
 __global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
-    constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
-    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP>::lds_doubles()];
-    const int64_t c = blockIdx.x;
+    constexpr int CPL = KpGeo<KP, LPS>::CPL, XS = KpGeo<KP, LPS>::XS, KP_RB = KpGeo<KP, LPS>::RB;
+    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP, LPS>::lds_doubles()];
+    KpCtx<T, KP, LPS> cx(a, lds);
+    const int64_t c = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
+    if (c >= a.n_chunks) return;
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
-    KpCtx<T, KP> cx(a, lds);
     const int K = cx.K, r = cx.r, c0 = cx.c0;
     const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start;
     cx.zero_pads();
@@ -279,18 +312,17 @@ __global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
     }
     const double ff = a.ff, iff = 1.0 / a.ff;
     for (int64_t i0 = rel0; i0 < rel1; i0 += KP_RB) {
-        const unsigned long long vm = cx.stage(G.start, i0, 0, rel0, rel1, false);
+        const unsigned vm = cx.stage(G.start, i0, 0, rel0, rel1, false);
         const int nb = (int)min((int64_t)KP_RB, rel1 - i0);
         double predv = 0.0;
         for (int t = 0; t < nb; ++t) {
-            KpRow<KP> x;
+            KpRow<KP, LPS> x;
             x.load(cx.xin + t * XS, r, c0);
+            // (requesting row t + 1 before this row's dependent chain was measured: the extra CPL + 2 registers cost a wave per SIMD -- 1.13 ->
+            // 1.25 ms at 12 features, 4.10 -> 4.69 ms at 32)
             double xb = kp_rowsum<KP>(x.xr * beta);                        // x'beta: the prediction of a row that does not update
             if ((vm >> t) & 1) {
-                double zp = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
-                const double z = kp_segsum<KP>(zp);                        // (P x)_r
+                const double z = kp_segsum<KP, LPS>(kp_dot<CPL>(P, x.xc));   // (P x)_r
                 const double d = kp_rowsum<KP>(x.xr * z);
                 const double rr = fma(d, iff, 1.0);                        // :533
                 const double g = kp_rcp(rr * ff);
@@ -323,14 +355,15 @@ __global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
 //   validity prefix (K4Args::cnt) and the per-group constants come from the device tables (dyn_prep.hip valid_tables_launch).
 struct KpMasks { unsigned vin, vout, gate; };
 
-template <typename T, int KP, bool MASKED>
+template <typename T, int KP, int LPS, bool MASKED>
 __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
-    constexpr int CPL = KpGeo<KP>::CPL, XS = KpGeo<KP>::XS;
-    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP>::lds_doubles()];
-    const int64_t c = blockIdx.x;
+    constexpr int CPL = KpGeo<KP, LPS>::CPL, XS = KpGeo<KP, LPS>::XS, KP_RB = KpGeo<KP, LPS>::RB;
+    __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP, LPS>::lds_doubles()];
+    KpCtx<T, KP, LPS> cx(a, lds);
+    const int64_t c = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
+    if (c >= a.n_chunks) return;
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
-    KpCtx<T, KP> cx(a, lds);
     const int K = cx.K, r = cx.r, c0 = cx.c0;
     const int64_t rel0 = ch.t0 - G.start, rel1 = ch.t1 - G.start, n = G.end - G.start;
     const int64_t w = a.window, mpv = G.mpv;
@@ -347,13 +380,13 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     double S[CPL], P[CPL], bsum = 0.0, beta = 0.0;
     const uint8_t *valid = a.valid ? a.valid + G.start : nullptr;
     const int32_t *cnt = a.cnt ? a.cnt + G.start : nullptr;
-    // what row i's block of 32 does: which rows enter, which rows i - window leave, which rows are solved
+    // what the rows of the block starting at i0 do: which enter, which rows i - window leave, which are solved
     auto masks = [&](int64_t i0, int64_t hi) -> KpMasks {
-        const int t = cx.lane & 31;
+        const int t = cx.lane % KP_RB;
         const int64_t i = i0 + t;
         bool vin = false, vout = false, gate = false;
         if (i < hi) {
-            if (cx.lane < 32) {
+            if (cx.lane < KP_RB) {
                 vin = MASKED ? valid[i] != 0 : true;
                 if (i >= mpv - 1) {
                     if constexpr (MASKED) {
@@ -367,7 +400,9 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
             }
         }
         const unsigned long long bi = __ballot(vin), bo = __ballot(vout), bg = __ballot(gate);
-        return KpMasks{(unsigned)bi, (unsigned)(bo >> 32), (unsigned)bg};
+        const unsigned long long m = (1ull << KP_RB) - 1ull;
+        const int sh = cx.sub * LPS;
+        return KpMasks{(unsigned)((bi >> sh) & m), (unsigned)((bo >> (sh + KP_RB)) & m), (unsigned)((bg >> sh) & m)};
     };
     // S, bsum += the valid rows of [lo, hi)
     auto accumulate = [&](int64_t lo, int64_t hi) {
@@ -375,10 +410,13 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
             cx.stage(G.start, j0, 0, 0, hi, false);
             const int nb = (int)min((int64_t)KP_RB, hi - j0);
             unsigned vm = 0xffffffffu;
-            if constexpr (MASKED) { const int64_t j = j0 + (cx.lane & 31); vm = (unsigned)__ballot(cx.lane < 32 && j < hi && valid[j] != 0); }
+            if constexpr (MASKED) {
+                const int64_t j = j0 + (cx.lane % KP_RB);
+                vm = (unsigned)((__ballot(cx.lane < KP_RB && j < hi && valid[j] != 0) >> (cx.sub * LPS)) & ((1ull << KP_RB) - 1ull));
+            }
             for (int t = 0; t < nb; ++t) {
                 if (!((vm >> t) & 1)) continue;
-                KpRow<KP> x;
+                KpRow<KP, LPS> x;
                 x.load(cx.xin + t * XS, r, c0);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
@@ -441,7 +479,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
         double predv = 0.0;
         for (int t = 0; t < nb; ++t) {
             const int64_t i = i0 + t;
-            KpRow<KP> x;
+            KpRow<KP, LPS> x;
             x.load(cx.xin + t * XS, r, c0);
             // ---- the row enters (NonWoodburyState::update, :707-725)
             if ((mk.vin >> t) & 1) {
@@ -449,10 +487,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                 for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
                 bsum = fma(x.xr, x.y, bsum);
                 if (inverted) {
-                    double zp = 0.0;
-#pragma unroll
-                    for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], x.xc[cc], zp);
-                    const double z = kp_segsum<KP>(zp);
+                    const double z = kp_segsum<KP, LPS>(kp_dot<CPL>(P, x.xc));
                     const double d = kp_rowsum<KP>(x.xr * z), xb = kp_rowsum<KP>(x.xr * beta);
                     const double g = kp_rcp(1.0 + d);
                     beta = fma(g * z, x.y - xb, beta);
@@ -464,16 +499,13 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
             }
             // ---- row i - window leaves
             if ((mk.vout >> t) & 1) {
-                KpRow<KP> o;
+                KpRow<KP, LPS> o;
                 o.load(cx.xout + t * XS, r, c0);
 #pragma unroll
                 for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(-o.xr, o.xc[cc], S[cc]);
                 bsum = fma(-o.xr, o.y, bsum);
                 if (inverted) {
-                    double zp = 0.0;
-#pragma unroll
-                    for (int cc = 0; cc < CPL; ++cc) zp = fma(P[cc], o.xc[cc], zp);
-                    const double z = kp_segsum<KP>(zp);
+                    const double z = kp_segsum<KP, LPS>(kp_dot<CPL>(P, o.xc));
                     const double d = kp_rowsum<KP>(o.xr * z), xb = kp_rowsum<KP>(o.xr * beta);
                     const double den = 1.0 - d;
                     if (!(den > 1e-6)) inverted = false;                   // the downdate collapses: back to the sums (wave-uniform)
@@ -524,22 +556,42 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     }
 }
 
-template <typename T, int KP>
+template <typename T, int KP, int LPS>
 static int kp_launch_kp(pols_ctx *ctx, const K4Args &a, bool rls, bool single_chunk) {
+    const unsigned blocks = (unsigned)((a.n_chunks + KpGeo<KP, LPS>::SEQ - 1) / KpGeo<KP, LPS>::SEQ);
     timing_begin(ctx);
     if (rls) {
         if (!single_chunk) {
-            hipLaunchKernelGGL((kp_totals_kernel<T, KP>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL((kp_totals_kernel<T, KP, LPS>), dim3(blocks), dim3(64), 0, ctx->stream, a);
             chunk_scan_launch(ctx, a, a.k * a.k + a.k, 2);
         }
-        hipLaunchKernelGGL((kp_rls_walk_kernel<T, KP>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((kp_rls_walk_kernel<T, KP, LPS>), dim3(blocks), dim3(64), 0, ctx->stream, a);
     } else {
-        if (a.valid) hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, true>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, false>), dim3((unsigned)a.n_chunks), dim3(64), 0, ctx->stream, a);
+        if constexpr (KpGeo<KP, LPS>::CPL <= 16) {
+            if (a.valid) hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, true>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, false>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+        }
     }
     timing_end(ctx);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
+}
+
+template <typename T>
+static int kp_launch_t(pols_ctx *ctx, const K4Args &a, bool rls, bool single_chunk) {
+    // Lanes per sequence.  Few chunks: a whole wave each (the most parallelism per chunk).  From 4 096 chunks on (a wave per SIMD even
+    // after packing) up to 16 features: four chunks per wave, each on its own 16-lane row; 17..32 features, RLS: two per wave from 16 384
+    // chunks (rolling would need a 32-entry row of the sums AND of the inverse per lane: over the register file).  POLS_K4P_LPS forces one.
+    int lps = 64;
+    if (a.k <= 16) lps = a.n_chunks >= 4096 ? 16 : 64;
+    else lps = (rls && a.n_chunks >= 16384) ? 32 : 64;
+    const int want = ctx->opt.k4p_lps;
+    if (want == 64) lps = 64;
+    else if (want == 16 && a.k <= 16) lps = 16;
+    else if (want == 32 && a.k > 16 && rls) lps = 32;
+    ctx->last_kernel += lps == 64 ? "" : (lps == 16 ? "_x4" : "_x2");
+    if (a.k <= 16) return lps == 16 ? kp_launch_kp<T, 16, 16>(ctx, a, rls, single_chunk) : kp_launch_kp<T, 16, 64>(ctx, a, rls, single_chunk);
+    return lps == 32 ? kp_launch_kp<T, 32, 32>(ctx, a, rls, single_chunk) : kp_launch_kp<T, 32, 64>(ctx, a, rls, single_chunk);
 }
 
 // single_chunk: no sequence was cut (every chunk starts its sequence).  Rolling: min_periods <= window, window <= 1 024 unless
@@ -549,8 +601,7 @@ int k4p_launch(pols_ctx *ctx, int dtype, const K4Args &a, bool rls, bool single_
     if (a.k > 32 || a.k < 1) return fail(POLS_ERR_UNSUPPORTED, "k4p: %d features", a.k);
     if (a.n_chunks <= 0) return POLS_OK;
     ctx->last_kernel = std::string(rls ? "k3p_rls_inverse_wave" : "k4p_rolling_inverse_wave") + (dtype == POLS_F32 ? "_f32" : "_f64");
-    if (a.k <= 16) return dtype == POLS_F32 ? kp_launch_kp<float, 16>(ctx, a, rls, single_chunk) : kp_launch_kp<double, 16>(ctx, a, rls, single_chunk);
-    return dtype == POLS_F32 ? kp_launch_kp<float, 32>(ctx, a, rls, single_chunk) : kp_launch_kp<double, 32>(ctx, a, rls, single_chunk);
+    return dtype == POLS_F32 ? kp_launch_t<float>(ctx, a, rls, single_chunk) : kp_launch_t<double>(ctx, a, rls, single_chunk);
 }
 
 }  // namespace pols

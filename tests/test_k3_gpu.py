@@ -89,6 +89,16 @@ def test_rls_wide_features(eng, dtype, tol, k, half_life, p0, mean):
     assert eng.last_kernel.startswith("k3s_rls_rows" if k <= 10 else "k3p_")     # (up to 10 features fit the row-parallel kernel; beyond: k4p_wide.hip)
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
     assert np.allclose(_np(out["pred"]), _masked(ref["pred"], valid), rtol=tol, atol=tol, equal_nan=True)
+    if k > 10:                                    # the same cut sequences with several chunks per wave (totals, scan and walk)
+        eng.set_option("K4P_LPS", "16" if k <= 16 else "32")
+        try:
+            out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), half_life=half_life,
+                                              initial_state_covariance=p0, initial_state_mean=mean0)
+            assert eng.last_kernel.endswith("_x4" if k <= 16 else "_x2"), eng.last_kernel
+        finally:
+            eng.set_option("K4P_LPS", None)
+        assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+        assert np.allclose(_np(out["pred"]), _masked(ref["pred"], valid), rtol=tol, atol=tol, equal_nan=True)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
@@ -285,3 +295,13 @@ def test_rls_wave_per_chunk_single_chunk_sequences(eng, dtype, tol, k, half_life
     finally:
         eng.set_option("RLS_ENGINE", None)
     assert np.allclose(_np(old["coef"]), got_c, rtol=tol, atol=tol)
+    # several sequences per wave (what a frame of >= 16 384 / 8 192 chunks takes by itself): four on 16-lane rows up to 16 features, two on
+    # 32 lanes beyond -- ragged lengths, so the sub-waves of a wave finish at different rows
+    eng.set_option("K4P_LPS", "16" if k <= 16 else "32")
+    try:
+        packed = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid), **kw)
+        assert eng.last_kernel.startswith("k3p_") and eng.last_kernel.endswith("_x4" if k <= 16 else "_x2"), eng.last_kernel
+    finally:
+        eng.set_option("K4P_LPS", None)
+    assert np.allclose(_np(packed["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(packed["coef"]) - ref["coef"]).max())
+    assert np.allclose(_np(packed["pred"]), _masked(ref["pred"], valid) if valid is not None else ref["pred"], rtol=tol, atol=tol, equal_nan=True)

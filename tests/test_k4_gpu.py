@@ -585,6 +585,17 @@ def test_rolling_wave_per_chunk_null_free(eng, dtype, tol, k, window, min_period
         eng.set_option("ROLLING_ENGINE", None)
     out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, null_policy="drop", **kw)
     assert np.allclose(_np(old["coef"])[well], _np(out["coef"])[well], rtol=tol, atol=tol)
+    if k <= 16:                                   # four chunks per wave on 16-lane rows (what a frame of >= 16 384 chunks takes by itself)
+        eng.set_option("K4P_LPS", "16")
+        try:
+            packed = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, null_policy="drop", **kw)
+            assert eng.last_kernel.startswith("k4p_") and eng.last_kernel.endswith("_x4"), eng.last_kernel
+        finally:
+            eng.set_option("K4P_LPS", None)
+        pc = _np(packed["coef"])
+        assert np.array_equal(np.isnan(pc)[pinned], np.isnan(ref["coef"])[pinned])
+        assert np.allclose(pc[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(pc[well] - ref["coef"][well]).max())
+        assert np.allclose(_np(packed["pred"])[well], ref["pred"][well], rtol=tol, atol=tol)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
@@ -634,3 +645,13 @@ def test_rolling_wave_per_chunk_drop_window_with_nulls(eng, dtype, tol, k, windo
     assert np.isnan(got_c[before]).all()
     strict = sane & (nobs >= k + 4) & np.isfinite(old_c).all(axis=1)
     assert np.allclose(got_c[strict], old_c[strict], rtol=10 * tol, atol=tol) or np.allclose(got_c[strict], ref["coef"][strict], rtol=10 * tol, atol=tol)
+    if k <= 16:                                   # four chunks per wave
+        eng.set_option("K4P_LPS", "16")
+        try:
+            packed = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
+            assert eng.last_kernel.endswith("_x4"), eng.last_kernel
+        finally:
+            eng.set_option("K4P_LPS", None)
+        pc = _np(packed["coef"])
+        assert np.allclose(pc[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(pc[well] - ref["coef"][well]).max())
+        assert np.isnan(pc[before]).all()
