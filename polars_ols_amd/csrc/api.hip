@@ -807,8 +807,12 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
     if (!(max_rows > 2 * seg_target) || ctx->opt.no_split) return POLS_OK;
     auto &sc = ctx->seg_cache;
     int rc;
-    const bool hit = sc.ptr && sc.ptr == ctx->scratch[23].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups && sc.n_rows == b->n_rows &&
-                     sc.seg_target == seg_target && sc.nz2 == extra_per_seg;
+    // (the key is the frame; the per-segment extra area only has to be large enough -- its users differ in what they keep there: the Gram
+    // partials of ls_core, the moments of the statistics entry, nothing for pols_predict -- and it is kept at the largest size asked for,
+    // so that alternating users of one frame stop rebuilding and re-uploading the tables)
+    const bool same_frame = sc.ptr && sc.ptr == ctx->scratch[23].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups && sc.n_rows == b->n_rows &&
+                            sc.seg_target == seg_target;
+    const bool hit = same_frame && sc.nz2 >= extra_per_seg;
     auto lay = [&](char *sb, int64_t n_seg) {
         const size_t b_so = round256(sizeof(int64_t) * (size_t)(n_seg + 1)), b_sm = round256(sizeof(int32_t) * (size_t)n_seg),
                      b_sf = round256(sizeof(int32_t) * (size_t)(b->n_groups + 1));
@@ -820,6 +824,7 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
         return b_so + b_sm + b_sf;
     };
     if (hit) { lay(static_cast<char *>(ctx->scratch[23].ptr), sc.n_seg); return POLS_OK; }
+    if (same_frame) extra_per_seg = std::max<size_t>(extra_per_seg, sc.nz2);
     sc.ptr = nullptr;
     std::vector<int64_t> so;
     std::vector<int32_t> sm, sf((size_t)b->n_groups + 1);
@@ -1390,8 +1395,7 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
     sa.coef = info.st.coef; sa.lambda = p->alpha; sa.status = info.st.status;
     sa.k_user = b->n_features; sa.kt = kt;
     {   // long groups (ONE model summary over a whole frame): the row passes run per segment
-        int64_t mr = 0;
-        for (int64_t g = 0; g < b->n_groups; ++g) mr = std::max(mr, b->group_offsets[g + 1] - b->group_offsets[g]);
+        const int64_t mr = ctx->offs_max_rows;                 // (of the offsets ls_core just uploaded: no O(groups) host loop per call)
         SegTables sg;
         const size_t per_seg = sizeof(double) * 5;
         if ((rc = ensure_segments(ctx, b, mr, per_seg, &sg))) return rc;

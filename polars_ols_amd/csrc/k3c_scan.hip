@@ -375,7 +375,18 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
         else cq.load(a.carry + t * K3C_NCP, lane);
         if (!a.all_closed && a.carry_open[t] && t >= 64) {
             K3cLaneVec<NT> bq;
-            bq.load(a.bcarry + (t >> 6) * K3C_NCP, lane);
+            if (a.fold_top) {
+                // the block's carry-in = the records of the blocks below it, from the last closed one on (what k3c_top_scan_kernel writes
+                // to bcarry): up to 63 independent 232-byte loads and one multiply-add each -- cheaper than a dependent launch between the passes
+                bq.identity(lane);
+                const int64_t blk = t >> 6;
+                for (int64_t b2 = 0; b2 < blk; ++b2) {
+                    K3cLaneVec<NT> eq;
+                    eq.load(a.brec + b2 * K3C_NCP, lane);
+                    if (a.brec_closed[b2]) bq = eq;                        // (wave-uniform)
+                    else bq.then(eq, eq.get_d(), lane);
+                }
+            } else bq.load(a.bcarry + (t >> 6) * K3C_NCP, lane);
             bq.then(cq, cq.get_d(), lane);
             cq = bq;
         }
@@ -450,12 +461,13 @@ static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
         a.dbg = static_cast<unsigned long long *>(dbg);
     }
     timing_begin(ctx);                                            // all launches of the call as one timed span
+    a.fold_top = (a.n_tiles + 63) / 64 <= 64 ? 1 : 0;             // (POLS_RLS_ENGINE is not consulted: both forms are the same arithmetic)
     K3cArgs a1 = a;
     a1.dbg = nullptr;
     if (!a.tile_row0) hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 0>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a1);
     if (!a.tile_row0 && !a.all_closed) {                                          // sequences longer than a tile: the records are scanned (two small launches)
         hipLaunchKernelGGL((k3c_block_scan_kernel<K4N<K>::N>), dim3((unsigned)((a.n_tiles + 63) / 64)), dim3(64), 0, ctx->stream, a1);
-        hipLaunchKernelGGL((k3c_top_scan_kernel<K4N<K>::N>), dim3(1), dim3(64), 0, ctx->stream, a1);
+        if (!a.fold_top) hipLaunchKernelGGL((k3c_top_scan_kernel<K4N<K>::N>), dim3(1), dim3(64), 0, ctx->stream, a1);
     }
     hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 1>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a);
     timing_end(ctx);

@@ -99,6 +99,8 @@ struct K3cArgs {
     double *rec, *carry, *brec, *bcarry;
     int32_t *rec_closed, *carry_open, *brec_closed;
     int64_t n_tiles;
+    int32_t fold_top;                  // set by the launcher: at most 64 blocks of tiles -- pass 2 composes its block's carry-in from the block records itself
+                                       // (a loop over <= 63 lane-vector records) and the one-wave top-level scan launch is skipped
     int32_t all_closed;                // no sequence is longer than a tile: every tile holds a sequence start, tile t's carry-in is tile t - 1's record
     const int64_t *tile_row0;          // PACKED tiles (or nullptr): tile t owns rows [tile_row0[t], tile_row0[t + 1]), whole sequences only, and
                                        // loads from tile_row0[t] & ~3 on -- no carry-in, so one launch (pass 2 alone) does the frame
