@@ -77,7 +77,8 @@ typedef enum {
 /* Per-group status written to pols_out.status. */
 typedef enum {
     POLS_GROUP_OK = 0,
-    POLS_GROUP_FALLBACK = 1, /* Cholesky failed, the reference's fallback solver was taken (ls.rs:299-327) */
+    POLS_GROUP_FALLBACK = 1, /* Cholesky failed, the reference's fallback solver was taken (ls.rs:299-327); also every group with FEWER rows
+                              * than columns under solve_method None / "svd": the reference picks the SVD for it by shape (ls.rs:224-231) */
     POLS_GROUP_EMPTY = 2,    /* no rows: coefficients are zeros (src/expressions.rs:357-359) */
     POLS_GROUP_NOT_CONVERGED = 3, /* coordinate descent hit max_iter (result still returned, like the reference) */
     POLS_GROUP_BAD_DOF = 4   /* statistics only: degrees of freedom <= 0; the reference panics the whole query here
@@ -202,10 +203,16 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
 
 /* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions.
  * DIVERGENCE (the row-parallel kernel: up to 10 features, min_periods <= window, windows up to 508 rows -- 252 at 7 to 10 features -- or
- * any window when no sequence is longer than 1 021 rows; null-free frames, and frames with nulls under the drop family): a window whose X'X has
- * no Cholesky factorisation -- fewer than k independent rows -- yields NaN coefficients; the reference falls back to LU there
- * (ls.rs:732-734) and returns whatever a zero or noise pivot produces (inf / NaN / 1e15-sized numbers).
- * pols_set_option("ROLLING_ENGINE", "chunk") selects the kernels that run the LU. */
+ * any window when no sequence is longer than 1 021 rows; null-free frames, and frames with nulls under the drop family; and the
+ * wave-per-chunk kernel of 9 to 32 features, round 5: min_periods <= window, windows up to 1 024 rows or sequences of up to 1 024 rows,
+ * null-free frames, "drop" with nulls, "drop_window" with validity bytes): a window whose X'X has no Cholesky factorisation -- fewer than k
+ * independent rows -- yields NaN coefficients; the reference falls back to LU there (ls.rs:732-734) and returns whatever a zero or noise
+ * pivot produces (inf / NaN / 1e15-sized numbers).  tests/test_k4_gpu.py::test_rolling_divergence_band_is_pinned holds the NaN rows of the
+ * default route to the rows where the reference has fewer than k observations or no usable (finite, < 1e3) answer itself.
+ * pols_set_option("ROLLING_ENGINE", "chunk") selects the kernels that run the LU.
+ * p->use_woodbury is accepted and does not select a code path: up to 8 features (and wherever the chunk kernels run) the sums are
+ * re-factored per row, from 9 features on the inverse is propagated with Sherman-Morrison updates whatever the flag says (the
+ * reference's WoodburyState arithmetic, ls.rs:737-787, rebuilt from the sums every 128 rows) -- same mathematics, different rounding. */
 int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rolling_params *p, pols_out *o);
 
 /* Replaces the `predict` plugin body (src/expressions.rs:706-741): row-wise sum_j x[t,j] * coef[t,j].  `coef` holds one
