@@ -50,6 +50,19 @@ def _window_obs(offs, valid, window, policy):
     return out
 
 
+def _window_matrix(offs, valid, X, i, window, policy):
+    """the feature rows whose outer products make up row i's window state (the rows the reference's deque / fixed window holds)"""
+    g = int(np.searchsorted(offs, i, side="right") - 1)
+    s = int(offs[g])
+    v = np.ones(i + 1 - s, dtype=bool) if valid is None else np.asarray(valid[s:i + 1]).astype(bool)
+    idx = s + np.flatnonzero(v)
+    if policy == "drop":
+        idx = idx[-window:]                            # the last `window` VALID rows
+    else:
+        idx = idx[idx > i - window]                    # the valid rows among the last `window` rows
+    return X[idx]
+
+
 @pytest.mark.parametrize("policy", ["drop", "drop_window"])
 @pytest.mark.parametrize("k,window,min_periods,alpha,null_frac", [
     (1, 2, None, None, 0.0), (2, 2, 2, None, 0.1), (2, 10, 2, None, 0.1), (5, 63, 5, None, 0.2), (6, 252, None, None, 0.0),
@@ -73,9 +86,20 @@ def test_rolling_many_groups(eng, policy, k, window, min_periods, alpha, null_fr
     nobs = _window_obs(offs, valid, window, policy)
     sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
     strict = sane & (nobs >= k + 2)
-    assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
     vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
-    assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
+    # k + 2 ... 2k - 1 observations: north_star's 1e-6 too, unless THIS window's conditioning does not allow it -- then the bound is
+    # cond(X'X) eps of the window itself (recorded per row: VERDICT r04 asked for 1e-6 "or record per case why not")
+    X = np.stack(cols, axis=1)
+    loosened = 0
+    for i in np.flatnonzero(strict & (nobs < 2 * k)):
+        Xw = _window_matrix(offs, valid, X, int(i), window, policy)
+        tol_i = max(1e-6, 1e3 * np.linalg.cond(Xw.T @ Xw) * np.finfo(np.float64).eps)
+        loosened += tol_i > 1e-6
+        assert np.allclose(got_c[i], ref["coef"][i], rtol=tol_i, atol=tol_i), (int(i), int(nobs[i]), tol_i, got_c[i], ref["coef"][i])
+        if vm[i]:
+            assert np.isclose(got_p[i], ref["pred"][i], rtol=10 * tol_i, atol=10 * tol_i)
+    assert loosened <= 0.25 * max(1, int((strict & (nobs < 2 * k)).sum()))
+    assert np.isnan(got_p[~vm]).all()
     assert window < k + 2 or strict.sum() > 0.5 * sane.sum()
     well = sane & (nobs >= 2 * k)                                    # north_star's 1e-6 wherever the window holds 2k observations
     assert np.allclose(got_c[well], ref["coef"][well], rtol=1e-6, atol=1e-6), float(np.abs(got_c[well] - ref["coef"][well]).max())
