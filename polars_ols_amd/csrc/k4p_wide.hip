@@ -441,11 +441,13 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
             for (int cc = 0; cc < CPL; ++cc) S[cc] += (c0 + cc == r && r < K) ? a.alpha : 0.0;
         }
     };
-    auto solve_fresh = [&](double (&M)[CPL], bool &ok, double &ratio) -> double {
+    // the sums inverted afresh INTO P (whatever P held is dead: either nothing was propagated, or it is being rebuilt) -- no second
+    // CPL-register copy next to S and P
+    auto solve_fresh = [&](bool &ok, double &ratio) -> double {
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) M[cc] = S[cc];
-        cx.invert(M, ok, ratio);
-        return cx.matvec(M, bsum);
+        for (int cc = 0; cc < CPL; ++cc) P[cc] = S[cc];
+        cx.invert(P, ok, ratio);
+        return cx.matvec(P, bsum);
     };
 #pragma unroll
     for (int cc = 0; cc < CPL; ++cc) { S[cc] = 0.0; P[cc] = 0.0; }
@@ -461,8 +463,8 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                     if ((int64_t)cnt[ip] - (int64_t)cnt[is] >= G.gate_n) break;
                 }
                 state_after(ip);
-                double M[CPL]; bool ok; double ratio;
-                last = solve_fresh(M, ok, ratio);
+                bool ok; double ratio;
+                last = solve_fresh(ok, ratio);
                 last_good = ok;
                 if (ip != rel0 - 1) state_after(rel0 - 1);
             } else state_after(rel0 - 1);
@@ -529,17 +531,11 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
             if ((mk.gate >> t) & 1) {
                 ++since;
                 if (!inverted || since >= KP_REFRESH) {
-                    double M[CPL];
                     bool ok; double ratio;
-                    const double bnew = solve_fresh(M, ok, ratio);
+                    const double bnew = solve_fresh(ok, ratio);
                     good = ok; bout = bnew;
                     inverted = ok && may_propagate && ratio > KP_SWITCH_RATIO;
-                    if (inverted) {
-#pragma unroll
-                        for (int cc = 0; cc < CPL; ++cc) P[cc] = M[cc];
-                        beta = bnew;
-                        since = 0;
-                    }
+                    if (inverted) { beta = bnew; since = 0; }
                 } else {
                     good = true; bout = beta;
                 }
