@@ -765,6 +765,14 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
     if (enet) {
         if ((rc = wide_cd_launch(ctx, b->dtype, a))) return rc;
     } else {
+        // (known before the factorisation: wide_chol flags a group with fewer fit rows than columns BY SHAPE under solve_method None / "svd",
+        // where the reference picks the SVD without factoring anything, ls.rs:224-231 -- the last pivots of a rank-deficient Gram matrix can
+        // come out as positive noise above the threshold)
+        {
+            const int sm0 = p->solve_method;
+            a.fix_mode = ols_branch ? (m > 1 ? FIX_MINNORM : sm0 == POLS_SOLVE_AUTO ? FIX_OLS_AUTO : sm0 == POLS_SOLVE_QR ? FIX_OLS_QR : FIX_MINNORM)
+                                    : ((sm0 == POLS_SOLVE_SVD || m > 1) ? FIX_MINNORM : sm0 == POLS_SOLVE_LU ? FIX_LU : FIX_CHOL_LU);
+        }
         if ((rc = wide_chol_launch(ctx, b->dtype, a))) return rc;
         int workers = (int)std::min<size_t>(G, 64);
         void *wk = nullptr;

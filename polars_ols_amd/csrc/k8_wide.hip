@@ -231,9 +231,12 @@ __global__ void __launch_bounds__(NTHREADS) wide_chol_kernel(const WideArgs a) {
     }
     // A[kt + t][j] = d_j z_j with z the forward solution of target t; back substitution
     //   x_j = (A[kt + t][j] - sum_{i > j} A[i][j] x_i) / d_j
+    // fewer fit rows than columns under solve_method None / "svd": the reference takes the SVD by SHAPE (ls.rs:224-231) -- flagged whatever
+    // the pivots of this singular matrix happened to round to (alpha > 0, the ridge branch, is positive definite and keeps its answer)
+    const bool by_shape = n < (int64_t)kt && a.alpha == 0.0 && (a.fix_mode == FIX_OLS_AUTO || a.fix_mode == FIX_MINNORM);
     int st = POLS_GROUP_OK;
     if (n == 0) st = POLS_GROUP_EMPTY;
-    else if (!ok_s) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
+    else if (!ok_s || by_shape) { st = POLS_GROUP_FALLBACK; if (tid == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
     for (int t = 0; t < m; ++t) {
         __syncthreads();
         for (int i = tid; i < kt; i += NTHREADS) xs[i] = A[(size_t)(kt + t) * LD + i];

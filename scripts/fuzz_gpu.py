@@ -133,6 +133,83 @@ for it in range(N_DYN2):
         bad += 1
         print("DYN2 ERROR", it, dtype.__name__, k, G, top, repr(exc)[:200])
 print("row-parallel dynamic cases ran:", dict(sorted(seen2.items())))
+# ---- round 5: K4p / K3p (9..32 features, wave per chunk, forced sub-wave packings), DEVICE columns and validity bytes (the device-built
+# validity prefix), and K6s (groups with no more rows than columns)
+import torch
+N_DYN3 = int(os.environ.get("FUZZ_DYN3", "60")); seen3 = {}
+for it in range(N_DYN3):
+    dtype = np.float64 if rng.random() < 0.7 else np.float32
+    k = int(rng.integers(9, 33)); G = int(rng.integers(1, 60))
+    top = int(rng.choice([40, 300, 1024, 1100, 2600]))
+    y, cols, offs, _ = frame(G, int(rng.choice([0, 1, top // 2])), top, k, dtype)
+    if len(y) < 8:
+        continue
+    valid = None if rng.random() < 0.5 else (rng.random(len(y)) > float(rng.choice([0.05, 0.3]))).astype(np.uint8)
+    tol = 2e-6 if dtype == np.float64 else 2e-3
+    lps = str(rng.choice(["64", "16" if k <= 16 else "32", ""]))
+    eng.set_option("K4P_LPS", lps or None)
+    yd = torch.from_numpy(y).cuda(); cd = [torch.from_numpy(c).cuda() for c in cols]; vd = None if valid is None else torch.from_numpy(valid).cuda()
+    try:
+        if rng.random() < 0.45:
+            hl = None if rng.random() < 0.3 else float(rng.uniform(5, 300))
+            p0 = float(rng.choice([1.0, 10.0, 1e4]))
+            out = eng.recursive_least_squares(yd, cd, offs, valid=vd, half_life=hl, initial_state_covariance=p0, null_free=valid is None)
+            ref = orc.batched_rls(y, cols, offs, half_life=hl, initial_state_covariance=p0, is_valid=valid)
+            vm = np.ones(len(y), dtype=bool) if valid is None else valid.astype(bool)
+            oc, op = out["coef"].double().cpu().numpy(), out["pred"].double().cpu().numpy()
+            ok = np.allclose(oc, ref["coef"], rtol=tol, atol=tol) and np.allclose(op[vm], ref["pred"][vm], rtol=tol, atol=tol) and np.isnan(op[~vm]).all()
+            what = ("rls", hl, p0, lps)
+        else:
+            win = int(rng.integers(max(2, k), 1300)); pol = str(rng.choice(["drop", "drop_window"]))
+            mp = int(rng.integers(1, win + 1)) if rng.random() < 0.4 else None
+            alpha = None if rng.random() < 0.7 else float(rng.uniform(0.01, 1.0))
+            out = eng.rolling_least_squares(yd, cd, offs, valid=vd, window_size=win, min_periods=mp, alpha=alpha, null_policy=pol, null_free=valid is None)
+            ref = orc.batched_rolling(y, cols, offs, win, min_periods=mp, alpha=alpha, null_policy=pol, is_valid=valid)
+            sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e2)
+            v = np.ones(len(y), dtype=np.int64) if valid is None else valid.astype(np.int64); nobs = np.zeros(len(y), dtype=np.int64)
+            for g in range(G):
+                s_, e_ = offs[g], offs[g + 1]; c = np.cumsum(v[s_:e_])
+                if pol == "drop": nobs[s_:e_] = np.minimum(c, win)
+                else: nobs[s_:e_] = c - np.concatenate([np.zeros(min(win, e_ - s_), dtype=np.int64), c[: max(0, e_ - s_ - win)]])
+            m = sane & ((nobs >= 2 * k + 4) | (alpha is not None))
+            vm = v.astype(bool)
+            rt = 10 * tol
+            oc, op = out["coef"].double().cpu().numpy(), out["pred"].double().cpu().numpy()
+            ok = (np.allclose(oc[m], ref["coef"][m], rtol=rt, atol=rt) and np.allclose(op[m & vm], ref["pred"][m & vm], rtol=rt, atol=rt)
+                  and np.isnan(op[~vm]).all() and np.isnan(oc[np.isnan(ref["coef"]).all(axis=1)]).all())
+            what = ("rolling", win, mp, alpha, pol, lps)
+        seen3[eng.last_kernel] = seen3.get(eng.last_kernel, 0) + 1
+        if not ok:
+            bad += 1
+            print("DYN3 MISMATCH", it, dtype.__name__, "k", k, "G", G, "top", top, "valid", valid is not None, what, eng.last_kernel)
+    except Exception as exc:
+        bad += 1
+        print("DYN3 ERROR", it, dtype.__name__, k, G, top, repr(exc)[:200])
+eng.set_option("K4P_LPS", None)
+print("wave-per-chunk dynamic cases ran:", dict(sorted(seen3.items())))
+for it in range(int(os.environ.get("FUZZ_SHORT", "30"))):
+    dtype = np.float64 if rng.random() < 0.5 else np.float32
+    k = int(rng.integers(2, 32)); G = int(rng.integers(1, 4000)); icpt = bool(rng.random() < 0.3); wts = bool(rng.random() < 0.3)
+    kt = k + int(icpt)
+    y, cols, offs, w = frame(G, int(rng.choice([0, 1])), int(rng.choice([max(1, kt - 1), kt, min(32, kt + 3)])), k, dtype)
+    if len(y) < 4:
+        continue
+    method = rng.choice([None, "svd"])
+    w = w if wts else None
+    try:
+        out = eng.least_squares(y, cols, offs, weights=w, add_intercept=icpt, solve_method=method, want=("coef", "pred", "status"))
+        ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, solve_method=method)
+        sizes = np.diff(offs); under = sizes < kt                      # under-determined groups: the minimum-norm solution is unique
+        tol = 2e-6 if dtype == np.float64 else 2e-3
+        rows = np.repeat(under, sizes)
+        ok = np.allclose(out["coef"][under], ref["coef"][under], rtol=tol, atol=tol) and np.allclose(out["pred"][rows], ref["pred"][rows], rtol=tol, atol=tol)
+        if not ok:
+            bad += 1
+            print("SHORT MISMATCH", it, dtype.__name__, "k", k, "G", G, "icpt", icpt, "w", wts, method, eng.last_kernel,
+                  float(np.nanmax(np.abs(out["coef"][under] - ref["coef"][under]))))
+    except Exception as exc:
+        bad += 1
+        print("SHORT ERROR", it, dtype.__name__, k, G, method, repr(exc)[:200])
 # ---- null policies (static models; expected values composed like the reference composes them: tests/test_nulls_gpu.py::_expected)
 from test_nulls_gpu import _expected
 for it in range(80):

@@ -225,6 +225,7 @@ def test_ridge_svd_honours_rcond_on_every_group(eng, dtype, rcond):
     (8, (4, 4), False, False, None), (8, (1, 8), False, False, None), (8, (1, 9), True, True, None), (3, (1, 3), False, False, "svd"),
     (8, (2, 30), False, True, "svd"), (12, (1, 12), True, False, None), (16, (5, 16), False, False, None), (20, (1, 20), False, True, None),
     (31, (1, 31), False, False, None), (31, (20, 32), False, False, "svd"), (5, (1, 5), False, False, None),
+    (31, (1, 32), True, True, None),              # 32 columns with the intercept: the wide path (K8) flags such groups by shape too (fuzz seed 101)
 ])
 def test_short_groups_take_the_team_min_norm_solver(eng, dtype, tol, k, rows, add_intercept, weights, method):
     """K6s (k6s_small.hip): groups with no more rows than columns -- `solve_ols`'s own n <= k -> SVD branch (ls.rs:211-240,
