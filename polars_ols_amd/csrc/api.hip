@@ -1843,7 +1843,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     // (11..32 features, and 9 / 10 where the tile kernel's window / alignment conditions fail: the same compaction in front of the
     // wave-per-chunk kernel K4p, k4p_wide.hip)
     const bool c_tiles_ok = k <= K4C_KMAX && (w <= k4c_max_window(k) || max_rows <= K4C_PACKED_ROWS - 3);
-    const bool c_wave_ok = k > K4_KMAX && k <= POLS_MAX_FEATURES && (w <= 1024 || max_rows <= 1024);
+    const bool c_wave_ok = k > K4_KMAX && k <= POLS_MAX_FEATURES;
     bool tiles_c = !tiles && drop && st.valid != nullptr && mp <= w && (c_tiles_ok || c_wave_ok) &&
                    ctx->opt.rolling_engine != 1 && ctx->opt.rolling_engine != 3 && b->n_rows >= 8;
     if (tiles_c) {
@@ -1907,6 +1907,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
                 a.coef = dc; a.pred = nullptr;
                 a.window = w; a.alpha = p->alpha > 0.0 ? p->alpha : 0.0; a.k = k; a.drop_mode = 1;
                 a.tot_cs = k * k + k; a.tot_qs = 1;
+                a.use_totals = (max_c > pchunk && w > 1024) ? 1 : 0;
                 if ((rc = k4p_launch(ctx, b->dtype, a, false, max_c <= pchunk))) return rc;
                 ra.coef_c = dc; ra.coef = st.coef; ra.pred = st.pred;
                 if ((rc = row_compact_expand_launch(ctx, b->dtype, ra))) return rc;
@@ -1968,7 +1969,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     const int64_t pchunk = max_rows <= 1024 ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
     // ... and the FIXED window over rows ("drop_window") on frames with validity bytes on the device: the same kernel with the rows masked
     // and the solves gated (the validity prefix is built on the device, dyn_prep.hip)
-    const bool wave_p = wide && !xwide && mp <= w && (max_rows <= pchunk || w <= 1024) && ctx->opt.rolling_engine != 1 &&
+    const bool wave_p = wide && !xwide && mp <= w && ctx->opt.rolling_engine != 1 &&
                         (st.valid == nullptr || (!drop && ds.tables.valid != nullptr && ds.tables.mem == POLS_MEM_DEVICE));
     const int64_t minc = wave_p ? pchunk : (k > 128 ? hbm_state_chunk(b->n_rows) : 64);
     if ((rc = build_chunk_tables(ctx, &ds.tables, mp, wide ? k * k + k : k * (k + 1) / 2 + k, &a, minc, wave_p ? pchunk : std::max<int64_t>(512, minc)))) return rc;
@@ -1979,7 +1980,10 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     a.k = k; a.drop_mode = drop ? 1 : 0;
     if (wide) { a.tot_cs = k * k + k; a.tot_qs = 1; }
     else { a.tot_cs = 1; a.tot_qs = a.n_chunks; }
-    if (wave_p) rc = k4p_launch(ctx, b->dtype, a, false, max_rows <= pchunk);
+    if (wave_p) {
+        a.use_totals = (max_rows > pchunk && w > 1024) ? 1 : 0;    // cut sequences, a window too long to re-sum at every chunk start
+        rc = k4p_launch(ctx, b->dtype, a, false, max_rows <= pchunk);
+    }
     else rc = k > K4X_KMAX ? k4y_launch(ctx, b->dtype, a) : xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a));
     if (rc) return rc;
     if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;

@@ -244,7 +244,7 @@ struct KpCtx {
 };
 
 // ------------------------------------------------------------------ RLS: per-chunk decayed sums (only for sequences cut into chunks)
-template <typename T, int KP, int LPS>
+template <typename T, int KP, int LPS, bool RLS>
 __global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
     constexpr int CPL = KpGeo<KP, LPS>::CPL, XS = KpGeo<KP, LPS>::XS, KP_RB = KpGeo<KP, LPS>::RB;
     __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP, LPS>::lds_doubles()];
@@ -266,10 +266,11 @@ __global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
             if (!((vm >> t) & 1)) continue;
             KpRow<KP, LPS> x;
             x.load(cx.xin + t * XS, cx.r, cx.c0);
+            const double ffr = RLS ? a.ff : 1.0;                           // (rolling: plain sums of the chunk's valid rows)
 #pragma unroll
-            for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], a.ff * S[cc]);
-            b = fma(x.xr, x.y, a.ff * b);
-            decay *= a.ff;
+            for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], ffr * S[cc]);
+            b = fma(x.xr, x.y, ffr * b);
+            decay *= ffr;
         }
         kp_sync();
     }
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
             if (cx.c0 + cc < K) out[cx.r * K + cx.c0 + cc] = S[cc];
         if (cx.seg == 0) out[K * K + cx.r] = b;
     }
-    if (cx.lane == 0) out[K * K + K] = decay;
+    if (RLS && cx.lane == 0) out[K * K + K] = decay;
 }
 
 // ------------------------------------------------------------------ RLS walk (RecursiveLeastSquares::update, literally)
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     const uint8_t *valid = a.valid ? a.valid + G.start : nullptr;
     const int32_t *cnt = a.cnt ? a.cnt + G.start : nullptr;
     // what the rows of the block starting at i0 do: which enter, which rows i - window leave, which are solved
-    auto masks = [&](int64_t i0, int64_t hi) -> KpMasks {
+    auto masks = [&](int64_t i0, int64_t hi) __attribute__((always_inline)) -> KpMasks {
         const int t = cx.lane % KP_RB;
         const int64_t i = i0 + t;
         bool vin = false, vout = false, gate = false;
@@ -404,8 +405,8 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
         const int sh = cx.sub * LPS;
         return KpMasks{(unsigned)((bi >> sh) & m), (unsigned)((bo >> (sh + KP_RB)) & m), (unsigned)((bg >> sh) & m)};
     };
-    // S, bsum += the valid rows of [lo, hi)
-    auto accumulate = [&](int64_t lo, int64_t hi) {
+    // S, bsum += sign * the valid rows of [lo, hi)
+    auto accumulate = [&](int64_t lo, int64_t hi, double sign) __attribute__((always_inline)) {
         for (int64_t j0 = lo; j0 < hi; j0 += KP_RB) {
             cx.stage(G.start, j0, 0, 0, hi, false);
             const int nb = (int)min((int64_t)KP_RB, hi - j0);
@@ -418,23 +419,39 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                 if (!((vm >> t) & 1)) continue;
                 KpRow<KP, LPS> x;
                 x.load(cx.xin + t * XS, r, c0);
+                const double sx = sign * x.xr;
 #pragma unroll
-                for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(x.xr, x.xc[cc], S[cc]);
-                bsum = fma(x.xr, x.y, bsum);
+                for (int cc = 0; cc < CPL; ++cc) S[cc] = fma(sx, x.xc[cc], S[cc]);
+                bsum = fma(sx, x.y, bsum);
             }
             kp_sync();
         }
     };
+    // ... the same from the scanned per-chunk totals when the range is long (cut sequences with a window beyond 1 024 rows, expanding
+    // windows included): rows [0, p) = the exclusive prefix at p's chunk + the rows of that chunk in front of p
+    auto prefix = [&](int64_t p, double sign) __attribute__((always_inline)) {
+        const int64_t ci = p / a.chunk_len;
+        const double *tot = a.totals + (size_t)(G.first_chunk + ci) * a.tot_cs;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) S[cc] += (r < K && c0 + cc < K) ? sign * tot[r * K + c0 + cc] : 0.0;
+        bsum += r < K ? sign * tot[K * K + r] : 0.0;
+        accumulate(ci * a.chunk_len, p, sign);
+    };
+    auto add_range = [&](int64_t lo, int64_t hi) __attribute__((always_inline)) {
+        if (hi <= lo) return;
+        if (!a.use_totals || hi - lo <= 2 * (int64_t)a.chunk_len) accumulate(lo, hi, 1.0);
+        else { prefix(hi, 1.0); prefix(lo, -1.0); }
+    };
     // the sums after row ip (>= 0): the valid rows the sliding loop has not dropped yet (+ alpha I once the warm-up row has passed, :924-926)
-    auto state_after = [&](int64_t ip) {
+    auto state_after = [&](int64_t ip) __attribute__((always_inline)) {
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) S[cc] = 0.0;
         bsum = 0.0;
-        if (ip < mpv) accumulate(0, ip + 1);                       // (nothing is subtracted before the sliding loop starts)
+        if (ip < mpv) add_range(0, ip + 1);                        // (nothing is subtracted before the sliding loop starts)
         else {
             const int64_t lo = max(ip - w + 1, (int64_t)0);
-            if (j_min > 0) accumulate(0, min(j_min, lo));          // rows older than j_min are never dropped
-            accumulate(lo, ip + 1);
+            if (j_min > 0) add_range(0, min(j_min, lo));           // rows older than j_min are never dropped
+            add_range(lo, ip + 1);
         }
         if (ip >= mpv - 1 && a.alpha != 0.0) {
 #pragma unroll
@@ -443,7 +460,7 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     };
     // the sums inverted afresh INTO P (whatever P held is dead: either nothing was propagated, or it is being rebuilt) -- no second
     // CPL-register copy next to S and P
-    auto solve_fresh = [&](bool &ok, double &ratio) -> double {
+    auto solve_fresh = [&](bool &ok, double &ratio) __attribute__((always_inline)) -> double {
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) P[cc] = S[cc];
         cx.invert(P, ok, ratio);
@@ -558,11 +575,15 @@ static int kp_launch_kp(pols_ctx *ctx, const K4Args &a, bool rls, bool single_ch
     timing_begin(ctx);
     if (rls) {
         if (!single_chunk) {
-            hipLaunchKernelGGL((kp_totals_kernel<T, KP, LPS>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL((kp_totals_kernel<T, KP, LPS, true>), dim3(blocks), dim3(64), 0, ctx->stream, a);
             chunk_scan_launch(ctx, a, a.k * a.k + a.k, 2);
         }
         hipLaunchKernelGGL((kp_rls_walk_kernel<T, KP, LPS>), dim3(blocks), dim3(64), 0, ctx->stream, a);
     } else {
+        if (a.use_totals) {                                        // plain per-chunk sums + their exclusive prefix (mode 0)
+            hipLaunchKernelGGL((kp_totals_kernel<T, KP, LPS, false>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+            chunk_scan_launch(ctx, a, a.k * a.k + a.k, 0);
+        }
         if constexpr (KpGeo<KP, LPS>::CPL <= 16) {
             if (a.valid) hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, true>), dim3(blocks), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, false>), dim3(blocks), dim3(64), 0, ctx->stream, a);

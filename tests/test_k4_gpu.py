@@ -567,6 +567,7 @@ def test_rolling_divergence_band_is_pinned(eng, k, window, min_periods):
     (11, 252, None, None, "groups"), (12, 100, 12, None, "long"), (12, 30, 1, None, "groups"), (16, 64, 16, 0.5, "long"), (17, 40, 17, None, "groups"),
     (24, 300, None, None, "long"), (32, 252, 32, None, "groups"), (32, 1000, 40, None, "long"), (12, 1_000_000, 12, None, "groups"),
     (13, 14, 13, None, "groups"), (20, 2000, None, 0.1, "groups"), (9, 600, 9, None, "long"),
+    (12, 1_000_000, 12, None, "long"), (17, 1500, None, None, "long"), (32, 1025, 40, 0.2, "long"),   # cut sequences, windows beyond 1 024 rows: chunk starts from the scanned totals
 ])
 def test_rolling_wave_per_chunk_null_free(eng, dtype, tol, k, window, min_periods, alpha, shape):
     """K4p (k4p_wide.hip): 9..32 features on null-free frames.  "groups": no sequence beyond 1 024 rows (one chunk each, any window --
@@ -626,6 +627,7 @@ def test_rolling_wave_per_chunk_null_free(eng, dtype, tol, k, window, min_period
 @pytest.mark.parametrize("k,window,min_periods,alpha,null_frac,shape", [
     (12, 100, 12, None, 0.05, "long"), (11, 252, None, None, 0.03, "groups"), (16, 64, 16, 0.5, 0.3, "long"), (24, 300, 30, None, 0.1, "long"),
     (32, 400, None, None, 0.05, "groups"), (9, 30, 9, None, 0.5, "groups"), (12, 60, 3, None, 0.1, "groups"), (14, 2000, 20, None, 0.2, "groups"),
+    (12, 1500, 12, None, 0.1, "long"), (16, 1_000_000, None, None, 0.05, "long"),
 ])
 def test_rolling_wave_per_chunk_drop_window_with_nulls(eng, dtype, tol, k, window, min_periods, alpha, null_frac, shape):
     """K4p, masked form: the FIXED window over rows with validity bytes ("drop_window", ls.rs:987-1029) -- invalid rows neither enter nor
