@@ -187,6 +187,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
     else if (ieq(key, "K1_XCD")) o.k1_xcd = on ? std::atoi(v) : d.k1_xcd;
     else if (ieq(key, "K4P_LPS")) o.k4p_lps = on ? std::atoi(v) : d.k4p_lps;
+    else if (ieq(key, "SEG_TARGET")) o.seg_target = on ? std::atoi(v) : d.seg_target;
     else if (ieq(key, "DEBUG_SKIP_FIXUP")) o.debug_skip_fixup = on && std::atoi(v) != 0;
     else if (ieq(key, "K1_PERSIST")) o.k1_persist = on ? (std::atoi(v) != 0) : d.k1_persist;
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
@@ -204,7 +205,7 @@ void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
-                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS"};
+                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);
@@ -811,7 +812,8 @@ struct SegTables {
 };
 static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows, size_t extra_per_seg, SegTables *t) {
     *t = SegTables();
-    const int64_t seg_target = std::max<int64_t>(4096, ((b->n_rows / std::max<int64_t>(1, 8 * (int64_t)ctx->num_cus) + 1023) / 1024) * 1024);
+    const int64_t seg_target = ctx->opt.seg_target > 0 ? std::max<int64_t>(256, ctx->opt.seg_target)
+                                                      : std::max<int64_t>(4096, ((b->n_rows / std::max<int64_t>(1, 8 * (int64_t)ctx->num_cus) + 1023) / 1024) * 1024);
     if (!(max_rows > 2 * seg_target) || ctx->opt.no_split) return POLS_OK;
     auto &sc = ctx->seg_cache;
     int rc;
@@ -1028,7 +1030,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // over-resident shapes (rows beyond K1's registers, tile within LDS) it now beats K1m everywhere measured but f32 with 9-10
         // columns -- f64 9 / 12 / 15 columns x 1 100 rows: 434 / 447 / 455 us against 468 / 562 / 722; f32 x 2 200 rows: 358 / 364 / 366
         // against 306 / 371 / 442 (profiles/r03_ab_overresident.txt).
-        const bool k1m_wins = k1m_takes && f32 && kt <= 10;
+        // Round 5, re-measured at 8 columns (f32 groups of 2 049..4 096 rows -- ten years of trading days per asset): K2 wins there too, 0.165 /
+        // 0.143 / 0.119 ms against K1m's 0.189 / 0.177 / 0.156 on 4 000 x 2 500, 3 333 x 3 000 and 2 500 x 4 000 rows; K1m keeps 9-10 columns.
+        const bool k1m_wins = k1m_takes && f32 && kt >= 9 && kt <= 10;
         const bool want = enet || m == POLS_SOLVE_LU || ctx->opt.static_engine == 2 || (!k1_resident && !legacy_forced && !k1m_wins);
         if (k2_ok && want) {
             K2Args a2;
@@ -1137,6 +1141,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             std::memset(&ra, 0, sizeof(ra));
             ra.part = gram_part; ra.nv_part = nv_part; ra.first = seg_first;
             ra.gram = static_cast<double *>(scr); ra.nvalid = nvalid; ra.n_groups = b->n_groups; ra.nz2 = (int32_t)(nz * nz);
+            ra.max_segments = (int32_t)std::min<int64_t>(1 << 30, (max_rows + 255) / 256);   // (an upper bound is enough: segments are at least 256 rows)
             if ((rc = gram_reduce_launch(ctx, ra))) return rc;
             ga.gram = static_cast<double *>(scr);
             ctx->last_kernel += "_split";

@@ -269,15 +269,16 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     return POLS_OK;
 }
 
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const GramReduceArgs a) {
+template <int NW>   // waves per workgroup: 4, or 16 when some group has hundreds of segments (ONE regression over a 10 M-row frame: 1 954)
+__global__ void __launch_bounds__(64 * NW) gram_reduce_kernel(const GramReduceArgs a) {
     // one workgroup per (group, 64 matrix entries): a lane per entry (coalesced), the four waves take a quarter of the segments each,
     // eight loads in flight per lane (a plain loop was one load latency per segment: 243 us for the 2 048 segments of a 10M-row group);
     // the wave sums meet in LDS in wave order -- the order of the additions depends on nothing but the segment list
-    __shared__ double part[4][64];
+    __shared__ double part[NW][64];
     const int64_t g = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v0 = a.first[g], v1 = a.first[g + 1];
-    const int per = (v1 - v0 + 3) / 4, va = v0 + wave * per < v1 ? v0 + wave * per : v1, vb = va + per < v1 ? va + per : v1;
+    const int per = (v1 - v0 + NW - 1) / NW, va = v0 + wave * per < v1 ? v0 + wave * per : v1, vb = va + per < v1 ? va + per : v1;
     const int e = blockIdx.y * 64 + lane;
     double acc = 0.0;
     if (e < a.nz2) {
@@ -293,17 +294,25 @@ __global__ void __launch_bounds__(256) gram_reduce_kernel(const GramReduceArgs a
     }
     part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && e < a.nz2) a.gram[(size_t)g * a.nz2 + e] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-    if (a.nvalid && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (wave == 0 && e < a.nz2) {
+        double t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t += part[w][lane];          // wave order: the result depends on nothing but the segment list and NW
+        a.gram[(size_t)g * a.nz2 + e] = t;
+    }
+    if (a.nvalid && blockIdx.y == 0 && wave == 0) {               // (counts: exact in any order; one thread's dependent loop was ~1 us per segment)
         double n = 0.0;
-        for (int v = v0; v < v1; ++v) n += a.nv_part[v];
-        a.nvalid[g] = n;
+        for (int v = v0 + lane; v < v1; v += 64) n += a.nv_part[v];
+        n = wave_sum_row3(n);
+        if (lane == 63) a.nvalid[g] = n;
     }
 }
 
 int gram_reduce_launch(pols_ctx *ctx, const GramReduceArgs &a) {
     if (a.n_groups == 0) return POLS_OK;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)a.n_groups, (unsigned)((a.nz2 + 63) / 64)), dim3(256), 0, ctx->stream, a);
+    // (one workgroup per (group, 64 entries): with ~2 000 segments in ONE group the four-wave form was 31 us of a 225-us call)
+    if (a.max_segments >= 256) hipLaunchKernelGGL(gram_reduce_kernel<16>, dim3((unsigned)a.n_groups, (unsigned)((a.nz2 + 63) / 64)), dim3(1024), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(gram_reduce_kernel<4>, dim3((unsigned)a.n_groups, (unsigned)((a.nz2 + 63) / 64)), dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

@@ -80,6 +80,7 @@ struct GramReduceArgs {
     double *nvalid;         // n_groups or nullptr
     int64_t n_groups;
     int32_t nz2;
+    int32_t max_segments;   // most segments of one group (0: unknown -> the four-wave form)
 };
 int gram_reduce_launch(pols_ctx *ctx, const GramReduceArgs &a);
 
