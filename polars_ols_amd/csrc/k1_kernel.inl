@@ -1441,7 +1441,7 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             if (resident && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
         }
     }
-    if constexpr (sizeof(T) == 4 && TEAM == 256 && (RC == 1 || RC == 2) && KT >= 6 && KT <= 10) {
+    if constexpr (sizeof(T) == 4 && TEAM == 256 && (RC == 1 || RC == 2 || (RC == 4 && KT <= 8)) && KT >= 6 && KT <= 10) {
         // f32, one chunk per lane of a 256-thread team: two passes at 6-8 columns, three at 9-10 (POLS_K1_PASSES=1|2|3 overrides)
         const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 9 ? 3 : 2);
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
@@ -1579,6 +1579,13 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
         if (want_wave && wave_default && (need <= wave_cap || (need <= 2 * wave_cap && ctx->offs_wave_overflow * 16 <= a.n_rows)))
             return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
+#ifndef K1_NULLS_TU
+        // 2 049..4 096 rows (ten years of trading days per asset), up to 8 columns, round 5: FOUR chunks per lane of the 256-thread team --
+        // 144 resident registers, two workgroups per CU -- instead of handing the frame to K2 / K1m (2.1-3.4 TB/s there)
+        if constexpr (KT <= 8) {
+            if (need > 256 * 2 * VEC && need <= 256 * 4 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 4>(ctx, a, max_rows);
+        }
+#endif
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);
     } else {
 #ifndef K1_NULLS_TU
