@@ -389,7 +389,7 @@ static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_row
     const int vec = f32 ? 4 : 2;
     if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
     const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
-    if (f32 && kt <= 8 && need <= (int64_t)256 * 4 * vec && ctx->opt.static_engine != 2) return true;   // four chunks per lane of the 256-thread team (round 5)
+    if (kt <= 8 && need <= (int64_t)256 * 4 * vec && ctx->opt.static_engine != 2) return true;   // four chunks per lane of the 256-thread team (round 5)
     if (kt <= K1_MAX_KT) return need <= 1024;
     if (kt <= K1W_MAX_KT) return need <= (int64_t)256 * 2 * vec;   // 11-15 columns: up to the 256-thread team's resident rows
     // 16-31 columns: one chunk per lane.  f64 only where it measured faster than the alternatives (scripts/bench_k16.py, 50 000 x 200

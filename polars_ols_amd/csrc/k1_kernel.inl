@@ -1430,12 +1430,12 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
                       !ctx->opt.k1_nofast;
     // (f32 wave-per-group: the multi-pass form was tried -- 216 -> 187 VGPRs with three passes, still two waves per SIMD because the
     // 16 resident rows alone are 144 registers -- and dropped.)
-    if constexpr (sizeof(T) == 8 && TEAM == 256 && RC == 2 && KT >= 6) {
+    if constexpr (sizeof(T) == 8 && TEAM == 256 && (RC == 2 || (RC == 4 && KT <= 8)) && KT >= 6) {
         // f64, 6+ columns: the full accumulator set costs a workgroup per CU; POLS_K1_PASSES=1|2|3 overrides
         const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 10 ? 3 : 2);
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
-        if constexpr (KT >= 9) {                             // ragged frames whose rows all stay resident: the same passes, general loads
+        if constexpr (KT >= 9 || RC == 4) {                  // ragged frames whose rows all stay resident: the same passes, general loads
             const bool resident = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC && !fast;
             if (resident && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
             if (resident && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
@@ -1612,6 +1612,11 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
                     return al ? k1_launch_fast<T, KT, HAS_W, 128, 4, true, 2>(ctx, a) : k1_launch_fast<T, KT, HAS_W, 128, 4, false, 2>(ctx, a);
                 }
             }
+        }
+        // 1 025..2 048 f64 rows, up to 8 columns (round 5): four chunks per lane of the 256-thread team instead of K2
+        if constexpr (KT <= 8) {
+            const int64_t need4 = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1);
+            if (need4 > 256 * 2 * VEC && need4 <= 256 * 4 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 4>(ctx, a, max_rows);
         }
 #endif
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);

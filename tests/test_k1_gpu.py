@@ -587,3 +587,33 @@ def test_eight_lane_teams(eng, dtype, k, weights, icpt, slots):
         got = out[q].double().cpu().numpy()
         assert np.allclose(got, ref[q], rtol=tol, atol=tol), (q, float(np.abs(got - ref[q]).max()))
         assert np.allclose(got, one[q].double().cpu().numpy(), rtol=tol, atol=tol), q
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,weights,icpt,alpha,ragged", [(8, False, False, None, False), (8, True, False, 1.0, True), (7, False, True, None, True),
+                                                        (4, True, True, None, False), (1, False, False, None, True), (6, False, False, 0.5, False)])
+def test_decade_sized_groups_stay_register_resident(eng, dtype, k, weights, icpt, alpha, ragged):
+    """Round 5: groups of 2 049..4 096 f32 / 1 025..2 048 f64 rows (ten years of trading days per asset) at up to 8 columns take FOUR chunks per
+    lane of K1's 256-thread team -- X read once -- instead of K2 / K1m / the streamed path.  Aligned (FAST) and ragged (EDGE) frames, weights,
+    intercept, ridge; every group against the oracle; an empty and a short group in the frame."""
+    from oracle import orc
+
+    vec = 4 if dtype == np.float32 else 2
+    cap = 256 * 4 * vec
+    rng = np.random.default_rng(k * 17 + int(ragged))
+    if ragged:
+        sizes = np.concatenate([[cap - 3, 0, 37, cap // 2 + 5], rng.integers(cap // 2 + 1, cap - 2, size=9)])
+    else:
+        sizes = np.array([cap, cap - vec * 8, cap // 2 + vec * 4, cap, cap - vec * 100] * 2)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, dtype, weights=weights)
+    kw = dict(add_intercept=icpt)
+    if alpha is not None:
+        kw.update(alpha=alpha, l1_ratio=0.0)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w),
+                            want=("coef", "pred", "resid", "status"), **kw)
+    assert "team256_rc4" in eng.last_kernel, eng.last_kernel
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, **kw)
+    _check(out, ref, dtype)
+    st = out["status"].cpu().numpy()
+    assert (st[sizes > 0] == 0).all() and (st[sizes == 0] == 2).all()
