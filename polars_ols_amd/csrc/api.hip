@@ -188,6 +188,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_XCD")) o.k1_xcd = on ? std::atoi(v) : d.k1_xcd;
     else if (ieq(key, "K4P_LPS")) o.k4p_lps = on ? std::atoi(v) : d.k4p_lps;
     else if (ieq(key, "SEG_TARGET")) o.seg_target = on ? std::atoi(v) : d.seg_target;
+    else if (ieq(key, "K1_RC2_WIDE")) o.k1_rc2_wide = on ? std::atoi(v) != 0 : d.k1_rc2_wide;
     else if (ieq(key, "DEBUG_SKIP_FIXUP")) o.debug_skip_fixup = on && std::atoi(v) != 0;
     else if (ieq(key, "K1_PERSIST")) o.k1_persist = on ? (std::atoi(v) != 0) : d.k1_persist;
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
@@ -205,7 +206,7 @@ void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
-                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET"};
+                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);
@@ -385,11 +386,17 @@ static int check_batch(const pols_batch *b, const pols_out *o, int max_features 
 // columns (8 features + intercept, the smoke() shape) while every row stays resident in the wave / two-wave kernels whose Gram
 // is accumulated in passes -- 10 000 x 1 000 x (8 + 1) f32: 77.8 us = 5.1 TB/s against 110 us for the LDS-tile engine (K1m),
 // f64 153.8 against 243.5 us (scripts/bench_k9.py).
-static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_rows) {
+static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_rows, bool has_w = false) {
     const int vec = f32 ? 4 : 2;
     if (kt <= 8 && max_rows <= (int64_t)256 * 2 * vec) return true;
     const int64_t need = max_rows + (ctx->offs_aligned[f32 ? 1 : 0] ? 0 : vec - 1);
-    if (kt <= 8 && need <= (int64_t)256 * 4 * vec && ctx->opt.static_engine != 2) return true;   // four chunks per lane of the 256-thread team (round 5)
+    // round 5: four chunks per lane of the 256-thread team -- up to 4 096 f32 / 2 048 f64 rows stay register-resident at up to 10 columns
+    // (9-10 f32 columns used to leave K1 at 1 024 rows for K1m: 3.2 against 5.3 TB/s on 5 000 x 2 000 x (8 + 1)); POLS_K1_RC2_WIDE=0: the old rule
+    if (kt <= K1_MAX_KT && ctx->opt.static_engine != 2) {
+        // (f64, 10 columns WITH weights: the four-chunk kernel needs 278 registers -- AGPRs, one wave per SIMD -- and stays with K2)
+        if (kt <= 8 || (ctx->opt.k1_rc2_wide && !(!f32 && kt == 10 && has_w))) return need <= (int64_t)256 * 4 * vec;
+        return need <= 1024;
+    }
     if (kt <= K1_MAX_KT) return need <= 1024;
     if (kt <= K1W_MAX_KT) return need <= (int64_t)256 * 2 * vec;   // 11-15 columns: up to the 256-thread team's resident rows
     // 16-31 columns: one chunk per lane.  f64 only where it measured faster than the alternatives (scripts/bench_k16.py, 50 000 x 200
@@ -1017,7 +1024,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool aligned = ctx->offs_aligned[f32 ? 1 : 0];
         const bool k2_ok = !nulls && kt <= K2_KMAX && k2_fits(b->dtype, kt, max_rows, aligned) && b->n_rows >= vec && ctx->opt.static_engine != 1 &&
                            ctx->opt.static_engine != 3;
-        const bool k1_resident = nulls ? k1_nulls_takes(ctx, f32, kt, max_rows) : k1_valu_takes(ctx, f32, kt, max_rows);
+        const bool k1_resident = nulls ? k1_nulls_takes(ctx, f32, kt, max_rows) : k1_valu_takes(ctx, f32, kt, max_rows, b->weights != nullptr);
         // POLS_K1_ENGINE=valu | mfma keep the K1 / K1m kernels reachable for the shapes they cover (A/B measurements, tests)
         const bool legacy_forced = (ctx->opt.k1_engine == 2 && kt <= K1M_MAX_KT) || (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT);
         (void)K1W_MAX_KT;
@@ -1101,7 +1108,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool f32 = b->dtype == POLS_F32;
         const bool fits_lds = f32 ? k1m_fits<float>(b->n_features, b->weights != nullptr, max_rows)
                                   : k1m_fits<double>(b->n_features, b->weights != nullptr, max_rows);
-        const bool k1_resident = nulls ? k1_nulls_takes(ctx, f32, kt, max_rows) : k1_valu_takes(ctx, f32, kt, max_rows);
+        const bool k1_resident = nulls ? k1_nulls_takes(ctx, f32, kt, max_rows) : k1_valu_takes(ctx, f32, kt, max_rows, b->weights != nullptr);
         // null policies: the register-resident K1 has a NULLS family; everything else goes through the streamed kernels
         stream = (nulls && !k1_resident) || (!k1_resident && (kt > K1M_MAX_KT || !fits_lds));
         stream = stream || ctx->opt.static_engine == 1;
@@ -2266,7 +2273,7 @@ int k1_launch(pols_ctx *ctx, int dtype, int kt, const K1Args &a, int64_t max_gro
     // kernel with the same access pattern reaches whenever a group's rows stay register-resident (k <= 8:
     // <= 2048 rows f32, <= 1024 rows f64); K1m reads HBM once for any group whose tile fits LDS and carries up
     // to 15 features, at ~65 % of that bandwidth (LDS caps it at 4 groups in flight per CU).
-    const bool k1_ok = k1_valu_takes(ctx, f32, kt, max_group_rows);
+    const bool k1_ok = k1_valu_takes(ctx, f32, kt, max_group_rows, a.w != nullptr);
     bool use_mfma = fits && !k1_ok && (max_group_rows > 64 * 2 * vec || kt > K1_MAX_KT);
     if (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT) use_mfma = false;
     if (ctx->opt.k1_engine == 2 && fits) use_mfma = true;

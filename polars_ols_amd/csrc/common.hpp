@@ -66,6 +66,7 @@ struct Options {
     int k1_persist_sub = 0;       // POLS_K1_PERSIST_SUB 0: default rule, 64 / 32 / 16 lanes per group
     int k1_persist = -1;          // POLS_K1_PERSIST     -1: default rule (enough groups), 0 never, 1 whenever the groups fit K1p
     bool debug_skip_fixup = false; // POLS_DEBUG_SKIP_FIXUP  measurement switch: the fix-up dispatch behind a static solve is skipped (flagged groups keep their unusable coefficients)
+    bool k1_rc2_wide = true;      // POLS_K1_RC2_WIDE    9-10 columns: K1's two- / four-chunk team beyond 1 024 rows instead of K1m / K2 (0: the round-4 rule, A/B)
     int seg_target = 0;           // POLS_SEG_TARGET     streamed static path: rows per segment of a cut group (0: the default rule)
     int k4p_lps = 0;              // POLS_K4P_LPS        K4p / K3p (k4p_wide.hip): lanes per sequence, 0 auto, 64 / 16 (up to 16 features) / 32 (17..32, RLS)
     int k1_xcd = 0;               // POLS_K1_XCD         resident K1 kernels: 1 = XCD-contiguous workgroup -> group map (each XCD walks one eighth of the frame)

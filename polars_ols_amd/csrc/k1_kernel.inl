@@ -1430,9 +1430,10 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
                       !ctx->opt.k1_nofast;
     // (f32 wave-per-group: the multi-pass form was tried -- 216 -> 187 VGPRs with three passes, still two waves per SIMD because the
     // 16 resident rows alone are 144 registers -- and dropped.)
-    if constexpr (sizeof(T) == 8 && TEAM == 256 && (RC == 2 || (RC == 4 && KT <= 8)) && KT >= 6) {
+    if constexpr (sizeof(T) == 8 && TEAM == 256 && (RC == 2 || RC == 4) && KT >= 6) {
         // f64, 6+ columns: the full accumulator set costs a workgroup per CU; POLS_K1_PASSES=1|2|3 overrides
-        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 10 ? 3 : 2);
+        // (four chunks per lane at 9-10 columns: 160-176 resident registers -- three passes keep the accumulators at 19-22 doubles)
+        const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : ((KT >= 10 || (RC == 4 && KT >= 9)) ? 3 : 2);
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
         if constexpr (KT >= 9 || RC == 4) {                  // ragged frames whose rows all stay resident: the same passes, general loads
@@ -1441,13 +1442,13 @@ static int k1_launch_variant(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             if (resident && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
         }
     }
-    if constexpr (sizeof(T) == 4 && TEAM == 256 && (RC == 1 || RC == 2 || (RC == 4 && KT <= 8)) && KT >= 6 && KT <= 10) {
+    if constexpr (sizeof(T) == 4 && TEAM == 256 && (RC == 1 || RC == 2 || RC == 4) && KT >= 6 && KT <= 10) {
         // f32, one chunk per lane of a 256-thread team: two passes at 6-8 columns, three at 9-10 (POLS_K1_PASSES=1|2|3 overrides)
         const int npass = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 9 ? 3 : 2);
         if (fast && npass == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 2>(ctx, a);
         if (fast && npass == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, true, 3>(ctx, a);
         const bool resident = max_rows + (ctx->offs_aligned[1] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
-        const int npass_r = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 8 && RC == 1 ? 3 : 2);   // ragged, 8 columns, one chunk: 69.8 (three) vs 71.4 us (two)
+        const int npass_r = ctx->opt.k1_passes ? ctx->opt.k1_passes : ((KT >= 8 && RC == 1) || (KT >= 9 && RC == 4) ? 3 : 2);   // ragged, 8 columns, one chunk: 69.8 (three) vs 71.4 us (two)
         if (!fast && resident && npass_r == 2) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 2>(ctx, a);
         if (!fast && resident && npass_r == 3) return k1_launch_fast<T, KT, HAS_W, TEAM, RC, false, 3>(ctx, a);
     }
@@ -1580,11 +1581,9 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             return k1_launch_variant<T, KT, HAS_W, 64, 4>(ctx, a, max_rows);
         if (max_rows <= 256 * 1 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 1>(ctx, a, max_rows);
 #ifndef K1_NULLS_TU
-        // 2 049..4 096 rows (ten years of trading days per asset), up to 8 columns, round 5: FOUR chunks per lane of the 256-thread team --
-        // 144 resident registers, two workgroups per CU -- instead of handing the frame to K2 / K1m (2.1-3.4 TB/s there)
-        if constexpr (KT <= 8) {
-            if (need > 256 * 2 * VEC && need <= 256 * 4 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 4>(ctx, a, max_rows);
-        }
+        // 2 049..4 096 rows (ten years of trading days per asset), up to 10 columns, round 5: FOUR chunks per lane of the 256-thread team --
+        // 144-176 resident registers, two workgroups per CU -- instead of handing the frame to K2 / K1m (2.1-3.4 TB/s there)
+        if (need > 256 * 2 * VEC && need <= 256 * 4 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 4>(ctx, a, max_rows);   // (up to 10 columns)
 #endif
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);
     } else {
@@ -1613,10 +1612,10 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
                 }
             }
         }
-        // 1 025..2 048 f64 rows, up to 8 columns (round 5): four chunks per lane of the 256-thread team instead of K2
-        if constexpr (KT <= 8) {
+        // 1 025..2 048 f64 rows, up to 10 columns (round 5): four chunks per lane of the 256-thread team instead of K2
+        {
             const int64_t need4 = max_rows + (ctx->offs_aligned[0] ? 0 : VEC - 1);
-            if (need4 > 256 * 2 * VEC && need4 <= 256 * 4 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 4>(ctx, a, max_rows);
+            if (need4 > 256 * 2 * VEC && need4 <= 256 * 4 * VEC) return k1_launch_variant<T, KT, HAS_W, 256, 4>(ctx, a, max_rows);   // (up to 10 columns)
         }
 #endif
         return k1_launch_variant<T, KT, HAS_W, 256, 2>(ctx, a, max_rows);

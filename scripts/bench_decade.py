@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polars_ols_amd.engine import Engine
 eng = Engine(0)
 for dt, nm, b in ((torch.float32, "f32", 4), (torch.float64, "f64", 8)):
-    for G, n, k in ((4000, 2500, 8), (3333, 3000, 8), (2500, 4000, 8), (4000, 2500, 4), (4000, 2500, 6), (4000, 2520, 8), (5000, 2000, 8), (6000, 1500, 8), (8000, 1250, 8)):
+    for G, n, k in ((4000, 2500, 8), (3333, 3000, 8), (2500, 4000, 8), (4000, 2500, 4), (4000, 2500, 6), (4000, 2520, 8), (5000, 2000, 8), (6000, 1500, 8), (8000, 1250, 8),
+                    (5000, 2000, 9), (5000, 2000, 10), (3333, 3000, 9), (2500, 4000, 10), (8000, 1250, 9)):
         gen = torch.Generator(device="cuda").manual_seed(3)
         cols = [torch.randn(G * n, generator=gen, device="cuda", dtype=dt) for _ in range(k)]
         y = sum(cols) + 0.1 * torch.randn(G * n, generator=gen, device="cuda", dtype=dt)

@@ -236,7 +236,7 @@ def test_host_path_and_determinism(eng):
 @pytest.mark.parametrize("dtype,kt,weights,icpt,kw", [
     (np.float64, 12, True, True, dict(alpha=0.3, l1_ratio=0.0)),
     (np.float64, 16, False, False, dict(alpha=0.01, l1_ratio=0.5, tol=1e-10, max_iter=20_000)),
-    (np.float32, 9, True, False, {}),
+    (np.float32, 12, True, False, {}),          # (9-10 columns at these row counts stay with K1 since round 5)
 ])
 def test_persistent_workgroups_and_prefetch(eng, dtype, kt, weights, icpt, kw):
     """More groups than the chip holds eight-wave workgroups: every workgroup walks several groups and the first chunks of its
@@ -314,11 +314,12 @@ def test_k2w_is_the_default_beyond_the_resident_k1_shapes(eng, k, family):
     _check(out, orc.batched_least_squares(y, cols, offs), np.float64)
 
 
-@pytest.mark.parametrize("dtype,k,rows,family", [(np.float64, 12, 1300, "k2_gram_mfma_resident_f64_k16_w8_rc2"), (np.float64, 9, 1100, "k2_gram_mfma_resident_f64_k16_w8_rc2"),
-                                                 (np.float32, 14, 2600, "k2_gram_mfma_resident_f32_k16_w8_rc2"), (np.float32, 9, 2600, "k1m_gram_mfma_f32_k9")])
+@pytest.mark.parametrize("dtype,k,rows,family", [(np.float64, 12, 1300, "k2_gram_mfma_resident_f64_k16_w8_rc2"), (np.float64, 9, 1100, "k1_gram_chol_f64_k9_team256_rc4"),
+                                                 (np.float32, 14, 2600, "k2_gram_mfma_resident_f32_k16_w8_rc2"), (np.float32, 9, 2600, "k1_gram_chol_f32_k9_team256_rc4")])
 def test_over_resident_groups_route_to_k2_where_it_wins(eng, dtype, k, rows, family):
     """Rows beyond K1's registers, tile within LDS: K2 by default (it beats the LDS-tile engine there since round 3) except f32 with 9-10
-    columns; ragged groups whose upper waves own no row of the second chunk (they skip its tile stages)."""
+    columns; ragged groups whose upper waves own no row of the second chunk (they skip its tile stages).  Round 5: up to 10 columns K1's own
+    registers reach 4 096 f32 / 2 048 f64 rows (four chunks per lane), so K2 / K1m start beyond that."""
     from oracle import orc
 
     rng = np.random.default_rng(rows + k)
