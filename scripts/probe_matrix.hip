@@ -151,11 +151,25 @@ static Kern pick(const Cell &c) {
 int main(int argc, char **argv) {
     const long N = 10000000;
     const int FRAMES = 3, REPS = argc > 1 ? std::atoi(argv[1]) : 60;
+    // argv[2] = bytes of SKEW between consecutive columns of a frame (0: one hipMalloc per column -- 2 MiB-aligned bases, 40 MiB apart, what
+    // torch's allocator hands out too; > 0: the ten columns of a frame carved out of ONE allocation, column j at j * (N * 4 + skew)): do the
+    // ten streams collide in the HBM channel / bank mapping when their bases are congruent modulo a large power of two?
+    const long SKEW = argc > 2 ? std::atol(argv[2]) : 0;
     Cols fr[FRAMES];
     for (int f = 0; f < FRAMES; ++f) {
+        if (SKEW > 0) {
+            char *big; const size_t stride = (size_t)N * 4 + (size_t)SKEW, total = stride * 10 + (1 << 20);
+            CK(hipMalloc(&big, total)); CK(hipMemset(big, 0x3c, total));
+            for (int j = 0; j < 9; ++j) fr[f].x[j] = reinterpret_cast<const float *>(big + stride * j);
+            fr[f].out = reinterpret_cast<float *>(big + stride * 9);
+            continue;
+        }
         for (int j = 0; j < 9; ++j) { float *p; CK(hipMalloc(&p, (N + 4096) * 4)); CK(hipMemset(p, 0x3c, (N + 4096) * 4)); fr[f].x[j] = p; }
         CK(hipMalloc(&fr[f].out, (N + 4096) * 4));
     }
+    printf("# column base skew: %ld bytes%s\n", SKEW, SKEW ? " (one allocation per frame)" : " (one hipMalloc per column)");
+    for (int j = 0; j < 3; ++j) printf("# frame 0 column %d at %p\n", j, (const void *)fr[0].x[j]);
+    const bool QUICK = argc > 3;      // argv[3]: only the headline's cells (9R+1W and 9R, 4 / 16 KB, rows = 1000, nt loads)
     float *sink; CK(hipMalloc(&sink, 64));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -173,6 +187,7 @@ int main(int argc, char **argv) {
                             if (mix == 1 && storek) continue;
                             if (mix == 2 && loadk) continue;
                             if (storek == 2 && subp == 1) continue;       // burst == nt with one sub-piece
+                            if (QUICK && (mix == 2 || rows != 1000 || subp == 16 || loadk != 1 || map == 1 || storek == 0)) continue;
                             const Cell cell{mix, loadk, storek, subp};
                             Kern k = pick(cell);
                             const long subs = N / rows, n_pieces = subs / subp;      // whole pieces only (the tail is outside the byte count too)
