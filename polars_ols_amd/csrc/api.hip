@@ -179,6 +179,8 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_SHAPE")) { o.k1_shape_team = on && ieq(v, "team"); o.k1_shape_wave = on && ieq(v, "wave"); }
     else if (ieq(key, "K1_F64_TEAM")) o.k1_f64_team256 = on && std::atoi(v) == 256;
     else if (ieq(key, "KG_NOYV")) o.kg_noyv = on;
+    else if (ieq(key, "KG_SINGLE_BUFFER")) o.kg_single_buffer = on;
+    else if (ieq(key, "PREDICT_LOOP")) o.predict_loop = on;
     else if (ieq(key, "K2_NOPREFETCH")) o.k2_noprefetch = on;
     else if (ieq(key, "NO_SPLIT")) o.no_split = on;
     else if (ieq(key, "K1_PASSES")) o.k1_passes = on ? std::atoi(v) : d.k1_passes;
@@ -206,7 +208,7 @@ void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
-                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE"};
+                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE", "KG_SINGLE_BUFFER", "PREDICT_LOOP"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);
@@ -815,7 +817,7 @@ static int wide_static(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
 struct SegTables {
     const int64_t *offs = nullptr;
     const int32_t *map = nullptr, *first = nullptr;
-    int64_t n_seg = 0;
+    int64_t n_seg = 0, max_len = 0, max_seg = 0;      // rows of the longest segment; most segments of one group
     char *extra = nullptr;
 };
 static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows, size_t extra_per_seg, SegTables *t) {
@@ -841,17 +843,20 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
         t->n_seg = n_seg;
         return b_so + b_sm + b_sf;
     };
-    if (hit) { lay(static_cast<char *>(ctx->scratch[23].ptr), sc.n_seg); return POLS_OK; }
+    if (hit) { lay(static_cast<char *>(ctx->scratch[23].ptr), sc.n_seg); t->max_len = sc.max_len; t->max_seg = sc.max_seg; return POLS_OK; }
     if (same_frame) extra_per_seg = std::max<size_t>(extra_per_seg, sc.nz2);
     sc.ptr = nullptr;
     std::vector<int64_t> so;
     std::vector<int32_t> sm, sf((size_t)b->n_groups + 1);
     so.push_back(0);
+    int64_t max_len = 0, max_seg = 0;
     for (int64_t g = 0; g < b->n_groups; ++g) {
+        if (g > 0) max_seg = std::max<int64_t>(max_seg, (int64_t)sm.size() - sf[(size_t)g - 1]);
         sf[(size_t)g] = (int32_t)sm.size();
         const int64_t s0 = b->group_offsets[g], e0 = b->group_offsets[g + 1];
         const int64_t pieces = std::max<int64_t>(1, (e0 - s0 + seg_target - 1) / seg_target);
         const int64_t len = std::max<int64_t>(1, ((e0 - s0 + pieces - 1) / pieces + 255) / 256 * 256);   // (256-row multiples: whole staging chunks)
+        max_len = std::max(max_len, std::min(len, e0 - s0));
         for (int64_t r = s0; r < e0 || r == s0; r += len) {
             so.push_back(std::min(e0, r + len));
             sm.push_back((int32_t)g);
@@ -859,6 +864,7 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
         }
     }
     sf[(size_t)b->n_groups] = (int32_t)sm.size();
+    if (b->n_groups > 0) max_seg = std::max<int64_t>(max_seg, (int64_t)sm.size() - sf[(size_t)b->n_groups - 1]);
     const int64_t n_seg = (int64_t)sm.size();
     const size_t tabs = round256(sizeof(int64_t) * so.size()) + round256(sizeof(int32_t) * sm.size()) + round256(sizeof(int32_t) * sf.size());
     void *ds = nullptr;
@@ -869,7 +875,8 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
     if ((rc = upload_small(ctx, const_cast<int32_t *>(t->map), sm.data(), sizeof(int32_t) * sm.size()))) return rc;
     if ((rc = upload_small(ctx, const_cast<int32_t *>(t->first), sf.data(), sizeof(int32_t) * sf.size()))) return rc;
     sc.ptr = ds; sc.offs_id = ctx->offs_id; sc.n_groups = b->n_groups; sc.n_rows = b->n_rows; sc.seg_target = seg_target;
-    sc.n_seg = n_seg; sc.nz2 = extra_per_seg; sc.nulls = false;
+    sc.n_seg = n_seg; sc.nz2 = extra_per_seg; sc.nulls = false; sc.max_len = max_len; sc.max_seg = max_seg;
+    t->max_len = max_len; t->max_seg = max_seg;
     return POLS_OK;
 }
 
@@ -1121,8 +1128,6 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const size_t gram_bytes = round256(sizeof(double) * nz * nz * (size_t)b->n_groups);
         const size_t c64_bytes = round256(sizeof(double) * (size_t)kt * (size_t)b->n_groups);
         const size_t nv_bytes = nulls ? round256(sizeof(double) * (size_t)b->n_groups) : 0;
-        if ((rc = ensure_scratch(ctx, 5, gram_bytes + c64_bytes + nv_bytes, &scr))) return rc;
-        double *nvalid = nulls ? reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes + c64_bytes) : nullptr;
         // Few long groups (ONE regression over a whole frame is the reference's first README example): a group is one workgroup in
         // the Gram and the prediction pass, so a 10M-row group used to be one CU's work -- 94 ms.  Long groups are cut into segments
         // (segment offsets, one workgroup each; the segments' Gram matrices are summed per group in segment order), sized so that the
@@ -1130,6 +1135,11 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         SegTables sg;
         if ((rc = ensure_segments(ctx, b, max_rows, sizeof(double) * (nz * nz + 1), &sg))) return rc;
         const bool split = sg.n_seg > 0;
+        // few groups of hundreds of segments: the segment sums go through 16 slices per group (gram_reduce_launch)
+        const int n_slices = (split && sg.max_seg >= 256 && b->n_groups <= 256) ? 16 : 1;
+        const size_t slice_bytes = n_slices > 1 ? round256(sizeof(double) * nz * nz * (size_t)n_slices * (size_t)b->n_groups) : 0;
+        if ((rc = ensure_scratch(ctx, 5, gram_bytes + c64_bytes + nv_bytes + slice_bytes, &scr))) return rc;
+        double *nvalid = nulls ? reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes + c64_bytes) : nullptr;
         const int64_t *seg_offs = split ? sg.offs : d_offs;
         const int32_t *seg_map = sg.map, *seg_first = sg.first;
         const int64_t n_seg = split ? sg.n_seg : b->n_groups;
@@ -1149,7 +1159,8 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             std::memset(&ra, 0, sizeof(ra));
             ra.part = gram_part; ra.nv_part = nv_part; ra.first = seg_first;
             ra.gram = static_cast<double *>(scr); ra.nvalid = nvalid; ra.n_groups = b->n_groups; ra.nz2 = (int32_t)(nz * nz);
-            ra.max_segments = (int32_t)std::min<int64_t>(1 << 30, (max_rows + 255) / 256);   // (an upper bound is enough: segments are at least 256 rows)
+            ra.max_segments = (int32_t)std::min<int64_t>(1 << 30, sg.max_seg);
+            if (n_slices > 1) { ra.slices = reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes + c64_bytes + nv_bytes); ra.n_slices = n_slices; }
             if ((rc = gram_reduce_launch(ctx, ra))) return rc;
             ga.gram = static_cast<double *>(scr);
             ctx->last_kernel += "_split";
@@ -1178,6 +1189,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             pa.y = st.y; pa.w = st.w;
             for (int j = 0; j < b->n_features; ++j) pa.x[j] = st.x[j];
             pa.offs = seg_offs; pa.n_groups = n_seg; pa.n_rows = b->n_rows; pa.gmap = seg_map;
+            pa.max_item_rows = split ? sg.max_len : max_rows;
             pa.coef64 = ca.coef64; pa.pred = st.pred; pa.resid = st.resid;
             pa.k_user = b->n_features; pa.kt = kt;
             pa.valid = st.valid; pa.null_policy = pol;
@@ -2064,6 +2076,7 @@ int pols_predict_policy(pols_ctx *ctx, const pols_batch *b, const void *coef, in
         SegTables sg;
         if ((rc = ensure_segments(ctx, b, max_rows, 0, &sg))) return rc;
         if (sg.n_seg > 0) { pa.offs = sg.offs; pa.n_groups = sg.n_seg; }
+        pa.max_item_rows = sg.n_seg > 0 ? sg.max_len : max_rows;
     }
     if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, kt, &o, st);

@@ -49,6 +49,8 @@ struct Options {
     bool k1_shape_team = false;   // POLS_K1_SHAPE=team  f32: 256-thread teams instead of wave-per-group
     bool k1_shape_wave = false;   // POLS_K1_SHAPE=wave  f32: wave-per-group even where the 256-thread team is the default
     bool k1_f64_team256 = false;  // POLS_K1_F64_TEAM=256
+    bool kg_single_buffer = false; // POLS_KG_SINGLE_BUFFER  streamed Gram: one LDS tile (the round-4 form), A/B for the double-buffered DMA
+    bool predict_loop = false;    // POLS_PREDICT_LOOP   prediction pass: one looping workgroup per item (the round-4 form)
     bool kg_noyv = false;         // POLS_KG_NOYV        streamed Gram: keep the target in a second MFMA tile at 16 columns
     int k1_passes = 0;            // POLS_K1_PASSES      0: default
     int k1t_rc4 = -1;             // POLS_K1T_RC4        -1: default rule
@@ -127,7 +129,7 @@ struct pols_ctx {
     // this frame does not pack (a sequence longer than a tile, or tiles too empty)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, tile_rows = 0, n_tiles = 0; } k3c;
     // segment tables of the streamed static path (scratch slot 23: long groups cut into segments): rebuilt when other offsets arrive
-    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0; size_t nz2 = 0; bool nulls = false; } seg_cache;
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0; size_t nz2 = 0; bool nulls = false; } seg_cache;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };

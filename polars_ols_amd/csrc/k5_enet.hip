@@ -12,7 +12,7 @@ constexpr int KG_CR = 256;   // rows per LDS chunk
 // X'y is then accumulated on the VALU from the operands the lanes already hold (one extra LDS read + FMA per step) and only
 // tile (0, 0) goes through the matrix cores; y'y is not produced (nothing on this path reads it).
 template <typename T, int NT, bool HAS_W, bool YV = false>
-__global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, const int rs, const int ncols, const int tile_elems) {
+__global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, const int rs, const int ncols, const int tile_elems, const int nbuf, const int cr) {
     using V = typename Vec16<T>::type;
     using M = Mfma16<T>;
     using acc_t = typename M::acc_t;
@@ -21,8 +21,11 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
     constexpr int NPAIR = NT * (NT + 1) / 2;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *tile = reinterpret_cast<T *>(smem);          // [ncols][rs]; re-used for the cross-wave partial tiles at the end
-    T *zeros = tile + tile_elems;
+    // [nbuf][ncols][rs]; the first is re-used for the cross-wave partial tiles at the end.  nbuf == 2 (narrow tiles): the DMA of chunk
+    // c + 1 is issued before the MFMAs of chunk c, so a workgroup has a chunk in flight the whole time instead of one exposed load
+    // latency per 256 rows (gram_stream at 3.8 / 4.2 TB/s f32 / f64 on 8 features, profiles/r05_kernel_stats_long_groups.txt)
+    T *const tile0 = reinterpret_cast<T *>(smem);
+    T *zeros = tile0 + (size_t)nbuf * tile_elems;
     T *ones = zeros + K1M_CONST_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -64,17 +67,16 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
     const int pol = a.null_policy;
     const int nld = (HAS_W && !a.w) ? ncols - 1 : ncols;   // no weights column to stage: the prep pass writes ones
 
-    for (int64_t c0 = 0; c0 < span; c0 += KG_CR) {
-        const int rows_here = (int)min((int64_t)KG_CR, span - c0);
-        const int rows8 = (rows_here + 7) & ~7;
-        // ---- stage the chunk: HBM -> LDS
+    // ---- stage one chunk: HBM -> LDS (asynchronous; the caller waits for vmcnt(0) and the barrier)
+    auto stage = [&](const int64_t c0, T *const tl) __attribute__((always_inline)) {
+        const int rows_here = (int)min((int64_t)cr, span - c0);
         const int ppc = (rows_here + RPP - 1) / RPP;
         for (int p = wave; p < nld * ppc; p += 4) {
             const int col = p / ppc, q = p - col * ppc;
             const T *src = static_cast<const T *>(col < ku ? a.x[col] : (col == ku ? a.y : a.w));
             const int row0 = q * RPP + lane * VEC;
             const int64_t grow = base + c0 + row0;
-            T *ldst = tile + (size_t)col * rs + q * RPP;
+            T *ldst = tl + (size_t)col * rs + q * RPP;
             if (row0 < rows_here) {
                 if (grow + VEC <= a.n_rows) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + grow),
@@ -85,8 +87,17 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
                 }
             }
         }
+    };
+    if (nbuf == 2 && span > 0) stage(0, tile0);
+    int buf = 0;
+    for (int64_t c0 = 0; c0 < span; c0 += cr, buf ^= (nbuf - 1)) {
+        const int rows_here = (int)min((int64_t)cr, span - c0);
+        const int rows8 = (rows_here + 7) & ~7;
+        T *const tile = tile0 + (size_t)buf * tile_elems;
+        if (nbuf == 1) stage(c0, tile);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                            // this chunk has landed; every wave is done with the other buffer
+        if (nbuf == 2 && c0 + cr < span) stage(c0 + cr, tile0 + (size_t)(buf ^ 1) * tile_elems);
         // ---- prep: zero rows outside the group, apply sqrt(w)
         const int64_t lo = head - c0, hi = span - c0;       // valid chunk rows: lo <= r < hi
         if constexpr (HAS_W) {
@@ -123,6 +134,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
                     *reinterpret_cast<V *>(tile + (size_t)c * rs + row0) = xv;
                 }
             }
+            __syncthreads();
         } else {
             const int nhead = (c0 == 0) ? head : 0;
             const int ntail = rows8 - rows_here;
@@ -132,8 +144,8 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
                 const int r = (k < nhead) ? k : rows_here + (k - nhead);
                 tile[(size_t)c * rs + r] = T(0);
             }
+            if (npad > 0) __syncthreads();          // (workgroup-uniform: only a segment's first and last chunk have rows to blank)
         }
-        __syncthreads();
         // ---- MFMA: each wave takes a contiguous quarter of this chunk's 8-row steps
         const int nsteps = rows8 >> 3;
         const int per_wave = (nsteps + 3) >> 2;
@@ -146,7 +158,11 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
             else { zp[t] = (zsrc[t] == -2) ? ones : zeros; zinc[t] = 0; }
         }
         const T *yp = tile + (size_t)ku * rs + t_begin * 8 + rlane;      // YV: the target rows matching this lane's operands
-        for (int n = t_end - t_begin; n > 0; --n) {
+        for (int left = t_end - t_begin; left > 0;) {
+        // (f32: at most eight steps = 64 rows per wave between two flushes into the f64 sums, whatever the chunk length)
+        const int nb = (sizeof(T) == 4 && left > 8) ? 8 : left;
+        left -= nb;
+        for (int n = nb; n > 0; --n) {
             T v0[NT], v1[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -173,7 +189,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
                 }
         }
         if constexpr (sizeof(T) == 4) {
-            // f32: every chunk's tile (at most 64 rows per wave) is flushed into f64 running sums, so the Gram matrix of an f32
+            // f32: every 64 rows per wave the tile is flushed into f64 running sums, so the Gram matrix of an f32
             // frame carries f64-summation error -- what holds the f32 paths fed from here to the 1e-4 parity bound
 #pragma unroll
             for (int p = 0; p < NPAIR; ++p) {
@@ -183,8 +199,10 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
             }
             if constexpr (YV) { xyd += (double)xy0 + (double)xy1; xy0 = T(0); xy1 = T(0); }
         }
-        __syncthreads();   // the next chunk's DMA overwrites the tile
+        }
+        if (nbuf == 1) __syncthreads();             // the next chunk's DMA overwrites the tile
     }
+    __syncthreads();                                // the partial tiles below re-use the first buffer
     if constexpr (sizeof(T) == 8) {
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p)
@@ -199,7 +217,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
         if (tid == 0) a.nvalid[g] = (double)nfit_s;
     }
     // ---- cross-wave sum (fixed order) and write-out of the (symmetric) Gram matrix in f64
-    double *part = reinterpret_cast<double *>(tile);    // [pair][wave][reg * 64 + lane], f64
+    double *part = reinterpret_cast<double *>(tile0);   // [pair][wave][reg * 64 + lane], f64
     if constexpr (YV) {                                     // X'y: fold the four row-quarters of the wave, then the waves
         double xy = xyd;
         xy += __shfl_xor(xy, 16);
@@ -246,11 +264,18 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
 template <typename T, int NT, bool HAS_W, bool YV = false>
 static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     const int ncols = a.k_user + 1 + (HAS_W ? 1 : 0);
-    const int rs = k1m_row_stride<T>(KG_CR);
+    // rows per LDS chunk: 256, doubled while a column's piece stays within 4 KB and the tile within 48 KB (three workgroups per CU).  The
+    // 1 KB pieces of a 256-row f32 chunk streamed at 3.8 TB/s (2 KB, f64: 4.2) where 4 KB pieces of the same columns stream at 5.5
+    // (profiles/r05_probe_matrix.txt, r05_kernel_stats_long_groups.txt)
+    int cr = KG_CR;
+    if (!ctx->opt.kg_single_buffer)
+        while ((size_t)cr * 2 * sizeof(T) <= 4096 && (size_t)ncols * k1m_row_stride<T>(cr * 2) * sizeof(T) <= 48 * 1024) cr *= 2;
+    const int rs = k1m_row_stride<T>(cr);
     const int npair = NT * (NT + 1) / 2;
     // the tile is re-used for the cross-wave partial tiles, which are f64 whatever T is
     const int tile_elems = std::max(ncols * rs, (int)((npair * 4 * 256 + (YV ? 64 : 0)) * (sizeof(double) / sizeof(T))));
-    const size_t lds = sizeof(T) * ((size_t)tile_elems + 2 * K1M_CONST_ELEMS);
+    const int nbuf = (!ctx->opt.kg_single_buffer && sizeof(T) * (size_t)tile_elems <= 24 * 1024) ? 2 : 1;   // (wider tiles: two workgroups per CU do the same job)
+    const size_t lds = sizeof(T) * ((size_t)nbuf * tile_elems + 2 * K1M_CONST_ELEMS);
     static OncePerDevice attr_once;
     if (attr_once.needed(ctx->device)) {
         POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<T, NT, HAS_W, YV>),
@@ -262,22 +287,31 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     ctx->last_kernel = name;
     hipEvent_t ev0, ev1;
     if (timing_pair(ctx, &ev0, &ev1))
-        hipExtLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), (unsigned)lds, ctx->stream, ev0, ev1, 0, a, rs, ncols, tile_elems);
+        hipExtLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), (unsigned)lds, ctx->stream, ev0, ev1, 0, a, rs, ncols, tile_elems, nbuf, cr);
     else
-        hipLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols, tile_elems);
+        hipLaunchKernelGGL((gram_stream_kernel<T, NT, HAS_W, YV>), dim3((unsigned)a.n_groups), dim3(256), lds, ctx->stream, a, rs, ncols, tile_elems, nbuf, cr);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
 
-template <int NW>   // waves per workgroup: 4, or 16 when some group has hundreds of segments (ONE regression over a 10 M-row frame: 1 954)
+template <int NW>   // waves per workgroup
 __global__ void __launch_bounds__(64 * NW) gram_reduce_kernel(const GramReduceArgs a) {
-    // one workgroup per (group, 64 matrix entries): a lane per entry (coalesced), the four waves take a quarter of the segments each,
-    // eight loads in flight per lane (a plain loop was one load latency per segment: 243 us for the 2 048 segments of a 10M-row group);
-    // the wave sums meet in LDS in wave order -- the order of the additions depends on nothing but the segment list
+    // one workgroup per (group, 64 matrix entries, slice of the segment list): a lane per entry (coalesced), the waves take a share of
+    // the slice's segments each, eight loads in flight per lane (a plain loop was one load latency per segment: 243 us for the 2 048
+    // segments of a 10M-row group); the wave sums meet in LDS in wave order.  gridDim.z > 1 (ONE regression over a 10 M-row frame:
+    // ~2 000 segments, and two workgroups to sum them -- 20 us of latency chains): the segment list is cut into gridDim.z slices whose
+    // sums go to `slices`, and gram_reduce_final_kernel adds those in slice order.  The order of the additions depends on nothing but
+    // the segment list and the launch shape, which the frame alone decides.
     __shared__ double part[NW][64];
     const int64_t g = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int v0 = a.first[g], v1 = a.first[g + 1];
+    int v0 = a.first[g], v1 = a.first[g + 1];
+    const int nz_ = (int)gridDim.z, z = (int)blockIdx.z;
+    if (nz_ > 1) {
+        const int per_z = (v1 - v0 + nz_ - 1) / nz_;
+        v0 = v0 + z * per_z < v1 ? v0 + z * per_z : v1;
+        v1 = v0 + per_z < v1 ? v0 + per_z : v1;
+    }
     const int per = (v1 - v0 + NW - 1) / NW, va = v0 + wave * per < v1 ? v0 + wave * per : v1, vb = va + per < v1 ? va + per : v1;
     const int e = blockIdx.y * 64 + lane;
     double acc = 0.0;
@@ -297,27 +331,46 @@ __global__ void __launch_bounds__(64 * NW) gram_reduce_kernel(const GramReduceAr
     if (wave == 0 && e < a.nz2) {
         double t = part[0][lane];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) t += part[w][lane];          // wave order: the result depends on nothing but the segment list and NW
-        a.gram[(size_t)g * a.nz2 + e] = t;
+        for (int w = 1; w < NW; ++w) t += part[w][lane];          // wave order
+        if (nz_ > 1) a.slices[((size_t)g * nz_ + z) * a.nz2 + e] = t;
+        else a.gram[(size_t)g * a.nz2 + e] = t;
     }
-    if (a.nvalid && blockIdx.y == 0 && wave == 0) {               // (counts: exact in any order; one thread's dependent loop was ~1 us per segment)
+    if (a.nvalid && blockIdx.y == 0 && z == 0 && wave == 0) {     // (counts: exact in any order; one thread's dependent loop was ~1 us per segment)
         double n = 0.0;
-        for (int v = v0 + lane; v < v1; v += 64) n += a.nv_part[v];
+        for (int v = a.first[g] + lane; v < a.first[g + 1]; v += 64) n += a.nv_part[v];
         n = wave_sum_row3(n);
         if (lane == 63) a.nvalid[g] = n;
     }
 }
 
+__global__ void __launch_bounds__(64) gram_reduce_final_kernel(const GramReduceArgs a, const int n_slices) {
+    const int64_t g = blockIdx.x;
+    const int e = blockIdx.y * 64 + threadIdx.x;
+    if (e >= a.nz2) return;
+    const double *p = a.slices + (size_t)g * n_slices * a.nz2 + e;
+    double t = p[0];
+    for (int z = 1; z < n_slices; ++z) t += p[(size_t)z * a.nz2];   // slice order
+    a.gram[(size_t)g * a.nz2 + e] = t;
+}
+
 int gram_reduce_launch(pols_ctx *ctx, const GramReduceArgs &a) {
     if (a.n_groups == 0) return POLS_OK;
-    // (one workgroup per (group, 64 entries): with ~2 000 segments in ONE group the four-wave form was 31 us of a 225-us call)
-    if (a.max_segments >= 256) hipLaunchKernelGGL(gram_reduce_kernel<16>, dim3((unsigned)a.n_groups, (unsigned)((a.nz2 + 63) / 64)), dim3(1024), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(gram_reduce_kernel<4>, dim3((unsigned)a.n_groups, (unsigned)((a.nz2 + 63) / 64)), dim3(256), 0, ctx->stream, a);
+    const unsigned eb = (unsigned)((a.nz2 + 63) / 64);
+    if (a.slices && a.n_slices > 1) {
+        hipLaunchKernelGGL(gram_reduce_kernel<4>, dim3((unsigned)a.n_groups, eb, (unsigned)a.n_slices), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(gram_reduce_final_kernel, dim3((unsigned)a.n_groups, eb), dim3(64), 0, ctx->stream, a, a.n_slices);
+    } else if (a.max_segments >= 256) {
+        // (one workgroup per (group, 64 entries): with ~2 000 segments in ONE group the four-wave form was 31 us of a 225-us call)
+        hipLaunchKernelGGL(gram_reduce_kernel<16>, dim3((unsigned)a.n_groups, eb), dim3(1024), 0, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(gram_reduce_kernel<4>, dim3((unsigned)a.n_groups, eb), dim3(256), 0, ctx->stream, a);
+    }
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
 
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
+    if (gram_valu_takes(ctx, a)) return gram_valu_launch(ctx, dtype, a);
     if (a.kt + 1 > 32) return fail(POLS_ERR_UNSUPPORTED, "gram_stream: %d features (incl. intercept) > 31", a.kt);
     const bool two = a.kt + 1 > 16, w = a.w != nullptr || a.null_policy != POLS_NULL_IGNORE;   // null policies ride on the sqrt(w) prep pass
     if (a.kt == 16 && !ctx->opt.kg_noyv) {   // the target would be alone in the second tile: X'y on the VALU
@@ -535,7 +588,7 @@ int gram_solve_launch(pols_ctx *ctx, int dtype, const CdArgs &a) {
 // pred[r] = sum_j x_j[r] * c_j with c = per-group coefficients (f64) or per-row coefficients (dynamic models,
 // src/expressions.rs:184); residuals = y - pred.  With sample weights the reference's arithmetic is kept:
 // (sqrt_w x) . c * (1 / sqrt_w)  (least_squares.py:190-196, 234-235), so w == 0 gives NaN here too.
-template <typename T>
+template <typename T, int JB>   // JB: columns loaded per batch (4 / 8 / 16: the smallest that covers the features keeps the registers, hence the waves per SIMD, for them)
 __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
@@ -549,7 +602,10 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
     T *pred = static_cast<T *>(a.pred);
     T *resid = static_cast<T *>(a.resid);
     const int pol = a.null_policy;
-    for (int64_t row0 = base + (int64_t)threadIdx.x * VEC; row0 < e; row0 += 256 * VEC) {
+    // blockIdx.y: long items (segments of a split group, 10 000-row groups) are covered by several ONE-SHOT workgroups instead of one
+    // workgroup looping -- every resident workgroup looping in step made the loads come in bursts (4.0 TB/s where K1's one-shot
+    // workgroups stream 5.5)
+    for (int64_t row0 = base + ((int64_t)blockIdx.y * 256 + threadIdx.x) * VEC; row0 < e; row0 += (int64_t)gridDim.y * 256 * VEC) {
         const bool full = (row0 >= s) && (row0 + VEC <= e);
         T p[VEC], sw[VEC], yv[VEC];
 #pragma unroll
@@ -560,9 +616,13 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
         }
         // columns in batches of JB: every load of a batch is issued before the first FMA, so a thread has JB 16-byte
         // requests in flight instead of one (the per-column loop was a chain of full memory latencies)
-        constexpr int JB = 16;
         for (int j0 = 0; j0 < kt; j0 += JB) {
             T xb[JB][VEC];
+            T cb[JB];                               // this batch's group coefficients: wave-uniform loads, all issued before the first wait
+            if (cg) {
+#pragma unroll
+                for (int u = 0; u < JB; ++u) cb[u] = (j0 + u < kt) ? (T)cg[j0 + u] : T(0);
+            }
             if (full) {
                 V tv[JB];
 #pragma unroll
@@ -589,7 +649,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
                     for (int v = 0; v < VEC; ++v) {
                         const int64_t r = row0 + v;
                         T c;
-                        if (cg) c = (T)cg[j];
+                        if (cg) c = cb[u];
                         else c = (r >= s && r < e) ? crow[r * kt + j] : T(0);
                         p[v] = fma(null_fill<T>(pol, xb[u][v]) * sw[v], c, p[v]);
                     }
@@ -632,10 +692,86 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
     }
 }
 
+// The same for the static models' plain case -- per-group coefficients, no sample weights, no residuals, no "drop" mask, kt <= JB --
+// without the general kernel's control flow: there, the column pointers and the coefficients were fetched one by one inside the divergent
+// `full` branch, each behind its own s_waitcnt (eight dependent L2 round trips per workgroup before the first FMA: 4.06 TB/s on
+// 8 f32 features where the same frame streams at 5.5 through K1).  Here every index is a compile-time constant: one s_load for the pointers,
+// one for the coefficients, JB vector loads in flight, one wait.
+template <typename T, int JB>
+__global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a) {
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N;
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t base = s - (s % VEC);
+    const int ku = a.k_user, kt = a.kt;
+    const double *cg = a.coef64 + (size_t)(a.gmap ? a.gmap[g] : g) * kt;
+    T *pred = static_cast<T *>(a.pred);
+    const int pol = a.null_policy;
+    T c[JB];
+#pragma unroll
+    for (int u = 0; u < JB; ++u) c[u] = (u < kt) ? (T)cg[u] : T(0);   // (zero beyond kt: the unrolled sums below run over all JB slots)
+    for (int64_t row0 = base + ((int64_t)blockIdx.y * 256 + threadIdx.x) * VEC; row0 < e; row0 += (int64_t)gridDim.y * 256 * VEC) {
+        T p[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) p[v] = T(0);
+        if ((row0 >= s) && (row0 + VEC <= e)) {
+            V tv[JB];
+#pragma unroll
+            for (int u = 0; u < JB; ++u)
+                if (u < ku) tv[u] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[u]) + row0);
+#pragma unroll
+            for (int u = 0; u < JB; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) p[v] = fma((u < ku) ? null_fill<T>(pol, vget<T>(tv[u], v)) : T(1), c[u], p[v]);
+            V o;
+            if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
+            store_stream(reinterpret_cast<V *>(pred + row0), o);
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int64_t r = row0 + v;
+                if (r >= s && r < e) {
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) p[v] = fma((u < ku) ? null_fill<T>(pol, static_cast<const T *>(a.x[u])[r]) : T(1), c[u], p[v]);
+                    pred[r] = p[v];
+                }
+            }
+        }
+    }
+}
+
 int predict_launch(pols_ctx *ctx, int dtype, const PredictArgs &a) {
     if (a.n_groups == 0) return POLS_OK;
-    if (dtype == POLS_F32) hipLaunchKernelGGL(predict_kernel<float>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(predict_kernel<double>, dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    const int64_t per_wg = 256 * (dtype == POLS_F32 ? 4 : 2);
+    int64_t gy = std::max<int64_t>(1, (a.max_item_rows + per_wg - 1) / per_wg);
+    gy = std::min<int64_t>(std::min<int64_t>(gy, 1024), std::max<int64_t>(1, 16384 / a.n_groups));   // (short items of the same frame get gy - 1 empty workgroups each)
+    if (ctx->opt.predict_loop) gy = 1;
+    const dim3 grid((unsigned)a.n_groups, (unsigned)gy);
+    const int jb = a.kt <= 4 ? 4 : (a.kt <= 8 ? 8 : (a.kt <= 12 ? 12 : 16));
+    if (a.coef64 && !a.w && !a.resid && a.pred && a.null_policy != POLS_NULL_DROP && a.kt <= 16 && !ctx->opt.predict_loop) {
+#define POLS_PREDICT_GROUPS_GO(T)                                                                                           \
+    do {                                                                                                                    \
+        if (jb == 4) hipLaunchKernelGGL((predict_groups_kernel<T, 4>), grid, dim3(256), 0, ctx->stream, a);                 \
+        else if (jb == 8) hipLaunchKernelGGL((predict_groups_kernel<T, 8>), grid, dim3(256), 0, ctx->stream, a);            \
+        else if (jb == 12) hipLaunchKernelGGL((predict_groups_kernel<T, 12>), grid, dim3(256), 0, ctx->stream, a);          \
+        else hipLaunchKernelGGL((predict_groups_kernel<T, 16>), grid, dim3(256), 0, ctx->stream, a);                        \
+    } while (0)
+        if (dtype == POLS_F32) POLS_PREDICT_GROUPS_GO(float);
+        else POLS_PREDICT_GROUPS_GO(double);
+#undef POLS_PREDICT_GROUPS_GO
+        POLS_HIP(hipGetLastError());
+        return POLS_OK;
+    }
+#define POLS_PREDICT_GO(T)                                                                                          \
+    do {                                                                                                            \
+        if (jb == 4) hipLaunchKernelGGL((predict_kernel<T, 4>), grid, dim3(256), 0, ctx->stream, a);                \
+        else if (jb <= 8) hipLaunchKernelGGL((predict_kernel<T, 8>), grid, dim3(256), 0, ctx->stream, a);           \
+        else hipLaunchKernelGGL((predict_kernel<T, 16>), grid, dim3(256), 0, ctx->stream, a);                       \
+    } while (0)
+    if (dtype == POLS_F32) POLS_PREDICT_GO(float);
+    else POLS_PREDICT_GO(double);
+#undef POLS_PREDICT_GO
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

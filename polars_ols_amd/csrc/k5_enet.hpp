@@ -68,6 +68,7 @@ struct PredictArgs {
     const uint8_t *valid;
     int32_t null_policy;
     const int32_t *gmap;    // SPLIT groups (or nullptr): `offs` cuts long groups into segments, segment g uses the coefficients of group gmap[g]
+    int64_t max_item_rows;  // rows of the longest item of `offs` (or 0 = unknown): sizes the workgroups per item
 };
 
 // Long groups cut into segments (one workgroup each in gram_stream / predict): partial Gram matrices (and fit-row counts) of the
@@ -81,10 +82,17 @@ struct GramReduceArgs {
     int64_t n_groups;
     int32_t nz2;
     int32_t max_segments;   // most segments of one group (0: unknown -> the four-wave form)
+    double *slices;         // n_groups x n_slices x NZ x NZ or nullptr: few groups of very many segments -- two-level sum (gram_reduce_launch)
+    int32_t n_slices;
 };
 int gram_reduce_launch(pols_ctx *ctx, const GramReduceArgs &a);
 
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a);
+// K5v (k5v_gram.hip): the same pass on the VALU, rows loaded straight into registers -- up to K5V_MAX_KT columns, no sample weights, no
+// null policy; gram_stream_launch routes to it (POLS_KG_SINGLE_BUFFER = the round-4 pass: MFMA tiles, one 256-row LDS buffer)
+constexpr int K5V_MAX_KT = 10;
+bool gram_valu_takes(const pols_ctx *ctx, const GramArgs &a);
+int gram_valu_launch(pols_ctx *ctx, int dtype, const GramArgs &a);
 int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a);
 // OLS / ridge (alpha = ridge penalty) from the streamed Gram: generic kt <= 31, any group size
 int gram_solve_launch(pols_ctx *ctx, int dtype, const CdArgs &a);

@@ -1,0 +1,133 @@
+// k5v_gram.hip -- K5v: the streamed Gram pass on the VALU, for up to ten columns without sample weights or a null policy.
+//
+// The streamed path (K5: a Gram pass, the small solve, a prediction pass) serves every group that is too long to stay in registers --
+// and the one-regression-over-the-whole-frame call of the reference's README (long groups cut into segments).  Its Gram kernel puts
+// Z'Z (Z = [X | y]) on the matrix cores in 16-column tiles, which is the right shape at 16 or 31 columns; at 9 columns a third of the tile
+// is useful, half of that is the mirror image, and on this part the f32 / f64 MFMA peaks EQUAL the vector peaks (157 / 78.6 TFLOP/s), so
+// the tile only costs: the f64 16x16x4 MFMA is 64 cycles for 4 rows -- 54 % of the matrix pipe at the HBM rate for 72-byte rows, behind
+// LDS staging with a barrier per chunk.  gram_stream measured 3.8 / 4.2 TB/s (f32 / f64, 8 features) before and 4.4 / 4.0 after 4 KB
+// pieces and double buffering (profiles/r05_long_groups_ab.txt).
+//
+// Here every lane loads 16-byte vectors (4 f32 / 2 f64 rows) of each column straight into registers -- 4 KB pieces per column per
+// workgroup step, nothing staged -- and accumulates the (kt + 1)(kt + 2) / 2 packed products of its own rows: 45 FMAs per row at 8
+// columns, 19 % of the vector pipe at the HBM rate.  The lanes' sums (f32 frames: at most a few dozen rows each, so the f32 partial
+// carries no visible error) are converted to f64, reduce-scattered over the wave, and added across the four waves in wave order:
+// the Gram matrix leaves in f64 in the layout gram_stream_kernel writes, for the same consumers (gram_reduce, gram_solve, gram_cd).
+#include "k5_enet.hpp"
+
+namespace pols {
+
+template <int NZ>
+__host__ __device__ constexpr int k5v_tri(int i, int j) { return i * NZ - i * (i - 1) / 2 + (j - i); }   // packed upper triangle, i <= j < NZ
+
+template <typename T, int KT>
+__global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NZ = KT + 1, NACC = NZ * (NZ + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t g = blockIdx.x;
+    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t base = s - (s % VEC);
+    const int ku = a.k_user;                                 // KT or KT - 1: only the last slot can be the intercept column
+
+    T acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = T(0);
+
+    for (int64_t row0 = base + (int64_t)tid * VEC; row0 < e; row0 += 256 * VEC) {
+        V z[NZ];
+        if (row0 >= s && row0 + VEC <= e) {
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                if (j < KT - 1 || j < ku) z[j] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + row0));
+                else { if constexpr (VEC == 4) z[j] = V{T(1), T(1), T(1), T(1)}; else z[j] = V{T(1), T(1)}; }
+            }
+            z[KT] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
+        } else {                                             // the segment's first / last vector: rows outside it are zero rows
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                T t[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const int64_t r = row0 + v;
+                    const bool in = r >= s && r < e;
+                    if (j == KT) t[v] = in ? static_cast<const T *>(a.y)[r] : T(0);
+                    else if (j < KT - 1 || j < ku) t[v] = in ? static_cast<const T *>(a.x[j])[r] : T(0);
+                    else t[v] = in ? T(1) : T(0);
+                }
+                if constexpr (VEC == 4) z[j] = V{t[0], t[1], t[2], t[3]}; else z[j] = V{t[0], t[1]};
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) {
+                const T zi = vget<T>(z[i], v);
+#pragma unroll
+                for (int j = i; j < NZ; ++j) acc[k5v_tri<NZ>(i, j)] = fma(zi, vget<T>(z[j], v), acc[k5v_tri<NZ>(i, j)]);
+            }
+    }
+
+    // ---- lanes -> wave (f64 reduce-scatter) -> workgroup (LDS, wave order) -> the symmetric NZ x NZ matrix
+    double accd[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) accd[q] = (double)acc[q];
+    constexpr int NU = (NACC + 3) / 4;
+    double u[NU];
+    wave_reduce_scatter<double, NACC>(accd, u);             // u[i], in every lane of 16-lane row r: the wave total of entry 4 i + rs_perm(r)
+    __shared__ double part[4][NU * 4];
+    if ((lane & 15) == 0) {
+        const int r = rs_perm(lane >> 4);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) part[wave][4 * i + r] = u[i];
+    }
+    __syncthreads();
+    double *G = a.gram + (size_t)g * NZ * NZ;
+    if (tid < NZ * NZ) {
+        const int i = tid / NZ, j = tid - i * NZ;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int q = lo * NZ - lo * (lo - 1) / 2 + (hi - lo);
+        G[tid] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+    }
+}
+
+template <typename T, int KT>
+static void k5v_go(pols_ctx *ctx, const GramArgs &a) {
+    hipEvent_t ev0, ev1;
+    if (timing_pair(ctx, &ev0, &ev1)) hipExtLaunchKernelGGL((gram_valu_kernel<T, KT>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gram_valu_kernel<T, KT>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+}
+
+template <typename T>
+static int k5v_launch_t(pols_ctx *ctx, const GramArgs &a) {
+    switch (a.kt) {
+        case 1: k5v_go<T, 1>(ctx, a); break;
+        case 2: k5v_go<T, 2>(ctx, a); break;
+        case 3: k5v_go<T, 3>(ctx, a); break;
+        case 4: k5v_go<T, 4>(ctx, a); break;
+        case 5: k5v_go<T, 5>(ctx, a); break;
+        case 6: k5v_go<T, 6>(ctx, a); break;
+        case 7: k5v_go<T, 7>(ctx, a); break;
+        case 8: k5v_go<T, 8>(ctx, a); break;
+        case 9: k5v_go<T, 9>(ctx, a); break;
+        case 10: k5v_go<T, 10>(ctx, a); break;
+        default: return fail(POLS_ERR_UNSUPPORTED, "k5v: %d columns", a.kt);
+    }
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+bool gram_valu_takes(const pols_ctx *ctx, const GramArgs &a) {
+    return a.kt >= 1 && a.kt <= K5V_MAX_KT && !a.w && a.null_policy == POLS_NULL_IGNORE && !a.nvalid && !ctx->opt.kg_single_buffer;
+}
+
+int gram_valu_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
+    if (a.n_groups > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
+    char name[96];
+    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_valu_k%d", dtype == POLS_F32 ? "f32" : "f64", a.kt);
+    ctx->last_kernel = name;
+    return dtype == POLS_F32 ? k5v_launch_t<float>(ctx, a) : k5v_launch_t<double>(ctx, a);
+}
+
+}  // namespace pols
