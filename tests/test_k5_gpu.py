@@ -275,3 +275,36 @@ def test_static_few_long_groups_are_split_into_segments(eng, dtype, tol, sizes, 
         ref = orc.batched_least_squares(y, cols, offs, **okw)
         assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
         assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,icpt,kind", [(1, False, "ols"), (1, True, "ols"), (2, False, "ridge"), (3, True, "ols"), (4, False, "lu"), (5, True, "ridge"),
+                                         (6, False, "ols"), (7, True, "ols"), (8, False, "ols"), (8, True, "ridge"), (9, True, "ols"), (10, False, "lu"),
+                                         (9, False, "enet")])
+def test_static_long_groups_valu_gram(eng, dtype, tol, k, icpt, kind):
+    """Round 5: plain frames (no weights, no null policy) of up to ten columns take the VALU Gram pass (K5v, k5v_gram.hip) and the lean
+    prediction kernel whenever a group is too long for the register-resident kernels -- ragged, unaligned groups next to short ones,
+    every solver the streamed path serves, against the oracle."""
+    from oracle import orc
+
+    rng = np.random.default_rng(100 * k + int(icpt))
+    sizes = [5_001, 12_345, 7, 9_000, 0, 4_097 + k, 3, 20_011]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, _ = _frame(rng, offs, k, dtype, sparsity=0.0)
+    kw = {"ols": {}, "ridge": dict(alpha=0.7, l1_ratio=0.0), "lu": dict(solve_method="lu"),
+          "enet": dict(alpha=0.01, l1_ratio=0.5, tol=1e-10, max_iter=20_000)}[kind]
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream") and "_valu_" in eng.last_kernel, eng.last_kernel
+    ref = orc.batched_least_squares(y, cols, offs, add_intercept=icpt, **kw)
+    st = _np(out["status"]).astype(int)
+    # (the 3-row group has fewer rows than columns from k = 4 on and the empty one is flagged empty; everything else factors)
+    long_rows = np.repeat(np.asarray(sizes) >= 1000, sizes)
+    long_groups = np.asarray(sizes) >= 1000
+    assert (st[long_groups] == 0).all(), st
+    kt = k + int(icpt)
+    got_c, ref_c = _np(out["coef"]).reshape(-1, kt), np.asarray(ref["coef"]).reshape(-1, kt)
+    assert np.allclose(got_c[long_groups], ref_c[long_groups], rtol=tol, atol=tol), float(np.abs(got_c[long_groups] - ref_c[long_groups]).max())
+    for key in ("pred", "resid"):
+        assert np.allclose(_np(out[key])[long_rows], np.asarray(ref[key])[long_rows], rtol=tol, atol=tol), key
+    if kind in ("ols", "ridge"):      # the short groups too: same reference branch per group (n <= k groups get the minimum-norm fix-up)
+        assert np.allclose(got_c, ref_c, rtol=10 * tol, atol=10 * tol), float(np.abs(got_c - ref_c).max())
