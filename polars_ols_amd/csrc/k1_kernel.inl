@@ -1521,6 +1521,12 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             // 88.5: the single-pass form (below 6 columns) with 4-5 columns keeps its 16-lane teams
             if (need <= 8 * 2 * VEC && s8 != 0 && s8 != 1 && (KT >= K1T_PASS_MIN_KT || KT <= 3 || s8 == 2)) return k1t_launch<T, KT, HAS_W, 8, 2>(ctx, a);
         }
+        if constexpr (KT <= 8 && sizeof(T) == 8 && KT >= K1T_PASS_MIN_KT) {
+            // f64, three chunks per lane of an eight-lane team (48 rows: a month or two of trading days per group), eight groups per wave
+            // where the 16-lane team's 32 slots were at most 2/3 full
+            const int s8 = ctx->opt.k1t_sub8;
+            if (need > 16 * 1 * VEC && need <= 8 * 3 * VEC && s8 != 0 && s8 != 1) return k1t_launch<T, KT, HAS_W, 8, 3>(ctx, a);
+        }
         if (need <= 16 * 1 * VEC) return k1t_launch<T, KT, HAS_W, 16, 1>(ctx, a);      // one chunk per lane: a third fewer registers
         if (need <= 16 * 2 * VEC) return k1t_launch<T, KT, HAS_W, 16, 2>(ctx, a);
         // four chunks per lane (128 f64 / 256 f32 rows): f64 with 6+ columns has the registers for it since the two-pass form;

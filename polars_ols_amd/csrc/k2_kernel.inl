@@ -631,6 +631,9 @@ int k2_launch_t(pols_ctx *ctx, const K2Args &a, int64_t need) {
     if (need <= 256 * 1 * VEC) return k2_launch_shape<T, HAS_W, 4, 1>(ctx, a);
     if (need <= 256 * 2 * VEC) return k2_launch_shape<T, HAS_W, 4, 2>(ctx, a);
     if (need <= 512 * 2 * VEC) return k2_launch_shape<T, HAS_W, 8, 2>(ctx, a);
+    // up to eight columns: four chunks per lane (128 + 32 data registers of the 256) -- 8 192 f32 / 4 096 f64 rows stay on chip, twenty
+    // to thirty years of trading days per asset; the streamed path reads such groups twice (2.8 TB/s of algorithmic bytes)
+    if (a.kt >= 7 && a.kt <= 8 && need <= 512 * 4 * VEC) return k2_launch_v<T, 8, 8, 4, false, HAS_W>(ctx, a);
     return fail(POLS_ERR_UNSUPPORTED, "k2: %lld-row groups exceed the resident capacity", (long long)need);
 }
 

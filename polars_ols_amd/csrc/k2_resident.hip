@@ -13,7 +13,10 @@ static int64_t k2_need(int dtype, int64_t max_group_rows, bool offsets_aligned) 
 
 bool k2_fits(int dtype, int kt, int64_t max_group_rows, bool offsets_aligned) {
     const int vec = dtype == POLS_F32 ? 4 : 2;
-    return kt >= 1 && kt <= K2_KMAX && k2_need(dtype, max_group_rows, offsets_aligned) <= (int64_t)512 * 2 * vec;   // (+ n_rows >= vec: caller)
+    return kt >= 1 && kt <= K2_KMAX && k2_need(dtype, max_group_rows, offsets_aligned) <= (int64_t)512 * ((kt == 7 || kt == 8) ? 4 : 2) * vec;   // (+ n_rows >= vec: caller)
+    // (four chunks per lane, 8 192 f32 / 4 096 f64 rows: the eight-slot kernel loads all eight column slots whatever kt is, so below seven
+    // columns the two-pass streamed path is faster -- 2.8-3.0 TB/s against 1.4-2.7; at 7-8 columns 2.9-4.1 against 2.8,
+    // profiles/r05_sweep_k2rc4_ab.txt)
 }
 
 int k2_launch(pols_ctx *ctx, int dtype, const K2Args &a, int64_t max_group_rows) {

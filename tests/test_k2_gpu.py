@@ -315,7 +315,11 @@ def test_k2w_is_the_default_beyond_the_resident_k1_shapes(eng, k, family):
 
 
 @pytest.mark.parametrize("dtype,k,rows,family", [(np.float64, 12, 1300, "k2_gram_mfma_resident_f64_k16_w8_rc2"), (np.float64, 9, 1100, "k1_gram_chol_f64_k9_team256_rc4"),
-                                                 (np.float32, 14, 2600, "k2_gram_mfma_resident_f32_k16_w8_rc2"), (np.float32, 9, 2600, "k1_gram_chol_f32_k9_team256_rc4")])
+                                                 (np.float32, 14, 2600, "k2_gram_mfma_resident_f32_k16_w8_rc2"), (np.float32, 9, 2600, "k1_gram_chol_f32_k9_team256_rc4"),
+                                                 # round 5, up to eight columns: four chunks per lane of the eight-wave K2 (8 192 f32 / 4 096 f64 rows)
+                                                 (np.float64, 8, 4090, "k2_gram_mfma_resident_f64_k8_w8_rc4"), (np.float64, 7, 2300, "k2_gram_mfma_resident_f64_k8_w8_rc4"),
+                                                 (np.float32, 8, 8190, "k2_gram_mfma_resident_f32_k8_w8_rc4"), (np.float32, 7, 6000, "k2_gram_mfma_resident_f32_k8_w8_rc4"),
+                                                 (np.float32, 3, 4300, "k5_gram_stream_f32_valu_k3"), (np.float64, 5, 2300, "k5_gram_stream_f64_valu_k5")])
 def test_over_resident_groups_route_to_k2_where_it_wins(eng, dtype, k, rows, family):
     """Rows beyond K1's registers, tile within LDS: K2 by default (it beats the LDS-tile engine there since round 3) except f32 with 9-10
     columns; ragged groups whose upper waves own no row of the second chunk (they skip its tile stages).  Round 5: up to 10 columns K1's own
