@@ -141,7 +141,8 @@ def test_hot_kernels_keep_their_arrays_in_registers():
     hot = ("pols::k1_kernel<", "pols::k1t_kernel<", "pols::k1p_kernel<", "pols::k1m_kernel<", "pols::k2_kernel<", "pols::gram_stream_kernel<",
            "pols::predict_kernel<", "pols::gram_solve_kernel<", "pols::take_kernel<", "pols::arrow_ingest_kernel<",
            "pols::k2w_kernel<", "pols::k3c_kernel<", "pols::k4c_kernel<",      # round 4: the 17..31-column and the row-parallel dynamic kernels
-           "pols::kp_rls_walk_kernel<", "pols::kp_rolling_walk_kernel<", "pols::kp_totals_kernel<", "pols::k6s_kernel<")   # round 5 (three nested lambdas
+           "pols::kp_rls_walk_kernel<", "pols::kp_rolling_walk_kernel<", "pols::kp_totals_kernel<", "pols::k6s_kernel<",
+           "pols::gram_valu_kernel<", "pols::predict_groups_kernel<")   # round 5 (three nested lambdas
     # around K4p's chunk-start sums once parked its state in 864 bytes of scratch per lane: 2.6 -> 17.8 ms, again without a warning)
     bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0}
     assert not bad, sorted(bad.items())[:5]
