@@ -119,12 +119,14 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
     for (; g < cnt; ++g) h0 = (h0 ^ u[g]) * P;
     int64_t mx = 0, ored = 0, mn = 0, mn_pos = INT64_MAX;
     for (int64_t i = 0; i < cnt; ++i) ored |= offs[i];
+    int32_t small_mask = 0;                            // which of K6s' team sizes the frame has groups for
     int64_t over = 0;                                  // rows beyond the 1 021 (+ 3 of chunk-grid slack) a wave-per-group f32 kernel keeps resident
     for (int64_t i = 1; i < cnt; ++i) {
         const int64_t d = offs[i] - offs[i - 1];
         mn = d < mn ? d : mn; mx = d > mx ? d : mx;
         mn_pos = (d > 0 && d < mn_pos) ? d : mn_pos;
         over += d > 1021 ? d - 1021 : 0;
+        if (d > 0 && d <= 32) small_mask |= d <= 4 ? 1 : (d <= 8 ? 2 : (d <= 16 ? 4 : 8));
     }
     if (mn < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending");
     const uint64_t sum = ((h0 * 31 + h1) * 31 + h2) * 31 + h3;
@@ -144,6 +146,7 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
     ctx->offs_generation = generation;
     ctx->offs_max_rows = mx;
     ctx->offs_min_rows = mn_pos == INT64_MAX ? 0 : mn_pos;
+    ctx->offs_small_mask = small_mask;
     ctx->offs_wave_overflow = over;
     {
         int64_t tail = -1;                             // the last group that has rows: its chunk grid may cross the end of the columns

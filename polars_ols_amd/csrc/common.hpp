@@ -116,6 +116,7 @@ struct pols_ctx {
     int pinned_next = 0;
     int64_t offs_max_rows = 0;
     int64_t offs_min_rows = 0;               // fewest rows of a NON-EMPTY group (0: no group has rows)
+    int32_t offs_small_mask = 0;             // bit b: some group has (b ? 2 << b : 0) < rows <= 4 << b, b = 0..3 (1-4, 5-8, 9-16, 17-32 rows): K6s team sizes
     int64_t offs_tail_group = -1;            // last group with rows (K1p hands it to one wave when n_rows is not a multiple of the vector width)
     int64_t offs_wave_overflow = 0;          // sum over groups of the rows beyond 1 021 (see k1_launch_kw)
     int32_t *fb_flag = nullptr;              // device word, see K1Args::fb_flag

@@ -24,15 +24,28 @@ int k6_launch(pols_ctx *ctx, int dtype, const K6Args &a, int workers) {
     // per group; the host knows from the offsets whether the frame holds any (no extra dispatch on the frames the benchmarks visit).
     K6Args aa = a;
     aa.small_rows = 0;
-    const int64_t short_rows = ctx->offs_min_rows;                // fewest rows of a non-empty group
-    if (short_rows > 0 && short_rows <= 32 && (a.mode == FIX_MINNORM || (a.mode == FIX_OLS_AUTO && short_rows <= a.kt))) {
-        const int64_t top = std::min<int64_t>(32, ctx->offs_max_rows);
-        aa.small_rows = top <= 4 ? 4 : top <= 8 ? 8 : top <= 16 ? 16 : 32;
+    aa.small_lo = 0;
+    // one K6s launch per team size the frame has groups for (the offsets scan knows: 1-4, 5-8, 9-16, 17-32 rows) -- a frame of 1 000-row groups
+    // with 100 000 six-row groups among them ran all of those in 32-lane teams (31 rounds per sweep over 26 zero rows): 1.83 ms, now the 8-lane form
+    int top_team = 0;
+    for (int b = 3; b >= 0 && top_team == 0; --b) {
+        const int lo = b ? (2 << b) : 0;
+        if (((ctx->offs_small_mask >> b) & 1) && (a.mode == FIX_MINNORM || (a.mode == FIX_OLS_AUTO && lo < a.kt))) top_team = 4 << b;
     }
+    aa.small_rows = top_team;                                     // what the pool leaves to K6s: k6s_takes(mode, n, kt, top_team)
     if (dtype == POLS_F32) hipLaunchKernelGGL(k6_svd_kernel<float>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, aa);
     else hipLaunchKernelGGL(k6_svd_kernel<double>, dim3((unsigned)workers), dim3(256), 0, ctx->stream, aa);
     POLS_HIP(hipGetLastError());
-    if (aa.small_rows > 0) return k6s_launch(ctx, dtype, aa);
+    bool first = true;
+    for (int b = 0; b < 4 && (4 << b) <= top_team; ++b) {
+        if (!((ctx->offs_small_mask >> b) & 1)) continue;
+        K6Args as = aa;
+        as.small_rows = 4 << b;
+        as.small_lo = first ? -1 : (2 << b);        // (the first launch also owns the flagged EMPTY groups, which the pool leaves to K6s like every n <= top_team)
+        first = false;
+        int rc = k6s_launch(ctx, dtype, as);
+        if (rc) return rc;
+    }
     return POLS_OK;
 }
 

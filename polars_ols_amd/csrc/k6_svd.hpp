@@ -26,6 +26,7 @@ struct K6Args {
     int32_t null_policy;
     int32_t mode;            // FixMode (fix_solvers.inl)
     int32_t small_rows;      // > 0: flagged groups of at most this many rows whose solver is the SVD belong to K6s (k6s_small.hip); K6 skips them
+    int32_t small_lo;        // K6s launches only: groups of more than this many rows (one launch per team size, k6_launch)
 };
 
 // Does K6s (a sub-wave team per group, dual Jacobi) take this flagged group?  Decided from (mode, rows, columns) alone so that K6 and K6s

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k6s_kernel(const K6Args a) {
     if (live) { s = a.offs[g]; e = a.offs[g + 1]; flagged = a.status[g] == POLS_GROUP_FALLBACK; }
     const int64_t n = e - s;
     const bool shaped = by_shape && n > 0 && n <= (int64_t)kt;    // n < kt: singular by construction; n == kt: the reference still takes the SVD
-    live = live && (flagged || shaped) && k6s_takes(a.mode, n, kt, a.small_rows);
+    live = live && (flagged || shaped) && k6s_takes(a.mode, n, kt, a.small_rows) && n > (int64_t)a.small_lo;   // (small_lo: the next smaller team size's launch has the shorter groups)
     if (!__any(live)) return;                                      // (wave-uniform; from here on every lane stays active: the shuffles need them)
 
     // ---- lane `sub` = data row s + sub: kt features and the target, sqrt(w)-scaled; dropped rows and lanes beyond the group: zero rows

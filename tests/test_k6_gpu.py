@@ -299,3 +299,30 @@ def test_short_groups_full_size_min_norm(eng):
         assert (_np(out["status"]) == 1).all()
         assert np.allclose(got, exp, rtol=tol, atol=tol), float(np.abs(got - exp).max())
         assert np.allclose(_np(out["pred"]).reshape(G, n), Y, rtol=10 * tol, atol=10 * tol)     # n < k: the fit interpolates
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("method", [None, "svd"])
+def test_short_groups_among_long_ones_use_their_own_team_size(eng, dtype, tol, method):
+    """A frame of 1 000-row groups with hundreds of 3-, 6-, 12- and 20-row groups among them (assets that only just listed): K6s is launched once
+    per team size the offsets hold (4 / 8 / 16 / 32 lanes), not once at the size of the largest short group -- 100 000 six-row groups among
+    5 000 long ones took 1.83 ms in 32-lane teams, 0.2 ms now (profiles/r05_bench_shape_cliffs.txt).  Every short group against the oracle."""
+    from oracle import orc
+
+    rng = np.random.default_rng(11)
+    k = 8
+    sizes = np.array([1000] * 12 + [6] * 300 + [3] * 50 + [0] + [12] * 40 + [20] * 30 + [1000] * 3 + [7] * 9)
+    rng.shuffle(sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(c.astype(np.float64) for c in cols) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, want=("coef", "pred", "status"), solve_method=method)
+    ref = orc.batched_least_squares(y, cols, offs, solve_method=method)
+    st = _np(out["status"]).astype(int)
+    assert (st[sizes == 0] == 2).all() and (st[(sizes > 0) & (sizes < k)] == 1).all() and (st[sizes == 1000] == 0).all()
+    coef = _np(out["coef"])
+    assert np.allclose(coef, ref["coef"], rtol=10 * tol, atol=10 * tol), float(np.abs(coef - ref["coef"]).max())
+    short = sizes < k
+    assert np.allclose(coef[short], ref["coef"][short], rtol=tol, atol=tol), float(np.abs(coef[short] - ref["coef"][short]).max())
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=10 * tol, atol=10 * tol)
