@@ -120,6 +120,7 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
     int64_t mx = 0, ored = 0, mn = 0, mn_pos = INT64_MAX;
     for (int64_t i = 0; i < cnt; ++i) ored |= offs[i];
     int32_t small_mask = 0;                            // which of K6s' team sizes the frame has groups for
+    int64_t hist_cnt[48] = {0}, hist_rows[48] = {0};
     int64_t over = 0;                                  // rows beyond the 1 021 (+ 3 of chunk-grid slack) a wave-per-group f32 kernel keeps resident
     for (int64_t i = 1; i < cnt; ++i) {
         const int64_t d = offs[i] - offs[i - 1];
@@ -127,6 +128,8 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
         mn_pos = (d > 0 && d < mn_pos) ? d : mn_pos;
         over += d > 1021 ? d - 1021 : 0;
         if (d > 0 && d <= 32) small_mask |= d <= 4 ? 1 : (d <= 8 ? 2 : (d <= 16 ? 4 : 8));
+        const int bkt = d <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(d - 1));
+        hist_cnt[bkt < 47 ? bkt : 47]++; hist_rows[bkt < 47 ? bkt : 47] += d;
     }
     if (mn < 0) return fail(POLS_ERR_INVALID, "group_offsets must be ascending");
     const uint64_t sum = ((h0 * 31 + h1) * 31 + h2) * 31 + h3;
@@ -147,6 +150,8 @@ int upload_offsets(pols_ctx *ctx, const int64_t *offs, int64_t n_groups, const i
     ctx->offs_max_rows = mx;
     ctx->offs_min_rows = mn_pos == INT64_MAX ? 0 : mn_pos;
     ctx->offs_small_mask = small_mask;
+    std::memcpy(ctx->offs_hist_cnt, hist_cnt, sizeof(hist_cnt));
+    std::memcpy(ctx->offs_hist_rows, hist_rows, sizeof(hist_rows));
     ctx->offs_wave_overflow = over;
     {
         int64_t tail = -1;                             // the last group that has rows: its chunk grid may cross the end of the columns
@@ -183,6 +188,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_F64_TEAM")) o.k1_f64_team256 = on && std::atoi(v) == 256;
     else if (ieq(key, "KG_NOYV")) o.kg_noyv = on;
     else if (ieq(key, "KG_SINGLE_BUFFER")) o.kg_single_buffer = on;
+    else if (ieq(key, "NO_CLASSES")) o.no_classes = on;
     else if (ieq(key, "PREDICT_LOOP")) o.predict_loop = on;
     else if (ieq(key, "K2_NOPREFETCH")) o.k2_noprefetch = on;
     else if (ieq(key, "NO_SPLIT")) o.no_split = on;
@@ -211,7 +217,7 @@ void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
                                        "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
-                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE", "KG_SINGLE_BUFFER", "PREDICT_LOOP"};
+                                       "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE", "KG_SINGLE_BUFFER", "PREDICT_LOOP", "NO_CLASSES"};
     char name[64];
     for (const char *k : keys) {
         std::snprintf(name, sizeof(name), "POLS_%s", k);
@@ -883,6 +889,52 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
     return POLS_OK;
 }
 
+// Size-class split of the static K1 path (see the launches at the end of ls_core): up to two thresholds t[0] < t[1] (rows), n = how many; 0 = one launch.
+// Cost model: a group costs max(rows, 0.3 x the capacity of the kernel its class gets) row-times (fitted to scripts/bench_spread.py: log-normal sizes
+// with a 4 000-row tail 1.5 TB/s, 90 % 50-row + 10 % 1 000-row groups 1.9 TB/s in one launch), an extra launch a fixed 6e5.
+static int pick_size_classes(const pols_ctx *ctx, bool f32, int64_t n_groups, int64_t max_rows, int64_t (&t)[2]) {
+    t[0] = t[1] = 0;
+    if (ctx->opt.no_classes || n_groups < 2048) return 0;
+    const double alpha = 0.3, launch_cost = 6.0e5;                    // (an extra launch: ~5 us of a chip that moves ~1.2e5 rows per us)
+    const int b0 = f32 ? 7 : 6;                                       // the smallest kernels hold 128 f32 / 64 f64 rows per group
+    int bc = b0;
+    while (((int64_t)1 << bc) < max_rows && bc < 46) ++bc;            // capacity of the kernel the largest group asks for: 2^bc rows
+    // cost with class boundaries at buckets s0 < s1 (-1: unused): bucket q goes to the first boundary >= q, else to the top kernel
+    auto cost = [&](int s0, int s1) {
+        double c = launch_cost * ((s0 >= 0) + (s1 >= 0));
+        for (int q = 0; q < 48; ++q) {
+            if (!ctx->offs_hist_cnt[q]) continue;
+            const double avg = (double)ctx->offs_hist_rows[q] / (double)ctx->offs_hist_cnt[q];
+            const int kb = (s0 >= 0 && q <= s0) ? s0 : ((s1 >= 0 && q <= s1) ? s1 : bc);
+            c += (double)ctx->offs_hist_cnt[q] * std::max(avg, alpha * (double)((int64_t)1 << kb));
+        }
+        return c;
+    };
+    auto count_le = [&](int sb) { int64_t n = 0; for (int q = 0; q <= sb; ++q) n += ctx->offs_hist_cnt[q]; return n; };
+    const double one = cost(-1, -1);
+    double best = one;
+    int bs0 = -1, bs1 = -1;
+    for (int s1 = b0; s1 < bc; ++s1) {
+        const int64_t le1 = count_le(s1);
+        if (le1 == 0 || le1 == n_groups) continue;
+        const double c1 = cost(-1, s1);
+        if (c1 < best) { best = c1; bs0 = -1; bs1 = s1; }
+        for (int s0 = b0; s0 < s1; ++s0) {
+            const int64_t le0 = count_le(s0);
+            if (le0 == 0 || le0 == le1) continue;
+            const double c2 = cost(s0, s1);
+            if (c2 < 0.9 * c1 && c2 < best) { best = c2; bs0 = s0; bs1 = s1; }   // (a third launch has to earn its exiting workgroups)
+        }
+    }
+    if (bs1 < 0 || !(best < 0.75 * one)) return 0;
+    // (a kernel that holds 2^b rows per group takes ragged groups of up to 2^b - (VEC - 1): the chunk grid starts at the 16-byte boundary below the group)
+    const int slack = ctx->offs_aligned[f32 ? 1 : 0] ? 0 : (f32 ? 3 : 1);
+    int n = 0;
+    if (bs0 >= 0) t[n++] = ((int64_t)1 << bs0) - slack;
+    t[n++] = ((int64_t)1 << bs1) - slack;
+    return n;
+}
+
 static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p, pols_out *o, LsInfo *info) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
@@ -1035,6 +1087,12 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         const bool k2_ok = !nulls && kt <= K2_KMAX && k2_fits(b->dtype, kt, max_rows, aligned) && b->n_rows >= vec && ctx->opt.static_engine != 1 &&
                            ctx->opt.static_engine != 3;
         const bool k1_resident = nulls ? k1_nulls_takes(ctx, f32, kt, max_rows) : k1_valu_takes(ctx, f32, kt, max_rows, b->weights != nullptr);
+        // (the eight-wave forms are ONE persistent workgroup per CU sized for the largest group: a frame whose groups mostly fill a fraction of it --
+        // log-normal sizes around 300 rows with a 4 000-row tail: 1.07 TB/s in the four-chunk form -- is better off on the streamed path, 2.9;
+        // elastic net keeps K2: its solve needs the rows once)
+        const int64_t k2_cap = max_rows > (int64_t)512 * 2 * vec ? (int64_t)512 * 4 * vec : (int64_t)512 * 2 * vec;
+        const bool k2_sparse = !enet && ctx->opt.static_engine != 2 && max_rows > (int64_t)256 * 2 * vec && b->n_groups >= 2048 &&
+                               (double)b->n_rows < 0.3 * (double)k2_cap * (double)b->n_groups;
         // POLS_K1_ENGINE=valu | mfma keep the K1 / K1m kernels reachable for the shapes they cover (A/B measurements, tests)
         const bool legacy_forced = (ctx->opt.k1_engine == 2 && kt <= K1M_MAX_KT) || (ctx->opt.k1_engine == 1 && kt <= K1_MAX_KT);
         (void)K1W_MAX_KT;
@@ -1052,7 +1110,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // 0.143 / 0.119 ms against K1m's 0.189 / 0.177 / 0.156 on 4 000 x 2 500, 3 333 x 3 000 and 2 500 x 4 000 rows; K1m keeps 9-10 columns.
         const bool k1m_wins = k1m_takes && f32 && kt >= 9 && kt <= 10;
         const bool want = enet || m == POLS_SOLVE_LU || ctx->opt.static_engine == 2 || (!k1_resident && !legacy_forced && !k1m_wins);
-        if (k2_ok && want) {
+        if (k2_ok && want && !k2_sparse) {
             K2Args a2;
             std::memset(&a2, 0, sizeof(a2));
             a2.y = st.y; a2.w = st.w;
@@ -1221,7 +1279,56 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     a.k_user = b->n_features;
     a.null_policy = pol;
     if ((rc = prepare_fix())) return rc;
-    if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
+    // SIZE CLASSES: the K1 family sizes its workgroup for the LARGEST group of the frame, so on a panel whose group sizes spread widely
+    // (most assets a few hundred rows, a few of them thousands) every small group paid for a team it did not fill -- log-normal sizes around
+    // 300 rows with a 4 000-row tail 1.5 TB/s, 90 % 50-row + 10 % 1 000-row groups 1.9 (scripts/bench_spread.py).  Two or three launches then,
+    // one per size class: each walks the list of its own groups with the kernel the dispatcher picks for the class' largest group.  The cuts come
+    // from the size histogram of the offsets scan and a two-parameter cost model (pick_size_classes).
+    int64_t class_t[2];
+    int n_cut = pick_size_classes(ctx, b->dtype == POLS_F32, b->n_groups, max_rows, class_t);
+    if (n_cut > 0 && !(nulls ? k1_nulls_takes(ctx, b->dtype == POLS_F32, kt, max_rows) : k1_valu_takes(ctx, b->dtype == POLS_F32, kt, max_rows, b->weights != nullptr)))
+        n_cut = 0;                                                   // (the largest groups would leave the K1 family: one launch as before)
+    if (ctx->opt.timeline || ctx->opt.k1_persist > 0 || b->n_groups > 0x7fffffffLL) n_cut = 0;
+    if (n_cut > 0) {
+        // the classes' group lists (ascending group ids, one list per class, in one buffer), rebuilt when the offsets or the cuts change
+        auto &cc = ctx->class_cache;
+        const int64_t t0 = class_t[0], t1 = n_cut > 1 ? class_t[1] : 0;
+        if (!(cc.ptr && cc.ptr == ctx->scratch[24].ptr && cc.offs_id == ctx->offs_id && cc.n_cut == n_cut && cc.t0 == t0 && cc.t1 == t1)) {
+            cc.ptr = nullptr;
+            std::vector<int32_t> lists[3];
+            for (int64_t g = 0; g < b->n_groups; ++g) {
+                const int64_t n = b->group_offsets[g + 1] - b->group_offsets[g];
+                lists[n <= t0 ? 0 : ((n_cut > 1 && n <= t1) ? 1 : n_cut)].push_back((int32_t)g);
+            }
+            void *d = nullptr;
+            if ((rc = ensure_scratch(ctx, 24, sizeof(int32_t) * (size_t)b->n_groups, &d))) return rc;
+            size_t at = 0;
+            for (int c = 0; c <= n_cut; ++c) {
+                if (!lists[c].empty() && (rc = upload_small(ctx, static_cast<int32_t *>(d) + at, lists[c].data(), sizeof(int32_t) * lists[c].size()))) return rc;
+                cc.n[c] = (int64_t)lists[c].size();
+                at += lists[c].size();
+            }
+            cc.ptr = d; cc.offs_id = ctx->offs_id; cc.n_cut = n_cut; cc.t0 = t0; cc.t1 = t1;
+        }
+        // (Tried: the long groups' launch on a second stream beside the short groups' -- fork / join through two events.  Slower: 0.136 against
+        // 0.124 ms on the log-normal frame, 0.102 against 0.089 on the 90 / 10 one; the two grids do not overlap enough to pay for the events.
+        // Tried first: every launch over ALL groups, the workgroups of the other classes exiting after reading their offsets -- 18 000 exits per
+        // launch on the log-normal frame cost more than the lists' indirection.)
+        std::string names;
+        int64_t first[3] = {0, cc.n[0], cc.n[0] + cc.n[1]};
+        for (int c = n_cut; c >= 0; --c) {                           // the long groups first: their workgroups take longest
+            if (cc.n[c] == 0) continue;
+            K1Args ac = a;
+            ac.glist = static_cast<const int32_t *>(cc.ptr) + first[c];
+            ac.n_groups = cc.n[c];
+            ac.class_max_rows = c < n_cut ? class_t[c] : max_rows;
+            if ((rc = k1_launch(ctx, b->dtype, kt, ac, ac.class_max_rows, true))) return rc;
+            names += (names.empty() ? "" : " | ") + ctx->last_kernel;
+        }
+        ctx->last_kernel = names;
+    } else {
+        if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;
+    }
     if ((rc = k6_launch(ctx, b->dtype, ka, fix_workers))) return rc;
     return finish(nullptr);
 }

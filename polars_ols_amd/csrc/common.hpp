@@ -49,6 +49,7 @@ struct Options {
     bool k1_shape_team = false;   // POLS_K1_SHAPE=team  f32: 256-thread teams instead of wave-per-group
     bool k1_shape_wave = false;   // POLS_K1_SHAPE=wave  f32: wave-per-group even where the 256-thread team is the default
     bool k1_f64_team256 = false;  // POLS_K1_F64_TEAM=256
+    bool no_classes = false;      // POLS_NO_CLASSES     static K1 path: one launch sized for the largest group whatever the spread of group sizes (the round-4 form)
     bool kg_single_buffer = false; // POLS_KG_SINGLE_BUFFER  streamed Gram: one LDS tile (the round-4 form), A/B for the double-buffered DMA
     bool predict_loop = false;    // POLS_PREDICT_LOOP   prediction pass: one looping workgroup per item (the round-4 form)
     bool kg_noyv = false;         // POLS_KG_NOYV        streamed Gram: keep the target in a second MFMA tile at 16 columns
@@ -91,7 +92,7 @@ struct pols_ctx {
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
     // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..22] row compaction of the rolling entry (columns, coefficients, start bytes, tile map), [23] segment tables + partial Gram matrices of the streamed static path
-    pols::Scratch scratch[24];
+    pols::Scratch scratch[25];
     pols::Options opt;
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
@@ -116,6 +117,7 @@ struct pols_ctx {
     int pinned_next = 0;
     int64_t offs_max_rows = 0;
     int64_t offs_min_rows = 0;               // fewest rows of a NON-EMPTY group (0: no group has rows)
+    int64_t offs_hist_cnt[48] = {0}, offs_hist_rows[48] = {0};   // groups / rows by size bucket b: 2^(b-1) < rows <= 2^b (bucket 0: 0 or 1 rows): the size-class split of ls_core
     int32_t offs_small_mask = 0;             // bit b: some group has (b ? 2 << b : 0) < rows <= 4 << b, b = 0..3 (1-4, 5-8, 9-16, 17-32 rows): K6s team sizes
     int64_t offs_tail_group = -1;            // last group with rows (K1p hands it to one wave when n_rows is not a multiple of the vector width)
     int64_t offs_wave_overflow = 0;          // sum over groups of the rows beyond 1 021 (see k1_launch_kw)
@@ -130,6 +132,7 @@ struct pols_ctx {
     // this frame does not pack (a sequence longer than a tile, or tiles too empty)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, tile_rows = 0, n_tiles = 0; } k3c;
     // segment tables of the streamed static path (scratch slot 23: long groups cut into segments): rebuilt when other offsets arrive
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t t0 = 0, t1 = 0, n[3] = {0, 0, 0}; int n_cut = 0; } class_cache;   // group lists of the size classes (slot 24)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0; size_t nz2 = 0; bool nulls = false; } seg_cache;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;

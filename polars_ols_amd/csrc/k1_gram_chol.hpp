@@ -47,6 +47,11 @@ struct K1Args {
     unsigned long long *dbg;             // POLS_TIMELINE=1: 8 s_memtime stamps per group (debug only)
     int64_t xcd_chunk;                   // 0: workgroup b takes block b of the groups; else b -> (b % 8) * xcd_chunk + b / 8, so that each XCD
                                          // (workgroups are dealt round-robin over the eight) walks one contiguous eighth of every column
+    // SIZE CLASSES (round 5): a frame whose group sizes spread widely is served by one launch per size class, each sized for its own largest
+    // group.  `glist` (or nullptr) lists the groups of this launch's class in ascending order and n_groups counts THEM: work item i is group
+    // glist[i]; class_max_rows (> 0) is the largest group of the class.
+    const int32_t *glist;
+    int64_t class_max_rows;
 };
 
 // Launches the (dtype, KT, team, resident-chunks) variant that fits max_group_rows.

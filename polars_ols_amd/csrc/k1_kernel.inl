@@ -569,8 +569,9 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
     const int lane = tix & 63;
     const int wave = (tix >> 6) % WAVES;
     const int tid = tix % TEAM;
-    const int64_t g = bid * (blockDim.x / TEAM) + tix / TEAM;   // bid: blockIdx.x, or the persistent kernel's walk (blockDim.x: 256)
-    if (g >= a.n_groups) return;   // wave-uniform for TEAM=64; never taken for TEAM=256 (grid == n_groups)
+    const int64_t gi = bid * (blockDim.x / TEAM) + tix / TEAM;  // bid: blockIdx.x, or the persistent kernel's walk (blockDim.x: 256)
+    if (gi >= a.n_groups) return;  // wave-uniform for TEAM=64; never taken for TEAM=256 (grid == n_groups)
+    const int64_t g = a.glist ? (int64_t)a.glist[gi] : gi;      // (size classes: the launch walks its own list of groups)
 
     const int64_t s = a.offs[g], e = a.offs[g + 1];
     const int64_t base = s - (s % VEC);                      // chunk grid is aligned to 16 bytes in every column
@@ -916,7 +917,7 @@ __global__ void __launch_bounds__(256) k1t_kernel(const K1Args a) {
     const int lane = threadIdx.x & 63, sub = lane & (K1T_SUB - 1);
     const int64_t gi = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / K1T_SUB) + (lane / K1T_SUB);
     const bool live = gi < a.n_groups;
-    const int64_t g = live ? gi : 0;
+    const int64_t g = live ? (a.glist ? (int64_t)a.glist[gi] : gi) : 0;   // (size classes: the launch walks its own list of groups)
     const int64_t s = live ? a.offs[g] : 0, e = live ? a.offs[g + 1] : 0;
     const int64_t base = s & ~(int64_t)(VEC - 1);            // chunk grid aligned to 16 bytes in every column (offsets are >= 0)
     const int nch = (int)((e - base + VEC - 1) / VEC);       // <= K1T_SUB * K1T_RC: the host checked the largest group
@@ -1372,7 +1373,8 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
         // ragged frames whose groups all stay resident: the branch-free EDGE form of the FAST kernel instead of the general code
         // (POLS_K1_NOEDGE=1 goes back)
         constexpr int VEC = Vec16<T>::N;
-        const bool resident = ctx->offs_max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
+        const int64_t largest = a.class_max_rows > 0 ? a.class_max_rows : ctx->offs_max_rows;   // (of this launch's size class)
+        const bool resident = largest + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1) <= (int64_t)RC * TEAM * VEC;
         if (resident && a.n_rows >= VEC && !ctx->opt.k1_noedge && !ctx->opt.timeline) {
             kern = k1_kernel<T, KT, HAS_W, TEAM, RC, true, NPASS, NULLS, false, true>;
             std::snprintf(name, sizeof(name), "k1_gram_chol_%s_k%d%s_team%d_rc%d_edge%s%s", sizeof(T) == 4 ? "f32" : "f64", KT, HAS_W ? "_w" : "", TEAM, RC,

@@ -617,3 +617,67 @@ def test_decade_sized_groups_stay_register_resident(eng, dtype, k, weights, icpt
     _check(out, ref, dtype)
     st = out["status"].cpu().numpy()
     assert (st[sizes > 0] == 0).all() and (st[sizes == 0] == 2).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dist,k,weights,icpt,policy", [
+    ("lognormal", 8, False, False, None), ("lognormal", 5, True, True, None), ("bimodal", 8, False, True, None),
+    ("bimodal", 3, False, False, "drop"), ("lognormal", 12, False, False, None), ("bimodal", 20, False, False, None),
+    ("with_empty_and_tiny", 6, False, False, None),
+])
+def test_size_classes_on_widely_spread_group_sizes(eng, dtype, dist, k, weights, icpt, policy):
+    """Round 5: a frame whose group sizes spread widely (most groups a few hundred rows, a tail of thousands; or many short groups next to a
+    few long ones) is served by TWO launches of the K1 family, each sized for its own size class -- the workgroups of the other class exit
+    after reading their offsets (`pick_size_classes`, api.hip).  Every group against the oracle, and against the one-launch form (NO_CLASSES)."""
+    from oracle import orc
+
+    if dtype == np.float64 and k > 16:
+        pytest.skip("f64 beyond 16 columns x 1 000 rows is K2w's, one launch")
+    rng = np.random.default_rng(len(dist) * 100 + k)
+    G = 12_000                                                        # (an extra launch has to pay for itself: small frames keep one)
+    if dist == "lognormal":
+        top = 1000 if k > 10 else (1900 if dtype == np.float64 else 3900)        # (what the register-resident K1 forms hold at this width)
+        sizes = np.clip(rng.lognormal(np.log(200 if k <= 10 else 60), 0.8, size=G).astype(np.int64), 5, top)
+        sizes[17] = top
+    elif dist == "bimodal":
+        sizes = np.where(rng.random(G) < 0.9, rng.integers(30, 60, size=G), rng.integers(900, 1001, size=G))
+    else:
+        sizes = np.where(rng.random(G) < 0.9, rng.integers(0, 40, size=G), rng.integers(700, 1001, size=G))
+        sizes[3] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, dtype, weights=weights)
+    kw = dict(add_intercept=icpt)
+    if policy:
+        y = y.copy(); y[rng.random(len(y)) < 0.02] = np.nan
+        kw["null_policy"] = policy
+    args = (_cuda(y), [_cuda(c) for c in cols], offs)
+    wd = None if w is None else _cuda(w)
+    out = eng.least_squares(*args, weights=wd, want=("coef", "pred", "resid", "status"), **kw)
+    name = eng.last_kernel
+    assert " | " in name and name.count("k1") >= 2, name             # two launches: the long groups' kernel | the short groups' kernel
+    eng.set_option("NO_CLASSES", "1")
+    try:
+        one = eng.least_squares(*args, weights=wd, want=("coef", "pred", "resid", "status"), **kw)
+        assert " | " not in eng.last_kernel
+    finally:
+        eng.set_option("NO_CLASSES", None)
+    tol = TOL[dtype]
+    kt = k + int(icpt)
+    full = sizes > 3 * kt                                             # (shorter groups: near-singular or minimum-norm fits, compared through the oracle below)
+    fr = np.repeat(full, sizes)
+    for key in ("coef", "pred", "resid"):
+        a_, b_ = out[key].double().cpu().numpy(), one[key].double().cpu().numpy()
+        if key == "coef":
+            a_, b_ = a_.reshape(-1, kt)[full], b_.reshape(-1, kt)[full]
+        else:
+            a_, b_ = a_[fr], b_[fr]
+        assert np.allclose(a_, b_, rtol=10 * tol, atol=10 * tol, equal_nan=True), key
+    assert (out["status"].cpu().numpy() == one["status"].cpu().numpy()).all()
+    if not policy:
+        ref = orc.batched_least_squares(y, cols, offs, weights=w, **kw)
+        got = out["coef"].double().cpu().numpy().reshape(-1, kt)
+        assert np.allclose(got[full], np.asarray(ref["coef"]).reshape(-1, kt)[full], rtol=tol, atol=tol), float(np.abs(got[full] - np.asarray(ref["coef"]).reshape(-1, kt)[full]).max())
+        assert np.allclose(out["pred"].double().cpu().numpy()[fr], np.asarray(ref["pred"])[fr], rtol=tol, atol=tol)
+        short = (sizes > 0) & (sizes < kt)
+        if short.any():                                                # the minimum-norm branch (K6s) still sees the short groups of both classes
+            assert np.allclose(got[short], np.asarray(ref["coef"]).reshape(-1, kt)[short], rtol=10 * tol, atol=10 * tol)
