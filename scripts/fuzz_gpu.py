@@ -210,6 +210,50 @@ for it in range(int(os.environ.get("FUZZ_SHORT", "30"))):
     except Exception as exc:
         bad += 1
         print("SHORT ERROR", it, dtype.__name__, k, G, method, repr(exc)[:200])
+# ---- size classes (round 5): frames whose group sizes spread widely, the per-class launches against the one-launch form of the same call
+seen_c = {}
+for it in range(int(os.environ.get("FUZZ_SPREAD", "24"))):
+    dtype = np.float64 if rng.random() < 0.5 else np.float32
+    k = int(rng.integers(1, 16)); G = int(rng.integers(2048, 30000)); icpt = bool(rng.random() < 0.3); wts = bool(rng.random() < 0.3)
+    cap = int(rng.choice([300, 1000, 1900 if dtype == np.float64 else 3900])) if k <= 10 else int(rng.choice([200, 500]))
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        sizes = np.clip(rng.lognormal(np.log(rng.uniform(20, 300)), rng.uniform(0.5, 1.2), size=G).astype(np.int64), 0, cap)
+    elif kind == 1:
+        sizes = np.where(rng.random(G) < rng.uniform(0.5, 0.98), rng.integers(1, 60, size=G), rng.integers(cap // 2, cap + 1, size=G))
+    else:
+        sizes = np.where(rng.random(G) < 0.5, rng.integers(0, 20, size=G), np.where(rng.random(G) < 0.8, rng.integers(60, 200, size=G), cap))
+    sizes[int(rng.integers(0, G))] = cap
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(c.astype(np.float64) for c in cols) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    w = rng.uniform(0.2, 2.0, N).astype(dtype) if wts else None
+    policy = str(rng.choice(["ignore", "ignore", "drop", "zero"]))
+    if policy != "ignore":
+        y[rng.random(N) < 0.01] = np.nan
+    kt = k + int(icpt)
+    try:
+        kw = dict(weights=w, add_intercept=icpt, want=("coef", "pred", "status"), null_policy=policy)
+        out = eng.least_squares(y, cols, offs, **kw)
+        name = eng.last_kernel
+        seen_c[name.count(" | ") + 1] = seen_c.get(name.count(" | ") + 1, 0) + 1
+        eng.set_option("NO_CLASSES", "1")
+        one = eng.least_squares(y, cols, offs, **kw)
+        eng.set_option("NO_CLASSES", None)
+        full = sizes > 3 * kt
+        rows = np.repeat(full, sizes)
+        tol = 2e-5 if dtype == np.float64 else 5e-3
+        ok = np.array_equal(out["status"], one["status"]) and np.allclose(out["coef"][full], one["coef"][full], rtol=tol, atol=tol, equal_nan=True) and \
+            np.allclose(out["pred"][rows], one["pred"][rows], rtol=tol, atol=tol, equal_nan=True)
+        if not ok:
+            bad += 1
+            print("SPREAD MISMATCH", it, dtype.__name__, "k", k, "G", G, "cap", cap, "kind", kind, "icpt", icpt, "w", wts, policy, name)
+    except Exception as exc:
+        eng.set_option("NO_CLASSES", None)
+        bad += 1
+        print("SPREAD ERROR", it, dtype.__name__, k, G, cap, kind, repr(exc)[:200])
+print("size-class cases by number of launches:", dict(sorted(seen_c.items())))
 # ---- null policies (static models; expected values composed like the reference composes them: tests/test_nulls_gpu.py::_expected)
 from test_nulls_gpu import _expected
 for it in range(80):

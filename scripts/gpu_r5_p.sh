@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 900 python -m pytest tests/test_k1_gpu.py -m gpu -q -k "size_classes" 2>&1 | grep -E "Error|error|assert|FAILED|passed|failed|kernel" | head -30
+FUZZ_SHORT=0 FUZZ_DYN2=0 FUZZ_DYN3=0 FUZZ_SPREAD=40 timeout 1200 python scripts/fuzz_gpu.py 2>&1 | grep -v amdgpu.ids | tail -12
