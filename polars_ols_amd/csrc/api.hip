@@ -829,22 +829,26 @@ struct SegTables {
     int64_t n_seg = 0, max_len = 0, max_seg = 0;      // rows of the longest segment; most segments of one group
     char *extra = nullptr;
 };
-static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows, size_t extra_per_seg, SegTables *t) {
+// ids (size classes): the tables cover only the listed groups (ascending), `offs` holds (start, end) PAIRS per segment, `map` gives the segment's
+// position in the list and `first` is indexed by list position; class_key tells such tables apart in the cache (0 = the whole frame).
+static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows, size_t extra_per_seg, SegTables *t,
+                           const std::vector<int32_t> *ids = nullptr, int64_t class_key = 0) {
     *t = SegTables();
     const int64_t seg_target = ctx->opt.seg_target > 0 ? std::max<int64_t>(256, ctx->opt.seg_target)
                                                       : std::max<int64_t>(4096, ((b->n_rows / std::max<int64_t>(1, 8 * (int64_t)ctx->num_cus) + 1023) / 1024) * 1024);
-    if (!(max_rows > 2 * seg_target) || ctx->opt.no_split) return POLS_OK;
+    if (!ids && (!(max_rows > 2 * seg_target) || ctx->opt.no_split)) return POLS_OK;
+    const int64_t n_items = ids ? (int64_t)ids->size() : b->n_groups;
     auto &sc = ctx->seg_cache;
     int rc;
     // (the key is the frame; the per-segment extra area only has to be large enough -- its users differ in what they keep there: the Gram
     // partials of ls_core, the moments of the statistics entry, nothing for pols_predict -- and it is kept at the largest size asked for,
     // so that alternating users of one frame stop rebuilding and re-uploading the tables)
     const bool same_frame = sc.ptr && sc.ptr == ctx->scratch[23].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups && sc.n_rows == b->n_rows &&
-                            sc.seg_target == seg_target;
+                            sc.seg_target == seg_target && sc.class_key == class_key && sc.n_items == n_items;
     const bool hit = same_frame && sc.nz2 >= extra_per_seg;
     auto lay = [&](char *sb, int64_t n_seg) {
-        const size_t b_so = round256(sizeof(int64_t) * (size_t)(n_seg + 1)), b_sm = round256(sizeof(int32_t) * (size_t)n_seg),
-                     b_sf = round256(sizeof(int32_t) * (size_t)(b->n_groups + 1));
+        const size_t b_so = round256(sizeof(int64_t) * (size_t)(ids ? 2 * n_seg : n_seg + 1)), b_sm = round256(sizeof(int32_t) * (size_t)n_seg),
+                     b_sf = round256(sizeof(int32_t) * (size_t)(n_items + 1));
         t->offs = reinterpret_cast<const int64_t *>(sb);
         t->map = reinterpret_cast<const int32_t *>(sb + b_so);
         t->first = reinterpret_cast<const int32_t *>(sb + b_so + b_sm);
@@ -856,24 +860,26 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
     if (same_frame) extra_per_seg = std::max<size_t>(extra_per_seg, sc.nz2);
     sc.ptr = nullptr;
     std::vector<int64_t> so;
-    std::vector<int32_t> sm, sf((size_t)b->n_groups + 1);
-    so.push_back(0);
+    std::vector<int32_t> sm, sf((size_t)n_items + 1);
+    if (!ids) so.push_back(0);
     int64_t max_len = 0, max_seg = 0;
-    for (int64_t g = 0; g < b->n_groups; ++g) {
-        if (g > 0) max_seg = std::max<int64_t>(max_seg, (int64_t)sm.size() - sf[(size_t)g - 1]);
-        sf[(size_t)g] = (int32_t)sm.size();
+    for (int64_t i = 0; i < n_items; ++i) {
+        const int64_t g = ids ? (int64_t)(*ids)[(size_t)i] : i;
+        if (i > 0) max_seg = std::max<int64_t>(max_seg, (int64_t)sm.size() - sf[(size_t)i - 1]);
+        sf[(size_t)i] = (int32_t)sm.size();
         const int64_t s0 = b->group_offsets[g], e0 = b->group_offsets[g + 1];
         const int64_t pieces = std::max<int64_t>(1, (e0 - s0 + seg_target - 1) / seg_target);
         const int64_t len = std::max<int64_t>(1, ((e0 - s0 + pieces - 1) / pieces + 255) / 256 * 256);   // (256-row multiples: whole staging chunks)
         max_len = std::max(max_len, std::min(len, e0 - s0));
         for (int64_t r = s0; r < e0 || r == s0; r += len) {
+            if (ids) so.push_back(r);
             so.push_back(std::min(e0, r + len));
-            sm.push_back((int32_t)g);
+            sm.push_back((int32_t)i);
             if (e0 == s0) break;
         }
     }
-    sf[(size_t)b->n_groups] = (int32_t)sm.size();
-    if (b->n_groups > 0) max_seg = std::max<int64_t>(max_seg, (int64_t)sm.size() - sf[(size_t)b->n_groups - 1]);
+    sf[(size_t)n_items] = (int32_t)sm.size();
+    if (n_items > 0) max_seg = std::max<int64_t>(max_seg, (int64_t)sm.size() - sf[(size_t)n_items - 1]);
     const int64_t n_seg = (int64_t)sm.size();
     const size_t tabs = round256(sizeof(int64_t) * so.size()) + round256(sizeof(int32_t) * sm.size()) + round256(sizeof(int32_t) * sf.size());
     void *ds = nullptr;
@@ -884,6 +890,7 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
     if ((rc = upload_small(ctx, const_cast<int32_t *>(t->map), sm.data(), sizeof(int32_t) * sm.size()))) return rc;
     if ((rc = upload_small(ctx, const_cast<int32_t *>(t->first), sf.data(), sizeof(int32_t) * sf.size()))) return rc;
     sc.ptr = ds; sc.offs_id = ctx->offs_id; sc.n_groups = b->n_groups; sc.n_rows = b->n_rows; sc.seg_target = seg_target;
+    sc.class_key = class_key; sc.n_items = n_items;
     sc.n_seg = n_seg; sc.nz2 = extra_per_seg; sc.nulls = false; sc.max_len = max_len; sc.max_seg = max_seg;
     t->max_len = max_len; t->max_seg = max_seg;
     return POLS_OK;
@@ -1187,35 +1194,40 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         stream = stream || ctx->opt.static_engine == 1;
         stream = stream || (m == POLS_SOLVE_LU && kt > K1M_MAX_KT);   // explicit LU beyond K2's 16 columns: the streamed solver has one
     }
-    if (stream) {
+    // The streamed path over the whole frame (ids == nullptr), or over a LIST of its groups (size classes: the groups beyond the K1 family's
+    // registers; segment tables with (start, end) pairs, Gram matrices / coef64 indexed by list position, gram_solve maps back to group ids).
+    double *stream_gram = nullptr;
+    auto run_stream = [&](const std::vector<int32_t> *ids, const int32_t *d_ids, int64_t class_key, int64_t cls_max_rows) -> int {
+        const int64_t ng = ids ? (int64_t)ids->size() : b->n_groups;
+        const int64_t mr = ids ? cls_max_rows : max_rows;
         // one streaming Gram pass, the small solve (Gram-form CD or Cholesky), then (only if asked for) a prediction pass
         void *scr = nullptr;
         const size_t nz = (size_t)kt + 1;
-        const size_t gram_bytes = round256(sizeof(double) * nz * nz * (size_t)b->n_groups);
-        const size_t c64_bytes = round256(sizeof(double) * (size_t)kt * (size_t)b->n_groups);
+        const size_t gram_bytes = round256(sizeof(double) * nz * nz * (size_t)ng);
+        const size_t c64_bytes = round256(sizeof(double) * (size_t)kt * (size_t)ng);
         const size_t nv_bytes = nulls ? round256(sizeof(double) * (size_t)b->n_groups) : 0;
         // Few long groups (ONE regression over a whole frame is the reference's first README example): a group is one workgroup in
         // the Gram and the prediction pass, so a 10M-row group used to be one CU's work -- 94 ms.  Long groups are cut into segments
         // (segment offsets, one workgroup each; the segments' Gram matrices are summed per group in segment order), sized so that the
         // launch fills the chip about eight deep.
         SegTables sg;
-        if ((rc = ensure_segments(ctx, b, max_rows, sizeof(double) * (nz * nz + 1), &sg))) return rc;
+        if ((rc = ensure_segments(ctx, b, mr, sizeof(double) * (nz * nz + 1), &sg, ids, class_key))) return rc;
         const bool split = sg.n_seg > 0;
         // few groups of hundreds of segments: the segment sums go through 16 slices per group (gram_reduce_launch)
-        const int n_slices = (split && sg.max_seg >= 256 && b->n_groups <= 256) ? 16 : 1;
-        const size_t slice_bytes = n_slices > 1 ? round256(sizeof(double) * nz * nz * (size_t)n_slices * (size_t)b->n_groups) : 0;
+        const int n_slices = (split && sg.max_seg >= 256 && ng <= 256) ? 16 : 1;
+        const size_t slice_bytes = n_slices > 1 ? round256(sizeof(double) * nz * nz * (size_t)n_slices * (size_t)ng) : 0;
         if ((rc = ensure_scratch(ctx, 5, gram_bytes + c64_bytes + nv_bytes + slice_bytes, &scr))) return rc;
         double *nvalid = nulls ? reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes + c64_bytes) : nullptr;
         const int64_t *seg_offs = split ? sg.offs : d_offs;
         const int32_t *seg_map = sg.map, *seg_first = sg.first;
-        const int64_t n_seg = split ? sg.n_seg : b->n_groups;
+        const int64_t n_seg = split ? sg.n_seg : ng;
         double *gram_part = reinterpret_cast<double *>(sg.extra);
         double *nv_part = (split && nulls) ? gram_part + nz * nz * (size_t)n_seg : nullptr;
         GramArgs ga;
         std::memset(&ga, 0, sizeof(ga));
         ga.y = st.y; ga.w = st.w;
         for (int j = 0; j < b->n_features; ++j) ga.x[j] = st.x[j];
-        ga.offs = seg_offs; ga.n_groups = n_seg; ga.n_rows = b->n_rows;
+        ga.offs = seg_offs; ga.n_groups = n_seg; ga.n_rows = b->n_rows; ga.offs_pairs = ids ? 1 : 0;
         ga.gram = split ? gram_part : static_cast<double *>(scr);
         ga.k_user = b->n_features; ga.kt = kt;
         ga.valid = st.valid; ga.null_policy = pol; ga.nvalid = split ? nv_part : nvalid;
@@ -1224,7 +1236,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             GramReduceArgs ra;
             std::memset(&ra, 0, sizeof(ra));
             ra.part = gram_part; ra.nv_part = nv_part; ra.first = seg_first;
-            ra.gram = static_cast<double *>(scr); ra.nvalid = nvalid; ra.n_groups = b->n_groups; ra.nz2 = (int32_t)(nz * nz);
+            ra.gram = static_cast<double *>(scr); ra.nvalid = nvalid; ra.n_groups = ng; ra.nz2 = (int32_t)(nz * nz);
             ra.max_segments = (int32_t)std::min<int64_t>(1 << 30, sg.max_seg);
             if (n_slices > 1) { ra.slices = reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes + c64_bytes + nv_bytes); ra.n_slices = n_slices; }
             if ((rc = gram_reduce_launch(ctx, ra))) return rc;
@@ -1233,7 +1245,7 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         }
         CdArgs ca;
         std::memset(&ca, 0, sizeof(ca));
-        ca.gram = ga.gram; ca.offs = d_offs; ca.n_groups = b->n_groups;
+        ca.gram = ga.gram; ca.offs = d_offs; ca.n_groups = ng; ca.glist = d_ids;
         ca.coef = st.coef; ca.coef64 = reinterpret_cast<double *>(static_cast<char *>(scr) + gram_bytes);
         ca.status = st.status;
         ca.alpha = alpha; ca.l1_ratio = enet_l1; ca.tol = p->tol; ca.max_iter = p->max_iter;
@@ -1254,16 +1266,16 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
             std::memset(&pa, 0, sizeof(pa));
             pa.y = st.y; pa.w = st.w;
             for (int j = 0; j < b->n_features; ++j) pa.x[j] = st.x[j];
-            pa.offs = seg_offs; pa.n_groups = n_seg; pa.n_rows = b->n_rows; pa.gmap = seg_map;
-            pa.max_item_rows = split ? sg.max_len : max_rows;
+            pa.offs = seg_offs; pa.n_groups = n_seg; pa.n_rows = b->n_rows; pa.gmap = seg_map; pa.offs_pairs = ids ? 1 : 0;
+            pa.max_item_rows = split ? sg.max_len : mr;
             pa.coef64 = ca.coef64; pa.pred = st.pred; pa.resid = st.resid;
             pa.k_user = b->n_features; pa.kt = kt;
             pa.valid = st.valid; pa.null_policy = pol;
             if ((rc = predict_launch(ctx, b->dtype, pa))) return rc;
         }
-        if ((rc = svd_fixup())) return rc;
-        return finish(ga.gram);
-    }
+        stream_gram = ga.gram;
+        return POLS_OK;
+    };
 
     K1Args a;
     std::memset(&a, 0, sizeof(a));
@@ -1278,53 +1290,110 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
     a.fb_flag = ctx->fb_flag; a.epoch = ctx->epoch;
     a.k_user = b->n_features;
     a.null_policy = pol;
-    if ((rc = prepare_fix())) return rc;
-    // SIZE CLASSES: the K1 family sizes its workgroup for the LARGEST group of the frame, so on a panel whose group sizes spread widely
+    // ---- SIZE CLASSES.  The K1 family sizes its workgroup for the LARGEST group of the frame, so on a panel whose group sizes spread widely
     // (most assets a few hundred rows, a few of them thousands) every small group paid for a team it did not fill -- log-normal sizes around
-    // 300 rows with a 4 000-row tail 1.5 TB/s, 90 % 50-row + 10 % 1 000-row groups 1.9 (scripts/bench_spread.py).  Two or three launches then,
-    // one per size class: each walks the list of its own groups with the kernel the dispatcher picks for the class' largest group.  The cuts come
-    // from the size histogram of the offsets scan and a two-parameter cost model (pick_size_classes).
-    int64_t class_t[2];
-    int n_cut = pick_size_classes(ctx, b->dtype == POLS_F32, b->n_groups, max_rows, class_t);
-    if (n_cut > 0 && !(nulls ? k1_nulls_takes(ctx, b->dtype == POLS_F32, kt, max_rows) : k1_valu_takes(ctx, b->dtype == POLS_F32, kt, max_rows, b->weights != nullptr)))
-        n_cut = 0;                                                   // (the largest groups would leave the K1 family: one launch as before)
-    if (ctx->opt.timeline || ctx->opt.k1_persist > 0 || b->n_groups > 0x7fffffffLL) n_cut = 0;
-    if (n_cut > 0) {
-        // the classes' group lists (ascending group ids, one list per class, in one buffer), rebuilt when the offsets or the cuts change
+    // 300 rows with a 4 000-row tail 1.5 TB/s, 90 % 50-row + 10 % 1 000-row groups 1.9 (scripts/bench_spread.py).  Such frames get one launch per
+    // size class: each walks the list of its own groups with the kernel the dispatcher picks for the class' largest group.  The cuts come
+    // from the size histogram of the offsets scan and a two-parameter cost model (pick_size_classes).  When the largest groups do not fit the
+    // K1 family at all, they form a class of their own on the streamed path (run_stream over their list) and the rest is classed as above.
+    const bool f32b = b->dtype == POLS_F32;
+    auto k1_takes = [&](int64_t rows) { return nulls ? k1_nulls_takes(ctx, f32b, kt, rows) : k1_valu_takes(ctx, f32b, kt, rows, b->weights != nullptr); };
+    const bool classes_allowed = !enet && !ctx->opt.no_classes && !ctx->opt.timeline && ctx->opt.k1_persist <= 0 && ctx->opt.static_engine == 0 &&
+                                 ctx->opt.k1_engine == 0 && b->n_groups >= 2048 && b->n_groups <= 0x7fffffffLL && m != POLS_SOLVE_LU;
+    // the lists of the classes cut[0] < cut[1] < ... (rows): class c holds the groups of cut[c - 1] < rows <= cut[c], the last one the rest
+    auto build_lists = [&](const int64_t *cut, int n_cut) -> int {
         auto &cc = ctx->class_cache;
-        const int64_t t0 = class_t[0], t1 = n_cut > 1 ? class_t[1] : 0;
-        if (!(cc.ptr && cc.ptr == ctx->scratch[24].ptr && cc.offs_id == ctx->offs_id && cc.n_cut == n_cut && cc.t0 == t0 && cc.t1 == t1)) {
-            cc.ptr = nullptr;
-            std::vector<int32_t> lists[3];
-            for (int64_t g = 0; g < b->n_groups; ++g) {
-                const int64_t n = b->group_offsets[g + 1] - b->group_offsets[g];
-                lists[n <= t0 ? 0 : ((n_cut > 1 && n <= t1) ? 1 : n_cut)].push_back((int32_t)g);
-            }
-            void *d = nullptr;
-            if ((rc = ensure_scratch(ctx, 24, sizeof(int32_t) * (size_t)b->n_groups, &d))) return rc;
-            size_t at = 0;
-            for (int c = 0; c <= n_cut; ++c) {
-                if (!lists[c].empty() && (rc = upload_small(ctx, static_cast<int32_t *>(d) + at, lists[c].data(), sizeof(int32_t) * lists[c].size()))) return rc;
-                cc.n[c] = (int64_t)lists[c].size();
-                at += lists[c].size();
-            }
-            cc.ptr = d; cc.offs_id = ctx->offs_id; cc.n_cut = n_cut; cc.t0 = t0; cc.t1 = t1;
+        bool same = cc.ptr && cc.ptr == ctx->scratch[24].ptr && cc.offs_id == ctx->offs_id && cc.n_cut == n_cut;
+        for (int c = 0; c < n_cut && same; ++c) same = cc.cut[c] == cut[c];
+        if (same) return POLS_OK;
+        cc.ptr = nullptr;
+        std::vector<int32_t> lists[4];
+        for (int64_t g = 0; g < b->n_groups; ++g) {
+            const int64_t n = b->group_offsets[g + 1] - b->group_offsets[g];
+            int c = 0;
+            while (c < n_cut && n > cut[c]) ++c;
+            lists[c].push_back((int32_t)g);
         }
-        // (Tried: the long groups' launch on a second stream beside the short groups' -- fork / join through two events.  Slower: 0.136 against
-        // 0.124 ms on the log-normal frame, 0.102 against 0.089 on the 90 / 10 one; the two grids do not overlap enough to pay for the events.
-        // Tried first: every launch over ALL groups, the workgroups of the other classes exiting after reading their offsets -- 18 000 exits per
-        // launch on the log-normal frame cost more than the lists' indirection.)
-        std::string names;
-        int64_t first[3] = {0, cc.n[0], cc.n[0] + cc.n[1]};
-        for (int c = n_cut; c >= 0; --c) {                           // the long groups first: their workgroups take longest
+        void *d = nullptr;
+        int r2 = ensure_scratch(ctx, 24, sizeof(int32_t) * (size_t)b->n_groups, &d);
+        if (r2) return r2;
+        size_t at = 0;
+        for (int c = 0; c <= n_cut; ++c) {
+            if (!lists[c].empty() && (r2 = upload_small(ctx, static_cast<int32_t *>(d) + at, lists[c].data(), sizeof(int32_t) * lists[c].size()))) return r2;
+            cc.n[c] = (int64_t)lists[c].size();
+            at += lists[c].size();
+        }
+        for (int c = n_cut + 1; c < 4; ++c) cc.n[c] = 0;
+        cc.host_last.swap(lists[n_cut]);
+        cc.ptr = d; cc.offs_id = ctx->offs_id; cc.n_cut = n_cut;
+        for (int c = 0; c < n_cut; ++c) cc.cut[c] = cut[c];
+        return POLS_OK;
+    };
+    // K1 launches for the classes [c_lo, c_hi] of the cached lists, longest groups first (their workgroups take longest)
+    // (Tried: every launch over ALL groups, the workgroups of the other classes exiting after reading their offsets -- 18 000 exits per launch on
+    // the log-normal frame cost more than the lists' indirection; and the long groups' launch on a second stream beside the short groups' --
+    // slower by the two events, 0.136 against 0.124 ms.)
+    auto launch_k1_classes = [&](const int64_t *cut, int n_cut, int c_lo, int c_hi, std::string &names) -> int {
+        const auto &cc = ctx->class_cache;
+        int64_t first[4] = {0, cc.n[0], cc.n[0] + cc.n[1], cc.n[0] + cc.n[1] + cc.n[2]};
+        for (int c = c_hi; c >= c_lo; --c) {
             if (cc.n[c] == 0) continue;
             K1Args ac = a;
             ac.glist = static_cast<const int32_t *>(cc.ptr) + first[c];
             ac.n_groups = cc.n[c];
-            ac.class_max_rows = c < n_cut ? class_t[c] : max_rows;
-            if ((rc = k1_launch(ctx, b->dtype, kt, ac, ac.class_max_rows, true))) return rc;
+            ac.class_max_rows = c < n_cut ? cut[c] : max_rows;
+            int r2 = k1_launch(ctx, b->dtype, kt, ac, ac.class_max_rows, true);
+            if (r2) return r2;
             names += (names.empty() ? "" : " | ") + ctx->last_kernel;
         }
+        return POLS_OK;
+    };
+
+    if (stream) {
+        // the largest groups leave the K1 family: do the others fit it, and are they worth their own launches?
+        int64_t k1_top = 0;
+        if (classes_allowed && !k1_takes(max_rows)) {
+            const int slack = ctx->offs_aligned[f32b ? 1 : 0] ? 0 : (f32b ? 3 : 1);
+            for (int bb = 13; bb >= (f32b ? 7 : 6) && k1_top == 0; --bb)
+                if (((int64_t)1 << bb) - slack < max_rows && k1_takes(((int64_t)1 << bb) - slack)) k1_top = ((int64_t)1 << bb) - slack;
+            int64_t rows_low = 0;
+            for (int q = 0; q < 48 && k1_top > 0; ++q)
+                if (((int64_t)1 << q) <= k1_top + 3) rows_low += ctx->offs_hist_rows[q];
+            if ((double)rows_low < 0.3 * (double)b->n_rows) k1_top = 0;      // (mostly long groups: the streamed path for all of them, as before)
+        }
+        if (k1_top > 0) {
+            int64_t cut[3];
+            int64_t low_t[2];
+            const int n_low = pick_size_classes(ctx, f32b, b->n_groups, k1_top, low_t);
+            int n_cut = 0;
+            for (int c = 0; c < n_low; ++c) cut[n_cut++] = low_t[c];
+            cut[n_cut++] = k1_top;
+            if ((rc = build_lists(cut, n_cut))) return rc;
+            if ((rc = prepare_fix())) return rc;
+            std::string names;
+            const auto &cc = ctx->class_cache;
+            if (cc.n[n_cut] > 0) {
+                const int32_t *d_top = static_cast<const int32_t *>(cc.ptr) + (b->n_groups - cc.n[n_cut]);
+                if ((rc = run_stream(&cc.host_last, d_top, k1_top, max_rows))) return rc;
+                names = ctx->last_kernel;
+            }
+            if ((rc = launch_k1_classes(cut, n_cut, 0, n_cut - 1, names))) return rc;
+            ctx->last_kernel = names;
+            if ((rc = k6_launch(ctx, b->dtype, ka, fix_workers))) return rc;
+            return finish(nullptr);
+        }
+        if ((rc = run_stream(nullptr, nullptr, 0, 0))) return rc;
+        if ((rc = svd_fixup())) return rc;
+        return finish(stream_gram);
+    }
+
+    if ((rc = prepare_fix())) return rc;
+    int64_t class_t[2];
+    const int n_cut = (classes_allowed && k1_takes(max_rows)) ? pick_size_classes(ctx, f32b, b->n_groups, max_rows, class_t) : 0;
+    if (n_cut > 0) {
+        if ((rc = build_lists(class_t, n_cut))) return rc;
+        std::string names;
+        if ((rc = launch_k1_classes(class_t, n_cut, 0, n_cut, names))) return rc;
         ctx->last_kernel = names;
     } else {
         if ((rc = k1_launch(ctx, b->dtype, kt, a, max_rows, true))) return rc;

@@ -132,8 +132,9 @@ struct pols_ctx {
     // this frame does not pack (a sequence longer than a tile, or tiles too empty)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, tile_rows = 0, n_tiles = 0; } k3c;
     // segment tables of the streamed static path (scratch slot 23: long groups cut into segments): rebuilt when other offsets arrive
-    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t t0 = 0, t1 = 0, n[3] = {0, 0, 0}; int n_cut = 0; } class_cache;   // group lists of the size classes (slot 24)
-    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0; size_t nz2 = 0; bool nulls = false; } seg_cache;
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t cut[3] = {0, 0, 0}, n[4] = {0, 0, 0, 0}; int n_cut = 0;
+             std::vector<int32_t> host_last; } class_cache;   // group lists of the size classes (slot 24; host_last: the last class' ids, for its segment tables)
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0, class_key = 0, n_items = 0; size_t nz2 = 0; bool nulls = false; } seg_cache;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };

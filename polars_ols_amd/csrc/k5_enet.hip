@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t g = blockIdx.x;
-    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t s = a.offs_pairs ? a.offs[2 * g] : a.offs[g], e = a.offs_pairs ? a.offs[2 * g + 1] : a.offs[g + 1];
     const int64_t base = s - (s % VEC);
     const int head = (int)(s - base);
     const int64_t span = e - base;                  // rows [head, span) relative to base belong to the group
@@ -487,7 +487,8 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
     const double *G = a.gram + (size_t)grp * NZ * NZ;
     double *L = Ls[wv];
     double *rinv = rs[wv];
-    const int64_t n = a.nvalid ? (int64_t)a.nvalid[grp] : a.offs[grp + 1] - a.offs[grp];
+    const int64_t gid = a.glist ? (int64_t)a.glist[grp] : grp;   // (size classes: item grp of the launch is group gid of the frame)
+    const int64_t n = a.nvalid ? (int64_t)a.nvalid[grp] : a.offs[gid + 1] - a.offs[gid];
     for (int q = lane; q < kt * kt; q += 64) {
         const int i = q / kt, j = q - i * kt;
         L[q] = G[i * NZ + j] + (i == j ? a.alpha : 0.0);
@@ -569,10 +570,10 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const CdArgs a) {
     if (n == 0) { bi = 0.0; st = POLS_GROUP_EMPTY; }
     else if (!ok) { st = POLS_GROUP_FALLBACK; if (lane == 0 && a.fb_flag) *a.fb_flag = a.epoch; }
     if (lane < kt) {
-        if (a.coef) static_cast<T *>(a.coef)[grp * kt + lane] = (T)bi;
+        if (a.coef) static_cast<T *>(a.coef)[gid * kt + lane] = (T)bi;
         if (a.coef64) a.coef64[grp * kt + lane] = bi;
     }
-    if (lane == 0 && a.status) a.status[grp] = st;
+    if (lane == 0 && a.status) a.status[gid] = st;
 }
 
 int gram_solve_launch(pols_ctx *ctx, int dtype, const CdArgs &a) {
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
     const int64_t g = blockIdx.x;
-    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t s = a.offs_pairs ? a.offs[2 * g] : a.offs[g], e = a.offs_pairs ? a.offs[2 * g + 1] : a.offs[g + 1];
     const int64_t base = s - (s % VEC);
     const int ku = a.k_user, kt = a.kt;
     const bool icpt = ku != kt;
@@ -702,7 +703,7 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
     const int64_t g = blockIdx.x;
-    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t s = a.offs_pairs ? a.offs[2 * g] : a.offs[g], e = a.offs_pairs ? a.offs[2 * g + 1] : a.offs[g + 1];
     const int64_t base = s - (s % VEC);
     const int ku = a.k_user, kt = a.kt;
     const double *cg = a.coef64 + (size_t)(a.gmap ? a.gmap[g] : g) * kt;

@@ -31,6 +31,7 @@ struct GramArgs {
     const uint8_t *valid;   // optional, drop family only
     int32_t null_policy;    // pols_null_policy
     double *nvalid;         // n_groups: rows that took part in the fit (the n of alpha * n, ls.rs:419), or nullptr
+    int32_t offs_pairs;     // 0: item g is rows [offs[g], offs[g + 1]); 1: [offs[2 g], offs[2 g + 1]) -- segment tables of a LIST of groups (size classes)
 };
 
 struct CdArgs {
@@ -49,6 +50,7 @@ struct CdArgs {
     const double *nvalid;   // per-group number of fit rows under a null policy, or nullptr = offs[g + 1] - offs[g]
     int32_t solver;         // gram_solve only: 0 Cholesky, 1 partial-pivot LU (solve_method = "lu", ls.rs:264-273)
     int32_t lu_fallback;    // gram_solve only: a failed Cholesky is retried with LU (solve_ridge, ls.rs:358-363)
+    const int32_t *glist;   // gram_solve only (size classes): item i is group glist[i] -- gram / coef64 / nvalid are indexed by item, offs / coef / status by group
 };
 
 struct PredictArgs {
@@ -69,6 +71,7 @@ struct PredictArgs {
     int32_t null_policy;
     const int32_t *gmap;    // SPLIT groups (or nullptr): `offs` cuts long groups into segments, segment g uses the coefficients of group gmap[g]
     int64_t max_item_rows;  // rows of the longest item of `offs` (or 0 = unknown): sizes the workgroups per item
+    int32_t offs_pairs;     // see GramArgs::offs_pairs
 };
 
 // Long groups cut into segments (one workgroup each in gram_stream / predict): partial Gram matrices (and fit-row counts) of the

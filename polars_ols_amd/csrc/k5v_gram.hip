@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
     constexpr int NZ = KT + 1, NACC = NZ * (NZ + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t g = blockIdx.x;
-    const int64_t s = a.offs[g], e = a.offs[g + 1];
+    const int64_t s = a.offs_pairs ? a.offs[2 * g] : a.offs[g], e = a.offs_pairs ? a.offs[2 * g + 1] : a.offs[g + 1];
     const int64_t base = s - (s % VEC);
     const int ku = a.k_user;                                 // KT or KT - 1: only the last slot can be the intercept column
 

@@ -681,3 +681,50 @@ def test_size_classes_on_widely_spread_group_sizes(eng, dtype, dist, k, weights,
         short = (sizes > 0) & (sizes < kt)
         if short.any():                                                # the minimum-norm branch (K6s) still sees the short groups of both classes
             assert np.allclose(got[short], np.asarray(ref["coef"]).reshape(-1, kt)[short], rtol=10 * tol, atol=10 * tol)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k,weights,icpt,policy", [(8, False, False, None), (5, True, True, None), (3, False, False, "drop"), (10, False, True, None)])
+def test_size_classes_with_a_streamed_top_class(eng, dtype, k, weights, icpt, policy):
+    """The largest groups do not fit the K1 family's registers (beyond 4 096 f32 / 2 048 f64 rows) but most groups are short: the long ones form a
+    class of their own on the streamed path (segment tables over THEIR list, gram_solve mapping list positions back to group ids), the others are
+    classed among the K1 kernels.  One frame-wide streamed call was 2.2 TB/s on such a frame.  Against the oracle and the one-launch form."""
+    from oracle import orc
+
+    rng = np.random.default_rng(1000 + k)
+    G = 9000
+    cap = 9000 if dtype == np.float32 else 5000
+    sizes = np.clip(rng.lognormal(np.log(250), 0.9, size=G).astype(np.int64), 0, cap)
+    sizes[rng.integers(0, G, size=25)] = rng.integers(cap // 2 + 200, cap, size=25)
+    sizes[11] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, dtype, weights=weights)
+    kw = dict(add_intercept=icpt)
+    if policy:
+        y = y.copy(); y[rng.random(len(y)) < 0.02] = np.nan
+        kw["null_policy"] = policy
+    args = (_cuda(y), [_cuda(c) for c in cols], offs)
+    wd = None if w is None else _cuda(w)
+    out = eng.least_squares(*args, weights=wd, want=("coef", "pred", "resid", "status"), **kw)
+    name = eng.last_kernel
+    assert name.startswith("k5_gram_stream") and " | k1" in name, name     # the streamed top class | the K1 launches
+    eng.set_option("NO_CLASSES", "1")
+    try:
+        one = eng.least_squares(*args, weights=wd, want=("coef", "pred", "resid", "status"), **kw)
+        assert " | " not in eng.last_kernel
+    finally:
+        eng.set_option("NO_CLASSES", None)
+    tol = TOL[dtype]
+    kt = k + int(icpt)
+    full = sizes > 3 * kt
+    fr = np.repeat(full, sizes)
+    assert (out["status"].cpu().numpy() == one["status"].cpu().numpy()).all()
+    for key in ("coef", "pred", "resid"):
+        a_, b_ = out[key].double().cpu().numpy(), one[key].double().cpu().numpy()
+        a_, b_ = (a_.reshape(-1, kt)[full], b_.reshape(-1, kt)[full]) if key == "coef" else (a_[fr], b_[fr])
+        assert np.allclose(a_, b_, rtol=10 * tol, atol=10 * tol, equal_nan=True), key
+    if not policy:
+        ref = orc.batched_least_squares(y, cols, offs, weights=w, **kw)
+        got = out["coef"].double().cpu().numpy().reshape(-1, kt)
+        assert np.allclose(got[full], np.asarray(ref["coef"]).reshape(-1, kt)[full], rtol=tol, atol=tol)
+        assert np.allclose(out["pred"].double().cpu().numpy()[fr], np.asarray(ref["pred"])[fr], rtol=tol, atol=tol)
