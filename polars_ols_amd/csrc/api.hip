@@ -1187,9 +1187,9 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // null policies: the register-resident K1 has a NULLS family; everything else goes through the streamed kernels
         stream = (nulls && !k1_resident) || (!k1_resident && (kt > K1M_MAX_KT || !fits_lds));
         // Round 5: with the VALU Gram pass (K5v) and the lean prediction kernel the two-pass path runs at 2.7-3.1 TB/s of algorithmic bytes
-        // on plain frames of up to ten columns, K1m's LDS-resident single pass at 1.5-2.2 (profiles/r05_sweep_stream_ab.txt): K1m keeps
-        // the weighted frames and POLS_K1_ENGINE=mfma
-        const bool k5v_ok = !nulls && !b->weights && kt <= K5V_MAX_KT && !ctx->opt.kg_single_buffer && ctx->opt.k1_engine != 2;
+        // on frames of up to ten columns without a null policy, K1m's LDS-resident single pass at 1.5-2.2 (profiles/r05_sweep_stream_ab.txt): K1m and K1's
+        // streamed-overflow form stay reachable through POLS_K1_ENGINE=mfma | valu
+        const bool k5v_ok = !nulls && kt <= K5V_MAX_KT && !ctx->opt.kg_single_buffer && ctx->opt.k1_engine == 0;
         stream = stream || (!k1_resident && k5v_ok);
         stream = stream || ctx->opt.static_engine == 1;
         stream = stream || (m == POLS_SOLVE_LU && kt > K1M_MAX_KT);   // explicit LU beyond K2's 16 columns: the streamed solver has one

@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
 // `full` branch, each behind its own s_waitcnt (eight dependent L2 round trips per workgroup before the first FMA: 4.06 TB/s on
 // 8 f32 features where the same frame streams at 5.5 through K1).  Here every index is a compile-time constant: one s_load for the pointers,
 // one for the coefficients, JB vector loads in flight, one wait.
-template <typename T, int JB>
+template <typename T, int JB, bool HAS_W = false>   // HAS_W: the reference's weighted arithmetic, (sqrt(w) x) . c * (1 / sqrt(w)) (see predict_kernel)
 __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
@@ -721,10 +721,25 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
 #pragma unroll
             for (int u = 0; u < JB; ++u)
                 if (u < ku) tv[u] = *reinterpret_cast<const V *>(static_cast<const T *>(a.x[u]) + row0);
+            T sw[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) sw[v] = T(1);
+            if constexpr (HAS_W) {
+                const V wv = *reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sw[v] = sqrt(vget<T>(wv, v));
+            }
 #pragma unroll
             for (int u = 0; u < JB; ++u)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) p[v] = fma((u < ku) ? null_fill<T>(pol, vget<T>(tv[u], v)) : T(1), c[u], p[v]);
+                for (int v = 0; v < VEC; ++v) {
+                    const T xv = (u < ku) ? null_fill<T>(pol, vget<T>(tv[u], v)) : T(1);
+                    p[v] = fma(HAS_W ? xv * sw[v] : xv, c[u], p[v]);
+                }
+            if constexpr (HAS_W) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) p[v] *= T(1) / sw[v];
+            }
             V o;
             if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
             store_stream(reinterpret_cast<V *>(pred + row0), o);
@@ -733,8 +748,13 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
             for (int v = 0; v < VEC; ++v) {
                 const int64_t r = row0 + v;
                 if (r >= s && r < e) {
+                    const T sw = HAS_W ? sqrt(static_cast<const T *>(a.w)[r]) : T(1);
 #pragma unroll
-                    for (int u = 0; u < JB; ++u) p[v] = fma((u < ku) ? null_fill<T>(pol, static_cast<const T *>(a.x[u])[r]) : T(1), c[u], p[v]);
+                    for (int u = 0; u < JB; ++u) {
+                        const T xv = (u < ku) ? null_fill<T>(pol, static_cast<const T *>(a.x[u])[r]) : T(1);
+                        p[v] = fma(HAS_W ? xv * sw : xv, c[u], p[v]);
+                    }
+                    if constexpr (HAS_W) p[v] *= T(1) / sw;
                     pred[r] = p[v];
                 }
             }
@@ -750,16 +770,16 @@ int predict_launch(pols_ctx *ctx, int dtype, const PredictArgs &a) {
     if (ctx->opt.predict_loop) gy = 1;
     const dim3 grid((unsigned)a.n_groups, (unsigned)gy);
     const int jb = a.kt <= 4 ? 4 : (a.kt <= 8 ? 8 : (a.kt <= 12 ? 12 : 16));
-    if (a.coef64 && !a.w && !a.resid && a.pred && a.null_policy != POLS_NULL_DROP && a.kt <= 16 && !ctx->opt.predict_loop) {
-#define POLS_PREDICT_GROUPS_GO(T)                                                                                           \
+    if (a.coef64 && !a.resid && a.pred && a.null_policy != POLS_NULL_DROP && a.kt <= 16 && !ctx->opt.predict_loop) {
+#define POLS_PREDICT_GROUPS_GO(T, W)                                                                                        \
     do {                                                                                                                    \
-        if (jb == 4) hipLaunchKernelGGL((predict_groups_kernel<T, 4>), grid, dim3(256), 0, ctx->stream, a);                 \
-        else if (jb == 8) hipLaunchKernelGGL((predict_groups_kernel<T, 8>), grid, dim3(256), 0, ctx->stream, a);            \
-        else if (jb == 12) hipLaunchKernelGGL((predict_groups_kernel<T, 12>), grid, dim3(256), 0, ctx->stream, a);          \
-        else hipLaunchKernelGGL((predict_groups_kernel<T, 16>), grid, dim3(256), 0, ctx->stream, a);                        \
+        if (jb == 4) hipLaunchKernelGGL((predict_groups_kernel<T, 4, W>), grid, dim3(256), 0, ctx->stream, a);              \
+        else if (jb == 8) hipLaunchKernelGGL((predict_groups_kernel<T, 8, W>), grid, dim3(256), 0, ctx->stream, a);         \
+        else if (jb == 12) hipLaunchKernelGGL((predict_groups_kernel<T, 12, W>), grid, dim3(256), 0, ctx->stream, a);       \
+        else hipLaunchKernelGGL((predict_groups_kernel<T, 16, W>), grid, dim3(256), 0, ctx->stream, a);                     \
     } while (0)
-        if (dtype == POLS_F32) POLS_PREDICT_GROUPS_GO(float);
-        else POLS_PREDICT_GROUPS_GO(double);
+        if (dtype == POLS_F32) { if (a.w) POLS_PREDICT_GROUPS_GO(float, true); else POLS_PREDICT_GROUPS_GO(float, false); }
+        else { if (a.w) POLS_PREDICT_GROUPS_GO(double, true); else POLS_PREDICT_GROUPS_GO(double, false); }
 #undef POLS_PREDICT_GROUPS_GO
         POLS_HIP(hipGetLastError());
         return POLS_OK;

@@ -1,4 +1,4 @@
-// k5v_gram.hip -- K5v: the streamed Gram pass on the VALU, for up to ten columns without sample weights or a null policy.
+// k5v_gram.hip -- K5v: the streamed Gram pass on the VALU, for up to ten columns without a null policy (sample weights: scaled on load).
 //
 // The streamed path (K5: a Gram pass, the small solve, a prediction pass) serves every group that is too long to stay in registers --
 // and the one-regression-over-the-whole-frame call of the reference's README (long groups cut into segments).  Its Gram kernel puts
@@ -17,10 +17,13 @@
 
 namespace pols {
 
+__device__ __forceinline__ void k5v_scale(float4 &z, const float (&sw)[4]) { z.x *= sw[0]; z.y *= sw[1]; z.z *= sw[2]; z.w *= sw[3]; }
+__device__ __forceinline__ void k5v_scale(double2 &z, const double (&sw)[2]) { z.x *= sw[0]; z.y *= sw[1]; }
+
 template <int NZ>
 __host__ __device__ constexpr int k5v_tri(int i, int j) { return i * NZ - i * (i - 1) / 2 + (j - i); }   // packed upper triangle, i <= j < NZ
 
-template <typename T, int KT>
+template <typename T, int KT, bool HAS_W>   // HAS_W: sample weights -- every column of [X | 1 | y] scaled by sqrt(w) as it is loaded (least_squares.py:190-196)
 __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
@@ -44,6 +47,14 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
                 else { if constexpr (VEC == 4) z[j] = V{T(1), T(1), T(1), T(1)}; else z[j] = V{T(1), T(1)}; }
             }
             z[KT] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
+            if constexpr (HAS_W) {
+                const V wv = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
+                T sw[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sw[v] = sqrt(vget<T>(wv, v));
+#pragma unroll
+                for (int j = 0; j < NZ; ++j) k5v_scale(z[j], sw);
+            }
         } else {                                             // the segment's first / last vector: rows outside it are zero rows
 #pragma unroll
             for (int j = 0; j < NZ; ++j) {
@@ -55,6 +66,7 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
                     if (j == KT) t[v] = in ? static_cast<const T *>(a.y)[r] : T(0);
                     else if (j < KT - 1 || j < ku) t[v] = in ? static_cast<const T *>(a.x[j])[r] : T(0);
                     else t[v] = in ? T(1) : T(0);
+                    if constexpr (HAS_W) t[v] = in ? t[v] * sqrt(static_cast<const T *>(a.w)[r]) : T(0);
                 }
                 if constexpr (VEC == 4) z[j] = V{t[0], t[1], t[2], t[3]}; else z[j] = V{t[0], t[1]};
             }
@@ -92,11 +104,16 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
     }
 }
 
+template <typename T, int KT, bool HAS_W>
+static void k5v_go_w(pols_ctx *ctx, const GramArgs &a) {
+    hipEvent_t ev0, ev1;
+    if (timing_pair(ctx, &ev0, &ev1)) hipExtLaunchKernelGGL((gram_valu_kernel<T, KT, HAS_W>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gram_valu_kernel<T, KT, HAS_W>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+}
 template <typename T, int KT>
 static void k5v_go(pols_ctx *ctx, const GramArgs &a) {
-    hipEvent_t ev0, ev1;
-    if (timing_pair(ctx, &ev0, &ev1)) hipExtLaunchKernelGGL((gram_valu_kernel<T, KT>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL((gram_valu_kernel<T, KT>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    if (a.w) k5v_go_w<T, KT, true>(ctx, a);
+    else k5v_go_w<T, KT, false>(ctx, a);
 }
 
 template <typename T>
@@ -119,13 +136,13 @@ static int k5v_launch_t(pols_ctx *ctx, const GramArgs &a) {
 }
 
 bool gram_valu_takes(const pols_ctx *ctx, const GramArgs &a) {
-    return a.kt >= 1 && a.kt <= K5V_MAX_KT && !a.w && a.null_policy == POLS_NULL_IGNORE && !a.nvalid && !ctx->opt.kg_single_buffer;
+    return a.kt >= 1 && a.kt <= K5V_MAX_KT && a.null_policy == POLS_NULL_IGNORE && !a.nvalid && !ctx->opt.kg_single_buffer;
 }
 
 int gram_valu_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
     if (a.n_groups > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     char name[96];
-    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_valu_k%d", dtype == POLS_F32 ? "f32" : "f64", a.kt);
+    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_valu%s_k%d", dtype == POLS_F32 ? "f32" : "f64", a.w ? "_w" : "", a.kt);
     ctx->last_kernel = name;
     return dtype == POLS_F32 ? k5v_launch_t<float>(ctx, a) : k5v_launch_t<double>(ctx, a);
 }

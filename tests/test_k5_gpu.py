@@ -308,3 +308,23 @@ def test_static_long_groups_valu_gram(eng, dtype, tol, k, icpt, kind):
         assert np.allclose(_np(out[key])[long_rows], np.asarray(ref[key])[long_rows], rtol=tol, atol=tol), key
     if kind in ("ols", "ridge"):      # the short groups too: same reference branch per group (n <= k groups get the minimum-norm fix-up)
         assert np.allclose(got_c, ref_c, rtol=10 * tol, atol=10 * tol), float(np.abs(got_c - ref_c).max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,icpt,kind", [(1, False, "ols"), (3, True, "ridge"), (8, False, "ols"), (8, True, "ols"), (10, False, "ridge"), (6, True, "lu")])
+def test_static_long_groups_valu_gram_with_weights(eng, dtype, tol, k, icpt, kind):
+    """WLS on groups too long for the registers: the VALU Gram pass scales every column by sqrt(w) as it loads it, the lean prediction kernel
+    keeps the reference's arithmetic, (sqrt(w) x) . c * (1 / sqrt(w)) (least_squares.py:190-196, 234-235).  Against the oracle."""
+    from oracle import orc
+
+    rng = np.random.default_rng(200 * k + int(icpt))
+    sizes = [6_001, 14_345, 9_000, 4_097 + k, 23_011, 5_555]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, dtype, sparsity=0.0, weights=True)
+    kw = {"ols": {}, "ridge": dict(alpha=0.7, l1_ratio=0.0), "lu": dict(solve_method="lu")}[kind]
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=_cuda(w), add_intercept=icpt, want=("coef", "pred", "resid", "status"), **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream") and "_valu_w_" in eng.last_kernel, eng.last_kernel
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt, **kw)
+    assert int(_np(out["status"]).sum()) == 0
+    for key in ("coef", "pred", "resid"):
+        assert np.allclose(_np(out[key]), ref[key], rtol=tol, atol=tol), (key, float(np.abs(_np(out[key]) - ref[key]).max()))
