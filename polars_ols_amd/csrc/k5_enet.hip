@@ -698,7 +698,9 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
 // `full` branch, each behind its own s_waitcnt (eight dependent L2 round trips per workgroup before the first FMA: 4.06 TB/s on
 // 8 f32 features where the same frame streams at 5.5 through K1).  Here every index is a compile-time constant: one s_load for the pointers,
 // one for the coefficients, JB vector loads in flight, one wait.
-template <typename T, int JB, bool HAS_W = false>   // HAS_W: the reference's weighted arithmetic, (sqrt(w) x) . c * (1 / sqrt(w)) (see predict_kernel)
+// HAS_W: the reference's weighted arithmetic, (sqrt(w) x) . c * (1 / sqrt(w)) (see predict_kernel).  DROP: null_policy "drop" -- the rows that were not
+// part of the fit get a NaN prediction (ex.rs:409-417), decided from the feature vectors already in registers + the target + the validity bytes.
+template <typename T, int JB, bool HAS_W = false, bool DROP = false>
 __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
@@ -740,6 +742,18 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) p[v] *= T(1) / sw[v];
             }
+            if constexpr (DROP) {
+                const V yv = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const T y1 = vget<T>(yv, v);
+                    bool fit = (y1 == y1) && !(a.valid && !a.valid[row0 + v]);
+#pragma unroll
+                    for (int u = 0; u < JB; ++u)
+                        if (u < ku) { const T x1 = vget<T>(tv[u], v); fit = fit && (x1 == x1); }
+                    p[v] = nan_if<T>(fit ? 0u : 1u, p[v]);
+                }
+            }
             V o;
             if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
             store_stream(reinterpret_cast<V *>(pred + row0), o);
@@ -755,6 +769,7 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
                         p[v] = fma(HAS_W ? xv * sw : xv, c[u], p[v]);
                     }
                     if constexpr (HAS_W) p[v] *= T(1) / sw;
+                    if constexpr (DROP) p[v] = nan_if<T>(null_row_in_fit<T>(pol, a.valid, a.y, a.x, ku, r) ? 0u : 1u, p[v]);
                     pred[r] = p[v];
                 }
             }
@@ -770,16 +785,22 @@ int predict_launch(pols_ctx *ctx, int dtype, const PredictArgs &a) {
     if (ctx->opt.predict_loop) gy = 1;
     const dim3 grid((unsigned)a.n_groups, (unsigned)gy);
     const int jb = a.kt <= 4 ? 4 : (a.kt <= 8 ? 8 : (a.kt <= 12 ? 12 : 16));
-    if (a.coef64 && !a.resid && a.pred && a.null_policy != POLS_NULL_DROP && a.kt <= 16 && !ctx->opt.predict_loop) {
-#define POLS_PREDICT_GROUPS_GO(T, W)                                                                                        \
+    if (a.coef64 && !a.resid && a.pred && (a.null_policy != POLS_NULL_DROP || a.y) && a.kt <= 16 && !ctx->opt.predict_loop) {
+#define POLS_PREDICT_GROUPS_GO(T, W, D)                                                                                     \
     do {                                                                                                                    \
-        if (jb == 4) hipLaunchKernelGGL((predict_groups_kernel<T, 4, W>), grid, dim3(256), 0, ctx->stream, a);              \
-        else if (jb == 8) hipLaunchKernelGGL((predict_groups_kernel<T, 8, W>), grid, dim3(256), 0, ctx->stream, a);         \
-        else if (jb == 12) hipLaunchKernelGGL((predict_groups_kernel<T, 12, W>), grid, dim3(256), 0, ctx->stream, a);       \
-        else hipLaunchKernelGGL((predict_groups_kernel<T, 16, W>), grid, dim3(256), 0, ctx->stream, a);                     \
+        if (jb == 4) hipLaunchKernelGGL((predict_groups_kernel<T, 4, W, D>), grid, dim3(256), 0, ctx->stream, a);           \
+        else if (jb == 8) hipLaunchKernelGGL((predict_groups_kernel<T, 8, W, D>), grid, dim3(256), 0, ctx->stream, a);      \
+        else if (jb == 12) hipLaunchKernelGGL((predict_groups_kernel<T, 12, W, D>), grid, dim3(256), 0, ctx->stream, a);    \
+        else hipLaunchKernelGGL((predict_groups_kernel<T, 16, W, D>), grid, dim3(256), 0, ctx->stream, a);                  \
     } while (0)
-        if (dtype == POLS_F32) { if (a.w) POLS_PREDICT_GROUPS_GO(float, true); else POLS_PREDICT_GROUPS_GO(float, false); }
-        else { if (a.w) POLS_PREDICT_GROUPS_GO(double, true); else POLS_PREDICT_GROUPS_GO(double, false); }
+#define POLS_PREDICT_GROUPS_T(T)                                                                                            \
+    do {                                                                                                                    \
+        if (a.null_policy == POLS_NULL_DROP) { if (a.w) POLS_PREDICT_GROUPS_GO(T, true, true); else POLS_PREDICT_GROUPS_GO(T, false, true); } \
+        else { if (a.w) POLS_PREDICT_GROUPS_GO(T, true, false); else POLS_PREDICT_GROUPS_GO(T, false, false); }            \
+    } while (0)
+        if (dtype == POLS_F32) POLS_PREDICT_GROUPS_T(float);
+        else POLS_PREDICT_GROUPS_T(double);
+#undef POLS_PREDICT_GROUPS_T
 #undef POLS_PREDICT_GROUPS_GO
         POLS_HIP(hipGetLastError());
         return POLS_OK;

@@ -1,4 +1,4 @@
-// k5v_gram.hip -- K5v: the streamed Gram pass on the VALU, for up to ten columns without a null policy (sample weights: scaled on load).
+// k5v_gram.hip -- K5v: the streamed Gram pass on the VALU, for up to ten columns (sample weights and null policies applied on the registers as the rows are loaded).
 //
 // The streamed path (K5: a Gram pass, the small solve, a prediction pass) serves every group that is too long to stay in registers --
 // and the one-regression-over-the-whole-frame call of the reference's README (long groups cut into segments).  Its Gram kernel puts
@@ -23,7 +23,11 @@ __device__ __forceinline__ void k5v_scale(double2 &z, const double (&sw)[2]) { z
 template <int NZ>
 __host__ __device__ constexpr int k5v_tri(int i, int j) { return i * NZ - i * (i - 1) / 2 + (j - i); }   // packed upper triangle, i <= j < NZ
 
-template <typename T, int KT, bool HAS_W>   // HAS_W: sample weights -- every column of [X | 1 | y] scaled by sqrt(w) as it is loaded (least_squares.py:190-196)
+// HAS_W: sample weights -- every column of [X | 1 | y] scaled by sqrt(w) as it is loaded (least_squares.py:190-196).
+// NULLS: a null policy (src/expressions.rs:201-296), what gram_stream_kernel's prep pass does in LDS done on the registers: rows the policy drops
+// (null target / null feature / validity byte 0, by policy) become zero rows, nulls that stay in the fit become 0, and the rows left in the fit are
+// counted into a.nvalid (the n of alpha * n, and "no row left" = an empty group).
+template <typename T, int KT, bool HAS_W, bool NULLS>
 __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
     using V = typename Vec16<T>::type;
     constexpr int VEC = Vec16<T>::N;
@@ -37,6 +41,8 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
     T acc[NACC];
 #pragma unroll
     for (int q = 0; q < NACC; ++q) acc[q] = T(0);
+    const int pol = a.null_policy;
+    int nfit = 0;                                            // NULLS: this lane's rows that take part in the fit
 
     for (int64_t row0 = base + (int64_t)tid * VEC; row0 < e; row0 += 256 * VEC) {
         V z[NZ];
@@ -47,11 +53,43 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
                 else { if constexpr (VEC == 4) z[j] = V{T(1), T(1), T(1), T(1)}; else z[j] = V{T(1), T(1)}; }
             }
             z[KT] = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0));
-            if constexpr (HAS_W) {
-                const V wv = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
+            if constexpr (HAS_W || NULLS) {
                 T sw[VEC];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) sw[v] = sqrt(vget<T>(wv, v));
+                for (int v = 0; v < VEC; ++v) sw[v] = T(1);
+                if constexpr (HAS_W) {
+                    const V wv = load_stream(reinterpret_cast<const V *>(static_cast<const T *>(a.w) + row0));
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) sw[v] = sqrt(vget<T>(wv, v));
+                }
+                if constexpr (NULLS) {
+                    bool ok[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) ok[v] = true;
+                    if (a.valid && null_checks_y(pol)) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) ok[v] = a.valid[row0 + v] != 0;
+                    }
+                    if (null_checks_y(pol)) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { const T yv = vget<T>(z[KT], v); ok[v] = ok[v] && (yv == yv); }
+                    }
+                    if (null_checks_x(pol)) {
+#pragma unroll
+                        for (int j = 0; j < KT; ++j)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) { const T xv = vget<T>(z[j], v); ok[v] = ok[v] && (xv == xv); }   // (the ones column is never a null)
+                    }
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { nfit += ok[v] ? 1 : 0; sw[v] = ok[v] ? sw[v] : T(0); }
+#pragma unroll
+                    for (int j = 0; j < NZ; ++j) {             // nulls that stay -> 0 (handle_nulls, ex.rs:257-296); dropped rows -> zero rows (a NaN x 0 would stay NaN)
+                        T t[VEC];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) t[v] = ok[v] ? null_fill<T>(pol, vget<T>(z[j], v)) : T(0);
+                        if constexpr (VEC == 4) z[j] = V{t[0], t[1], t[2], t[3]}; else z[j] = V{t[0], t[1]};
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < NZ; ++j) k5v_scale(z[j], sw);
             }
@@ -66,7 +104,13 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
                     if (j == KT) t[v] = in ? static_cast<const T *>(a.y)[r] : T(0);
                     else if (j < KT - 1 || j < ku) t[v] = in ? static_cast<const T *>(a.x[j])[r] : T(0);
                     else t[v] = in ? T(1) : T(0);
-                    if constexpr (HAS_W) t[v] = in ? t[v] * sqrt(static_cast<const T *>(a.w)[r]) : T(0);
+                    bool use = in;
+                    if constexpr (NULLS) {
+                        use = in && null_row_in_fit<T>(pol, a.valid, a.y, a.x, ku, r);
+                        t[v] = use ? null_fill<T>(pol, t[v]) : T(0);
+                        if (j == KT) nfit += use ? 1 : 0;
+                    }
+                    if constexpr (HAS_W) t[v] = use ? t[v] * sqrt(static_cast<const T *>(a.w)[r]) : T(0);
                 }
                 if constexpr (VEC == 4) z[j] = V{t[0], t[1], t[2], t[3]}; else z[j] = V{t[0], t[1]};
             }
@@ -94,7 +138,14 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) part[wave][4 * i + r] = u[i];
     }
+    __shared__ int nfit_s;
+    if constexpr (NULLS) { if (tid == 0) nfit_s = 0; }
     __syncthreads();
+    if constexpr (NULLS) {
+        if (nfit) atomicAdd(&nfit_s, nfit);
+        __syncthreads();
+        if (tid == 0 && a.nvalid) a.nvalid[g] = (double)nfit_s;
+    }
     double *G = a.gram + (size_t)g * NZ * NZ;
     if (tid < NZ * NZ) {
         const int i = tid / NZ, j = tid - i * NZ;
@@ -104,16 +155,17 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
     }
 }
 
-template <typename T, int KT, bool HAS_W>
+template <typename T, int KT, bool HAS_W, bool NULLS>
 static void k5v_go_w(pols_ctx *ctx, const GramArgs &a) {
     hipEvent_t ev0, ev1;
-    if (timing_pair(ctx, &ev0, &ev1)) hipExtLaunchKernelGGL((gram_valu_kernel<T, KT, HAS_W>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL((gram_valu_kernel<T, KT, HAS_W>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
+    if (timing_pair(ctx, &ev0, &ev1)) hipExtLaunchKernelGGL((gram_valu_kernel<T, KT, HAS_W, NULLS>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((gram_valu_kernel<T, KT, HAS_W, NULLS>), dim3((unsigned)a.n_groups), dim3(256), 0, ctx->stream, a);
 }
 template <typename T, int KT>
 static void k5v_go(pols_ctx *ctx, const GramArgs &a) {
-    if (a.w) k5v_go_w<T, KT, true>(ctx, a);
-    else k5v_go_w<T, KT, false>(ctx, a);
+    const bool nulls = a.null_policy != POLS_NULL_IGNORE;
+    if (a.w) { if (nulls) k5v_go_w<T, KT, true, true>(ctx, a); else k5v_go_w<T, KT, true, false>(ctx, a); }
+    else { if (nulls) k5v_go_w<T, KT, false, true>(ctx, a); else k5v_go_w<T, KT, false, false>(ctx, a); }
 }
 
 template <typename T>
@@ -136,13 +188,13 @@ static int k5v_launch_t(pols_ctx *ctx, const GramArgs &a) {
 }
 
 bool gram_valu_takes(const pols_ctx *ctx, const GramArgs &a) {
-    return a.kt >= 1 && a.kt <= K5V_MAX_KT && a.null_policy == POLS_NULL_IGNORE && !a.nvalid && !ctx->opt.kg_single_buffer;
+    return a.kt >= 1 && a.kt <= K5V_MAX_KT && (a.null_policy == POLS_NULL_IGNORE ? !a.nvalid : a.nvalid != nullptr) && !ctx->opt.kg_single_buffer;
 }
 
 int gram_valu_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
     if (a.n_groups > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
     char name[96];
-    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_valu%s_k%d", dtype == POLS_F32 ? "f32" : "f64", a.w ? "_w" : "", a.kt);
+    std::snprintf(name, sizeof(name), "k5_gram_stream_%s_valu%s%s_k%d", dtype == POLS_F32 ? "f32" : "f64", a.w ? "_w" : "", a.null_policy != POLS_NULL_IGNORE ? "_nulls" : "", a.kt);
     ctx->last_kernel = name;
     return dtype == POLS_F32 ? k5v_launch_t<float>(ctx, a) : k5v_launch_t<double>(ctx, a);
 }

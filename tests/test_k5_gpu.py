@@ -328,3 +328,37 @@ def test_static_long_groups_valu_gram_with_weights(eng, dtype, tol, k, icpt, kin
     assert int(_np(out["status"]).sum()) == 0
     for key in ("coef", "pred", "resid"):
         assert np.allclose(_np(out[key]), ref[key], rtol=tol, atol=tol), (key, float(np.abs(_np(out[key]) - ref[key]).max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("policy", ["zero", "drop", "drop_zero", "drop_y_zero_x"])
+@pytest.mark.parametrize("k,weights,icpt,kw", [(8, False, False, {}), (5, True, True, {"alpha": 0.5}), (10, False, False, {}), (2, True, False, {})])
+def test_static_long_groups_valu_gram_null_policies(eng, dtype, tol, policy, k, weights, icpt, kw):
+    """Null policies on groups too long for the registers (round 5): K5v applies them to the rows as it loads them -- dropped rows become zero rows,
+    nulls that stay become 0, the rows left in the fit are counted -- and the lean prediction kernel masks the dropped rows under "drop".
+    "drop" on ONE 10M-row group took 0.38 ms (f32) before, 2.5 x the plain call (profiles/r05_bench_long_nulls.txt).  Expected values composed
+    like the reference composes them (tests/test_nulls_gpu.py::_expected)."""
+    from test_nulls_gpu import _expected
+
+    rng = np.random.default_rng(300 * k + len(policy))
+    sizes = [7_003, 15_345, 9_000, 4_097 + k, 5, 21_011]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, dtype, sparsity=0.0, weights=weights)
+    y = y.copy()
+    y[rng.random(len(y)) < 0.02] = np.nan
+    for j in range(0, k, 3):
+        cols[j] = cols[j].copy()
+        cols[j][rng.random(len(y)) < 0.01] = np.nan
+    y[offs[4]:offs[5]] = np.nan                                      # the 5-row group: nothing left to fit under the drop family
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                            want=("coef", "pred", "resid"), null_policy=policy, **kw)
+    assert eng.last_kernel.startswith("k5_gram_stream") and "_valu" in eng.last_kernel and "_nulls_" in eng.last_kernel, eng.last_kernel
+    coef, pred, resid = _expected(y, cols, offs, w, icpt, policy, **kw)
+    long_g = np.asarray(sizes) >= 1000
+    rows = np.repeat(long_g, sizes)
+    got_c = _np(out["coef"]).reshape(-1, k + int(icpt))
+    assert np.allclose(got_c[long_g], coef[long_g], rtol=tol, atol=tol), float(np.abs(got_c[long_g] - coef[long_g]).max())
+    gp = _np(out["pred"])
+    assert np.array_equal(np.isnan(gp[rows]), np.isnan(pred[rows]))
+    assert np.allclose(gp[rows], pred[rows], rtol=tol, atol=tol, equal_nan=True)
+    assert np.allclose(_np(out["resid"])[rows], resid[rows], rtol=tol, atol=tol, equal_nan=True)
