@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const PredictArgs a) {
     }
 }
 
-// The same for the static models' plain case -- per-group coefficients, no sample weights, no residuals, no "drop" mask, kt <= JB --
+// The same for the static models -- per-group coefficients, kt <= JB (predictions and / or residuals; sample weights and the "drop" mask as template forms) --
 // without the general kernel's control flow: there, the column pointers and the coefficients were fetched one by one inside the divergent
 // `full` branch, each behind its own s_waitcnt (eight dependent L2 round trips per workgroup before the first FMA: 4.06 TB/s on
 // 8 f32 features where the same frame streams at 5.5 through K1).  Here every index is a compile-time constant: one s_load for the pointers,
@@ -710,6 +710,7 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
     const int ku = a.k_user, kt = a.kt;
     const double *cg = a.coef64 + (size_t)(a.gmap ? a.gmap[g] : g) * kt;
     T *pred = static_cast<T *>(a.pred);
+    T *resid = static_cast<T *>(a.resid);
     const int pol = a.null_policy;
     T c[JB];
 #pragma unroll
@@ -742,8 +743,9 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) p[v] *= T(1) / sw[v];
             }
+            V yv;
+            if (DROP || resid) yv = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);   // (workgroup-uniform)
             if constexpr (DROP) {
-                const V yv = *reinterpret_cast<const V *>(static_cast<const T *>(a.y) + row0);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const T y1 = vget<T>(yv, v);
@@ -754,9 +756,16 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
                     p[v] = nan_if<T>(fit ? 0u : 1u, p[v]);
                 }
             }
-            V o;
-            if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
-            store_stream(reinterpret_cast<V *>(pred + row0), o);
+            if (pred) {
+                V o;
+                if constexpr (VEC == 4) o = V{p[0], p[1], p[2], p[3]}; else o = V{p[0], p[1]};
+                store_stream(reinterpret_cast<V *>(pred + row0), o);
+            }
+            if (resid) {                                     // ORIGINAL target - prediction (least_squares.py:239)
+                V o;
+                if constexpr (VEC == 4) o = V{yv.x - p[0], yv.y - p[1], yv.z - p[2], yv.w - p[3]}; else o = V{yv.x - p[0], yv.y - p[1]};
+                store_stream(reinterpret_cast<V *>(resid + row0), o);
+            }
         } else {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -770,7 +779,8 @@ __global__ void __launch_bounds__(256) predict_groups_kernel(const PredictArgs a
                     }
                     if constexpr (HAS_W) p[v] *= T(1) / sw;
                     if constexpr (DROP) p[v] = nan_if<T>(null_row_in_fit<T>(pol, a.valid, a.y, a.x, ku, r) ? 0u : 1u, p[v]);
-                    pred[r] = p[v];
+                    if (pred) pred[r] = p[v];
+                    if (resid) resid[r] = static_cast<const T *>(a.y)[r] - p[v];
                 }
             }
         }
@@ -785,7 +795,7 @@ int predict_launch(pols_ctx *ctx, int dtype, const PredictArgs &a) {
     if (ctx->opt.predict_loop) gy = 1;
     const dim3 grid((unsigned)a.n_groups, (unsigned)gy);
     const int jb = a.kt <= 4 ? 4 : (a.kt <= 8 ? 8 : (a.kt <= 12 ? 12 : 16));
-    if (a.coef64 && !a.resid && a.pred && (a.null_policy != POLS_NULL_DROP || a.y) && a.kt <= 16 && !ctx->opt.predict_loop) {
+    if (a.coef64 && (a.pred || a.resid) && ((a.null_policy != POLS_NULL_DROP && !a.resid) || a.y) && a.kt <= 16 && !ctx->opt.predict_loop) {
 #define POLS_PREDICT_GROUPS_GO(T, W, D)                                                                                     \
     do {                                                                                                                    \
         if (jb == 4) hipLaunchKernelGGL((predict_groups_kernel<T, 4, W, D>), grid, dim3(256), 0, ctx->stream, a);           \
