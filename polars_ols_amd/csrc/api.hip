@@ -1159,7 +1159,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // 409 us against 729 / 837 / 492 streamed -- ahead at every width it covers now)
         // (round 4, two-wave workgroups -- four per CU, four solves in flight: f64 groups of up to 256 rows 24 / 31 columns x 200 rows
         // 2.03 / 2.10 TB/s against 1.83 (K1) / 1.25 (four waves); at 20 columns K1 stays ahead, 2.02 against 1.87)
-        const bool short_wide = !f32 && kt >= 23 && max_rows <= 254;
+        // (round 5, re-measured over 128 .. 512 rows, scripts/ab_wide_f64.py -> profiles/r05_ab_wide_f64.txt: at 23-24 columns K2w is ahead at every length
+        // K1 would take (256 rows 0.310 vs 0.404 ms, 512 rows 0.263 vs 0.378), at 22 from ~200 rows (0.396 vs 0.419; 512: 0.256 vs 0.333), at 20-21 from
+        // 256 (0.268 vs 0.293; 512: 0.253 vs 0.297); at 17-19 and for groups of ~128 rows K1 stays ahead)
+        const bool short_wide = !f32 && (kt >= 23 || (kt == 22 && max_rows >= 192) || (kt >= 20 && max_rows >= 224));
         if (fits && (!k1_resident || short_wide || ctx->opt.static_engine == 4)) {
             K2wArgs aw;
             std::memset(&aw, 0, sizeof(aw));
