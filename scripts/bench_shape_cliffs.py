@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polars_ols_amd.engine import Engine  # noqa: E402
 
 eng = Engine(0)
+time.sleep(2.0)                                               # (a benchmark process that has just exited is still being torn down: its frees disturb the first measurement)
 N, k = 10_000_000, 8
 SHAPES = [("1 x 10M", [N]), ("10 x 1M", [N // 10] * 10), ("100 x 100k", [100_000] * 100), ("1k x 10k", [10_000] * 1000),
           ("4k x 2.5k", [2_500] * 4000), ("10k x 1k", [1_000] * 10_000), ("100k x 100", [100] * 100_000), ("1M x 10", [10] * 1_000_000),
