@@ -413,6 +413,7 @@ static bool k1_valu_takes(const pols_ctx *ctx, bool f32, int kt, int64_t max_row
     // 16-31 columns: one chunk per lane.  f64 only where it measured faster than the alternatives (scripts/bench_k16.py, 50 000 x 200
     // rows): 17-24 columns (867 vs 1 189 us at 20, 1 122 vs 1 418 at 24; at 16 K2 wins 433 vs 506, at 31 the 15-pass kernel is down
     // to one wave per SIMD and loses 2 686 vs 1 923)
+    if (!f32 && kt == 16 && need <= 16 * vec && !ctx->opt.k1_notiny) return true;   // (round 5: K1t, four groups per wave: 24-row groups 0.7 TB/s in K2)
     if (!f32 && (kt < 17 || kt > 24)) return false;
     return kt <= K1X_MAX_KT && need <= (int64_t)256 * 1 * vec;
 }

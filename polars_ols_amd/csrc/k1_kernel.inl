@@ -1655,13 +1655,15 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NP, NL>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NP, NL>(ctx, a)) \
                : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NP, NL>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NP, NL>(ctx, a))
 #ifndef K1_NULLS_TU
-    if constexpr (KT <= 15) {
-        // 11-15 columns, groups of at most 32 chunks (128 f32 / 64 f64 rows -- a quarter of daily data against a dozen factors): K1t's four groups
+    if constexpr (KT <= 16) {
+        // 11-16 columns, groups of at most 32 chunks (128 f32 / 64 f64 rows -- a quarter of daily data against a dozen factors): K1t's four groups
         // per wave, 16 packed Gram entries per pass and the row-cooperative Cholesky, instead of one wave per group with 16 of its 64 lanes
         // holding rows (64-row groups x 12 columns: 1.8 TB/s, profiles/r05_bench_rows_sweep.txt)
         if (!ctx->opt.k1_notiny && !ctx->opt.timeline && a.n_rows >= VEC) {
             if (need <= 16 * 1 * VEC) return a.w ? k1t_launch<T, KT, true, 16, 1>(ctx, a) : k1t_launch<T, KT, false, 16, 1>(ctx, a);
-            if (need <= 16 * 2 * VEC) return a.w ? k1t_launch<T, KT, true, 16, 2>(ctx, a) : k1t_launch<T, KT, false, 16, 2>(ctx, a);
+            if constexpr (KT <= 15 || sizeof(T) == 4) {     // (f64 at 16 columns: two chunks per lane are past 256 registers)
+                if (need <= 16 * 2 * VEC) return a.w ? k1t_launch<T, KT, true, 16, 2>(ctx, a) : k1t_launch<T, KT, false, 16, 2>(ctx, a);
+            }
         }
     }
 #endif
