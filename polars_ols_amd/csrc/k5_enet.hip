@@ -370,7 +370,7 @@ int gram_reduce_launch(pols_ctx *ctx, const GramReduceArgs &a) {
 }
 
 int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {
-    if (gram_valu_takes(ctx, a)) return gram_valu_launch(ctx, dtype, a);
+    if (gram_valu_takes(ctx, dtype, a)) return gram_valu_launch(ctx, dtype, a);
     if (a.kt + 1 > 32) return fail(POLS_ERR_UNSUPPORTED, "gram_stream: %d features (incl. intercept) > 31", a.kt);
     const bool two = a.kt + 1 > 16, w = a.w != nullptr || a.null_policy != POLS_NULL_IGNORE;   // null policies ride on the sqrt(w) prep pass
     if (a.kt == 16 && !ctx->opt.kg_noyv) {   // the target would be alone in the second tile: X'y on the VALU

@@ -94,7 +94,8 @@ int gram_stream_launch(pols_ctx *ctx, int dtype, const GramArgs &a);
 // K5v (k5v_gram.hip): the same pass on the VALU, rows loaded straight into registers -- up to K5V_MAX_KT columns, no sample weights, no
 // null policy; gram_stream_launch routes to it (POLS_KG_SINGLE_BUFFER = the round-4 pass: MFMA tiles, one 256-row LDS buffer)
 constexpr int K5V_MAX_KT = 10;
-bool gram_valu_takes(const pols_ctx *ctx, const GramArgs &a);
+constexpr int K5V_MAX_KT_F32 = 13;   // f32 frames: up to 13 columns (105 accumulators + 14 vectors in flight: 254 registers, two waves per SIMD; 14-16 need AGPRs)
+bool gram_valu_takes(const pols_ctx *ctx, int dtype, const GramArgs &a);
 int gram_valu_launch(pols_ctx *ctx, int dtype, const GramArgs &a);
 int gram_cd_launch(pols_ctx *ctx, int dtype, const CdArgs &a);
 // OLS / ridge (alpha = ridge penalty) from the streamed Gram: generic kt <= 31, any group size

@@ -125,18 +125,22 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
             }
     }
 
-    // ---- lanes -> wave (f64 reduce-scatter) -> workgroup (LDS, wave order) -> the symmetric NZ x NZ matrix
-    double accd[NACC];
+    // ---- lanes -> wave (f64 reduce-scatter, 32 entries at a time: an f64 copy of all of them would double the registers at 11-16 columns) -> workgroup
+    // (LDS, wave order) -> the symmetric NZ x NZ matrix
+    constexpr int SL = 32, NSL = (NACC + SL - 1) / SL;
+    __shared__ double part[4][NSL * SL];
 #pragma unroll
-    for (int q = 0; q < NACC; ++q) accd[q] = (double)acc[q];
-    constexpr int NU = (NACC + 3) / 4;
-    double u[NU];
-    wave_reduce_scatter<double, NACC>(accd, u);             // u[i], in every lane of 16-lane row r: the wave total of entry 4 i + rs_perm(r)
-    __shared__ double part[4][NU * 4];
-    if ((lane & 15) == 0) {
-        const int r = rs_perm(lane >> 4);
+    for (int sl = 0; sl < NSL; ++sl) {
+        double accd[SL];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) part[wave][4 * i + r] = u[i];
+        for (int q = 0; q < SL; ++q) accd[q] = (sl * SL + q < NACC) ? (double)acc[(sl * SL + q < NACC) ? sl * SL + q : 0] : 0.0;
+        double u[SL / 4];
+        wave_reduce_scatter<double, SL>(accd, u);           // u[i], in every lane of 16-lane row r: the wave total of entry 4 i + rs_perm(r) of the slice
+        if ((lane & 15) == 0) {
+            const int r = rs_perm(lane >> 4);
+#pragma unroll
+            for (int i = 0; i < SL / 4; ++i) part[wave][sl * SL + 4 * i + r] = u[i];
+        }
     }
     __shared__ int nfit_s;
     if constexpr (NULLS) { if (tid == 0) nfit_s = 0; }
@@ -147,11 +151,11 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
         if (tid == 0 && a.nvalid) a.nvalid[g] = (double)nfit_s;
     }
     double *G = a.gram + (size_t)g * NZ * NZ;
-    if (tid < NZ * NZ) {
-        const int i = tid / NZ, j = tid - i * NZ;
+    for (int t = tid; t < NZ * NZ; t += 256) {
+        const int i = t / NZ, j = t - i * NZ;
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         const int q = lo * NZ - lo * (lo - 1) / 2 + (hi - lo);
-        G[tid] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+        G[t] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
     }
 }
 
@@ -181,14 +185,24 @@ static int k5v_launch_t(pols_ctx *ctx, const GramArgs &a) {
         case 8: k5v_go<T, 8>(ctx, a); break;
         case 9: k5v_go<T, 9>(ctx, a); break;
         case 10: k5v_go<T, 10>(ctx, a); break;
-        default: return fail(POLS_ERR_UNSUPPORTED, "k5v: %d columns", a.kt);
+        default:
+            if constexpr (sizeof(T) == 4) {                  // f32 only: 78-105 accumulators + 12-14 vectors in flight fit 256 registers; f64 would need twice that
+                switch (a.kt) {
+                    case 11: k5v_go<T, 11>(ctx, a); break;
+                    case 12: k5v_go<T, 12>(ctx, a); break;
+                    case 13: k5v_go<T, 13>(ctx, a); break;
+                    default: return fail(POLS_ERR_UNSUPPORTED, "k5v: %d columns", a.kt);
+                }
+                break;
+            }
+            return fail(POLS_ERR_UNSUPPORTED, "k5v: %d columns", a.kt);
     }
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
 
-bool gram_valu_takes(const pols_ctx *ctx, const GramArgs &a) {
-    return a.kt >= 1 && a.kt <= K5V_MAX_KT && (a.null_policy == POLS_NULL_IGNORE ? !a.nvalid : a.nvalid != nullptr) && !ctx->opt.kg_single_buffer;
+bool gram_valu_takes(const pols_ctx *ctx, int dtype, const GramArgs &a) {
+    return a.kt >= 1 && a.kt <= (dtype == POLS_F32 ? K5V_MAX_KT_F32 : K5V_MAX_KT) && (a.null_policy == POLS_NULL_IGNORE ? !a.nvalid : a.nvalid != nullptr) && !ctx->opt.kg_single_buffer;
 }
 
 int gram_valu_launch(pols_ctx *ctx, int dtype, const GramArgs &a) {

@@ -362,3 +362,39 @@ def test_static_long_groups_valu_gram_null_policies(eng, dtype, tol, policy, k, 
     assert np.array_equal(np.isnan(gp[rows]), np.isnan(pred[rows]))
     assert np.allclose(gp[rows], pred[rows], rtol=tol, atol=tol, equal_nan=True)
     assert np.allclose(_np(out["resid"])[rows], resid[rows], rtol=tol, atol=tol, equal_nan=True)
+
+
+@pytest.mark.parametrize("k,icpt,weights,policy", [(11, False, False, None), (12, True, False, None), (13, False, True, None), (12, False, False, "drop")])
+def test_static_long_groups_valu_gram_f32_up_to_13_columns(eng, k, icpt, weights, policy):
+    """f32 frames keep the VALU Gram pass up to 13 columns (105 accumulators + 14 vectors in flight: 254 registers); f64 and 14+ columns take the MFMA tiles."""
+    from oracle import orc
+    from test_nulls_gpu import _expected
+
+    kt = k + int(icpt)
+    if kt > 13:
+        pytest.skip("14 columns: MFMA")
+    rng = np.random.default_rng(400 + k)
+    sizes = [9_001, 14_345, 11_000, 12_097]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    y, cols, w = _frame(rng, offs, k, np.float32, sparsity=0.0, weights=weights)
+    kw = {}
+    if policy:
+        y = y.copy(); y[rng.random(len(y)) < 0.02] = np.nan
+        kw["null_policy"] = policy
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt, want=("coef", "pred"), **kw)
+    assert "_valu" in eng.last_kernel, eng.last_kernel
+    if policy:
+        coef, pred, _ = _expected(y, cols, offs, w, icpt, policy)
+    else:
+        ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
+        coef, pred = np.asarray(ref["coef"]).reshape(-1, kt), np.asarray(ref["pred"])
+    assert np.allclose(_np(out["coef"]).reshape(-1, kt), coef, rtol=1e-4, atol=1e-4)
+    assert np.allclose(_np(out["pred"]), pred, rtol=1e-4, atol=1e-4, equal_nan=True)
+    eng.set_option("STATIC_ENGINE", "stream")
+    try:                                                              # f64, same width: the MFMA Gram pass
+        out64 = eng.least_squares(_cuda(y.astype(np.float64)), [_cuda(c.astype(np.float64)) for c in cols], offs,
+                                  weights=None if w is None else _cuda(w.astype(np.float64)), add_intercept=icpt, want=("coef",), **kw)
+        assert "_valu" not in eng.last_kernel, eng.last_kernel
+    finally:
+        eng.set_option("STATIC_ENGINE", None)
+    assert np.allclose(_np(out64["coef"]).reshape(-1, kt), coef, rtol=1e-4, atol=1e-4)
