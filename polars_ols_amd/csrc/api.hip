@@ -898,12 +898,12 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
 }
 
 // Size-class split of the static K1 path (see the launches at the end of ls_core): up to two thresholds t[0] < t[1] (rows), n = how many; 0 = one launch.
-// Cost model: a group costs max(rows, 0.3 x the capacity of the kernel its class gets) row-times (fitted to scripts/bench_spread.py: log-normal sizes
+// Cost model: a group costs max(rows, 0.5 x the capacity of the kernel its class gets) row-times (fitted to scripts/bench_spread.py -- 0.3 explains the one-launch numbers, 0.5 also cuts the 50 / 50 frame of 30- and 1 000-row groups, 4.6 -> 5.0 TB/s: log-normal sizes
 // with a 4 000-row tail 1.5 TB/s, 90 % 50-row + 10 % 1 000-row groups 1.9 TB/s in one launch), an extra launch a fixed 6e5.
 static int pick_size_classes(const pols_ctx *ctx, bool f32, int64_t n_groups, int64_t max_rows, int64_t (&t)[2]) {
     t[0] = t[1] = 0;
     if (ctx->opt.no_classes || n_groups < 2048) return 0;
-    const double alpha = 0.3, launch_cost = 6.0e5;                    // (an extra launch: ~5 us of a chip that moves ~1.2e5 rows per us)
+    const double alpha = 0.5, launch_cost = 6.0e5;                    // (an extra launch: ~5 us of a chip that moves ~1.2e5 rows per us)
     const int b0 = f32 ? 7 : 6;                                       // the smallest kernels hold 128 f32 / 64 f64 rows per group
     int bc = b0;
     while (((int64_t)1 << bc) < max_rows && bc < 46) ++bc;            // capacity of the kernel the largest group asks for: 2^bc rows
