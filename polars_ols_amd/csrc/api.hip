@@ -905,6 +905,8 @@ static int pick_size_classes(const pols_ctx *ctx, bool f32, int64_t n_groups, in
     if (ctx->opt.no_classes || n_groups < 2048) return 0;
     const double alpha = 0.5, launch_cost = 6.0e5;                    // (an extra launch: ~5 us of a chip that moves ~1.2e5 rows per us)
     const int b0 = f32 ? 7 : 6;                                       // the smallest kernels hold 128 f32 / 64 f64 rows per group
+                                                                      // (cuts at 32 / 16 rows -- K1t's eight-lane teams -- measured no better: the 6-row groups of the mixed frame
+                                                                      // are minimum-norm problems anyway, and 50-row groups lost 6 % to the 64-row form)
     int bc = b0;
     while (((int64_t)1 << bc) < max_rows && bc < 46) ++bc;            // capacity of the kernel the largest group asks for: 2^bc rows
     // cost with class boundaries at buckets s0 < s1 (-1: unused): bucket q goes to the first boundary >= q, else to the top kernel
