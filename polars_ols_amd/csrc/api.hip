@@ -1873,7 +1873,8 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         // 9..32 features: one wave per chunk with the covariance distributed over its registers (K3p, k4p_wide.hip).  A sequence of up to
         // 1 024 rows is one chunk (the recursion starts from the prior: no totals, no scan); POLS_RLS_ENGINE=chunk keeps k4w_wide.hip.
         const bool wave_p = wide && !xwide && ctx->opt.rls_engine != 3;
-        const int64_t pchunk = max_rows <= 1024 ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
+        // (thousands of sequences are parallelism enough: only the few beyond 1 024 rows are cut then, and only they pay the totals pass and the scan)
+        const int64_t pchunk = (max_rows <= 1024 || b->n_groups >= 4096) ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
         const int64_t minc = wave_p ? pchunk : (k > 128 ? hbm_state_chunk(b->n_rows) : 64);
         if ((rc = build_chunk_tables(ctx, &ds.tables, 1, wide ? k * k + k + 1 : k * (k + 1) / 2 + k + 1, &s4, minc, wave_p ? pchunk : std::max<int64_t>(512, minc)))) return rc;
         s4.y = st.y; s4.valid = st.valid;
@@ -1926,6 +1927,7 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
         const char *tp = static_cast<const char *>(cc.tab);
         a->groups = reinterpret_cast<const K4Group *>(tp);
         a->chunks = reinterpret_cast<const K4Chunk *>(tp + cc.b_groups);
+        a->order = reinterpret_cast<const int32_t *>(tp + cc.b_groups + round256(sizeof(K4Chunk) * (size_t)cc.n_chunks));
         a->cnt = nullptr; a->vidx = nullptr;
         a->n_chunks = cc.n_chunks; a->n_groups = (int32_t)b->n_groups;
         a->totals = static_cast<double *>(tot);
@@ -1970,25 +1972,35 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
     const int64_t n_slabs = (N + 255) / 256;
     const size_t b_sc = dev_tables ? round256(sizeof(uint32_t) * (size_t)n_slabs) : 0, b_sb = dev_tables ? round256(sizeof(int64_t) * (size_t)(n_slabs + 1)) : 0,
                  b_co = dev_tables ? round256(sizeof(int64_t) * (size_t)(b->n_groups + 1)) : 0;
+    // work order of the wave-per-chunk kernels (K4Args::order): chunk ids sorted by length, longest first (stable: equal chunks keep their order) --
+    // sequences of 5 .. 4 000 rows cut at ~500 gave waves whose four chunks were 30 and 480 rows long: RLS at 12 features 2.9 ms on a log-normal
+    // frame against 0.9 ms on equal sequences (scripts/bench_dyn_spread.py)
+    std::vector<int32_t> order(chunks.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)i;
+    if (chunks.size() < 0x7fffffffULL)
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return chunks[(size_t)x].t1 - chunks[(size_t)x].t0 > chunks[(size_t)y].t1 - chunks[(size_t)y].t0; });
+    const size_t b_order = round256(sizeof(int32_t) * order.size());
     void *tab = nullptr, *tot = nullptr;
     cc.tab = nullptr;                                  // the slot is about to be rewritten (and possibly re-allocated)
-    if ((rc = ensure_scratch(ctx, 10, b_groups + b_chunks + 2 * b_cnt + b_sc + b_sb + b_co + 256, &tab))) return rc;   // slot 10 belongs to these tables alone
+    if ((rc = ensure_scratch(ctx, 10, b_groups + b_chunks + b_order + 2 * b_cnt + b_sc + b_sb + b_co + 256, &tab))) return rc;   // slot 10 belongs to these tables alone
     if ((rc = ensure_scratch(ctx, 5, sizeof(double) * (size_t)slots * std::max<size_t>(1, chunks.size()), &tot))) return rc;
     char *tp = static_cast<char *>(tab);
     if ((rc = upload_small(ctx, tp, groups.data(), sizeof(K4Group) * groups.size()))) return rc;   // locals: through the pinned ring
     if ((rc = upload_small(ctx, tp + b_groups, chunks.data(), sizeof(K4Chunk) * chunks.size()))) return rc;
+    if ((rc = upload_small(ctx, tp + b_groups + b_chunks, order.data(), sizeof(int32_t) * order.size()))) return rc;
     if (hv) {
-        if ((rc = upload_small(ctx, tp + b_groups + b_chunks, cnt.data(), sizeof(int32_t) * (size_t)N))) return rc;
-        if ((rc = upload_small(ctx, tp + b_groups + b_chunks + b_cnt, vidx.data(), sizeof(int32_t) * (size_t)N))) return rc;
+        if ((rc = upload_small(ctx, tp + b_groups + b_chunks + b_order, cnt.data(), sizeof(int32_t) * (size_t)N))) return rc;
+        if ((rc = upload_small(ctx, tp + b_groups + b_chunks + b_order + b_cnt, vidx.data(), sizeof(int32_t) * (size_t)N))) return rc;
     }
     a->groups = reinterpret_cast<const K4Group *>(tp);
     a->chunks = reinterpret_cast<const K4Chunk *>(tp + b_groups);
-    a->cnt = (hv || dev_tables) ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks) : nullptr;
-    a->vidx = (hv || dev_tables) ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks + b_cnt) : nullptr;
+    a->order = reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks);
+    a->cnt = (hv || dev_tables) ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks + b_order) : nullptr;
+    a->vidx = (hv || dev_tables) ? reinterpret_cast<const int32_t *>(tp + b_groups + b_chunks + b_order + b_cnt) : nullptr;
     if (dev_tables) {
         // (the groups were uploaded with the null-free constants -- mpv = min_periods, gate_n = min(rows, min_periods); the device pass
         // patches both from the validity bytes.  all_nan only depends on the group's length: n_valid never exceeds min_periods)
-        char *xb = tp + b_groups + b_chunks + 2 * b_cnt;
+        char *xb = tp + b_groups + b_chunks + b_order + 2 * b_cnt;
         RowCompactArgs ra;
         std::memset(&ra, 0, sizeof(ra));
         ra.valid = b->valid; ra.offs = static_cast<const int64_t *>(ctx->scratch[0].ptr);
@@ -2002,8 +2014,8 @@ static int build_chunk_tables(pols_ctx *ctx, const pols_batch *b, int64_t mp, in
         std::memset(&va, 0, sizeof(va));
         va.valid = b->valid; va.offs = ra.offs; va.n_rows = N; va.n_groups = b->n_groups; va.n_slabs = n_slabs;
         va.slab_base = ra.slab_base; va.c_offs = ra.c_offs;
-        va.cnt = reinterpret_cast<int32_t *>(tp + b_groups + b_chunks);
-        va.vidx = reinterpret_cast<int32_t *>(tp + b_groups + b_chunks + b_cnt);
+        va.cnt = reinterpret_cast<int32_t *>(tp + b_groups + b_chunks + b_order);
+        va.vidx = reinterpret_cast<int32_t *>(tp + b_groups + b_chunks + b_order + b_cnt);
         va.groups = tp; va.min_periods = mp;
         if ((rc = valid_tables_launch(ctx, va))) return rc;
     }
@@ -2181,7 +2193,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     // 9..32 features on a null-free frame, min_periods <= window: one wave per chunk, the inverse distributed over its registers and the
     // sums kept beside it (K4p, k4p_wide.hip).  A sequence of up to 1 024 rows is one chunk; a chunk of a longer one re-sums the rows of the
     // window in front of it, so cut sequences need a window of at most 1 024 rows.  POLS_ROLLING_ENGINE=chunk keeps k4w_wide.hip.
-    const int64_t pchunk = max_rows <= 1024 ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
+    const int64_t pchunk = (max_rows <= 1024 || b->n_groups >= 4096) ? 1024 : std::min<int64_t>(1024, std::max<int64_t>(256, b->n_rows / 16384));
     // ... and the FIXED window over rows ("drop_window") on frames with validity bytes on the device: the same kernel with the rows masked
     // and the solves gated (the validity prefix is built on the device, dyn_prep.hip)
     const bool wave_p = wide && !xwide && mp <= w && ctx->opt.rolling_engine != 1 &&

@@ -156,27 +156,38 @@ __global__ void __launch_bounds__(64) k4_totals_kernel(const K4Args a) {
 //   mode 2  RLS, full K x K state (k4w_wide.hip)
 // SW waves per (group, component): a long sequence's chunk list is cut into SW segments; every wave first composes its own segment
 // (no writes), the segment aggregates meet in LDS, and each wave then re-walks its segment from its carry-in writing the prefixes.
+// qb components per workgroup (blockIdx.y covers [qb y, qb (y + 1))): frames of MANY sequences of which few are cut -- a long tail of sequence lengths --
+// launched one workgroup per (sequence, component) whatever the sequence (19 000 x 157 workgroups at 12 features for 1 100 cut sequences); with qb = 16
+// an uncut sequence costs a sixteenth of them, and each of those only stores the prior (what its one chunk enters with) and leaves.
 template <int SW>
-__global__ void __launch_bounds__(64 * SW) chunk_scan_kernel(const K4Args a, const int nacc, const int mode) {
+__global__ void __launch_bounds__(64 * SW) chunk_scan_kernel(const K4Args a, const int nacc, const int mode, const int qb) {
     __shared__ double segD[SW], segT[SW];
     const int64_t g = blockIdx.x;
-    const int q = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const K4Group G = a.groups[g];
     const int64_t n = G.end - G.start;
     const int64_t nch = (n + a.chunk_len - 1) / a.chunk_len;
-    double carry = 0.0;
-    if (mode) {                                              // A_0 = I / p0, b_0 = A_0 mean0
+    auto prior = [&](int q) -> double {                      // A_0 = I / p0, b_0 = A_0 mean0 (mode 0: nothing)
+        if (!mode) return 0.0;
         const int K = a.k;
         const int nx = (mode == 1) ? K * (K + 1) / 2 : K * K;
         if (q < nx) {
             bool diag;
             if (mode == 1) { int i = 0, rem = q; while (rem >= K - i) { rem -= K - i; ++i; } diag = rem == 0; }
             else diag = (q / K) == (q % K);
-            carry = diag ? 1.0 / a.p0 : 0.0;
-        } else {
-            carry = a.mean0 ? a.mean0[q - nx] / a.p0 : 0.0;
+            return diag ? 1.0 / a.p0 : 0.0;
         }
+        return a.mean0 ? a.mean0[q - nx] / a.p0 : 0.0;
+    };
+    const int q_lo = (int)blockIdx.y * qb, q_hi = q_lo + qb < nacc ? q_lo + qb : nacc;
+    if (nch <= 1) {                                          // nothing to scan: the sequence's only chunk enters with the prior
+        const int q = q_lo + (int)threadIdx.x;
+        if (nch == 1 && q < q_hi) a.totals[(size_t)G.first_chunk * a.tot_cs + (size_t)q * a.tot_qs] = prior(q);
+        return;
     }
+    for (int q = q_lo; q < q_hi; ++q) {
+    if (SW > 1 && q > q_lo) __syncthreads();                // (segD / segT of the previous component have been read)
+    double carry = prior(q);
     double *base = a.totals + (size_t)G.first_chunk * a.tot_cs + (size_t)q * a.tot_qs;      // this component's chunk series
     const double *dbase = a.totals + (size_t)G.first_chunk * a.tot_cs + (size_t)nacc * a.tot_qs;   // the decay series (mode != 0)
     const int64_t cs = a.tot_cs;
@@ -238,13 +249,16 @@ __global__ void __launch_bounds__(64 * SW) chunk_scan_kernel(const K4Args a, con
         }
         carry = __shfl(D, 63) * carry + __shfl(T, 63);
     }
+    }
 }
 
 void chunk_scan_launch(pols_ctx *ctx, const K4Args &a, int nacc, int mode) {
-    // few long sequences: 8 waves per (group, component); many short ones: one wave each
+    // few long sequences: 8 waves per (group, component); many short ones: one wave each, 16 components per workgroup from 1 024 sequences on
     const bool lng = a.n_chunks / std::max<int64_t>(1, a.n_groups) > 2048;
-    if (lng) hipLaunchKernelGGL(chunk_scan_kernel<8>, dim3((unsigned)a.n_groups, (unsigned)nacc), dim3(512), 0, ctx->stream, a, nacc, mode);
-    else hipLaunchKernelGGL(chunk_scan_kernel<1>, dim3((unsigned)a.n_groups, (unsigned)nacc), dim3(64), 0, ctx->stream, a, nacc, mode);
+    const int qb = (!lng && a.n_groups >= 1024) ? 16 : 1;
+    const unsigned gy = (unsigned)((nacc + qb - 1) / qb);
+    if (lng) hipLaunchKernelGGL(chunk_scan_kernel<8>, dim3((unsigned)a.n_groups, gy), dim3(512), 0, ctx->stream, a, nacc, mode, qb);
+    else hipLaunchKernelGGL(chunk_scan_kernel<1>, dim3((unsigned)a.n_groups, gy), dim3(64), 0, ctx->stream, a, nacc, mode, qb);
 }
 
 // ------------------------------------------------------------------ pass 3: the walk

@@ -50,6 +50,8 @@ struct K4Args {
     double p0;                   // initial_state_covariance: A_0 = I / p0
     const double *mean0;         // device, k values or nullptr
     double *state;               // k4x beyond 128 features: one k x (k | 1) matrix per chunk in HBM (set by the launcher)
+    const int32_t *order;        // k4p / k3p (or nullptr): work slot i takes chunk order[i] -- the chunks sorted by length, longest first, so that the chunks that
+                                 // share a wave (up to four) are about equally long; chunk ids, totals and the group tables are untouched
     int32_t use_totals;          // k4p rolling: sequences are cut AND the window exceeds 1 024 rows -- the chunk-start sums come from the scanned
                                  // per-chunk totals (prefix differences) instead of re-summing the window in front of the chunk
 };

@@ -249,10 +249,12 @@ __global__ void __launch_bounds__(64) kp_totals_kernel(const K4Args a) {
     constexpr int CPL = KpGeo<KP, LPS>::CPL, XS = KpGeo<KP, LPS>::XS, KP_RB = KpGeo<KP, LPS>::RB;
     __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP, LPS>::lds_doubles()];
     KpCtx<T, KP, LPS> cx(a, lds);
-    const int64_t c = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
-    if (c >= a.n_chunks) return;                                   // (a whole sub-wave: the others' cross-lane traffic stays inside them)
+    const int64_t ci = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
+    if (ci >= a.n_chunks) return;                                  // (a whole sub-wave: the others' cross-lane traffic stays inside them)
+    const int64_t c = a.order ? (int64_t)a.order[ci] : ci;
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
+    if (ch.index_in_group == 0 && ch.t1 >= G.end) return;          // the sequence's only chunk: nobody reads its sums (the walk starts it from the prior / from nothing)
     const int K = cx.K;
     cx.zero_pads();
     double S[CPL], b = 0.0, decay = 1.0;
@@ -290,8 +292,9 @@ __global__ void __launch_bounds__(64) kp_rls_walk_kernel(const K4Args a) {
     constexpr int CPL = KpGeo<KP, LPS>::CPL, XS = KpGeo<KP, LPS>::XS, KP_RB = KpGeo<KP, LPS>::RB;
     __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP, LPS>::lds_doubles()];
     KpCtx<T, KP, LPS> cx(a, lds);
-    const int64_t c = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
-    if (c >= a.n_chunks) return;
+    const int64_t ci = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
+    if (ci >= a.n_chunks) return;
+    const int64_t c = a.order ? (int64_t)a.order[ci] : ci;       // (work slots in order of chunk length: see K4Args::order)
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
     const int K = cx.K, r = cx.r, c0 = cx.c0;
@@ -361,8 +364,9 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
     constexpr int CPL = KpGeo<KP, LPS>::CPL, XS = KpGeo<KP, LPS>::XS, KP_RB = KpGeo<KP, LPS>::RB;
     __shared__ __attribute__((aligned(16))) double lds[KpCtx<T, KP, LPS>::lds_doubles()];
     KpCtx<T, KP, LPS> cx(a, lds);
-    const int64_t c = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
-    if (c >= a.n_chunks) return;
+    const int64_t ci = (int64_t)blockIdx.x * KpGeo<KP, LPS>::SEQ + cx.sub;
+    if (ci >= a.n_chunks) return;
+    const int64_t c = a.order ? (int64_t)a.order[ci] : ci;       // (work slots in order of chunk length: see K4Args::order)
     const K4Chunk ch = a.chunks[c];
     const K4Group G = a.groups[ch.group];
     const int K = cx.K, r = cx.r, c0 = cx.c0;
