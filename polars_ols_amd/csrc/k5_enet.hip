@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) gram_stream_kernel(const GramArgs a, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [nbuf][ncols][rs]; the first is re-used for the cross-wave partial tiles at the end.  nbuf == 2 (narrow tiles): the DMA of chunk
     // c + 1 is issued before the MFMAs of chunk c, so a workgroup has a chunk in flight the whole time instead of one exposed load
-    // latency per 256 rows (gram_stream at 3.8 / 4.2 TB/s f32 / f64 on 8 features, profiles/r05_kernel_stats_long_groups.txt)
+    // latency per 256 rows (gram_stream at 3.8 / 4.2 TB/s f32 / f64 on 8 features, profiles/r05_kernel_stats_long_groups.csv)
     T *const tile0 = reinterpret_cast<T *>(smem);
     T *zeros = tile0 + (size_t)nbuf * tile_elems;
     T *ones = zeros + K1M_CONST_ELEMS;
@@ -266,7 +266,7 @@ static int gram_stream_launch_t(pols_ctx *ctx, const GramArgs &a) {
     const int ncols = a.k_user + 1 + (HAS_W ? 1 : 0);
     // rows per LDS chunk: 256, doubled while a column's piece stays within 4 KB and the tile within 48 KB (three workgroups per CU).  The
     // 1 KB pieces of a 256-row f32 chunk streamed at 3.8 TB/s (2 KB, f64: 4.2) where 4 KB pieces of the same columns stream at 5.5
-    // (profiles/r05_probe_matrix.txt, r05_kernel_stats_long_groups.txt)
+    // (profiles/r05_probe_matrix.txt, r05_kernel_stats_long_groups.csv)
     int cr = KG_CR;
     if (!ctx->opt.kg_single_buffer)
         while ((size_t)cr * 2 * sizeof(T) <= 4096 && (size_t)ncols * k1m_row_stride<T>(cr * 2) * sizeof(T) <= 48 * 1024) cr *= 2;
