@@ -344,7 +344,7 @@ def main() -> None:
         dist = dist_mod
 
     from polars_ols_amd import Engine
-    from polars_ols_amd.distributed import CoefficientRing, create_comm
+    from polars_ols_amd.distributed import CoefficientRing, check_gathered_table, collective_identity, create_comm
 
     eng = Engine(local_rank)
     # run the engine on a torch-visible stream so torch events can order the collective's stream against it
@@ -400,6 +400,7 @@ def main() -> None:
                                consumed=lambda r: consumed[r].record(side))
         collective = {"kind": f"pols_comm_allgather_rows (RCCL behind the C-ABI) of {RING} steps' coefficient tables, side stream",
                       "backend": dist.get_backend(), "bytes_per_step_per_rank": int(coef.numel() * coef.element_size()) * (world - 1)}
+        collective.update(collective_identity(comm))          # what RCCL itself saw: rank count, every rank's device + PCI bus id
 
     pred_state = None
     if gather_pred:
@@ -420,6 +421,7 @@ def main() -> None:
         pred_state = dict(i=0)
         collective = {"kind": "pols_comm_gather_rows (RCCL behind the C-ABI) of the predictions column to rank 0, every step, side stream",
                       "backend": dist.get_backend(), "bytes_per_step_per_rank": int(pred0.numel() * pred0.element_size())}
+        collective.update(collective_identity(comm))
 
     step_no = [0]
 
@@ -468,6 +470,33 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # the re-assembled table against its parts, outside the timed region: one more gather of the current step's table, then every rank's
+    # checksum of its own rows against the checksum of its slice of what arrived (collective: all ranks take part, rank 0 asserts)
+    if gather:
+        local_tab = plan.results["coef"]
+        side.wait_stream(eng_stream)
+        whole = comm.allgather_rows(local_tab, counts)
+        side.synchronize()
+        chk = check_gathered_table(whole, local_tab, counts)
+        collective["gathered_equals_concatenation"] = chk["ok"]
+        assert chk["ok"], f"rank {rank}: the gathered coefficient table is not the concatenation of the shards: {chk}"
+    elif gather_pred:
+        side.synchronize()
+        last = bufs[(pred_state["i"] - 1) & 1]
+        chk = check_gathered_table(gathered_pred, last, rows)
+        collective["gathered_equals_concatenation"] = chk["ok"]
+        assert chk["ok"] is not False, f"rank {rank}: the gathered predictions are not the concatenation of the shards: {chk}"
+    elif world == 1 and not os.environ.get("POLS_BENCH_NO_COMM_PROBE"):
+        # N = 1: a world of one through the same entries, so that the line says what the communicator saw here too
+        try:
+            from polars_ols_amd.engine import Comm
+
+            c1 = Comm(eng, 1, 0, Comm.unique_id())
+            collective.update(collective_identity(c1))
+            c1.close()
+        except Exception as exc:                                                       # RCCL missing on a one-GPU box is not a bench failure
+            collective["nranks_seen"] = None
+            collective["identity_error"] = str(exc)[:200]
     kernel_ms = list(eng.timing_collect())
     eng.timing(False)
     kernel_name = eng.last_kernel

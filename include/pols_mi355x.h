@@ -409,6 +409,14 @@ int pols_comm_create_all(pols_ctx *const *ctxs, int n, pols_comm **out /* n comm
 void pols_comm_destroy(pols_comm *comm);
 int pols_comm_world_size(const pols_comm *comm);
 int pols_comm_rank(const pols_comm *comm);
+/* What RCCL itself says about this communicator -- not what the caller passed to pols_comm_create: the rank count and rank the library
+ * reports (ncclCommCount / ncclCommUserRank), the HIP device it is bound to (ncclCommCuDevice) with its PCI bus id, and the library's
+ * version code (ncclGetVersion).  A measurement line that carries these proves the collective saw N ranks on N different devices. */
+typedef struct pols_comm_info {
+    int32_t nranks_seen, rank_seen, device, rccl_version;
+    char pci_bus_id[32];
+} pols_comm_info;
+int pols_comm_query(const pols_comm *comm, pols_comm_info *out);
 int pols_comm_group_begin(void);
 int pols_comm_group_end(void);
 /* Every rank receives all rows, in rank order (= group order, the shards being contiguous ranges): `local` holds counts[rank]

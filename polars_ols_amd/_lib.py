@@ -65,6 +65,11 @@ class Out(C.Structure):
     _fields_ = [("coef", C.c_void_p), ("pred", C.c_void_p), ("resid", C.c_void_p), ("status", C.c_void_p)]
 
 
+class CommInfo(C.Structure):          # pols_comm_info
+    _fields_ = [("nranks_seen", C.c_int32), ("rank_seen", C.c_int32), ("device", C.c_int32), ("rccl_version", C.c_int32),
+                ("pci_bus_id", C.c_char * 32)]
+
+
 class ArrowColumn(C.Structure):       # pols_arrow_column
     _fields_ = [("schema", C.c_void_p), ("chunks", C.POINTER(C.c_void_p)), ("n_chunks", C.c_int32)]
 
@@ -84,7 +89,7 @@ EXPORTS = [
     "pols_layout_create", "pols_layout_destroy", "pols_layout_n_rows", "pols_layout_n_groups", "pols_layout_is_identity",
     "pols_layout_group_offsets", "pols_layout_group_keys", "pols_layout_take", "pols_layout_untake", "pols_layout_row_groups",
     "pols_partition_groups", "pols_comm_unique_id", "pols_comm_create", "pols_comm_create_all", "pols_comm_destroy",
-    "pols_comm_world_size", "pols_comm_rank", "pols_comm_group_begin", "pols_comm_group_end", "pols_comm_allgather_rows",
+    "pols_comm_world_size", "pols_comm_rank", "pols_comm_query", "pols_comm_group_begin", "pols_comm_group_end", "pols_comm_allgather_rows",
     "pols_comm_gather_rows", "pols_least_squares_arrow", "pols_least_squares_statistics_arrow",
     "pols_multi_target_least_squares_arrow", "pols_recursive_least_squares_arrow", "pols_rolling_least_squares_arrow",
     "pols_predict_arrow", "pols_least_squares_sharded",
@@ -171,6 +176,7 @@ def lib() -> C.CDLL:
         L.pols_comm_destroy.argtypes, L.pols_comm_destroy.restype = [C.c_void_p], None
         L.pols_comm_world_size.argtypes = [C.c_void_p]
         L.pols_comm_rank.argtypes = [C.c_void_p]
+        L.pols_comm_query.argtypes = [C.c_void_p, C.POINTER(CommInfo)]
         L.pols_comm_allgather_rows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p]
         L.pols_comm_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.c_void_p]
         _lib = L

@@ -1796,6 +1796,32 @@ static int ensure_packed_tiles(pols_ctx *ctx, const pols_batch *b, int64_t tile_
     return POLS_OK;
 }
 
+// K3c's halo form: per tile of tile_rows rows the first row of the sequence that holds the row in front of the tile (tile 0: 0) -- the
+// prior's decay up to the tile is then exact.  Scratch slot 25, cached per frame.
+static int ensure_tile_seq0(pols_ctx *ctx, const pols_batch *b, int64_t tile_rows, int64_t n_tiles, const int64_t **map) {
+    *map = nullptr;
+    const int64_t N = b->n_rows;
+    auto &tc = ctx->k3h;
+    void *dmap = nullptr;
+    int rc = ensure_scratch(ctx, 25, round256(sizeof(int64_t) * (size_t)(n_tiles + 1)), &dmap);
+    if (rc) return rc;
+    if (tc.ptr != dmap || tc.offs_id != ctx->offs_id || tc.n_groups != b->n_groups || tc.n_rows != N || tc.tile_rows != tile_rows) {
+        tc.ptr = nullptr;
+        std::vector<int64_t> first((size_t)n_tiles, 0);
+        const int64_t *offs = b->group_offsets;
+        int64_t g = 0;
+        for (int64_t t = 1; t < n_tiles; ++t) {
+            const int64_t row = t * tile_rows - 1;
+            while (g + 1 < b->n_groups && offs[g + 1] <= row) ++g;            // the (non-empty) group that holds `row`
+            first[(size_t)t] = offs[g];
+        }
+        if ((rc = upload_small(ctx, dmap, first.data(), sizeof(int64_t) * first.size()))) return rc;
+        tc.ptr = dmap; tc.offs_id = ctx->offs_id; tc.n_groups = b->n_groups; tc.n_rows = N; tc.tile_rows = tile_rows;
+    }
+    *map = static_cast<const int64_t *>(dmap);
+    return POLS_OK;
+}
+
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o) {
     if (!p) return fail(POLS_ERR_INVALID, "params is NULL");
     const int64_t *d_offs = nullptr;
@@ -1865,6 +1891,15 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         c.brec_closed = reinterpret_cast<int32_t *>(base + 2 * b_rec + 2 * b_int + 2 * b_brec);
         c.n_tiles = n_packed ? n_packed : n_tiles; c.k = kf;
         c.all_closed = n_packed || max_rows <= tile_rows ? 1 : 0;   // (any tile_rows consecutive rows then hold a sequence start)
+        // A finite half-life bounds how far back a row's state reaches: with ff^H <= 2^-36 for H = 256 .. 2 048 rows (half_life <= 56.9) a tile
+        // re-accumulates its carry-in from the H rows in front of it -- one launch, no records, no scan over the tiles (k3c_scan.hip, step H).
+        // Null-free frames only (a masked row does not decay the state, so the distance to the tile is not the row distance);
+        // POLS_RLS_ENGINE=scan keeps the exact scan, which also serves half_life = None and the longer half-lives.
+        const int32_t halo = n_packed || st.valid || ctx->opt.rls_engine == 2 || kf > K3C_HALO_KMAX ? 0 : k3c_halo_batches(c.ff);
+        if (halo) {
+            if ((rc = ensure_tile_seq0(ctx, b, tile_rows, n_tiles, &c.tile_seq0))) return rc;
+            c.halo_batches = halo; c.log2ff = std::log2(c.ff); c.ffstep = std::pow(c.ff, (double)(tile_rows - 4));
+        }
         if ((rc = k3c_launch(ctx, b->dtype, c))) return rc;
     } else if (scan) {
         const int k = kf;

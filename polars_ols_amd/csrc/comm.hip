@@ -32,6 +32,10 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(NcclComm, int *) = nullptr;
+    int (*CommUserRank)(NcclComm, int *) = nullptr;
+    int (*CommCuDevice)(NcclComm, int *) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
 };
 
 static Rccl g_rccl;
@@ -55,6 +59,7 @@ static void rccl_bind() {
     BIND(CommDestroy, "ncclCommDestroy") BIND(AllGather, "ncclAllGather") BIND(Broadcast, "ncclBroadcast")
     BIND(Send, "ncclSend") BIND(Recv, "ncclRecv") BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
     BIND(GetErrorString, "ncclGetErrorString")
+    BIND(CommCount, "ncclCommCount") BIND(CommUserRank, "ncclCommUserRank") BIND(CommCuDevice, "ncclCommCuDevice") BIND(GetVersion, "ncclGetVersion")
 #undef BIND
     g_rccl = r;
 }
@@ -159,6 +164,20 @@ void pols_comm_destroy(pols_comm *comm) {
 
 int pols_comm_world_size(const pols_comm *comm) { return comm ? comm->world : -1; }
 int pols_comm_rank(const pols_comm *comm) { return comm ? comm->rank : -1; }
+
+int pols_comm_query(const pols_comm *comm, pols_comm_info *out) {
+    if (!comm || !out) return fail(POLS_ERR_INVALID, "comm / out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    int rc = rccl_ready();
+    if (rc) return rc;
+    int v = 0;
+    POLS_NCCL(g_rccl.CommCount(comm->comm, &v)); out->nranks_seen = v;
+    POLS_NCCL(g_rccl.CommUserRank(comm->comm, &v)); out->rank_seen = v;
+    POLS_NCCL(g_rccl.CommCuDevice(comm->comm, &v)); out->device = v;
+    POLS_NCCL(g_rccl.GetVersion(&v)); out->rccl_version = v;
+    POLS_HIP(hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), out->device));
+    return POLS_OK;
+}
 
 int pols_comm_group_begin(void) {
     int rc = rccl_ready();

@@ -91,8 +91,9 @@ struct pols_ctx {
     // [7] status words, [8] K3c tile / block records, [9] group-key ingestion (K9), [10] chunk / group tables of the dynamic kernels
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
-    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..22] row compaction of the rolling entry (columns, coefficients, start bytes, tile map), [23] segment tables + partial Gram matrices of the streamed static path
-    pols::Scratch scratch[25];
+    // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..22] row compaction of the rolling entry (columns, coefficients, start bytes, tile map), [23] segment tables + partial Gram matrices of the streamed static path,
+    // [24] group lists of the size classes, [25] K3c halo form: first row of the sequence in front of every tile
+    pols::Scratch scratch[26];
     pols::Options opt;
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
@@ -131,6 +132,8 @@ struct pols_ctx {
     // K3c (k3c_scan.hip), scratch slot 18: first row of every PACKED tile (tiles cut at sequence starts, single-pass mode); n_tiles 0 =
     // this frame does not pack (a sequence longer than a tile, or tiles too empty)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, tile_rows = 0, n_tiles = 0; } k3c;
+    // K3c halo form, scratch slot 25: per tile the first row of the sequence that holds the row in front of it
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, tile_rows = 0; } k3h;
     // segment tables of the streamed static path (scratch slot 23: long groups cut into segments): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t cut[3] = {0, 0, 0}, n[4] = {0, 0, 0, 0}; int n_cut = 0;
              std::vector<int32_t> host_last; } class_cache;   // group lists of the size classes (slot 24; host_last: the last class' ids, for its segment tables)

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.hpp"
 
+#include <cmath>
+
 namespace pols {
 
 constexpr int K4_KMAX = 8;
@@ -110,7 +112,21 @@ struct K3cArgs {
                                        // loads from tile_row0[t] & ~3 on -- no carry-in, so one launch (pass 2 alone) does the frame
     unsigned long long *dbg;           // POLS_TIMELINE: 8 words per tile (s_memtime stamps of the tile's last wave) or nullptr
     int32_t k;
+    // HALO form (finite half-life, null-free frames, K3C_HALO_KMAX features): tile t's carry-in is re-accumulated from the 256 halo_batches rows in front of
+    // it -- one launch, no records.  tile_seq0[t]: first row of the sequence that holds row t * tile_rows - 1 (tile 0: 0); nullptr = the scan forms above.
+    const int64_t *tile_seq0;
+    int32_t halo_batches;              // 256-row batches: ff^(256 halo_batches) <= 2^-36
+    double log2ff, ffstep;             // log2(ff); ff^(256 waves - 4): a lane's runs of its wave's consecutive batches are 256 waves rows apart
 };
+constexpr int K3C_HALO_KMAX = 9;      // (one state component per lane in the cross-wave steps)
+constexpr int K3C_HALO_MAX_BATCHES = 8;
+// 256-row batches the halo form re-reads in front of every tile for this forgetting factor (0: it does not apply -- no / too long a half-life)
+inline int32_t k3c_halo_batches(double ff) {
+    if (!(ff > 0.0) || !(ff < 1.0)) return 0;
+    const double need = -36.0 / std::log2(ff);              // ff^need = 2^-36 = 1.5e-11
+    const int32_t nb = need <= 256.0 ? 1 : (int32_t)std::ceil(need / 256.0);
+    return nb <= K3C_HALO_MAX_BATCHES ? nb : 0;
+}
 int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a);
 int k3c_start_flags(pols_ctx *ctx, const int64_t *d_offs, int64_t n_groups, int64_t n_rows, uint8_t *start);
 

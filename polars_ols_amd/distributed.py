@@ -111,6 +111,50 @@ def create_comm(eng, group=None):
     return Comm(eng, world, rank, box[0])
 
 
+def collective_identity(comm=None, group=None) -> dict:
+    """Who took part in the collective, for a measurement line that has to prove it: ``nranks_seen`` and one entry per rank (rank,
+    device, PCI bus id) as the communicator's library reports them -- ``Comm.info()`` (RCCL behind the C-ABI) when ``comm`` is given,
+    else the ``torch.distributed`` group itself (the CPU twin the gloo tests run).  Collective: every rank of the group calls it."""
+    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_initialized() else (1, 0)
+    if comm is not None:
+        mine = comm.info()
+        backend = "rccl (pols_comm)"
+    else:
+        mine = {"nranks_seen": world, "rank_seen": rank, "device": -1, "pci_bus_id": "", "rccl_version": 0}
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+    table = [mine]
+    if world > 1:
+        table = [None] * world
+        dist.all_gather_object(table, mine, group=group)
+    seen = sorted({int(e["nranks_seen"]) for e in table})
+    return {"library": backend, "nranks_seen": seen[0] if len(seen) == 1 else seen, "rccl_version": int(mine["rccl_version"]),
+            "ranks": [{"rank": int(e["rank_seen"]), "device": int(e["device"]), "pci_bus_id": e["pci_bus_id"]} for e in table],
+            "distinct_devices": len({(e["device"], e["pci_bus_id"]) for e in table})}
+
+
+def check_gathered_table(gathered: torch.Tensor, local: torch.Tensor, counts: Sequence[int], group=None) -> dict:
+    """The re-assembled table against its parts: every rank's checksum of its own ``local`` rows (sum of the f64 bit patterns, exact) is
+    exchanged, and the root compares it with the checksum of that rank's slice of ``gathered`` -- the gathered table IS the concatenation
+    of the shards, in rank order.  Collective; returns {"ok": bool, "per_rank": [...]} on the ranks that hold ``gathered`` (None: {"ok": None})."""
+    def cks(t):
+        b = t.detach().contiguous().to(torch.float64).cpu().numpy().view(np.uint64)
+        return int(b.sum(dtype=np.uint64))                    # (wraps modulo 2^64: exact, order-independent)
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = cks(local)
+    sums = [mine]
+    if world > 1:
+        sums = [None] * world
+        dist.all_gather_object(sums, mine, group=group)
+    if gathered is None:
+        return {"ok": None, "per_rank": []}
+    lo, per = 0, []
+    for r in range(world):
+        per.append(cks(gathered[lo: lo + int(counts[r])]) == sums[r])
+        lo += int(counts[r])
+    return {"ok": bool(all(per)) and lo == gathered.shape[0], "per_rank": per}
+
+
 class CoefficientRing:
     """Fewer, larger collectives for the per-step coefficient tables (the one exchange step of the path): the tables of ``n_slots``
     consecutive steps are written into one ring buffer and ONE all-gather moves the whole ring -- a ring all-gather over

@@ -591,6 +591,13 @@ class Comm:
         except Exception:
             pass
 
+    def info(self) -> Dict:
+        """``pols_comm_query``: what RCCL itself reports for this communicator (rank count, rank, device, PCI bus id, version code)."""
+        ci = L.CommInfo()
+        L.check(self._lib.pols_comm_query(self._h, C.byref(ci)))
+        return {"nranks_seen": int(ci.nranks_seen), "rank_seen": int(ci.rank_seen), "device": int(ci.device),
+                "pci_bus_id": ci.pci_bus_id.decode(), "rccl_version": int(ci.rccl_version)}
+
     def _counts(self, counts):
         if len(counts) != self.world:
             raise ValueError("one count per rank")

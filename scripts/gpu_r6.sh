@@ -1,0 +1,65 @@
+#!/bin/bash
+# Round-6 GPU lease driver: ONE script, stages picked by name (scripts/gpu_r6.sh stage [stage ...]); outputs under gpurun_out/r6/.
+#   k3h      halo-form RLS: its parity tests, the cfg4 A/B against the scan (bench lines + timeline), rlsg for regressions
+#   tests    the whole GPU suite
+#   prof     rocprofv3 kernel stats + PMC traffic of the BASELINE configs (copied to profiles/ by hand afterwards)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; O=$R/gpurun_out/r6; mkdir -p $O
+TAG=r06
+bench() { # name, extra env..., -- args
+  local name=$1; shift
+  timeout 300 env "$@" 2>$O/$name.err > $O/$name.json; cut -c1-330 $O/$name.json; echo
+}
+pmc() { # cfg, env...
+  local cfg=$1; shift
+  ( cd /tmp && export TMPDIR=/tmp
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $O/pmc_${ctr}_$cfg; timeout 300 env "$@" rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_${ctr}_$cfg -o p -- python $R/bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_${ctr}_$cfg.err
+    f=$(find $O/pmc_${ctr}_$cfg -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python3 - "$f" $ctr <<'PY' | tee $O/${TAG}_pmc_${ctr}_$cfg.txt
+import csv,sys,collections
+acc=collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    k=r['Kernel_Name']
+    if r.get('Counter_Name')==sys.argv[2] and 'pols::' in k and 'probe' not in k and 'start_kernel' not in k:
+        acc[k[:100]].append(float(r['Counter_Value']))
+for k,v in acc.items(): print(sys.argv[2], 'dispatches', len(v), 'mean', sum(v)/len(v), 'kernel', k)
+PY
+    else tail -3 $O/pmc_${ctr}_$cfg.err; fi
+    rm -rf $O/pmc_${ctr}_$cfg
+  done )
+}
+kstats() { # cfg, env...
+  local cfg=$1; shift
+  ( cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/kt_$cfg; timeout 300 env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$cfg -o k -- python $R/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof_$cfg.json 2> $O/kt_$cfg.err
+  f=$(find $O/kt_$cfg -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_$cfg.csv && head -6 $O/${TAG}_kernel_stats_$cfg.csv | cut -c1-200
+  rm -rf $O/kt_$cfg )
+}
+for stage in "$@"; do
+case $stage in
+k3h)
+  echo "== halo-form RLS: parity"
+  timeout 1500 python -m pytest tests/test_k3_gpu.py -m gpu -x -q -k "halo or cfg4 or many_sequences or lookback or packed" 2>&1 | tail -15 | tee $O/${TAG}_pytest_k3h.txt
+  echo "== cfg4 A/B: halo (default) vs scan"
+  for i in 1 2 3; do
+    bench ${TAG}_bench_cfg4_halo_$i A=1 python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline
+    bench ${TAG}_bench_cfg4_scan_$i POLS_RLS_ENGINE=scan python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline
+  done
+  bench ${TAG}_bench_rlsg A=1 python bench.py --config rlsg --steps 20 --warmup 5 --no-cpu-baseline
+  echo "== timeline (halo)"
+  POLS_TIMELINE=1 timeout 120 python bench.py --config cfg4 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep -v amdgpu | tail -20 | tee $O/${TAG}_timeline_cfg4_halo.txt
+  kstats cfg4 A=1
+  pmc cfg4 A=1
+  ;;
+tests)
+  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_pytest_gpu.txt
+  ;;
+prof)
+  timeout 600 python bench.py 2> $O/bench.err > $O/${TAG}_bench.json; cut -c1-400 $O/${TAG}_bench.json
+  for cfg in cfg3 cfg4 cfg4r rlsg rlsgr cfg5; do bench ${TAG}_bench_$cfg A=1 python bench.py --config $cfg --steps 20 --warmup 5; done
+  for cfg in cfg2 cfg3 cfg4 cfg4r cfg5; do kstats $cfg A=1; pmc $cfg A=1; done
+  ;;
+*) echo "unknown stage $stage";;
+esac
+done
+ls $O | head -50

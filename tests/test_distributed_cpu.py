@@ -162,6 +162,61 @@ def test_bench_ring_logic_world2(steps):
     assert res[0] == res[1] == -(-steps // 4)
 
 
+def _identity_worker(rank, world, port, q):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    from polars_ols_amd.distributed import check_gathered_table, collective_identity, gather_coefficients, shard_for_rank
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ident = collective_identity(None)                              # the gloo twin: the group itself stands in for the communicator
+    _, _, offs = _frame()
+    sh = shard_for_rank(offs, world, rank)
+    g = sh.group_hi - sh.group_lo
+    local = torch.arange(g * 3, dtype=torch.float64).reshape(g, 3) + 1000.0 * rank
+    whole = gather_coefficients(local, sh)
+    good = check_gathered_table(whole, local, sh.group_counts)
+    broken = whole.clone()
+    broken[sh.group_counts[0]] += 1.0                              # first row of rank 1's slice
+    bad = check_gathered_table(broken, local, sh.group_counts)
+    q.put((rank, ident, good, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_identity_and_table_check_world2():
+    """What bench.py puts into config.collective for N > 1 (nranks_seen, one entry per rank) and the gathered-table-equals-concatenation
+    check, on the world-2 gloo twin: the fields are there, the rank count is the group's, a corrupted slice is pinned to its rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_identity_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda e: e[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ident, good, bad in res:
+        assert ident["nranks_seen"] == 2 and ident["library"] == "gloo"
+        assert [e["rank"] for e in ident["ranks"]] == [0, 1]
+        assert set(ident["ranks"][0]) == {"rank", "device", "pci_bus_id"} and "rccl_version" in ident and "distinct_devices" in ident
+        assert good == {"ok": True, "per_rank": [True, True]}
+        assert bad == {"ok": False, "per_rank": [True, False]}
+
+
+def test_collective_identity_single_process():
+    from polars_ols_amd.distributed import check_gathered_table, collective_identity
+
+    ident = collective_identity(None)
+    assert ident["nranks_seen"] == 1 and len(ident["ranks"]) == 1
+    t = torch.arange(12, dtype=torch.float64).reshape(4, 3)
+    assert check_gathered_table(t, t, [4])["ok"] is True
+    assert check_gathered_table(None, t, [4])["ok"] is None
+
+
 def test_native_partition_matches_python():
     """pols_partition_groups (the C-ABI's partitioner, what a non-Python host calls) == distributed.partition_groups."""
     from polars_ols_amd.engine import partition_groups_native

@@ -161,6 +161,91 @@ def test_rls_cfg4_full_size_single_sequence(eng, rls_engine):
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
 
 
+def test_rls_cfg4_full_size_default_route_is_the_halo_form(eng):
+    """BASELINE configs[3] on the DEFAULT route: half_life = 21 gives ff^768 = 2^-36.6, so every tile re-accumulates its carry-in from the
+    768 rows in front of it (k3c_scan.hip step H: one launch, no tile records) -- every row of the 1 000 000 against the sequential oracle
+    at north_star's 1e-6, and against the exact scan (POLS_RLS_ENGINE=scan) far inside it."""
+    from oracle import orc
+
+    rng = np.random.default_rng(4)
+    n, k = 1_000_000, 6
+    cols = [rng.standard_normal(n) for _ in range(k)]
+    y = sum(cols) + 0.1 * rng.standard_normal(n)
+    dy, dc = _cuda(y), [_cuda(c) for c in cols]
+    out = eng.recursive_least_squares(dy, dc, [0, n], half_life=21.0, null_free=True)
+    assert eng.last_kernel == "k3s_rls_rows_halo_f64"
+    ref = orc.batched_rls(y, cols, [0, n], half_life=21.0)
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
+    eng.set_option("RLS_ENGINE", "scan")
+    try:
+        ex = eng.recursive_least_squares(dy, dc, [0, n], half_life=21.0, null_free=True)
+        assert eng.last_kernel == "k3s_rls_rows_f64"
+    finally:
+        eng.set_option("RLS_ENGINE", None)
+    # what the halo drops is 2^-36.6 = 1e-11 of the state 768 rows back
+    assert float(np.abs(_np(out["coef"]) - _np(ex["coef"])).max()) < 1e-9
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k", [1, 3, 6, 7, 9, 10])
+@pytest.mark.parametrize("half_life,halo", [(5.0, True), (21.0, True), (21.5, True), (43.0, True), (56.5, True), (57.0, False), (252.0, False), (None, False)])
+def test_rls_halo_route_boundary(eng, dtype, tol, k, half_life, halo):
+    """The halo form's route: taken iff ff^H <= 2^-36 for some H = 256 .. 2 048 rows (half_life <= 56.9: 5 -> 256 rows, 21 -> 768, 21.5 -> 1 024,
+    43 -> 1 792, 56.5 -> 2 048), on null-free frames with a sequence longer than a tile, up to 9 features; half_life = None / longer half-lives keep the scan.  Frame: sequences of 1 row to
+    20 000 rows, several starting exactly on tile boundaries, one straddling four tiles; a diffuse prior with a mean (the prior's own decay
+    up to a tile is exact: first row of the sequence from the per-tile table) -- every row against the oracle."""
+    from oracle import orc
+
+    rng = np.random.default_rng(31 * k + int(half_life or 0))
+    sizes = np.array([20_000, 1, 3, 1020, 1024, 2048, 5, 4099, 700, 2, 3500, 1024 * 3 - 7, 7, 9000], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    N = int(offs[-1])
+    cols = [rng.standard_normal(N).astype(dtype) for _ in range(k)]
+    y = (sum(cols).astype(np.float64) + 0.1 * rng.standard_normal(N)).astype(dtype)
+    mean0 = [0.25] * k
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, half_life=half_life, initial_state_covariance=1e3,
+                                      initial_state_mean=mean0, null_free=True)
+    name = eng.last_kernel
+    assert name.startswith("k3s_rls_rows")
+    assert ("halo" in name) == (halo and k <= 9), (name, half_life, k)
+    ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=1e3, initial_state_mean=mean0)
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
+
+
+def test_rls_halo_prior_decay_is_exact_on_small_features(eng):
+    """Returns-sized features (sigma = 1e-4) under the default prior (p0 = 10): the prior 1 / p0 outweighs the data sums (~30 sigma^2 = 3e-7) by
+    five orders of magnitude for hundreds of rows and fades as ff^t -- the halo form carries that term in closed form from the sequence's
+    first row, so the coefficients follow the oracle through the whole fade-out (tiles 1 .. 3 of the long sequence are the test)."""
+    from oracle import orc
+
+    rng = np.random.default_rng(8)
+    n, k = 6_000, 4
+    cols = [1e-4 * rng.standard_normal(n) for _ in range(k)]
+    y = sum(cols) + 1e-5 * rng.standard_normal(n)
+    offs = np.array([0, 37, 37 + n - 37], dtype=np.int64)
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, half_life=10.0, null_free=True)
+    assert eng.last_kernel == "k3s_rls_rows_halo_f64"
+    ref = orc.batched_rls(y, cols, offs, half_life=10.0)
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-9), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
+
+
+def test_rls_halo_not_taken_with_validity_bytes(eng):
+    """A masked row does not decay the state (least_squares.rs:589-591 updates on valid rows only), so the distance to the tile is not the row distance: masked frames keep the scan."""
+    from oracle import orc
+
+    rng = np.random.default_rng(9)
+    n, k = 5_000, 3
+    cols = [rng.standard_normal(n) for _ in range(k)]
+    y = sum(cols) + 0.1 * rng.standard_normal(n)
+    valid = (rng.random(n) > 0.2).astype(np.uint8)
+    out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], [0, n], valid=_cuda(valid), half_life=5.0)
+    assert eng.last_kernel == "k3s_rls_rows_f64"
+    ref = orc.batched_rls(y, cols, [0, n], half_life=5.0, is_valid=valid)
+    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6)
+
+
 def test_rls_many_sequences_full_size(eng):
     """The dynamic models the way the reference is used (README.md:119-137, `.rls(...).over("group")`), bench.py --config rlsg:
     10 000 sequences x 1 000 rows x 6 features, half_life = 21, f64 -- sampled sequences against the oracle, every row of them."""
