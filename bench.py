@@ -330,6 +330,11 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if args.mem == "host" and (world > 1 or args.config not in ("cfg1", "cfg2", "cfg3")):
         raise SystemExit("--mem host: cfg1 / cfg2 / cfg3 on one GPU")
+    # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 on their own (RCCL prints a version banner
+    # when a communicator is created) are pointed at stderr for the whole run; the line goes out through the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     force_collective = os.environ.get("POLS_BENCH_FORCE_COLLECTIVE") == "1"   # exercises the N > 1 code path on one GPU
@@ -613,7 +618,8 @@ def main() -> None:
                                         "from HBM-bound it is")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.config)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

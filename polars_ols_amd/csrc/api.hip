@@ -193,6 +193,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K2_NOPREFETCH")) o.k2_noprefetch = on;
     else if (ieq(key, "NO_SPLIT")) o.no_split = on;
     else if (ieq(key, "K1_PASSES")) o.k1_passes = on ? std::atoi(v) : d.k1_passes;
+    else if (ieq(key, "K1_WG")) o.k1_wg = on ? std::atoi(v) : d.k1_wg;
     else if (ieq(key, "K1T_RC4")) o.k1t_rc4 = on ? (std::atoi(v) != 0) : d.k1t_rc4;
     else if (ieq(key, "K1T_SUB8")) o.k1t_sub8 = on ? std::atoi(v) : d.k1t_sub8;
     else if (ieq(key, "K1_NT_LOADS")) o.k1_nt_loads = on ? (std::atoi(v) != 0) : d.k1_nt_loads;
@@ -215,7 +216,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
-                                       "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
+                                       "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1_WG", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
                                        "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE", "KG_SINGLE_BUFFER", "PREDICT_LOOP", "NO_CLASSES"};
     char name[64];
@@ -839,12 +840,13 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
                                                       : std::max<int64_t>(4096, ((b->n_rows / std::max<int64_t>(1, 8 * (int64_t)ctx->num_cus) + 1023) / 1024) * 1024);
     if (!ids && (!(max_rows > 2 * seg_target) || ctx->opt.no_split)) return POLS_OK;
     const int64_t n_items = ids ? (int64_t)ids->size() : b->n_groups;
-    auto &sc = ctx->seg_cache;
+    auto &sc = ctx->seg_cache[ids ? 1 : 0];               // (class tables have their own slot: they no longer evict the whole-frame tables)
+    const int slot = ids ? 26 : 23;
     int rc;
     // (the key is the frame; the per-segment extra area only has to be large enough -- its users differ in what they keep there: the Gram
     // partials of ls_core, the moments of the statistics entry, nothing for pols_predict -- and it is kept at the largest size asked for,
     // so that alternating users of one frame stop rebuilding and re-uploading the tables)
-    const bool same_frame = sc.ptr && sc.ptr == ctx->scratch[23].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups && sc.n_rows == b->n_rows &&
+    const bool same_frame = sc.ptr && sc.ptr == ctx->scratch[slot].ptr && sc.offs_id == ctx->offs_id && sc.n_groups == b->n_groups && sc.n_rows == b->n_rows &&
                             sc.seg_target == seg_target && sc.class_key == class_key && sc.n_items == n_items;
     const bool hit = same_frame && sc.nz2 >= extra_per_seg;
     auto lay = [&](char *sb, int64_t n_seg) {
@@ -857,7 +859,7 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
         t->n_seg = n_seg;
         return b_so + b_sm + b_sf;
     };
-    if (hit) { lay(static_cast<char *>(ctx->scratch[23].ptr), sc.n_seg); t->max_len = sc.max_len; t->max_seg = sc.max_seg; return POLS_OK; }
+    if (hit) { lay(static_cast<char *>(ctx->scratch[slot].ptr), sc.n_seg); t->max_len = sc.max_len; t->max_seg = sc.max_seg; return POLS_OK; }
     if (same_frame) extra_per_seg = std::max<size_t>(extra_per_seg, sc.nz2);
     sc.ptr = nullptr;
     std::vector<int64_t> so;
@@ -884,7 +886,7 @@ static int ensure_segments(pols_ctx *ctx, const pols_batch *b, int64_t max_rows,
     const int64_t n_seg = (int64_t)sm.size();
     const size_t tabs = round256(sizeof(int64_t) * so.size()) + round256(sizeof(int32_t) * sm.size()) + round256(sizeof(int32_t) * sf.size());
     void *ds = nullptr;
-    if ((rc = ensure_scratch(ctx, 23, tabs + round256(extra_per_seg * (size_t)n_seg), &ds))) return rc;
+    if ((rc = ensure_scratch(ctx, slot, tabs + round256(extra_per_seg * (size_t)n_seg), &ds))) return rc;
     char *sb = static_cast<char *>(ds);
     lay(sb, n_seg);
     if ((rc = upload_small(ctx, const_cast<int64_t *>(t->offs), so.data(), sizeof(int64_t) * so.size()))) return rc;
@@ -1607,7 +1609,24 @@ int pols_least_squares_statistics(pols_ctx *ctx, const pols_batch *b, const pols
         ga.offs = info.d_offs; ga.n_groups = b->n_groups; ga.n_rows = b->n_rows;
         ga.gram = static_cast<double *>(gs);
         ga.k_user = b->n_features; ga.kt = kt;
-        if ((rc = gram_stream_launch(ctx, b->dtype, ga))) return rc;
+        // long groups (the size-class + streamed route of ls_core keeps no per-group Gram matrices): the segment split of the streamed path
+        // here too -- an unsplit launch is one workgroup per group, i.e. ONE CU for a multi-million-row group
+        SegTables sgg;
+        if ((rc = ensure_segments(ctx, b, ctx->offs_max_rows, sizeof(double) * (nz * nz + 1), &sgg))) return rc;
+        if (sgg.n_seg > 0) {
+            const int n_slices = (sgg.max_seg >= 256 && G <= 256) ? 16 : 1;
+            void *sl = nullptr;
+            if (n_slices > 1 && (rc = ensure_scratch(ctx, 3, round256(sizeof(double) * nz * nz * (size_t)n_slices * G), &sl))) return rc;   // (slot 3: the fix-up work area, idle here)
+            ga.offs = sgg.offs; ga.n_groups = sgg.n_seg; ga.gram = reinterpret_cast<double *>(sgg.extra);
+            if ((rc = gram_stream_launch(ctx, b->dtype, ga))) return rc;
+            GramReduceArgs ra;
+            std::memset(&ra, 0, sizeof(ra));
+            ra.part = ga.gram; ra.first = sgg.first; ra.gram = static_cast<double *>(gs); ra.n_groups = b->n_groups; ra.nz2 = (int32_t)(nz * nz);
+            ra.max_segments = (int32_t)std::min<int64_t>(1 << 30, sgg.max_seg);
+            if (n_slices > 1) { ra.slices = static_cast<double *>(sl); ra.n_slices = n_slices; }
+            if ((rc = gram_reduce_launch(ctx, ra))) return rc;
+            ga.gram = static_cast<double *>(gs);
+        } else if ((rc = gram_stream_launch(ctx, b->dtype, ga))) return rc;
         gram = ga.gram;
     }
     StatsArgs sa;
@@ -2222,6 +2241,70 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
         if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
         return unstage_outputs(ctx, b, b->n_rows, k, o, st);
+    }
+    // The FIXED window over rows ("drop_window", the RollingKwargs default, ls.rs:987-1029) on a frame WITH nulls, up to 10 features: the
+    // tile kernel with every invalid row a zero row (k4c_kernel.inl, MASKED) -- all rows solved from S_i = E(i) - E(i - window) -- behind a
+    // per-row table of which rows the reference solves (dyn_prep.hip: NaN before the warm-up row, the last solved row's coefficients where the
+    // n_valid_window gate is closed), applied by a fill pass.  One case stays with the chunk kernels: a sequence in which a valid row is
+    // older than the window when its warm-up ends is never subtracted by the reference (:989) -- the device flags it, the host reads the flag.
+    bool tiles_m = !drop && st.valid != nullptr && ds.tables.valid != nullptr && ds.tables.mem == POLS_MEM_DEVICE && k <= K4C_KMAX && mp <= w &&
+                   ctx->opt.rolling_engine != 1 && ctx->opt.rolling_engine != 3 && b->n_rows >= 8 && aligned16(st.y) && (!st.coef || aligned16(st.coef)) &&
+                   (!st.pred || aligned16(st.pred)) && (reinterpret_cast<uintptr_t>(st.valid) & 3) == 0;
+    for (int j = 0; j < k && tiles_m; ++j) tiles_m = aligned16(st.x[j]);
+    if (tiles_m) {
+        const int64_t *pmap = nullptr;
+        int64_t n_pk = 0;
+        if (ctx->opt.rolling_engine != 2 && (rc = ensure_packed_tiles(ctx, b, K4C_PACKED_ROWS, max_rows, &pmap, &n_pk))) return rc;
+        if (!pmap && w > k4c_max_window(k)) tiles_m = false;
+        if (tiles_m) {
+            const int64_t N = b->n_rows, G = b->n_groups, n_slabs = (N + 255) / 256;
+            const size_t b_row = round256(sizeof(int32_t) * (size_t)N), b_sc = round256(sizeof(uint32_t) * (size_t)n_slabs),
+                         b_s8 = round256(sizeof(int64_t) * (size_t)(n_slabs + 1)), b_g8 = round256(sizeof(int64_t) * (size_t)(G + 1)),
+                         b_g4 = round256(sizeof(int32_t) * (size_t)G);
+            void *d = nullptr;
+            if ((rc = ensure_scratch(ctx, 19, 256 + 3 * b_row + b_sc + 3 * b_s8 + 2 * b_g8 + b_g4, &d))) return rc;   // (slot 19: the compaction's, never live here)
+            char *q = static_cast<char *>(d);
+            RowCompactArgs ra;
+            std::memset(&ra, 0, sizeof(ra));
+            RollMaskArgs ma;
+            std::memset(&ma, 0, sizeof(ma));
+            ma.flag = reinterpret_cast<int32_t *>(q); q += 256;
+            ma.cnt = reinterpret_cast<int32_t *>(q); q += b_row;
+            ma.vidx = reinterpret_cast<int32_t *>(q); q += b_row;
+            ma.code = reinterpret_cast<int32_t *>(q); q += b_row;
+            ra.slab_cnt = reinterpret_cast<uint32_t *>(q); q += b_sc;
+            ra.slab_base = reinterpret_cast<int64_t *>(q); q += b_s8;
+            ma.slab_last = reinterpret_cast<int64_t *>(q); q += b_s8;
+            ma.slab_carry = reinterpret_cast<int64_t *>(q); q += b_s8;
+            ra.c_offs = reinterpret_cast<int64_t *>(q); q += b_g8;
+            ma.g_mpv = reinterpret_cast<int64_t *>(q); q += b_g8;
+            ma.g_gate = reinterpret_cast<int32_t *>(q); q += b_g4;
+            ra.valid = st.valid; ra.offs = d_offs; ra.n_rows = N; ra.n_groups = G; ra.n_slabs = n_slabs;
+            if ((rc = row_compact_offsets_launch(ctx, ra))) return rc;
+            ma.valid = st.valid; ma.offs = d_offs; ma.n_rows = N; ma.n_groups = G; ma.n_slabs = n_slabs;
+            ma.slab_base = ra.slab_base; ma.c_offs = ra.c_offs; ma.window = w; ma.min_periods = mp;
+            if ((rc = roll_mask_tables_launch(ctx, ma))) return rc;
+            int32_t flag = 0;
+            POLS_HIP(hipMemcpyAsync(&flag, ma.flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+            POLS_HIP(hipStreamSynchronize(ctx->stream));       // the host decides which kernel runs
+            if (flag == 0) {
+                if ((rc = roll_mask_rows_launch(ctx, ma))) return rc;
+                K4cArgs c;
+                std::memset(&c, 0, sizeof(c));
+                if ((rc = ensure_start_flags(ctx, d_offs, b->n_groups, b->n_rows, &c.start))) return rc;
+                c.y = st.y; c.valid = st.valid;
+                for (int j = 0; j < k; ++j) { c.x[j] = st.x[j]; ma.x[j] = st.x[j]; }
+                c.n_rows = N; c.coef = st.coef; c.pred = st.pred;
+                c.window = pmap ? std::min<int64_t>(w, 2 * K4C_PACKED_ROWS) : w;
+                c.min_periods = std::min<int64_t>(mp, c.window); c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
+                c.tile_row0 = pmap; c.n_packed = n_pk;
+                if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
+                ma.coef = st.coef; ma.pred = st.pred; ma.k = k;
+                if ((rc = roll_mask_fill_launch(ctx, b->dtype, ma))) return rc;
+                if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+                return unstage_outputs(ctx, b, b->n_rows, k, o, st);
+            }
+        }
     }
     K4Args a;
     std::memset(&a, 0, sizeof(a));

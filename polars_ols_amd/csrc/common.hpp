@@ -72,6 +72,7 @@ struct Options {
     bool k1_rc2_wide = true;      // POLS_K1_RC2_WIDE    9-10 columns: K1's two- / four-chunk team beyond 1 024 rows instead of K1m / K2 (0: the round-4 rule, A/B)
     int seg_target = 0;           // POLS_SEG_TARGET     streamed static path: rows per segment of a cut group (0: the default rule)
     int k4p_lps = 0;              // POLS_K4P_LPS        K4p / K3p (k4p_wide.hip): lanes per sequence, 0 auto, 64 / 16 (up to 16 features) / 32 (17..32, RLS)
+    int k1_wg = 0;                // POLS_K1_WG          8-column team kernels: 2 / 4 = 512- / 1 024-thread workgroups (2 / 4 times the groups per workgroup, A/B)
     int k1_xcd = 0;               // POLS_K1_XCD         resident K1 kernels: 1 = XCD-contiguous workgroup -> group map (each XCD walks one eighth of the frame)
 };
 void options_from_env(Options &o);
@@ -92,8 +93,8 @@ struct pols_ctx {
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
     // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..22] row compaction of the rolling entry (columns, coefficients, start bytes, tile map), [23] segment tables + partial Gram matrices of the streamed static path,
-    // [24] group lists of the size classes, [25] K3c halo form: first row of the sequence in front of every tile
-    pols::Scratch scratch[26];
+    // [24] group lists of the size classes, [25] K3c halo form: first row of the sequence in front of every tile, [26] segment tables of the last size class
+    pols::Scratch scratch[27];
     pols::Options opt;
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
@@ -137,7 +138,7 @@ struct pols_ctx {
     // segment tables of the streamed static path (scratch slot 23: long groups cut into segments): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t cut[3] = {0, 0, 0}, n[4] = {0, 0, 0, 0}; int n_cut = 0;
              std::vector<int32_t> host_last; } class_cache;   // group lists of the size classes (slot 24; host_last: the last class' ids, for its segment tables)
-    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0, class_key = 0, n_items = 0; size_t nz2 = 0; bool nulls = false; } seg_cache;
+    struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0, class_key = 0, n_items = 0; size_t nz2 = 0; bool nulls = false; } seg_cache[2];   // [0] whole-frame tables (slot 23), [1] the last size class' tables (slot 26)
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };

@@ -353,6 +353,148 @@ int valid_tables_launch(pols_ctx *ctx, const ValidTablesArgs &a) {
     return POLS_OK;
 }
 
+// ---------------------------------------------------------------- per-row solve table of the masked tile kernel ("drop_window" with nulls, K4c)
+// Which rows does solve_rolling_ols solve under the fixed window (ls.rs:987-1029)?  Row i of a sequence is NaN before the warm-up row
+// mpv - 1 (:864, :939-943), solved when it is that row or its window holds gate_n valid rows (n_valid_window >= n_valid, :1013 / :1022:
+// the valid rows among (i - window, i], from row 1 on while i < window -- the saturating_sub of :990), and repeats the last solved
+// row's coefficients otherwise.  All of it is a function of the validity bytes: rm_groups_kernel derives the per-sequence constants,
+// rm_rows_kernel marks every row and finds the last solved row inside its 256-row slab, rm_carry_kernel carries it across slabs.
+__global__ void __launch_bounds__(256) rm_groups_kernel(const RollMaskArgs a) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.n_groups) return;
+    const int64_t s = a.offs[g], n = a.offs[g + 1] - s, tot = a.c_offs[g + 1] - a.c_offs[g], mp = a.min_periods;
+    // ls.rs:881-891: min_periods_valid = the row at which the min_periods-th valid observation arrives (else it stays min_periods)
+    int64_t mpv = tot >= mp ? (int64_t)a.vidx[s + mp - 1] + 1 : mp;
+    const int64_t gate = tot < mp ? tot : mp;
+    if (n < mp) mpv = n + 1;                                 // :893-900: every row NaN
+    a.g_mpv[g] = mpv;
+    a.g_gate[g] = (int32_t)gate;
+    // a valid row older than the window when the warm-up ends is never subtracted (the sliding loop starts at row mpv, :989): such a
+    // sequence is outside the tile kernel's prefix-difference form -- the caller routes the frame to the chunk kernels
+    const int64_t jm = mpv - a.window - 1;
+    if (n >= mp && jm >= 0 && jm < n && a.cnt[s + jm] > 0) atomicOr(a.flag, 1);
+}
+
+__global__ void __launch_bounds__(RC_SLAB) rm_rows_kernel(const RollMaskArgs a) {
+    __shared__ int wave_last[RC_SLAB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
+    const bool in = r < a.n_rows;
+    bool solved = false, nan = true;
+    if (in) {
+        int64_t lo = 0, hi = a.n_groups;                     // the group holding row r: the last g with offs[g] <= r
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.offs[mid] <= r) lo = mid; else hi = mid;
+        }
+        const int64_t s = a.offs[lo], i = r - s, mpv = a.g_mpv[lo], w = a.window;
+        if (i >= mpv - 1) {
+            nan = false;
+            const int64_t is = i >= w ? i - w : 0;
+            solved = (i == mpv - 1) || ((int64_t)a.cnt[r] - (int64_t)a.cnt[s + is] >= (int64_t)a.g_gate[lo]);
+        }
+    }
+    // the last solved row of the slab at or before this one: highest set bit of the wave's ballot below the lane, else an earlier wave's last
+    const unsigned long long bal = __ballot(solved);
+    if (lane == 0) wave_last[wave] = bal ? wave * 64 + (63 - __clzll(bal)) : -1;
+    __syncthreads();
+    const unsigned long long upto = bal & ((2ull << lane) - 1ull);
+    int loc = upto ? wave * 64 + (63 - __clzll(upto)) : -1;
+    for (int w2 = wave - 1; w2 >= 0 && loc < 0; --w2) loc = wave_last[w2];
+    if (in) a.code[r] = nan ? -1 : (loc >= 0 ? loc : RC_SLAB);   // -1: NaN row; 0 .. 255: the slab's row that was solved last; 256: before this slab
+    if (threadIdx.x == RC_SLAB - 1) a.slab_last[blockIdx.x] = loc >= 0 ? (int64_t)blockIdx.x * RC_SLAB + loc : -1;
+}
+
+__global__ void __launch_bounds__(1024) rm_carry_kernel(const RollMaskArgs a) {           // one workgroup: exclusive running maximum over the slabs
+    __shared__ long long part[1024 / 64];
+    __shared__ long long carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = -1;
+    __syncthreads();
+    for (int64_t s0 = 0; s0 < a.n_slabs; s0 += 1024) {
+        const int64_t s = s0 + threadIdx.x;
+        const long long v = s < a.n_slabs ? (long long)a.slab_last[s] : -1;
+        long long incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long up = __shfl_up(incl, off);
+            if (lane >= off) incl = incl > up ? incl : up;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        long long before = carry;
+        for (int w = 0; w < wave; ++w) before = before > part[w] ? before : part[w];
+        const long long excl_in_wave = __shfl_up(incl, 1);
+        long long excl = before;
+        if (lane > 0) excl = excl > excl_in_wave ? excl : excl_in_wave;
+        if (s < a.n_slabs) a.slab_carry[s] = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before > incl ? before : incl;
+        __syncthreads();
+    }
+}
+
+// The fill pass behind the masked tile kernel: a row the reference does not solve takes NaN (before the warm-up) or the coefficients of the
+// last solved row (a fixed point of this pass: solved rows are never written), and its prediction is recomputed from them.
+template <typename T>
+__global__ void __launch_bounds__(256) rm_fill_kernel(const RollMaskArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_rows) return;
+    const int code = a.code[r];
+    const int64_t slab0 = r & ~(int64_t)(RC_SLAB - 1);
+    if (code >= 0 && code < RC_SLAB && slab0 + code == r) return;      // solved here
+    const int k = a.k;
+    T *coef = static_cast<T *>(a.coef);
+    T *pred = static_cast<T *>(a.pred);
+    const T qnan = nan_if<T>(1u, T(0));
+    if (code < 0) {
+        if (coef) for (int j = 0; j < k; ++j) coef[r * k + j] = qnan;
+        if (pred) pred[r] = qnan;
+        return;
+    }
+    const int64_t src = code < RC_SLAB ? slab0 + code : a.slab_carry[r >> 8];
+    T p = T(0);
+    for (int j = 0; j < k; ++j) {
+        const T c = coef[src * k + j];
+        coef[r * k + j] = c;
+        T xv = static_cast<const T *>(a.x[j])[r];
+        if (!a.valid[r]) xv = T(0);                          // (an invalid row's prediction is masked by the caller's post pass; keep NaNs out of the sum)
+        p = fma(xv, c, p);
+    }
+    if (pred) pred[r] = p;
+}
+
+int roll_mask_tables_launch(pols_ctx *ctx, const RollMaskArgs &a) {
+    if (a.n_rows == 0 || a.n_groups == 0) return POLS_OK;
+    static_assert(RC_SLAB == 256, "rm_fill_kernel's slab arithmetic");
+    ValidTablesArgs va;
+    std::memset(&va, 0, sizeof(va));
+    va.valid = a.valid; va.offs = a.offs; va.n_rows = a.n_rows; va.n_groups = a.n_groups; va.n_slabs = a.n_slabs;
+    va.slab_base = a.slab_base; va.c_offs = a.c_offs; va.cnt = a.cnt; va.vidx = a.vidx;
+    POLS_HIP(hipMemsetAsync(a.vidx, 0xff, sizeof(int32_t) * (size_t)a.n_rows, ctx->stream));
+    POLS_HIP(hipMemsetAsync(a.flag, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(vt_rows_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, va);
+    hipLaunchKernelGGL(rm_groups_kernel, dim3((unsigned)((a.n_groups + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+int roll_mask_rows_launch(pols_ctx *ctx, const RollMaskArgs &a) {
+    if (a.n_rows == 0 || a.n_groups == 0) return POLS_OK;
+    hipLaunchKernelGGL(rm_rows_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rm_carry_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
+int roll_mask_fill_launch(pols_ctx *ctx, int dtype, const RollMaskArgs &a) {
+    if (a.n_rows == 0 || (!a.coef && !a.pred)) return POLS_OK;
+    const dim3 grid((unsigned)((a.n_rows + 255) / 256));
+    if (dtype == POLS_F32) hipLaunchKernelGGL(rm_fill_kernel<float>, grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(rm_fill_kernel<double>, grid, dim3(256), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+
 int row_compact_mask_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a) {
     if (a.n_rows == 0) return POLS_OK;
     if (dtype == POLS_F32) hipLaunchKernelGGL(rc_mask_kernel<float>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);

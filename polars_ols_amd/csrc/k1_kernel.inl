@@ -554,7 +554,7 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
 // zeroed in registers; stores of edge chunks guarded per row.  The general (FAST = false) code loads chunk by chunk inside per-lane
 // branches: with the same group sizes it runs 797 vs 679 us (130..252 rows) and 118 vs 91 us (100..300 rows) behind FAST.
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false, bool NT = false,
-          bool EDGE = false>
+          bool EDGE = false, int BLOCK = 256>
 __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
     static_assert(!EDGE || FAST, "EDGE refines FAST");
     // (tried: a PERSISTENT form of the 256-thread team -- one workgroup per resident slot walking the groups b, b + gridDim.x, ... --
@@ -651,7 +651,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
     // ---- team reduction, fixed order (deterministic): reduce-scatter inside each wave, partials through LDS
     constexpr int NACC4 = (NACC + 3) / 4;
     constexpr int SLOTS = NACC4 * 4;                         // accumulator slots, padded to a multiple of 4
-    __shared__ __attribute__((aligned(16))) T part[(256 / TEAM) * (SLOTS * WAVES + 32)];
+    __shared__ __attribute__((aligned(16))) T part[(BLOCK / TEAM) * (SLOTS * WAVES + 32)];
     T *mypart = part + (tix / TEAM) * (SLOTS * WAVES + 32);   // one region per team
     T *bcast = mypart + SLOTS * WAVES;                       // beta broadcast, 32 slots
     if constexpr (NPASS == 1) {
@@ -675,7 +675,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
     // SIMDs' VALU issue slots that co-resident workgroups need), beta goes back through LDS
     T beta[KT];
     if constexpr (NPASS > 1) {
-        constexpr int TEAMS = 256 / TEAM;                          // one scratch set per team of the block
+        constexpr int TEAMS = BLOCK / TEAM;                        // one scratch set per team of the block
         __shared__ T gsum_s[TEAMS][NACC + 3], lfac_s[TEAMS][KT * KT], lrinv_s[TEAMS][KT];
         T *gsum = gsum_s[tix / TEAM], *lfac = lfac_s[tix / TEAM], *lrinv = lrinv_s[tix / TEAM];
         if (wave == 0) {
@@ -776,6 +776,14 @@ template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS
           bool EDGE = false>
 __global__ void __launch_bounds__(256) k1_kernel(const K1Args a) {
     k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, NT, EDGE>(a, k1_block_id(a));
+}
+// SEVERAL teams per workgroup (POLS_K1_WG=2|4, A/B): BLOCK = 512 / 1 024 threads = 2 / 4 times the teams of the 256-thread block, i.e. four
+// consecutive groups of the headline shape per workgroup -- their 4 x 4 000-byte column slices are exactly 125 whole 128-byte lines,
+// and the teams meet at the workgroup's barriers, so their loads leave together and their stores leave together (the "16 KB pieces,
+// burst stores" cell of profiles/r05_probe_matrix.txt).  Same arithmetic, same outputs.
+template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS, bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k1_kernel_wg(const K1Args a) {
+    k1_body<T, KT, HAS_W, TEAM, RC, FAST, NPASS, false, NT, false, BLOCK>(a, k1_block_id(a));
 }
 // The same body held to 128 VGPRs (four waves per SIMD): the ragged one-chunk-per-lane wave kernel needs 130.
 template <typename T, int KT, bool HAS_W, int TEAM, int RC, bool FAST, int NPASS = 1, bool NULLS = false>
@@ -1329,7 +1337,11 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
                   HAS_W ? "_w" : "", TEAM, RC, FAST ? "_fast" : "", passes, NULLS ? "_nulls" : "");
     // (one team per workgroup -- a finished wave's slot refilled at once instead of waiting for its block-mates -- measured no
     // different: 74.4 vs 74.0 us on configs[1])
-    const int block_threads = 256;
+    // POLS_K1_WG=2|4: 512- / 1 024-thread workgroups of the 8-column team kernels (see k1_kernel_wg)
+    constexpr bool WG_OK = FAST && !NULLS && KT == 8 && ((sizeof(T) == 4 && TEAM == 256 && RC == 1 && (NPASS == 2 || NPASS == 3)) ||
+                                                          (sizeof(T) == 8 && TEAM == 128 && RC == 4 && NPASS == 2));
+    const int wg = WG_OK && (ctx->opt.k1_wg == 2 || ctx->opt.k1_wg == 4) && !ctx->opt.timeline ? ctx->opt.k1_wg : 1;
+    const int block_threads = 256 * wg;
     const int64_t teams_per_block = block_threads / TEAM;
     int64_t blocks = (a.n_groups + teams_per_block - 1) / teams_per_block;
     if (blocks > 0x7ffffff0LL) return fail(POLS_ERR_UNSUPPORTED, "too many groups for one launch");
@@ -1363,6 +1375,12 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
                             FAST && !NULLS;
     if constexpr (HAS_NT) {
         if (ctx->opt.k1_nt_loads != 0) { kern = k1_kernel<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS, true>; std::strcat(name, "_nt"); }
+    }
+    if constexpr (WG_OK) {
+        constexpr bool WNT = HAS_NT;                          // (the loads of the shipped build of this shape)
+        if (wg == 2) kern = k1_kernel_wg<T, KT, HAS_W, TEAM, RC, FAST, NPASS, WNT, 512>;
+        if (wg == 4) kern = k1_kernel_wg<T, KT, HAS_W, TEAM, RC, FAST, NPASS, WNT, 1024>;
+        if (wg > 1) { char sfx[16]; std::snprintf(sfx, sizeof(sfx), "_wg%d", wg); std::strcat(name, sfx); }
     }
     if constexpr (OCC4) {
         if (!ctx->opt.k1_noocc4) kern = k1_kernel_occ4<T, KT, HAS_W, TEAM, RC, FAST, NPASS, NULLS>;

@@ -562,20 +562,22 @@ static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
         if (rc) return rc;
         a.dbg = static_cast<unsigned long long *>(dbg);
     }
-    timing_begin(ctx);                                            // all launches of the call as one timed span
-    a.fold_top = (a.n_tiles + 63) / 64 <= 64 ? 1 : 0;             // (POLS_RLS_ENGINE is not consulted: both forms are the same arithmetic)
-    K3cArgs a1 = a;
-    a1.dbg = nullptr;
     if constexpr (K <= K3C_HALO_KMAX) {
         if (a.tile_seq0) {                                            // HALO form: one launch, the grid rounded up to whole XCD rounds
-            hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 2>), dim3((unsigned)(((a.n_tiles + 7) / 8) * 8)), dim3(64 * WAVES), 0, ctx->stream, a);
-            timing_end(ctx);
+            hipEvent_t e0, e1;
+            const bool timed = timing_pair(ctx, &e0, &e1);            // (one kernel: stamped by its own dispatch packet, the duration rocprofv3 reports)
+            hipExtLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 2>), dim3((unsigned)(((a.n_tiles + 7) / 8) * 8)), dim3(64 * WAVES), 0, ctx->stream,
+                                  timed ? e0 : nullptr, timed ? e1 : nullptr, 0, a);
             POLS_HIP(hipGetLastError());
             if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k3c_rls_rows_halo");
             return POLS_OK;
         }
     }
     if (a.tile_seq0) return fail(POLS_ERR_UNSUPPORTED, "rls (row-parallel, halo form): %d features > %d", K, K3C_HALO_KMAX);
+    timing_begin(ctx);                                            // all launches of the call as one timed span
+    a.fold_top = (a.n_tiles + 63) / 64 <= 64 ? 1 : 0;             // (POLS_RLS_ENGINE is not consulted: both forms are the same arithmetic)
+    K3cArgs a1 = a;
+    a1.dbg = nullptr;
     if (!a.tile_row0) hipLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 0>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, a1);
     if (!a.tile_row0 && !a.all_closed) {                                          // sequences longer than a tile: the records are scanned (two small launches)
         hipLaunchKernelGGL((k3c_block_scan_kernel<K4N<K>::N>), dim3((unsigned)((a.n_tiles + 63) / 64)), dim3(64), 0, ctx->stream, a1);

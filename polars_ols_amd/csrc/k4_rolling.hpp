@@ -137,6 +137,7 @@ struct K4cArgs {
     const void *y;
     const void *x[KC_KMAX];
     const uint8_t *start;              // 1 on the first row of every sequence (k3c_start_flags)
+    const uint8_t *valid;              // MASKED form ("drop_window" with nulls): validity bytes, 4-byte aligned; nullptr: every row valid
     int64_t n_rows, n_tiles;           // n_tiles is set by the launcher
     void *coef, *pred;                 // n_rows x k / n_rows, batch dtype, 16-byte aligned; either may be nullptr
     int64_t window, min_periods;       // 1 <= min_periods <= window <= K4C_MAX_WINDOW

@@ -1,355 +1,17 @@
-// k4c_rolling.hip -- K4c "rolling_window_tiles": rolling-window OLS for up to 6 features on null-free frames, ROW-PARALLEL, every
-// access a 16-byte one down the row axis, no cross-workgroup dependency.
-//
-// Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + the dynamic make_predictions (src/expressions.rs:184, 695-700) for
-// the frames where every row is valid (then the "drop" deque of :947-986 and the fixed window of :987-1029 are the same thing:
-// S_i = alpha I + sum of the last min(i + 1, window) rows' outer products, solved from row min_periods - 1 on) and
-// min_periods <= window <= 508.  Everything else -- validity masks, windows beyond the halo, the min_periods > window quirk --
-// stays with the lane-per-chunk kernels of k4_rolling.hip.
-//
-// Layout like K3c: the frame's rows [0, N), all sequences back to back, are cut into tiles of BW x 256 rows (BW body waves, a
-// lane owns 4 CONSECUTIVE rows); a sequence start resets the sums.  A window reaches at most `window` rows back, so a tile needs
-// nothing from its predecessors but their last HW x 256 > window rows: HW halo waves per workgroup re-read them (an L2 hit when
-// the neighbouring tile runs on the same XCD -- the tile -> workgroup map keeps consecutive tiles on one XCD), run the same
-// local sums and scan, and retire.  No look-back, no tickets, no inter-workgroup traffic.
-//   A  every lane sums its run: [x x' | x y] packed (NT values) + the row count since the last sequence start
-//   B  segmented inclusive scan (plain sums) over the lanes, wave totals through LDS: every run's EXCLUSIVE prefix -- the sums from
-//      the last sequence start (or the halo's first row) up to the run's first row -- goes to an LDS table, component-major
-//   D  body lanes: S before the run = E(own run) - E'(row i0 - window) when no sequence started within the last `window` rows, where
-//      E' is the table entry of the run holding that row plus the o = (-window) mod 4 rows in front of it; then per row
-//      S += entering row, S -= leaving row (the same add / subtract NonWoodburyState::update performs, :707-725), one K x K solve
-//      (L D L'; LU on a non-positive pivot, :732-734), coefficients and predictions stored 16 bytes at a time.
-// Bound: HBM, 8 (k + 1) bytes in + 8 (k + 1) bytes out per row (f64), plus the halo re-reads (HW / BW of the input, L2 hits mostly).
-#include "k4_rolling.hpp"
-#include "k4_small.inl"
-#include "dyn_out.inl"
-
-#include <algorithm>
+// k4c_rolling.hip -- K4c on null-free frames (kernel, interface and reference citations: k4c_kernel.inl); the masked form for frames with
+// validity bytes is instantiated in k4cm_rolling.hip.
+#include "k4c_kernel.inl"
 
 namespace pols {
 
-template <int NC>
-__device__ __forceinline__ void k4c_seg_scan_add(double (&Tv)[NC], const int h, const int lane) {
-    // inclusive segmented prefix SUM over the lanes: a partner p < lane is added iff no segment starts in (p, lane], i.e. h <= p
-    const int li = lane & 15;
-    constexpr int CH = NC < 12 ? NC : 12;
-#define K4C_STEP(CTRL, RM, OK)                                                                                  \
-    {                                                                                                           \
-        const bool ok_ = (OK);                                                                                  \
-        _Pragma("unroll") for (int q0 = 0; q0 < NC; q0 += CH) {                                                 \
-            double tp[CH];                                                                                      \
-            _Pragma("unroll") for (int q = 0; q < CH; ++q) tp[q] = dpp_get0<CTRL>(Tv[q0 + q < NC ? q0 + q : NC - 1]); \
-            if (ok_) {                                                                                          \
-                _Pragma("unroll") for (int q = 0; q < CH; ++q)                                                  \
-                    if (q0 + q < NC) Tv[q0 + q] += tp[q];                                                       \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-    K4C_STEP(0x111, 0xf, li >= 1 && h <= lane - 1)
-    K4C_STEP(0x112, 0xf, li >= 2 && h <= lane - 2)
-    K4C_STEP(0x114, 0xf, li >= 4 && h <= lane - 4)
-    K4C_STEP(0x118, 0xf, li >= 8 && h <= lane - 8)
-    K4C_STEP(0x142, 0xa, (lane & 16) && h <= (lane & ~15) - 1)
-    K4C_STEP(0x143, 0xc, lane >= 32 && h <= 31)
-#undef K4C_STEP
-}
-
-template <typename T, int K, int HW, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K4cArgs a) {
-    constexpr int BW = WAVES - HW, R = 4, RUNS = WAVES * 64;
-    constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NC = NT + 1;   // slot NT: rows since the last sequence start (or the halo's first row)
-    using V = typename Vec16<T>::type;
-    constexpr int VN = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *s_E = reinterpret_cast<double *>(smem);              // [NC][RUNS]: exclusive prefix of every run
-    // (the same region first holds the tile's rows -- 4 (K + 1) x RUNS values of the batch dtype -- for the hand-over of the leaving rows)
-    constexpr size_t TAB_B = sizeof(double) * NC * RUNS > sizeof(T) * 4 * (K + 1) * RUNS ? sizeof(double) * NC * RUNS : sizeof(T) * 4 * (K + 1) * RUNS;
-    double *s_agg = reinterpret_cast<double *>(smem + TAB_B);    // [WAVES][NC]: wave totals (from the wave's last sequence start on)
-    int *s_closed = reinterpret_cast<int *>(s_agg + WAVES * NC); // [WAVES]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#define K4C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    // consecutive tiles on one XCD (workgroup b runs on XCD b % 8): a tile's halo is its neighbour's body
-    const int64_t per_xcd = (a.n_tiles + 7) / 8;
-    const int64_t t = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (t >= a.n_tiles) return;
-    const int64_t N = a.n_rows, w = a.window;
-    // HW == 0: packed tiles -- the tile owns the whole sequences of rows [lo, hi) and starts at lo rounded down to a run
-    int64_t lo = 0, hi = N, hs = t * (BW * 256) - HW * 256;      // hs: the halo's first row (may be negative)
-    if constexpr (HW == 0) { lo = a.tile_row0[t]; hi = a.tile_row0[t + 1]; hs = lo & ~(int64_t)3; }
-    const int u = wv * 64 + lane;                                // this lane's run
-    const int64_t i0 = hs + (int64_t)u * R;
-    const bool inside = i0 >= 0 && i0 + R <= N;
-    K4C_STAMP(0);
-
-    // ---- A: the run's rows (rows outside the frame: zeros, no sequence start)
-    double x[R][K], y[R];
-    unsigned sbits = 0;
-    if (__all(inside)) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + i0);
-#pragma unroll
-            for (int i = 0; i < R / VN; ++i) {
-                const V v = p[i];                        // (not a streaming load: the rows come back as LEAVING rows, from L2)
-#pragma unroll
-                for (int e = 0; e < VN; ++e) x[i * VN + e][j] = (double)vget<T>(v, e);
-            }
-        }
-        const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.y) + i0);
-#pragma unroll
-        for (int i = 0; i < R / VN; ++i) {
-            const V v = p[i];
-#pragma unroll
-            for (int e = 0; e < VN; ++e) y[i * VN + e] = (double)vget<T>(v, e);
-        }
-        sbits = *reinterpret_cast<const unsigned *>(a.start + i0);
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t i = i0 + r;
-            const bool in = i >= 0 && i < N;
-            const int64_t ic = in ? i : 0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) x[r][j] = in ? (double)static_cast<const T *>(a.x[j])[ic] : 0.0;
-            y[r] = in ? (double)static_cast<const T *>(a.y)[ic] : 0.0;
-            if (in && a.start[ic]) sbits |= 1u << (8 * r);
-        }
-    }
-    const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
-    const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window
-    const int up = u - sh < 0 ? 0 : u - sh;                                    // table index: u - sh >= 0 for body lanes behind a halo (it covers `window`
-                                                                               // rows); packed tiles: a negative one is never looked up (use_ep below is false)
-    const int64_t rho_run = hs + (int64_t)(u - sh) * R;                        // first row of the run holding row i0 - window
-    auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
-        const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
-#pragma unroll
-        for (int j = 0; j < K; ++j) xr[j] = (double)static_cast<const T *>(a.x[j])[ic];
-        yr = (double)static_cast<const T *>(a.y)[ic];
-    };
-    // The LEAVING rows of a body lane's run -- rows i0 - window .. + 3: rows (o + r) of the runs u - sh and u - sh + 1 -- are rows other
-    // lanes of this workgroup have just loaded: they change hands through LDS (the region the prefix table takes over after the next
-    // barrier: [row of the run][column][run], batch dtype).  Loaded from global memory instead (round 4 until then: 16-byte loads, L2
-    // hits) they went through the CU's memory pipe a second time -- a third of the tile's traffic on the resource this kernel is bound
-    // by (10.5 bytes per clock per CU with them).
-    double xo[R][K], yo[R];
-    {
-        T *s_X = reinterpret_cast<T *>(smem);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int j = 0; j < K; ++j) s_X[(size_t)(r * (K + 1) + j) * RUNS + u] = (T)x[r][j];
-            s_X[(size_t)(r * (K + 1) + K) * RUNS + u] = (T)y[r];
-        }
-        __syncthreads();
-        if (wv >= HW) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                int g = (u - sh) * R + o + r;                                  // row index inside [halo | body]; negative: never used (the
-                g = g < 0 ? 0 : g;                                             // sequence then starts inside the tile, `sub` below stays false)
-                const int run = g >> 2, rr = g & 3;
-#pragma unroll
-                for (int j = 0; j < K; ++j) xo[r][j] = (double)s_X[(size_t)(rr * (K + 1) + j) * RUNS + run];
-                yo[r] = (double)s_X[(size_t)(rr * (K + 1) + K) * RUNS + run];
-            }
-        }
-    }
-    bool st[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) st[r] = ((sbits >> (8 * r)) & 0xffu) != 0;
-    auto add_row = [&](double (&S)[NC], const double (&xr)[K], double yr, double sign) {
-#pragma unroll
-        for (int p = 0; p < K; ++p) {
-#pragma unroll
-            for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = fma(sign * xr[p], xr[q], S[tri_index<K>(p, q)]);
-            S[NX + p] = fma(sign * xr[p], yr, S[NX + p]);
-        }
-    };
-    auto reset_if = [&](double (&S)[NC], bool cond, bool any) {   // the sums start over at a sequence start
-        if (any) {
-#pragma unroll
-            for (int q = 0; q < NC; ++q) S[q] = cond ? 0.0 : S[q];
-        }
-    };
-    double Tl[NC];
-    bool head = false;
-#pragma unroll
-    for (int q = 0; q < NC; ++q) Tl[q] = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        reset_if(Tl, st[r], __any(st[r]));
-        head = head || st[r];
-        add_row(Tl, x[r], y[r], 1.0);
-        Tl[NT] += 1.0;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    K4C_STAMP(1);
-
-    // ---- B: segmented inclusive prefix over the lanes, then over the waves; the exclusive prefixes go to the LDS table
-    const unsigned long long hmask = __ballot(head);
-    const unsigned long long upto = hmask & (~0ull >> (63 - lane));
-    const int h = upto ? 63 - __clzll(upto) : -1;
-    k4c_seg_scan_add<NC>(Tl, h, lane);
-    if (lane == 63) {
-#pragma unroll
-        for (int q = 0; q < NC; ++q) s_agg[wv * NC + q] = Tl[q];
-        s_closed[wv] = hmask != 0;
-    }
-    double ET[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) ET[q] = dpp_get0<0x138>(Tl[q]);                // wave_shr:1 -- the lane below's inclusive value
-    const bool eopen = (hmask & ((1ull << lane) - 1ull)) == 0;                // no sequence start in the lanes below
-    __syncthreads();
-    if (eopen) {                                                               // prepend the waves below, from their last sequence start
-#pragma unroll 1
-        for (int w2 = wv - 1; w2 >= 0; --w2) {
-#pragma unroll
-            for (int q = 0; q < NC; ++q) ET[q] += s_agg[w2 * NC + q];
-            if (s_closed[w2]) break;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NC; ++q) s_E[q * RUNS + u] = ET[q];
-    __syncthreads();
-    if (wv < HW) return;                                                       // halo waves are done
-    K4C_STAMP(2);
-
-    // ---- D: body lanes.  S before the run, then one add / subtract / solve per row.
-    double S[NC];
-    const double cnt_excl = ET[NT];                                            // rows since the last sequence start, before this run
-    // (exact when a sequence starts inside the tile or its halo; otherwise the rows since the halo's first row: >= 256 HW >= window + o + 1)
-    // The part of the prefix E(own run) that lies before row i0 - window goes: the table entry of the run holding that row when the
-    // sequence started before that run, and the rows of that run in front of row i0 - window that the sequence reaches back to.
-    const bool use_ep = cnt_excl >= (double)(w + o + 1);
-#pragma unroll
-    for (int q = 0; q < NC; ++q) S[q] = ET[q] - (use_ep ? s_E[q * RUNS + up] : 0.0);
-    double cnt = cnt_excl;
-    T *coef = static_cast<T *>(a.coef);
-    T *pred = static_cast<T *>(a.pred);
-    const T qnan = nan_if<T>(1u, T(0));
-#pragma unroll 1
-    for (int r = 0; r < o; ++r) {                                             // (window not a multiple of 4: up to 3 rows, one L2 round trip each)
-        const bool gone = cnt_excl >= (double)(w + o - r);                     // the sequence reaches back to row rho_run + r
-        if (__any(gone)) {
-            double xf[K], yf;
-            load_row(rho_run + r, xf, yf);
-            if (gone) add_row(S, xf, yf, -1.0);
-        }
-    }
-    K4C_STAMP(3);
-    // the prefix table has been read by every body lane: its LDS becomes the staging area of the outputs (dyn_out.inl) -- a row's
-    // coefficients and prediction wait there until the wave's 256 rows leave as whole lines
-    __syncthreads();                                                           // (the halo waves have retired: they no longer count)
-    T *stage = reinterpret_cast<T *>(smem) + (size_t)(wv - HW) * (R * (K + 1) * DYN_STAGE_STRIDE);
-    double beta[K];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (__any(st[r])) {
-#pragma unroll
-            for (int q = 0; q < NC; ++q) S[q] = st[r] ? 0.0 : S[q];
-            cnt = st[r] ? 0.0 : cnt;
-        }
-        add_row(S, x[r], y[r], 1.0);
-        cnt += 1.0;
-        const bool sub = cnt >= (double)(w + 1);                               // the window is full: row i - window leaves
-        if (__any(sub)) {
-            if (sub) add_row(S, xo[r], yo[r], -1.0);
-            cnt = sub ? (double)w : cnt;                                       // (rows in the window)
-        }
-        // Cholesky -> LU in the reference (:732-734).  A non-positive pivot here means a window without K independent rows (or one
-        // whose X'X is singular to working precision): the reference's LU then divides by a zero or noise pivot and returns
-        // inf / NaN / 1e15-sized numbers.  This kernel reports such rows as NaN -- no LU, hence no scratch memory in the launch;
-        // POLS_ROLLING_ENGINE=chunk has the LU.
-        const bool ok = ldl_solve_small<K, false>(S, a.alpha, beta);
-        const bool good = (cnt >= (double)a.min_periods || sub) && ok;         // row min_periods - 1 of the sequence and later
-        double pr = 0.0;
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            stage[(r * (K + 1) + j) * DYN_STAGE_STRIDE + lane] = good ? (T)beta[j] : qnan;
-            pr = fma(x[r][j], beta[j], pr);
-        }
-        stage[(r * (K + 1) + K) * DYN_STAGE_STRIDE + lane] = good ? (T)pr : qnan;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    {
-        const T none[4] = {};
-        dyn_wave_copy_out<T, K, K + 1>(stage, lane, hs + (int64_t)wv * 64 * R, hi, coef, pred, lo, none);
-    }
-    K4C_STAMP(4);
-    K4C_STAMP(5);
-    if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + 6] = 0;
-#undef K4C_STAMP
-}
-
-template <typename T, int K, int HW>
-static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
-    constexpr int NC = K4N<K>::N + 1;
-    // Waves per workgroup.  The prefix table is NC x 64 WAVES doubles of LDS (K = 6: 14 KiB per wave) and a lane holds its entering
-    // and leaving rows through the scan (229 VGPRs: two waves per SIMD).  One halo wave: FOUR waves, two workgroups per CU whose
-    // phases interleave (one streams rows in while the other walks) -- measured against one 8-wave workgroup, which repeats
-    // 1 / 7 instead of 1 / 3 of the rows: 1M rows 54.5 -> 43.5 us, 10 000 x 1 000 rows 390 -> 326 us.  Two halo waves: eight.
-    constexpr int WAVES = HW <= 1 ? 4 : 8;
-    K4cArgs a = a0;
-    const int64_t tile_rows = (int64_t)(WAVES - HW) * 256;
-    static_assert(HW != 0 || (WAVES - HW) * 256 == K4C_PACKED_ROWS, "the packed tile map is built for this tile");
-    a.n_tiles = HW == 0 ? a.n_packed : (a.n_rows + tile_rows - 1) / tile_rows;
-    const int64_t per_xcd = (a.n_tiles + 7) / 8;
-    const size_t tab = std::max(sizeof(double) * (size_t)NC * 64 * WAVES, sizeof(T) * (size_t)4 * (K + 1) * 64 * WAVES);   // the tile's rows, then the prefix table
-    const size_t lds = std::max(tab + sizeof(double) * WAVES * NC + 64,                                             // ... + wave totals
-                                (size_t)(WAVES - HW) * 4 * (K + 1) * DYN_STAGE_STRIDE * sizeof(T));              // ... reused as the output staging area
-    static OncePerDevice attr_once;
-    if (attr_once.needed(ctx->device)) {
-        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k4c_kernel<T, K, HW, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_once.done(ctx->device);
-    }
-    if (ctx->opt.timeline) {
-        void *dbg = nullptr;
-        int rc = ensure_scratch(ctx, 11, sizeof(unsigned long long) * 8 * (size_t)a.n_tiles, &dbg);
-        if (rc) return rc;
-        a.dbg = static_cast<unsigned long long *>(dbg);
-    }
-    hipEvent_t e0, e1;
-    const bool timed = timing_pair(ctx, &e0, &e1);
-    hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
-                          timed ? e1 : nullptr, 0, a);
-    POLS_HIP(hipGetLastError());
-    if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k4c_rolling_tiles");
-    return POLS_OK;
-}
-
-template <typename T, int K>
-static int k4c_launch_k(pols_ctx *ctx, const K4cArgs &a) {
-    if (a.tile_row0) return k4c_launch_h<T, K, 0>(ctx, a);                                      // packed tiles: no halo
-    if (a.window <= 252) return k4c_launch_h<T, K, 1>(ctx, a);                                  // 256 HW >= 4 ceil(window / 4) + 1
-    if constexpr (K <= 6) return k4c_launch_h<T, K, 2>(ctx, a);
-    // (7 / 8 features need more than 256 registers: one four-wave workgroup per CU; the eight-wave two-halo form would spill)
-    return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): window %lld with %d features needs packed tiles", (long long)a.window, K);
-}
-
-template <typename T>
-static int k4c_launch_t(pols_ctx *ctx, const K4cArgs &a) {
-    switch (a.k) {
-        case 1: return k4c_launch_k<T, 1>(ctx, a);
-        case 2: return k4c_launch_k<T, 2>(ctx, a);
-        case 3: return k4c_launch_k<T, 3>(ctx, a);
-        case 4: return k4c_launch_k<T, 4>(ctx, a);
-        case 5: return k4c_launch_k<T, 5>(ctx, a);
-        case 6: return k4c_launch_k<T, 6>(ctx, a);
-        case 7: return k4c_launch_k<T, 7>(ctx, a);
-        case 8: return k4c_launch_k<T, 8>(ctx, a);
-        case 9: return k4c_launch_k<T, 9>(ctx, a);
-        case 10: return k4c_launch_k<T, 10>(ctx, a);
-        default: return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): %d features > %d", a.k, K4C_KMAX);
-    }
-}
+int k4cm_launch(pols_ctx *ctx, int dtype, const K4cArgs &a);
 
 int k4c_launch(pols_ctx *ctx, int dtype, const K4cArgs &a) {
     if (a.window < 1 || (a.window > k4c_max_window(a.k) && !a.tile_row0) || a.min_periods < 1 || a.min_periods > a.window)
         return fail(POLS_ERR_INVALID, "k4c: window %lld / min_periods %lld outside the row-parallel kernel's range", (long long)a.window, (long long)a.min_periods);
+    if (a.valid) return k4cm_launch(ctx, dtype, a);
     ctx->last_kernel = dtype == POLS_F32 ? "k4_rolling_tiles_f32" : "k4_rolling_tiles_f64";
-    return dtype == POLS_F32 ? k4c_launch_t<float>(ctx, a) : k4c_launch_t<double>(ctx, a);
+    return dtype == POLS_F32 ? k4c_launch_t<float, false>(ctx, a) : k4c_launch_t<double, false>(ctx, a);
 }
 
 }  // namespace pols

@@ -10,9 +10,11 @@
 //
 // Here every lane loads 16-byte vectors (4 f32 / 2 f64 rows) of each column straight into registers -- 4 KB pieces per column per
 // workgroup step, nothing staged -- and accumulates the (kt + 1)(kt + 2) / 2 packed products of its own rows: 45 FMAs per row at 8
-// columns, 19 % of the vector pipe at the HBM rate.  The lanes' sums (f32 frames: at most a few dozen rows each, so the f32 partial
-// carries no visible error) are converted to f64, reduce-scattered over the wave, and added across the four waves in wave order:
-// the Gram matrix leaves in f64 in the layout gram_stream_kernel writes, for the same consumers (gram_reduce, gram_solve, gram_cd).
+// columns, 19 % of the vector pipe at the HBM rate.  The lanes' sums are converted to f64, reduce-scattered over the wave into the wave's
+// f64 totals in LDS, and added across the four waves in wave order: the Gram matrix leaves in f64 in the layout gram_stream_kernel writes,
+// for the same consumers (gram_reduce, gram_solve, gram_cd).  f32 frames: a lane's f32 partial is flushed into those f64 totals every
+// K5V_FLUSH_STEPS steps (128 of its rows) -- an item is as long as its group or segment, up to millions of rows in the statistics entry,
+// and the MFMA pass this kernel replaced flushed to f64 every 64 rows per wave: that flush is what holds the streamed f32 paths to 1e-4.
 #include "k5_enet.hpp"
 
 namespace pols {
@@ -44,7 +46,41 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
     const int pol = a.null_policy;
     int nfit = 0;                                            // NULLS: this lane's rows that take part in the fit
 
-    for (int64_t row0 = base + (int64_t)tid * VEC; row0 < e; row0 += 256 * VEC) {
+    // lanes -> wave: f64 reduce-scatter, 32 entries at a time (an f64 copy of all of them would double the registers at 11-16 columns), ADDED
+    // to the wave's totals in LDS (every entry has one owner lane: no race); acc starts over
+    constexpr int SL = 32, NSL = (NACC + SL - 1) / SL;
+    __shared__ double part[4][NSL * SL];
+    for (int q = lane; q < NSL * SL; q += 64) part[wave][q] = 0.0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+            double accd[SL];
+#pragma unroll
+            for (int q = 0; q < SL; ++q) accd[q] = (sl * SL + q < NACC) ? (double)acc[(sl * SL + q < NACC) ? sl * SL + q : 0] : 0.0;
+            double u[SL / 4];
+            wave_reduce_scatter<double, SL>(accd, u);       // u[i], in every lane of 16-lane row r: the wave total of entry 4 i + rs_perm(r) of the slice
+            if ((lane & 15) == 0) {
+                const int r = rs_perm(lane >> 4);
+#pragma unroll
+                for (int i = 0; i < SL / 4; ++i) part[wave][sl * SL + 4 * i + r] += u[i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc[q] = T(0);
+    };
+    constexpr int K5V_FLUSH_STEPS = 32;                      // f32: 32 steps x 4 rows per lane between flushes
+    int since = 0;
+
+    // (a counted loop, the same trip count in every lane: the flush is a cross-lane step and must meet the whole wave -- lanes past the
+    // item's last row skip the body and rejoin)
+    const int64_t n_steps = (e - base + 256 * VEC - 1) / (256 * VEC);
+    for (int64_t it = 0; it < n_steps; ++it) {
+        const int64_t row0 = base + (it * 256 + tid) * VEC;
+        if constexpr (sizeof(T) == 4) {
+            if (since == K5V_FLUSH_STEPS) { flush(); since = 0; }
+            ++since;
+        }
+        if (row0 >= e) continue;
         V z[NZ];
         if (row0 >= s && row0 + VEC <= e) {
 #pragma unroll
@@ -125,23 +161,7 @@ __global__ void __launch_bounds__(256) gram_valu_kernel(const GramArgs a) {
             }
     }
 
-    // ---- lanes -> wave (f64 reduce-scatter, 32 entries at a time: an f64 copy of all of them would double the registers at 11-16 columns) -> workgroup
-    // (LDS, wave order) -> the symmetric NZ x NZ matrix
-    constexpr int SL = 32, NSL = (NACC + SL - 1) / SL;
-    __shared__ double part[4][NSL * SL];
-#pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) {
-        double accd[SL];
-#pragma unroll
-        for (int q = 0; q < SL; ++q) accd[q] = (sl * SL + q < NACC) ? (double)acc[(sl * SL + q < NACC) ? sl * SL + q : 0] : 0.0;
-        double u[SL / 4];
-        wave_reduce_scatter<double, SL>(accd, u);           // u[i], in every lane of 16-lane row r: the wave total of entry 4 i + rs_perm(r) of the slice
-        if ((lane & 15) == 0) {
-            const int r = rs_perm(lane >> 4);
-#pragma unroll
-            for (int i = 0; i < SL / 4; ++i) part[wave][sl * SL + 4 * i + r] = u[i];
-        }
-    }
+    flush();
     __shared__ int nfit_s;
     if constexpr (NULLS) { if (tid == 0) nfit_s = 0; }
     __syncthreads();

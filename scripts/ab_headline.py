@@ -16,18 +16,44 @@ if os.environ.get("RAGGED"):                                  # RAGGED=lo,hi: un
     offs = np.concatenate([[0], np.cumsum(np.random.default_rng(0).integers(lo, hi + 1, size=G))]).astype(np.int64)
 N = int(offs[-1])
 g = torch.Generator(device="cuda").manual_seed(0)
-cols = [torch.randn(N, device="cuda", generator=g) for _ in range(k)]
-y = sum(cols) + 0.1 * torch.randn(N, device="cuda", generator=g)
-plan = eng.plan_least_squares(y, cols, offs, want=("pred", "coef"))
+F64 = os.environ.get("DTYPE") == "f64"                        # DTYPE=f64: cfg3's shape (f64, ridge alpha = 1, sample weights)
+dt = torch.float64 if F64 else torch.float32
+FRAMES = int(os.environ.get("FRAMES", "3"))                   # rotated frames: more input than the Infinity Cache holds, like bench.py
+plans = []
+out = None
+for f in range(FRAMES):
+    cols = [torch.randn(N, device="cuda", generator=g, dtype=dt) for _ in range(k)]
+    y = sum(cols) + 0.1 * torch.randn(N, device="cuda", generator=g, dtype=dt)
+    kw = dict(weights=torch.rand(N, device="cuda", generator=g, dtype=dt) + 0.5, alpha=1.0) if F64 else {}
+    p = eng.plan_least_squares(y, cols, offs, want=("pred", "coef"), **kw)
+    if out is None:
+        out = p.results
+    else:
+        for key in ("pred", "coef"):
+            p.set_output(key, out[key])
+    plans.append(p)
+
+
+class _Rot:
+    i = 0
+
+    def run(self):
+        plans[self.i % FRAMES].run()
+        self.i += 1
+
+
+plan = _Rot()
 variants = {"wave_rc4_nt": {"K1_SHAPE": "wave"}, "default": {}, "team256_rc1_nt": {"K1_SHAPE": "team"}, "team256_rc1_p2_nt": {"K1_SHAPE": "team", "K1_PASSES": "2"},
-            "team256_rc1_p2": {"K1_SHAPE": "team", "K1_PASSES": "2", "K1_NT_LOADS": "0"}, "team256_rc1_p3_nt": {"K1_SHAPE": "team", "K1_PASSES": "3"}}
+            "team256_rc1_p2": {"K1_SHAPE": "team", "K1_PASSES": "2", "K1_NT_LOADS": "0"}, "team256_rc1_p3_nt": {"K1_SHAPE": "team", "K1_PASSES": "3"},
+            # round 6: several teams per workgroup (k1_kernel_wg): 512 / 1 024 threads = 2 / 4 times the groups of the 256-thread block
+            "wg2": {"K1_WG": "2"}, "wg4": {"K1_WG": "4"}, "wg4_p3": {"K1_WG": "4", "K1_PASSES": "3"}, "wg2_p3": {"K1_WG": "2", "K1_PASSES": "3"}}
 if os.environ.get("ONLY"):
     variants = {k: v for k, v in variants.items() if k in os.environ["ONLY"].split(",")}
 res = {v: [] for v in variants}
 names = {}
 for rnd in range(12):
     for v, opts in variants.items():
-        for key in ("K1_SHAPE", "K1_PASSES", "K1_NT_LOADS"):
+        for key in ("K1_SHAPE", "K1_PASSES", "K1_NT_LOADS", "K1_WG"):
             eng.set_option(key, opts.get(key))
         for _ in range(5):
             plan.run()

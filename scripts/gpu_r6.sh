@@ -51,6 +51,30 @@ k3h)
   kstats cfg4 A=1
   pmc cfg4 A=1
   ;;
+k1wg)
+  echo "== headline A/B: teams per workgroup (scripts/ab_headline.py, three rotated frames)"
+  ONLY=default,wg2,wg4,wg4_p3,wg2_p3,team256_rc1_p3_nt timeout 600 python scripts/ab_headline.py 2>&1 | grep -v amdgpu | tee $O/${TAG}_ab_headline_wg.txt
+  echo "== cfg3 shape (f64, weights, ridge)"
+  DTYPE=f64 ONLY=default,wg2,wg4 timeout 600 python scripts/ab_headline.py 2>&1 | grep -v amdgpu | tee $O/${TAG}_ab_cfg3_wg.txt
+  echo "== parity of the wg builds (bit-identical outputs expected)"
+  timeout 300 python scripts/check_k1_wg.py 2>&1 | grep -v amdgpu | tee $O/${TAG}_check_k1_wg.txt
+  echo "== timeline of the headline kernel"
+  POLS_TIMELINE=1 timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep timeline | tail -3 | tee $O/${TAG}_timeline_cfg2.txt
+  echo "== SQ wait share: K1 and the stream probe in one trace"
+  ( cd /tmp && export TMPDIR=/tmp; rm -rf $O/pmc_sq; timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_sq.err
+    f=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python3 - "$f" <<'PY' | tee $O/${TAG}_pmc_sq_cfg2.txt
+import csv,sys,collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k=r['Kernel_Name']
+    if 'pols::' in k: acc[k[:90]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k,v in acc.items():
+    m={c: sum(x)/len(x) for c,x in v.items()}
+    print(k, {c: round(x) for c,x in m.items()}, 'wait share', round(m.get('SQ_WAIT_ANY',0)/max(1,m.get('SQ_WAVE_CYCLES',1)),3))
+PY
+    else tail -3 $O/pmc_sq.err; fi; rm -rf $O/pmc_sq )
+  ;;
 tests)
   timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_pytest_gpu.txt
   ;;

@@ -20,8 +20,8 @@ def _run(extra_env, *args):
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "12", "--warmup", "3", *args], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout       # ONE JSON line and nothing else (RCCL's banner goes to stderr)
     return json.loads(lines[0])
 
 
@@ -33,6 +33,9 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert "10000 groups x 1000 rows x 8 feats" in d["config"]["workload"] and d["config"]["collective"]["kind"] == "none"
     assert d["config"]["world_size"] == 1
+    # N = 1 says what a world-of-one communicator saw, through the same entries the N > 1 line uses (pols_comm_query)
+    col = d["config"]["collective"]
+    assert col.get("nranks_seen") == 1 and len(col["ranks"]) == 1 and col["ranks"][0]["rank"] == 0 and col["ranks"][0]["pci_bus_id"], col
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"].startswith("k1_gram_chol_f32_k8")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
@@ -73,6 +76,9 @@ def test_bench_collective_path_on_one_gpu():
     c = d["config"]["collective"]
     assert c["kind"].startswith("pols_comm_allgather_rows") and c["backend"] == "nccl", d["config"]
     assert d["value"] > 1e7
+    # the line proves its collective: what RCCL reports for the communicator, and the gathered table checked against its parts
+    assert c["nranks_seen"] == 1 and c["library"].startswith("rccl") and c["rccl_version"] > 0 and c["distinct_devices"] == 1, c
+    assert c["gathered_equals_concatenation"] is True
 
 
 def test_bench_predictions_gather_on_one_gpu():
@@ -81,6 +87,7 @@ def test_bench_predictions_gather_on_one_gpu():
     c = d["config"]["collective"]
     assert c["kind"].startswith("pols_comm_gather_rows") and c["backend"] == "nccl" and c["bytes_per_step_per_rank"] == 40_000_000, d["config"]
     assert d["value"] > 1e6
+    assert c["nranks_seen"] == 1 and c["gathered_equals_concatenation"] is True, c
 
 
 @pytest.mark.parametrize("cfg,metric,kernel", [("cfg1", "single_problems_per_sec", "k5_gram_stream"), ("cfg5", "group_regressions_per_sec", "k2_gram_mfma_resident_f64_k16yv_w8_rc2_cd")])

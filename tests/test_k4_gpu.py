@@ -63,6 +63,53 @@ def _window_matrix(offs, valid, X, i, window, policy):
     return X[idx]
 
 
+def _band_check(tag, got_c, ref_c, rows, offs, valid, X, window, policy, tol, alpha=None, cap=0.25, src=None):
+    """The band of barely-determined windows (k + 2 .. 2k - 1 observations): every row in `rows` against the oracle at north_star's `tol`
+    unless THAT window's conditioning does not allow it -- then at 1e3 cond(X'X + alpha I) eps of the window itself -- and at most `cap` of
+    the rows may need the looser bound.  src[i] (masked drop_window): the row whose solve row i repeats (its window sets the bound).
+    POLS_BAND_REPORT=<file>: append the statistics instead of asserting (calibration runs)."""
+    import os
+
+    rows = np.asarray(rows, dtype=np.int64)
+    eps = np.finfo(np.float64).eps
+    loosened, worst, bad = 0, 0.0, []
+    for i in rows:
+        j = int(i if src is None else src[i])
+        Xw = _window_matrix(offs, valid, X, j, window, policy).astype(np.float64)
+        A = Xw.T @ Xw
+        if alpha:
+            A = A + alpha * np.eye(A.shape[0])
+        tol_i = max(tol, 1e3 * np.linalg.cond(A) * eps)
+        loosened += tol_i > tol
+        err = float(np.max(np.abs(got_c[i] - ref_c[i]) / (tol_i + tol_i * np.abs(ref_c[i]))))      # <= 1 iff allclose(rtol = atol = tol_i)
+        worst = max(worst, err)
+        if not err <= 1.0:
+            bad.append((int(i), tol_i, err))
+    n = max(1, len(rows))
+    rep = os.environ.get("POLS_BAND_REPORT")
+    if rep:
+        with open(rep, "a") as f:
+            f.write(f"{tag}: rows {len(rows)} loosened {loosened} ({loosened / n:.3f}) worst err/bound {worst:.3g} violations {len(bad)} {bad[:3]}\n")
+        return
+    assert not bad, (tag, len(bad), bad[:5])
+    assert loosened <= cap * n, (tag, loosened, len(rows))
+
+
+def _solved_source(ref_c, offs):
+    """masked drop_window: src[i] = the last row at or before i (inside its sequence) whose coefficients the oracle SOLVED -- a row that
+    differs from its predecessor -- or -1 before the first one (NaN rows)."""
+    src = np.full(ref_c.shape[0], -1, dtype=np.int64)
+    for g in range(len(offs) - 1):
+        s, e = int(offs[g]), int(offs[g + 1])
+        last = -1
+        for i in range(s, e):
+            fresh = not np.isnan(ref_c[i]).all() and (i == s or last < 0 or not np.array_equal(ref_c[i], ref_c[i - 1]))
+            if fresh:
+                last = i
+            src[i] = last
+    return src
+
+
 @pytest.mark.parametrize("policy", ["drop", "drop_window"])
 @pytest.mark.parametrize("k,window,min_periods,alpha,null_frac", [
     (1, 2, None, None, 0.0), (2, 2, 2, None, 0.1), (2, 10, 2, None, 0.1), (5, 63, 5, None, 0.2), (6, 252, None, None, 0.0),
@@ -137,13 +184,17 @@ def test_rolling_wide_features(eng, policy, k, window, min_periods, alpha, null_
     pinned = (nobs >= k) | (nobs < mp_eff)
     assert np.array_equal(np.isnan(got_c)[pinned], np.isnan(ref["coef"])[pinned])
     sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
-    strict = sane & (nobs >= k + 4)
+    strict = sane & (nobs >= k + 2)
     assert strict.sum() > 0.3 * sane.sum()
-    assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-5, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
     well = sane & (nobs >= 2 * k)
     assert np.allclose(got_c[well], ref["coef"][well], rtol=1e-6, atol=1e-6), float(np.abs(got_c[well] - ref["coef"][well]).max())
     vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
-    assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
+    assert np.allclose(got_p[well & vm], ref["pred"][well & vm], rtol=1e-6, atol=1e-6) and np.isnan(got_p[~vm]).all()
+    # k + 2 .. 2k - 1 observations: 1e-6 as well, or the window's own cond(X'X) eps where that is larger (like test_rolling_many_groups)
+    src = _solved_source(ref["coef"], offs) if (policy == "drop_window" and valid is not None) else None
+    band = strict & ~well if src is None else strict & ~well & (src >= 0) & (nobs[np.maximum(src, 0)] >= k + 2)
+    _band_check(f"wide_features k={k} w={window} {policy}", got_c, ref["coef"], np.flatnonzero(band), offs, valid, np.stack(cols, axis=1), window, policy, 1e-6,
+                alpha=alpha, src=src)
 
 
 @pytest.mark.parametrize("policy", ["drop", "drop_window"])
@@ -174,6 +225,14 @@ def test_rolling_inverse_propagation_33_features_and_up(eng, policy, k, window, 
     assert np.allclose(got_c[strict], ref["coef"][strict], rtol=1e-6, atol=1e-6), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
     vm = np.ones(len(y), dtype=bool) if valid is None else np.asarray(valid).astype(bool)      # masked rows: nulls (ex.rs:695-700)
     assert np.allclose(got_p[strict & vm], ref["pred"][strict & vm], rtol=1e-5, atol=1e-6) and np.isnan(got_p[~vm]).all()
+    # k + 2 .. 2k - 1 observations: values too, at 1e-6 or the window's own cond(X'X) eps
+    src = _solved_source(ref["coef"], offs) if (policy == "drop_window" and valid is not None) else None
+    band = sane & (nobs >= k + 2) & (nobs < 2 * k)
+    if src is not None:
+        band = band & (src >= 0) & (nobs[np.maximum(src, 0)] >= k + 2)
+    rows = np.flatnonzero(band)
+    _band_check(f"inverse_33+ k={k} w={window} {policy}", got_c, ref["coef"], rows[:: max(1, len(rows) // 60)], offs, valid, np.stack(cols, axis=1), window, policy,
+                1e-6, alpha=alpha, src=src)
 
 
 def test_rolling_non_contiguous_reference_case():               # tests/test_ols.py:969-995 (10 features, weights, drop)
@@ -594,12 +653,14 @@ def test_rolling_wave_per_chunk_null_free(eng, dtype, tol, k, window, min_period
         pinned = (nobs >= k) | (nobs < mp_eff) | (alpha is not None)
         assert np.array_equal(np.isnan(got_c)[pinned], np.isnan(ref["coef"])[pinned])
         sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
-        strict = sane & (nobs >= k + 4)
+        strict = sane & (nobs >= k + 2)
         if window >= k + 4:
             assert strict.sum() > 0.3 * sane.sum()
-        loose = 10 * tol
-        assert np.allclose(got_c[strict], ref["coef"][strict], rtol=loose, atol=tol), float(np.abs(got_c[strict] - ref["coef"][strict]).max())
         well = sane & ((nobs >= 2 * k) | (alpha is not None))
+        # k + 2 .. 2k - 1 observations: north_star's tolerance, or the window's own cond(X'X) eps where that is larger (at most a quarter of the rows)
+        band = np.flatnonzero(strict & ~well)
+        _band_check(f"k4p_null_free k={k} w={window} {shape} {policy} {np.dtype(dtype).name}", got_c, ref["coef"], band[:: max(1, len(band) // 150)], offs, None,
+                    np.stack(cols, axis=1), window, policy, tol, alpha=alpha)
         assert np.allclose(got_c[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(got_c[well] - ref["coef"][well]).max())
         assert np.allclose(got_p[well], ref["pred"][well], rtol=tol, atol=tol)
     eng.set_option("ROLLING_ENGINE", "chunk")
@@ -669,8 +730,18 @@ def test_rolling_wave_per_chunk_drop_window_with_nulls(eng, dtype, tol, k, windo
     # than k valid rows
     before = np.isnan(ref["coef"]).all(axis=1)
     assert np.isnan(got_c[before]).all()
-    strict = sane & (nobs >= k + 4) & np.isfinite(old_c).all(axis=1)
-    assert np.allclose(got_c[strict], old_c[strict], rtol=10 * tol, atol=tol) or np.allclose(got_c[strict], ref["coef"][strict], rtol=10 * tol, atol=tol)
+    # after the warm-up: a row repeats the coefficients of the last row the oracle SOLVED (src); where that row's window held >= k valid
+    # observations the NaN pattern is the oracle's, and with k + 2 .. 2k - 1 of them the values are too (tol, or that window's cond eps)
+    src = _solved_source(ref["coef"], offs)
+    has = src >= 0
+    nsrc = np.where(has, nobs[np.maximum(src, 0)], 0)
+    pinned = has & (nsrc >= k)
+    assert np.array_equal(np.isnan(got_c).any(axis=1)[pinned], np.isnan(ref["coef"]).any(axis=1)[pinned]), \
+        np.flatnonzero(pinned & (np.isnan(got_c).any(axis=1) != np.isnan(ref["coef"]).any(axis=1)))[:10]
+    band = np.flatnonzero(sane & has & (nsrc >= k + 2) & (nsrc < 2 * k) & (alpha is None))
+    _band_check(f"k4p_masked k={k} w={window} {shape} nf={null_frac} {np.dtype(dtype).name}", got_c, ref["coef"], band[:: max(1, len(band) // 150)], offs, valid,
+                np.stack(cols, axis=1), window, "drop_window", tol, alpha=alpha, src=src)
+    assert np.isfinite(old_c[well]).all()                 # (the chunk engine on the same frame: run for its kernel-name assertion above)
     if k <= 16:                                   # four chunks per wave
         eng.set_option("K4P_LPS", "16")
         try:

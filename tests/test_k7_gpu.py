@@ -319,3 +319,40 @@ def test_statistics_of_long_groups_run_per_segment(engine, dtype, sizes, k, weig
         f = lambda v: v.double().cpu().numpy() if hasattr(v, "cpu") else np.asarray(v, dtype=np.float64)  # noqa: E731
         a, b2 = f(out[key])[live], f(one[key])[live]
         assert np.allclose(a, b2, rtol=tol, atol=tol, equal_nan=True), (key, a, b2)
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_f32_multi_million_row_group_with_nonzero_means(engine, split):
+    """ONE f32 group of 4 000 000 rows whose columns have means of 1 .. 3 (nearly every product is positive: an f32 running sum of a million of
+    them loses five digits) through least_squares and least_squares_statistics, cut into segments and unsplit (NO_SPLIT: the whole group is
+    one item of the VALU Gram kernel, k5v_gram.hip) -- the lanes' f32 partials are flushed into f64 every 128 rows, so the coefficients
+    hold north_star's f32 bound of 1e-4 against the f64 oracle on the same f32 data."""
+    import torch
+
+    eng = engine
+    rng = np.random.default_rng(77)
+    n, k = 4_000_000, 6
+    cols = [(rng.standard_normal(n) + 1.0 + 0.4 * j).astype(np.float32) for j in range(k)]
+    beta = np.linspace(0.5, 1.5, k)
+    y = (sum(b * c.astype(np.float64) for b, c in zip(beta, cols)) + 2.0 + rng.standard_normal(n)).astype(np.float32)
+    offs = np.array([0, n], dtype=np.int64)
+    X = np.column_stack([c.astype(np.float64) for c in cols] + [np.ones(n)])
+    ref = np.linalg.lstsq(X, y.astype(np.float64), rcond=None)[0]
+    dy, dc = torch.from_numpy(y).cuda(), [torch.from_numpy(c).cuda() for c in cols]
+    eng.set_option("NO_SPLIT", None if split else "1")
+    try:
+        out = eng.least_squares(dy, dc, offs, add_intercept=True, want=("coef", "pred"))
+        name = eng.last_kernel
+        st = eng.least_squares_statistics(dy, dc, offs, add_intercept=True)
+    finally:
+        eng.set_option("NO_SPLIT", None)
+    coef = out["coef"].double().cpu().numpy()[0]
+    assert np.allclose(coef, ref, rtol=1e-4, atol=1e-4), (name, coef, ref)
+    pred = out["pred"].double().cpu().numpy()
+    assert np.allclose(pred, X @ ref, rtol=1e-4, atol=1e-3)
+    sc = st["coef"].double().cpu().numpy()[0] if hasattr(st["coef"], "cpu") else np.asarray(st["coef"], dtype=np.float64)[0]
+    assert np.allclose(sc, ref, rtol=1e-4, atol=1e-4), (sc, ref)
+    resid = y.astype(np.float64) - X @ ref
+    r2 = 1.0 - (resid ** 2).sum() / ((y.astype(np.float64) - y.astype(np.float64).mean()) ** 2).sum()
+    got_r2 = float(st["r2"].cpu().numpy()[0]) if hasattr(st["r2"], "cpu") else float(np.asarray(st["r2"])[0])
+    assert abs(got_r2 - r2) < 1e-4
