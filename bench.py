@@ -162,15 +162,13 @@ def cpu_baseline(cfg: str, target_seconds: float = 10.0) -> dict:
 # ------------------------------------------------------------------------------------------------ workloads
 
 def make_columns(n: int, feats: int, tdt, seed: int, weights: bool = False):
-    gen = torch.Generator(device="cuda").manual_seed(seed)
-    cols = [torch.randn(n, generator=gen, device="cuda", dtype=tdt) for _ in range(feats)]
-    y = torch.zeros(n, device="cuda", dtype=tdt)
-    for c in cols:
-        y += c
-    y += 0.1 * torch.randn(n, generator=gen, device="cuda", dtype=tdt)
-    w = None
-    if weights:
-        w = torch.rand(n, generator=gen, device="cuda", dtype=tdt)
+    """The synthetic frame of SURVEY.md section 8d, generated ON the device by the counter-based generator (synth.py: Philox-4x32-10 keyed by
+    (seed; row, column)): x ~ N(0, 1), beta = 1, y = x.beta + 0.1 N(0, 1), w ~ U(0, 1) / mean.  A host regenerates any row range of it
+    bit for bit (synth.frame_columns(seed, feats, lo, hi)) -- no device-to-host copy is needed to check a group."""
+    import synth
+
+    y, cols, w = synth.frame_columns(seed, feats, 0, n, dtype=tdt, device="cuda", weights=weights)
+    if w is not None:
         w /= w.mean()
     return y, cols, w
 

@@ -202,14 +202,12 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o);
 
 /* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions.
- * DIVERGENCE (the row-parallel kernel: up to 10 features, min_periods <= window, windows up to 508 rows -- 252 at 7 to 10 features -- or
- * any window when no sequence is longer than 1 021 rows; null-free frames, and frames with nulls under the drop family; and the
- * wave-per-chunk kernel of 9 to 32 features, round 5: min_periods <= window, windows up to 1 024 rows or sequences of up to 1 024 rows,
- * null-free frames, "drop" with nulls, "drop_window" with validity bytes): a window whose X'X has no Cholesky factorisation -- fewer than k
- * independent rows -- yields NaN coefficients; the reference falls back to LU there (ls.rs:732-734) and returns whatever a zero or noise
- * pivot produces (inf / NaN / 1e15-sized numbers).  tests/test_k4_gpu.py::test_rolling_divergence_band_is_pinned holds the NaN rows of the
- * default route to the rows where the reference has fewer than k observations or no usable (finite, < 1e3) answer itself.
- * pols_set_option("ROLLING_ENGINE", "chunk") selects the kernels that run the LU.
+ * Up to 10 features (the row-parallel tile kernel: null-free frames, the drop family with nulls by compaction, "drop_window" with nulls
+ * by masking) a window whose sums have no Cholesky factorisation is solved by LU with partial pivoting like the reference (ls.rs:732-734):
+ * same kind of answer on the same rows (tests/test_k4_gpu.py::test_rolling_divergence_band_is_pinned).
+ * DIVERGENCE (the wave-per-chunk kernel of 11 to 32 features -- 9 / 10 where the tile kernel's window conditions fail): there such a window
+ * yields NaN coefficients where the reference's LU returns whatever a zero or noise pivot produces (inf / NaN / 1e15-sized numbers);
+ * pols_set_option("ROLLING_ENGINE", "chunk") selects the kernels that run the LU at those widths.
  * p->use_woodbury is accepted and does not select a code path: up to 8 features (and wherever the chunk kernels run) the sums are
  * re-factored per row, from 9 features on the inverse is propagated with Sherman-Morrison updates whatever the flag says (the
  * reference's WoodburyState arithmetic, ls.rs:737-787, rebuilt from the sums every 128 rows) -- same mathematics, different rounding. */

@@ -2258,31 +2258,27 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         if (!pmap && w > k4c_max_window(k)) tiles_m = false;
         if (tiles_m) {
             const int64_t N = b->n_rows, G = b->n_groups, n_slabs = (N + 255) / 256;
-            const size_t b_row = round256(sizeof(int32_t) * (size_t)N), b_sc = round256(sizeof(uint32_t) * (size_t)n_slabs),
+            const size_t b_r2 = round256(sizeof(uint16_t) * (size_t)N), b_sol = round256((size_t)N + 4), b_sc = round256(sizeof(uint32_t) * (size_t)n_slabs),
                          b_s8 = round256(sizeof(int64_t) * (size_t)(n_slabs + 1)), b_g8 = round256(sizeof(int64_t) * (size_t)(G + 1)),
                          b_g4 = round256(sizeof(int32_t) * (size_t)G);
             void *d = nullptr;
-            if ((rc = ensure_scratch(ctx, 19, 256 + 3 * b_row + b_sc + 3 * b_s8 + 2 * b_g8 + b_g4, &d))) return rc;   // (slot 19: the compaction's, never live here)
+            if ((rc = ensure_scratch(ctx, 19, 256 + 2 * b_r2 + b_sol + b_sc + 3 * b_s8 + 2 * b_g8 + b_g4, &d))) return rc;   // (slot 19: the compaction's, never live here)
             char *q = static_cast<char *>(d);
-            RowCompactArgs ra;
-            std::memset(&ra, 0, sizeof(ra));
             RollMaskArgs ma;
             std::memset(&ma, 0, sizeof(ma));
             ma.flag = reinterpret_cast<int32_t *>(q); q += 256;
-            ma.cnt = reinterpret_cast<int32_t *>(q); q += b_row;
-            ma.vidx = reinterpret_cast<int32_t *>(q); q += b_row;
-            ma.code = reinterpret_cast<int32_t *>(q); q += b_row;
-            ra.slab_cnt = reinterpret_cast<uint32_t *>(q); q += b_sc;
-            ra.slab_base = reinterpret_cast<int64_t *>(q); q += b_s8;
+            ma.incl = reinterpret_cast<uint16_t *>(q); q += b_r2;
+            ma.code = reinterpret_cast<uint16_t *>(q); q += b_r2;
+            ma.solved = reinterpret_cast<uint8_t *>(q); q += b_sol;
+            ma.slab_cnt = reinterpret_cast<uint32_t *>(q); q += b_sc;
+            ma.slab_base = reinterpret_cast<int64_t *>(q); q += b_s8;
             ma.slab_last = reinterpret_cast<int64_t *>(q); q += b_s8;
             ma.slab_carry = reinterpret_cast<int64_t *>(q); q += b_s8;
-            ra.c_offs = reinterpret_cast<int64_t *>(q); q += b_g8;
+            ma.c_offs = reinterpret_cast<int64_t *>(q); q += b_g8;
             ma.g_mpv = reinterpret_cast<int64_t *>(q); q += b_g8;
             ma.g_gate = reinterpret_cast<int32_t *>(q); q += b_g4;
-            ra.valid = st.valid; ra.offs = d_offs; ra.n_rows = N; ra.n_groups = G; ra.n_slabs = n_slabs;
-            if ((rc = row_compact_offsets_launch(ctx, ra))) return rc;
             ma.valid = st.valid; ma.offs = d_offs; ma.n_rows = N; ma.n_groups = G; ma.n_slabs = n_slabs;
-            ma.slab_base = ra.slab_base; ma.c_offs = ra.c_offs; ma.window = w; ma.min_periods = mp;
+            ma.window = w; ma.min_periods = mp;
             if ((rc = roll_mask_tables_launch(ctx, ma))) return rc;
             int32_t flag = 0;
             POLS_HIP(hipMemcpyAsync(&flag, ma.flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
@@ -2292,7 +2288,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
                 K4cArgs c;
                 std::memset(&c, 0, sizeof(c));
                 if ((rc = ensure_start_flags(ctx, d_offs, b->n_groups, b->n_rows, &c.start))) return rc;
-                c.y = st.y; c.valid = st.valid;
+                c.y = st.y; c.valid = st.valid; c.solved = ma.solved;
                 for (int j = 0; j < k; ++j) { c.x[j] = st.x[j]; ma.x[j] = st.x[j]; }
                 c.n_rows = N; c.coef = st.coef; c.pred = st.pred;
                 c.window = pmap ? std::min<int64_t>(w, 2 * K4C_PACKED_ROWS) : w;
@@ -2301,7 +2297,8 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
                 if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
                 ma.coef = st.coef; ma.pred = st.pred; ma.k = k;
                 if ((rc = roll_mask_fill_launch(ctx, b->dtype, ma))) return rc;
-                if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+                // (the kernel and the fill pass null the predictions of masked rows themselves: the post pass only un-scales by 1 / sqrt(w))
+                if (ds.post && ds.pa.sw_out && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
                 return unstage_outputs(ctx, b, b->n_rows, k, o, st);
             }
         }

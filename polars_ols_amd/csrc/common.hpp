@@ -93,8 +93,8 @@ struct pols_ctx {
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
     // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..22] row compaction of the rolling entry (columns, coefficients, start bytes, tile map), [23] segment tables + partial Gram matrices of the streamed static path,
-    // [24] group lists of the size classes, [25] K3c halo form: first row of the sequence in front of every tile, [26] segment tables of the last size class
-    pols::Scratch scratch[27];
+    // [24] group lists of the size classes, [25] K3c halo form: first row of the sequence in front of every tile, [26] segment tables of the last size class, [27] K4c: rows without a factorisation (the LU list)
+    pols::Scratch scratch[28];
     pols::Options opt;
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
@@ -139,6 +139,8 @@ struct pols_ctx {
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t cut[3] = {0, 0, 0}, n[4] = {0, 0, 0, 0}; int n_cut = 0;
              std::vector<int32_t> host_last; } class_cache;   // group lists of the size classes (slot 24; host_last: the last class' ids, for its segment tables)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0, class_key = 0, n_items = 0; size_t nz2 = 0; bool nulls = false; } seg_cache[2];   // [0] whole-frame tables (slot 23), [1] the last size class' tables (slot 26)
+    const void *k4c_fix_ptr = nullptr;       // K4c's LU list (scratch slot 27): the slot's address when its counters were last zeroed, and whose turn it is
+    uint64_t k4c_fix_turn = 0;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1; } start_flags;
 };

@@ -355,16 +355,39 @@ int valid_tables_launch(pols_ctx *ctx, const ValidTablesArgs &a) {
 
 // ---------------------------------------------------------------- per-row solve table of the masked tile kernel ("drop_window" with nulls, K4c)
 // Which rows does solve_rolling_ols solve under the fixed window (ls.rs:987-1029)?  Row i of a sequence is NaN before the warm-up row
-// mpv - 1 (:864, :939-943), solved when it is that row or its window holds gate_n valid rows (n_valid_window >= n_valid, :1013 / :1022:
-// the valid rows among (i - window, i], from row 1 on while i < window -- the saturating_sub of :990), and repeats the last solved
-// row's coefficients otherwise.  All of it is a function of the validity bytes: rm_groups_kernel derives the per-sequence constants,
-// rm_rows_kernel marks every row and finds the last solved row inside its 256-row slab, rm_carry_kernel carries it across slabs.
+// mpv - 1 (:864, :939-943), solved when it is that row, or when the state changed (row i is valid, or row i - window is and leaves) and
+// the window holds gate_n valid rows (n_valid_window >= n_valid, :1013 / :1022: the valid rows among (i - window, i], from row 1 on while
+// i < window -- the saturating_sub of :990), and repeats the last solved row's coefficients otherwise.  All of it is a function of the
+// validity bytes.  P(r) = valid rows of the FRAME at or before row r = slab_base[r / 256] + incl[r] (a 16-bit count inside the slab):
+//   rm_count_kernel   slab totals + incl[]            (then rc_scan_kernel / rc_groups_kernel: slab_base, c_offs = P before every group)
+//   rm_groups_kernel  per sequence mpv / gate_n, and the flag for the one shape the tile kernel cannot take
+//   rm_rows_kernel    every row: solved / NaN / where the last solved row of its slab is;   rm_carry_kernel: ... of the slabs before
+__global__ void __launch_bounds__(RC_SLAB) rm_count_kernel(const RollMaskArgs a) {
+    __shared__ unsigned wave_cnt[RC_SLAB / 64];
+    const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
+    unsigned total;
+    const unsigned incl = rc_slab_prefix(r < a.n_rows && a.valid[r], wave_cnt, &total);
+    if (r < a.n_rows) a.incl[r] = (uint16_t)incl;
+    if (threadIdx.x == 0) a.slab_cnt[blockIdx.x] = total;
+}
+
+__device__ __forceinline__ int64_t rm_prefix(const RollMaskArgs &a, int64_t r) { return a.slab_base[r >> 8] + (int64_t)a.incl[r]; }
+
 __global__ void __launch_bounds__(256) rm_groups_kernel(const RollMaskArgs a) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= a.n_groups) return;
-    const int64_t s = a.offs[g], n = a.offs[g + 1] - s, tot = a.c_offs[g + 1] - a.c_offs[g], mp = a.min_periods;
-    // ls.rs:881-891: min_periods_valid = the row at which the min_periods-th valid observation arrives (else it stays min_periods)
-    int64_t mpv = tot >= mp ? (int64_t)a.vidx[s + mp - 1] + 1 : mp;
+    const int64_t s = a.offs[g], n = a.offs[g + 1] - s, before = a.c_offs[g], tot = a.c_offs[g + 1] - before, mp = a.min_periods;
+    // ls.rs:881-891: min_periods_valid = the row at which the min_periods-th valid observation arrives (else it stays min_periods):
+    // the first row of the sequence whose prefix reaches `before + mp` (the prefix is monotone: a binary search)
+    int64_t mpv = mp;
+    if (tot >= mp) {
+        int64_t lo = 0, hi = n - 1;                          // P(s + hi) - before >= mp holds at hi = n - 1
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rm_prefix(a, s + mid) - before >= mp) hi = mid; else lo = mid + 1;
+        }
+        mpv = lo + 1;
+    }
     const int64_t gate = tot < mp ? tot : mp;
     if (n < mp) mpv = n + 1;                                 // :893-900: every row NaN
     a.g_mpv[g] = mpv;
@@ -372,26 +395,36 @@ __global__ void __launch_bounds__(256) rm_groups_kernel(const RollMaskArgs a) {
     // a valid row older than the window when the warm-up ends is never subtracted (the sliding loop starts at row mpv, :989): such a
     // sequence is outside the tile kernel's prefix-difference form -- the caller routes the frame to the chunk kernels
     const int64_t jm = mpv - a.window - 1;
-    if (n >= mp && jm >= 0 && jm < n && a.cnt[s + jm] > 0) atomicOr(a.flag, 1);
+    if (n >= mp && jm >= 0 && jm < n && rm_prefix(a, s + jm) - before > 0) atomicOr(a.flag, 1);
 }
 
 __global__ void __launch_bounds__(RC_SLAB) rm_rows_kernel(const RollMaskArgs a) {
     __shared__ int wave_last[RC_SLAB / 64];
+    __shared__ long long g_first;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
     const bool in = r < a.n_rows;
-    bool solved = false, nan = true;
-    if (in) {
-        int64_t lo = 0, hi = a.n_groups;                     // the group holding row r: the last g with offs[g] <= r
+    if (threadIdx.x == 0) {                                  // the group holding the slab's first row: the last g with offs[g] <= row (one search per slab)
+        const int64_t r0 = (int64_t)blockIdx.x * RC_SLAB;
+        int64_t lo = 0, hi = a.n_groups;
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
-            if (a.offs[mid] <= r) lo = mid; else hi = mid;
+            if (a.offs[mid] <= r0) lo = mid; else hi = mid;
         }
-        const int64_t s = a.offs[lo], i = r - s, mpv = a.g_mpv[lo], w = a.window;
+        g_first = lo;
+    }
+    __syncthreads();
+    bool solved = false, nan = true;
+    if (in) {
+        int64_t g = g_first;
+        while (g + 1 < a.n_groups && a.offs[g + 1] <= r) ++g;    // (groups that start inside the slab: a short walk)
+        const int64_t s = a.offs[g], i = r - s, mpv = a.g_mpv[g], w = a.window;
         if (i >= mpv - 1) {
             nan = false;
             const int64_t is = i >= w ? i - w : 0;
-            solved = (i == mpv - 1) || ((int64_t)a.cnt[r] - (int64_t)a.cnt[s + is] >= (int64_t)a.g_gate[lo]);
+            // :1007-1026: the state changes when row i is valid (it enters) or row i - window is (it leaves); only then is the gate consulted
+            const bool changed = a.valid[r] != 0 || (i >= w && a.valid[r - w] != 0);
+            solved = (i == mpv - 1) || (changed && rm_prefix(a, r) - rm_prefix(a, s + is) >= (int64_t)a.g_gate[g]);
         }
     }
     // the last solved row of the slab at or before this one: highest set bit of the wave's ballot below the lane, else an earlier wave's last
@@ -401,7 +434,9 @@ __global__ void __launch_bounds__(RC_SLAB) rm_rows_kernel(const RollMaskArgs a) 
     const unsigned long long upto = bal & ((2ull << lane) - 1ull);
     int loc = upto ? wave * 64 + (63 - __clzll(upto)) : -1;
     for (int w2 = wave - 1; w2 >= 0 && loc < 0; --w2) loc = wave_last[w2];
-    if (in) a.code[r] = nan ? -1 : (loc >= 0 ? loc : RC_SLAB);   // -1: NaN row; 0 .. 255: the slab's row that was solved last; 256: before this slab
+    // 0: solved here; 1: NaN row; 2 + j: repeats row j of its slab (j < 256); 2 + 256: repeats a row before the slab (slab_carry)
+    if (in) a.code[r] = (uint16_t)(solved ? 0 : nan ? 1 : 2 + (loc >= 0 ? loc : RC_SLAB));
+    if (in) a.solved[r] = solved ? 1 : 0;
     if (threadIdx.x == RC_SLAB - 1) a.slab_last[blockIdx.x] = loc >= 0 ? (int64_t)blockIdx.x * RC_SLAB + loc : -1;
 }
 
@@ -434,45 +469,45 @@ __global__ void __launch_bounds__(1024) rm_carry_kernel(const RollMaskArgs a) { 
 }
 
 // The fill pass behind the masked tile kernel: a row the reference does not solve takes NaN (before the warm-up) or the coefficients of the
-// last solved row (a fixed point of this pass: solved rows are never written), and its prediction is recomputed from them.
+// last solved row (a fixed point of this pass: solved rows are never written), and its prediction is recomputed from them (NaN on a
+// masked row, src/expressions.rs:695-700).  Reads one byte per row; everything else only for the rows it rewrites.
 template <typename T>
 __global__ void __launch_bounds__(256) rm_fill_kernel(const RollMaskArgs a) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.n_rows) return;
+    if (r >= a.n_rows || a.solved[r]) return;                // solved here
     const int code = a.code[r];
     const int64_t slab0 = r & ~(int64_t)(RC_SLAB - 1);
-    if (code >= 0 && code < RC_SLAB && slab0 + code == r) return;      // solved here
     const int k = a.k;
     T *coef = static_cast<T *>(a.coef);
     T *pred = static_cast<T *>(a.pred);
     const T qnan = nan_if<T>(1u, T(0));
-    if (code < 0) {
+    if (code == 1) {
         if (coef) for (int j = 0; j < k; ++j) coef[r * k + j] = qnan;
         if (pred) pred[r] = qnan;
         return;
     }
-    const int64_t src = code < RC_SLAB ? slab0 + code : a.slab_carry[r >> 8];
+    const int64_t src = code - 2 < RC_SLAB ? slab0 + (code - 2) : a.slab_carry[r >> 8];
+    const bool vr = a.valid[r] != 0;
     T p = T(0);
     for (int j = 0; j < k; ++j) {
-        const T c = coef[src * k + j];
-        coef[r * k + j] = c;
-        T xv = static_cast<const T *>(a.x[j])[r];
-        if (!a.valid[r]) xv = T(0);                          // (an invalid row's prediction is masked by the caller's post pass; keep NaNs out of the sum)
-        p = fma(xv, c, p);
+        const T c = coef ? coef[src * k + j] : T(0);
+        if (coef) coef[r * k + j] = c;
+        if (vr) p = fma(static_cast<const T *>(a.x[j])[r], c, p);
     }
-    if (pred) pred[r] = p;
+    if (pred) pred[r] = vr ? p : qnan;
 }
 
 int roll_mask_tables_launch(pols_ctx *ctx, const RollMaskArgs &a) {
     if (a.n_rows == 0 || a.n_groups == 0) return POLS_OK;
-    static_assert(RC_SLAB == 256, "rm_fill_kernel's slab arithmetic");
-    ValidTablesArgs va;
-    std::memset(&va, 0, sizeof(va));
-    va.valid = a.valid; va.offs = a.offs; va.n_rows = a.n_rows; va.n_groups = a.n_groups; va.n_slabs = a.n_slabs;
-    va.slab_base = a.slab_base; va.c_offs = a.c_offs; va.cnt = a.cnt; va.vidx = a.vidx;
-    POLS_HIP(hipMemsetAsync(a.vidx, 0xff, sizeof(int32_t) * (size_t)a.n_rows, ctx->stream));
+    static_assert(RC_SLAB == 256, "the slab arithmetic of rm_prefix / rm_fill_kernel");
+    RowCompactArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.valid = a.valid; ra.offs = a.offs; ra.n_rows = a.n_rows; ra.n_groups = a.n_groups; ra.n_slabs = a.n_slabs;
+    ra.slab_cnt = a.slab_cnt; ra.slab_base = a.slab_base; ra.c_offs = a.c_offs;
     POLS_HIP(hipMemsetAsync(a.flag, 0, sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(vt_rows_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, va);
+    hipLaunchKernelGGL(rm_count_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ra);
+    hipLaunchKernelGGL(rc_groups_kernel, dim3((unsigned)((a.n_groups + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ra);
     hipLaunchKernelGGL(rm_groups_kernel, dim3((unsigned)((a.n_groups + 255) / 256)), dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;

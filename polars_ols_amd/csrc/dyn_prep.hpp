@@ -113,18 +113,19 @@ int valid_tables_launch(pols_ctx *ctx, const ValidTablesArgs &a);
 // The per-row solve table of the masked tile kernel (rolling OLS, "drop_window" on frames with validity bytes; k4c_kernel.inl MASKED):
 // roll_mask_tables_launch -- validity prefix + per-sequence warm-up constants + the "never-dropped row" flag the host reads before it
 // routes; roll_mask_rows_launch -- every row's code and the slabs' carries; roll_mask_fill_launch -- behind the kernel.
-// Needs row_compact_offsets_launch's slab_base / c_offs of the same frame.
 struct RollMaskArgs {
     const uint8_t *valid;
     const int64_t *offs;         // DEVICE group offsets, n_groups + 1
     int64_t n_rows, n_groups, n_slabs;
-    const int64_t *slab_base;    // valid rows before each 256-row slab
-    const int64_t *c_offs;       // valid rows before each group
-    int32_t *cnt, *vidx;         // n_rows each: inclusive count of valid rows inside the group; row of the r-th valid row (scratch)
+    uint32_t *slab_cnt;          // n_slabs: valid rows of every 256-row slab
+    int64_t *slab_base;          // n_slabs + 1: valid rows before the slab
+    int64_t *c_offs;             // n_groups + 1: valid rows before every group
+    uint16_t *incl;              // n_rows: valid rows of the slab at or before the row
     int64_t *g_mpv;              // n_groups: min_periods_valid (n + 1: the whole sequence is NaN)
     int32_t *g_gate;             // n_groups: n_valid of the gate
     int32_t *flag;               // bit 0: some sequence keeps a valid row older than its window in the warm-up sum
-    int32_t *code;               // n_rows: -1 NaN; 0 .. 255 the slab's row solved last at or before this one; 256: before the slab
+    uint8_t *solved;             // n_rows: 1 on the rows the reference solves
+    uint16_t *code;              // n_rows: 0 solved here; 1 NaN; 2 + j: repeats row j of its slab; 2 + 256: repeats slab_carry[slab]
     int64_t *slab_last, *slab_carry;   // n_slabs each
     int64_t window, min_periods;
     // fill pass

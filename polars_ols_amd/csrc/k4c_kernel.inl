@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     // ---- A: the run's rows (rows outside the frame: zeros, no sequence start)
     double x[R][K], y[R];
     unsigned sbits = 0;
+    [[maybe_unused]] unsigned vmask = 0;                                        // MASKED: byte r != 0 -- row i0 + r is valid
     if (__all(inside)) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -110,6 +111,7 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
         sbits = *reinterpret_cast<const unsigned *>(a.start + i0);
         if constexpr (MASKED) {
             const unsigned vbits = *reinterpret_cast<const unsigned *>(a.valid + i0);
+            vmask = vbits;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool vr = ((vbits >> (8 * r)) & 0xffu) != 0;
@@ -125,10 +127,19 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
             bool in = i >= 0 && i < N;
             const int64_t ic = in ? i : 0;
             if (in && a.start[ic]) sbits |= 1u << (8 * r);
-            if constexpr (MASKED) in = in && a.valid[ic] != 0;
+            if constexpr (MASKED) { in = in && a.valid[ic] != 0; if (in) vmask |= 1u << (8 * r); }
 #pragma unroll
             for (int j = 0; j < K; ++j) x[r][j] = in ? (double)static_cast<const T *>(a.x[j])[ic] : 0.0;
             y[r] = in ? (double)static_cast<const T *>(a.y)[ic] : 0.0;
+        }
+    }
+    [[maybe_unused]] unsigned solbits = 0;                                     // MASKED: byte r != 0 -- the reference solves row i0 + r (dyn_prep.hip rm_rows_kernel)
+    if constexpr (MASKED) {
+        if (inside) solbits = *reinterpret_cast<const unsigned *>(a.solved + i0);
+        else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (i0 + r >= 0 && i0 + r < N && a.solved[i0 + r]) solbits |= 1u << (8 * r);
         }
     }
     const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
@@ -259,6 +270,7 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     __syncthreads();                                                           // (the halo waves have retired: they no longer count)
     T *stage = reinterpret_cast<T *>(smem) + (size_t)(wv - HW) * (R * (K + 1) * DYN_STAGE_STRIDE);
     double beta[K];
+    unsigned failed = 0;                                                       // bit r: row i0 + r is one the reference solves and its sums had no L D L' factorisation
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         __builtin_amdgcn_sched_barrier(0);
@@ -279,14 +291,18 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
         // inf / NaN / 1e15-sized numbers.  This kernel reports such rows as NaN -- no LU, hence no scratch memory in the launch;
         // POLS_ROLLING_ENGINE=chunk has the LU.
         const bool ok = ldl_solve_small<K, false>(S, a.alpha, beta);
-        const bool good = MASKED ? ok : ((cnt >= (double)a.min_periods || sub) && ok);   // row min_periods - 1 of the sequence and later (MASKED: the fill pass knows)
+        const bool territory = MASKED ? ((solbits >> (8 * r)) & 0xffu) != 0 : (cnt >= (double)a.min_periods || sub);   // a row the reference solves
+        const bool good = MASKED ? ok : (territory && ok);          // (MASKED: the fill pass rewrites the rows that are not solved here)
+        failed |= (territory && !ok) ? (1u << r) : 0u;   // no factorisation: the reference goes on to LU (ls.rs:732-734) -- see below
         double pr = 0.0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             stage[(r * (K + 1) + j) * DYN_STAGE_STRIDE + lane] = good ? (T)beta[j] : qnan;
             pr = fma(x[r][j], beta[j], pr);
         }
-        stage[(r * (K + 1) + K) * DYN_STAGE_STRIDE + lane] = good ? (T)pr : qnan;
+        bool pgood = good;
+        if constexpr (MASKED) pgood = good && ((vmask >> (8 * r)) & 0xffu) != 0;   // a masked row's prediction is a null (src/expressions.rs:695-700)
+        stage[(r * (K + 1) + K) * DYN_STAGE_STRIDE + lane] = pgood ? (T)pr : qnan;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -295,10 +311,128 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
         const T none[4] = {};
         dyn_wave_copy_out<T, K, K + 1>(stage, lane, hs + (int64_t)wv * 64 * R, hi, coef, pred, lo, none);
     }
+    // rows whose window sums had no factorisation go on a list: k4c_lu_fix_kernel re-sums their windows and runs the reference's LU behind
+    // this kernel (rare -- degenerate windows only: one wave-aggregated append per wave that has any)
+    if (__any(failed != 0)) {
+        unsigned mine = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = i0 + r;
+            if (((failed >> r) & 1u) && row >= lo && row < hi) mine |= 1u << r;
+        }
+        const int cnt_mine = __popc(mine);
+        int incl = cnt_mine;                                   // inclusive prefix of the lanes' counts
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        const int total = __shfl(incl, 63);
+        int base = 0;
+        if (lane == 0 && total) base = atomicAdd(a.fix_count, total);
+        base = __shfl(base, 0) + incl - cnt_mine;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((mine >> r) & 1u) { if (base < a.fix_cap) a.fix_rows[base] = i0 + r; ++base; }
+    }
     K4C_STAMP(4);
     K4C_STAMP(5);
     if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + 6] = 0;
 #undef K4C_STAMP
+}
+
+// The rows whose window sums have no L D L' factorisation, solved the reference's way (Cholesky -> LU with partial pivoting, ls.rs:732-734 /
+// :277-337): one wave per listed row re-sums the window -- the rows (i - window, i] of the row's sequence, the valid ones under MASKED --
+// from global memory, every lane runs the same K x K elimination, the coefficients and the prediction replace the NaNs.
+template <typename T, int K, bool MASKED>
+__global__ void __launch_bounds__(64) k4c_lu_fix_kernel(const K4cArgs a) {
+    constexpr int NX = K4N<K>::NX, NT = K4N<K>::N;
+    const int lane = threadIdx.x;
+    const int n_fix = min(*a.fix_count, (int)a.fix_cap);
+    if (blockIdx.x == 0 && lane == 0) *a.fix_next = 0;          // the next call's counter (nobody reads it during this call)
+    for (int e = blockIdx.x; e < n_fix; e += gridDim.x) {
+        const int64_t i = a.fix_rows[e];
+        int64_t lo = i - a.window + 1 < 0 ? 0 : i - a.window + 1;
+        for (int64_t base = i; base >= lo; base -= 64) {       // the last sequence start at or before row i inside the window
+            const int64_t j = base - lane;
+            const unsigned long long m = __ballot(j >= lo && a.start[j] != 0);
+            if (m) { lo = base - (int64_t)__builtin_ctzll(m); break; }
+        }
+        double S[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) S[q] = 0.0;
+        for (int64_t j = lo + lane; j <= i; j += 64) {
+            if constexpr (MASKED) { if (!a.valid[j]) continue; }
+            double xr[K];
+#pragma unroll
+            for (int p = 0; p < K; ++p) xr[p] = (double)static_cast<const T *>(a.x[p])[j];
+            const double yr = (double)static_cast<const T *>(a.y)[j];
+#pragma unroll
+            for (int p = 0; p < K; ++p) {
+#pragma unroll
+                for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = fma(xr[p], xr[q], S[tri_index<K>(p, q)]);
+                S[NX + p] = fma(xr[p], yr, S[NX + p]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) S[q] += __shfl_xor(S[q], off);
+        }
+        // LU with partial pivoting on ONE copy of [A | b] in LDS (faer's partial_piv_lu as the oracle restates it, oracle/pols_oracle.c:108-141): lane c owns
+        // column c (column K: the right-hand side); per pivot step every lane reads the pivot column (broadcast reads), swaps and updates its own column
+        __shared__ double As[K][K + 1], Ss[NT];
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q) Ss[q] = S[q];          // (every lane holds the totals; static indices keep S in registers)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane <= K) {
+            for (int p = 0; p < K; ++p) {
+                double v;
+                if (lane < K) {
+                    const int r0 = p < lane ? p : lane, r1 = p < lane ? lane : p;
+                    v = Ss[tri_index<K>(r0, r1)] + (p == lane ? a.alpha : 0.0);
+                } else v = Ss[NX + p];
+                As[p][lane] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int j = 0; j < K; ++j) {
+            int pv = j;
+            double best = fabs(As[j][j]);
+            for (int r2 = j + 1; r2 < K; ++r2) { const double v = fabs(As[r2][j]); if (v > best) { best = v; pv = r2; } }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane <= K && pv != j) { const double t0 = As[j][lane]; As[j][lane] = As[pv][lane]; As[pv][lane] = t0; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double d = As[j][j];
+            double f[K];
+            for (int r2 = j + 1; r2 < K; ++r2) f[r2] = As[r2][j] / d;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane <= K && lane > j) {
+                const double top = As[j][lane];
+                for (int r2 = j + 1; r2 < K; ++r2) As[r2][lane] -= f[r2] * top;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        double beta[K];
+        for (int p = K - 1; p >= 0; --p) {
+            double sacc = As[p][K];
+            for (int q = p + 1; q < K; ++q) sacc -= As[p][q] * beta[q];
+            beta[p] = sacc / As[p][p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) {
+            double pr = 0.0;
+            bool vi = true;
+            if constexpr (MASKED) vi = a.valid[i] != 0;
+            for (int p = 0; p < K; ++p) {
+                if (a.coef) static_cast<T *>(a.coef)[i * K + p] = (T)beta[p];
+                pr = fma(vi ? (double)static_cast<const T *>(a.x[p])[i] : 0.0, beta[p], pr);
+            }
+            if (a.pred) static_cast<T *>(a.pred)[i] = vi ? (T)pr : nan_if<T>(1u, T(0));      // (a masked row's prediction is a null)
+        }
+    }
 }
 
 template <typename T, int K, int HW, bool MASKED>
@@ -330,8 +464,24 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     }
     hipEvent_t e0, e1;
     const bool timed = timing_pair(ctx, &e0, &e1);
+    // the list of rows without a factorisation (scratch slot 27: [count][rows]); empty on all but degenerate frames
+    {
+        void *fx = nullptr;
+        const int64_t cap = std::min<int64_t>(a.n_rows, (int64_t)1 << 22);
+        int rc = ensure_scratch(ctx, 27, 256 + sizeof(int64_t) * (size_t)cap, &fx);
+        if (rc) return rc;
+        // two counters take turns: this call appends to one, its fix-up kernel zeroes the other for the next call (no memset on the stream);
+        // a fresh (or grown) slot starts zeroed
+        if (ctx->k4c_fix_ptr != fx) { POLS_HIP(hipMemsetAsync(fx, 0, 256, ctx->stream)); ctx->k4c_fix_ptr = fx; ctx->k4c_fix_turn = 0; }
+        a.fix_count = static_cast<int32_t *>(fx) + 32 * (ctx->k4c_fix_turn & 1);
+        a.fix_next = static_cast<int32_t *>(fx) + 32 * ((ctx->k4c_fix_turn + 1) & 1);
+        ++ctx->k4c_fix_turn;
+        a.fix_rows = reinterpret_cast<int64_t *>(static_cast<char *>(fx) + 256);
+        a.fix_cap = cap;
+    }
     hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES, MASKED>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
                           timed ? e1 : nullptr, 0, a);
+    hipLaunchKernelGGL((k4c_lu_fix_kernel<T, K, MASKED>), dim3(512), dim3(64), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k4c_rolling_tiles");
     return POLS_OK;

@@ -32,7 +32,7 @@ def timed(fn, reps=5):
 for name, kw in (("null-free", dict(y=y, null_free=True)), ("validity bytes", dict(y=y, valid=valid)), ("NaN targets", dict(y=y_nan))):
     yy = kw.pop("y")
     for pol in ("drop", "drop_window"):
-        ms = timed(lambda: eng.rolling_least_squares(yy, cols, offs, window_size=252, min_periods=6, null_policy=pol, **kw))
+        ms = timed(lambda: eng.rolling_least_squares(yy, cols, offs, window_size=252, min_periods=max(6, k), null_policy=pol, **kw))
         print(f"k={k:2d} rolling {name:15s} {pol:12s} {ms:8.3f} ms per call  {eng.last_kernel}")
     ms = timed(lambda: eng.recursive_least_squares(yy, cols, offs, half_life=21.0, **kw))
     print(f"k={k:2d} rls     {name:15s} {'':12s} {ms:8.3f} ms per call  {eng.last_kernel}")

@@ -75,6 +75,12 @@ for k,v in acc.items():
 PY
     else tail -3 $O/pmc_sq.err; fi; rm -rf $O/pmc_sq )
   ;;
+k4cm)
+  echo "== masked tile kernel: parity"
+  timeout 1500 python -m pytest tests/test_k4_gpu.py -m gpu -x -q -k "many_groups or tile_kernel or divergence" 2>&1 | tail -15 | tee $O/${TAG}_pytest_k4cm.txt
+  echo "== dynamic entries on frames with nulls"
+  for K in 6 8 10; do K=$K timeout 600 python scripts/bench_dyn_nulls.py 2>&1 | grep -v amdgpu; done | tee $O/${TAG}_bench_dyn_nulls.txt
+  ;;
 tests)
   timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_pytest_gpu.txt
   ;;

@@ -252,10 +252,12 @@ def test_rls_many_sequences_full_size(eng):
     from oracle import orc
     import torch
 
+    import synth
+
     G, n, k = 10_000, 1_000, 6
-    gen = torch.Generator(device="cuda").manual_seed(77)
-    cols = [torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64) for _ in range(k)]
-    y = sum(cols) + 0.1 * torch.randn(G * n, generator=gen, device="cuda", dtype=torch.float64)
+    # the frame is generated ON the device by the counter-based generator (synth.py); the host regenerates the sampled sequences' rows bit for
+    # bit from (seed, row, column) -- no input column is copied back
+    y, cols, _ = synth.frame_columns(77, k, 0, G * n, dtype=torch.float64, device="cuda")
     offs = np.arange(G + 1, dtype=np.int64) * n
     out = eng.recursive_least_squares(y, cols, offs, half_life=21.0, null_free=True)
     assert eng.last_kernel.startswith("k3s_rls_rows")
@@ -263,9 +265,12 @@ def test_rls_many_sequences_full_size(eng):
     assert bool(torch.isfinite(coef).all()) and bool(torch.isfinite(pred).all())
     rng = np.random.default_rng(5)
     pick = np.unique(np.concatenate([[0, 1, 2, G - 1], rng.integers(0, G, size=60)]))   # sequences 0..2 straddle the first tiles
+    hy0, hc0, _ = synth.frame_columns(77, k, 0, n)
+    assert np.array_equal(hy0, _np(y[:n])) and all(np.array_equal(h, _np(c[:n])) for h, c in zip(hc0, cols))   # host == device, bit for bit
     for g in pick:
         s, e = int(offs[g]), int(offs[g + 1])
-        ref = orc.batched_rls(_np(y[s:e]), [_np(c[s:e]) for c in cols], [0, n], half_life=21.0)
+        hy, hc, _ = synth.frame_columns(77, k, s, e)
+        ref = orc.batched_rls(hy, hc, [0, n], half_life=21.0)
         assert np.allclose(_np(coef[s:e]), ref["coef"], rtol=1e-6, atol=1e-6), g
         assert np.allclose(_np(pred[s:e]), ref["pred"], rtol=1e-6, atol=1e-6), g
 

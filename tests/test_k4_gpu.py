@@ -63,6 +63,33 @@ def _window_matrix(offs, valid, X, i, window, policy):
     return X[idx]
 
 
+def _keeps_a_never_dropped_row(offs, valid, window, min_periods):
+    """solve_rolling_ols' sliding loop starts at row mpv (ls.rs:989): a valid row older than the window when the warm-up ends is never
+    subtracted.  True when some sequence has one -- such frames stay with the chunk kernels (the tile kernels' sums are prefix differences)."""
+    for g in range(len(offs) - 1):
+        s, e = int(offs[g]), int(offs[g + 1])
+        v = np.asarray(valid[s:e]).astype(bool)
+        n, idx = e - s, np.flatnonzero(v)
+        if n < min_periods:
+            continue
+        mpv = int(idx[min_periods - 1]) + 1 if len(idx) >= min_periods else min_periods
+        jm = mpv - window - 1
+        if 0 <= jm < n and v[: jm + 1].any():
+            return True
+    return False
+
+
+def _before_warm_up(offs, valid, min_periods):
+    """rows solve_rolling_ols never writes (ls.rs:864, :893-900, :939-943): everything before row mpv - 1, and whole sequences shorter than min_periods"""
+    out = np.zeros(int(offs[-1]), dtype=bool)
+    for g in range(len(offs) - 1):
+        s, e = int(offs[g]), int(offs[g + 1])
+        idx = np.flatnonzero(np.asarray(valid[s:e]).astype(bool))
+        mpv = int(idx[min_periods - 1]) + 1 if len(idx) >= min_periods else min_periods
+        out[s: e if e - s < min_periods else min(e, s + mpv - 1)] = True
+    return out
+
+
 def _band_check(tag, got_c, ref_c, rows, offs, valid, X, window, policy, tol, alpha=None, cap=0.25, src=None):
     """The band of barely-determined windows (k + 2 .. 2k - 1 observations): every row in `rows` against the oracle at north_star's `tol`
     unless THAT window's conditioning does not allow it -- then at 1e3 cond(X'X + alpha I) eps of the window itself -- and at most `cap` of
@@ -125,6 +152,13 @@ def test_rolling_many_groups(eng, policy, k, window, min_periods, alpha, null_fr
     y, cols, offs, valid = _frame(rng, sizes, k, null_frac=null_frac)
     out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=None if valid is None else _cuda(valid),
                                     window_size=window, min_periods=min_periods, alpha=alpha, null_policy=policy)
+    if policy == "drop_window" and valid is not None:
+        # the fixed window over masked rows: the tile kernel with invalid rows as zero rows + the per-row solve table (k4c_kernel.inl MASKED),
+        # unless a sequence keeps a never-dropped row (then the chunk kernels, which walk the reference's loop)
+        mp_eff = min_periods if min_periods is not None else min(k, window)
+        fits = window <= (508 if k <= 6 else 252) or int(np.diff(offs).max()) <= 1021      # the halo forms' windows, or whole sequences per tile
+        masked_tiles = mp_eff <= window and fits and not _keeps_a_never_dropped_row(offs, valid, window, mp_eff)
+        assert eng.last_kernel.startswith("k4_rolling_tiles_masked") == masked_tiles, (eng.last_kernel, masked_tiles)
     ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy=policy, is_valid=valid)
     got_c, got_p = _np(out["coef"]), _np(out["pred"])
     assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
@@ -151,6 +185,76 @@ def test_rolling_many_groups(eng, policy, k, window, min_periods, alpha, null_fr
     well = sane & (nobs >= 2 * k)                                    # north_star's 1e-6 wherever the window holds 2k observations
     assert np.allclose(got_c[well], ref["coef"][well], rtol=1e-6, atol=1e-6), float(np.abs(got_c[well] - ref["coef"][well]).max())
     assert np.allclose(got_p[well & vm], ref["pred"][well & vm], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
+@pytest.mark.parametrize("k,window,min_periods,alpha,null_frac,shape", [
+    (6, 252, 6, None, 0.03, "long"), (6, 252, None, None, 0.03, "groups"), (1, 10, 1, None, 0.3, "long"), (3, 30, 12, None, 0.5, "groups"),
+    (6, 300, 8, 0.5, 0.1, "long"), (7, 100, 7, None, 0.1, "long"), (8, 252, 9, None, 0.05, "groups"), (10, 60, 10, None, 0.05, "groups"),
+    (9, 200, 9, None, 0.1, "long"), (6, 2000, 6, None, 0.1, "groups"), (4, 64, 4, None, 0.9, "long"), (2, 4, 2, None, 0.2, "groups"),
+    (6, 252, 6, None, 0.03, "late"),
+])
+def test_rolling_drop_window_with_nulls_on_the_tile_kernel(eng, dtype, tol, k, window, min_periods, alpha, null_frac, shape):
+    """K4c MASKED (k4c_kernel.inl): "drop_window" -- the RollingKwargs default -- on frames with validity bytes, up to 10 features.  Invalid rows are
+    zero rows of the windowed sums; which rows are NaN / solved / repeat the last solved row comes from the device-built per-row table
+    (dyn_prep.hip roll_mask_*) and is applied by the fill pass.  "groups": sequences of at most 1 021 rows (packed tiles, any window);
+    "long": cut sequences (halo waves); "late": sequences whose first 300 .. 900 rows are all null (an asset that starts trading later --
+    the warm-up ends far beyond the window, and nothing is older than it); heavy null fractions give long gated stretches whose rows repeat
+    coefficients from hundreds of rows back (across tiles and slabs).  Every row's NaN pattern and every well-posed row's values against the
+    oracle; the band of barely-determined windows at the window's own conditioning."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 13 + window % 1009 + int(100 * null_frac))
+    if shape == "groups":
+        sizes = np.concatenate([[1021, 0, 1, 2, k, k + 1, 2 * k, 1000], rng.integers(1, 900, size=24)])
+    elif shape == "late":
+        sizes = np.array([2500, 1000, 1700, 300])
+    else:
+        sizes = np.array([3000, 5, 0, 1025, 2049, 700, 4100])
+    y, cols, offs, valid = _frame(rng, sizes, k, dtype=dtype, null_frac=null_frac)
+    if shape == "late":
+        for g, lead in enumerate((900, 300, 650, 0)):
+            valid[int(offs[g]): int(offs[g]) + lead] = 0
+    mp_eff = min_periods if min_periods is not None else min(k, window)
+    kw = dict(window_size=window, min_periods=min_periods, alpha=alpha, null_policy="drop_window")
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
+    flagged = _keeps_a_never_dropped_row(offs, valid, window, mp_eff)
+    fits = window <= (508 if k <= 6 else 252) or int(np.diff(offs).max()) <= 1021
+    assert eng.last_kernel.startswith("k4_rolling_tiles_masked") == (fits and not flagged), (eng.last_kernel, flagged, fits)
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy="drop_window", is_valid=valid)
+    got_c, got_p = _np(out["coef"]), _np(out["pred"])
+    nobs = _window_obs(offs, valid, window, "drop_window")
+    src = _solved_source(ref["coef"], offs)
+    has = src >= 0
+    nsrc = np.where(has, nobs[np.maximum(src, 0)], 0)
+    # NaN pattern: before the warm-up row both are NaN; afterwards the kernel is NaN exactly where the oracle is, on every row whose source
+    # window holds at least k observations (with fewer X'X is singular: the reference's LU returns noise there, this kernel NaN)
+    pre = _before_warm_up(offs, valid, mp_eff)
+    assert np.isnan(got_c[pre]).all() and np.isnan(ref["coef"][pre]).all()
+    pinned = has & ((nsrc >= k) | (alpha is not None))
+    assert np.array_equal(np.isnan(got_c).any(axis=1)[pinned], np.isnan(ref["coef"]).any(axis=1)[pinned]), \
+        np.flatnonzero(pinned & (np.isnan(got_c).any(axis=1) != np.isnan(ref["coef"]).any(axis=1)))[:10]
+    sane = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3)
+    well = sane & has & ((nsrc >= 2 * k) | (alpha is not None))
+    if null_frac < 0.8:
+        assert well.sum() > 0.1 * has.sum()
+    assert np.allclose(got_c[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(got_c[well] - ref["coef"][well]).max())
+    vm = np.asarray(valid).astype(bool)
+    assert np.allclose(got_p[well & vm], ref["pred"][well & vm], rtol=tol, atol=tol) and np.isnan(got_p[~vm]).all()
+    if fits and not flagged:                        # on the tile route repeated rows are bit-identical copies of their source row (the fill pass)
+        rep = np.flatnonzero(has & (src != np.arange(len(src))) & pinned)
+        assert np.array_equal(got_c[rep], got_c[src[rep]], equal_nan=True)
+    band = np.flatnonzero(sane & has & (nsrc >= k + 2) & (nsrc < 2 * k) & (alpha is None))
+    _band_check(f"k4c_masked k={k} w={window} {shape} nf={null_frac} {np.dtype(dtype).name}", got_c, ref["coef"], band[:: max(1, len(band) // 150)], offs, valid,
+                np.stack(cols, axis=1), window, "drop_window", tol, alpha=alpha, src=src)
+    if fits and not flagged:                       # the same frame through the chunk kernels (the reference's loop, LU fallback included)
+        eng.set_option("ROLLING_ENGINE", "chunk")
+        try:
+            old = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
+            assert not eng.last_kernel.startswith("k4_rolling_tiles")
+        finally:
+            eng.set_option("ROLLING_ENGINE", None)
+        assert np.allclose(_np(old["coef"])[well], got_c[well], rtol=tol, atol=tol)
 
 
 @pytest.mark.parametrize("policy", ["drop", "drop_window"])
@@ -569,9 +673,9 @@ def test_rolling_divergence_band_is_pinned(eng, k, window, min_periods):
     (i)  POLS_ROLLING_ENGINE=chunk (the lane-per-chunk kernels, which have the LU) on windows holding k ... k + 1 observations:
          value-compared with the oracle wherever the oracle is finite and < 1e3, at 1e-6 or -- recorded per row -- at the bound the
          window's own conditioning allows (cond(X'X) eps: a k-row window is a square system);
-    (ii) the default route's NaN rows are a SUBSET of the rows where the oracle has no usable answer either (non-finite or > 1e3:
-         a window with fewer than k independent rows, where the reference's LU divides by zero or by rounding noise), and everywhere
-         else the two routes agree with the oracle to the same bound."""
+    (ii) round 6: the default route runs the reference's LU on the rows whose window sums have no factorisation (a small follow-up launch
+         over a list of such rows), so its NaN pattern equals the oracle's wherever it is pinned (k or more observations, or none
+         expected), and everywhere the oracle is usable the two routes agree with it to the same bound."""
     from oracle import orc
 
     rng = np.random.default_rng(1000 * k + window)
@@ -610,12 +714,9 @@ def test_rolling_divergence_band_is_pinned(eng, k, window, min_periods):
     mp_eff = min_periods if min_periods is not None else min(k, window)
     pinned = (nobs >= k) | (nobs < mp_eff)
     assert np.array_equal(np.isnan(c_c)[pinned], np.isnan(ref["coef"])[pinned])
-    # (ii) the default route
-    # (with fewer observations than features X'X is exactly singular: what the reference's LU returns there -- a finite number now and then --
-    # is rounding noise, the default route says NaN)
-    d_nan = np.isnan(d_c).any(axis=1)
-    assert not (d_nan & usable & (nobs >= k)).any(), np.flatnonzero(d_nan & usable & (nobs >= k))[:10]
-    assert np.array_equal(d_nan[nobs >= k] | ~usable[nobs >= k], ~usable[nobs >= k])
+    # (ii) the default route: a window without an L D L' factorisation goes through the reference's LU too (k4c_lu_fix_kernel re-sums the window
+    # and eliminates with partial pivoting, ls.rs:732-734), so its NaN pattern IS the oracle's wherever that is pinned
+    assert np.array_equal(np.isnan(d_c)[pinned], np.isnan(ref["coef"])[pinned])
     for i in np.flatnonzero(usable & (nobs >= k)):
         tol = bound(i)
         assert np.allclose(d_c[i], ref["coef"][i], rtol=tol, atol=tol), (i, int(nobs[i]), tol)
