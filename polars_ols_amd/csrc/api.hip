@@ -206,7 +206,8 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "K1_PERSIST_SUB")) o.k1_persist_sub = on ? std::atoi(v) : d.k1_persist_sub;
     else if (ieq(key, "K1T_SUB32")) o.k1t_sub32 = on ? (std::atoi(v) != 0) : d.k1t_sub32;
     else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : ieq(v, "k2w") ? 4 : 0;
-    else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : 0;
+    else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : ieq(v, "halo") ? 4 : 0;
+    else if (ieq(key, "RLS_SPINS")) o.rls_spin_limit = on ? std::atoi(v) : d.rls_spin_limit;
     else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : ieq(v, "nocompact") ? 3 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
@@ -216,7 +217,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
-                                       "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1_WG", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
+                                       "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1_WG", "RLS_SPINS", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
                                        "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE", "KG_SINGLE_BUFFER", "PREDICT_LOOP", "NO_CLASSES"};
     char name[64];
@@ -1673,10 +1674,14 @@ struct DynState {
     bool post = false;               // predictions need the 1 / sqrt(w) un-scaling and / or the validity mask
     DynPrepArgs pa;
     pols_batch tables;               // the batch as build_chunk_tables should see it (validity bytes may now live on the device)
+    bool deferred = false;           // the zero-filling rewrite of the columns has been left out (see dynamic_prologue's may_defer)
+    std::vector<void *> outp;        // ... and these are the columns it would write
 };
 
+// may_defer: the caller has a kernel that masks invalid rows itself (the masked tile kernel of the rolling entry): the zero-filling rewrite
+// of the columns -- a read and a write of the whole frame -- is skipped and left to dynamic_rewrite_deferred() should that kernel not be taken.
 static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, int null_policy, pols_out *o, const int64_t **d_offs, int64_t *max_rows,
-                            Staged *st, DynState *ds) {
+                            Staged *st, DynState *ds, bool may_defer = false) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if ((rc = check_batch(b, o, K4Y_KMAX))) return rc;
@@ -1731,15 +1736,30 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, int null_policy,
         }
         if (has_w || icpt || some_invalid || some_null) {
             // (rows left out of the fit hold the nulls that put them there: zero-filled too, so that no kernel ever multiplies a NaN by 0)
-            if ((rc = dyn_rewrite_launch(ctx, b->dtype, pa))) return rc;
-            st->y = pa.y_out;
-            st->x.assign(outp.begin(), outp.end());
+            if (may_defer && !has_w && !icpt && st->valid != nullptr) {
+                ds->deferred = true;                          // the columns stay the caller's; dynamic_rewrite_deferred() does this later if needed
+                ds->outp.assign(outp.begin(), outp.end());
+            } else {
+                if ((rc = dyn_rewrite_launch(ctx, b->dtype, pa))) return rc;
+                st->y = pa.y_out;
+                st->x.assign(outp.begin(), outp.end());
+            }
         }
     }
     ds->post = (has_w || st->valid != nullptr) && st->pred != nullptr;
     pa.pred = st->pred;
     pa.valid_post = st->valid;
     if (!has_w) pa.sw_out = nullptr;
+    return POLS_OK;
+}
+
+static int dynamic_rewrite_deferred(pols_ctx *ctx, const pols_batch *b, Staged *st, DynState *ds) {
+    if (!ds->deferred) return POLS_OK;
+    int rc = dyn_rewrite_launch(ctx, b->dtype, ds->pa);
+    if (rc) return rc;
+    st->y = ds->pa.y_out;
+    st->x.assign(ds->outp.begin(), ds->outp.end());
+    ds->deferred = false;
     return POLS_OK;
 }
 
@@ -1875,7 +1895,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     const bool wide = kf > K4_KMAX, xwide = kf > POLS_MAX_FEATURES;
     bool scan = max_rows > 4096 || wide;
     if (ctx->opt.rls_engine == 1 && !wide) scan = false;
-    if (ctx->opt.rls_engine >= 2) scan = true;
+    if (ctx->opt.rls_engine == 2 || ctx->opt.rls_engine == 3) scan = true;
     // Up to 9 features (8 + intercept): the row-parallel, read-once kernel (K3c, k3c_scan.hip) whatever the sequence lengths -- every access a
     // 16-byte one down the row axis, so it needs 16-byte aligned columns / outputs (anything else: the chunk kernels below).
     // POLS_RLS_ENGINE=seq|chunk go back to K3 / the lane-per-chunk K3s.
@@ -1918,6 +1938,20 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
         if (halo) {
             if ((rc = ensure_tile_seq0(ctx, b, tile_rows, n_tiles, &c.tile_seq0))) return rc;
             c.halo_batches = halo; c.log2ff = std::log2(c.ff); c.ffstep = std::pow(c.ff, (double)(tile_rows - 4));
+            // ... and when the rows that matter all lie in the ONE tile in front (H <= 1 024 = a four-wave tile, up to 6 features), that tile's own
+            // aggregate is all the carry-in needs: the look-back-one form (k3c_scan.hip MODE 3) -- every tile publishes its aggregate early, picks up
+            // its predecessor's behind its own scan, and re-reads nothing.  POLS_RLS_ENGINE=halo keeps the halo form.
+            const size_t gbytes = (size_t)n_tiles * 32 * 16;
+            if (kf <= 6 && halo <= 4 && tile_rows == 1024 && n_tiles > 1 && gbytes < ((size_t)1 << 31) && ctx->opt.rls_engine != 4) {
+                void *g = nullptr;
+                if ((rc = ensure_scratch(ctx, 28, gbytes, &g))) return rc;
+                if (ctx->k3c_gran_ptr != g || ctx->scratch[28].cap != ctx->k3c_gran_cap) {       // fresh or grown: no stale tag may survive
+                    POLS_HIP(hipMemsetAsync(g, 0, ctx->scratch[28].cap, ctx->stream));
+                    ctx->k3c_gran_ptr = g; ctx->k3c_gran_cap = ctx->scratch[28].cap;
+                }
+                c.gran = g; c.gran_bytes = (int64_t)gbytes; c.epoch = ++ctx->k3c_epoch;
+                c.spin_limit = ctx->opt.rls_spin_limit >= 0 ? ctx->opt.rls_spin_limit : 64;
+            }
         }
         if ((rc = k3c_launch(ctx, b->dtype, c))) return rc;
     } else if (scan) {
@@ -2091,7 +2125,9 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     int64_t max_rows = 0;
     Staged st;
     DynState ds;
-    int rc = dynamic_prologue(ctx, b, p->null_policy, o, &d_offs, &max_rows, &st, &ds);
+    // ("drop_window" without weights / intercept on up to 10 features: the masked tile kernel reads the caller's columns as they are)
+    const bool may_defer = p->null_policy == POLS_NULL_DROP_WINDOW && b->n_features <= K4C_KMAX && ctx->opt.rolling_engine != 1 && ctx->opt.rolling_engine != 3;
+    int rc = dynamic_prologue(ctx, b, p->null_policy, o, &d_offs, &max_rows, &st, &ds, may_defer);
     if (rc) return rc;
     if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
     if (o->resid) return fail(POLS_ERR_INVALID, "rolling: residuals are target - predictions in the caller (least_squares.py:239)");
@@ -2262,11 +2298,14 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
                          b_s8 = round256(sizeof(int64_t) * (size_t)(n_slabs + 1)), b_g8 = round256(sizeof(int64_t) * (size_t)(G + 1)),
                          b_g4 = round256(sizeof(int32_t) * (size_t)G);
             void *d = nullptr;
-            if ((rc = ensure_scratch(ctx, 19, 256 + 2 * b_r2 + b_sol + b_sc + 3 * b_s8 + 2 * b_g8 + b_g4, &d))) return rc;   // (slot 19: the compaction's, never live here)
+            const int64_t n_blk = (n_slabs + 1023) / 1024;
+            const size_t b_blk = round256(sizeof(unsigned long long) * 2 * (size_t)n_blk);
+            if ((rc = ensure_scratch(ctx, 19, 256 + b_blk + 2 * b_r2 + b_sol + b_sc + 3 * b_s8 + 2 * b_g8 + b_g4, &d))) return rc;   // (slot 19: the compaction's, never live here)
             char *q = static_cast<char *>(d);
             RollMaskArgs ma;
             std::memset(&ma, 0, sizeof(ma));
             ma.flag = reinterpret_cast<int32_t *>(q); q += 256;
+            ma.blk_cnt = reinterpret_cast<unsigned long long *>(q); ma.blk_last = ma.blk_cnt + n_blk; q += b_blk;
             ma.incl = reinterpret_cast<uint16_t *>(q); q += b_r2;
             ma.code = reinterpret_cast<uint16_t *>(q); q += b_r2;
             ma.solved = reinterpret_cast<uint8_t *>(q); q += b_sol;
@@ -2303,6 +2342,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
             }
         }
     }
+    if ((rc = dynamic_rewrite_deferred(ctx, b, &st, &ds))) return rc;   // the masked tile kernel did not take the frame: the chunk kernels want zero-filled columns
     K4Args a;
     std::memset(&a, 0, sizeof(a));
     // 9..32 features on a null-free frame, min_periods <= window: one wave per chunk, the inverse distributed over its registers and the

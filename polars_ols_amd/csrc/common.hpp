@@ -57,7 +57,8 @@ struct Options {
     int k1t_rc4 = -1;             // POLS_K1T_RC4        -1: default rule
     int k1t_sub8 = -1;            // POLS_K1T_SUB8       eight-lane K1t teams: -1 default rule (frames that fit 16 chunk slots), 0 never, 1 only frames that fit 8
     int static_engine = 0;        // POLS_STATIC_ENGINE  0 auto, 1 "stream" (three launches), 2 "k2" (wherever it fits), 3 "nok2"
-    int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq" (K3), 2 "scan" (K3c up to 8 features, else the chunk kernels), 3 "chunk" (lane-per-chunk K3s)
+    int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq" (K3), 2 "scan" (K3c up to 8 features, else the chunk kernels), 3 "chunk" (lane-per-chunk K3s), 4 "halo" (K3c: the halo form where the look-back form would run)
+    int rls_spin_limit = -1;      // POLS_RLS_SPINS      K3c look-back form: polls before a wave falls back to the halo (-1: default 64; 0: always fall back -- the test of that path)
     int rolling_engine = 0;       // POLS_ROLLING_ENGINE 0 auto (K4c tiles where they apply), 1 "chunk" (lane-per-chunk K4)
     int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
@@ -93,8 +94,8 @@ struct pols_ctx {
     // (nothing else may take this slot: the tables are cached across calls), [11] timeline stamps, [12] Arrow ingestion,
     // [13] collective staging, [14] dynamic-path prep / null-policy compaction (dyn_prep.hip), [15] their host-batch outputs
     // [16] sequence-start bytes of the row-parallel dynamic kernels (K3c / K4c), [17] null-weight-filled copy of a DEVICE batch's weights column (static entries), [18] first rows of K3c's packed tiles, [19..22] row compaction of the rolling entry (columns, coefficients, start bytes, tile map), [23] segment tables + partial Gram matrices of the streamed static path,
-    // [24] group lists of the size classes, [25] K3c halo form: first row of the sequence in front of every tile, [26] segment tables of the last size class, [27] K4c: rows without a factorisation (the LU list)
-    pols::Scratch scratch[28];
+    // [24] group lists of the size classes, [25] K3c halo form: first row of the sequence in front of every tile, [26] segment tables of the last size class, [27] K4c: rows without a factorisation (the LU list), [28] K3c look-back form: the tiles' record granules
+    pols::Scratch scratch[29];
     pols::Options opt;
     bool timing = false;
     int timing_stride = 1;                   // time every n-th eligible launch (pols_timing_enable(ctx, n))
@@ -139,6 +140,9 @@ struct pols_ctx {
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t cut[3] = {0, 0, 0}, n[4] = {0, 0, 0, 0}; int n_cut = 0;
              std::vector<int32_t> host_last; } class_cache;   // group lists of the size classes (slot 24; host_last: the last class' ids, for its segment tables)
     struct { const void *ptr = nullptr; uint64_t offs_id = 0; int64_t n_groups = -1, n_rows = -1, seg_target = 0, n_seg = 0, max_len = 0, max_seg = 0, class_key = 0, n_items = 0; size_t nz2 = 0; bool nulls = false; } seg_cache[2];   // [0] whole-frame tables (slot 23), [1] the last size class' tables (slot 26)
+    const void *k3c_gran_ptr = nullptr;      // K3c look-back form (scratch slot 28): the slot's address when it was last zeroed; the launches' running tag
+    unsigned long long k3c_epoch = 0;
+    size_t k3c_gran_cap = 0;
     const void *k4c_fix_ptr = nullptr;       // K4c's LU list (scratch slot 27): the slot's address when its counters were last zeroed, and whose turn it is
     uint64_t k4c_fix_turn = 0;
     // sequence-start bytes (scratch slot 16): rebuilt when other offsets arrive

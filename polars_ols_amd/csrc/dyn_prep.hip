@@ -359,9 +359,9 @@ int valid_tables_launch(pols_ctx *ctx, const ValidTablesArgs &a) {
 // the window holds gate_n valid rows (n_valid_window >= n_valid, :1013 / :1022: the valid rows among (i - window, i], from row 1 on while
 // i < window -- the saturating_sub of :990), and repeats the last solved row's coefficients otherwise.  All of it is a function of the
 // validity bytes.  P(r) = valid rows of the FRAME at or before row r = slab_base[r / 256] + incl[r] (a 16-bit count inside the slab):
-//   rm_count_kernel   slab totals + incl[]            (then rc_scan_kernel / rc_groups_kernel: slab_base, c_offs = P before every group)
+//   rm_count_kernel   slab totals + incl[]            (then rm_scan_kernel<false>: slab_base)
 //   rm_groups_kernel  per sequence mpv / gate_n, and the flag for the one shape the tile kernel cannot take
-//   rm_rows_kernel    every row: solved / NaN / where the last solved row of its slab is;   rm_carry_kernel: ... of the slabs before
+//   rm_rows_kernel    every row: solved / NaN / where the last solved row of its slab is;   rm_scan_kernel<true>: ... of the slabs before
 __global__ void __launch_bounds__(RC_SLAB) rm_count_kernel(const RollMaskArgs a) {
     __shared__ unsigned wave_cnt[RC_SLAB / 64];
     const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
@@ -376,7 +376,8 @@ __device__ __forceinline__ int64_t rm_prefix(const RollMaskArgs &a, int64_t r) {
 __global__ void __launch_bounds__(256) rm_groups_kernel(const RollMaskArgs a) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= a.n_groups) return;
-    const int64_t s = a.offs[g], n = a.offs[g + 1] - s, before = a.c_offs[g], tot = a.c_offs[g + 1] - before, mp = a.min_periods;
+    const int64_t s = a.offs[g], n = a.offs[g + 1] - s, mp = a.min_periods;
+    const int64_t before = s > 0 ? rm_prefix(a, s - 1) : 0, tot = n > 0 ? rm_prefix(a, s + n - 1) - before : 0;   // valid rows before / inside the sequence
     // ls.rs:881-891: min_periods_valid = the row at which the min_periods-th valid observation arrives (else it stays min_periods):
     // the first row of the sequence whose prefix reaches `before + mp` (the prefix is monotone: a binary search)
     int64_t mpv = mp;
@@ -440,32 +441,51 @@ __global__ void __launch_bounds__(RC_SLAB) rm_rows_kernel(const RollMaskArgs a) 
     if (threadIdx.x == RC_SLAB - 1) a.slab_last[blockIdx.x] = loc >= 0 ? (int64_t)blockIdx.x * RC_SLAB + loc : -1;
 }
 
-__global__ void __launch_bounds__(1024) rm_carry_kernel(const RollMaskArgs a) {           // one workgroup: exclusive running maximum over the slabs
+// Exclusive prefix over the slabs, one workgroup per 1 024 of them: rm_blk_kernel reduces every block of 1 024 slabs to one value, rm_scan_kernel
+// sums the blocks below its own (a few dozen values) and scans its block in LDS -- two launches of ~40 workgroups (3 + 5 us) instead of one
+// workgroup looping over 39 000 slabs (55 us on a 10M-row frame; per-block totals by atomics from the producing kernels: 39 000 atomics on 39
+// words, 250 us).
+template <bool MAXSCAN>
+__global__ void __launch_bounds__(1024) rm_blk_kernel(const RollMaskArgs a) {
     __shared__ long long part[1024 / 64];
-    __shared__ long long carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = -1;
+    const int64_t s = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    long long v = s < a.n_slabs ? (MAXSCAN ? (long long)a.slab_last[s] + 1 : (long long)a.slab_cnt[s]) : 0;    // (MAXSCAN: row + 1, 0 = none)
+    for (int off = 32; off >= 1; off >>= 1) { const long long o = __shfl_xor(v, off); v = MAXSCAN ? (v > o ? v : o) : v + o; }
+    if (lane == 0) part[wave] = v;
     __syncthreads();
-    for (int64_t s0 = 0; s0 < a.n_slabs; s0 += 1024) {
-        const int64_t s = s0 + threadIdx.x;
-        const long long v = s < a.n_slabs ? (long long)a.slab_last[s] : -1;
-        long long incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const long long up = __shfl_up(incl, off);
-            if (lane >= off) incl = incl > up ? incl : up;
-        }
-        if (lane == 63) part[wave] = incl;
-        __syncthreads();
-        long long before = carry;
-        for (int w = 0; w < wave; ++w) before = before > part[w] ? before : part[w];
-        const long long excl_in_wave = __shfl_up(incl, 1);
-        long long excl = before;
-        if (lane > 0) excl = excl > excl_in_wave ? excl : excl_in_wave;
-        if (s < a.n_slabs) a.slab_carry[s] = excl;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before > incl ? before : incl;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = part[0];
+        for (int w = 1; w < 1024 / 64; ++w) t = MAXSCAN ? (t > part[w] ? t : part[w]) : t + part[w];
+        (MAXSCAN ? a.blk_last : a.blk_cnt)[blockIdx.x] = (unsigned long long)t;
     }
+}
+
+// MAXSCAN = false: slab_base[s] = valid rows before slab s (slab_base[n_slabs] = all);  true: slab_carry[s] = the last solved row before slab s.
+template <bool MAXSCAN>
+__global__ void __launch_bounds__(1024) rm_scan_kernel(const RollMaskArgs a) {
+    __shared__ long long part[1024 / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto op = [](long long x, long long y) { return MAXSCAN ? (x > y ? x : y) : x + y; };
+    const long long ident = MAXSCAN ? -1 : 0;
+    long long before = ident;                                // the blocks below this one
+    for (int64_t b2 = lane; b2 < (int64_t)blockIdx.x; b2 += 64)
+        before = op(before, MAXSCAN ? (long long)a.blk_last[b2] - 1 : (long long)a.blk_cnt[b2]);
+    for (int off = 32; off >= 1; off >>= 1) before = op(before, __shfl_xor(before, off));
+    const int64_t s = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const long long v = s < a.n_slabs ? (MAXSCAN ? (long long)a.slab_last[s] : (long long)a.slab_cnt[s]) : ident;
+    long long incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long up = __shfl_up(incl, off);
+        if (lane >= off) incl = op(incl, up);
+    }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) before = op(before, part[w]);
+    const long long up1 = __shfl_up(incl, 1);
+    const long long excl = lane > 0 ? op(before, up1) : before;
+    if (s < a.n_slabs) { if (MAXSCAN) a.slab_carry[s] = excl; else a.slab_base[s] = excl; }
+    if (!MAXSCAN && s == a.n_slabs - 1) a.slab_base[a.n_slabs] = op(before, incl);
 }
 
 // The fill pass behind the masked tile kernel: a row the reference does not solve takes NaN (before the warm-up) or the coefficients of the
@@ -473,41 +493,46 @@ __global__ void __launch_bounds__(1024) rm_carry_kernel(const RollMaskArgs a) { 
 // masked row, src/expressions.rs:695-700).  Reads one byte per row; everything else only for the rows it rewrites.
 template <typename T>
 __global__ void __launch_bounds__(256) rm_fill_kernel(const RollMaskArgs a) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.n_rows || a.solved[r]) return;                // solved here
-    const int code = a.code[r];
-    const int64_t slab0 = r & ~(int64_t)(RC_SLAB - 1);
+    const int64_t r4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;     // four rows per thread: one 32-bit load of their solved bytes
+    if (r4 >= a.n_rows) return;
+    if (r4 + 4 <= a.n_rows && *reinterpret_cast<const unsigned *>(a.solved + r4) == 0x01010101u) return;   // all four solved here
     const int k = a.k;
     T *coef = static_cast<T *>(a.coef);
     T *pred = static_cast<T *>(a.pred);
     const T qnan = nan_if<T>(1u, T(0));
-    if (code == 1) {
-        if (coef) for (int j = 0; j < k; ++j) coef[r * k + j] = qnan;
-        if (pred) pred[r] = qnan;
-        return;
+    for (int64_t r = r4; r < r4 + 4 && r < a.n_rows; ++r) {
+        if (a.solved[r]) continue;
+        const int code = a.code[r];
+        const int64_t slab0 = r & ~(int64_t)(RC_SLAB - 1);
+        if (code == 1) {
+            if (coef) for (int j = 0; j < k; ++j) coef[r * k + j] = qnan;
+            if (pred) pred[r] = qnan;
+            continue;
+        }
+        const int64_t src = code - 2 < RC_SLAB ? slab0 + (code - 2) : a.slab_carry[r >> 8];
+        const bool vr = a.valid[r] != 0;
+        T c[10], xv[10];                                      // every load of the row issued before the first use (k <= 10)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            c[j] = (j < k && coef) ? coef[src * k + j] : T(0);
+            xv[j] = (j < k && vr) ? static_cast<const T *>(a.x[j])[r] : T(0);
+        }
+        T p = T(0);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            if (j < k) { if (coef) coef[r * k + j] = c[j]; p = fma(xv[j], c[j], p); }
+        }
+        if (pred) pred[r] = vr ? p : qnan;
     }
-    const int64_t src = code - 2 < RC_SLAB ? slab0 + (code - 2) : a.slab_carry[r >> 8];
-    const bool vr = a.valid[r] != 0;
-    T p = T(0);
-    for (int j = 0; j < k; ++j) {
-        const T c = coef ? coef[src * k + j] : T(0);
-        if (coef) coef[r * k + j] = c;
-        if (vr) p = fma(static_cast<const T *>(a.x[j])[r], c, p);
-    }
-    if (pred) pred[r] = vr ? p : qnan;
 }
 
 int roll_mask_tables_launch(pols_ctx *ctx, const RollMaskArgs &a) {
     if (a.n_rows == 0 || a.n_groups == 0) return POLS_OK;
     static_assert(RC_SLAB == 256, "the slab arithmetic of rm_prefix / rm_fill_kernel");
-    RowCompactArgs ra;
-    std::memset(&ra, 0, sizeof(ra));
-    ra.valid = a.valid; ra.offs = a.offs; ra.n_rows = a.n_rows; ra.n_groups = a.n_groups; ra.n_slabs = a.n_slabs;
-    ra.slab_cnt = a.slab_cnt; ra.slab_base = a.slab_base; ra.c_offs = a.c_offs;
     POLS_HIP(hipMemsetAsync(a.flag, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(rm_count_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
-    hipLaunchKernelGGL(rc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ra);
-    hipLaunchKernelGGL(rc_groups_kernel, dim3((unsigned)((a.n_groups + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ra);
+    hipLaunchKernelGGL(rm_blk_kernel<false>, dim3((unsigned)((a.n_slabs + 1023) / 1024)), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rm_scan_kernel<false>, dim3((unsigned)((a.n_slabs + 1023) / 1024)), dim3(1024), 0, ctx->stream, a);
     hipLaunchKernelGGL(rm_groups_kernel, dim3((unsigned)((a.n_groups + 255) / 256)), dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
@@ -516,14 +541,15 @@ int roll_mask_tables_launch(pols_ctx *ctx, const RollMaskArgs &a) {
 int roll_mask_rows_launch(pols_ctx *ctx, const RollMaskArgs &a) {
     if (a.n_rows == 0 || a.n_groups == 0) return POLS_OK;
     hipLaunchKernelGGL(rm_rows_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
-    hipLaunchKernelGGL(rm_carry_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rm_blk_kernel<true>, dim3((unsigned)((a.n_slabs + 1023) / 1024)), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rm_scan_kernel<true>, dim3((unsigned)((a.n_slabs + 1023) / 1024)), dim3(1024), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
 
 int roll_mask_fill_launch(pols_ctx *ctx, int dtype, const RollMaskArgs &a) {
     if (a.n_rows == 0 || (!a.coef && !a.pred)) return POLS_OK;
-    const dim3 grid((unsigned)((a.n_rows + 255) / 256));
+    const dim3 grid((unsigned)((a.n_rows + 1023) / 1024));
     if (dtype == POLS_F32) hipLaunchKernelGGL(rm_fill_kernel<float>, grid, dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(rm_fill_kernel<double>, grid, dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());

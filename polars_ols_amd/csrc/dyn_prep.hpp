@@ -124,6 +124,7 @@ struct RollMaskArgs {
     int64_t *g_mpv;              // n_groups: min_periods_valid (n + 1: the whole sequence is NaN)
     int32_t *g_gate;             // n_groups: n_valid of the gate
     int32_t *flag;               // bit 0: some sequence keeps a valid row older than its window in the warm-up sum
+    unsigned long long *blk_cnt, *blk_last;   // per 1 024 slabs: valid rows / (last solved row + 1) (rm_blk_kernel)
     uint8_t *solved;             // n_rows: 1 on the rows the reference solves
     uint16_t *code;              // n_rows: 0 solved here; 1 NaN; 2 + j: repeats row j of its slab; 2 + 256: repeats slab_carry[slab]
     int64_t *slab_last, *slab_carry;   // n_slabs each

@@ -206,18 +206,72 @@ __global__ void __launch_bounds__(64) k3c_top_scan_kernel(const K3cArgs a) {
     }
 }
 
+// LOOK-BACK form, fallback: components [Q0, Q1) of the decayed sums over the a.halo_batches 256-row batches in front of the tile that starts at
+// row tbase, re-accumulated by ONE wave; rows before s0 (the sequence's first row) are left out; component q lands in lane q's cv.
+template <typename T, int K, int R, int Q0, int Q1>
+__device__ __forceinline__ void k3c_slow_halo_piece(const K3cArgs &a, const int64_t tbase, const int64_t s0, const int lane, const double ff, double &cv) {
+    constexpr int NX = K4N<K>::NX, NP = Q1 - Q0;
+    if constexpr (NP > 0) {
+        double hacc[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) hacc[q] = 0.0;
+        const double f252 = exp2(252.0 * a.log2ff);
+#pragma unroll 1
+        for (int j = a.halo_batches - 1; j >= 0; --j) {
+            const int64_t base = tbase - 256 * (int64_t)(j + 1) + lane * R;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) hacc[q] *= f252;
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = base + r;
+                const bool in = row >= s0;                               // (s0 >= 0)
+                const int64_t ic = row < 0 ? 0 : row;
+                double hx[K];
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) hx[jj] = in ? (double)static_cast<const T *>(a.x[jj])[ic] : 0.0;
+                const double hyr = in ? (double)static_cast<const T *>(a.y)[ic] : 0.0;
+#pragma unroll
+                for (int p = 0; p < K; ++p) {
+#pragma unroll
+                    for (int q = p; q < K; ++q) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int idx = tri_index<K>(p, q);
+                        if (idx >= Q0 && idx < Q1) hacc[idx - Q0] = fma(ff, hacc[idx - Q0], hx[p] * hx[q]);
+                    }
+                    if (NX + p >= Q0 && NX + p < Q1) hacc[NX + p - Q0] = fma(ff, hacc[NX + p - Q0], hx[p] * hyr);
+                }
+            }
+        }
+        const double wgt = exp2((double)(252 - lane * R) * a.log2ff);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            double v = hacc[q] * wgt;
+            v += dpp_get0<0x111>(v); v += dpp_get0<0x112>(v); v += dpp_get0<0x114>(v); v += dpp_get0<0x118>(v);   // row sums in lanes 15 / 31 / 47 / 63
+            v += dpp_get0<0x142>(v); v += dpp_get0<0x143>(v);                                                      // lane 63: the wave's sum
+            const double tot = k1p_readlane(v, 63);
+            cv = lane == Q0 + q ? tot : cv;
+        }
+    }
+}
+
+// MODE 0 / 1: the two passes of the scan form; 2: the HALO form (step H); 3: the LOOK-BACK-ONE form -- a finite half-life makes tile t's
+// carry-in a function of tile t - 1's LOCAL aggregate alone (no chain), so every tile publishes that aggregate early (step E, before its
+// scan) as self-validating granules and picks its predecessor's up after its own scan; a wave whose predecessor has not published within the
+// spin limit re-accumulates the halo itself -- correctness never depends on the order in which workgroups are dispatched.
 template <typename T, int K, int R, int WAVES, int MODE>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1)) k3c_kernel(const K3cArgs a) {
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NCP = K3C_NCP;
     static_assert(NT + 1 <= NCP && NT + 1 <= 128, "at most two components per lane in the cross-wave steps");
     static_assert(R == 4, "validity / start bytes travel as one 32-bit word per run");
-    __shared__ double s_agg[WAVES][NT + 1];      // wave aggregates (slot NT: the decay)
+    __shared__ double s_aw[2][WAVES][NT + 1];    // [0]: wave aggregates (slot NT: the decay); [1]: carry-in of every wave
+    double (&s_agg)[WAVES][NT + 1] = s_aw[0];
+    double (&s_wfull)[WAVES][NT + 1] = s_aw[1];
     __shared__ int s_closed[WAVES];              // the aggregate starts at a sequence start inside the wave
-    __shared__ double s_wfull[WAVES][NT + 1];    // carry-in of every wave
     // every lane parks its run here between A and D (its own words only: no synchronisation) -- the scan and the look-back then
     // run without R x (K + 1) row values in registers
     __shared__ T s_x[MODE >= 1 ? WAVES : 1][R * K][DYN_STAGE_STRIDE];   // (targets and predictions stay in registers)
-    __shared__ double s_hagg[MODE == 2 ? WAVES : 1][NT + 1];   // HALO form: every wave's share of the decayed sums over the rows in front of the tile
+    __shared__ double s_hagg[MODE >= 2 ? WAVES : 1][NT + 1];   // HALO form: every wave's share of the decayed sums over the rows in front of the tile; LOOK-BACK: every wave's share of the tile's own aggregate
+    __shared__ int s_eclosed[MODE == 3 ? WAVES : 1];          // LOOK-BACK: the wave holds a sequence start
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #define K3C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     int64_t t = blockIdx.x;
@@ -405,11 +459,69 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
             for (int j = 0; j < K; ++j) s_x[wv][r * K + j][lane] = (T)x[r][j];
         }
     }
+    const unsigned long long hmask = __ballot(head);
+    using U4 = __attribute__((ext_vector_type(4))) unsigned;
+    [[maybe_unused]] U4 pg = {0u, 0u, 0u, 0u};               // LOOK-BACK: this lane's granule of the predecessor's record
+    if constexpr (MODE == 3) {
+        // ---- E: the tile's own aggregate, EARLY (the successor needs it after ITS scan: published now it has a whole scan's time to arrive).
+        // A lane's composite Tl carried to the tile's last row is Tl x ff^(rows behind its run) -- every row decays by ff on a null-free frame --
+        // from the wave's last sequence start on; the 64 lanes' terms are summed like step H's (two DPP steps + a table in the parking slots,
+        // which are still empty: the rows are parked below), half of the components at a time.
+        static_assert(K3cLaneVec<NT>::NS == 1, "one state component per lane");
+        const int hi_l = hmask ? 63 - __clzll(hmask) : 0;
+        const bool incl = lane >= hi_l;
+        const double W = exp2((double)(WAVES * 64 * R - (wv * 64 + lane) * R - R) * a.log2ff);
+        // (the table: this wave's 2 (NT + 1) doubles of the s_agg | s_wfull region, idle until step B -- three DPP steps leave every 8 lanes' sum in
+        // their last lane, those 8 lanes write a [PIECE][9] table, lane q adds up row q)
+        constexpr int PIECE = (2 * (NT + 1)) / 9 < 1 ? 1 : (2 * (NT + 1)) / 9;
+        double *tr = &s_aw[0][0][0] + wv * 2 * (NT + 1);
+#pragma unroll
+        for (int q0 = 0; q0 < NT; q0 += PIECE) {
+            double c[PIECE];
+#pragma unroll
+            for (int q = 0; q < PIECE; ++q) c[q] = (q0 + q < NT && incl) ? Tl[q0 + q < NT ? q0 + q : 0] * W : 0.0;
+#pragma unroll
+            for (int q = 0; q < PIECE; ++q) c[q] += dpp_get0<0x111>(c[q]);           // row_shr:1
+#pragma unroll
+            for (int q = 0; q < PIECE; ++q) c[q] += dpp_get0<0x112>(c[q]);           // row_shr:2
+#pragma unroll
+            for (int q = 0; q < PIECE; ++q) c[q] += dpp_get0<0x114>(c[q]);           // row_shr:4
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if ((lane & 7) == 7) {
+#pragma unroll
+                for (int q = 0; q < PIECE; ++q) tr[q * 9 + (lane >> 3)] = c[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < PIECE && q0 + lane < NT) {
+                double hs = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hs += tr[lane * 9 + i];
+                s_hagg[wv][q0 + lane] = hs;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) s_eclosed[wv] = hmask != 0;
+        __syncthreads();
+        // the record: NT granules {value, tag = epoch << 1 | "holds a sequence start"} of 16 bytes, each written by ONE write-through store and
+        // validated by its own tag (no flag, no fence: MI355X_MICROARCH.md, hand-off granules); tile t's granule q at (32 t + q) 16
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.gran, 0, (int)a.gran_bytes, 0x00020000);
+        if (wv == WAVES - 1 && lane < NT) {
+            double rec = 0.0;
+            unsigned long long closed = 0;
+            for (int w2 = WAVES - 1; w2 >= 0; --w2) {         // the waves from the tile's last sequence start on (their terms are already carried to the tile's end)
+                rec += s_hagg[w2][lane];
+                if (s_eclosed[w2]) { closed = 1; break; }
+            }
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(rec), tg = (a.epoch << 1) | closed;
+            const U4 g = {(unsigned)vb, (unsigned)(vb >> 32), (unsigned)tg, (unsigned)(tg >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (int)((t * 32 + lane) * 16), 0, /*sc1*/ 16);
+        }
+        if (t > 0 && lane < NT) pg = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((t - 1) * 32 + lane) * 16), 0, /*sc1*/ 16);   // first look, behind the scan
+    }
 
     __builtin_amdgcn_sched_barrier(0);
     K3C_STAMP(1);
     // ---- B: segmented inclusive scan over the lanes
-    const unsigned long long hmask = __ballot(head);
     const unsigned long long upto = hmask & (~0ull >> (63 - lane));          // heads at lanes <= lane
     const int h = upto ? 63 - __clzll(upto) : -1;
     k3c_seg_scan<NT>(Dl, Tl, h, lane);
@@ -472,6 +584,44 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
                 for (int w2 = 0; w2 < WAVES; ++w2) cv += s_hagg[w2][lane];
             }
             cq.v[0] = lane == NT ? 1.0 : cv;
+        } else if constexpr (MODE == 3) {
+            // LOOK-BACK: the carry-in = tile t - 1's record (its aggregate from its last sequence start on, carried to its last row) + -- when it holds
+            // no sequence start -- the prior decayed over the rows since the sequence's first row (exact, like the halo form's); what lies
+            // further back than tile t - 1 is dropped: ff^(tile rows) <= 2^-36 (the host's route condition)
+            const int64_t s0 = a.tile_seq0[t];
+            const double pw = exp2((double)(tbase - s0) * a.log2ff) * ip0;
+            double pv = 0.0;
+#pragma unroll
+            for (int p = 0; p < K; ++p) {
+                pv = lane == tri_index<K>(p, p) ? pw : pv;
+                if (a.mean0) pv = lane == NX + p ? pw * a.mean0[p] : pv;
+            }
+            double cv = 0.0;
+            bool got = t == 0, pclosed = false;
+            if (t > 0) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.gran, 0, (int)a.gran_bytes, 0x00020000);
+                for (int spins = 0;; ++spins) {
+                    const unsigned long long tg = ((unsigned long long)pg[3] << 32) | pg[2];
+                    if (__all(lane >= NT || (tg >> 1) == a.epoch)) { got = true; break; }
+                    if (spins >= a.spin_limit) break;
+                    __builtin_amdgcn_s_sleep(16);
+                    if (lane < NT) pg = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((t - 1) * 32 + lane) * 16), 0, /*sc1*/ 16);
+                }
+                if (got) {
+                    cv = lane < NT ? __longlong_as_double((long long)(((unsigned long long)pg[1] << 32) | pg[0])) : 0.0;
+                    pclosed = (__builtin_amdgcn_readfirstlane((int)pg[2]) & 1) != 0;
+                }
+            }
+            if (!got) {
+                // the predecessor has not published (not dispatched yet?): this wave re-accumulates the halo itself -- a row at a time (8-byte
+                // loads) and a third of the components per sweep over the rows, because the registers hold the scan's results.  The slow way,
+                // taken under no dispatch order seen so far.
+                constexpr int P3 = (NT + 2) / 3;
+                k3c_slow_halo_piece<T, K, R, 0, P3>(a, tbase, s0, lane, ff, cv);
+                k3c_slow_halo_piece<T, K, R, P3, 2 * P3>(a, tbase, s0, lane, ff, cv);
+                k3c_slow_halo_piece<T, K, R, 2 * P3, NT>(a, tbase, s0, lane, ff, cv);
+            }
+            cq.v[0] = lane == NT ? 1.0 : (pclosed ? cv : cv + pv);
         } else if (a.tile_row0) cq.identity(lane);                               // packed: the tile starts (within a run) at a sequence start
         else if (a.all_closed) cq.load(a.rec + (t > 0 ? t - 1 : 0) * K3C_NCP, lane);   // (tile 0 starts with a sequence start: its carry-in is never used)
         else cq.load(a.carry + t * K3C_NCP, lane);
@@ -562,6 +712,17 @@ static int k3c_launch_k(pols_ctx *ctx, const K3cArgs &a0) {
         if (rc) return rc;
         a.dbg = static_cast<unsigned long long *>(dbg);
     }
+    if constexpr (K <= 6 && WAVES == 4) {
+        if (a.tile_seq0 && a.gran) {                                  // LOOK-BACK-ONE form: one launch, tile t = workgroup t
+            hipEvent_t e0, e1;
+            const bool timed = timing_pair(ctx, &e0, &e1);
+            hipExtLaunchKernelGGL((k3c_kernel<T, K, R, WAVES, 3>), dim3((unsigned)a.n_tiles), dim3(64 * WAVES), 0, ctx->stream, timed ? e0 : nullptr,
+                                  timed ? e1 : nullptr, 0, a);
+            POLS_HIP(hipGetLastError());
+            if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k3c_rls_rows_lookback");
+            return POLS_OK;
+        }
+    }
     if constexpr (K <= K3C_HALO_KMAX) {
         if (a.tile_seq0) {                                            // HALO form: one launch, the grid rounded up to whole XCD rounds
             hipEvent_t e0, e1;
@@ -608,7 +769,9 @@ static int k3c_launch_t(pols_ctx *ctx, const K3cArgs &a) {
 }
 
 int k3c_launch(pols_ctx *ctx, int dtype, const K3cArgs &a) {
-    ctx->last_kernel = a.tile_seq0 ? (dtype == POLS_F32 ? "k3s_rls_rows_halo_f32" : "k3s_rls_rows_halo_f64") : (dtype == POLS_F32 ? "k3s_rls_rows_f32" : "k3s_rls_rows_f64");
+    ctx->last_kernel = a.tile_seq0 && a.gran ? (dtype == POLS_F32 ? "k3s_rls_rows_lookback_f32" : "k3s_rls_rows_lookback_f64")
+                       : a.tile_seq0         ? (dtype == POLS_F32 ? "k3s_rls_rows_halo_f32" : "k3s_rls_rows_halo_f64")
+                                             : (dtype == POLS_F32 ? "k3s_rls_rows_f32" : "k3s_rls_rows_f64");
     return dtype == POLS_F32 ? k3c_launch_t<float>(ctx, a) : k3c_launch_t<double>(ctx, a);
 }
 

@@ -117,6 +117,12 @@ struct K3cArgs {
     const int64_t *tile_seq0;
     int32_t halo_batches;              // 256-row batches: ff^(256 halo_batches) <= 2^-36
     double log2ff, ffstep;             // log2(ff); ff^(256 waves - 4): a lane's runs of its wave's consecutive batches are 256 waves rows apart
+    // LOOK-BACK-ONE form (up to 6 features, halo_batches <= 4: the rows that matter lie inside the tile in front): every tile publishes its own
+    // aggregate as granules, tile t reads tile t - 1's; nullptr = the halo form
+    void *gran;                        // n_tiles x 32 granules of 16 bytes {value, tag}, zeroed when allocated
+    int64_t gran_bytes;
+    unsigned long long epoch;          // this launch's tag (never 0, never reused on this area)
+    int32_t spin_limit;                // polls before a wave gives up on its predecessor and re-accumulates the halo itself
 };
 constexpr int K3C_HALO_KMAX = 9;      // (one state component per lane in the cross-wave steps)
 constexpr int K3C_HALO_MAX_BATCHES = 8;

@@ -481,7 +481,7 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     }
     hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES, MASKED>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
                           timed ? e1 : nullptr, 0, a);
-    hipLaunchKernelGGL((k4c_lu_fix_kernel<T, K, MASKED>), dim3(512), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k4c_lu_fix_kernel<T, K, MASKED>), dim3(128), dim3(64), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k4c_rolling_tiles");
     return POLS_OK;

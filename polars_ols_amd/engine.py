@@ -275,7 +275,12 @@ class Engine:
                                    min_periods: Optional[int] = None, use_woodbury: Optional[bool] = None,
                                    alpha: Optional[float] = None, null_policy: str = "drop_window") -> "Plan":
         """solve_rolling_ols (src/least_squares.rs:848-1032) for every group; ``coef`` is n_rows x kt, NaN where undefined.
-        Raw columns in, like plan_recursive_least_squares."""
+        Raw columns in, like plan_recursive_least_squares.
+
+        Two places where this differs from the reference in KIND, both documented in include/pols_mi355x.h: a window whose X'X has no
+        Cholesky factorisation is solved by LU like the reference up to 10 features, but yields NaN at 11 to 32 features (the reference's
+        LU returns inf / NaN / huge numbers there; ``Engine.set_option("ROLLING_ENGINE", "chunk")`` selects kernels that run it); and
+        ``use_woodbury`` is accepted without selecting a code path (the inverse is propagated from 9 features on whatever it says)."""
         b, keep, dev, dt = self._batch(y, x_cols, offsets, weights, valid, add_intercept, null_free)
         res, o = self._dynamic_outputs(b, keep, dev, dt, want, out)
         p = L.RollingParams()

@@ -92,6 +92,8 @@ class RLSKwargs(Kwargs):  # least_squares.py:121-140
 
 @dataclass
 class RollingKwargs(Kwargs):  # least_squares.py:143-160
+    # (use_woodbury is accepted and does not select a code path; at 11 to 32 features a window without a Cholesky factorisation gives NaN
+    #  where the reference's LU gives inf / NaN / huge numbers -- Engine.plan_rolling_least_squares' docstring, include/pols_mi355x.h)
     window_size: int = 1_000_000
     min_periods: Optional[int] = None
     use_woodbury: Optional[bool] = None

@@ -40,14 +40,16 @@ case $stage in
 k3h)
   echo "== halo-form RLS: parity"
   timeout 1500 python -m pytest tests/test_k3_gpu.py -m gpu -x -q -k "halo or cfg4 or many_sequences or lookback or packed" 2>&1 | tail -15 | tee $O/${TAG}_pytest_k3h.txt
-  echo "== cfg4 A/B: halo (default) vs scan"
+  echo "== cfg4 A/B: look-back (default) vs halo vs scan"
   for i in 1 2 3; do
-    bench ${TAG}_bench_cfg4_halo_$i A=1 python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline
+    bench ${TAG}_bench_cfg4_lookback_$i A=1 python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline
+    bench ${TAG}_bench_cfg4_halo_$i POLS_RLS_ENGINE=halo python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline
     bench ${TAG}_bench_cfg4_scan_$i POLS_RLS_ENGINE=scan python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline
   done
+  bench ${TAG}_bench_cfg4_lookback_slow POLS_RLS_SPINS=0 python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline
   bench ${TAG}_bench_rlsg A=1 python bench.py --config rlsg --steps 20 --warmup 5 --no-cpu-baseline
   echo "== timeline (halo)"
-  POLS_TIMELINE=1 timeout 120 python bench.py --config cfg4 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep -v amdgpu | tail -20 | tee $O/${TAG}_timeline_cfg4_halo.txt
+  POLS_TIMELINE=1 timeout 120 python bench.py --config cfg4 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep -v amdgpu | tail -20 | tee $O/${TAG}_timeline_cfg4.txt
   kstats cfg4 A=1
   pmc cfg4 A=1
   ;;
@@ -80,9 +82,11 @@ k4cm)
   timeout 1500 python -m pytest tests/test_k4_gpu.py -m gpu -x -q -k "many_groups or tile_kernel or divergence" 2>&1 | tail -15 | tee $O/${TAG}_pytest_k4cm.txt
   echo "== dynamic entries on frames with nulls"
   for K in 6 8 10; do K=$K timeout 600 python scripts/bench_dyn_nulls.py 2>&1 | grep -v amdgpu; done | tee $O/${TAG}_bench_dyn_nulls.txt
+  ( cd /tmp && export TMPDIR=/tmp; rm -rf $O/kt_dn; K=6 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dn -o k -- python $R/scripts/bench_dyn_nulls.py > /dev/null 2> $O/kt_dn.err
+    f=$(find $O/kt_dn -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_dyn_nulls_k6.csv && head -30 $O/${TAG}_kernel_stats_dyn_nulls_k6.csv | cut -c1-160; rm -rf $O/kt_dn )
   ;;
 tests)
-  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_pytest_gpu.txt
+  timeout 3000 python -m pytest tests -m gpu -q --maxfail=25 2>&1 | tail -40 | tee $O/${TAG}_pytest_gpu.txt
   ;;
 prof)
   timeout 600 python bench.py 2> $O/bench.err > $O/${TAG}_bench.json; cut -c1-400 $O/${TAG}_bench.json

@@ -161,10 +161,13 @@ def test_rls_cfg4_full_size_single_sequence(eng, rls_engine):
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
 
 
-def test_rls_cfg4_full_size_default_route_is_the_halo_form(eng):
-    """BASELINE configs[3] on the DEFAULT route: half_life = 21 gives ff^768 = 2^-36.6, so every tile re-accumulates its carry-in from the
-    768 rows in front of it (k3c_scan.hip step H: one launch, no tile records) -- every row of the 1 000 000 against the sequential oracle
-    at north_star's 1e-6, and against the exact scan (POLS_RLS_ENGINE=scan) far inside it."""
+def test_rls_cfg4_full_size_default_route_is_one_launch(eng):
+    """BASELINE configs[3] on the DEFAULT route: half_life = 21 gives ff^768 = 2^-36.6, so a tile's carry-in is a function of the rows right in
+    front of it.  Up to 6 features that is tile t - 1's own aggregate: the LOOK-BACK-ONE form (k3c_scan.hip MODE 3: every tile publishes its
+    aggregate early, picks up its predecessor's behind its scan); POLS_RLS_ENGINE=halo re-accumulates the 768 rows instead (MODE 2), and
+    POLS_RLS_SPINS=0 makes every wave of the look-back form take its fallback (the slow halo) -- the path a dispatch order that starts tile t
+    before tile t - 1 would take.  Every row of the 1 000 000 of all three against the sequential oracle at north_star's 1e-6, and against the
+    exact scan (POLS_RLS_ENGINE=scan) far inside it."""
     from oracle import orc
 
     rng = np.random.default_rng(4)
@@ -172,19 +175,27 @@ def test_rls_cfg4_full_size_default_route_is_the_halo_form(eng):
     cols = [rng.standard_normal(n) for _ in range(k)]
     y = sum(cols) + 0.1 * rng.standard_normal(n)
     dy, dc = _cuda(y), [_cuda(c) for c in cols]
-    out = eng.recursive_least_squares(dy, dc, [0, n], half_life=21.0, null_free=True)
-    assert eng.last_kernel == "k3s_rls_rows_halo_f64"
     ref = orc.batched_rls(y, cols, [0, n], half_life=21.0)
-    assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6)
-    assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
     eng.set_option("RLS_ENGINE", "scan")
     try:
         ex = eng.recursive_least_squares(dy, dc, [0, n], half_life=21.0, null_free=True)
         assert eng.last_kernel == "k3s_rls_rows_f64"
     finally:
         eng.set_option("RLS_ENGINE", None)
-    # what the halo drops is 2^-36.6 = 1e-11 of the state 768 rows back
-    assert float(np.abs(_np(out["coef"]) - _np(ex["coef"])).max()) < 1e-9
+    for opts, name in (({}, "k3s_rls_rows_lookback_f64"), ({"RLS_ENGINE": "halo"}, "k3s_rls_rows_halo_f64"), ({"RLS_SPINS": "0"}, "k3s_rls_rows_lookback_f64")):
+        for key, v in opts.items():
+            eng.set_option(key, v)
+        try:
+            for rep in range(3):                              # (repeated launches: the record granules of one launch must never satisfy the next)
+                out = eng.recursive_least_squares(dy, dc, [0, n], half_life=21.0, null_free=True)
+                assert eng.last_kernel == name
+                assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-6), (opts, rep)
+                assert np.allclose(_np(out["pred"]), ref["pred"], rtol=1e-6, atol=1e-6)
+        finally:
+            for key in opts:
+                eng.set_option(key, None)
+        # what these forms drop is <= 2^-36.6 = 1e-11 of the state 768 (1 024) rows back
+        assert float(np.abs(_np(out["coef"]) - _np(ex["coef"])).max()) < 1e-9, opts
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
@@ -208,7 +219,17 @@ def test_rls_halo_route_boundary(eng, dtype, tol, k, half_life, halo):
                                       initial_state_mean=mean0, null_free=True)
     name = eng.last_kernel
     assert name.startswith("k3s_rls_rows")
-    assert ("halo" in name) == (halo and k <= 9), (name, half_life, k)
+    one_launch = halo and k <= 9
+    lookback = one_launch and k <= 6 and half_life * 36.0 <= 1024.0      # the rows that matter lie inside the ONE tile in front
+    assert ("lookback" in name) == lookback and ("halo" in name) == (one_launch and not lookback), (name, half_life, k)
+    if lookback:                                   # ... and the same frame with every wave on the look-back form's fallback
+        eng.set_option("RLS_SPINS", "0")
+        try:
+            slow = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, half_life=half_life, initial_state_covariance=1e3,
+                                               initial_state_mean=mean0, null_free=True)
+        finally:
+            eng.set_option("RLS_SPINS", None)
+        assert np.allclose(_np(slow["coef"]), _np(out["coef"]), rtol=tol, atol=tol)
     ref = orc.batched_rls(y, cols, offs, half_life=half_life, initial_state_covariance=1e3, initial_state_mean=mean0)
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=tol, atol=tol), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
     assert np.allclose(_np(out["pred"]), ref["pred"], rtol=tol, atol=tol)
@@ -226,7 +247,7 @@ def test_rls_halo_prior_decay_is_exact_on_small_features(eng):
     y = sum(cols) + 1e-5 * rng.standard_normal(n)
     offs = np.array([0, 37, 37 + n - 37], dtype=np.int64)
     out = eng.recursive_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, half_life=10.0, null_free=True)
-    assert eng.last_kernel == "k3s_rls_rows_halo_f64"
+    assert eng.last_kernel == "k3s_rls_rows_lookback_f64"
     ref = orc.batched_rls(y, cols, offs, half_life=10.0)
     assert np.allclose(_np(out["coef"]), ref["coef"], rtol=1e-6, atol=1e-9), float(np.abs(_np(out["coef"]) - ref["coef"]).max())
 

@@ -807,6 +807,12 @@ def test_rolling_wave_per_chunk_drop_window_with_nulls(eng, dtype, tol, k, windo
     y, cols, offs, valid = _frame(rng, sizes, k, dtype=dtype, null_frac=null_frac)
     kw = dict(window_size=window, min_periods=min_periods, alpha=alpha, null_policy="drop_window")
     out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
+    if k <= 10:                                    # round 6: up to 10 features the masked TILE kernel takes these frames (k4c_kernel.inl); K4p's masked form is forced here
+        eng.set_option("ROLLING_ENGINE", "nocompact")
+        try:
+            out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
+        finally:
+            eng.set_option("ROLLING_ENGINE", None)
     assert eng.last_kernel.startswith("k4p_"), eng.last_kernel
     ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, alpha=alpha, null_policy="drop_window", is_valid=valid)
     got_c, got_p = _np(out["coef"]), _np(out["pred"])
@@ -845,11 +851,14 @@ def test_rolling_wave_per_chunk_drop_window_with_nulls(eng, dtype, tol, k, windo
     assert np.isfinite(old_c[well]).all()                 # (the chunk engine on the same frame: run for its kernel-name assertion above)
     if k <= 16:                                   # four chunks per wave
         eng.set_option("K4P_LPS", "16")
+        if k <= 10:
+            eng.set_option("ROLLING_ENGINE", "nocompact")
         try:
             packed = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), **kw)
             assert eng.last_kernel.endswith("_x4"), eng.last_kernel
         finally:
             eng.set_option("K4P_LPS", None)
+            eng.set_option("ROLLING_ENGINE", None)
         pc = _np(packed["coef"])
         assert np.allclose(pc[well], ref["coef"][well], rtol=tol, atol=tol), float(np.abs(pc[well] - ref["coef"][well]).max())
         assert np.isnan(pc[before]).all()
