@@ -473,11 +473,20 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
         const double W = exp2((double)(WAVES * 64 * R - (wv * 64 + lane) * R - R) * a.log2ff);
         // (the table: this wave's 2 (NT + 1) doubles of the s_agg | s_wfull region, idle until step B -- three DPP steps leave every 8 lanes' sum in
         // their last lane, those 8 lanes write a [PIECE][9] table, lane q adds up row q)
-        constexpr int PIECE = (2 * (NT + 1)) / 9 < 1 ? 1 : (2 * (NT + 1)) / 9;
+        constexpr int PIECE = (2 * (NT + 1)) / 9;
         double *tr = &s_aw[0][0][0] + wv * 2 * (NT + 1);
+        if constexpr (PIECE == 0) {                           // one feature: two components, the region is too small for a table -- six DPP steps each
 #pragma unroll
-        for (int q0 = 0; q0 < NT; q0 += PIECE) {
-            double c[PIECE];
+            for (int q = 0; q < NT; ++q) {
+                double v = incl ? Tl[q] * W : 0.0;
+                v += dpp_get0<0x111>(v); v += dpp_get0<0x112>(v); v += dpp_get0<0x114>(v); v += dpp_get0<0x118>(v);
+                v += dpp_get0<0x142>(v); v += dpp_get0<0x143>(v);
+                if (lane == 63) s_hagg[wv][q] = v;
+            }
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < (PIECE ? NT : 0); q0 += (PIECE ? PIECE : 1)) {
+            double c[PIECE ? PIECE : 1];
 #pragma unroll
             for (int q = 0; q < PIECE; ++q) c[q] = (q0 + q < NT && incl) ? Tl[q0 + q < NT ? q0 + q : 0] * W : 0.0;
 #pragma unroll
