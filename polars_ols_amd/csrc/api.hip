@@ -2126,7 +2126,9 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     Staged st;
     DynState ds;
     // ("drop_window" without weights / intercept on up to 10 features: the masked tile kernel reads the caller's columns as they are)
-    const bool may_defer = p->null_policy == POLS_NULL_DROP_WINDOW && b->n_features <= K4C_KMAX && ctx->opt.rolling_engine != 1 && ctx->opt.rolling_engine != 3;
+    // ("drop": the compaction in front of the tile kernel copies the VALID rows, which hold no null under that policy, out of the caller's columns)
+    const bool may_defer = (p->null_policy == POLS_NULL_DROP_WINDOW || p->null_policy == POLS_NULL_DROP) && b->n_features <= K4C_KMAX &&
+                           ctx->opt.rolling_engine != 1 && ctx->opt.rolling_engine != 3;
     int rc = dynamic_prologue(ctx, b, p->null_policy, o, &d_offs, &max_rows, &st, &ds, may_defer);
     if (rc) return rc;
     if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
