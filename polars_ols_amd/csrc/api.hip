@@ -208,6 +208,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "STATIC_ENGINE")) o.static_engine = !on ? 0 : ieq(v, "stream") ? 1 : ieq(v, "k2") ? 2 : ieq(v, "nok2") ? 3 : ieq(v, "k2w") ? 4 : 0;
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : ieq(v, "halo") ? 4 : 0;
     else if (ieq(key, "RLS_SPINS")) o.rls_spin_limit = on ? std::atoi(v) : d.rls_spin_limit;
+    else if (ieq(key, "RLS_EARLY")) o.rls_early = on ? std::atoi(v) : d.rls_early;
     else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : ieq(v, "nocompact") ? 3 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
@@ -217,7 +218,7 @@ bool options_set(Options &o, const char *key, const char *v) {
 
 void options_from_env(Options &o) {
     static const char *const keys[] = {"TIMELINE", "K1_NOOCC4", "K1_NOFAST", "K1_NOTINY", "K1_NORC1", "K1_SHAPE", "K1_F64_TEAM",
-                                       "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1_WG", "RLS_SPINS", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
+                                       "KG_NOYV", "K2_NOPREFETCH", "K1_PASSES", "K1_WG", "RLS_SPINS", "RLS_EARLY", "K1T_RC4", "K1_NT_LOADS", "STATIC_ENGINE",
                                        "RLS_ENGINE", "ROLLING_ENGINE", "K1_ENGINE", "K9_TAKE", "K1_PERSIST", "K1_PERSIST_SUB", "K1T_SUB32", "K1_NOEDGE", "K1T_SUB8",
                                        "K1_XCD", "NO_SPLIT", "DEBUG_SKIP_FIXUP", "K4P_LPS", "SEG_TARGET", "K1_RC2_WIDE", "KG_SINGLE_BUFFER", "PREDICT_LOOP", "NO_CLASSES"};
     char name[64];
@@ -1951,6 +1952,7 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
                 }
                 c.gran = g; c.gran_bytes = (int64_t)gbytes; c.epoch = ++ctx->k3c_epoch;
                 c.spin_limit = ctx->opt.rls_spin_limit >= 0 ? ctx->opt.rls_spin_limit : 64;
+                c.early_publish = ctx->opt.rls_early;
             }
         }
         if ((rc = k3c_launch(ctx, b->dtype, c))) return rc;

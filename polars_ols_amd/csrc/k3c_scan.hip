@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
     const unsigned long long hmask = __ballot(head);
     using U4 = __attribute__((ext_vector_type(4))) unsigned;
     [[maybe_unused]] U4 pg = {0u, 0u, 0u, 0u};               // LOOK-BACK: this lane's granule of the predecessor's record
-    if constexpr (MODE == 3) {
+    if constexpr (MODE == 3) if (a.early_publish) {
         // ---- E: the tile's own aggregate, EARLY (the successor needs it after ITS scan: published now it has a whole scan's time to arrive).
         // A lane's composite Tl carried to the tile's last row is Tl x ff^(rows behind its run) -- every row decays by ff on a null-free frame --
         // from the wave's last sequence start on; the 64 lanes' terms are summed like step H's (two DPP steps + a table in the parking slots,
@@ -594,6 +594,24 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
             }
             cq.v[0] = lane == NT ? 1.0 : cv;
         } else if constexpr (MODE == 3) {
+            if (!a.early_publish) {
+                // LATE publish (POLS_RLS_EARLY=0, A/B): the record falls out of the scan -- the waves' aggregates composed from the tile's last
+                // sequence start on (what pass 1 of the scan form writes); the successor then waits a hand-off's latency at this point of ITS life
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.gran, 0, (int)a.gran_bytes, 0x00020000);
+                if (wv == WAVES - 1) {
+                    K3cLaneVec<NT> full = run, eq;
+                    bool tclosed = !wopen;
+                    eq.load(&s_agg[wv][0], lane);
+                    if (s_closed[wv]) { full = eq; tclosed = true; }
+                    else full.then(eq, s_agg[wv][NT], lane);
+                    if (lane < NT) {
+                        const unsigned long long vb = (unsigned long long)__double_as_longlong(full.v[0]), tg = (a.epoch << 1) | (tclosed ? 1ull : 0ull);
+                        const U4 g = {(unsigned)vb, (unsigned)(vb >> 32), (unsigned)tg, (unsigned)(tg >> 32)};
+                        __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (int)((t * 32 + lane) * 16), 0, /*sc1*/ 16);
+                    }
+                }
+                if (t > 0 && lane < NT) pg = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((t - 1) * 32 + lane) * 16), 0, /*sc1*/ 16);
+            }
             // LOOK-BACK: the carry-in = tile t - 1's record (its aggregate from its last sequence start on, carried to its last row) + -- when it holds
             // no sequence start -- the prior decayed over the rows since the sequence's first row (exact, like the halo form's); what lies
             // further back than tile t - 1 is dropped: ff^(tile rows) <= 2^-36 (the host's route condition)

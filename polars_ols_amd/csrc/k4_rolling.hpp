@@ -123,6 +123,7 @@ struct K3cArgs {
     int64_t gran_bytes;
     unsigned long long epoch;          // this launch's tag (never 0, never reused on this area)
     int32_t spin_limit;                // polls before a wave gives up on its predecessor and re-accumulates the halo itself
+    int32_t early_publish;             // 1: the record is computed and published before the tile's scan (step E); 0: it falls out of the scan (A/B)
 };
 constexpr int K3C_HALO_KMAX = 9;      // (one state component per lane in the cross-wave steps)
 constexpr int K3C_HALO_MAX_BATCHES = 8;

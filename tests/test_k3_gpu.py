@@ -164,7 +164,8 @@ def test_rls_cfg4_full_size_single_sequence(eng, rls_engine):
 def test_rls_cfg4_full_size_default_route_is_one_launch(eng):
     """BASELINE configs[3] on the DEFAULT route: half_life = 21 gives ff^768 = 2^-36.6, so a tile's carry-in is a function of the rows right in
     front of it.  Up to 6 features that is tile t - 1's own aggregate: the LOOK-BACK-ONE form (k3c_scan.hip MODE 3: every tile publishes its
-    aggregate early, picks up its predecessor's behind its scan); POLS_RLS_ENGINE=halo re-accumulates the 768 rows instead (MODE 2), and
+    aggregate -- it falls out of the tile's scan; POLS_RLS_EARLY=1: computed and published before the scan -- and picks up its predecessor's);
+    POLS_RLS_ENGINE=halo re-accumulates the 768 rows instead (MODE 2), and
     POLS_RLS_SPINS=0 makes every wave of the look-back form take its fallback (the slow halo) -- the path a dispatch order that starts tile t
     before tile t - 1 would take.  Every row of the 1 000 000 of all three against the sequential oracle at north_star's 1e-6, and against the
     exact scan (POLS_RLS_ENGINE=scan) far inside it."""
@@ -182,7 +183,8 @@ def test_rls_cfg4_full_size_default_route_is_one_launch(eng):
         assert eng.last_kernel == "k3s_rls_rows_f64"
     finally:
         eng.set_option("RLS_ENGINE", None)
-    for opts, name in (({}, "k3s_rls_rows_lookback_f64"), ({"RLS_ENGINE": "halo"}, "k3s_rls_rows_halo_f64"), ({"RLS_SPINS": "0"}, "k3s_rls_rows_lookback_f64")):
+    for opts, name in (({}, "k3s_rls_rows_lookback_f64"), ({"RLS_ENGINE": "halo"}, "k3s_rls_rows_halo_f64"), ({"RLS_SPINS": "0"}, "k3s_rls_rows_lookback_f64"),
+                       ({"RLS_EARLY": "1"}, "k3s_rls_rows_lookback_f64"), ({"RLS_EARLY": "1", "RLS_SPINS": "0"}, "k3s_rls_rows_lookback_f64")):
         for key, v in opts.items():
             eng.set_option(key, v)
         try:
