@@ -209,7 +209,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : ieq(v, "halo") ? 4 : 0;
     else if (ieq(key, "RLS_SPINS")) o.rls_spin_limit = on ? std::atoi(v) : d.rls_spin_limit;
     else if (ieq(key, "RLS_EARLY")) o.rls_early = on ? std::atoi(v) : d.rls_early;
-    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : ieq(v, "nocompact") ? 3 : 0;
+    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : ieq(v, "nocompact") ? 3 : ieq(v, "halowave") ? 4 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
     else return false;
@@ -2229,6 +2229,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
                 a.window = w; a.alpha = p->alpha > 0.0 ? p->alpha : 0.0; a.k = k; a.drop_mode = 1;
                 a.tot_cs = k * k + k; a.tot_qs = 1;
                 a.use_totals = (max_c > pchunk && w > 1024) ? 1 : 0;
+                a.groups_end_row = Nc;
                 if ((rc = k4p_launch(ctx, b->dtype, a, false, max_c <= pchunk))) return rc;
                 ra.coef_c = dc; ra.coef = st.coef; ra.pred = st.pred;
                 if ((rc = row_compact_expand_launch(ctx, b->dtype, ra))) return rc;
@@ -2368,6 +2369,7 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
     else { a.tot_cs = 1; a.tot_qs = a.n_chunks; }
     if (wave_p) {
         a.use_totals = (max_rows > pchunk && w > 1024) ? 1 : 0;    // cut sequences, a window too long to re-sum at every chunk start
+        a.groups_end_row = b->n_rows;
         rc = k4p_launch(ctx, b->dtype, a, false, max_rows <= pchunk);
     }
     else rc = k > K4X_KMAX ? k4y_launch(ctx, b->dtype, a) : xwide ? k4x_launch(ctx, b->dtype, a) : (wide ? k4w_launch(ctx, b->dtype, a) : k4_launch(ctx, b->dtype, a));

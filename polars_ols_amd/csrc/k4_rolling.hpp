@@ -54,6 +54,10 @@ struct K4Args {
     double *state;               // k4x beyond 128 features: one k x (k | 1) matrix per chunk in HBM (set by the launcher)
     const int32_t *order;        // k4p / k3p (or nullptr): work slot i takes chunk order[i] -- the chunks sorted by length, longest first, so that the chunks that
                                  // share a wave (up to four) are about equally long; chunk ids, totals and the group tables are untouched
+    // k4p rolling on null-free frames: rows whose window sums could not be inverted, for kp_lu_fix_kernel (set by k4p_launch; see K4cArgs)
+    int64_t *fix_rows;
+    int32_t *fix_count, *fix_next;
+    int64_t fix_cap, groups_end_row;   // groups_end_row: rows of the frame the tables describe (the caller sets it)
     int32_t use_totals;          // k4p rolling: sequences are cut AND the window exceeds 1 024 rows -- the chunk-start sums come from the scanned
                                  // per-chunk totals (prefix differences) instead of re-summing the window in front of the chunk
 };

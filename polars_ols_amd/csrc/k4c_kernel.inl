@@ -59,8 +59,16 @@ __device__ __forceinline__ void k4c_seg_scan_add(double (&Tv)[NC], const int h, 
 // is still in a warm-up sum (api.hip checks): an invalid row is a zero row -- it enters and leaves the sums as nothing -- every row is
 // solved from S_i = E(i) - E(i - window), and the rows the reference does NOT solve (before the warm-up row: NaN; a closed
 // n_valid_window gate: the last solved row's coefficients) are rewritten afterwards by the fill pass (k4cm_fill.hip) from a per-row table.
-template <typename T, int K, int HW, int WAVES, bool MASKED>
+//
+// SELF (round 6, windows up to 256 rows on frames that do not pack): NO halo wave.  Four body waves, 1 024-row tiles; only the lanes whose
+// window starts in front of the tile -- the first ceil(window / 4) lanes of the tile's first wave -- need anything from outside it, and what
+// they need is (a) their LEAVING rows, which they load themselves (L2 hits), and (b) the sum of the rows between their window's first row
+// and the tile's first row: a suffix sum over those same leaving rows, one 64-lane scan on that wave alone (total - prefix), parked in LDS
+// next to the table.  A quarter of every workgroup used to be halo: 1 303 tiles of 768 rows on 512 tile slots (three rounds) become 977
+// tiles of 1 024 rows (two).  Which wave takes the tile's first 256 rows rotates with the tile so that the extra work spreads over the SIMDs.
+template <typename T, int K, int HW, int WAVES, bool MASKED, bool SELF = false>
 __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K4cArgs a) {
+    static_assert(!SELF || (HW == 0 && WAVES == 4), "the own-halo form: four body waves");
     constexpr int BW = WAVES - HW, R = 4, RUNS = WAVES * 64;
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NC = NT + 1;   // slot NT: rows since the last sequence start (or the halo's first row)
     using V = typename Vec16<T>::type;
@@ -71,7 +79,8 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     constexpr size_t TAB_B = sizeof(double) * NC * RUNS > sizeof(T) * 4 * (K + 1) * RUNS ? sizeof(double) * NC * RUNS : sizeof(T) * 4 * (K + 1) * RUNS;
     double *s_agg = reinterpret_cast<double *>(smem + TAB_B);    // [WAVES][NC]: wave totals (from the wave's last sequence start on)
     int *s_closed = reinterpret_cast<int *>(s_agg + WAVES * NC); // [WAVES]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    [[maybe_unused]] double *s_P = reinterpret_cast<double *>(smem + TAB_B + sizeof(double) * WAVES * NC + 64);   // SELF: [NC][64] -- the rows in front of the tile
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
 #define K4C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     // consecutive tiles on one XCD (workgroup b runs on XCD b % 8): a tile's halo is its neighbour's body
     const int64_t per_xcd = (a.n_tiles + 7) / 8;
@@ -80,11 +89,33 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     const int64_t N = a.n_rows, w = a.window;
     // HW == 0: packed tiles -- the tile owns the whole sequences of rows [lo, hi) and starts at lo rounded down to a run
     int64_t lo = 0, hi = N, hs = t * (BW * 256) - HW * 256;      // hs: the halo's first row (may be negative)
-    if constexpr (HW == 0) { lo = a.tile_row0[t]; hi = a.tile_row0[t + 1]; hs = lo & ~(int64_t)3; }
+    if constexpr (HW == 0 && !SELF) { lo = a.tile_row0[t]; hi = a.tile_row0[t + 1]; hs = lo & ~(int64_t)3; }
+    const int wv = SELF ? ((wq + (int)(t & 3)) & 3) : wq;        // the 256-row block of the tile this wave takes (SELF: rotates with the tile)
     const int u = wv * 64 + lane;                                // this lane's run
     const int64_t i0 = hs + (int64_t)u * R;
     const bool inside = i0 >= 0 && i0 + R <= N;
     K4C_STAMP(0);
+    const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
+    const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window
+    const int up = u - sh < 0 ? 0 : u - sh;                                    // table index: u - sh >= 0 for body lanes behind a halo (it covers `window`
+                                                                               // rows); packed tiles: a negative one is never looked up (use_ep below is false)
+    const int64_t rho_run = hs + (int64_t)(u - sh) * R;                        // first row of the run holding row i0 - window
+    auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
+        const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
+        bool vr = true;
+        if constexpr (MASKED) vr = a.valid[ic] != 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) xr[j] = vr ? (double)static_cast<const T *>(a.x[j])[ic] : 0.0;
+        yr = vr ? (double)static_cast<const T *>(a.y)[ic] : 0.0;
+    };
+    auto add_row = [&](double (&S)[NC], const double (&xr)[K], double yr, double sign) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+#pragma unroll
+            for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = fma(sign * xr[p], xr[q], S[tri_index<K>(p, q)]);
+            S[NX + p] = fma(sign * xr[p], yr, S[NX + p]);
+        }
+    };
 
     // ---- A: the run's rows (rows outside the frame: zeros, no sequence start)
     double x[R][K], y[R];
@@ -142,25 +173,56 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
                 if (i0 + r >= 0 && i0 + r < N && a.solved[i0 + r]) solbits |= 1u << (8 * r);
         }
     }
-    const int sh = (int)((w + 3) / 4);                                         // runs between this run and the one holding row i0 - window
-    const int o = (int)(sh * 4 - w);                                           // rows of that run in FRONT of row i0 - window
-    const int up = u - sh < 0 ? 0 : u - sh;                                    // table index: u - sh >= 0 for body lanes behind a halo (it covers `window`
-                                                                               // rows); packed tiles: a negative one is never looked up (use_ep below is false)
-    const int64_t rho_run = hs + (int64_t)(u - sh) * R;                        // first row of the run holding row i0 - window
-    auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
-        const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
-        bool vr = true;
-        if constexpr (MASKED) vr = a.valid[ic] != 0;
+    double xo[R][K], yo[R];
+    [[maybe_unused]] bool pre[R] = {};                                         // SELF: leaving row r lies in FRONT of the tile (loaded here, not handed over)
+    if constexpr (SELF) {
+        if (wv == 0) {
+            // The rows in front of the tile that this wave's windows reach: lane u's leaving rows i0 - window .. + 3 where they lie before
+            // the tile's first row.  They stay in xo / yo for the walk; their sum from the window's first row (or the last sequence start
+            // in front of the tile, whichever is later) up to the tile's first row is what the lane's prefix E(own run) lacks.
+            unsigned hb = 0;                                                   // bit r: such a row starts a sequence
 #pragma unroll
-        for (int j = 0; j < K; ++j) xr[j] = vr ? (double)static_cast<const T *>(a.x[j])[ic] : 0.0;
-        yr = vr ? (double)static_cast<const T *>(a.y)[ic] : 0.0;
-    };
+            for (int r = 0; r < R; ++r) {
+                const int g = (u - sh) * R + o + r;                            // row index relative to the tile's first row
+                pre[r] = g < 0 && hs + g >= 0;
+                if (pre[r]) {
+                    load_row(hs + g, xo[r], yo[r]);
+                    if (a.start[hs + g]) hb |= 1u << r;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) xo[r][j] = 0.0;
+                    yo[r] = 0.0;
+                }
+            }
+            const unsigned long long hm = __ballot(hb != 0);
+            int gstar = -(1 << 30);                                            // the last sequence start in front of the tile (as far back as the windows reach)
+            if (hm) {
+                const int vs = 63 - __clzll(hm);
+                const unsigned hbs = (unsigned)__shfl((int)hb, vs);
+                gstar = (vs - sh) * R + o + (31 - __clz(hbs));
+            }
+            double L[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) L[q] = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool inc = pre[r] && (u - sh) * R + o + r >= gstar;
+                double xm[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) xm[j] = inc ? xo[r][j] : 0.0;
+                add_row(L, xm, inc ? yo[r] : 0.0, 1.0);
+                L[NT] += inc ? 1.0 : 0.0;
+            }
+            k4c_seg_scan_add<NC>(L, -1, lane);                                 // inclusive prefix over the lanes (no segments: the rows before the start are zeros)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) s_P[q * 64 + lane] = readlane63(L[q]) - dpp_get0<0x138>(L[q]);   // total - exclusive prefix: the lanes from this one on
+        }
+    }
     // The LEAVING rows of a body lane's run -- rows i0 - window .. + 3: rows (o + r) of the runs u - sh and u - sh + 1 -- are rows other
     // lanes of this workgroup have just loaded: they change hands through LDS (the region the prefix table takes over after the next
     // barrier: [row of the run][column][run], batch dtype).  Loaded from global memory instead (round 4 until then: 16-byte loads, L2
     // hits) they went through the CU's memory pipe a second time -- a third of the tile's traffic on the resource this kernel is bound
     // by (10.5 bytes per clock per CU with them).
-    double xo[R][K], yo[R];
     {
         T *s_X = reinterpret_cast<T *>(smem);
 #pragma unroll
@@ -176,6 +238,7 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
                 int g = (u - sh) * R + o + r;                                  // row index inside [halo | body]; negative: never used (the
                 g = g < 0 ? 0 : g;                                             // sequence then starts inside the tile, `sub` below stays false)
                 const int run = g >> 2, rr = g & 3;
+                if (SELF && pre[r]) continue;                                  // (already here, from in front of the tile)
 #pragma unroll
                 for (int j = 0; j < K; ++j) xo[r][j] = (double)s_X[(size_t)(rr * (K + 1) + j) * RUNS + run];
                 yo[r] = (double)s_X[(size_t)(rr * (K + 1) + K) * RUNS + run];
@@ -185,14 +248,6 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     bool st[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) st[r] = ((sbits >> (8 * r)) & 0xffu) != 0;
-    auto add_row = [&](double (&S)[NC], const double (&xr)[K], double yr, double sign) {
-#pragma unroll
-        for (int p = 0; p < K; ++p) {
-#pragma unroll
-            for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = fma(sign * xr[p], xr[q], S[tri_index<K>(p, q)]);
-            S[NX + p] = fma(sign * xr[p], yr, S[NX + p]);
-        }
-    };
     auto reset_if = [&](double (&S)[NC], bool cond, bool any) {   // the sums start over at a sequence start
         if (any) {
 #pragma unroll
@@ -244,13 +299,21 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
 
     // ---- D: body lanes.  S before the run, then one add / subtract / solve per row.
     double S[NC];
-    const double cnt_excl = ET[NT];                                            // rows since the last sequence start, before this run
+    double cnt_excl = ET[NT];                                                  // rows since the last sequence start, before this run
     // (exact when a sequence starts inside the tile or its halo; otherwise the rows since the halo's first row: >= 256 HW >= window + o + 1)
     // The part of the prefix E(own run) that lies before row i0 - window goes: the table entry of the run holding that row when the
     // sequence started before that run, and the rows of that run in front of row i0 - window that the sequence reaches back to.
     const bool use_ep = cnt_excl >= (double)(w + o + 1);
 #pragma unroll
     for (int q = 0; q < NC; ++q) S[q] = ET[q] - (use_ep ? s_E[q * RUNS + up] : 0.0);
+    if constexpr (SELF) {
+        if (wv == 0) {                                                         // the part of the window in front of the tile (no sequence start in the tile before this run)
+            const bool reach = eopen && (int64_t)u * R < w;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) S[q] += reach ? s_P[q * 64 + lane] : 0.0;
+            cnt_excl += reach ? s_P[NT * 64 + lane] : 0.0;                     // (at most `window`: use_ep above stays false, the rows-in-front loop below idle)
+        }
+    }
     double cnt = cnt_excl;
     T *coef = static_cast<T *>(a.coef);
     T *pred = static_cast<T *>(a.pred);
@@ -435,7 +498,7 @@ __global__ void __launch_bounds__(64) k4c_lu_fix_kernel(const K4cArgs a) {
     }
 }
 
-template <typename T, int K, int HW, bool MASKED>
+template <typename T, int K, int HW, bool MASKED, bool SELF = false>
 static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     constexpr int NC = K4N<K>::N + 1;
     // Waves per workgroup.  The prefix table is NC x 64 WAVES doubles of LDS (K = 6: 14 KiB per wave) and a lane holds its entering
@@ -446,14 +509,14 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     K4cArgs a = a0;
     const int64_t tile_rows = (int64_t)(WAVES - HW) * 256;
     static_assert(HW != 0 || (WAVES - HW) * 256 == K4C_PACKED_ROWS, "the packed tile map is built for this tile");
-    a.n_tiles = HW == 0 ? a.n_packed : (a.n_rows + tile_rows - 1) / tile_rows;
+    a.n_tiles = HW == 0 && !SELF ? a.n_packed : (a.n_rows + tile_rows - 1) / tile_rows;
     const int64_t per_xcd = (a.n_tiles + 7) / 8;
     const size_t tab = std::max(sizeof(double) * (size_t)NC * 64 * WAVES, sizeof(T) * (size_t)4 * (K + 1) * 64 * WAVES);   // the tile's rows, then the prefix table
-    const size_t lds = std::max(tab + sizeof(double) * WAVES * NC + 64,                                             // ... + wave totals
+    const size_t lds = std::max(tab + sizeof(double) * WAVES * NC + 64 + (SELF ? sizeof(double) * NC * 64 : 0),     // ... + wave totals (+ SELF: the sums in front of the tile)
                                 (size_t)(WAVES - HW) * 4 * (K + 1) * DYN_STAGE_STRIDE * sizeof(T));              // ... reused as the output staging area
     static OncePerDevice attr_once;
     if (attr_once.needed(ctx->device)) {
-        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k4c_kernel<T, K, HW, WAVES, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k4c_kernel<T, K, HW, WAVES, MASKED, SELF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_once.done(ctx->device);
     }
     if (ctx->opt.timeline) {
@@ -479,7 +542,7 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
         a.fix_rows = reinterpret_cast<int64_t *>(static_cast<char *>(fx) + 256);
         a.fix_cap = cap;
     }
-    hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES, MASKED>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
+    hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES, MASKED, SELF>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
                           timed ? e1 : nullptr, 0, a);
     hipLaunchKernelGGL((k4c_lu_fix_kernel<T, K, MASKED>), dim3(128), dim3(64), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
@@ -490,6 +553,11 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
 template <typename T, int K, bool MASKED>
 static int k4c_launch_k(pols_ctx *ctx, const K4cArgs &a) {
     if (a.tile_row0) return k4c_launch_h<T, K, 0, MASKED>(ctx, a);                              // packed tiles: no halo
+    // no halo wave: the tile's first wave reaches in front of the tile itself (windows up to 256 rows; at 10 features the table and the parked sums
+    // are more than a CU's LDS).  POLS_ROLLING_ENGINE=halowave keeps the halo wave (A/B).
+    if constexpr (K <= 9) {
+        if (a.window <= 256 && ctx->opt.rolling_engine != 4) return k4c_launch_h<T, K, 0, MASKED, true>(ctx, a);
+    }
     if (a.window <= 252) return k4c_launch_h<T, K, 1, MASKED>(ctx, a);                          // 256 HW >= 4 ceil(window / 4) + 1
     if constexpr (K <= 6) return k4c_launch_h<T, K, 2, MASKED>(ctx, a);
     // (7 / 8 features need more than 256 registers: one four-wave workgroup per CU; the eight-wave two-halo form would spill)

@@ -565,10 +565,79 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                 good = last_good; bout = last;
             }
             cx.store_coef(G.start + i, bout, good);
+            if constexpr (!MASKED) {
+                // a row the reference solves whose window sums could not be inverted: the reference runs LU there (ls.rs:732-734) -- kp_lu_fix_kernel does,
+                // behind this kernel, for the rows put on the list here (rare; MASKED frames repeat coefficients across rows: they keep the NaN)
+                if (((mk.gate >> t) & 1) && !good && a.fix_rows && cx.lane == 0) {
+                    const int idx = atomicAdd(a.fix_count, 1);
+                    if (idx < a.fix_cap) a.fix_rows[idx] = G.start + i;
+                }
+            }
             const double p = kp_rowsum<KP>(x.xr * bout);
             predv = (cx.lane == t) ? (good ? p : qnan) : predv;
         }
         if (a.pred && cx.lane < nb) static_cast<T *>(a.pred)[G.start + i0 + cx.lane] = (T)predv;
+        kp_sync();
+    }
+}
+
+// The rows of the list: one wave each re-sums the row's window -- rows (i - window, i] of its sequence -- into [X'X + alpha I | X'y] in LDS (a lane
+// owns the entries e = lane, lane + 64, ...; the rows are staged one at a time) and eliminates with partial pivoting, a lane per column, like the
+// reference's fallback (faer partial_piv_lu as restated in oracle/pols_oracle.c:108-141).  Any width up to 32; null-free frames.
+template <typename T>
+__global__ void __launch_bounds__(64) kp_lu_fix_kernel(const K4Args a) {
+    __shared__ double As[32][33], xs[33];
+    const int lane = threadIdx.x, K = a.k, K1 = K + 1;
+    const int n_fix = min(*a.fix_count, (int)a.fix_cap);
+    if (blockIdx.x == 0 && lane == 0) *a.fix_next = 0;              // the next call's counter
+    for (int e = blockIdx.x; e < n_fix; e += gridDim.x) {
+        const int64_t i = a.fix_rows[e];
+        int lo_g = 0, hi_g = a.n_groups;                            // the sequence holding row i: the last g with start <= i
+        while (hi_g - lo_g > 1) {
+            const int mid = (lo_g + hi_g) >> 1;
+            if (a.groups[mid].start <= i) lo_g = mid; else hi_g = mid;
+        }
+        const int64_t s = a.groups[lo_g].start;
+        const int64_t lo = i - a.window + 1 < s ? s : i - a.window + 1;
+        for (int q = lane; q < K * K1; q += 64) As[q / K1][q % K1] = 0.0;
+        kp_sync();
+        for (int64_t j = lo; j <= i; ++j) {
+            if (lane < K) xs[lane] = (double)static_cast<const T *>(a.x[lane])[j];
+            if (lane == K) xs[K] = (double)static_cast<const T *>(a.y)[j];
+            kp_sync();
+            for (int q = lane; q < K * K1; q += 64) { const int p = q / K1, c = q % K1; As[p][c] = fma(xs[p], xs[c], As[p][c]); }
+            kp_sync();
+        }
+        if (lane < K) As[lane][lane] += a.alpha;
+        kp_sync();
+        for (int j = 0; j < K; ++j) {
+            int pv = j;
+            double best = fabs(As[j][j]);
+            for (int r2 = j + 1; r2 < K; ++r2) { const double v = fabs(As[r2][j]); if (v > best) { best = v; pv = r2; } }
+            kp_sync();
+            if (lane <= K && pv != j) { const double t0 = As[j][lane]; As[j][lane] = As[pv][lane]; As[pv][lane] = t0; }
+            kp_sync();
+            const double d = As[j][j];
+            if (lane <= K && lane > j) {
+                const double top = As[j][lane];
+                for (int r2 = j + 1; r2 < K; ++r2) As[r2][lane] -= (As[r2][j] / d) * top;      // (column j itself is not written in this step)
+            }
+            kp_sync();
+        }
+        if (lane == 0) {
+            double beta[32];
+            for (int p = K - 1; p >= 0; --p) {
+                double sacc = As[p][K];
+                for (int q = p + 1; q < K; ++q) sacc -= As[p][q] * beta[q];
+                beta[p] = sacc / As[p][p];
+            }
+            double pr = 0.0;
+            for (int p = 0; p < K; ++p) {
+                if (a.coef) static_cast<T *>(a.coef)[i * K + p] = (T)beta[p];
+                pr = fma((double)static_cast<const T *>(a.x[p])[i], beta[p], pr);
+            }
+            if (a.pred) static_cast<T *>(a.pred)[i] = (T)pr;
+        }
         kp_sync();
     }
 }
@@ -590,7 +659,10 @@ static int kp_launch_kp(pols_ctx *ctx, const K4Args &a, bool rls, bool single_ch
         }
         if constexpr (KpGeo<KP, LPS>::CPL <= 16) {
             if (a.valid) hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, true>), dim3(blocks), dim3(64), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, false>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+            else {
+                hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, false>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+                if (a.fix_rows) hipLaunchKernelGGL((kp_lu_fix_kernel<T>), dim3(128), dim3(64), 0, ctx->stream, a);
+            }
         }
     }
     timing_end(ctx);
@@ -622,7 +694,22 @@ int k4p_launch(pols_ctx *ctx, int dtype, const K4Args &a, bool rls, bool single_
     if (a.k > 32 || a.k < 1) return fail(POLS_ERR_UNSUPPORTED, "k4p: %d features", a.k);
     if (a.n_chunks <= 0) return POLS_OK;
     ctx->last_kernel = std::string(rls ? "k3p_rls_inverse_wave" : "k4p_rolling_inverse_wave") + (dtype == POLS_F32 ? "_f32" : "_f64");
-    return dtype == POLS_F32 ? kp_launch_t<float>(ctx, a, rls, single_chunk) : kp_launch_t<double>(ctx, a, rls, single_chunk);
+    K4Args aa = a;
+    if (!rls && !a.valid && !ctx->opt.debug_skip_fixup) {          // (POLS_DEBUG_SKIP_FIXUP: the walk's own answer, NaN on such rows -- the test's A/B)
+        // the list of rows whose sums could not be inverted (scratch slot 27, shared with K4c: [two counters that take turns][rows])
+        const int64_t n_rows = a.groups_end_row;
+        void *fx = nullptr;
+        const int64_t cap = std::min<int64_t>(std::max<int64_t>(n_rows, 1), (int64_t)1 << 22);
+        int rc = ensure_scratch(ctx, 27, 256 + sizeof(int64_t) * (size_t)cap, &fx);
+        if (rc) return rc;
+        if (ctx->k4c_fix_ptr != fx) { POLS_HIP(hipMemsetAsync(fx, 0, 256, ctx->stream)); ctx->k4c_fix_ptr = fx; ctx->k4c_fix_turn = 0; }
+        aa.fix_count = static_cast<int32_t *>(fx) + 32 * (ctx->k4c_fix_turn & 1);
+        aa.fix_next = static_cast<int32_t *>(fx) + 32 * ((ctx->k4c_fix_turn + 1) & 1);
+        ++ctx->k4c_fix_turn;
+        aa.fix_rows = reinterpret_cast<int64_t *>(static_cast<char *>(fx) + 256);
+        aa.fix_cap = cap;
+    }
+    return dtype == POLS_F32 ? kp_launch_t<float>(ctx, aa, rls, single_chunk) : kp_launch_t<double>(ctx, aa, rls, single_chunk);
 }
 
 }  // namespace pols

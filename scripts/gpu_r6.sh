@@ -85,6 +85,22 @@ k4cm)
   ( cd /tmp && export TMPDIR=/tmp; rm -rf $O/kt_dn; K=6 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dn -o k -- python $R/scripts/bench_dyn_nulls.py > /dev/null 2> $O/kt_dn.err
     f=$(find $O/kt_dn -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_dyn_nulls_k6.csv && head -30 $O/${TAG}_kernel_stats_dyn_nulls_k6.csv | cut -c1-160; rm -rf $O/kt_dn )
   ;;
+k4plu)
+  echo "== K4p: LU on rows without an inverse"
+  timeout 1500 python -m pytest tests/test_k4_gpu.py -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_pytest_k4plu.txt
+  ;;
+k4self)
+  echo "== K4c without a halo wave: parity (rolling tests), then cfg4r A/B against the halo-wave form"
+  timeout 1500 python -m pytest tests/test_k4_gpu.py tests/test_dyn_prep_gpu.py -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_pytest_k4self.txt
+  for i in 1 2 3; do
+    bench ${TAG}_bench_cfg4r_self_$i A=1 python bench.py --config cfg4r --steps 50 --warmup 10 --no-cpu-baseline
+    bench ${TAG}_bench_cfg4r_halowave_$i POLS_ROLLING_ENGINE=halowave python bench.py --config cfg4r --steps 50 --warmup 10 --no-cpu-baseline
+  done
+  POLS_TIMELINE=1 timeout 120 python bench.py --config cfg4r --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep timeline | tail -3 | tee $O/${TAG}_timeline_cfg4r.txt
+  for K in 6 8; do K=$K timeout 600 python scripts/bench_dyn_nulls.py 2>&1 | grep -v amdgpu; done | tee $O/${TAG}_bench_dyn_nulls_self.txt
+  kstats cfg4r A=1
+  pmc cfg4r A=1
+  ;;
 tests)
   timeout 3000 python -m pytest tests -m gpu -q --maxfail=25 2>&1 | tail -40 | tee $O/${TAG}_pytest_gpu.txt
   ;;

@@ -722,6 +722,55 @@ def test_rolling_divergence_band_is_pinned(eng, k, window, min_periods):
         assert np.allclose(d_c[i], ref["coef"][i], rtol=tol, atol=tol), (i, int(nobs[i]), tol)
 
 
+@pytest.mark.parametrize("k,window,shape", [(12, 40, "groups"), (16, 64, "long"), (24, 100, "groups"), (32, 80, "long"), (9, 600, "long")])
+def test_rolling_wide_windows_without_an_inverse_take_the_lu(eng, k, window, shape):
+    """K4p (9..32 features, null-free): a window whose sums cannot be inverted used to give NaN; the reference runs LU with partial pivoting
+    there (ls.rs:732-734) and so does kp_lu_fix_kernel now, on a list of such rows behind the walk.  Frame: one feature is another plus
+    1e-9 of noise -- every window's X'X is singular to working precision (cond ~ 1e18): the symmetric sweep meets a non-positive pivot on
+    about half the rows, the oracle's Cholesky likewise, and what either LU returns there is rounding noise in the twins' direction (the
+    reference's own numbers are).  What IS pinned:
+      * the NaN pattern equals the oracle's on every row with k or more observations (the reference never returns NaN there);
+      * POLS_DEBUG_SKIP_FIXUP=1 shows which rows the walk gave up on (NaN); the default route fills exactly those, and each filled row
+        solves ITS window's normal equations as well as an LU with partial pivoting does: |A beta - b| <= 1e-9 (|A| |beta| + |b|)
+        (backward stability -- a bound the conditioning does not enter);
+      * the rows the walk solved itself are bit-for-bit what they were."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k + window)
+    sizes = np.array([900, 40, 0, 700, k, 1021]) if shape == "groups" else np.array([2500, 300, 0, 1100])
+    y, cols, offs, _ = _frame(rng, sizes, k)
+    cols[1] = cols[0] + 1e-9 * rng.standard_normal(len(y))
+    y = sum(cols[2:]) + 2.0 * cols[0] + 0.1 * rng.standard_normal(len(y))
+    kw = dict(window_size=window, min_periods=k, null_policy="drop", null_free=True)
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    assert eng.last_kernel.startswith("k4p_"), eng.last_kernel
+    eng.set_option("DEBUG_SKIP_FIXUP", "1")
+    try:
+        raw = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    finally:
+        eng.set_option("DEBUG_SKIP_FIXUP", None)
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=k, null_policy="drop")
+    got_c, got_p, raw_c = _np(out["coef"]), _np(out["pred"]), _np(raw["coef"])
+    nobs = _window_obs(offs, None, window, "drop")
+    full = nobs >= k
+    assert np.array_equal(np.isnan(got_c).any(axis=1)[full], np.isnan(ref["coef"]).any(axis=1)[full])
+    assert np.isnan(got_c[~full]).all() and np.isnan(ref["coef"][~full]).all()
+    gave_up = full & np.isnan(raw_c).any(axis=1)
+    assert gave_up.sum() >= 0.05 * full.sum(), (int(gave_up.sum()), int(full.sum()))     # the frame does produce such rows
+    kept = full & ~gave_up
+    assert np.array_equal(got_c[kept], raw_c[kept])
+    X = np.stack(cols, axis=1)
+    filled = np.flatnonzero(gave_up & np.isfinite(got_c).all(axis=1))
+    assert len(filled) >= 0.9 * gave_up.sum()
+    for i in filled[:: max(1, len(filled) // 200)]:
+        lo, hi = _window_rows(offs, i, window)
+        A, b = X[lo:hi].T @ X[lo:hi], X[lo:hi].T @ y[lo:hi]
+        res = np.abs(A @ got_c[i] - b).max()
+        scale = np.abs(A).sum(axis=1).max() * np.abs(got_c[i]).max() + np.abs(b).max()
+        assert res <= 1e-9 * scale, (i, res, scale)
+        assert np.isclose(got_p[i], X[i] @ got_c[i], rtol=1e-9, atol=1e-9 * np.abs(X[i] * got_c[i]).sum())
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("k,window,min_periods,alpha,shape", [
     (11, 252, None, None, "groups"), (12, 100, 12, None, "long"), (12, 30, 1, None, "groups"), (16, 64, 16, 0.5, "long"), (17, 40, 17, None, "groups"),
