@@ -26,6 +26,7 @@
 #include "dyn_out.inl"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace pols {
 
@@ -79,7 +80,10 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     constexpr size_t TAB_B = sizeof(double) * NC * RUNS > sizeof(T) * 4 * (K + 1) * RUNS ? sizeof(double) * NC * RUNS : sizeof(T) * 4 * (K + 1) * RUNS;
     double *s_agg = reinterpret_cast<double *>(smem + TAB_B);    // [WAVES][NC]: wave totals (from the wave's last sequence start on)
     int *s_closed = reinterpret_cast<int *>(s_agg + WAVES * NC); // [WAVES]
-    [[maybe_unused]] double *s_P = reinterpret_cast<double *>(smem + TAB_B + sizeof(double) * WAVES * NC + 64);   // SELF: [NC][64] -- the rows in front of the tile
+    // SELF: the rows in front of the tile -- [4 (K + 1)][64] values, zero where they do not count, then [NC][64] sums -- and how many of a lane's count
+    [[maybe_unused]] double *s_H = reinterpret_cast<double *>(smem + TAB_B + sizeof(double) * WAVES * NC + 64);
+    constexpr int HN = NC > 4 * (K + 1) ? NC : 4 * (K + 1);
+    [[maybe_unused]] int *s_nin = reinterpret_cast<int *>(s_H + HN * 64);
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
 #define K4C_STAMP(i) do { if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     // consecutive tiles on one XCD (workgroup b runs on XCD b % 8): a tile's halo is its neighbour's body
@@ -175,24 +179,28 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     }
     double xo[R][K], yo[R];
     [[maybe_unused]] bool pre[R] = {};                                         // SELF: leaving row r lies in FRONT of the tile (loaded here, not handed over)
+    constexpr int NP = (NC + 3) / 4;                                           // SELF: components of the sums in front of the tile per wave
+    [[maybe_unused]] double Pp[NP];
     if constexpr (SELF) {
         if (wv == 0) {
             // The rows in front of the tile that this wave's windows reach: lane u's leaving rows i0 - window .. + 3 where they lie before
-            // the tile's first row.  They stay in xo / yo for the walk; their sum from the window's first row (or the last sequence start
-            // in front of the tile, whichever is later) up to the tile's first row is what the lane's prefix E(own run) lacks.
+            // the tile's first row.  They stay in xo / yo for the walk.  Their sum from the window's first row (or the last sequence start
+            // in front of the tile, whichever is later) up to the tile's first row is what the lane's prefix E(own run) lacks: a suffix sum
+            // over the lanes -- its NC components are shared out over the FOUR waves (the rows travel through LDS, zeroed where they do
+            // not count), so that no wave waits for 28 components' worth of scan on this one.
             unsigned hb = 0;                                                   // bit r: such a row starts a sequence
+            uint8_t sb[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {                                      // every load first (clamped into the frame, no branch between them): ONE round trip
+                const int64_t gi = hs + (u - sh) * R + o + r;
+                load_row(gi, xo[r], yo[r]);
+                sb[r] = a.start[gi < 0 ? 0 : (gi >= N ? N - 1 : gi)];
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int g = (u - sh) * R + o + r;                            // row index relative to the tile's first row
                 pre[r] = g < 0 && hs + g >= 0;
-                if (pre[r]) {
-                    load_row(hs + g, xo[r], yo[r]);
-                    if (a.start[hs + g]) hb |= 1u << r;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < K; ++j) xo[r][j] = 0.0;
-                    yo[r] = 0.0;
-                }
+                hb |= (pre[r] && sb[r]) ? 1u << r : 0u;
             }
             const unsigned long long hm = __ballot(hb != 0);
             int gstar = -(1 << 30);                                            // the last sequence start in front of the tile (as far back as the windows reach)
@@ -201,21 +209,16 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
                 const unsigned hbs = (unsigned)__shfl((int)hb, vs);
                 gstar = (vs - sh) * R + o + (31 - __clz(hbs));
             }
-            double L[NC];
-#pragma unroll
-            for (int q = 0; q < NC; ++q) L[q] = 0.0;
+            int nin = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool inc = pre[r] && (u - sh) * R + o + r >= gstar;
-                double xm[K];
+                nin += inc ? 1 : 0;
 #pragma unroll
-                for (int j = 0; j < K; ++j) xm[j] = inc ? xo[r][j] : 0.0;
-                add_row(L, xm, inc ? yo[r] : 0.0, 1.0);
-                L[NT] += inc ? 1.0 : 0.0;
+                for (int j = 0; j < K; ++j) s_H[(r * (K + 1) + j) * 64 + lane] = inc ? xo[r][j] : 0.0;
+                s_H[(r * (K + 1) + K) * 64 + lane] = inc ? yo[r] : 0.0;
             }
-            k4c_seg_scan_add<NC>(L, -1, lane);                                 // inclusive prefix over the lanes (no segments: the rows before the start are zeros)
-#pragma unroll
-            for (int q = 0; q < NC; ++q) s_P[q * 64 + lane] = readlane63(L[q]) - dpp_get0<0x138>(L[q]);   // total - exclusive prefix: the lanes from this one on
+            s_nin[lane] = nin;
         }
     }
     // The LEAVING rows of a body lane's run -- rows i0 - window .. + 3: rows (o + r) of the runs u - sh and u - sh + 1 -- are rows other
@@ -232,6 +235,43 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
             s_X[(size_t)(r * (K + 1) + K) * RUNS + u] = (T)y[r];
         }
         __syncthreads();
+        if constexpr (SELF) {
+            // this wave's components q = 4 i + wq of the 64 lanes' sums in front of the tile: local sums, an inclusive prefix over the lanes,
+            // total - exclusive prefix = the lanes from this one on; parked in registers until the rows' LDS can take them (after the next barrier)
+            double hx[R][K], hy[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) hx[r][j] = s_H[(r * (K + 1) + j) * 64 + lane];
+                hy[r] = s_H[(r * (K + 1) + K) * 64 + lane];
+            }
+            const double hn = (double)s_nin[lane];
+            auto part = [&](auto vc) {
+                constexpr int V = decltype(vc)::value;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) Pp[i] = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int p2 = 0; p2 < K; ++p2) {
+#pragma unroll
+                        for (int q2 = p2; q2 < K; ++q2)
+                            if (tri_index<K>(p2, q2) % 4 == V) Pp[tri_index<K>(p2, q2) / 4] = fma(hx[r][p2], hx[r][q2], Pp[tri_index<K>(p2, q2) / 4]);
+                        if ((NX + p2) % 4 == V) Pp[(NX + p2) / 4] = fma(hx[r][p2], hy[r], Pp[(NX + p2) / 4]);
+                    }
+                }
+                if (NT % 4 == V) Pp[NT / 4] = hn;
+            };
+            switch (wq) {
+                case 0: part(std::integral_constant<int, 0>{}); break;
+                case 1: part(std::integral_constant<int, 1>{}); break;
+                case 2: part(std::integral_constant<int, 2>{}); break;
+                default: part(std::integral_constant<int, 3>{}); break;
+            }
+            k4c_seg_scan_add<NP>(Pp, -1, lane);                                // (no segments: the rows before the last sequence start are zeros)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) Pp[i] = readlane63(Pp[i]) - dpp_get0<0x138>(Pp[i]);
+        }
         if (wv >= HW) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -293,6 +333,11 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     }
 #pragma unroll
     for (int q = 0; q < NC; ++q) s_E[q * RUNS + u] = ET[q];
+    if constexpr (SELF) {                                                      // (the rows in front of the tile have been read by every wave: two barriers ago)
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (4 * i + wq < NC) s_H[(4 * i + wq) * 64 + lane] = Pp[i];
+    }
     __syncthreads();
     if (wv < HW) return;                                                       // halo waves are done
     K4C_STAMP(2);
@@ -310,8 +355,8 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
         if (wv == 0) {                                                         // the part of the window in front of the tile (no sequence start in the tile before this run)
             const bool reach = eopen && (int64_t)u * R < w;
 #pragma unroll
-            for (int q = 0; q < NT; ++q) S[q] += reach ? s_P[q * 64 + lane] : 0.0;
-            cnt_excl += reach ? s_P[NT * 64 + lane] : 0.0;                     // (at most `window`: use_ep above stays false, the rows-in-front loop below idle)
+            for (int q = 0; q < NT; ++q) S[q] += reach ? s_H[q * 64 + lane] : 0.0;
+            cnt_excl += reach ? s_H[NT * 64 + lane] : 0.0;                     // (at most `window`: use_ep above stays false, the rows-in-front loop below idle)
         }
     }
     double cnt = cnt_excl;
@@ -512,7 +557,7 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     a.n_tiles = HW == 0 && !SELF ? a.n_packed : (a.n_rows + tile_rows - 1) / tile_rows;
     const int64_t per_xcd = (a.n_tiles + 7) / 8;
     const size_t tab = std::max(sizeof(double) * (size_t)NC * 64 * WAVES, sizeof(T) * (size_t)4 * (K + 1) * 64 * WAVES);   // the tile's rows, then the prefix table
-    const size_t lds = std::max(tab + sizeof(double) * WAVES * NC + 64 + (SELF ? sizeof(double) * NC * 64 : 0),     // ... + wave totals (+ SELF: the sums in front of the tile)
+    const size_t lds = std::max(tab + sizeof(double) * WAVES * NC + 64 + (SELF ? sizeof(double) * std::max(NC, 4 * (K + 1)) * 64 + 256 : 0),     // ... + wave totals (+ SELF: the sums in front of the tile)
                                 (size_t)(WAVES - HW) * 4 * (K + 1) * DYN_STAGE_STRIDE * sizeof(T));              // ... reused as the output staging area
     static OncePerDevice attr_once;
     if (attr_once.needed(ctx->device)) {
