@@ -209,7 +209,7 @@ bool options_set(Options &o, const char *key, const char *v) {
     else if (ieq(key, "RLS_ENGINE")) o.rls_engine = !on ? 0 : ieq(v, "seq") ? 1 : ieq(v, "scan") ? 2 : ieq(v, "chunk") ? 3 : ieq(v, "halo") ? 4 : 0;
     else if (ieq(key, "RLS_SPINS")) o.rls_spin_limit = on ? std::atoi(v) : d.rls_spin_limit;
     else if (ieq(key, "RLS_EARLY")) o.rls_early = on ? std::atoi(v) : d.rls_early;
-    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : ieq(v, "nocompact") ? 3 : ieq(v, "halowave") ? 4 : 0;
+    else if (ieq(key, "ROLLING_ENGINE")) o.rolling_engine = !on ? 0 : ieq(v, "chunk") ? 1 : ieq(v, "halo") ? 2 : ieq(v, "nocompact") ? 3 : ieq(v, "halowave") ? 4 : ieq(v, "scatter") ? 5 : 0;
     else if (ieq(key, "K1_ENGINE")) o.k1_engine = !on ? 0 : ieq(v, "valu") ? 1 : ieq(v, "mfma") ? 2 : 0;
     else if (ieq(key, "K9_TAKE")) o.k9_take = !on ? 0 : ieq(v, "gather") ? 1 : ieq(v, "scatter") ? 2 : 0;
     else return false;
@@ -1737,7 +1737,7 @@ static int dynamic_prologue(pols_ctx *ctx, const pols_batch *b, int null_policy,
         }
         if (has_w || icpt || some_invalid || some_null) {
             // (rows left out of the fit hold the nulls that put them there: zero-filled too, so that no kernel ever multiplies a NaN by 0)
-            if (may_defer && !has_w && !icpt && st->valid != nullptr) {
+            if (may_defer && !has_w && !icpt && st->valid != nullptr && !some_null) {    // (a null INSIDE a kept row has to be filled: no deferral)
                 ds->deferred = true;                          // the columns stay the caller's; dynamic_rewrite_deferred() does this later if needed
                 ds->outp.assign(outp.begin(), outp.end());
             } else {
@@ -1868,11 +1868,27 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     int64_t max_rows = 0;
     Staged st;
     DynState ds;
-    int rc = dynamic_prologue(ctx, b, p->null_policy, o, &d_offs, &max_rows, &st, &ds);
+    // (may_defer: the row-parallel kernel K3c masks invalid rows itself -- their values are SELECTED to zero, their decay is 1 -- so the zero-filling
+    //  rewrite of the frame, a read and a write of every column, is left out on frames it takes: 10 000 x 1 000 x 6 with 3 % nulls 0.49 -> 0.31 ms)
+    int rc = dynamic_prologue(ctx, b, p->null_policy, o, &d_offs, &max_rows, &st, &ds, true);
     if (rc) return rc;
     if (b->n_groups == 0 || b->n_rows == 0) return POLS_OK;
     if (o->resid) return fail(POLS_ERR_INVALID, "rls: residuals are target - predictions in the caller (least_squares.py:239)");
     const int kf = ds.k;                                  // features the kernels see (the intercept column included)
+    // Up to 10 features (8 + intercept and beyond): the row-parallel, read-once kernel (K3c, k3c_scan.hip) whatever the sequence lengths -- every
+    // access a 16-byte one down the row axis, so it needs 16-byte aligned columns / outputs (anything else: the chunk kernels below).
+    // POLS_RLS_ENGINE=seq|chunk go back to K3 / the lane-per-chunk K3s.
+    auto rowpar_ok = [&]() {
+        bool ok = kf <= K3C_KMAX && ctx->opt.rls_engine != 1 && ctx->opt.rls_engine != 3 && aligned16(st.y) && (!st.coef || aligned16(st.coef)) &&
+                  (!st.pred || aligned16(st.pred)) && (!st.valid || (reinterpret_cast<uintptr_t>(st.valid) & 3) == 0);
+        for (int j = 0; j < kf && ok; ++j) ok = aligned16(st.x[j]);
+        return ok;
+    };
+    bool rowpar = rowpar_ok();
+    if (!rowpar && ds.deferred) {                         // every other kernel wants zero-filled columns (and the rewritten ones are aligned)
+        if ((rc = dynamic_rewrite_deferred(ctx, b, &st, &ds))) return rc;
+        rowpar = rowpar_ok();
+    }
     K3Args a;
     std::memset(&a, 0, sizeof(a));
     a.y = st.y; a.valid = st.valid;
@@ -1897,12 +1913,6 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     bool scan = max_rows > 4096 || wide;
     if (ctx->opt.rls_engine == 1 && !wide) scan = false;
     if (ctx->opt.rls_engine == 2 || ctx->opt.rls_engine == 3) scan = true;
-    // Up to 9 features (8 + intercept): the row-parallel, read-once kernel (K3c, k3c_scan.hip) whatever the sequence lengths -- every access a
-    // 16-byte one down the row axis, so it needs 16-byte aligned columns / outputs (anything else: the chunk kernels below).
-    // POLS_RLS_ENGINE=seq|chunk go back to K3 / the lane-per-chunk K3s.
-    bool rowpar = kf <= K3C_KMAX && ctx->opt.rls_engine != 1 && ctx->opt.rls_engine != 3 && aligned16(st.y) && (!st.coef || aligned16(st.coef)) &&
-                  (!st.pred || aligned16(st.pred)) && (!st.valid || (reinterpret_cast<uintptr_t>(st.valid) & 3) == 0);
-    for (int j = 0; j < kf && rowpar; ++j) rowpar = aligned16(st.x[j]);
     if (rowpar) {
         const int64_t N = b->n_rows, tile_rows = k3c_tile_rows(kf), n_tiles = (N + tile_rows - 1) / tile_rows;
         const int64_t n_blocks = (n_tiles + 63) / 64;
@@ -1980,7 +1990,8 @@ int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_
     } else {
         if ((rc = k3_launch(ctx, b->dtype, a))) return rc;
     }
-    if (ds.post && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+    // (the row-parallel kernel writes the null predictions of the rows left out itself: the post pass is only its 1 / sqrt(w) un-scaling there)
+    if (ds.post && (!rowpar || ds.pa.sw_out) && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
     return unstage_outputs(ctx, b, b->n_rows, kf, o, st);
 }
 
@@ -2173,15 +2184,19 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         const size_t b_cnt = round256(sizeof(uint32_t) * (size_t)n_slabs), b_base = round256(sizeof(int64_t) * (size_t)(n_slabs + 1)),
                      b_offs = round256(sizeof(int64_t) * (size_t)(G + 1)), b_gf = round256(sizeof(int64_t) * (size_t)n_slabs),
                      b_tab = round256(sizeof(void *) * (size_t)(k + 1));
+        // Up to 10 features the tile kernel GATHERS the valid rows through a source map and writes the frame's rows itself (k4c_kernel.inl GATHER,
+        // dyn_out_gather.inl): no compacted copy of the columns, no expansion pass.  POLS_ROLLING_ENGINE=scatter keeps the three-pass form (and
+        // K4p, 11..32 features, still runs on compacted columns).
+        const bool gather = c_tiles_ok && N < ((int64_t)1 << 31) && ctx->opt.rolling_engine != 5;
         void *d = nullptr;
-        if ((rc = ensure_scratch(ctx, 19, b_cnt + b_base + b_offs + b_gf + 2 * b_tab + colb * (size_t)(k + 1), &d))) return rc;
+        if ((rc = ensure_scratch(ctx, 19, b_cnt + b_base + b_offs + b_gf + 2 * b_tab + (gather ? 0 : colb * (size_t)(k + 1)), &d))) return rc;
         char *base = static_cast<char *>(d);
         char *cols = base + b_cnt + b_base + b_offs + b_gf + 2 * b_tab;
         std::vector<const void *> inp((size_t)k + 1);
         std::vector<void *> outp((size_t)k + 1);
         inp[0] = st.y;
         for (int j = 0; j < k; ++j) inp[(size_t)j + 1] = st.x[(size_t)j];
-        for (int j = 0; j <= k; ++j) outp[(size_t)j] = cols + colb * (size_t)j;
+        for (int j = 0; j <= k; ++j) outp[(size_t)j] = gather ? nullptr : cols + colb * (size_t)j;
         if ((rc = upload_small(ctx, base + b_cnt + b_base + b_offs + b_gf, inp.data(), sizeof(void *) * (size_t)(k + 1)))) return rc;
         if ((rc = upload_small(ctx, base + b_cnt + b_base + b_offs + b_gf + b_tab, outp.data(), sizeof(void *) * (size_t)(k + 1)))) return rc;
         RowCompactArgs ra;
@@ -2209,9 +2224,16 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
         }
         if (Nc < 8) tiles_c = false;
         if (tiles_c) {
-            if ((rc = row_compact_scatter_launch(ctx, b->dtype, ra))) return rc;
             void *dc = nullptr, *df = nullptr, *dm = nullptr;
-            if ((rc = ensure_scratch(ctx, 20, round256(sz * (size_t)Nc * (size_t)k), &dc))) return rc;
+            if (gather) {
+                void *dsrc = nullptr;
+                if ((rc = ensure_scratch(ctx, 23, round256(sizeof(int32_t) * (size_t)(Nc + 4)), &dsrc))) return rc;
+                ra.src = static_cast<int32_t *>(dsrc);
+                if ((rc = row_compact_srcmap_launch(ctx, ra))) return rc;
+            } else {
+                if ((rc = row_compact_scatter_launch(ctx, b->dtype, ra))) return rc;
+                if ((rc = ensure_scratch(ctx, 20, round256(sz * (size_t)Nc * (size_t)k), &dc))) return rc;
+            }
             if (!c_tiles_ok) {
                 // the compacted frame through K4p: chunk tables of the COMPACTED offsets (never cached: two null patterns of one frame can
                 // share every key the cache compares)
@@ -2242,9 +2264,16 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
             K4cArgs c;
             std::memset(&c, 0, sizeof(c));
             c.start = static_cast<const uint8_t *>(df);
-            c.y = outp[0];
-            for (int j = 0; j < k; ++j) c.x[j] = outp[(size_t)j + 1];
-            c.n_rows = Nc; c.coef = dc; c.pred = nullptr;
+            if (gather) {
+                c.y = st.y;
+                for (int j = 0; j < k; ++j) c.x[j] = st.x[(size_t)j];
+                c.src = ra.src; c.n_frame = N; c.fvalid = st.valid; c.fstart = ra.start;
+                c.n_rows = Nc; c.coef = st.coef; c.pred = st.pred;
+            } else {
+                c.y = outp[0];
+                for (int j = 0; j < k; ++j) c.x[j] = outp[(size_t)j + 1];
+                c.n_rows = Nc; c.coef = dc; c.pred = nullptr;
+            }
             c.window = w; c.min_periods = mp; c.alpha = p->alpha > 0.0 ? p->alpha : 0.0; c.k = k;
             if (max_c <= K4C_PACKED_ROWS - 3 && (ctx->opt.rolling_engine != 2 || w > k4c_max_window(k))) {
                 std::vector<int64_t> first;
@@ -2259,6 +2288,11 @@ int pols_rolling_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ro
                 }
             }
             if ((rc = k4c_launch(ctx, b->dtype, c))) return rc;
+            if (gather) {
+                // (the kernel wrote NaN predictions on the rows left out: the post pass is only needed for the 1 / sqrt(w) un-scaling)
+                if (ds.post && ds.pa.sw_out && (rc = dyn_post_launch(ctx, b->dtype, ds.pa))) return rc;
+                return unstage_outputs(ctx, b, b->n_rows, k, o, st);
+            }
             ra.coef_c = dc; ra.coef = st.coef; ra.pred = st.pred;
             if ((rc = row_compact_expand_launch(ctx, b->dtype, ra))) return rc;
             ctx->last_kernel += "_compacted";

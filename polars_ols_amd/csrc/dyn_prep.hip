@@ -184,30 +184,41 @@ __global__ void __launch_bounds__(RC_SLAB) rc_count_kernel(const RowCompactArgs 
     if (threadIdx.x == 0) a.slab_cnt[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(1024) rc_scan_kernel(const RowCompactArgs a) {          // one workgroup: exclusive prefix over the slabs
+// Exclusive prefix over the slabs, one workgroup per 1 024 of them (see rm_blk_kernel / rm_scan_kernel below: one workgroup looping over the
+// 39 000 slabs of a 10M-row frame took 55 us, the two launches of ~40 workgroups take 3 + 5).
+__global__ void __launch_bounds__(1024) rc_blk_kernel(const RowCompactArgs a) {
     __shared__ long long part[1024 / 64];
-    __shared__ long long carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
+    const int64_t s = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    long long v = s < a.n_slabs ? (long long)a.slab_cnt[s] : 0;
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) part[wave] = v;
     __syncthreads();
-    for (int64_t s0 = 0; s0 < a.n_slabs; s0 += 1024) {
-        const int64_t s = s0 + threadIdx.x;
-        const long long v = s < a.n_slabs ? (long long)a.slab_cnt[s] : 0;
-        long long incl = v;                                   // inclusive scan inside the wave
-        for (int off = 1; off < 64; off <<= 1) {
-            const long long up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        if (lane == 63) part[wave] = incl;
-        __syncthreads();
-        long long before = carry;
-        for (int w = 0; w < wave; ++w) before += part[w];
-        if (s < a.n_slabs) a.slab_base[s] = before + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before + incl;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < 1024 / 64; ++w) t += part[w];
+        a.blk_cnt[blockIdx.x] = (unsigned long long)t;
     }
-    if (threadIdx.x == 0) a.slab_base[a.n_slabs] = carry;
+}
+
+__global__ void __launch_bounds__(1024) rc_scan_kernel(const RowCompactArgs a) {
+    __shared__ long long part[1024 / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long before = 0;                                    // the blocks below this one
+    for (int64_t b2 = lane; b2 < (int64_t)blockIdx.x; b2 += 64) before += (long long)a.blk_cnt[b2];
+    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off);
+    const int64_t s = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const long long v = s < a.n_slabs ? (long long)a.slab_cnt[s] : 0;
+    long long incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) before += part[w];
+    if (s < a.n_slabs) a.slab_base[s] = before + incl - v;
+    if (s == a.n_slabs - 1) a.slab_base[a.n_slabs] = before + incl;
 }
 
 __global__ void __launch_bounds__(256) rc_groups_kernel(const RowCompactArgs a) {
@@ -215,8 +226,16 @@ __global__ void __launch_bounds__(256) rc_groups_kernel(const RowCompactArgs a) 
     if (g > a.n_groups) return;
     const int64_t r0 = a.offs[g], s = r0 / RC_SLAB;
     int64_t c = a.slab_base[s < a.n_slabs ? s : a.n_slabs];
-    if (s < a.n_slabs)
-        for (int64_t i = s * RC_SLAB; i < r0; ++i) c += a.valid[i] ? 1 : 0;
+    if (s < a.n_slabs) {
+        int64_t i = s * RC_SLAB;
+        if ((reinterpret_cast<uintptr_t>(a.valid) & 3) == 0) {                          // four validity bytes (0 / 1) per load
+            for (; i + 4 <= r0; i += 4) {
+                const unsigned v4 = *reinterpret_cast<const unsigned *>(a.valid + i);
+                c += ((v4 & 0xffu) != 0) + ((v4 & 0xff00u) != 0) + ((v4 & 0xff0000u) != 0) + ((v4 & 0xff000000u) != 0);
+            }
+        }
+        for (; i < r0; ++i) c += a.valid[i] ? 1 : 0;
+    }
     a.c_offs[g] = c;
 }
 
@@ -259,6 +278,16 @@ __global__ void __launch_bounds__(RC_SLAB) rc_scatter_kernel(const RowCompactArg
             static_cast<T *>(a.out[c])[pos] = v;
         }
     }
+}
+
+// The source map instead of the compacted columns: 4 bytes per valid row written where the scatter copies k + 1 columns
+__global__ void __launch_bounds__(RC_SLAB) rc_srcmap_kernel(const RowCompactArgs a) {
+    __shared__ unsigned wave_cnt[RC_SLAB / 64];
+    const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
+    const bool ok = r < a.n_rows && a.valid[r];
+    unsigned total;
+    const unsigned incl = rc_slab_prefix(ok, wave_cnt, &total);
+    if (ok) a.src[a.slab_base[blockIdx.x] + incl - 1] = (int32_t)r;
 }
 
 template <typename T>
@@ -563,10 +592,17 @@ int row_compact_mask_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a) {
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }
-int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a) {
-    if (a.n_rows == 0) return POLS_OK;
+int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a0) {
+    if (a0.n_rows == 0) return POLS_OK;
+    RowCompactArgs a = a0;
+    const unsigned n_blk = (unsigned)((a.n_slabs + 1023) / 1024);
+    void *bc = nullptr;
+    int rc = ensure_scratch(ctx, 26, sizeof(unsigned long long) * (size_t)n_blk, &bc);    // totals of every 1 024 slabs
+    if (rc) return rc;
+    a.blk_cnt = static_cast<unsigned long long *>(bc);
     hipLaunchKernelGGL(rc_count_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
-    hipLaunchKernelGGL(rc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rc_blk_kernel, dim3(n_blk), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rc_scan_kernel, dim3(n_blk), dim3(1024), 0, ctx->stream, a);
     hipLaunchKernelGGL(rc_groups_kernel, dim3((unsigned)((a.n_groups + 1 + 255) / 256)), dim3(256), 0, ctx->stream, a);
     if (a.slab_gfirst) hipLaunchKernelGGL(rc_gfirst_kernel, dim3((unsigned)((a.n_slabs + 255) / 256)), dim3(256), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
@@ -576,6 +612,12 @@ int row_compact_scatter_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a
     if (a.n_rows == 0) return POLS_OK;
     if (dtype == POLS_F32) hipLaunchKernelGGL(rc_scatter_kernel<float>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
     else hipLaunchKernelGGL(rc_scatter_kernel<double>, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
+    POLS_HIP(hipGetLastError());
+    return POLS_OK;
+}
+int row_compact_srcmap_launch(pols_ctx *ctx, const RowCompactArgs &a) {
+    if (a.n_rows == 0) return POLS_OK;
+    hipLaunchKernelGGL(rc_srcmap_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     return POLS_OK;
 }

@@ -87,11 +87,14 @@ struct RowCompactArgs {
     int32_t n_mask, drop;        // drop == 0: only valid_in decides
     // scatter: what a surviving null becomes -- the weights column -> 1e-24 (least_squares.py:193), others -> 0 when zero_fill
     int32_t w_col, zero_fill;
+    unsigned long long *blk_cnt; // valid rows of every 1 024 slabs (set by row_compact_offsets_launch)
+    int32_t *src;                // source map (row_compact_srcmap_launch): src[c] = the frame row compacted row c came from, n_valid entries
 };
 int row_compact_mask_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
 int row_compact_offsets_launch(pols_ctx *ctx, const RowCompactArgs &a);            // count + scan + groups
 int row_compact_scatter_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
 int row_compact_expand_launch(pols_ctx *ctx, int dtype, const RowCompactArgs &a);
+int row_compact_srcmap_launch(pols_ctx *ctx, const RowCompactArgs &a);             // instead of the scatter: the tile kernel gathers through src (k4c_kernel.inl, GATHER)
 
 // The validity prefix of the chunk-parallel dynamic kernels (K4Args::cnt / vidx and the per-group warm-up constants of
 // solve_rolling_ols, ls.rs:881-891) built ON THE DEVICE from device validity bytes: the host-side build copied the bytes home, walked

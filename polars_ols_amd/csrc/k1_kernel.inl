@@ -1371,6 +1371,8 @@ static int k1_launch_fast(pols_ctx *ctx, const K1Args &a) {
     // (POLS_K1_NT_LOADS=0 selects the plain-load build of the same kernel)
     // (the f64 two-wave kernel of cfg3 as well: 169-173 against 173-174 us per call; the f32 256-thread team from 8 columns: 71.9 vs
     // 72.4 us at 8 -- but 57.8 vs 50.4 us at 6 columns, where the plain loads win by far)
+    // (round 6: `nt` loads in the null-policy build of the f32 256-thread team measured no different -- "drop" on a null-free frame 80.8 vs 80.4 us,
+    // 5 % null targets 85.5 vs 86.0, profiles/r06_bench_nulls.txt -- so that build keeps its plain loads)
     constexpr bool HAS_NT = ((sizeof(T) == 4 && TEAM == 64 && RC == 4 && NPASS == 1) || (sizeof(T) == 4 && TEAM == 256 && RC == 1 && KT >= 8 && KT <= 10) || (sizeof(T) == 8 && TEAM == 128 && RC == 4 && NPASS == 2 && KT <= 8)) &&
                             FAST && !NULLS;
     if constexpr (HAS_NT) {

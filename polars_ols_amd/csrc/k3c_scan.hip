@@ -398,8 +398,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
         }
     }
     // Invalid rows leave the fit: their element is the identity (decay 1, nothing added).  Branch-free: the row's values become
-    // zeros and its decay 1, so that every lane runs the same instruction stream (their predictions are masked by the caller's
-    // post pass, ex.rs:640-645).
+    // zeros and its decay 1, so that every lane runs the same instruction stream (their predictions are NaN: the walk below,
+    // ex.rs:640-645).
     bool st[R];
     unsigned fit = 0;                             // bit r: row r is a valid row inside the frame (its decay is ff, else 1)
 #pragma unroll
@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : (K <= 8 ? 2 : 1))
             pr = fma(xr[j], beta[j], pr);
         }
         prd[r] = (T)pr;
+        if (a.valid) prd[r] = ((fit >> r) & 1u) ? prd[r] : nan_if<T>(1u, T(0));   // a row left out of the fit: a null prediction (make_predictions(.., is_valid), ex.rs:640-645)
         asm volatile("" : "+v"(prd[r]));           // computed HERE: left alone the compiler keeps x and beta of every row alive for it (190 VGPRs, not 150)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

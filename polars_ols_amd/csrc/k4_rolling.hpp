@@ -161,6 +161,12 @@ struct K4cArgs {
     int32_t k;
     const int64_t *tile_row0;          // PACKED tiles (or nullptr), K3cArgs::tile_row0's table for 1 024-row tiles: whole sequences per tile, so no
     int64_t n_packed;                  // window reaches outside it and the halo waves go (n_packed tiles)
+    // GATHER ("drop" family on a frame with nulls): the kernel's rows are the VALID rows of the frame -- n_rows of them, `start` their
+    // sequence-start flags -- read THROUGH src from the frame's own columns x / y, and the outputs go to the FRAME's rows (forward fill,
+    // dyn_out_gather.inl): no compacted copy of the columns, no expansion pass.  nullptr: the rows are the columns' rows.
+    const int32_t *src;                // src[c]: the frame row of compacted row c
+    int64_t n_frame;                   // rows of the frame (coef / pred are n_frame x k / n_frame)
+    const uint8_t *fvalid, *fstart;    // the frame's validity and sequence-start bytes
 };
 // widest window of the halo forms (packed tiles take any window: nothing reaches outside a tile)
 constexpr int64_t k4c_max_window(int k) { return k <= 6 ? K4C_MAX_WINDOW : 252; }

@@ -24,6 +24,7 @@
 #include "k4_rolling.hpp"
 #include "k4_small.inl"
 #include "dyn_out.inl"
+#include "dyn_out_gather.inl"
 
 #include <algorithm>
 #include <type_traits>
@@ -67,9 +68,15 @@ __device__ __forceinline__ void k4c_seg_scan_add(double (&Tv)[NC], const int h, 
 // and the tile's first row: a suffix sum over those same leaving rows, one 64-lane scan on that wave alone (total - prefix), parked in LDS
 // next to the table.  A quarter of every workgroup used to be halo: 1 303 tiles of 768 rows on 512 tile slots (three rounds) become 977
 // tiles of 1 024 rows (two).  Which wave takes the tile's first 256 rows rotates with the tile so that the extra work spreads over the SIMDs.
-template <typename T, int K, int HW, int WAVES, bool MASKED, bool SELF = false>
+//
+// GATHER (round 6, the "drop" family on frames WITH nulls, ls.rs:947-986): the rows of this kernel are the frame's VALID rows, read through
+// the source map a.src from the frame's own columns (8-byte loads: a run's four rows are neighbours in the frame but for the nulls between
+// them), and every wave writes the FRAME rows between its first valid row and the next wave's -- coefficients forward-filled inside the
+// sequence, NaN predictions on the rows left out (dyn_out_gather.inl).  The compacted copy of the columns and the expansion pass are gone.
+template <typename T, int K, int HW, int WAVES, bool MASKED, bool SELF = false, bool GATHER = false>
 __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K4cArgs a) {
     static_assert(!SELF || (HW == 0 && WAVES == 4), "the own-halo form: four body waves");
+    static_assert(!GATHER || !MASKED, "the gathered rows are all valid");
     constexpr int BW = WAVES - HW, R = 4, RUNS = WAVES * 64;
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N, NC = NT + 1;   // slot NT: rows since the last sequence start (or the halo's first row)
     using V = typename Vec16<T>::type;
@@ -105,7 +112,8 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
                                                                                // rows); packed tiles: a negative one is never looked up (use_ep below is false)
     const int64_t rho_run = hs + (int64_t)(u - sh) * R;                        // first row of the run holding row i0 - window
     auto load_row = [&](int64_t i, double (&xr)[K], double &yr) {              // one row, clamped into the frame (callers mask)
-        const int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
+        int64_t ic = i < 0 ? 0 : (i >= N ? N - 1 : i);
+        if constexpr (GATHER) ic = a.src[ic];
         bool vr = true;
         if constexpr (MASKED) vr = a.valid[ic] != 0;
 #pragma unroll
@@ -125,7 +133,39 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     double x[R][K], y[R];
     unsigned sbits = 0;
     [[maybe_unused]] unsigned vmask = 0;                                        // MASKED: byte r != 0 -- row i0 + r is valid
-    if (__all(inside)) {
+    [[maybe_unused]] int64_t g_ra = 0, g_rb = 0;
+    [[maybe_unused]] unsigned g_vb[DYN_GATHER_PRE], g_sb[DYN_GATHER_PRE];
+    [[maybe_unused]] const int64_t gwrow0 = hs + (int64_t)wv * 64 * R;                       // GATHER: the compacted rows [gc0, gc1) whose outputs this wave holds
+    [[maybe_unused]] const int64_t gc0 = gwrow0 > lo ? gwrow0 : lo, gc1 = gwrow0 + 256 < hi ? gwrow0 + 256 : hi;
+    if constexpr (GATHER) {
+        // the run's four rows through the source map (one 16-byte load of it when the run lies inside the frame), then a row at a time
+        int32_t sr[R];
+        bool in[R];
+        if (inside) {
+            const int4 s4 = *reinterpret_cast<const int4 *>(a.src + i0);
+            sr[0] = s4.x; sr[1] = s4.y; sr[2] = s4.z; sr[3] = s4.w;
+#pragma unroll
+            for (int r = 0; r < R; ++r) in[r] = true;
+            sbits = *reinterpret_cast<const unsigned *>(a.start + i0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t i = i0 + r;
+                in[r] = i >= 0 && i < N;
+                sr[r] = in[r] ? a.src[i] : 0;
+                if (in[r] && a.start[i]) sbits |= 1u << (8 * r);
+            }
+        }
+        // (the frame rows this wave will write and their validity / sequence-start bytes: two more reads of the source map in this round trip,
+        // the bytes in the next one, behind the rows)
+        dyn_gather_range(g_ra, g_rb, g_vb, g_sb, lane, gc0, gc1, a.src, N, a.n_frame, a.fvalid, a.fstart);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) x[r][j] = in[r] ? (double)static_cast<const T *>(a.x[j])[sr[r]] : 0.0;
+            y[r] = in[r] ? (double)static_cast<const T *>(a.y)[sr[r]] : 0.0;
+        }
+    } else if (__all(inside)) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const V *p = reinterpret_cast<const V *>(static_cast<const T *>(a.x[j]) + i0);
@@ -415,7 +455,9 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    {
+    if constexpr (GATHER) {
+        dyn_wave_copy_out_gather<T, K, K + 1>(stage, lane, gwrow0, gc0, gc1, g_ra, g_rb, g_vb, g_sb, a.fvalid, a.fstart, coef, pred);
+    } else {
         const T none[4] = {};
         dyn_wave_copy_out<T, K, K + 1>(stage, lane, hs + (int64_t)wv * 64 * R, hi, coef, pred, lo, none);
     }
@@ -452,7 +494,9 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
 // The rows whose window sums have no L D L' factorisation, solved the reference's way (Cholesky -> LU with partial pivoting, ls.rs:732-734 /
 // :277-337): one wave per listed row re-sums the window -- the rows (i - window, i] of the row's sequence, the valid ones under MASKED --
 // from global memory, every lane runs the same K x K elimination, the coefficients and the prediction replace the NaNs.
-template <typename T, int K, bool MASKED>
+// GATHER: the listed rows are compacted rows -- their windows are read through the source map, and the coefficients go to every frame row
+// that repeats them (up to the next valid row, the end of the sequence or of the frame).
+template <typename T, int K, bool MASKED, bool GATHER = false>
 __global__ void __launch_bounds__(64) k4c_lu_fix_kernel(const K4cArgs a) {
     constexpr int NX = K4N<K>::NX, NT = K4N<K>::N;
     const int lane = threadIdx.x;
@@ -472,9 +516,10 @@ __global__ void __launch_bounds__(64) k4c_lu_fix_kernel(const K4cArgs a) {
         for (int64_t j = lo + lane; j <= i; j += 64) {
             if constexpr (MASKED) { if (!a.valid[j]) continue; }
             double xr[K];
+            const int64_t jf = GATHER ? (int64_t)a.src[j] : j;
 #pragma unroll
-            for (int p = 0; p < K; ++p) xr[p] = (double)static_cast<const T *>(a.x[p])[j];
-            const double yr = (double)static_cast<const T *>(a.y)[j];
+            for (int p = 0; p < K; ++p) xr[p] = (double)static_cast<const T *>(a.x[p])[jf];
+            const double yr = (double)static_cast<const T *>(a.y)[jf];
 #pragma unroll
             for (int p = 0; p < K; ++p) {
 #pragma unroll
@@ -534,16 +579,22 @@ __global__ void __launch_bounds__(64) k4c_lu_fix_kernel(const K4cArgs a) {
             double pr = 0.0;
             bool vi = true;
             if constexpr (MASKED) vi = a.valid[i] != 0;
+            const int64_t fi = GATHER ? (int64_t)a.src[i] : i;
             for (int p = 0; p < K; ++p) {
-                if (a.coef) static_cast<T *>(a.coef)[i * K + p] = (T)beta[p];
-                pr = fma(vi ? (double)static_cast<const T *>(a.x[p])[i] : 0.0, beta[p], pr);
+                if (a.coef) static_cast<T *>(a.coef)[fi * K + p] = (T)beta[p];
+                pr = fma(vi ? (double)static_cast<const T *>(a.x[p])[fi] : 0.0, beta[p], pr);
             }
-            if (a.pred) static_cast<T *>(a.pred)[i] = vi ? (T)pr : nan_if<T>(1u, T(0));      // (a masked row's prediction is a null)
+            if (a.pred) static_cast<T *>(a.pred)[fi] = vi ? (T)pr : nan_if<T>(1u, T(0));     // (a masked row's prediction is a null)
+            if constexpr (GATHER) {                                                           // the rows left out behind it repeat its coefficients
+                const int64_t fe = i + 1 < a.n_rows ? (int64_t)a.src[i + 1] : a.n_frame;
+                for (int64_t f = fi + 1; f < fe && !a.fstart[f] && a.coef; ++f)
+                    for (int p = 0; p < K; ++p) static_cast<T *>(a.coef)[f * K + p] = (T)beta[p];
+            }
         }
     }
 }
 
-template <typename T, int K, int HW, bool MASKED, bool SELF = false>
+template <typename T, int K, int HW, bool MASKED, bool SELF = false, bool GATHER = false>
 static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     constexpr int NC = K4N<K>::N + 1;
     // Waves per workgroup.  The prefix table is NC x 64 WAVES doubles of LDS (K = 6: 14 KiB per wave) and a lane holds its entering
@@ -561,7 +612,7 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
                                 (size_t)(WAVES - HW) * 4 * (K + 1) * DYN_STAGE_STRIDE * sizeof(T));              // ... reused as the output staging area
     static OncePerDevice attr_once;
     if (attr_once.needed(ctx->device)) {
-        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k4c_kernel<T, K, HW, WAVES, MASKED, SELF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        POLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k4c_kernel<T, K, HW, WAVES, MASKED, SELF, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_once.done(ctx->device);
     }
     if (ctx->opt.timeline) {
@@ -587,41 +638,41 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
         a.fix_rows = reinterpret_cast<int64_t *>(static_cast<char *>(fx) + 256);
         a.fix_cap = cap;
     }
-    hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES, MASKED, SELF>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
+    hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES, MASKED, SELF, GATHER>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
                           timed ? e1 : nullptr, 0, a);
-    hipLaunchKernelGGL((k4c_lu_fix_kernel<T, K, MASKED>), dim3(128), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k4c_lu_fix_kernel<T, K, MASKED, GATHER>), dim3(128), dim3(64), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k4c_rolling_tiles");
     return POLS_OK;
 }
 
-template <typename T, int K, bool MASKED>
+template <typename T, int K, bool MASKED, bool GATHER = false>
 static int k4c_launch_k(pols_ctx *ctx, const K4cArgs &a) {
-    if (a.tile_row0) return k4c_launch_h<T, K, 0, MASKED>(ctx, a);                              // packed tiles: no halo
+    if (a.tile_row0) return k4c_launch_h<T, K, 0, MASKED, false, GATHER>(ctx, a);                // packed tiles: no halo
     // no halo wave: the tile's first wave reaches in front of the tile itself (windows up to 256 rows; at 10 features the table and the parked sums
     // are more than a CU's LDS).  POLS_ROLLING_ENGINE=halowave keeps the halo wave (A/B).
     if constexpr (K <= 9) {
-        if (a.window <= 256 && ctx->opt.rolling_engine != 4) return k4c_launch_h<T, K, 0, MASKED, true>(ctx, a);
+        if (a.window <= 256 && ctx->opt.rolling_engine != 4) return k4c_launch_h<T, K, 0, MASKED, true, GATHER>(ctx, a);
     }
-    if (a.window <= 252) return k4c_launch_h<T, K, 1, MASKED>(ctx, a);                          // 256 HW >= 4 ceil(window / 4) + 1
-    if constexpr (K <= 6) return k4c_launch_h<T, K, 2, MASKED>(ctx, a);
+    if (a.window <= 252) return k4c_launch_h<T, K, 1, MASKED, false, GATHER>(ctx, a);            // 256 HW >= 4 ceil(window / 4) + 1
+    if constexpr (K <= 6) return k4c_launch_h<T, K, 2, MASKED, false, GATHER>(ctx, a);
     // (7 / 8 features need more than 256 registers: one four-wave workgroup per CU; the eight-wave two-halo form would spill)
     return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): window %lld with %d features needs packed tiles", (long long)a.window, K);
 }
 
-template <typename T, bool MASKED>
+template <typename T, bool MASKED, bool GATHER = false>
 static int k4c_launch_t(pols_ctx *ctx, const K4cArgs &a) {
     switch (a.k) {
-        case 1: return k4c_launch_k<T, 1, MASKED>(ctx, a);
-        case 2: return k4c_launch_k<T, 2, MASKED>(ctx, a);
-        case 3: return k4c_launch_k<T, 3, MASKED>(ctx, a);
-        case 4: return k4c_launch_k<T, 4, MASKED>(ctx, a);
-        case 5: return k4c_launch_k<T, 5, MASKED>(ctx, a);
-        case 6: return k4c_launch_k<T, 6, MASKED>(ctx, a);
-        case 7: return k4c_launch_k<T, 7, MASKED>(ctx, a);
-        case 8: return k4c_launch_k<T, 8, MASKED>(ctx, a);
-        case 9: return k4c_launch_k<T, 9, MASKED>(ctx, a);
-        case 10: return k4c_launch_k<T, 10, MASKED>(ctx, a);
+        case 1: return k4c_launch_k<T, 1, MASKED, GATHER>(ctx, a);
+        case 2: return k4c_launch_k<T, 2, MASKED, GATHER>(ctx, a);
+        case 3: return k4c_launch_k<T, 3, MASKED, GATHER>(ctx, a);
+        case 4: return k4c_launch_k<T, 4, MASKED, GATHER>(ctx, a);
+        case 5: return k4c_launch_k<T, 5, MASKED, GATHER>(ctx, a);
+        case 6: return k4c_launch_k<T, 6, MASKED, GATHER>(ctx, a);
+        case 7: return k4c_launch_k<T, 7, MASKED, GATHER>(ctx, a);
+        case 8: return k4c_launch_k<T, 8, MASKED, GATHER>(ctx, a);
+        case 9: return k4c_launch_k<T, 9, MASKED, GATHER>(ctx, a);
+        case 10: return k4c_launch_k<T, 10, MASKED, GATHER>(ctx, a);
         default: return fail(POLS_ERR_UNSUPPORTED, "rolling (row-parallel): %d features > %d", a.k, K4C_KMAX);
     }
 }

@@ -101,6 +101,24 @@ k4self)
   kstats cfg4r A=1
   pmc cfg4r A=1
   ;;
+nulls)
+  echo "== null-policy cost on the headline shape: nt loads in the null-policy build (default) vs plain loads, one and two passes"
+  for v in "A=1" "POLS_K1_NT_LOADS=0" "POLS_K1_PASSES=2"; do
+    echo "-- $v"; env $v timeout 600 python scripts/bench_nulls.py 2>/dev/null | python -c "
+import sys, json
+for k, v in json.loads(sys.stdin.read()).items(): print(f'{k:36s} {v[\"us\"]:8.2f} us  {v[\"kernel\"]}')"
+  done | tee $O/${TAG}_bench_nulls.txt
+  timeout 900 python -m pytest tests/test_nulls_gpu.py -m gpu -x -q 2>&1 | tail -3 | tee $O/${TAG}_pytest_nulls.txt
+  ;;
+gather)
+  echo "== drop family with nulls: the gathered tile kernel; RLS without the zero-fill rewrite"
+  timeout 1500 python -m pytest tests/test_k4_gpu.py tests/test_k3_gpu.py tests/test_dyn_prep_gpu.py tests/test_frontend_gpu.py -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_pytest_gather.txt
+  for K in 6 8 10; do K=$K timeout 600 python scripts/bench_dyn_nulls.py 2>&1 | grep -v amdgpu; done | tee $O/${TAG}_bench_dyn_nulls.txt
+  echo "-- POLS_ROLLING_ENGINE=scatter (the three-pass form)" | tee -a $O/${TAG}_bench_dyn_nulls.txt
+  K=6 POLS_ROLLING_ENGINE=scatter timeout 600 python scripts/bench_dyn_nulls.py 2>&1 | grep -v amdgpu | grep "drop " | tee -a $O/${TAG}_bench_dyn_nulls.txt
+  ( cd /tmp && export TMPDIR=/tmp; rm -rf $O/kt_dn; K=6 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dn -o k -- python $R/scripts/bench_dyn_nulls.py > /dev/null 2> $O/kt_dn.err
+    f=$(find $O/kt_dn -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_dyn_nulls_k6.csv && grep pols:: $O/${TAG}_kernel_stats_dyn_nulls_k6.csv | cut -c1-150 | head -24; rm -rf $O/kt_dn )
+  ;;
 tests)
   timeout 3000 python -m pytest tests -m gpu -q --maxfail=25 2>&1 | tail -40 | tee $O/${TAG}_pytest_gpu.txt
   ;;

@@ -599,7 +599,7 @@ def test_rolling_drop_with_nulls_compacted(eng, dtype, tol, k, window, min_perio
             yy[valid == 0] = np.nan
         args = dict(window_size=window, min_periods=min_periods, null_policy="drop")
         out = eng.rolling_least_squares(_cuda(yy), [_cuda(c) for c in cols], offs, **args, **kw)
-        assert eng.last_kernel.endswith("_compacted"), eng.last_kernel
+        assert eng.last_kernel.endswith("_gathered"), eng.last_kernel   # round 6: the tile kernel reads the valid rows through a source map and writes the frame's rows
         ref = orc.batched_rolling(y, cols, offs, window, min_periods=min_periods, null_policy="drop", is_valid=valid)
         got_c, got_p = _np(out["coef"]), _np(out["pred"])
         assert np.array_equal(np.isnan(got_c), np.isnan(ref["coef"]))
@@ -614,12 +614,22 @@ def test_rolling_drop_with_nulls_compacted(eng, dtype, tol, k, window, min_perio
         eng.set_option("ROLLING_ENGINE", "nocompact")
         try:
             old = eng.rolling_least_squares(_cuda(yy), [_cuda(c) for c in cols], offs, **args, **kw)
-            assert not eng.last_kernel.endswith("_compacted")
+            assert not eng.last_kernel.endswith("_compacted") and not eng.last_kernel.endswith("_gathered")
         finally:
             eng.set_option("ROLLING_ENGINE", None)
         old_c = _np(old["coef"])
         assert np.array_equal(np.isnan(old_c), np.isnan(got_c))
         assert np.allclose(old_c[well], got_c[well], rtol=tol, atol=tol)
+        # the three-pass form (compacted copy of the columns, tile kernel, expansion pass) runs the same arithmetic on the same values:
+        # identical coefficients on every row of the frame
+        eng.set_option("ROLLING_ENGINE", "scatter")
+        try:
+            three = eng.rolling_least_squares(_cuda(yy), [_cuda(c) for c in cols], offs, **args, **kw)
+            assert eng.last_kernel.endswith("_compacted"), eng.last_kernel
+        finally:
+            eng.set_option("ROLLING_ENGINE", None)
+        assert np.array_equal(_np(three["coef"]), got_c, equal_nan=True)
+        assert np.allclose(_np(three["pred"]), got_p, rtol=tol, atol=tol, equal_nan=True)
 
 
 def test_rolling_drop_with_nulls_short_of_min_periods_keeps_the_old_path(eng):
@@ -634,7 +644,7 @@ def test_rolling_drop_with_nulls_short_of_min_periods_keeps_the_old_path(eng):
     valid[int(offs[1]):int(offs[2])] = 0
     valid[int(offs[1]) + 3] = 1                                          # one valid row in the middle sequence, min_periods = 8
     out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, valid=_cuda(valid), window_size=50, min_periods=8, null_policy="drop")
-    assert not eng.last_kernel.endswith("_compacted")
+    assert not eng.last_kernel.endswith("_compacted") and not eng.last_kernel.endswith("_gathered")
     ref = orc.batched_rolling(y, cols, offs, 50, min_periods=8, null_policy="drop", is_valid=valid)
     healthy = np.ones(len(y), dtype=bool)
     healthy[int(offs[1]):int(offs[2])] = False                           # (the starved sequence is a singular system: whatever LU makes of it)
