@@ -202,11 +202,13 @@ int pols_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_ols_params
 int pols_recursive_least_squares(pols_ctx *ctx, const pols_batch *b, const pols_rls_params *p, pols_out *o);
 
 /* Replaces solve_rolling_ols (src/least_squares.rs:848-1032) + dynamic make_predictions.
- * Up to 10 features (the row-parallel tile kernel: null-free frames, the drop family with nulls by compaction, "drop_window" with nulls
- * by masking) a window whose sums have no Cholesky factorisation is solved by LU with partial pivoting like the reference (ls.rs:732-734):
- * same kind of answer on the same rows (tests/test_k4_gpu.py::test_rolling_divergence_band_is_pinned).
- * DIVERGENCE (the wave-per-chunk kernel of 11 to 32 features -- 9 / 10 where the tile kernel's window conditions fail): there such a window
- * yields NaN coefficients where the reference's LU returns whatever a zero or noise pivot produces (inf / NaN / 1e15-sized numbers);
+ * A window whose sums have no Cholesky factorisation is solved by LU with partial pivoting like the reference (ls.rs:732-734) on the
+ * default routes: up to 10 features (the row-parallel tile kernel: null-free frames, the drop family with nulls through a source map,
+ * "drop_window" with nulls by masking; tests/test_k4_gpu.py::test_rolling_divergence_band_is_pinned) and, since round 6, 11 to 32 features on
+ * null-free frames and under the drop family (the wave-per-chunk kernel lists the rows whose sums it could not invert, a follow-up launch runs
+ * the LU on them; ::test_rolling_wide_windows_without_an_inverse_take_the_lu): same kind of answer on the same rows.
+ * DIVERGENCE (what is left): "drop_window" on a frame WITH nulls at 11 to 32 features -- there such a window yields NaN coefficients where the
+ * reference's LU returns whatever a zero or noise pivot produces (inf / NaN / 1e15-sized numbers);
  * pols_set_option("ROLLING_ENGINE", "chunk") selects the kernels that run the LU at those widths.
  * p->use_woodbury is accepted and does not select a code path: up to 8 features (and wherever the chunk kernels run) the sums are
  * re-factored per row, from 9 features on the inverse is propagated with Sherman-Morrison updates whatever the flag says (the

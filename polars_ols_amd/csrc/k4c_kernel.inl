@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(64) k4c_lu_fix_kernel(const K4cArgs a) {
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) S[q] += __shfl_xor(S[q], off);
         }
-        // LU with partial pivoting on ONE copy of [A | b] in LDS (faer's partial_piv_lu as the oracle restates it, oracle/pols_oracle.c:108-141): lane c owns
+        // LU with partial pivoting on ONE copy of [A | b] in LDS (faer's partial_piv_lu -- row interchanges on the largest magnitude of the column, the solve behind ls.rs:277-337): lane c owns
         // column c (column K: the right-hand side); per pivot step every lane reads the pivot column (broadcast reads), swaps and updates its own column
         __shared__ double As[K][K + 1], Ss[NT];
         if (lane == 0) {

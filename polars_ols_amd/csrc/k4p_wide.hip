@@ -565,13 +565,11 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
                 good = last_good; bout = last;
             }
             cx.store_coef(G.start + i, bout, good);
-            if constexpr (!MASKED) {
-                // a row the reference solves whose window sums could not be inverted: the reference runs LU there (ls.rs:732-734) -- kp_lu_fix_kernel does,
-                // behind this kernel, for the rows put on the list here (rare; MASKED frames repeat coefficients across rows: they keep the NaN)
-                if (((mk.gate >> t) & 1) && !good && a.fix_rows && cx.lane == 0) {
-                    const int idx = atomicAdd(a.fix_count, 1);
-                    if (idx < a.fix_cap) a.fix_rows[idx] = G.start + i;
-                }
+            // a row the reference solves whose window sums could not be inverted: the reference runs LU there (ls.rs:732-734) -- kp_lu_fix_kernel does,
+            // behind this kernel, for the rows put on the list here (rare; on MASKED frames it also rewrites the rows behind that repeat the row)
+            if (((mk.gate >> t) & 1) && !good && a.fix_rows && cx.lane == 0) {
+                const int idx = atomicAdd(a.fix_count, 1);
+                if (idx < a.fix_cap) a.fix_rows[idx] = G.start + i;
             }
             const double p = kp_rowsum<KP>(x.xr * bout);
             predv = (cx.lane == t) ? (good ? p : qnan) : predv;
@@ -583,13 +581,17 @@ __global__ void __launch_bounds__(64) kp_rolling_walk_kernel(const K4Args a) {
 
 // The rows of the list: one wave each re-sums the row's window -- rows (i - window, i] of its sequence -- into [X'X + alpha I | X'y] in LDS (a lane
 // owns the entries e = lane, lane + 64, ...; the rows are staged one at a time) and eliminates with partial pivoting, a lane per column, like the
-// reference's fallback (faer partial_piv_lu as restated in oracle/pols_oracle.c:108-141).  Any width up to 32; null-free frames.
-template <typename T>
+// reference's fallback (faer's partial_piv_lu: row interchanges on the largest magnitude of the column, the solve behind ls.rs:277-337).  Any width up to 32.
+// MASKED ("drop_window" with validity bytes, ls.rs:987-1029): the window holds the VALID rows the walk's masks let in and out -- every valid row up
+// to i, less the valid rows of [max(mpv - window, 0), i - window] once i >= mpv (the rows in front of that are never subtracted, :989) -- and the
+// rows behind i whose gate is closed repeat its coefficients: they are rewritten too.
+template <typename T, bool MASKED>
 __global__ void __launch_bounds__(64) kp_lu_fix_kernel(const K4Args a) {
-    __shared__ double As[32][33], xs[33];
+    __shared__ double As[32][33], xs[33], bs[32];
     const int lane = threadIdx.x, K = a.k, K1 = K + 1;
     const int n_fix = min(*a.fix_count, (int)a.fix_cap);
     if (blockIdx.x == 0 && lane == 0) *a.fix_next = 0;              // the next call's counter
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     for (int e = blockIdx.x; e < n_fix; e += gridDim.x) {
         const int64_t i = a.fix_rows[e];
         int lo_g = 0, hi_g = a.n_groups;                            // the sequence holding row i: the last g with start <= i
@@ -597,16 +599,28 @@ __global__ void __launch_bounds__(64) kp_lu_fix_kernel(const K4Args a) {
             const int mid = (lo_g + hi_g) >> 1;
             if (a.groups[mid].start <= i) lo_g = mid; else hi_g = mid;
         }
-        const int64_t s = a.groups[lo_g].start;
-        const int64_t lo = i - a.window + 1 < s ? s : i - a.window + 1;
+        const K4Group G = a.groups[lo_g];
+        const int64_t s = G.start, w = a.window;
+        const int64_t rel = i - s;
+        // the rows of the window: [lo, i], and on MASKED frames [0, front) in front of it as well (valid rows only)
+        int64_t lo = rel - w + 1 < 0 ? 0 : rel - w + 1, front = 0;
+        if constexpr (MASKED) {
+            const int64_t j_min = G.mpv - w > 0 ? G.mpv - w : 0;
+            if (rel < G.mpv) lo = 0;                                // nothing has left yet
+            else { if (lo < j_min) lo = j_min; front = j_min < lo ? j_min : lo; }
+        }
         for (int q = lane; q < K * K1; q += 64) As[q / K1][q % K1] = 0.0;
         kp_sync();
-        for (int64_t j = lo; j <= i; ++j) {
-            if (lane < K) xs[lane] = (double)static_cast<const T *>(a.x[lane])[j];
-            if (lane == K) xs[K] = (double)static_cast<const T *>(a.y)[j];
-            kp_sync();
-            for (int q = lane; q < K * K1; q += 64) { const int p = q / K1, c = q % K1; As[p][c] = fma(xs[p], xs[c], As[p][c]); }
-            kp_sync();
+        for (int part = 0; part < 2; ++part) {
+            const int64_t j0 = part == 0 ? 0 : lo, j1 = part == 0 ? front : rel + 1;
+            for (int64_t j = j0; j < j1; ++j) {
+                if constexpr (MASKED) { if (!a.valid[s + j]) continue; }   // (wave-uniform)
+                if (lane < K) xs[lane] = (double)static_cast<const T *>(a.x[lane])[s + j];
+                if (lane == K) xs[K] = (double)static_cast<const T *>(a.y)[s + j];
+                kp_sync();
+                for (int q = lane; q < K * K1; q += 64) { const int p = q / K1, c = q % K1; As[p][c] = fma(xs[p], xs[c], As[p][c]); }
+                kp_sync();
+            }
         }
         if (lane < K) As[lane][lane] += a.alpha;
         kp_sync();
@@ -631,12 +645,26 @@ __global__ void __launch_bounds__(64) kp_lu_fix_kernel(const K4Args a) {
                 for (int q = p + 1; q < K; ++q) sacc -= As[p][q] * beta[q];
                 beta[p] = sacc / As[p][p];
             }
-            double pr = 0.0;
-            for (int p = 0; p < K; ++p) {
-                if (a.coef) static_cast<T *>(a.coef)[i * K + p] = (T)beta[p];
-                pr = fma((double)static_cast<const T *>(a.x[p])[i], beta[p], pr);
+            for (int p = 0; p < K; ++p) bs[p] = beta[p];
+        }
+        kp_sync();
+        // row i, and on MASKED frames the rows behind it that repeat it (gate closed: the walk's masks)
+        for (int64_t f = rel; f < G.end - s; ++f) {
+            if (f > rel) {
+                if constexpr (!MASKED) break;
+                const int64_t is = f >= w ? f - w : 0;
+                if (f == G.mpv - 1 || (int64_t)a.cnt[s + f] - (int64_t)a.cnt[s + is] >= G.gate_n) break;   // solved on its own
             }
-            if (a.pred) static_cast<T *>(a.pred)[i] = (T)pr;
+            if (lane == 0) {
+                double pr = 0.0;
+                for (int p = 0; p < K; ++p) {
+                    if (a.coef) static_cast<T *>(a.coef)[(s + f) * K + p] = (T)bs[p];
+                    pr = fma((double)static_cast<const T *>(a.x[p])[s + f], bs[p], pr);
+                }
+                bool vf = true;
+                if constexpr (MASKED) vf = a.valid[s + f] != 0;
+                if (a.pred) static_cast<T *>(a.pred)[s + f] = (T)(vf ? pr : qnan);
+            }
         }
         kp_sync();
     }
@@ -658,10 +686,12 @@ static int kp_launch_kp(pols_ctx *ctx, const K4Args &a, bool rls, bool single_ch
             chunk_scan_launch(ctx, a, a.k * a.k + a.k, 0);
         }
         if constexpr (KpGeo<KP, LPS>::CPL <= 16) {
-            if (a.valid) hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, true>), dim3(blocks), dim3(64), 0, ctx->stream, a);
-            else {
+            if (a.valid) {
+                hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, true>), dim3(blocks), dim3(64), 0, ctx->stream, a);
+                if (a.fix_rows) hipLaunchKernelGGL((kp_lu_fix_kernel<T, true>), dim3(128), dim3(64), 0, ctx->stream, a);
+            } else {
                 hipLaunchKernelGGL((kp_rolling_walk_kernel<T, KP, LPS, false>), dim3(blocks), dim3(64), 0, ctx->stream, a);
-                if (a.fix_rows) hipLaunchKernelGGL((kp_lu_fix_kernel<T>), dim3(128), dim3(64), 0, ctx->stream, a);
+                if (a.fix_rows) hipLaunchKernelGGL((kp_lu_fix_kernel<T, false>), dim3(128), dim3(64), 0, ctx->stream, a);
             }
         }
     }
@@ -695,7 +725,7 @@ int k4p_launch(pols_ctx *ctx, int dtype, const K4Args &a, bool rls, bool single_
     if (a.n_chunks <= 0) return POLS_OK;
     ctx->last_kernel = std::string(rls ? "k3p_rls_inverse_wave" : "k4p_rolling_inverse_wave") + (dtype == POLS_F32 ? "_f32" : "_f64");
     K4Args aa = a;
-    if (!rls && !a.valid && !ctx->opt.debug_skip_fixup) {          // (POLS_DEBUG_SKIP_FIXUP: the walk's own answer, NaN on such rows -- the test's A/B)
+    if (!rls && !ctx->opt.debug_skip_fixup) {          // (POLS_DEBUG_SKIP_FIXUP: the walk's own answer, NaN on such rows -- the test's A/B)
         // the list of rows whose sums could not be inverted (scratch slot 27, shared with K4c: [two counters that take turns][rows])
         const int64_t n_rows = a.groups_end_row;
         void *fx = nullptr;

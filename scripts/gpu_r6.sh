@@ -119,6 +119,23 @@ gather)
   ( cd /tmp && export TMPDIR=/tmp; rm -rf $O/kt_dn; K=6 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dn -o k -- python $R/scripts/bench_dyn_nulls.py > /dev/null 2> $O/kt_dn.err
     f=$(find $O/kt_dn -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_kernel_stats_dyn_nulls_k6.csv && grep pols:: $O/${TAG}_kernel_stats_dyn_nulls_k6.csv | cut -c1-150 | head -24; rm -rf $O/kt_dn )
   ;;
+pmcinst)
+  echo "== dynamic instruction mix of the row-parallel dynamic kernels (per dispatch; SQ counters in their own runs)"
+  for cfg in cfg4r cfg4; do
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+  ( cd /tmp && export TMPDIR=/tmp; rm -rf $O/pmc_i; timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_i -o p -- python $R/bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_i.err
+    f=$(find $O/pmc_i -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then python3 - "$f" $cfg <<'PY'
+import csv,sys,collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k=r['Kernel_Name']
+    if ('k4c_kernel' in k or 'k3c_kernel' in k): acc[k[:70]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k,v in acc.items(): print(sys.argv[2], k, {c: round(sum(x)/len(x)) for c,x in v.items()})
+PY
+    else tail -3 $O/pmc_i.err; fi; rm -rf $O/pmc_i )
+  done; done | tee $O/${TAG}_pmc_inst_dyn.txt
+  ;;
 tests)
   timeout 3000 python -m pytest tests -m gpu -q --maxfail=25 2>&1 | tail -40 | tee $O/${TAG}_pytest_gpu.txt
   ;;

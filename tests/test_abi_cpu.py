@@ -173,8 +173,12 @@ def test_bench_kernels_keep_two_waves_per_simd():
         "pols::k2_kernel<double, 16, 8, 2, true, false>(": 256,                             # configs[4]
         "pols::k3c_kernel<double, 6, 4, 4, 1>(": 168,                                       # configs[3] as RLS: three tiles (12 waves) per CU
         "pols::k3c_kernel<double, 6, 4, 4, 0>(": 128,                                       # ... its first pass: four waves per SIMD
-        "pols::k4c_kernel<double, 6, 1, 4>(": 256,                                          # configs[3] as rolling OLS: two four-wave workgroups per CU
-        "pols::k4c_kernel<double, 6, 0, 4>(": 256,                                          # ... on packed tiles (many sequences)
+        "pols::k3c_kernel<double, 6, 4, 4, 3>(": 168,                                       # ... the look-back-one form (round 6: what configs[3] runs)
+        "pols::k4c_kernel<double, 6, 0, 4, false, true, false>(": 256,                      # configs[3] as rolling OLS: two four-wave workgroups per CU (own-halo form)
+        "pols::k4c_kernel<double, 6, 1, 4, false, false, false>(": 256,                     # ... with a halo wave (POLS_ROLLING_ENGINE=halowave)
+        "pols::k4c_kernel<double, 6, 0, 4, false, false, false>(": 256,                     # ... on packed tiles (many sequences)
+        "pols::k4c_kernel<double, 6, 0, 4, true, false, false>(": 256,                      # ... "drop_window" with nulls (masked)
+        "pols::k4c_kernel<double, 6, 0, 4, false, false, true>(": 256,                      # ... "drop" with nulls (gathered through the source map)
     }
     for key, cap in want.items():
         hits = [(k, v) for k, v in ks.items() if key in k]

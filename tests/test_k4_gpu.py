@@ -781,6 +781,62 @@ def test_rolling_wide_windows_without_an_inverse_take_the_lu(eng, k, window, sha
         assert np.isclose(got_p[i], X[i] @ got_c[i], rtol=1e-9, atol=1e-9 * np.abs(X[i] * got_c[i]).sum())
 
 
+@pytest.mark.parametrize("k,window,shape", [(12, 40, "groups"), (16, 64, "long"), (24, 100, "groups"), (9, 600, "long")])
+def test_rolling_wide_masked_windows_without_an_inverse_take_the_lu(eng, k, window, shape):
+    """The same on "drop_window" with validity bytes (K4p MASKED, the last route that returned NaN there): the walk lists the solved rows whose
+    sums it could not invert, kp_lu_fix_kernel<.., MASKED> re-sums the window's VALID rows, runs the reference's LU (ls.rs:732-734) and also
+    rewrites the rows behind that repeat the row (a closed n_valid_window gate, :1013, :1022).  Pinned: the NaN pattern against the oracle on
+    every row whose window holds k or more valid observations; the rows the walk gave up on (POLS_DEBUG_SKIP_FIXUP) are the only ones that change;
+    a filled VALID row with a healthy gate solves its window's normal equations to LU's backward error; a filled row behind a filled row that
+    the walk had repeated still repeats it."""
+    from oracle import orc
+
+    rng = np.random.default_rng(3 * k + window)
+    sizes = np.array([900, 40, 0, 700, k, 1021]) if shape == "groups" else np.array([2500, 300, 0, 1100])
+    y, cols, offs, _ = _frame(rng, sizes, k)
+    cols[1] = cols[0] + 1e-9 * rng.standard_normal(len(y))
+    y = sum(cols[2:]) + 2.0 * cols[0] + 0.1 * rng.standard_normal(len(y))
+    valid = (rng.random(len(y)) > 0.05).astype(np.uint8)
+    kw = dict(window_size=window, min_periods=k, null_policy="drop_window", valid=_cuda(valid))
+    out = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    assert eng.last_kernel.startswith("k4p_"), eng.last_kernel
+    eng.set_option("DEBUG_SKIP_FIXUP", "1")
+    try:
+        raw = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+    finally:
+        eng.set_option("DEBUG_SKIP_FIXUP", None)
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=k, null_policy="drop_window", is_valid=valid)
+    got_c, got_p, raw_c = _np(out["coef"]), _np(out["pred"]), _np(raw["coef"])
+    nobs = _window_obs(offs, valid, window, "drop_window")
+    # rows past their sequence's warm-up whose window holds k or more valid observations: the reference returns numbers there
+    full = (nobs >= k) & np.isfinite(ref["coef"]).all(axis=1)
+    assert full.sum() > 0.5 * len(y)
+    assert not np.isnan(got_c[full]).any(), int(np.isnan(got_c[full]).any(axis=1).sum())
+    enough = nobs >= k                                                  # (fewer valid rows than features: exactly singular, whatever LU makes of it)
+    assert np.array_equal(np.isnan(got_c).any(axis=1)[enough], np.isnan(ref["coef"]).any(axis=1)[enough])
+    gave_up = np.isnan(raw_c).any(axis=1) & ~np.isnan(ref["coef"]).any(axis=1) & enough
+    assert gave_up.sum() >= 0.05 * full.sum(), (int(gave_up.sum()), int(full.sum()))
+    kept = ~np.isnan(raw_c).any(axis=1)
+    assert np.array_equal(got_c[kept], raw_c[kept])
+    vm = valid.astype(bool)
+    assert np.isnan(got_p[~vm]).all()
+    X = np.stack(cols, axis=1)
+    solved = np.flatnonzero(gave_up & vm & (nobs >= 2 * k))
+    assert len(solved) > 20
+    for i in solved[:: max(1, len(solved) // 200)]:
+        Xw = _window_matrix(offs, valid, X, i, window, "drop_window")
+        yw = _window_matrix(offs, valid, y[:, None], i, window, "drop_window")[:, 0]
+        A, b = Xw.T @ Xw, Xw.T @ yw
+        res = np.abs(A @ got_c[i] - b).max()
+        scale = np.abs(A).sum(axis=1).max() * np.abs(got_c[i]).max() + np.abs(b).max()
+        assert res <= 1e-9 * scale, (i, res, scale)
+    # a row left out repeats the last solved row's coefficients (bit for bit), also when that row came from the LU
+    rep = np.flatnonzero(~vm[1:] & gave_up[1:] & gave_up[:-1] & (np.diff(np.searchsorted(offs, np.arange(len(y)), side="right")) == 0)) + 1
+    assert len(rep) > 0
+    same = np.array([np.array_equal(got_c[i], got_c[i - 1]) for i in rep])
+    assert same.mean() > 0.9, float(same.mean())                       # (a masked row whose LEAVING row was valid is solved afresh: not a repeat)
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-6), (np.float32, 1e-4)])
 @pytest.mark.parametrize("k,window,min_periods,alpha,shape", [
     (11, 252, None, None, "groups"), (12, 100, 12, None, "long"), (12, 30, 1, None, "groups"), (16, 64, 16, 0.5, "long"), (17, 40, 17, None, "groups"),
