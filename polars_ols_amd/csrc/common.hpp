@@ -60,7 +60,7 @@ struct Options {
     int rls_engine = 0;           // POLS_RLS_ENGINE     0 auto, 1 "seq" (K3), 2 "scan" (K3c up to 8 features, else the chunk kernels), 3 "chunk" (lane-per-chunk K3s), 4 "halo" (K3c: the halo form where the look-back form would run)
     int rls_early = 0;            // POLS_RLS_EARLY      K3c look-back form: 0 = the tile's record falls out of its scan (default), 1 = computed and published before it (step E; A/B: 34.6 vs 31.2 us on cfg4)
     int rls_spin_limit = -1;      // POLS_RLS_SPINS      K3c look-back form: polls before a wave falls back to the halo (-1: default 64; 0: always fall back -- the test of that path)
-    int rolling_engine = 0;       // POLS_ROLLING_ENGINE 0 auto (K4c tiles where they apply), 1 "chunk" (lane-per-chunk K4)
+    int rolling_engine = 0;       // POLS_ROLLING_ENGINE 0 auto (K4c tiles where they apply), 1 "chunk" (lane-per-chunk K4), 2 "halo" (no packed tiles), 3 "nocompact" (the drop family with nulls stays with the chunk kernels), 4 "halowave" (K4c keeps its halo wave: A/B of the own-halo form), 5 "scatter" (the drop family with nulls: compacted columns + expansion pass instead of the source map)
     int k1_engine = 0;            // POLS_K1_ENGINE      0 auto, 1 "valu", 2 "mfma"
     int k9_take = 0;              // POLS_K9_TAKE        0 auto, 1 "gather", 2 "scatter"
     int k1_nt_loads = -1;         // POLS_K1_NT_LOADS    -1: default rule, 0 / 1

@@ -489,6 +489,41 @@ def test_rolling_tiles_null_free(eng, dtype, tol, k, window, min_periods, alpha)
         assert np.allclose(got_p[well], ref["pred"][well], rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("k,window", [(6, 252), (3, 5), (6, 101), (9, 250), (10, 60)])
+def test_rolling_tiles_own_halo_against_the_halo_wave(eng, k, window):
+    """Round 6: up to 9 features and 256-row windows the tile kernel has NO halo wave -- the tile's first wave loads the rows in front of the
+    tile itself and the four waves share their sums out (k4c_kernel.inl SELF).  POLS_ROLLING_ENGINE=halowave keeps the halo-wave form (what 10
+    features still run): same frame, both forms, against the oracle and against each other; sequences that start on every position of a tile,
+    longer than several tiles, shorter than the window."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 131 + window)
+    sizes = np.concatenate([[4100, 1, 0, 1023, 1025, 2, 3071, 259], rng.integers(1, 700, size=10), [2049]])
+    y, cols, offs, _ = _frame(rng, sizes, k)
+    kw = dict(window_size=window, min_periods=k, null_policy="drop", null_free=True)
+    eng.set_option("ROLLING_ENGINE", "halo")                              # (no packed tiles: the forms under test are the ones that reach outside a tile)
+    try:
+        own = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+        assert eng.last_kernel.startswith("k4_rolling_tiles"), eng.last_kernel
+    finally:
+        eng.set_option("ROLLING_ENGINE", None)
+    eng.set_option("ROLLING_ENGINE", "halowave")
+    try:
+        hw = eng.rolling_least_squares(_cuda(y), [_cuda(c) for c in cols], offs, **kw)
+        assert eng.last_kernel.startswith("k4_rolling_tiles"), eng.last_kernel
+    finally:
+        eng.set_option("ROLLING_ENGINE", None)
+    ref = orc.batched_rolling(y, cols, offs, window, min_periods=k, null_policy="drop")
+    nobs = _window_obs(offs, None, window, "drop")
+    well = np.isfinite(ref["coef"]).all(axis=1) & (np.abs(ref["coef"]).max(axis=1) < 1e3) & (nobs >= 2 * k)
+    for out in (own, hw):
+        c, p = _np(out["coef"]), _np(out["pred"])
+        assert np.array_equal(np.isnan(c), np.isnan(ref["coef"]))
+        assert np.allclose(c[well], ref["coef"][well], rtol=1e-6, atol=1e-6), float(np.abs(c[well] - ref["coef"][well]).max())
+        assert np.allclose(p[well], ref["pred"][well], rtol=1e-6, atol=1e-6)
+    assert np.allclose(_np(own["coef"])[well], _np(hw["coef"])[well], rtol=1e-7, atol=1e-7)
+
+
 def test_rolling_many_sequences_full_size(eng):
     """bench.py --config rlsgr: 10 000 sequences x 1 000 rows x 6 features, window 252, f64 -- sampled sequences against the oracle."""
     from oracle import orc
