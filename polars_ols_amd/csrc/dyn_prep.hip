@@ -428,22 +428,27 @@ __global__ void __launch_bounds__(256) rm_groups_kernel(const RollMaskArgs a) {
     if (n >= mp && jm >= 0 && jm < n && rm_prefix(a, s + jm) - before > 0) atomicOr(a.flag, 1);
 }
 
+// The group holding every slab's first row (the last g with offs[g] <= row): a thread per slab, all searches side by side.  Inside rm_rows_kernel
+// -- thread 0 of every workgroup, 14 dependent loads in front of everything else -- the search was most of that kernel's 77 us on 10M rows.
+// (the table lives in slab_carry until rm_scan_kernel<true> writes the carries there, behind rm_rows_kernel)
+__global__ void __launch_bounds__(256) rm_slab_group_kernel(const RollMaskArgs a) {
+    const int64_t sl = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sl >= a.n_slabs) return;
+    const int64_t r0 = sl * RC_SLAB;
+    int64_t lo = 0, hi = a.n_groups;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.offs[mid] <= r0) lo = mid; else hi = mid;
+    }
+    a.slab_carry[sl] = lo;
+}
+
 __global__ void __launch_bounds__(RC_SLAB) rm_rows_kernel(const RollMaskArgs a) {
     __shared__ int wave_last[RC_SLAB / 64];
-    __shared__ long long g_first;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * RC_SLAB + threadIdx.x;
     const bool in = r < a.n_rows;
-    if (threadIdx.x == 0) {                                  // the group holding the slab's first row: the last g with offs[g] <= row (one search per slab)
-        const int64_t r0 = (int64_t)blockIdx.x * RC_SLAB;
-        int64_t lo = 0, hi = a.n_groups;
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (a.offs[mid] <= r0) lo = mid; else hi = mid;
-        }
-        g_first = lo;
-    }
-    __syncthreads();
+    const int64_t g_first = a.slab_carry[blockIdx.x];        // (rm_slab_group_kernel)
     bool solved = false, nan = true;
     if (in) {
         int64_t g = g_first;
@@ -569,6 +574,7 @@ int roll_mask_tables_launch(pols_ctx *ctx, const RollMaskArgs &a) {
 
 int roll_mask_rows_launch(pols_ctx *ctx, const RollMaskArgs &a) {
     if (a.n_rows == 0 || a.n_groups == 0) return POLS_OK;
+    hipLaunchKernelGGL(rm_slab_group_kernel, dim3((unsigned)((a.n_slabs + 255) / 256)), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(rm_rows_kernel, dim3((unsigned)a.n_slabs), dim3(RC_SLAB), 0, ctx->stream, a);
     hipLaunchKernelGGL(rm_blk_kernel<true>, dim3((unsigned)((a.n_slabs + 1023) / 1024)), dim3(1024), 0, ctx->stream, a);
     hipLaunchKernelGGL(rm_scan_kernel<true>, dim3((unsigned)((a.n_slabs + 1023) / 1024)), dim3(1024), 0, ctx->stream, a);
