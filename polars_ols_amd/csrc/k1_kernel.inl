@@ -542,6 +542,50 @@ __device__ __forceinline__ void predict_store(const K1Args &a, const Chunk<T, KT
     }
 }
 
+// The same with the coefficients read from LDS where they are used (wide multi-pass kernels: KT more live registers in this phase were what
+// kept the f32 kernels of 26+ columns at two waves per SIMD -- 173-205 VGPRs however short the Gram passes)
+template <typename T, int KT, bool HAS_W, bool FAST, bool NULLS = false>
+__device__ __forceinline__ void predict_store_lds(const K1Args &a, const Chunk<T, KT, HAS_W> &c, const T *beta_lds, int64_t row0, int64_t s, int64_t e) {
+    using V = typename Vec16<T>::type;
+    constexpr int VEC = Vec16<T>::N;
+    T acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = T(0);
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        if (j % 8 == 0) __builtin_amdgcn_sched_barrier(0);                       // (eight coefficients in flight at a time, not KT)
+        const T bj = beta_lds[j];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fma(vget<T>(c.x[j], v), bj, acc[v]);   // make_predictions on the FIT features (ex.rs:398-405)
+    }
+    V p, r;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        T pv = acc[v];
+        if constexpr (HAS_W) pv *= T(1) / vget<T>(c.sw, v);                          // predictions *= 1/sqrt_w (ls.py:234-235)
+        if constexpr (NULLS) {                                                       // "drop" masks the rows that were not fitted (ex.rs:409-417)
+            if (a.null_policy == POLS_NULL_DROP) pv = nan_if<T>(((c.m >> v) & 1u) ? 0u : 1u, pv);
+        }
+        vset<T>(p, v, pv);
+        vset<T>(r, v, vget<T>(c.y, v) - pv);                                         // ORIGINAL target - predictions (ls.py:239)
+    }
+    T *pred = static_cast<T *>(a.pred);
+    T *resid = static_cast<T *>(a.resid);
+    if (FAST || (row0 >= s && row0 + VEC <= e)) {
+        if (pred) store_stream(reinterpret_cast<V *>(pred + row0), p);
+        if (resid) store_stream(reinterpret_cast<V *>(resid + row0), r);
+    } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int64_t rr = row0 + v;
+            if (rr >= s && rr < e) {
+                if (pred) pred[rr] = vget<T>(p, v);
+                if (resid) resid[rr] = vget<T>(r, v);
+            }
+        }
+    }
+}
+
 // TEAM = 64: four independent waves per 256-thread block, one group each, no LDS, no barriers.
 // TEAM = 256: one group per block; cross-wave reduction through LDS with ONE barrier.
 // FAST: the host verified that every group starts on a 16-byte boundary, has a multiple of VEC rows and fits
@@ -678,7 +722,19 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
         constexpr int TEAMS = BLOCK / TEAM;                        // one scratch set per team of the block
         __shared__ T gsum_s[TEAMS][NACC + 3], lfac_s[TEAMS][KT * KT], lrinv_s[TEAMS][KT];
         T *gsum = gsum_s[tix / TEAM], *lfac = lfac_s[tix / TEAM], *lrinv = lrinv_s[tix / TEAM];
+        // f32 from 26 columns: the solving wave PARKS its resident rows in LDS for the duration of the solve (the right-looking factorisation
+        // keeps a row of the factor and its broadcasts next to them: 173-205 VGPRs, two waves per SIMD, however short the Gram passes are;
+        // without the rows the kernel fits 168 and a third workgroup fits the CU)
+        constexpr bool PARK = KT >= 26 && sizeof(T) == 4 && RC == 1 && TEAM == 256;
+        using PV = typename Vec16<T>::type;
+        __shared__ __attribute__((aligned(16))) PV park_s[PARK ? (KT + 2) * 64 : 1];
         if (wave == 0) {
+            if constexpr (PARK) {
+#pragma unroll
+                for (int j = 0; j < KT; ++j) park_s[j * 64 + lane] = res[0].x[j];
+                park_s[KT * 64 + lane] = res[0].y;
+                if constexpr (HAS_W) park_s[(KT + 1) * 64 + lane] = res[0].sw;
+            }
             for (int q = lane; q < NACC; q += 64) {     // NACC = 66 at 10 columns
                 T t = mypart[q * WAVES];
 #pragma unroll
@@ -700,11 +756,20 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
                 if (a.coef) static_cast<T *>(a.coef)[g * KT + tid] = bv;
                 bcast[tid] = bv;
             }
+            if constexpr (PARK) {
+                __builtin_amdgcn_sched_barrier(0);                 // (not before the solve is over)
+#pragma unroll
+                for (int j = 0; j < KT; ++j) res[0].x[j] = park_s[j * 64 + lane];
+                res[0].y = park_s[KT * 64 + lane];
+                if constexpr (HAS_W) res[0].sw = park_s[(KT + 1) * 64 + lane];
+            }
         }
         if constexpr (WAVES > 1) __syncthreads();
         else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        if constexpr (!(NPASS > 1 && KT >= 23)) {              // (23+ columns: the prediction phase reads them from LDS as it goes, predict_store_lds)
 #pragma unroll
-        for (int j = 0; j < KT; ++j) beta[j] = bcast[j];
+            for (int j = 0; j < KT; ++j) beta[j] = bcast[j];
+        }
     } else
     if (wave == 0) {
 #pragma unroll
@@ -749,7 +814,11 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
 #pragma unroll
         for (int rc = 0; rc < RC; ++rc) {
             const int64_t c = (int64_t)rc * TEAM + tid;
-            if (c < nch) predict_store<T, KT, HAS_W, (FAST && !EDGE), NULLS>(a, res[rc], beta, base + c * VEC, s, e);
+            if constexpr (NPASS > 1 && KT >= 23) {
+                if (c < nch) predict_store_lds<T, KT, HAS_W, (FAST && !EDGE), NULLS>(a, res[rc], bcast, base + c * VEC, s, e);
+            } else {
+                if (c < nch) predict_store<T, KT, HAS_W, (FAST && !EDGE), NULLS>(a, res[rc], beta, base + c * VEC, s, e);
+            }
         }
         if constexpr (!FAST && NPASS == 1) {
             for (int64_t c = (int64_t)RC * TEAM + tid; c < nch; c += TEAM) {
@@ -1663,7 +1732,13 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int NACC = (KT + 1) * (KT + 2) / 2;
     // passes: three up to 12 columns, four up to 15; beyond, ~60 f32 / ~36 f64 accumulators live at a time (31 columns: 528 entries)
-    constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + 59) / 60 : (NACC + 35) / 36));
+    // Round 6, f32 from 23 columns: the resident rows alone are 4 (KT + 1) registers, and with ~60 accumulators next to them the kernel needs 173-205
+    // VGPRs -- two waves per SIMD where 22 columns (165) still run three: 4.4 TB/s at 20 columns, 3.05 at 24 (profiles/r05_bench_k16.txt).  More,
+    // shorter passes keep it at 168: the accumulators a pass may hold are what three waves per SIMD leave next to the rows (the products per row
+    // are the same however they are split; a pass more is one more reduce-and-barrier round).
+    // (from 26 columns the solving wave also parks its rows in LDS while it solves: k1_body, PARK)
+    constexpr int ACC_F32 = KT >= 23 ? 148 - 4 * (KT + 1) : 60;
+    constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + ACC_F32 - 1) / ACC_F32 : (NACC + 35) / 36));
     const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
     const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
 #ifdef K1_NULLS_TU
