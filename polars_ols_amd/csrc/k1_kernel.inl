@@ -1737,7 +1737,10 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     // shorter passes keep it at 168: the accumulators a pass may hold are what three waves per SIMD leave next to the rows (the products per row
     // are the same however they are split; a pass more is one more reduce-and-barrier round).
     // (from 26 columns the solving wave also parks its rows in LDS while it solves: k1_body, PARK)
-    constexpr int ACC_F32 = KT >= 23 ? 148 - 4 * (KT + 1) : 60;
+    constexpr int ACC_F32 = KT >= 23 ? 148 - 4 * (KT + 1) : ((KT >= 16 && KT <= 18) ? 108 - 4 * (KT + 1) : 60);
+    // (16-18 columns the same way one step up: 40 / 36 / 32 accumulators per pass keep the kernel at 128 VGPRs, FOUR waves per SIMD: 4.8 -> 5.2 TB/s;
+    // at 19-20 it took parking too and bought 1-2 %: not kept.  The 256-thread team only: the one- and two-wave teams gain no workgroup by it.)
+    constexpr int NP0 = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + 59) / 60 : (NACC + 35) / 36));      // every other team
     constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + ACC_F32 - 1) / ACC_F32 : (NACC + 35) / 36));
     const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
     const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
@@ -1747,8 +1750,9 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr bool NL = false;
 #endif
 #define K1W_GO(TEAM, RC)                                                                                                       \
-    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NP, NL>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NP, NL>(ctx, a)) \
-               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NP, NL>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NP, NL>(ctx, a))
+    { constexpr int NPT = ((TEAM) == 256 && (RC) == 1) ? NP : NP0;                                                                          \
+    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NPT, NL>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NPT, NL>(ctx, a)) \
+               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NPT, NL>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NPT, NL>(ctx, a)); }
 #ifndef K1_NULLS_TU
     if constexpr (KT <= 16) {
         // 11-16 columns, groups of at most 32 chunks (128 f32 / 64 f64 rows -- a quarter of daily data against a dozen factors): K1t's four groups
