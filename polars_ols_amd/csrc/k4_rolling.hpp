@@ -150,9 +150,6 @@ struct K4cArgs {
     const uint8_t *start;              // 1 on the first row of every sequence (k3c_start_flags)
     const uint8_t *valid;              // MASKED form ("drop_window" with nulls): validity bytes, 4-byte aligned; nullptr: every row valid
     const uint8_t *solved;             // MASKED: 1 on the rows the reference solves (dyn_prep.hip rm_rows_kernel), 4-byte aligned
-    int64_t *fix_rows;                 // rows whose window sums had no factorisation (set by the launcher): k4c_lu_fix_kernel runs the reference's LU on them
-    int32_t *fix_count, *fix_next;     // this call's counter; the one the fix-up kernel zeroes for the next call
-    int64_t fix_cap;
     int64_t n_rows, n_tiles;           // n_tiles is set by the launcher
     void *coef, *pred;                 // n_rows x k / n_rows, batch dtype, 16-byte aligned; either may be nullptr
     int64_t window, min_periods;       // 1 <= min_periods <= window <= K4C_MAX_WINDOW

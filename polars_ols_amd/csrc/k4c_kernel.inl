@@ -57,6 +57,107 @@ __device__ __forceinline__ void k4c_seg_scan_add(double (&Tv)[NC], const int h, 
 #undef K4C_STEP
 }
 
+// A row whose window sums have no L D L' factorisation, solved the reference's way (Cholesky -> LU with partial pivoting, ls.rs:732-734 /
+// :277-337) by ONE wave: the window -- the rows (i - window, i] of the row's sequence, the valid ones under MASKED -- is re-summed from global
+// memory, every lane runs the same K x K elimination on one copy of [A | b] in LDS (lds: K (K + 1) + NT doubles of the wave's own), the
+// coefficients and the prediction replace the NaNs.  Called by the wave of the tile kernel that met the row, behind its copy-out (round 6: a
+// follow-up launch over a list of such rows cost every call ~4.5 us -- a tenth of cfg4r's step -- for a list that is empty on all but
+// degenerate frames).  GATHER: the rows are compacted rows -- the window is read through the source map, and the coefficients go to every
+// frame row that repeats them (up to the next valid row, the end of the sequence or of the frame).
+template <typename T, int K, bool MASKED, bool GATHER>
+__device__ __forceinline__ void k4c_lu_fix_row(const K4cArgs &a, const int64_t i, const int lane, double *lds) {
+    constexpr int NX = K4N<K>::NX, NT = K4N<K>::N;
+    double (*As)[K + 1] = reinterpret_cast<double (*)[K + 1]>(lds);
+    double *Ss = lds + K * (K + 1);
+    int64_t lo = i - a.window + 1 < 0 ? 0 : i - a.window + 1;
+    for (int64_t base = i; base >= lo; base -= 64) {       // the last sequence start at or before row i inside the window
+        const int64_t j = base - lane;
+        const unsigned long long m = __ballot(j >= lo && a.start[j] != 0);
+        if (m) { lo = base - (int64_t)__builtin_ctzll(m); break; }
+    }
+    double S[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) S[q] = 0.0;
+    for (int64_t j = lo + lane; j <= i; j += 64) {
+        if constexpr (MASKED) { if (!a.valid[j]) continue; }
+        double xr[K];
+        const int64_t jf = GATHER ? (int64_t)a.src[j] : j;
+#pragma unroll
+        for (int p = 0; p < K; ++p) xr[p] = (double)static_cast<const T *>(a.x[p])[jf];
+        const double yr = (double)static_cast<const T *>(a.y)[jf];
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+#pragma unroll
+            for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = fma(xr[p], xr[q], S[tri_index<K>(p, q)]);
+            S[NX + p] = fma(xr[p], yr, S[NX + p]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) S[q] += __shfl_xor(S[q], off);
+    }
+    // LU with partial pivoting on ONE copy of [A | b] in LDS (faer's partial_piv_lu -- row interchanges on the largest magnitude of the column, the solve behind ls.rs:277-337): lane c owns
+    // column c (column K: the right-hand side); per pivot step every lane reads the pivot column (broadcast reads), swaps and updates its own column
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) Ss[q] = S[q];          // (every lane holds the totals; static indices keep S in registers)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane <= K) {
+        for (int p = 0; p < K; ++p) {
+            double v;
+            if (lane < K) {
+                const int r0 = p < lane ? p : lane, r1 = p < lane ? lane : p;
+                v = Ss[tri_index<K>(r0, r1)] + (p == lane ? a.alpha : 0.0);
+            } else v = Ss[NX + p];
+            As[p][lane] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int j = 0; j < K; ++j) {
+        int pv = j;
+        double best = fabs(As[j][j]);
+        for (int r2 = j + 1; r2 < K; ++r2) { const double v = fabs(As[r2][j]); if (v > best) { best = v; pv = r2; } }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane <= K && pv != j) { const double t0 = As[j][lane]; As[j][lane] = As[pv][lane]; As[pv][lane] = t0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const double d = As[j][j];
+        double f[K];
+        for (int r2 = j + 1; r2 < K; ++r2) f[r2] = As[r2][j] / d;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane <= K && lane > j) {
+            const double top = As[j][lane];
+            for (int r2 = j + 1; r2 < K; ++r2) As[r2][lane] -= f[r2] * top;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    double beta[K];
+    for (int p = K - 1; p >= 0; --p) {
+        double sacc = As[p][K];
+        for (int q = p + 1; q < K; ++q) sacc -= As[p][q] * beta[q];
+        beta[p] = sacc / As[p][p];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+        double pr = 0.0;
+        bool vi = true;
+        if constexpr (MASKED) vi = a.valid[i] != 0;
+        const int64_t fi = GATHER ? (int64_t)a.src[i] : i;
+        for (int p = 0; p < K; ++p) {
+            if (a.coef) static_cast<T *>(a.coef)[fi * K + p] = (T)beta[p];
+            pr = fma(vi ? (double)static_cast<const T *>(a.x[p])[fi] : 0.0, beta[p], pr);
+        }
+        if (a.pred) static_cast<T *>(a.pred)[fi] = vi ? (T)pr : nan_if<T>(1u, T(0));     // (a masked row's prediction is a null)
+        if constexpr (GATHER) {                                                           // the rows left out behind it repeat its coefficients
+            const int64_t fe = i + 1 < a.n_rows ? (int64_t)a.src[i + 1] : a.n_frame;
+            for (int64_t f = fi + 1; f < fe && !a.fstart[f] && a.coef; ++f)
+                for (int p = 0; p < K; ++p) static_cast<T *>(a.coef)[f * K + p] = (T)beta[p];
+        }
+    }
+
+}
+
 // MASKED: the FIXED window over rows with validity bytes ("drop_window", ls.rs:987-1029) on frames where no row older than the window
 // is still in a warm-up sum (api.hip checks): an invalid row is a zero row -- it enters and leaves the sums as nothing -- every row is
 // solved from S_i = E(i) - E(i - window), and the rows the reference does NOT solve (before the warm-up row: NaN; a closed
@@ -461,8 +562,8 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
         const T none[4] = {};
         dyn_wave_copy_out<T, K, K + 1>(stage, lane, hs + (int64_t)wv * 64 * R, hi, coef, pred, lo, none);
     }
-    // rows whose window sums had no factorisation go on a list: k4c_lu_fix_kernel re-sums their windows and runs the reference's LU behind
-    // this kernel (rare -- degenerate windows only: one wave-aggregated append per wave that has any)
+    // rows whose window sums had no factorisation: this wave runs the reference's LU on them itself (rare -- degenerate windows only; the staging
+    // area has left with the copy-out and serves as the elimination's scratch)
     if (__any(failed != 0)) {
         unsigned mine = 0;
 #pragma unroll
@@ -470,128 +571,21 @@ __global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K
             const int64_t row = i0 + r;
             if (((failed >> r) & 1u) && row >= lo && row < hi) mine |= 1u << r;
         }
-        const int cnt_mine = __popc(mine);
-        int incl = cnt_mine;                                   // inclusive prefix of the lanes' counts
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        unsigned long long fm = __ballot(mine != 0);
+        while (fm) {                                                        // (wave-uniform)
+            const int L = __builtin_ctzll(fm);
+            fm &= fm - 1ull;
+            const unsigned bits = (unsigned)__shfl((int)mine, L);
+            const int64_t rb0 = hs + (int64_t)(wv * 64 + L) * R;
+            for (int r = 0; r < R; ++r)
+                if ((bits >> r) & 1u) k4c_lu_fix_row<T, K, MASKED, GATHER>(a, rb0 + r, lane, reinterpret_cast<double *>(stage));
         }
-        const int total = __shfl(incl, 63);
-        int base = 0;
-        if (lane == 0 && total) base = atomicAdd(a.fix_count, total);
-        base = __shfl(base, 0) + incl - cnt_mine;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((mine >> r) & 1u) { if (base < a.fix_cap) a.fix_rows[base] = i0 + r; ++base; }
     }
     K4C_STAMP(4);
     K4C_STAMP(5);
     if (a.dbg && threadIdx.x == 64 * (WAVES - 1)) a.dbg[t * 8 + 6] = 0;
 #undef K4C_STAMP
-}
-
-// The rows whose window sums have no L D L' factorisation, solved the reference's way (Cholesky -> LU with partial pivoting, ls.rs:732-734 /
-// :277-337): one wave per listed row re-sums the window -- the rows (i - window, i] of the row's sequence, the valid ones under MASKED --
-// from global memory, every lane runs the same K x K elimination, the coefficients and the prediction replace the NaNs.
-// GATHER: the listed rows are compacted rows -- their windows are read through the source map, and the coefficients go to every frame row
-// that repeats them (up to the next valid row, the end of the sequence or of the frame).
-template <typename T, int K, bool MASKED, bool GATHER = false>
-__global__ void __launch_bounds__(64) k4c_lu_fix_kernel(const K4cArgs a) {
-    constexpr int NX = K4N<K>::NX, NT = K4N<K>::N;
-    const int lane = threadIdx.x;
-    const int n_fix = min(*a.fix_count, (int)a.fix_cap);
-    if (blockIdx.x == 0 && lane == 0) *a.fix_next = 0;          // the next call's counter (nobody reads it during this call)
-    for (int e = blockIdx.x; e < n_fix; e += gridDim.x) {
-        const int64_t i = a.fix_rows[e];
-        int64_t lo = i - a.window + 1 < 0 ? 0 : i - a.window + 1;
-        for (int64_t base = i; base >= lo; base -= 64) {       // the last sequence start at or before row i inside the window
-            const int64_t j = base - lane;
-            const unsigned long long m = __ballot(j >= lo && a.start[j] != 0);
-            if (m) { lo = base - (int64_t)__builtin_ctzll(m); break; }
-        }
-        double S[NT];
-#pragma unroll
-        for (int q = 0; q < NT; ++q) S[q] = 0.0;
-        for (int64_t j = lo + lane; j <= i; j += 64) {
-            if constexpr (MASKED) { if (!a.valid[j]) continue; }
-            double xr[K];
-            const int64_t jf = GATHER ? (int64_t)a.src[j] : j;
-#pragma unroll
-            for (int p = 0; p < K; ++p) xr[p] = (double)static_cast<const T *>(a.x[p])[jf];
-            const double yr = (double)static_cast<const T *>(a.y)[jf];
-#pragma unroll
-            for (int p = 0; p < K; ++p) {
-#pragma unroll
-                for (int q = p; q < K; ++q) S[tri_index<K>(p, q)] = fma(xr[p], xr[q], S[tri_index<K>(p, q)]);
-                S[NX + p] = fma(xr[p], yr, S[NX + p]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) S[q] += __shfl_xor(S[q], off);
-        }
-        // LU with partial pivoting on ONE copy of [A | b] in LDS (faer's partial_piv_lu -- row interchanges on the largest magnitude of the column, the solve behind ls.rs:277-337): lane c owns
-        // column c (column K: the right-hand side); per pivot step every lane reads the pivot column (broadcast reads), swaps and updates its own column
-        __shared__ double As[K][K + 1], Ss[NT];
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < NT; ++q) Ss[q] = S[q];          // (every lane holds the totals; static indices keep S in registers)
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane <= K) {
-            for (int p = 0; p < K; ++p) {
-                double v;
-                if (lane < K) {
-                    const int r0 = p < lane ? p : lane, r1 = p < lane ? lane : p;
-                    v = Ss[tri_index<K>(r0, r1)] + (p == lane ? a.alpha : 0.0);
-                } else v = Ss[NX + p];
-                As[p][lane] = v;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int j = 0; j < K; ++j) {
-            int pv = j;
-            double best = fabs(As[j][j]);
-            for (int r2 = j + 1; r2 < K; ++r2) { const double v = fabs(As[r2][j]); if (v > best) { best = v; pv = r2; } }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane <= K && pv != j) { const double t0 = As[j][lane]; As[j][lane] = As[pv][lane]; As[pv][lane] = t0; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const double d = As[j][j];
-            double f[K];
-            for (int r2 = j + 1; r2 < K; ++r2) f[r2] = As[r2][j] / d;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane <= K && lane > j) {
-                const double top = As[j][lane];
-                for (int r2 = j + 1; r2 < K; ++r2) As[r2][lane] -= f[r2] * top;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        double beta[K];
-        for (int p = K - 1; p >= 0; --p) {
-            double sacc = As[p][K];
-            for (int q = p + 1; q < K; ++q) sacc -= As[p][q] * beta[q];
-            beta[p] = sacc / As[p][p];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane == 0) {
-            double pr = 0.0;
-            bool vi = true;
-            if constexpr (MASKED) vi = a.valid[i] != 0;
-            const int64_t fi = GATHER ? (int64_t)a.src[i] : i;
-            for (int p = 0; p < K; ++p) {
-                if (a.coef) static_cast<T *>(a.coef)[fi * K + p] = (T)beta[p];
-                pr = fma(vi ? (double)static_cast<const T *>(a.x[p])[fi] : 0.0, beta[p], pr);
-            }
-            if (a.pred) static_cast<T *>(a.pred)[fi] = vi ? (T)pr : nan_if<T>(1u, T(0));     // (a masked row's prediction is a null)
-            if constexpr (GATHER) {                                                           // the rows left out behind it repeat its coefficients
-                const int64_t fe = i + 1 < a.n_rows ? (int64_t)a.src[i + 1] : a.n_frame;
-                for (int64_t f = fi + 1; f < fe && !a.fstart[f] && a.coef; ++f)
-                    for (int p = 0; p < K; ++p) static_cast<T *>(a.coef)[f * K + p] = (T)beta[p];
-            }
-        }
-    }
 }
 
 template <typename T, int K, int HW, bool MASKED, bool SELF = false, bool GATHER = false>
@@ -623,24 +617,8 @@ static int k4c_launch_h(pols_ctx *ctx, const K4cArgs &a0) {
     }
     hipEvent_t e0, e1;
     const bool timed = timing_pair(ctx, &e0, &e1);
-    // the list of rows without a factorisation (scratch slot 27: [count][rows]); empty on all but degenerate frames
-    {
-        void *fx = nullptr;
-        const int64_t cap = std::min<int64_t>(a.n_rows, (int64_t)1 << 22);
-        int rc = ensure_scratch(ctx, 27, 256 + sizeof(int64_t) * (size_t)cap, &fx);
-        if (rc) return rc;
-        // two counters take turns: this call appends to one, its fix-up kernel zeroes the other for the next call (no memset on the stream);
-        // a fresh (or grown) slot starts zeroed
-        if (ctx->k4c_fix_ptr != fx) { POLS_HIP(hipMemsetAsync(fx, 0, 256, ctx->stream)); ctx->k4c_fix_ptr = fx; ctx->k4c_fix_turn = 0; }
-        a.fix_count = static_cast<int32_t *>(fx) + 32 * (ctx->k4c_fix_turn & 1);
-        a.fix_next = static_cast<int32_t *>(fx) + 32 * ((ctx->k4c_fix_turn + 1) & 1);
-        ++ctx->k4c_fix_turn;
-        a.fix_rows = reinterpret_cast<int64_t *>(static_cast<char *>(fx) + 256);
-        a.fix_cap = cap;
-    }
     hipExtLaunchKernelGGL((k4c_kernel<T, K, HW, WAVES, MASKED, SELF, GATHER>), dim3((unsigned)(per_xcd * 8)), dim3(64 * WAVES), (unsigned)lds, ctx->stream, timed ? e0 : nullptr,
                           timed ? e1 : nullptr, 0, a);
-    hipLaunchKernelGGL((k4c_lu_fix_kernel<T, K, MASKED, GATHER>), dim3(128), dim3(64), 0, ctx->stream, a);
     POLS_HIP(hipGetLastError());
     if (a.dbg) return report_timeline(ctx, a.dbg, a.n_tiles, 6, "k4c_rolling_tiles");
     return POLS_OK;

@@ -759,7 +759,7 @@ def test_rolling_divergence_band_is_pinned(eng, k, window, min_periods):
     mp_eff = min_periods if min_periods is not None else min(k, window)
     pinned = (nobs >= k) | (nobs < mp_eff)
     assert np.array_equal(np.isnan(c_c)[pinned], np.isnan(ref["coef"])[pinned])
-    # (ii) the default route: a window without an L D L' factorisation goes through the reference's LU too (k4c_lu_fix_kernel re-sums the window
+    # (ii) the default route: a window without an L D L' factorisation goes through the reference's LU too (k4c_lu_fix_row re-sums the window
     # and eliminates with partial pivoting, ls.rs:732-734), so its NaN pattern IS the oracle's wherever that is pinned
     assert np.array_equal(np.isnan(d_c)[pinned], np.isnan(ref["coef"])[pinned])
     for i in np.flatnonzero(usable & (nobs >= k)):
