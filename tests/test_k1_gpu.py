@@ -551,6 +551,35 @@ def test_sixteen_to_thirtyone_columns_resident_multi_pass(eng, dtype, k, icpt, l
     assert np.allclose(got_r, ref["resid"], rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("k,icpt,weights", [(16, False, False), (17, True, True), (18, False, True), (23, False, False), (24, True, True), (25, False, False),
+                                            (26, False, True), (27, True, False), (28, False, False), (30, True, True), (31, False, True)])
+@pytest.mark.parametrize("lo,hi", [(1000, 1000), (520, 1021)])
+def test_f32_wide_columns_on_the_256_thread_team(eng, k, icpt, weights, lo, hi):
+    """Round 6: f32 groups of 513 .. 1 024 rows at 16 .. 31 columns (the 256-thread team, one 16-byte chunk per lane).  The Gram passes are as
+    short as three (23+) / four (16-18) waves per SIMD allow -- up to 27 passes at 31 columns -- and from 26 columns the solving wave parks its
+    resident rows (the sqrt(w) vector included) in LDS while it solves and reads them back for the predictions.  Aligned and ragged frames,
+    weights, intercept, a rank-deficient group for the fix-up pass; every group against the oracle."""
+    from oracle import orc
+
+    rng = np.random.default_rng(k * 37 + hi)
+    offs = _ragged_offsets(rng, 40, lo, hi)
+    y, cols, w = _frame(rng, offs, k, np.float32, weights=weights)
+    s, e = offs[5], offs[6]
+    cols[1][s:e] = cols[3][s:e]                                      # rank-deficient group
+    out = eng.least_squares(_cuda(y), [_cuda(c) for c in cols], offs, weights=None if w is None else _cuda(w), add_intercept=icpt,
+                            want=("coef", "pred", "resid", "status"))
+    kt = k + int(icpt)
+    assert eng.last_kernel.startswith(f"k1_gram_chol_f32_k{kt}{'_w' if weights else ''}_team256_rc1"), eng.last_kernel
+    ref = orc.batched_least_squares(y, cols, offs, weights=w, add_intercept=icpt)
+    st = out["status"].cpu().numpy()
+    assert st[5] == 1 and (np.delete(st, 5) == 0).all(), st[:10]
+    tol = TOL[np.float32]
+    got_c, got_p, got_r = (out[q].double().cpu().numpy() for q in ("coef", "pred", "resid"))
+    assert np.allclose(got_c, ref["coef"], rtol=tol, atol=tol), float(np.abs(got_c - ref["coef"]).max())
+    assert np.allclose(got_p, ref["pred"], rtol=tol, atol=tol), float(np.abs(got_p - ref["pred"]).max())
+    assert np.allclose(got_r, ref["resid"], rtol=tol, atol=tol)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k,weights,icpt", [(8, False, False), (5, True, True), (7, False, True), (6, True, False), (4, False, False), (1, False, False)])
 @pytest.mark.parametrize("slots", [8, 16])
