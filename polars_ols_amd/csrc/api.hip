@@ -1169,7 +1169,10 @@ static int ls_core(pols_ctx *ctx, const pols_batch *b, const pols_ols_params *p,
         // (round 5, re-measured over 128 .. 512 rows, scripts/ab_wide_f64.py -> profiles/r05_ab_wide_f64.txt: at 23-24 columns K2w is ahead at every length
         // K1 would take (256 rows 0.310 vs 0.404 ms, 512 rows 0.263 vs 0.378), at 22 from ~200 rows (0.396 vs 0.419; 512: 0.256 vs 0.333), at 20-21 from
         // 256 (0.268 vs 0.293; 512: 0.253 vs 0.297); at 17-19 and for groups of ~128 rows K1 stays ahead)
-        const bool short_wide = !f32 && (kt >= 23 || (kt == 22 && max_rows >= 192) || (kt >= 20 && max_rows >= 224));
+        // (round 6: groups of 257 .. 512 rows take K1's 256-thread team, which runs three waves per SIMD from 18 columns now -- shorter Gram passes, the
+        // solving wave's rows parked in LDS: 500 rows x 20 / 21 / 22 columns 2.87 / 2.90 / 3.01 TB/s against 2.4-2.8 for K2w; 23 columns 2.88 vs 2.85 at 500 rows, 1.95 vs 1.76 at 300,
+        // profiles/r06_bench_wide_f64_short.txt)
+        const bool short_wide = !f32 && (max_rows > 256 ? kt >= 24 : (kt >= 23 || (kt == 22 && max_rows >= 192) || (kt >= 20 && max_rows >= 224)));
         if (fits && (!k1_resident || short_wide || ctx->opt.static_engine == 4)) {
             K2wArgs aw;
             std::memset(&aw, 0, sizeof(aw));

@@ -725,7 +725,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
         // f32 from 26 columns: the solving wave PARKS its resident rows in LDS for the duration of the solve (the right-looking factorisation
         // keeps a row of the factor and its broadcasts next to them: 173-205 VGPRs, two waves per SIMD, however short the Gram passes are;
         // without the rows the kernel fits 168 and a third workgroup fits the CU)
-        constexpr bool PARK = KT >= 26 && sizeof(T) == 4 && RC == 1 && TEAM == 256;
+        constexpr bool PARK = ((sizeof(T) == 4 && KT >= 26) || (sizeof(T) == 8 && KT >= 18)) && RC == 1 && TEAM == 256;   // (f64: 257 .. 512-row groups, the same step at 18 columns)
         using PV = typename Vec16<T>::type;
         __shared__ __attribute__((aligned(16))) PV park_s[PARK ? (KT + 2) * 64 : 1];
         if (wave == 0) {
@@ -1741,7 +1741,8 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     // (16-18 columns the same way one step up: 40 / 36 / 32 accumulators per pass keep the kernel at 128 VGPRs, FOUR waves per SIMD: 4.8 -> 5.2 TB/s;
     // at 19-20 it took parking too and bought 1-2 %: not kept.  The 256-thread team only: the one- and two-wave teams gain no workgroup by it.)
     constexpr int NP0 = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + 59) / 60 : (NACC + 35) / 36));      // every other team
-    constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + ACC_F32 - 1) / ACC_F32 : (NACC + 35) / 36));
+    constexpr int ACC_F64 = KT >= 18 ? (148 - 4 * (KT + 1)) / 2 - ((KT == 21 || KT == 23) ? 3 : 0) : 36;   // (doubles: two registers each; 21 / 23 columns sat at 170 / 171)
+    constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + ACC_F32 - 1) / ACC_F32 : (NACC + ACC_F64 - 1) / ACC_F64));
     const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
     const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
 #ifdef K1_NULLS_TU

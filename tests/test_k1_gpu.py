@@ -535,7 +535,8 @@ def test_sixteen_to_thirtyone_columns_resident_multi_pass(eng, dtype, k, icpt, l
     kt = k + int(icpt)
     mx = int(np.diff(offs).max())
     # f64, round 5 (scripts/ab_wide_f64.py): K2w is ahead of the VALU passes at 23-24 columns at every length, at 22 from ~200 rows, at 20-21 from ~224
-    k2w_wins = dtype == np.float64 and (kt >= 23 or (kt == 22 and mx >= 192) or (kt >= 20 and mx >= 224))
+    # round 6: groups of 257 .. 512 rows (K1's 256-thread team at three waves per SIMD) stay with K1 through 23 columns
+    k2w_wins = dtype == np.float64 and (kt >= 24 or (mx <= 256 and (kt >= 23 or (kt == 22 and mx >= 192) or (kt >= 20 and mx >= 224))))
     if k2w_wins and kt <= 24:
         assert name.startswith(f"k2w_gram_mfma_resident2_f64_k{kt}_w"), name
     elif dtype == np.float32 or 17 <= kt <= 24:                      # f64: K2 keeps 16 columns, K2w 25+
