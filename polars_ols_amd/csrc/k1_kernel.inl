@@ -1751,7 +1751,7 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr bool NL = false;
 #endif
 #define K1W_GO(TEAM, RC)                                                                                                       \
-    { constexpr int NPT = ((TEAM) == 256 && (RC) == 1) ? NP : NP0;                                                                          \
+    { constexpr int NPT = (((TEAM) == 256 || ((TEAM) == 128 && sizeof(T) == 4 && KT <= 25)) && (RC) == 1) ? NP : NP0;   /* (two-wave f32 teams: where the passes alone set the registers) */                                                                          \
     return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NPT, NL>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NPT, NL>(ctx, a)) \
                : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NPT, NL>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NPT, NL>(ctx, a)); }
 #ifndef K1_NULLS_TU

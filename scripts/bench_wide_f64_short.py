@@ -6,16 +6,19 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polars_ols_amd.engine import Engine
 eng = Engine(0)
+DT = torch.float32 if os.environ.get("DT") == "f32" else torch.float64          # DT=f32: the same sweep in f32 (16..31 columns with KS)
+NM, B = ("f32", 4) if DT == torch.float32 else ("f64", 8)
+KS = tuple(int(v) for v in os.environ.get("KS", "17,18,19,20,21,22,23").split(","))
 N = 3_840_000          # (a multiple of 500, 300 and 256)
 gen = torch.Generator(device="cuda").manual_seed(1)
-allc = [torch.randn(N, generator=gen, device="cuda", dtype=torch.float64) for _ in range(23)]
-for k in (17, 18, 19, 20, 21, 22, 23):
+allc = [torch.randn(N, generator=gen, device="cuda", dtype=DT) for _ in range(max(KS))]
+for k in KS:
     cols = allc[:k]
-    y = sum(cols[:4]) + 0.1 * torch.randn(N, generator=gen, device="cuda", dtype=torch.float64)
+    y = sum(cols[:4]) + 0.1 * torch.randn(N, generator=gen, device="cuda", dtype=DT)
     for n in (500, 300, 256):
         G = N // n
         offs = np.arange(G + 1, dtype=np.int64) * n
-        for engine in (None, "nok2", "k2w"):
+        for engine in ((None, "nok2", "k2w") if DT == torch.float64 else (None,)):
             eng.set_option("STATIC_ENGINE", engine)
             try:
                 plan = eng.plan_least_squares(y, cols, offs, want=("pred",))
@@ -24,7 +27,7 @@ for k in (17, 18, 19, 20, 21, 22, 23):
                 for _ in range(8): plan.run()
                 eng.synchronize(); torch.cuda.synchronize()
                 ms = 1e3 * (time.perf_counter() - t0) / 8
-                print(f"f64 k={k} rows={n} engine={engine}: {ms:.3f} ms {G * n * (k + 2) * 8 / ms / 1e9:.2f} TB/s {eng.last_kernel}", flush=True)
+                print(f"{NM} k={k} rows={n} engine={engine}: {ms:.3f} ms {G * n * (k + 2) * B / ms / 1e9:.2f} TB/s {eng.last_kernel}", flush=True)
             except Exception as exc:
-                print(f"f64 k={k} rows={n} engine={engine}: {exc}")
+                print(f"{NM} k={k} rows={n} engine={engine}: {exc}")
         eng.set_option("STATIC_ENGINE", None)
