@@ -1701,6 +1701,13 @@ static int k1_launch_kw(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
             const bool team128 = (KT < 10 && !(KT == 9 && HAS_W)) || need <= 128 * 2 * VEC;
             if (!ctx->opt.k1_f64_team256 && team128 && need <= 128 * 4 * VEC && !ctx->opt.timeline) {
                 const int pp = ctx->opt.k1_passes ? ctx->opt.k1_passes : (KT >= 10 ? 3 : 0);   // 10 columns: 66 f64 accumulators -> three passes
+                // (round 6: groups of up to 512 rows at 10 columns -- and at 9 WITH weights, 170 VGPRs in two passes -- take three passes over TWO chunks per
+                // lane: under 168 registers, three waves per SIMD; they used to run the four-chunk kernel half empty / sit two registers over the step)
+                if constexpr (KT == 10 || (KT == 9 && HAS_W)) {
+                    constexpr int P3 = (KT == 10 && HAS_W) ? 4 : 3;                             // (10 columns with weights: 171 VGPRs in three)
+                    if (need <= 128 * 2 * VEC && (pp == 3 || pp == 0))
+                        return al ? k1_launch_fast<T, KT, HAS_W, 128, 2, true, P3>(ctx, a) : k1_launch_fast<T, KT, HAS_W, 128, 2, false, P3>(ctx, a);
+                }
                 if (pp == 3 && al) return k1_launch_fast<T, KT, HAS_W, 128, 4, true, 3>(ctx, a);
                 if (pp == 0 || pp == 2) {
                     if (need <= 128 * 2 * VEC)
