@@ -725,7 +725,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const int64_t bid) {
         // f32 from 26 columns: the solving wave PARKS its resident rows in LDS for the duration of the solve (the right-looking factorisation
         // keeps a row of the factor and its broadcasts next to them: 173-205 VGPRs, two waves per SIMD, however short the Gram passes are;
         // without the rows the kernel fits 168 and a third workgroup fits the CU)
-        constexpr bool PARK = ((sizeof(T) == 4 && KT >= 26) || (sizeof(T) == 8 && KT >= 18)) && RC == 1 && TEAM == 256;   // (f64: 257 .. 512-row groups, the same step at 18 columns)
+        constexpr bool PARK = ((sizeof(T) == 4 && KT >= 25) || (sizeof(T) == 8 && KT >= 18)) && RC == 1 && TEAM == 256;   // (f64: 257 .. 512-row groups, the same step at 18 columns)
         using PV = typename Vec16<T>::type;
         __shared__ __attribute__((aligned(16))) PV park_s[PARK ? (KT + 2) * 64 : 1];
         if (wave == 0) {
@@ -1734,6 +1734,25 @@ static int k1_launch_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
 // 11-15 columns: only the multi-pass forms exist (91 accumulators at 12 features + target: three passes; 136 at 15: four), picked so
 // that the resident rows of a lane stay at 4-8 x (k + 1) values.  11-12 columns: one wave up to 512 f32 / 256 f64 rows, two waves
 // up to 1 024 / 512, the 256-thread team beyond.  13-15 columns: one chunk per lane (one wave, two waves, four) before two.
+// Gram passes of the resident wide kernels on the teams that gain a workgroup by it (round 6): the accumulators a pass may hold are what three waves per
+// SIMD (four at 16-18 f32 columns) leave next to the resident rows -- 4 (KT + 1) registers, 4 more with the sqrt(w) vector, ~8-10 more in the null-policy
+// builds (measured per build: weights +7..8, masks +8..10).  W: with weights, NL: null-policy family.  At least 16 f32 / 10 f64 per pass.
+template <typename T, int KT, bool NL>
+constexpr int k1w_short_passes(bool W) {
+    constexpr int NACC = (KT + 1) * (KT + 2) / 2;
+    const int rows = 4 * (KT + 1) + (W ? 8 : 0) + (NL ? 20 : 0);
+    if (sizeof(T) == 4) {
+        int acc = KT <= 18 ? 102 - rows : 141 - rows;                 // (16-18 columns: four waves per SIMD; from 19: three; ~20-25 registers of everything else)
+        if (acc > 60) acc = 60;
+        if (acc < 16) acc = 16;
+        return (NACC + acc - 1) / acc;
+    }
+    int acc = (142 - rows) / 2 - ((KT == 21 || KT == 23) ? 2 : 0);  // (doubles: two registers each; 21 / 23 columns sat a register or two over)
+    if (acc > 36) acc = 36;
+    if (acc < 10) acc = 10;
+    return (NACC + acc - 1) / acc;
+}
+
 template <typename T, int KT>
 static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr int VEC = Vec16<T>::N;
@@ -1744,12 +1763,10 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     // shorter passes keep it at 168: the accumulators a pass may hold are what three waves per SIMD leave next to the rows (the products per row
     // are the same however they are split; a pass more is one more reduce-and-barrier round).
     // (from 26 columns the solving wave also parks its rows in LDS while it solves: k1_body, PARK)
-    constexpr int ACC_F32 = KT >= 23 ? 148 - 4 * (KT + 1) : ((KT >= 16 && KT <= 18) ? 108 - 4 * (KT + 1) : 60);
     // (16-18 columns the same way one step up: 40 / 36 / 32 accumulators per pass keep the kernel at 128 VGPRs, FOUR waves per SIMD: 4.8 -> 5.2 TB/s;
-    // at 19-20 it took parking too and bought 1-2 %: not kept.  The 256-thread team only: the one- and two-wave teams gain no workgroup by it.)
+    // at 19-20 it took parking too and bought 1-2 %: not kept.  The 256-thread team, and the two-wave f32 team up to 25 columns: the other teams gain no
+    // workgroup by it and keep NP0.  k1w_short_passes above: per build -- weights and the null-policy masks take their registers off the budget.)
     constexpr int NP0 = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + 59) / 60 : (NACC + 35) / 36));      // every other team
-    constexpr int ACC_F64 = KT >= 18 ? (148 - 4 * (KT + 1)) / 2 - ((KT == 21 || KT == 23) ? 3 : 0) : 36;   // (doubles: two registers each; 21 / 23 columns sat at 170 / 171)
-    constexpr int NP = KT <= 12 ? 3 : (KT <= 15 ? 4 : (sizeof(T) == 4 ? (NACC + ACC_F32 - 1) / ACC_F32 : (NACC + ACC_F64 - 1) / ACC_F64));
     const bool al = ctx->offs_aligned[VEC == 4 ? 1 : 0] && !ctx->opt.k1_nofast;
     const int64_t need = max_rows + (ctx->offs_aligned[VEC == 4 ? 1 : 0] ? 0 : VEC - 1);
 #ifdef K1_NULLS_TU
@@ -1758,9 +1775,10 @@ static int k1_launch_wide_kt(pols_ctx *ctx, const K1Args &a, int64_t max_rows) {
     constexpr bool NL = false;
 #endif
 #define K1W_GO(TEAM, RC)                                                                                                       \
-    { constexpr int NPT = (((TEAM) == 256 || ((TEAM) == 128 && sizeof(T) == 4 && KT <= 25)) && (RC) == 1) ? NP : NP0;   /* (two-wave f32 teams: where the passes alone set the registers) */                                                                          \
-    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NPT, NL>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NPT, NL>(ctx, a)) \
-               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NPT, NL>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NPT, NL>(ctx, a)); }
+    { constexpr bool SHORT = KT >= 16 && (((TEAM) == 256 || ((TEAM) == 128 && sizeof(T) == 4 && KT <= 25)) && (RC) == 1);            \
+      constexpr int NPW = SHORT ? k1w_short_passes<T, KT, NL>(true) : NP0, NPN = SHORT ? k1w_short_passes<T, KT, NL>(false) : NP0;    \
+    return a.w ? (al ? k1_launch_fast<T, KT, true, TEAM, RC, true, NPW, NL>(ctx, a) : k1_launch_fast<T, KT, true, TEAM, RC, false, NPW, NL>(ctx, a)) \
+               : (al ? k1_launch_fast<T, KT, false, TEAM, RC, true, NPN, NL>(ctx, a) : k1_launch_fast<T, KT, false, TEAM, RC, false, NPN, NL>(ctx, a)); }
 #ifndef K1_NULLS_TU
     if constexpr (KT <= 16) {
         // 11-16 columns, groups of at most 32 chunks (128 f32 / 64 f64 rows -- a quarter of daily data against a dozen factors): K1t's four groups
