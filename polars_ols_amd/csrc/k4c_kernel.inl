@@ -175,7 +175,7 @@ __device__ __forceinline__ void k4c_lu_fix_row(const K4cArgs &a, const int64_t i
 // them), and every wave writes the FRAME rows between its first valid row and the next wave's -- coefficients forward-filled inside the
 // sequence, NaN predictions on the rows left out (dyn_out_gather.inl).  The compacted copy of the columns and the expansion pass are gone.
 template <typename T, int K, int HW, int WAVES, bool MASKED, bool SELF = false, bool GATHER = false>
-__global__ void __launch_bounds__(64 * WAVES, K <= 6 ? 2 : 1) k4c_kernel(const K4cArgs a) {
+__global__ void __launch_bounds__(64 * WAVES, (K <= 6 || (K == 7 && HW == 0 && !SELF)) ? 2 : 1) k4c_kernel(const K4cArgs a) {
     static_assert(!SELF || (HW == 0 && WAVES == 4), "the own-halo form: four body waves");
     static_assert(!GATHER || !MASKED, "the gathered rows are all valid");
     constexpr int BW = WAVES - HW, R = 4, RUNS = WAVES * 64;

@@ -179,6 +179,7 @@ def test_bench_kernels_keep_two_waves_per_simd():
         "pols::k4c_kernel<double, 6, 0, 4, false, false, false>(": 256,                     # ... on packed tiles (many sequences)
         "pols::k4c_kernel<double, 6, 0, 4, true, false, false>(": 256,                      # ... "drop_window" with nulls (masked)
         "pols::k4c_kernel<double, 6, 0, 4, false, false, true>(": 256,                      # ... "drop" with nulls (gathered through the source map)
+        "pols::k4c_kernel<double, 7, 0, 4, false, false, false>(": 256,                     # 7 features on packed tiles: held to two workgroups per CU (a few spills) since round 6
     }
     for key, cap in want.items():
         hits = [(k, v) for k, v in ks.items() if key in k]
