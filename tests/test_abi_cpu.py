@@ -144,7 +144,12 @@ def test_hot_kernels_keep_their_arrays_in_registers():
            "pols::kp_rls_walk_kernel<", "pols::kp_rolling_walk_kernel<", "pols::kp_totals_kernel<", "pols::k6s_kernel<",
            "pols::gram_valu_kernel<", "pols::predict_groups_kernel<")   # round 5 (three nested lambdas
     # around K4p's chunk-start sums once parked its state in 864 bytes of scratch per lane: 2.6 -> 17.8 ms, again without a warning)
-    bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0}
+    # (round 6, deliberate: the 7-feature tile kernel on packed tiles is held to 256 registers for a second workgroup per CU -- 25-42 spilled
+    #  REGISTERS, up to 172 bytes per lane, no array: 0.60 -> 0.40 ms; anything beyond 256 bytes there would be an array again)
+    def spills_on_purpose(name, scratch):
+        return "pols::k4c_kernel<" in name and ", 7, 0, 4, " in name and scratch <= 256
+
+    bad = {k: v for k, v in ks.items() if any(h in k for h in hot) and v[0] > 0 and not spills_on_purpose(k, v[0])}
     assert not bad, sorted(bad.items())[:5]
 
 
